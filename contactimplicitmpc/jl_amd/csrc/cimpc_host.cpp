@@ -1,0 +1,740 @@
+// Host runtime behind the C ABI of include/cimpc.h: handle, HBM residency, the per-knot
+// linearization packer (A1), window bucketing, and the lock-step driver of newton_solve!
+// (/root/reference/src/controller/newton.jl:169-288).  HIP runtime only - no torch, no BLAS.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cimpc_internal.h"
+#include "lin_table.h"
+#include "newton_state.h"
+
+using namespace cimpc;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+enum ProfClass { PC_IP = 0, PC_KKT = 1, PC_RESID = 2, PC_OTHER = 3, PC_COUNT = 4 };
+
+struct ProfRec {
+    hipEvent_t a, b;
+    int cls;
+};
+
+}  // namespace
+
+struct cimpc_ctx {
+    cimpc_dims dm{};
+    cimpc_ip_opts ip{};
+    cimpc_newton_opts nt{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    KernelInfo ki{};
+    int nz = 0, nth = 0, nths = 0, nd = 0, nr = 0, nx = 0, ny = 0, N = 0;
+    // device memory
+    std::vector<void*> allocs;
+    double* d_tab = nullptr;
+    int* d_wg_desc = nullptr;
+    int* d_plist = nullptr;
+    double* d_alt = nullptr;
+    double* d_zout = nullptr;
+    double *d_Q = nullptr, *d_R = nullptr, *d_Qinv = nullptr, *d_Rinv = nullptr, *d_Cg = nullptr,
+           *d_Cb = nullptr;
+    double *d_q0 = nullptr, *d_q1 = nullptr;
+    double* d_rhs = nullptr;   // B1 seam staging
+    NewtonDev S{};
+    int* h_counters = nullptr;   // pinned
+    // bookkeeping
+    std::vector<char> knot_set;
+    int n_knots_set = 0;
+    bool objective_set = false, window_set = false, reference_set = false, alt_set = false;
+    bool velocity_objective = false;
+    int n_wg = 0, waves = 4;
+    std::vector<double> h_tab;       // one knot staging
+    cimpc_stats last_stats{};
+    // profiling
+    bool prof_on = false;
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[PC_COUNT] = {0, 0, 0, 0};
+    long long prof_n[PC_COUNT] = {0, 0, 0, 0};
+    long long prof_ip_problems = 0, prof_kkt_systems = 0;
+};
+
+namespace {
+
+int fail(cimpc_ctx* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(h, call)                                                                     \
+    do {                                                                                     \
+        hipError_t e__ = (call);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return fail(h, CIMPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+template <class T>
+int dev_alloc(cimpc_ctx* h, T** p, size_t count) {
+    void* v = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(&v, count * sizeof(T));
+    if (e != hipSuccess) return fail(h, CIMPC_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    e = hipMemset(v, 0, count * sizeof(T));
+    if (e != hipSuccess) return fail(h, CIMPC_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e));
+    h->allocs.push_back(v);
+    *p = static_cast<T*>(v);
+    return CIMPC_OK;
+}
+
+// dense inverse by Gauss-Jordan with partial pivoting (column-major n x n); false if singular
+bool invert(const double* A, double* Ai, int n) {
+    std::vector<double> M((size_t)n * 2 * n);
+    auto at = [&](int r, int c) -> double& { return M[(size_t)r * 2 * n + c]; };
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < n; ++c) {
+            at(r, c) = A[r + (size_t)c * n];
+            at(r, n + c) = (r == c) ? 1.0 : 0.0;
+        }
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        for (int r = k + 1; r < n; ++r)
+            if (std::fabs(at(r, k)) > std::fabs(at(p, k))) p = r;
+        if (at(p, k) == 0.0 || !std::isfinite(at(p, k))) return false;
+        if (p != k)
+            for (int c = 0; c < 2 * n; ++c) std::swap(at(p, c), at(k, c));
+        const double piv = at(k, k);
+        for (int c = 0; c < 2 * n; ++c) at(k, c) /= piv;
+        for (int r = 0; r < n; ++r) {
+            if (r == k) continue;
+            const double f = at(r, k);
+            if (f == 0.0) continue;
+            for (int c = 0; c < 2 * n; ++c) at(r, c) -= f * at(k, c);
+        }
+    }
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < n; ++c) Ai[r + (size_t)c * n] = at(r, n + c);
+    return true;
+}
+
+void prof_begin(cimpc_ctx* h, int cls) {
+    if (!h->prof_on) return;
+    ProfRec r;
+    auto get = [&]() {
+        if (!h->ev_pool.empty()) {
+            hipEvent_t e = h->ev_pool.back();
+            h->ev_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        return e;
+    };
+    r.a = get();
+    r.b = get();
+    r.cls = cls;
+    (void)hipEventRecord(r.a, h->stream);
+    h->prof_recs.push_back(r);
+}
+void prof_end(cimpc_ctx* h) {
+    if (!h->prof_on) return;
+    (void)hipEventRecord(h->prof_recs.back().b, h->stream);
+}
+void prof_collect(cimpc_ctx* h) {
+    if (h->prof_recs.empty()) return;
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& r : h->prof_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            h->prof_ms[r.cls] += ms;
+            h->prof_n[r.cls] += 1;
+        }
+        h->ev_pool.push_back(r.a);
+        h->ev_pool.push_back(r.b);
+    }
+    h->prof_recs.clear();
+}
+
+IpParams make_ip_params(cimpc_ctx* h, const TrajDev& T, const int* need_sweep, double* zout) {
+    IpParams p{};
+    p.tab = h->d_tab;
+    p.wg_desc = h->d_wg_desc;
+    p.plist = h->d_plist;
+    p.q = T.q;
+    p.theta = T.th;
+    p.gam = T.g;
+    p.bfr = T.b;
+    p.alt = h->alt_set ? h->d_alt : nullptr;
+    p.need_sweep = need_sweep;
+    p.d = h->S.d;
+    p.dz = h->S.dz;
+    p.status = h->S.ip_status;
+    p.iters = h->S.ip_iters;
+    p.zout = zout;
+    p.H = h->dm.H;
+    p.o = h->ip;
+    return p;
+}
+
+int run_sweep(cimpc_ctx* h, const TrajDev& T, const int* need_sweep, double* zout) {
+    IpParams p = make_ip_params(h, T, need_sweep, zout);
+    prof_begin(h, PC_IP);
+    int rc = launch_ip_sweep(&h->dm, p, h->n_wg, h->waves, h->stream);
+    prof_end(h);
+    if (rc != CIMPC_OK) return fail(h, rc, "ip sweep launch failed");
+    return CIMPC_OK;
+}
+
+int check_ready(cimpc_ctx* h, bool need_newton) {
+    if (!h) return CIMPC_ERR_INVALID;
+    if (h->n_knots_set != h->dm.H_ref)
+        return fail(h, CIMPC_ERR_STATE, "set_linearization has not been called for every knot");
+    if (!h->window_set) return fail(h, CIMPC_ERR_STATE, "set_window has not been called");
+    if (need_newton) {
+        if (!h->objective_set) return fail(h, CIMPC_ERR_STATE, "set_objective has not been called");
+        if (!h->reference_set) return fail(h, CIMPC_ERR_STATE, "set_reference has not been called");
+        if (h->dm.mode != CIMPC_MODE_CONFIGURATION)
+            return fail(h, CIMPC_ERR_INVALID,
+                        "newton_solve / kkt_solve: only mode = :configuration is implemented "
+                        "(the :configurationforce KKT needs an indefinite solver; see DESIGN.md)");
+    }
+    return CIMPC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cimpc_version(void) { return 100; }
+
+void cimpc_default_ip_opts(cimpc_ip_opts* o) {
+    if (!o) return;
+    o->r_tol = 1.0e-8;
+    o->kappa_tol = 2.0e-4;
+    o->undercut = 5.0;
+    o->gamma_reg = 0.1;
+    o->kappa_reg = 1.0e-3;
+    o->eps_min = 0.05;
+    o->ls_scale = 0.5;
+    o->max_iter = 100;
+    o->max_ls = 3;
+}
+
+void cimpc_default_newton_opts(cimpc_newton_opts* o) {
+    if (!o) return;
+    o->r_tol = 3.0e-4;
+    o->beta_init = 1.0e-5;
+    o->max_time = 0.0;
+    o->kappa = 2.0e-4;
+    o->max_iter = 5;
+    o->kkt_backend = CIMPC_KKT_CONDENSED;
+}
+
+const char* cimpc_last_error(cimpc_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_newton_opts* nt,
+                 int device, cimpc_handle* out) {
+    if (!dims || !out) return fail(nullptr, CIMPC_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const cimpc_dims& d = *dims;
+    if (d.nq <= 0 || d.nu < 0 || d.nw < 0 || d.nc <= 0 || d.nb < 0 || d.H <= 0 || d.H_ref <= 0 ||
+        d.B <= 0 || (d.mode != 0 && d.mode != 1))
+        return fail(nullptr, CIMPC_ERR_INVALID, "invalid dimensions");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, CIMPC_ERR_NO_DEVICE,
+                    "no HIP device visible: this library has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(nullptr, CIMPC_ERR_NO_DEVICE, "device index out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+        return fail(nullptr, CIMPC_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, CIMPC_ERR_NO_DEVICE,
+                    std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, CIMPC_ERR_NO_DEVICE, "hipSetDevice failed");
+
+    cimpc_ctx* h = new cimpc_ctx();
+    h->dm = d;
+    if (ip) h->ip = *ip; else cimpc_default_ip_opts(&h->ip);
+    if (nt) h->nt = *nt; else cimpc_default_newton_opts(&h->nt);
+    h->device = device;
+    if (ip_kernel_info(&h->dm, &h->ki) != CIMPC_OK) {
+        delete h;
+        return fail(nullptr, CIMPC_ERR_INVALID,
+                    "no kernel instantiation for these model dimensions (pushbot, hopper_2D, "
+                    "quadruped, centroidal_quadruped are built)");
+    }
+    h->nx = d.nq;
+    h->ny = 2 * d.nc + d.nb;
+    h->nz = d.nq + 4 * d.nc + 2 * d.nb;
+    h->nth = 2 * d.nq + d.nu + d.nw + 2;
+    h->nths = 2 * d.nq + d.nu;
+    h->nd = d.mode ? d.nq + d.nc + d.nb : d.nq;
+    h->nr = d.mode ? d.nq + d.nu + d.nc + d.nb : d.nq + d.nu;
+    h->N = d.H * (h->nr + h->nd);
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return fail(nullptr, CIMPC_ERR_HIP, "hipStreamCreate failed");
+    }
+    h->own_stream = true;
+    h->knot_set.assign(d.H_ref, 0);
+    h->h_tab.assign(h->ki.tab_size, 0.0);
+
+    const size_t B = d.B, H = d.H;
+    int rc = CIMPC_OK;
+    auto A = [&](auto** p, size_t n) { if (rc == CIMPC_OK) rc = dev_alloc(h, p, n); };
+    A(&h->d_tab, (size_t)d.H_ref * h->ki.tab_size);
+    const int ppw = 64 / h->ki.G;
+    const size_t max_wg = (B * H + 0) / 1 + d.H_ref;   // generous upper bound (1 problem / wg)
+    A(&h->d_wg_desc, 4 * max_wg);
+    A(&h->d_plist, B * H);
+    A(&h->d_alt, B * d.nc);
+    A(&h->d_zout, B * H * h->nz);
+    A(&h->d_Q, H * d.nq * d.nq);
+    A(&h->d_R, H * d.nu * d.nu);
+    A(&h->d_Qinv, H * d.nq * d.nq);
+    A(&h->d_Rinv, H * d.nu * d.nu);
+    A(&h->d_Cg, H * d.nc * d.nc);
+    A(&h->d_Cb, H * d.nb * d.nb);
+    A(&h->d_q0, B * d.nq);
+    A(&h->d_q1, B * d.nq);
+    A(&h->d_rhs, B * h->N);
+    NewtonDev& S = h->S;
+    S.dm = d;
+    S.nd = h->nd; S.nr = h->nr; S.nth = h->nth; S.nths = h->nths; S.N = h->N;
+    for (TrajDev* T : {&S.traj, &S.cand, &S.ref}) {
+        A(&T->q, B * (H + 2) * d.nq);
+        A(&T->u, B * H * d.nu);
+        A(&T->w, B * H * d.nw);
+        A(&T->g, B * H * d.nc);
+        A(&T->b, B * H * d.nb);
+        A(&T->th, B * H * h->nth);
+    }
+    A(&S.nu, B * H * h->nd);
+    A(&S.nu_cand, B * H * h->nd);
+    A(&S.d, B * H * h->nd);
+    A(&S.dz, B * H * h->nths * h->nd);
+    A(&S.ip_status, B * H);
+    A(&S.ip_iters, B * H);
+    A(&S.res, B * h->N);
+    A(&S.res_cand, B * h->N);
+    A(&S.delta, B * h->N);
+    A(&S.r_norm, B); A(&S.r_cand, B); A(&S.alpha, B); A(&S.beta, B);
+    A(&S.ls_iter, B); A(&S.newton_l, B); A(&S.stage, B); A(&S.need_sweep, B);
+    A(&S.counters, 8);
+    A(&S.stats, 4);
+    A(&S.ro_sweeps, B); A(&S.ro_ip_iters, B); A(&S.ro_ip_fail, B);
+    A(&S.kkt_ws, B * H * (3 * (size_t)h->nd * h->nd + h->nd));
+    (void)ppw;
+    if (rc == CIMPC_OK && hipHostMalloc((void**)&h->h_counters, 8 * sizeof(int)) != hipSuccess)
+        rc = fail(h, CIMPC_ERR_HIP, "hipHostMalloc failed");
+    if (rc != CIMPC_OK) {
+        g_create_error = h->err;
+        cimpc_destroy(h);
+        return rc;
+    }
+    S.Q = h->d_Q; S.R = h->d_R; S.Qinv = h->d_Qinv; S.Rinv = h->d_Rinv; S.Cg = h->d_Cg; S.Cb = h->d_Cb;
+    S.r_tol = h->nt.r_tol; S.beta_init = h->nt.beta_init; S.kappa = h->nt.kappa; S.max_iter = h->nt.max_iter;
+    // small batches: one wave per workgroup keeps every problem on its own CU (latency);
+    // large batches: 4 waves share one staged table (throughput)
+    h->waves = (B * H >= 4096) ? 4 : 1;
+    *out = h;
+    return CIMPC_OK;
+}
+
+int cimpc_destroy(cimpc_handle h) {
+    if (!h) return CIMPC_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->h_counters) (void)hipHostFree(h->h_counters);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return CIMPC_OK;
+}
+
+int cimpc_set_stream(cimpc_handle h, void* hip_stream) {
+    if (!h) return CIMPC_ERR_INVALID;
+    (void)hipStreamSynchronize(h->stream);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    h->stream = static_cast<hipStream_t>(hip_stream);
+    h->own_stream = false;
+    return CIMPC_OK;
+}
+
+int cimpc_synchronize(cimpc_handle h) {
+    if (!h) return CIMPC_ERR_INVALID;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CIMPC_OK;
+}
+
+int cimpc_set_linearization(cimpc_handle h, int t, const double* z0, const double* th0,
+                            const double* r0, const double* rz0, const double* rth0) {
+    if (!h || !z0 || !th0 || !r0 || !rz0 || !rth0) return fail(h, CIMPC_ERR_INVALID, "null argument");
+    if (t < 1 || t > h->dm.H_ref) return fail(h, CIMPC_ERR_INVALID, "knot index out of range (1-based)");
+    const int nx = h->nx, ny = h->ny, nz = h->nz, nth = h->nth, G = h->ki.G;
+    const LinLayout L(nx, ny, nth, G);
+    std::vector<double>& T = h->h_tab;
+    std::fill(T.begin(), T.end(), 0.0);
+    auto RZ = [&](int r, int c) { return rz0[r + (size_t)c * nz]; };
+    auto RTH = [&](int r, int c) { return rth0[r + (size_t)c * nz]; };
+    // blocks (linearization_var_index / term_index are contiguous: index.jl:289-327)
+    std::vector<double> Dx((size_t)nx * nx), Ai((size_t)nx * nx), CAi((size_t)ny * nx), CAiB((size_t)ny * ny);
+    for (int c = 0; c < nx; ++c)
+        for (int r = 0; r < nx; ++r) Dx[r + (size_t)c * nx] = RZ(r, c);
+    if (!invert(Dx.data(), Ai.data(), nx))
+        return fail(h, CIMPC_ERR_INVALID, "Dx = rz0[idyn, ix] is singular");
+    // CAi = Rx * Ai ; CAiB = (Rx * Ai) * Dy1   (schur.jl:40-41)
+    for (int r = 0; r < ny; ++r)
+        for (int c = 0; c < nx; ++c) {
+            double s = 0.0;
+            for (int k = 0; k < nx; ++k) s += RZ(nx + r, k) * Ai[k + (size_t)c * nx];
+            CAi[r + (size_t)c * ny] = s;
+        }
+    for (int r = 0; r < ny; ++r)
+        for (int c = 0; c < ny; ++c) {
+            double s = 0.0;
+            for (int k = 0; k < nx; ++k) s += CAi[r + (size_t)k * ny] * RZ(k, nx + c);
+            CAiB[r + (size_t)c * ny] = s;
+        }
+    for (int i = 0; i < ny; ++i)        // W[i*G + j] = Ry1[i,j] - CAiB[i,j], diagonal kept apart
+        for (int j = 0; j < ny; ++j)
+            T[L.oW + i * G + j] = (i == j) ? 0.0 : RZ(nx + i, nx + j) - CAiB[i + (size_t)j * ny];
+    for (int k = 0; k < nx; ++k) {
+        for (int i = 0; i < ny; ++i) T[L.oCAi + k * G + i] = CAi[i + (size_t)k * ny];
+        for (int i = 0; i < nx; ++i) T[L.oAi + k * G + i] = Ai[i + (size_t)k * nx];
+        for (int i = 0; i < nx; ++i) T[L.oDx + k * G + i] = RZ(i, k);
+        for (int i = 0; i < ny; ++i) T[L.oRx + k * G + i] = RZ(nx + i, k);
+    }
+    for (int k = 0; k < ny; ++k) {
+        for (int i = 0; i < nx; ++i) T[L.oDy1 + k * G + i] = RZ(i, nx + k);
+        for (int i = 0; i < ny; ++i) T[L.oRy1 + k * G + i] = RZ(nx + i, nx + k);
+    }
+    for (int k = 0; k < nth; ++k) {
+        for (int i = 0; i < nx; ++i) T[L.oRthDyn + k * G + i] = RTH(i, k);
+        for (int i = 0; i < ny; ++i) T[L.oRthRst + k * G + i] = RTH(nx + i, k);
+    }
+    for (int i = 0; i < ny; ++i) {
+        T[L.oVec + LinLayout::V_RY2 * G + i] = RZ(nx + i, nx + ny + i);
+        T[L.oVec + LinLayout::V_RY1D * G + i] = RZ(nx + i, nx + i);
+        T[L.oVec + LinLayout::V_CAIBD * G + i] = CAiB[i + (size_t)i * ny];
+        T[L.oVec + LinLayout::V_RRST0 * G + i] = r0[nx + i];
+        T[L.oVec + LinLayout::V_Y10 * G + i] = z0[nx + i];
+        T[L.oVec + LinLayout::V_Y20 * G + i] = z0[nx + ny + i];
+    }
+    for (int i = 0; i < nx; ++i) {
+        T[L.oVec + LinLayout::V_RDYN0 * G + i] = r0[i];
+        T[L.oVec + LinLayout::V_X0 * G + i] = z0[i];
+    }
+    for (int k = 0; k < nth; ++k) T[L.oTh0 + k] = th0[k];
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpy(h->d_tab + (size_t)(t - 1) * L.size, T.data(), (size_t)L.size * sizeof(double),
+                         hipMemcpyHostToDevice));
+    if (!h->knot_set[t - 1]) { h->knot_set[t - 1] = 1; h->n_knots_set++; }
+    return CIMPC_OK;
+}
+
+int cimpc_set_objective(cimpc_handle h, const double* Q, const double* R, const double* Cg,
+                        const double* Cb, const double* V, const double* q_target,
+                        const double* v_target) {
+    if (!h || !Q || !R) return fail(h, CIMPC_ERR_INVALID, "Q and R are required");
+    (void)q_target; (void)v_target;
+    if (V != nullptr)
+        return fail(h, CIMPC_ERR_INVALID,
+                    "TrackingVelocityObjective (V != NULL) is not implemented in this build (DESIGN.md, next)");
+    const cimpc_dims& d = h->dm;
+    const size_t H = d.H;
+    std::vector<double> Qi(H * d.nq * d.nq), Ri(H * d.nu * d.nu);
+    for (size_t i = 0; i < H; ++i) {
+        if (!invert(Q + i * d.nq * d.nq, Qi.data() + i * d.nq * d.nq, d.nq))
+            return fail(h, CIMPC_ERR_INVALID, "objective block Q[i] is singular");
+        if (d.nu > 0 && !invert(R + i * d.nu * d.nu, Ri.data() + i * d.nu * d.nu, d.nu))
+            return fail(h, CIMPC_ERR_INVALID, "objective block R[i] is singular");
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpy(h->d_Q, Q, H * d.nq * d.nq * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_R, R, H * d.nu * d.nu * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_Qinv, Qi.data(), Qi.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_Rinv, Ri.data(), Ri.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (Cg) HIP_TRY(h, hipMemcpy(h->d_Cg, Cg, H * d.nc * d.nc * sizeof(double), hipMemcpyHostToDevice));
+    if (Cb) HIP_TRY(h, hipMemcpy(h->d_Cb, Cb, H * d.nb * d.nb * sizeof(double), hipMemcpyHostToDevice));
+    h->objective_set = true;
+    return CIMPC_OK;
+}
+
+int cimpc_set_altitude(cimpc_handle h, const double* alt) {
+    if (!h) return CIMPC_ERR_INVALID;
+    if (!alt) { h->alt_set = false; return CIMPC_OK; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpy(h->d_alt, alt, (size_t)h->dm.B * h->dm.nc * sizeof(double), hipMemcpyHostToDevice));
+    h->alt_set = true;
+    return CIMPC_OK;
+}
+
+int cimpc_set_window(cimpc_handle h, const int* window) {
+    if (!h || !window) return fail(h, CIMPC_ERR_INVALID, "null argument");
+    const cimpc_dims& d = h->dm;
+    const int B = d.B, H = d.H, K = d.H_ref;
+    // bucket problems (b, i) by reference knot window[b][i] (counting sort)
+    std::vector<int> cnt(K + 1, 0);
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < H; ++i) {
+            const int t = window[(size_t)b * (H + 2) + i];
+            if (t < 1 || t > K) return fail(h, CIMPC_ERR_INVALID, "window entry out of range (1-based knot index)");
+            cnt[t]++;
+        }
+    std::vector<int> off(K + 2, 0);
+    for (int t = 1; t <= K; ++t) off[t + 1] = off[t] + cnt[t];
+    std::vector<int> plist((size_t)B * H), fill(off.begin(), off.end());
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < H; ++i) {
+            const int t = window[(size_t)b * (H + 2) + i];
+            plist[fill[t]++] = b * H + i;
+        }
+    const int pw = (64 / h->ki.G) * h->waves;   // problems per workgroup
+    std::vector<int> desc;
+    for (int t = 1; t <= K; ++t)
+        for (int s = 0; s < cnt[t]; s += pw) {
+            desc.push_back(t - 1);
+            desc.push_back(off[t] + s);
+            desc.push_back(std::min(pw, cnt[t] - s));
+            desc.push_back(0);
+        }
+    h->n_wg = (int)desc.size() / 4;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpy(h->d_plist, plist.data(), plist.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_wg_desc, desc.data(), desc.size() * sizeof(int), hipMemcpyHostToDevice));
+    h->window_set = true;
+    return CIMPC_OK;
+}
+
+int cimpc_set_reference(cimpc_handle h, const double* q_ref, const double* u_ref,
+                        const double* w_ref, const double* gamma_ref, const double* b_ref,
+                        const double* theta_ref) {
+    if (!h || !q_ref || !u_ref || !theta_ref) return fail(h, CIMPC_ERR_INVALID, "q_ref, u_ref, theta_ref are required");
+    const cimpc_dims& d = h->dm;
+    const size_t B = d.B, H = d.H;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpy(h->S.ref.q, q_ref, B * (H + 2) * d.nq * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->S.ref.u, u_ref, B * H * d.nu * sizeof(double), hipMemcpyHostToDevice));
+    if (w_ref) HIP_TRY(h, hipMemcpy(h->S.ref.w, w_ref, B * H * d.nw * sizeof(double), hipMemcpyHostToDevice));
+    else HIP_TRY(h, hipMemset(h->S.ref.w, 0, B * H * d.nw * sizeof(double)));
+    if (gamma_ref) HIP_TRY(h, hipMemcpy(h->S.ref.g, gamma_ref, B * H * d.nc * sizeof(double), hipMemcpyHostToDevice));
+    if (b_ref) HIP_TRY(h, hipMemcpy(h->S.ref.b, b_ref, B * H * d.nb * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->S.ref.th, theta_ref, B * H * h->nth * sizeof(double), hipMemcpyHostToDevice));
+    h->reference_set = true;
+    return CIMPC_OK;
+}
+
+int cimpc_implicit_dynamics(cimpc_handle h, const double* q, const double* theta,
+                            const double* gamma, const double* b, double* d_out, double* dz,
+                            int* status, int* iters, double* z) {
+    int rc = check_ready(h, false);
+    if (rc != CIMPC_OK) return rc;
+    if (!q || !theta) return fail(h, CIMPC_ERR_INVALID, "q and theta are required");
+    const cimpc_dims& d = h->dm;
+    const size_t B = d.B, H = d.H;
+    if (d.mode == CIMPC_MODE_CONFIGURATIONFORCE && (!gamma || !b))
+        return fail(h, CIMPC_ERR_INVALID, "gamma and b are required in configurationforce mode");
+    HIP_TRY(h, hipSetDevice(h->device));
+    TrajDev& T = h->S.cand;
+    HIP_TRY(h, hipMemcpyAsync(T.q, q, B * (H + 2) * d.nq * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(T.th, theta, B * H * h->nth * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (gamma) HIP_TRY(h, hipMemcpyAsync(T.g, gamma, B * H * d.nc * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (b) HIP_TRY(h, hipMemcpyAsync(T.b, b, B * H * d.nb * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    rc = run_sweep(h, T, nullptr, z ? h->d_zout : nullptr);
+    if (rc != CIMPC_OK) return rc;
+    if (d_out) HIP_TRY(h, hipMemcpyAsync(d_out, h->S.d, B * H * h->nd * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (dz) HIP_TRY(h, hipMemcpyAsync(dz, h->S.dz, B * H * h->nths * h->nd * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (status) HIP_TRY(h, hipMemcpyAsync(status, h->S.ip_status, B * H * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (iters) HIP_TRY(h, hipMemcpyAsync(iters, h->S.ip_iters, B * H * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (z) HIP_TRY(h, hipMemcpyAsync(z, h->d_zout, B * H * h->nz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CIMPC_OK;
+}
+
+int cimpc_kkt_solve(cimpc_handle h, const double* r, double beta, double* delta) {
+    int rc = check_ready(h, true);
+    if (rc != CIMPC_OK) return rc;
+    if (!r || !delta) return fail(h, CIMPC_ERR_INVALID, "null argument");
+    const size_t n = (size_t)h->dm.B * h->N;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(h->d_rhs, r, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    prof_begin(h, PC_KKT);
+    rc = launch_kkt_raw(h->S, h->d_rhs, beta, h->S.delta, h->stream);
+    prof_end(h);
+    if (rc != CIMPC_OK) return fail(h, rc, "kkt launch failed");
+    HIP_TRY(h, hipMemcpyAsync(delta, h->S.delta, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CIMPC_OK;
+}
+
+int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q1_dev, int warm_start) {
+    int rc = check_ready(h, true);
+    if (rc != CIMPC_OK) return rc;
+    if (!q0_dev || !q1_dev) return fail(h, CIMPC_ERR_INVALID, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    NewtonDev& S = h->S;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto over_budget = [&]() {
+        if (h->nt.max_time <= 0.0) return false;
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return el >= h->nt.max_time;
+    };
+    HIP_TRY(h, hipMemsetAsync(S.stats, 0, 4 * sizeof(long long), h->stream));
+    prof_begin(h, PC_OTHER);
+    rc = launch_reset(S, q0_dev, q1_dev, warm_start, h->stream);
+    prof_end(h);
+    if (rc != CIMPC_OK) return fail(h, rc, "reset launch failed");
+    long long rounds = 0;
+    int n_kkt = 0;
+    const int max_rounds = h->nt.max_iter * 8 + 2;
+    while (true) {
+        // ---- one lock-step round: [KKT for rollouts that start an iteration] -> sweep ->
+        //      residual + line-search decision
+        HIP_TRY(h, hipMemsetAsync(S.counters, 0, 8 * sizeof(int), h->stream));
+        if (n_kkt > 0) {
+            prof_begin(h, PC_KKT);
+            rc = launch_kkt(S, h->stream);
+            prof_end(h);
+            if (rc != CIMPC_OK) return fail(h, rc, "kkt launch failed");
+            h->prof_kkt_systems += n_kkt;
+        }
+        rc = run_sweep(h, S.cand, S.need_sweep, nullptr);
+        if (rc != CIMPC_OK) return rc;
+        prof_begin(h, PC_RESID);
+        rc = launch_resid_decide(S, h->stream);
+        prof_end(h);
+        if (rc != CIMPC_OK) return fail(h, rc, "residual launch failed");
+        HIP_TRY(h, hipMemcpyAsync(h->h_counters, S.counters, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        ++rounds;
+        const int n_sweep = h->h_counters[0];
+        n_kkt = h->h_counters[1];
+        if (n_sweep == 0 && n_kkt == 0) break;
+        if (rounds >= max_rounds) break;
+        if (over_budget()) break;          // newton.jl:187-277: silent early return
+    }
+    long long st[4];
+    HIP_TRY(h, hipMemcpy(st, S.stats, sizeof(st), hipMemcpyDeviceToHost));
+    std::vector<int> l(h->dm.B);
+    HIP_TRY(h, hipMemcpy(l.data(), S.newton_l, l.size() * sizeof(int), hipMemcpyDeviceToHost));
+    h->last_stats.sweeps = st[0];
+    h->last_stats.ip_solves = st[1];
+    h->last_stats.ip_iters = st[2];
+    h->last_stats.ip_failures = st[3];
+    h->last_stats.rounds = rounds;
+    h->last_stats.newton_iters = 0;
+    for (int v : l) h->last_stats.newton_iters += v;
+    h->prof_ip_problems += st[1];
+    return CIMPC_OK;
+}
+
+int cimpc_newton_solve(cimpc_handle h, const double* q0, const double* q1, int warm_start,
+                       double* u1, int* newton_iters, double* r_norm) {
+    if (!h || !q0 || !q1) return fail(h, CIMPC_ERR_INVALID, "null argument");
+    const size_t n = (size_t)h->dm.B * h->dm.nq * sizeof(double);
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpy(h->d_q0, q0, n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_q1, q1, n, hipMemcpyHostToDevice));
+    int rc = cimpc_newton_solve_dev(h, h->d_q0, h->d_q1, warm_start);
+    if (rc != CIMPC_OK) return rc;
+    return cimpc_get_newton_info(h, newton_iters, r_norm, u1);
+}
+
+int cimpc_get_trajectory(cimpc_handle h, double* q, double* u, double* gamma, double* b, double* nu_dual) {
+    if (!h) return CIMPC_ERR_INVALID;
+    const cimpc_dims& d = h->dm;
+    const size_t B = d.B, H = d.H;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (q) HIP_TRY(h, hipMemcpy(q, h->S.traj.q, B * (H + 2) * d.nq * sizeof(double), hipMemcpyDeviceToHost));
+    if (u) HIP_TRY(h, hipMemcpy(u, h->S.traj.u, B * H * d.nu * sizeof(double), hipMemcpyDeviceToHost));
+    if (gamma) HIP_TRY(h, hipMemcpy(gamma, h->S.traj.g, B * H * d.nc * sizeof(double), hipMemcpyDeviceToHost));
+    if (b) HIP_TRY(h, hipMemcpy(b, h->S.traj.b, B * H * d.nb * sizeof(double), hipMemcpyDeviceToHost));
+    if (nu_dual) HIP_TRY(h, hipMemcpy(nu_dual, h->S.nu, B * H * h->nd * sizeof(double), hipMemcpyDeviceToHost));
+    return CIMPC_OK;
+}
+
+int cimpc_get_newton_info(cimpc_handle h, int* newton_iters, double* r_norm, double* u1) {
+    if (!h) return CIMPC_ERR_INVALID;
+    const cimpc_dims& d = h->dm;
+    const size_t B = d.B;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (newton_iters) HIP_TRY(h, hipMemcpy(newton_iters, h->S.newton_l, B * sizeof(int), hipMemcpyDeviceToHost));
+    if (r_norm) {
+        HIP_TRY(h, hipMemcpy(r_norm, h->S.r_norm, B * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t b = 0; b < B; ++b) r_norm[b] /= (double)h->N;
+    }
+    if (u1)     // core.traj.u[1] of every rollout (policy.jl:142)
+        HIP_TRY(h, hipMemcpy2D(u1, d.nu * sizeof(double), h->S.traj.u, (size_t)d.H * d.nu * sizeof(double),
+                               d.nu * sizeof(double), B, hipMemcpyDeviceToHost));
+    return CIMPC_OK;
+}
+
+int cimpc_get_rollout_counters(cimpc_handle h, int* sweeps, int* ip_iters, int* ip_failures) {
+    if (!h) return CIMPC_ERR_INVALID;
+    const size_t B = h->dm.B;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (sweeps) HIP_TRY(h, hipMemcpy(sweeps, h->S.ro_sweeps, B * sizeof(int), hipMemcpyDeviceToHost));
+    if (ip_iters) HIP_TRY(h, hipMemcpy(ip_iters, h->S.ro_ip_iters, B * sizeof(int), hipMemcpyDeviceToHost));
+    if (ip_failures) HIP_TRY(h, hipMemcpy(ip_failures, h->S.ro_ip_fail, B * sizeof(int), hipMemcpyDeviceToHost));
+    return CIMPC_OK;
+}
+
+int cimpc_get_stats(cimpc_handle h, cimpc_stats* s) {
+    if (!h || !s) return CIMPC_ERR_INVALID;
+    *s = h->last_stats;
+    return CIMPC_OK;
+}
+
+int cimpc_profile_enable(cimpc_handle h, int on) {
+    if (!h) return CIMPC_ERR_INVALID;
+    prof_collect(h);
+    h->prof_on = on != 0;
+    return CIMPC_OK;
+}
+
+int cimpc_profile_reset(cimpc_handle h) {
+    if (!h) return CIMPC_ERR_INVALID;
+    prof_collect(h);
+    for (int c = 0; c < PC_COUNT; ++c) { h->prof_ms[c] = 0.0; h->prof_n[c] = 0; }
+    h->prof_ip_problems = 0;
+    h->prof_kkt_systems = 0;
+    return CIMPC_OK;
+}
+
+int cimpc_profile_read(cimpc_handle h, cimpc_profile* p) {
+    if (!h || !p) return CIMPC_ERR_INVALID;
+    prof_collect(h);
+    p->ip_sweep_ms = h->prof_ms[PC_IP]; p->ip_sweep_launches = h->prof_n[PC_IP];
+    p->ip_sweep_problems = h->prof_ip_problems;
+    p->kkt_ms = h->prof_ms[PC_KKT]; p->kkt_launches = h->prof_n[PC_KKT]; p->kkt_systems = h->prof_kkt_systems;
+    p->resid_ms = h->prof_ms[PC_RESID]; p->resid_launches = h->prof_n[PC_RESID];
+    p->other_ms = h->prof_ms[PC_OTHER]; p->other_launches = h->prof_n[PC_OTHER];
+    return CIMPC_OK;
+}
+
+int cimpc_query_sizes(cimpc_handle h, int* table_doubles, int* N_kkt) {
+    if (!h) return CIMPC_ERR_INVALID;
+    if (table_doubles) *table_doubles = h->ki.tab_size;
+    if (N_kkt) *N_kkt = h->N;
+    return CIMPC_OK;
+}
+
+}  // extern "C"

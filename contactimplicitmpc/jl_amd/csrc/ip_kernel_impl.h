@@ -1,0 +1,358 @@
+// Batched interior-point solve of the linearized contact-LCP knots: the data-parallel hot
+// loop `implicit_dynamics!` (/root/reference/src/controller/implicit_dynamics.jl:156-192)
+// with every callback the reference supplies to RoboDojo's interior_point_solve! fused
+// into ONE gfx950 kernel:
+//   rlin!                      linearized_solver.jl:364-373
+//   rzlin! + schur_factorize!  linearized_solver.jl:378-399, schur.jl:80-88
+//   MGS-QR factorize!/qr_solve!  qr.jl:113-158
+//   linear_solve! (vector)     linearized_solver.jl:424-444, schur_solve! schur.jl:93-110
+//   general_correction_term!, residual_violation, bilinear_violation   :401-418
+//   linear_solve! (matrix rhs, sensitivities)                          :451-479
+// and the IP iteration control frozen in DESIGN.md ("IP iteration spec"; RoboDojo 0.1.3
+// owns it upstream and its source is not available).
+//
+// Mapping (CDNA4, wave64): one problem (rollout b, horizon position i) per group of
+// G = 16 (ny <= 16) or 32 lanes -> 4 / 2 problems per wavefront.  A workgroup serves
+// problems that share a reference knot: the knot's packed linearization table is
+// staged once into LDS with coalesced 16-byte loads.  Per lane: lane-indexed vectors
+// x, y1, y2, r, Delta; column l of the ny x ny Schur matrix / Q factor in registers;
+// the R factor goes through a padded LDS tile (row access for the triangular solve).
+// Broadcasts are `v_mov_b64_dpp row_newbcast`, reductions DPP quad_perm/row_ror.
+#pragma once
+#include "cimpc_internal.h"
+#include "lane_group.h"
+#include "lin_table.h"
+
+namespace cimpc {
+
+template <int NQ_, int NU_, int NW_, int NC_, int NB_, int MODE_>
+struct Model {
+    static constexpr int NQ = NQ_, NU = NU_, NW = NW_, NC = NC_, NB = NB_, MODE = MODE_;
+    static constexpr int NX = NQ, NY = 2 * NC + NB, NZ = NQ + 4 * NC + 2 * NB;
+    static constexpr int NTH = 2 * NQ + NU + NW + 2, NTHS = 2 * NQ + NU;
+    static constexpr int ND = MODE ? NQ + NC + NB : NQ;
+    static constexpr int G = (NX <= 16 && NY <= 16) ? 16 : 32;
+    static_assert(NX <= 32 && NY <= 32, "lane group holds at most 32 rows");
+    static constexpr int RST_LD = G + 1;                       // padded row stride of the R tile
+    static constexpr int LDS_GROUP = ((NY * RST_LD + NTH) + 1) & ~1;  // doubles / problem
+};
+
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS traffic of one wavefront is processed in issue order; this only stops the
+    // compiler from reordering across the hand-off between lanes of the same wave.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <class M>
+__global__ __launch_bounds__(256) void ip_sweep_kernel(IpParams p) {
+    constexpr int NX = M::NX, NY = M::NY, NTH = M::NTH, NTHS = M::NTHS, ND = M::ND, G = M::G;
+    constexpr int NC = M::NC, NB = M::NB;
+    constexpr LinLayout L(NX, NY, NTH, G);
+    using LG = LaneGroup<G>;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* tab = smem;
+    const int tid = (int)threadIdx.x;
+    const int4 desc = reinterpret_cast<const int4*>(p.wg_desc)[blockIdx.x];
+    const int knot = desc.x, start = desc.y, count = desc.z;
+
+    {   // stage the knot's table: 16 B per lane, fully coalesced
+        const double2* src = reinterpret_cast<const double2*>(p.tab + (size_t)knot * L.size);
+        double2* dst = reinterpret_cast<double2*>(tab);
+        for (int k = tid; k < L.size / 2; k += (int)blockDim.x) dst[k] = src[k];
+    }
+    __syncthreads();
+
+    const int grp = tid / G;
+    const int l = tid % G;
+    if (grp >= count) return;
+    const int prob = p.plist[start + grp];
+    const int b = prob / p.H, i = prob - b * p.H;
+    if (p.need_sweep != nullptr && p.need_sweep[b] == 0) return;
+
+    double* Rst = smem + L.size + (size_t)grp * M::LDS_GROUP;   // [NY][G+1]
+    double* dth = Rst + NY * M::RST_LD;                          // [NTH]
+
+    const bool vx = l < NX, vy = l < NY;
+    const double* tW = tab + L.oW;
+    const double* tCAi = tab + L.oCAi;
+    const double* tAi = tab + L.oAi;
+    const double* tDy1 = tab + L.oDy1;
+    const double* tDx = tab + L.oDx;
+    const double* tRx = tab + L.oRx;
+    const double* tRy1 = tab + L.oRy1;
+    const double* tVec = tab + L.oVec;
+    const double ry2 = tVec[LinLayout::V_RY2 * G + l];
+    const double ry1d = tVec[LinLayout::V_RY1D * G + l];
+    const double caibd = tVec[LinLayout::V_CAIBD * G + l];
+    const double rdyn0 = tVec[LinLayout::V_RDYN0 * G + l];
+    const double rrst0 = tVec[LinLayout::V_RRST0 * G + l];
+    const double x0 = tVec[LinLayout::V_X0 * G + l];
+    const double y10 = tVec[LinLayout::V_Y10 * G + l];
+    const double y20 = tVec[LinLayout::V_Y20 * G + l];
+
+    // ---- problem data: theta - theta0 (LDS, read as broadcast), start point ------------
+    const double* th = p.theta + ((size_t)b * p.H + i) * NTH;
+    for (int k = l; k < NTH; k += G) dth[k] = th[k] - tab[L.oTh0 + k];
+    wave_lds_fence();
+    double tthdyn = 0.0, tthrst = 0.0;   // rthdyn*(th-th0), rthrst*(th-th0): constant per solve
+#pragma unroll 2
+    for (int k = 0; k < NTH; ++k) {
+        const double dk = dth[k];
+        tthdyn = fma(tab[L.oRthDyn + k * G + l], dk, tthdyn);
+        tthrst = fma(tab[L.oRthRst + k * G + l], dk, tthrst);
+    }
+    double altl = 0.0;
+    if (p.alt != nullptr && l < NC) altl = p.alt[(size_t)b * NC + l];
+
+    const double* qrow = p.q + ((size_t)b * (p.H + 2) + (i + 2)) * M::NQ;
+    const double qinit = vx ? qrow[l] : 0.0;
+    // z_initialize!: z .= 1, z[iq2] = q   (simulation.jl:59-63)
+    double x = qinit, y1 = 1.0, y2 = 1.0;
+
+    double rdyn, rrst, rbil;
+    // rlin! (linearized_solver.jl:364-373), same association as the reference expression
+    auto residual = [&](double kappa) {
+        const double dx = x - x0, dy1 = y1 - y10, dy2 = y2 - y20;
+        double a = 0.0, c = 0.0;
+        static_for<0, NX>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const double v = LG::template bcast<k>(dx);
+            a = fma(tDx[k * G + l], v, a);
+            c = fma(tRx[k * G + l], v, c);
+        });
+        double bb = 0.0, e = 0.0;
+        static_for<0, NY>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const double v = LG::template bcast<k>(dy1);
+            bb = fma(tDy1[k * G + l], v, bb);
+            e = fma(tRy1[k * G + l], v, e);
+        });
+        rdyn = ((rdyn0 + a) + bb) + tthdyn;
+        rrst = ((((rrst0 + c) + e) + ry2 * dy2) + tthrst) + altl;
+        rbil = vy ? (y1 * y2 - kappa) : 0.0;
+    };
+    auto r_violation = [&]() { return LG::all_max(fmax(fabs(rdyn), fabs(rrst))); };
+    auto k_violation = [&]() { return LG::all_max(fabs(rbil)); };
+
+    double Qc[NY];        // column l of the Schur matrix, then of Q
+    double rdinv = 0.0;   // 1 / R[l,l]
+    double y1r = 1.0, y2r = 1.0;
+
+    // rzlin! + schur_factorize! + MGS factorize! (right-looking order: identical
+    // arithmetic per column to the reference's left-looking loop qr.jl:113-137)
+    auto factorize = [&](double reg) {
+        y1r = fmax(y1, reg);
+        y2r = fmax(y2, reg);
+        const double dd = ry2 * y2r / y1r;
+        static_for<0, NY>([&](auto ic) {
+            constexpr int r = decltype(ic)::value;
+            const double w = tW[r * G + l];                 // Ry1[r,l] - CAiB[r,l]   (r != l)
+            Qc[r] = (l == r) ? ((ry1d - dd) - caibd) : w;   // (D - CAiB)[r,l]
+        });
+        static_for<0, NY>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            double n2 = 0.0;
+            static_for<0, NY>([&](auto ic) {
+                constexpr int r = decltype(ic)::value;
+                n2 = fma(Qc[r], Qc[r], n2);
+            });
+            const double rkk = sqrt(n2);
+            const double inv = 1.0 / rkk;
+            const bool own = (l == k);
+            if (own) rdinv = inv;
+            double rk = 0.0;
+            double qk[NY];
+            static_for<0, NY>([&](auto ic) {
+                constexpr int r = decltype(ic)::value;
+                Qc[r] = own ? Qc[r] * inv : Qc[r];
+                qk[r] = LG::template bcast<k>(Qc[r]);
+                rk = fma(qk[r], Qc[r], rk);
+            });
+            const bool upd = (l > k) && vy;
+            rk = upd ? rk : 0.0;
+            static_for<0, NY>([&](auto ic) {
+                constexpr int r = decltype(ic)::value;
+                Qc[r] = fma(-rk, qk[r], Qc[r]);
+            });
+            Rst[k * M::RST_LD + l] = rk;   // R[k,l], l > k (zeros elsewhere)
+        });
+        wave_lds_fence();
+    };
+
+    // t = R^-1 Q^T rhs  (qr_solve!, qr.jl:142-158); rhs lane-indexed
+    auto qr_solve = [&](double rhs) {
+        double c = 0.0;
+        static_for<0, NY>([&](auto ic) {
+            constexpr int r = decltype(ic)::value;
+            c = fma(Qc[r], LG::template bcast<r>(rhs), c);
+        });
+        double t = 0.0;
+        static_rfor<NY - 1>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const double xk = LG::template bcast<k>(c * rdinv);
+            t = (l == k) ? xk : t;
+            const double rlk = vy ? Rst[l * M::RST_LD + k] : 0.0;   // R[l,k] (zero for k <= l)
+            c = fma(-rlk, xk, c);
+        });
+        return t;
+    };
+
+    // schur_solve! (schur.jl:93-110): returns temp; x = Ai*(u + B*temp), y = -temp
+    auto schur_solve = [&](double u, double v, double& xs) {
+        double bq = 0.0;
+        static_for<0, NX>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            bq = fma(tCAi[k * G + l], LG::template bcast<k>(u), bq);
+        });
+        const double t = qr_solve(bq - v);
+        double w = 0.0;
+        static_for<0, NY>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            w = fma(tDy1[k * G + l], LG::template bcast<k>(t), w);
+        });
+        w = u + w;
+        double xx = 0.0;
+        static_for<0, NX>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            xx = fma(tAi[k * G + l], LG::template bcast<k>(w), xx);
+        });
+        xs = xx;
+        return t;
+    };
+
+    double Dx_, Dy1_, Dy2_;
+    // linear_solve!(Delta, rz, r) (linearized_solver.jl:424-444)
+    auto linear_solve = [&]() {
+        const double u = rdyn;
+        const double v = vy ? (rrst - ry2 * rbil / y1r) : 0.0;
+        const double t = schur_solve(u, v, Dx_);
+        Dy1_ = -t;
+        Dy2_ = vy ? ((rbil - y2r * Dy1_) / y1r) : 0.0;
+    };
+    auto step_length = [&](double tau) {
+        double a = 1.0;
+        if (vy && Dy1_ > 0.0) a = fmin(a, tau * y1 / Dy1_);
+        if (vy && Dy2_ > 0.0) a = fmin(a, tau * y2 / Dy2_);
+        return LG::all_min(a);
+    };
+
+    // ---- interior-point iteration (DESIGN.md "IP iteration spec") ----------------------
+    const cimpc_ip_opts o = p.o;
+    residual(0.0);
+    double r_vio = r_violation();
+    double k_vio = k_violation();
+    int iters = 0;
+    double reg = 0.0;
+    for (int j = 0; j < o.max_iter; ++j) {
+        if (r_vio < o.r_tol && k_vio < o.kappa_tol) break;
+        ++iters;
+        reg = (k_vio < o.kappa_reg) ? k_vio * o.gamma_reg : 0.0;
+        factorize(reg);
+        linear_solve();                                   // predictor
+        const double a_aff = step_length(1.0);
+        const double mu = LG::all_sum(vy ? y1 * y2 : 0.0) / (double)NY;
+        const double mu_aff =
+            LG::all_sum(vy ? (y1 - a_aff * Dy1_) * (y2 - a_aff * Dy2_) : 0.0) / (double)NY;
+        double sg = fmin(fmax(mu_aff / mu, 0.0), 1.0);
+        sg = sg * sg * sg;
+        const double kc = fmax(sg * mu, o.kappa_tol / o.undercut);
+        // corrector residual: rdyn, rrst unchanged (same z), rbil = y1*y2 - kc + Dy1*Dy2
+        rbil = vy ? ((y1 * y2 - kc) + Dy1_ * Dy2_) : 0.0;
+        linear_solve();                                   // corrector
+        const double vm = fmax(r_vio, k_vio);
+        const double tau = fmax(1.0 - o.eps_min, 1.0 - vm * vm);
+        const double alpha = step_length(tau);
+        x -= alpha * Dx_;
+        y1 = vy ? (y1 - alpha * Dy1_) : 1.0;
+        y2 = vy ? (y2 - alpha * Dy2_) : 1.0;
+        double k_c = 0.0, r_c = 0.0, back = alpha;
+        for (int s = 1; s <= o.max_ls; ++s) {
+            residual(0.0);
+            k_c = k_violation();
+            r_c = r_violation();
+            if (r_c <= r_vio || k_c <= k_vio) break;
+            back *= o.ls_scale;                           // alpha * ls_scale^s
+            x += back * Dx_;
+            y1 = vy ? (y1 + back * Dy1_) : 1.0;
+            y2 = vy ? (y2 + back * Dy2_) : 1.0;
+        }
+        k_vio = k_c;
+        r_vio = r_c;
+    }
+    const bool ok = (r_vio < o.r_tol) && (k_vio < o.kappa_tol);
+
+    const size_t pi = (size_t)b * p.H + i;
+    if (l == 0) {
+        p.status[pi] = ok ? 1 : 0;
+        p.iters[pi] = iters;
+    }
+    // dynamics violation d = z[1:nd] - [q_{i+2}; gamma_i; b_i]  (implicit_dynamics.jl:180-190)
+    if (vx) p.d[pi * ND + l] = x - qinit;
+    if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) {
+        if (l < NC) p.d[pi * ND + NX + l] = y1 - p.gam[pi * NC + l];
+        else if (l < NC + NB) p.d[pi * ND + NX + l] = y1 - p.bfr[pi * NB + (l - NC)];
+    }
+    if (p.zout != nullptr) {
+        double* zo = p.zout + pi * M::NZ;
+        if (vx) zo[l] = x;
+        if (vy) { zo[NX + l] = y1; zo[NX + NY + l] = y2; }
+    }
+    if (!ok) return;   // failed solve: sensitivities of this slot stay untouched
+
+    // ---- differentiate_solution!: dz = -(rz^-1 rth), reg = max(reg, kappa_tol*gamma_reg)
+    factorize(fmax(reg, o.kappa_tol * o.gamma_reg));
+    double* dzo = p.dz + pi * (size_t)(NTHS * ND);
+#pragma unroll 1
+    for (int c = 0; c < NTHS; ++c) {
+        const double u = tab[L.oRthDyn + c * G + l];
+        const double v = tab[L.oRthRst + c * G + l];
+        double xs;
+        const double t = schur_solve(u, v, xs);
+        if (vx) dzo[c * ND + l] = -xs;
+        if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) {
+            if (l < NC + NB) dzo[c * ND + NX + l] = t;   // -(S.y) = +temp
+        }
+    }
+}
+
+
+// ----------------------------------------------------------------------------------------
+// per-model launch / info (instantiated in ip_model_*.hip, one translation unit per model
+// so that the models build in parallel)
+// ----------------------------------------------------------------------------------------
+template <class M>
+int launch_model(const IpParams& p, int n_wg, int waves, hipStream_t s) {
+    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G);
+    if (waves != 1 && waves != 2 && waves != 4) return CIMPC_ERR_INVALID;
+    const int ppw = 64 / M::G;
+    const size_t lds = (size_t)(L.size + waves * ppw * M::LDS_GROUP) * sizeof(double);
+    if (lds > 64 * 1024) {   // opt in to the full 160 KiB LDS of a gfx950 CU
+        if (hipFuncSetAttribute((const void*)ip_sweep_kernel<M>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return CIMPC_ERR_HIP;
+    }
+    hipLaunchKernelGGL((ip_sweep_kernel<M>), dim3(n_wg), dim3(64 * waves), lds, s, p);
+    return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+}
+
+template <class M>
+void info_model(KernelInfo* info) {
+    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G);
+    info->G = M::G;
+    info->lds_table = L.size;
+    info->lds_group = M::LDS_GROUP;
+    info->tab_size = L.size;
+}
+
+#define CIMPC_DEFINE_MODEL(name, q, u, w, c, b)                                              \
+    int ip_launch_##name(int mode, const IpParams& p, int n_wg, int waves, hipStream_t s) {  \
+        if (mode == 0) return launch_model<Model<q, u, w, c, b, 0>>(p, n_wg, waves, s);      \
+        return launch_model<Model<q, u, w, c, b, 1>>(p, n_wg, waves, s);                     \
+    }                                                                                        \
+    void ip_info_##name(int mode, KernelInfo* info) {                                        \
+        if (mode == 0) info_model<Model<q, u, w, c, b, 0>>(info);                            \
+        else info_model<Model<q, u, w, c, b, 1>>(info);                                      \
+    }
+
+}  // namespace cimpc

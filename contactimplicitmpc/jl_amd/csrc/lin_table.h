@@ -1,0 +1,40 @@
+// Packed per-knot linearization table: the HBM / LDS layout of the constant blocks the
+// reference keeps in RLin / RZLin / RthLin / Schur objects
+// (/root/reference/src/controller/linearized_solver.jl:15-65, 188-222, 311-323;
+//  src/solver/schur.jl:13-26).
+//
+// One table = LinLayout::size doubles, contiguous, 16-byte aligned.  Every matrix is
+// stored "lane strided": element (row i, col k) of an operator applied as
+//   y_i = sum_k A[i,k] x_k   (lane i owns row i, x_k broadcast from lane k)
+// sits at  base + k*G + i , so that the G lanes of a group read G consecutive doubles
+// (coalesced from HBM when the table is staged, conflict-free from LDS afterwards).
+// The Schur matrix W = Ry1 - C A^-1 B is stored transposed-strided (row i at i*G + j)
+// because the QR keeps one COLUMN j per lane.
+#pragma once
+
+namespace cimpc {
+
+struct LinLayout {
+    int nx, ny, nth, G;
+    // offsets in doubles
+    int oW, oCAi, oAi, oDy1, oDx, oRx, oRy1, oRthDyn, oRthRst, oVec, oTh0, size;
+    // oVec holds 8 lane-strided vectors:
+    enum { V_RY2 = 0, V_RY1D, V_CAIBD, V_RDYN0, V_RRST0, V_X0, V_Y10, V_Y20, V_COUNT };
+
+    __host__ __device__ constexpr LinLayout(int nx_, int ny_, int nth_, int G_)
+        : nx(nx_), ny(ny_), nth(nth_), G(G_),
+          oW(0),
+          oCAi(oW + ny_ * G_),
+          oAi(oCAi + nx_ * G_),
+          oDy1(oAi + nx_ * G_),
+          oDx(oDy1 + ny_ * G_),
+          oRx(oDx + nx_ * G_),
+          oRy1(oRx + nx_ * G_),
+          oRthDyn(oRy1 + ny_ * G_),
+          oRthRst(oRthDyn + nth_ * G_),
+          oVec(oRthRst + nth_ * G_),
+          oTh0(oVec + V_COUNT * G_),
+          size(((oTh0 + nth_) + 1) & ~1) {}
+};
+
+}  // namespace cimpc

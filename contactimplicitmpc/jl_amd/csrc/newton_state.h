@@ -1,0 +1,71 @@
+// Device-resident state of the batched Newton solver (one slot per rollout), the HBM
+// counterpart of the reference's `Newton` workspace (/root/reference/src/controller/newton.jl:17-35)
+// and `ContactTraj` containers (trajectory.jl:1-19).  Plain pointers, SoA, every array has a
+// leading rollout dimension B.
+#pragma once
+#include "cimpc_internal.h"
+
+namespace cimpc {
+
+enum Stage : int { STAGE_DONE = 0, STAGE_INIT = 1, STAGE_LINESEARCH = 2, STAGE_KKT = 3 };
+
+struct TrajDev {
+    double* q;    // [B][H+2][nq]
+    double* u;    // [B][H][nu]
+    double* w;    // [B][H][nw]
+    double* g;    // [B][H][nc]
+    double* b;    // [B][H][nb]
+    double* th;   // [B][H][nth]
+};
+
+struct NewtonDev {
+    cimpc_dims dm;
+    int nd, nr, nth, nths, N;
+    TrajDev traj, cand, ref;
+    double* nu;        // [B][H][nd]
+    double* nu_cand;   // [B][H][nd]
+    // implicit dynamics of the last sweep
+    double* d;         // [B][H][nd]
+    double* dz;        // [B][H][nths][nd]
+    int* ip_status;    // [B][H]
+    int* ip_iters;     // [B][H]
+    // Newton vectors, reference layout (newton_residual.jl:69-98)
+    double* res;       // [B][N]
+    double* res_cand;  // [B][N]
+    double* delta;     // [B][N]
+    // per-rollout scalars
+    double* r_norm;    // [B]  |res|_1
+    double* r_cand;    // [B]
+    double* alpha;     // [B]
+    double* beta;      // [B]
+    int* ls_iter;      // [B]
+    int* newton_l;     // [B]  Newton iterations done
+    int* stage;        // [B]
+    int* need_sweep;   // [B]
+    int* counters;     // [8]: 0 = #rollouts needing a sweep, 1 = #needing KKT
+    long long* stats;  // [4]: sweeps, ip_solves, ip_iters, ip_failures (accumulated)
+    int* ro_sweeps;    // [B] implicit_dynamics! evaluations of the last solve
+    int* ro_ip_iters;  // [B] interior-point iterations of the last solve
+    int* ro_ip_fail;   // [B] failed interior-point solves of the last solve
+    // objective (objective.jl), per horizon step, column-major blocks
+    const double* Q;     // [H][nq*nq]
+    const double* R;     // [H][nu*nu]
+    const double* Qinv;  // [H][nq*nq]
+    const double* Rinv;  // [H][nu*nu]
+    const double* Cg;    // [H][nc*nc] (cf) or null
+    const double* Cb;    // [H][nb*nb] (cf) or null
+    // KKT workspace: per rollout H * (3*nd*nd + nd) doubles (L1, L2, L0inv, y)
+    double* kkt_ws;
+    // options
+    double r_tol, beta_init, kappa;
+    int max_iter;
+};
+
+int launch_reset(const NewtonDev& nd, const double* q0, const double* q1, int warm, hipStream_t s);
+int launch_resid_decide(const NewtonDev& nd, hipStream_t s);
+int launch_kkt(const NewtonDev& nd, hipStream_t s);
+// B1 seam: solve with caller-provided residual / beta for all rollouts, no state change
+int launch_kkt_raw(const NewtonDev& nd, const double* r_dev, double beta, double* delta_dev,
+                   hipStream_t s);
+
+}  // namespace cimpc

@@ -1,0 +1,247 @@
+"""Host-side mirror of the reference's solver interface for the MI355X path.
+
+Names, argument meaning and error behaviour follow the reference (file:line relative to
+/root/reference):
+    ImplicitTrajectory / implicit_dynamics!   src/controller/implicit_dynamics.jl:21-90, 156-192
+    Newton / newton_solve!                    src/controller/newton.jl:37-91, 169-288
+    linear_solve!(solver, D, R, r)            src/controller/newton.jl:218 (LinearSolver seam)
+    TrackingObjective                         src/controller/objective.jl:3-16
+    NewtonOptions / InteriorPointOptions      src/controller/newton.jl:2-11, policy.jl:54-61
+All arithmetic happens in libcimpc_hip.so (HIP, gfx950); this module only marshals
+numpy arrays across the C ABI.  Batched: every trajectory argument carries a leading
+rollout dimension B (B = 1 is the reference's call).
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import CimpcError
+
+MODE_CONFIGURATION = 0
+MODE_CONFIGURATIONFORCE = 1
+
+
+@dataclass
+class InteriorPointOptions:
+    r_tol: float = 1.0e-8
+    kappa_tol: float = 2.0e-4
+    undercut: float = 5.0
+    gamma_reg: float = 0.1
+    kappa_reg: float = 1.0e-3
+    eps_min: float = 0.05
+    ls_scale: float = 0.5
+    max_iter: int = 100
+    max_ls: int = 3
+
+
+@dataclass
+class NewtonOptions:
+    r_tol: float = 3.0e-4
+    max_iter: int = 5
+    beta_init: float = 1.0e-5
+    max_time: float = 0.0
+    kappa: float = 2.0e-4
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ipt(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _f64(a, shape=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {tuple(a.shape)}")
+    return a
+
+
+class CIMPCSolver:
+    """One handle = one GPU.  Wraps the C ABI; raises CimpcError on any non-zero status."""
+
+    def __init__(self, nq, nu, nw, nc, nb, H_ref, H, B=1, mode=MODE_CONFIGURATION,
+                 ip_opts: InteriorPointOptions = None, newton_opts: NewtonOptions = None, device=0):
+        self.lib = _lib.load()
+        self.dims = _lib.Dims(nq, nu, nw, nc, nb, mode, H_ref, H, B)
+        ip_opts = ip_opts or InteriorPointOptions()
+        newton_opts = newton_opts or NewtonOptions()
+        self._ip = _lib.IpOpts(ip_opts.r_tol, ip_opts.kappa_tol, ip_opts.undercut, ip_opts.gamma_reg,
+                               ip_opts.kappa_reg, ip_opts.eps_min, ip_opts.ls_scale, ip_opts.max_iter,
+                               ip_opts.max_ls)
+        self._nt = _lib.NewtonOpts(newton_opts.r_tol, newton_opts.beta_init, newton_opts.max_time,
+                                   newton_opts.kappa, newton_opts.max_iter, 0)
+        self.h = C.c_void_p()
+        rc = self.lib.cimpc_create(C.byref(self.dims), C.byref(self._ip), C.byref(self._nt), device,
+                                   C.byref(self.h))
+        if rc != 0:
+            msg = self.lib.cimpc_last_error(None).decode()
+            self.h = None
+            raise CimpcError(f"cimpc_create failed ({rc}): {msg}")
+        self.nq, self.nu, self.nw, self.nc, self.nb = nq, nu, nw, nc, nb
+        self.H_ref, self.H, self.B, self.mode = H_ref, H, B, mode
+        self.ny = 2 * nc + nb
+        self.nz = nq + 4 * nc + 2 * nb
+        self.nth = 2 * nq + nu + nw + 2
+        self.nths = 2 * nq + nu
+        self.nd = nq if mode == MODE_CONFIGURATION else nq + nc + nb
+        self.nr = nq + nu if mode == MODE_CONFIGURATION else nq + nu + nc + nb
+        self.N = H * (self.nr + self.nd)
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != 0:
+            raise CimpcError(f"{what} failed ({rc}): {self.lib.cimpc_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cimpc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        self._check(self.lib.cimpc_set_stream(self.h, C.c_void_p(stream_ptr)), "set_stream")
+
+    def synchronize(self):
+        self._check(self.lib.cimpc_synchronize(self.h), "synchronize")
+
+    # -- A1 ---------------------------------------------------------------------------------
+    def set_linearization(self, t, z0, th0, r0, rz0, rth0):
+        """LinearizedStep + RLin/RZLin/RthLin of knot t (1-based).  rz0 (nz,nz), rth0 (nz,nth)."""
+        z0 = _f64(z0, (self.nz,)); th0 = _f64(th0, (self.nth,)); r0 = _f64(r0, (self.nz,))
+        rz = np.asfortranarray(np.asarray(rz0, dtype=np.float64))
+        rt = np.asfortranarray(np.asarray(rth0, dtype=np.float64))
+        if rz.shape != (self.nz, self.nz) or rt.shape != (self.nz, self.nth):
+            raise ValueError("rz0 / rth0 shape mismatch")
+        self._check(self.lib.cimpc_set_linearization(self.h, int(t), _dp(z0), _dp(th0), _dp(r0),
+                                                     _dp(rz), _dp(rt)), "set_linearization")
+
+    def set_objective(self, Q, R, Cg=None, Cb=None, V=None, q_target=None, v_target=None):
+        """TrackingObjective weights, per horizon step: Q (H,nq,nq), R (H,nu,nu) [row-major numpy
+        arrays of symmetric blocks are transposed to the column-major ABI]."""
+        def blk(a, n):
+            if a is None:
+                return None
+            a = np.asarray(a, dtype=np.float64)
+            if a.shape != (self.H, n, n):
+                raise ValueError(f"objective block shape {a.shape} != {(self.H, n, n)}")
+            return np.ascontiguousarray(np.transpose(a, (0, 2, 1)))
+        Qc, Rc, Gc, Bc, Vc = blk(Q, self.nq), blk(R, self.nu), blk(Cg, self.nc), blk(Cb, self.nb), blk(V, self.nq)
+        qt = _f64(q_target); vt = _f64(v_target)
+        self._check(self.lib.cimpc_set_objective(self.h, _dp(Qc), _dp(Rc), _dp(Gc), _dp(Bc), _dp(Vc),
+                                                 _dp(qt), _dp(vt)), "set_objective")
+
+    def set_altitude(self, alt):
+        alt = _f64(alt, (self.B, self.nc)) if alt is not None else None
+        self._check(self.lib.cimpc_set_altitude(self.h, _dp(alt)), "set_altitude")
+
+    def set_window(self, window):
+        """window: (B, H+2) 1-based reference-knot indices (policy.jl:154-171)."""
+        w = np.ascontiguousarray(window, dtype=np.int32)
+        if w.shape != (self.B, self.H + 2):
+            raise ValueError(f"window shape {w.shape} != {(self.B, self.H + 2)}")
+        self._check(self.lib.cimpc_set_window(self.h, _ipt(w)), "set_window")
+
+    def set_reference(self, q_ref, u_ref, w_ref, gamma_ref, b_ref, theta_ref):
+        B, H = self.B, self.H
+        self._check(self.lib.cimpc_set_reference(
+            self.h, _dp(_f64(q_ref, (B, H + 2, self.nq))), _dp(_f64(u_ref, (B, H, self.nu))),
+            _dp(_f64(w_ref, (B, H, self.nw)) if w_ref is not None else None),
+            _dp(_f64(gamma_ref, (B, H, self.nc)) if gamma_ref is not None else None),
+            _dp(_f64(b_ref, (B, H, self.nb)) if b_ref is not None else None),
+            _dp(_f64(theta_ref, (B, H, self.nth)))), "set_reference")
+
+    # -- B3: implicit_dynamics! ---------------------------------------------------------------
+    def implicit_dynamics(self, q, theta, gamma=None, b=None, want_z=False):
+        """implicit_dynamics!(im_traj, traj; window).  Returns dict with d (B,H,nd),
+        dq0/dq1 (B,H,nd,nq), du1 (B,H,nd,nu), status, iters (B,H) [, z (B,H,nz)]."""
+        B, H, nd, nq, nu = self.B, self.H, self.nd, self.nq, self.nu
+        q = _f64(q, (B, H + 2, nq)); theta = _f64(theta, (B, H, self.nth))
+        gamma = _f64(gamma, (B, H, self.nc)) if gamma is not None else None
+        b = _f64(b, (B, H, self.nb)) if b is not None else None
+        d = np.zeros((B, H, nd)); dz = np.zeros((B, H, self.nths, nd))
+        status = np.zeros((B, H), dtype=np.int32); iters = np.zeros((B, H), dtype=np.int32)
+        z = np.zeros((B, H, self.nz)) if want_z else None
+        self._check(self.lib.cimpc_implicit_dynamics(self.h, _dp(q), _dp(theta), _dp(gamma), _dp(b),
+                                                     _dp(d), _dp(dz), _ipt(status), _ipt(iters), _dp(z)),
+                    "implicit_dynamics")
+        dzt = np.transpose(dz, (0, 1, 3, 2))       # (B,H,nd,nths): column-major -> row-major view
+        out = dict(d=d, dq0=dzt[..., 0:nq], dq1=dzt[..., nq:2 * nq], du1=dzt[..., 2 * nq:2 * nq + nu],
+                   status=status, iters=iters)
+        if want_z:
+            out["z"] = z
+        return out
+
+    # -- B1: linear_solve!(solver, Delta, R, r) -----------------------------------------------
+    def kkt_solve(self, r, beta):
+        r = _f64(r, (self.B, self.N))
+        delta = np.zeros_like(r)
+        self._check(self.lib.cimpc_kkt_solve(self.h, _dp(r), float(beta), _dp(delta)), "kkt_solve")
+        return delta
+
+    # -- B4: newton_solve! ----------------------------------------------------------------------
+    def newton_solve(self, q0, q1, warm_start=False):
+        """newton_solve!(core, s, q0, q1, window, im_traj, ref_traj; warm_start).
+        Returns (u1 (B,nu), newton_iters (B,), r_norm (B,))."""
+        q0 = _f64(q0, (self.B, self.nq)); q1 = _f64(q1, (self.B, self.nq))
+        u1 = np.zeros((self.B, self.nu)); it = np.zeros(self.B, dtype=np.int32); rn = np.zeros(self.B)
+        self._check(self.lib.cimpc_newton_solve(self.h, _dp(q0), _dp(q1), int(bool(warm_start)),
+                                                _dp(u1), _ipt(it), _dp(rn)), "newton_solve")
+        return u1, it, rn
+
+    def newton_solve_dev(self, q0_ptr, q1_ptr, warm_start=False):
+        """Same, q0/q1 already in device memory (raw pointers, e.g. torch_tensor.data_ptr())."""
+        self._check(self.lib.cimpc_newton_solve_dev(self.h, C.c_void_p(q0_ptr), C.c_void_p(q1_ptr),
+                                                    int(bool(warm_start))), "newton_solve_dev")
+
+    def newton_info(self):
+        u1 = np.zeros((self.B, self.nu)); it = np.zeros(self.B, dtype=np.int32); rn = np.zeros(self.B)
+        self._check(self.lib.cimpc_get_newton_info(self.h, _ipt(it), _dp(rn), _dp(u1)), "get_newton_info")
+        return u1, it, rn
+
+    def trajectory(self):
+        B, H = self.B, self.H
+        q = np.zeros((B, H + 2, self.nq)); u = np.zeros((B, H, self.nu))
+        g = np.zeros((B, H, self.nc)); b = np.zeros((B, H, self.nb)); nu_dual = np.zeros((B, H, self.nd))
+        self._check(self.lib.cimpc_get_trajectory(self.h, _dp(q), _dp(u), _dp(g), _dp(b), _dp(nu_dual)),
+                    "get_trajectory")
+        return dict(q=q, u=u, gamma=g, b=b, nu=nu_dual)
+
+    def rollout_counters(self):
+        sw = np.zeros(self.B, dtype=np.int32); it = np.zeros(self.B, dtype=np.int32)
+        fl = np.zeros(self.B, dtype=np.int32)
+        self._check(self.lib.cimpc_get_rollout_counters(self.h, _ipt(sw), _ipt(it), _ipt(fl)),
+                    "get_rollout_counters")
+        return dict(sweeps=sw, ip_iters=it, ip_failures=fl)
+
+    def stats(self):
+        s = _lib.Stats()
+        self._check(self.lib.cimpc_get_stats(self.h, C.byref(s)), "get_stats")
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    # -- measurement ----------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self.lib.cimpc_profile_enable(self.h, int(on)), "profile_enable")
+
+    def profile_reset(self):
+        self._check(self.lib.cimpc_profile_reset(self.h), "profile_reset")
+
+    def profile_read(self):
+        p = _lib.Profile()
+        self._check(self.lib.cimpc_profile_read(self.h, C.byref(p)), "profile_read")
+        return {k: getattr(p, k) for k, _ in p._fields_}
+
+    def query_sizes(self):
+        a = C.c_int(); b = C.c_int()
+        self._check(self.lib.cimpc_query_sizes(self.h, C.byref(a), C.byref(b)), "query_sizes")
+        return a.value, b.value

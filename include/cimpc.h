@@ -1,0 +1,184 @@
+/*
+ * cimpc.h - C ABI of the MI355X (gfx950) contact-implicit MPC solver core.
+ *
+ * Drop-in boundary for the per-MPC-step solver path of dojo-sim/ContactImplicitMPC.jl
+ * (reference checkout: /root/reference, v0.2.0).  Each entry point replaces one of the
+ * reference's plugin seams; a Julia host binds them with `ccall`
+ * (see INTEGRATION.md).  Conventions:
+ *   - C linkage, no exceptions cross the boundary, every function returns an int status
+ *     (CIMPC_OK = 0, negative = error; cimpc_last_error() gives the message);
+ *   - fp64 everywhere, matrices COLUMN-MAJOR (Julia layout), indices in `window` are
+ *     1-BASED reference-knot indices exactly as the reference passes them;
+ *   - pointers are caller-owned HOST memory unless the name ends in `_dev`; the library
+ *     never retains a host pointer past the call;
+ *   - one handle per GPU, one caller thread per handle;
+ *   - batched: every per-trajectory array carries a leading rollout dimension B
+ *     (B = 1 reproduces the reference's single-trajectory calls).
+ *
+ * There is NO CPU fallback: creating a handle without a usable gfx950 device fails with
+ * CIMPC_ERR_NO_DEVICE.
+ */
+#ifndef CIMPC_H
+#define CIMPC_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CIMPC_OK 0
+#define CIMPC_ERR_INVALID (-1)     /* bad argument / unsupported dimensions            */
+#define CIMPC_ERR_NO_DEVICE (-2)   /* no HIP device / not gfx950 / HIP runtime failure */
+#define CIMPC_ERR_STATE (-3)       /* call order violated (e.g. tables not set)        */
+#define CIMPC_ERR_HIP (-4)         /* a HIP call failed; see cimpc_last_error          */
+
+#define CIMPC_MODE_CONFIGURATION 0       /* mode = :configuration      (nd = nq)        */
+#define CIMPC_MODE_CONFIGURATIONFORCE 1  /* mode = :configurationforce (nd = nq+nc+nb)  */
+
+#define CIMPC_KKT_CONDENSED 0  /* dual Schur complement + block Cholesky (structure of
+                                  newton_structure_solver/methods.jl:386-557)            */
+
+typedef struct cimpc_ctx* cimpc_handle;
+
+/* Model / problem sizes.  nb = nc * friction_dim(env)  (src/simulation/index.jl:371-384). */
+typedef struct cimpc_dims {
+    int nq, nu, nw, nc, nb;
+    int mode;   /* CIMPC_MODE_* ; ImplicitTrajectory(...; mode) implicit_dynamics.jl:21-50   */
+    int H_ref;  /* number of reference knots (linearizations), ref_traj.H                   */
+    int H;      /* MPC horizon H_mpc (policy.jl:43)                                          */
+    int B;      /* rollouts solved together (Monte-Carlo batch); 1 = reference behaviour    */
+} cimpc_dims;
+
+/* RoboDojo InteriorPointOptions fields used on the path (policy.jl:54-61). */
+typedef struct cimpc_ip_opts {
+    double r_tol;      /* 1e-8  */
+    double kappa_tol;  /* kappa_mpc, 2e-4 */
+    double undercut;   /* 5.0   */
+    double gamma_reg;  /* 0.1   */
+    double kappa_reg;  /* 1e-3  */
+    double eps_min;    /* 0.05  */
+    double ls_scale;   /* 0.5   */
+    int max_iter;      /* 100   */
+    int max_ls;        /* 3     */
+} cimpc_ip_opts;
+
+/* NewtonOptions (newton.jl:2-11) + the central-path parameter used for the dual
+ * regularisation (im_traj.ip[t].kappa[1], newton_jacobian.jl:185). */
+typedef struct cimpc_newton_opts {
+    double r_tol;      /* 3e-4 in policy.jl:48-52 */
+    double beta_init;  /* 1e-5 */
+    double max_time;   /* seconds; <=0 = unlimited (newton.jl:187-277 budget)              */
+    double kappa;      /* kappa_mpc */
+    int max_iter;      /* 5 */
+    int kkt_backend;   /* CIMPC_KKT_* */
+} cimpc_newton_opts;
+
+typedef struct cimpc_stats {
+    long long newton_iters;  /* sum over rollouts of Newton iterations l (newton.jl:202)      */
+    long long sweeps;        /* sum over rollouts of implicit_dynamics! evaluations           */
+    long long ip_solves;     /* interior-point solves executed                                */
+    long long ip_iters;      /* sum of interior-point iterations                              */
+    long long ip_failures;   /* solves that returned status = false                           */
+    long long rounds;        /* lock-step rounds (kernel launch groups) of the last solve     */
+} cimpc_stats;
+
+/* Per-kernel-class device time measured with HIP events on the library's stream. */
+typedef struct cimpc_profile {
+    double ip_sweep_ms;  long long ip_sweep_launches;  long long ip_sweep_problems;
+    double kkt_ms;       long long kkt_launches;       long long kkt_systems;
+    double resid_ms;     long long resid_launches;
+    double other_ms;     long long other_launches;
+} cimpc_profile;
+
+void cimpc_default_ip_opts(cimpc_ip_opts* o);
+void cimpc_default_newton_opts(cimpc_newton_opts* o);
+const char* cimpc_last_error(cimpc_handle h); /* h may be NULL: last create error */
+int cimpc_version(void);
+
+/* ---- lifetime ----------------------------------------------------------------------- */
+int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_newton_opts* nt,
+                 int device, cimpc_handle* out);
+int cimpc_destroy(cimpc_handle h);
+/* Use an externally owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
+int cimpc_set_stream(cimpc_handle h, void* hip_stream);
+int cimpc_synchronize(cimpc_handle h);
+
+/* ---- A1: linearization of reference knot t (1-based) -------------------------------- */
+/* Replaces LinearizedStep + RLin/RZLin/RthLin construction (linearized_step.jl:10-31,
+ * linearized_solver.jl:67-161,224-304,325-359) and set_implicit_trajectory!
+ * (implicit_dynamics.jl:128-139): splits (z0, th0, r0, rz0, rth0) into the constant blocks,
+ * precomputes inv(Dx), Rx*inv(Dx), Rx*inv(Dx)*Dy1 (schur.jl:39-41) and uploads the packed
+ * table.  rz0 is nz x nz, rth0 is nz x nth, both column-major. */
+int cimpc_set_linearization(cimpc_handle h, int t, const double* z0, const double* th0,
+                            const double* r0, const double* rz0, const double* rth0);
+
+/* ---- objective (objective.jl:3-47), per horizon step, shared by all rollouts --------- */
+/* Q: H x (nq x nq), R: H x (nu x nu), Cg: H x (nc x nc), Cb: H x (nb x nb) (may be NULL in
+ * :configuration mode).  V / q_target / v_target: TrackingVelocityObjective terms, NULL for
+ * a TrackingObjective. */
+int cimpc_set_objective(cimpc_handle h, const double* Q, const double* R, const double* Cg,
+                        const double* Cb, const double* V, const double* q_target,
+                        const double* v_target);
+
+/* RLin.alt (set_altitude!, implicit_dynamics.jl:141-154): B x nc, NULL = zeros. */
+int cimpc_set_altitude(cimpc_handle h, const double* alt);
+
+/* window: B x (H+2) 1-based reference-knot indices (policy.jl:154-171). */
+int cimpc_set_window(cimpc_handle h, const int* window);
+
+/* The `ref_traj` argument of newton_solve! (policy.jl:119-120 passes p.traj, already
+ * rotated to the window): q_ref B x (H+2) x nq, u_ref B x H x nu, w_ref B x H x nw,
+ * gamma_ref B x H x nc, b_ref B x H x nb, theta_ref B x H x nth. */
+int cimpc_set_reference(cimpc_handle h, const double* q_ref, const double* u_ref,
+                        const double* w_ref, const double* gamma_ref, const double* b_ref,
+                        const double* theta_ref);
+
+/* ---- B3: implicit_dynamics!(im_traj, traj; window) (implicit_dynamics.jl:156-192) --- */
+/* in : q B x (H+2) x nq, theta B x H x nth, gamma B x H x nc, b B x H x nb (cf mode only)
+ * out: d B x H x nd, dz B x H x (nd x (2nq+nu)) column-major = [dq0 | dq1 | du1]
+ *      (the views of implicit_dynamics.jl:84-86), status B x H (1 = converged),
+ *      iters B x H, z B x H x nz (may be NULL). */
+int cimpc_implicit_dynamics(cimpc_handle h, const double* q, const double* theta,
+                            const double* gamma, const double* b, double* d, double* dz,
+                            int* status, int* iters, double* z);
+
+/* ---- B1: linear_solve!(core.solver, Delta.r, jac.R, res.r) (newton.jl:218) ---------- */
+/* Solves R*Delta = r for every rollout, R assembled on the device from the sensitivities of
+ * the LAST sweep exactly as jacobian! does (newton_jacobian.jl:148-198) with dual
+ * regularisation rho = H*beta*kappa.  r, delta: B x N, N = H*(nr+nd), reference layout
+ * (newton_residual.jl:69-98). */
+int cimpc_kkt_solve(cimpc_handle h, const double* r, double beta, double* delta);
+
+/* ---- B4: newton_solve!(core, s, q0, q1, window, im_traj, ref_traj; warm_start) ------- */
+/* q0, q1: B x nq.  Requires set_linearization (all knots), set_objective, set_window,
+ * set_reference.  Outputs (any may be NULL): u1 B x nu = core.traj.u[1] (policy.jl:142),
+ * newton_iters B, r_norm B (|r|_1 / N at exit). */
+int cimpc_newton_solve(cimpc_handle h, const double* q0, const double* q1, int warm_start,
+                       double* u1, int* newton_iters, double* r_norm);
+/* Same with q0/q1 already resident in device memory (B x nq each); nothing is copied back.
+ * This is the entry the benchmark times. */
+int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q1_dev,
+                           int warm_start);
+
+/* ---- results of the last newton solve ----------------------------------------------- */
+/* core.traj: q B x (H+2) x nq, u B x H x nu, gamma B x H x nc, b B x H x nb; nu_dual B x H x nd.
+ * Any pointer may be NULL. */
+int cimpc_get_trajectory(cimpc_handle h, double* q, double* u, double* gamma, double* b,
+                         double* nu_dual);
+int cimpc_get_newton_info(cimpc_handle h, int* newton_iters, double* r_norm, double* u1);
+int cimpc_get_stats(cimpc_handle h, cimpc_stats* s);
+/* per rollout, last newton solve: implicit_dynamics! evaluations, sum of IP iterations
+ * ("solver iterations to tolerance"), failed IP solves.  Each B ints; any may be NULL. */
+int cimpc_get_rollout_counters(cimpc_handle h, int* sweeps, int* ip_iters, int* ip_failures);
+
+/* ---- measurement -------------------------------------------------------------------- */
+int cimpc_profile_enable(cimpc_handle h, int on);  /* HIP-event timing of every launch */
+int cimpc_profile_reset(cimpc_handle h);
+int cimpc_profile_read(cimpc_handle h, cimpc_profile* p);
+/* size in doubles of one packed linearization table and of the per-problem IP I/O
+ * (algorithmic-bytes bookkeeping for the roofline) */
+int cimpc_query_sizes(cimpc_handle h, int* table_doubles, int* N_kkt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CIMPC_H */

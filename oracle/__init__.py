@@ -1,0 +1,21 @@
+"""CPU oracle for the ContactImplicitMPC.jl per-MPC-step solver path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product path
+(`contactimplicitmpc/jl_amd`, `include/`, the HIP library) may import, link or
+execute anything under `oracle/`.  Allowed importers: `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg - and there only
+as the checker / the timed CPU baseline, never as the thing shipped.
+
+Parity status (see DESIGN.md section "Oracle"):
+  * reference-side callbacks (rlin!, rzlin!, Schur/MGS-QR, linear_solve!,
+    sensitivities) and the Newton layer (residual!, jacobian!, update_traj!,
+    newton_solve!) follow `/root/reference/src` line by line and are pinned by
+    re-running the reference's own test constructions
+    (tests/test_oracle_reference_constructions.py).
+  * the interior-point iteration itself lives in RoboDojo.jl 0.1.3, which is
+    NOT present under /root/reference and cannot be executed here (no Julia):
+    **IP iterate-level parity: unpinned** - the loop in `ip.py` is
+    build-defined, modelled on RoboDojo 0.1.3, pinned only at the level the
+    reference's tests pin it (converged answer to tolerance).
+"""
+from .dims import Dims  # noqa: F401

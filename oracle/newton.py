@@ -1,0 +1,429 @@
+"""Horizon Newton / KKT layer: CPU restatement (numpy, fp64); test infrastructure only.
+
+Follows:
+  src/controller/trajectory.jl:21-82        ContactTraj, update_z!/update_theta!
+  src/controller/objective.jl:1-47          TrackingObjective / TrackingVelocityObjective
+  src/controller/newton_residual.jl:18-98   residual layout (views)
+                                 :113-138   residual!
+                                 :140-176   update_traj!
+                                 :178-281   gradient! (4 variants)
+  src/controller/newton_jacobian.jl:24-134  KKT matrix layout (views)
+                                 :148-198   initialize_jacobian!/update_jacobian!/jacobian!
+                                 :200-248   hessian! (4 variants)
+  src/controller/newton.jl:130-167          reset!
+                          :169-288          newton_solve!
+  src/solver/lu.jl:4-12                     default KKT backend = dense LU of Array(R)
+  src/controller/newton_structure_solver/methods.jl:386-557  condensed solve (kkt_solve_condensed)
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import ip as ipm
+from .dims import Dims, MODE_CONFIGURATION, MODE_CONFIGURATIONFORCE
+
+
+# ----------------------------------------------------------------------------
+# containers
+# ----------------------------------------------------------------------------
+@dataclass
+class Traj:
+    """ContactTraj (trajectory.jl:1-49) restricted to what the path reads."""
+    q: np.ndarray       # (H+2, nq)
+    u: np.ndarray       # (H, nu)
+    w: np.ndarray       # (H, nw)
+    gamma: np.ndarray   # (H, nc)
+    b: np.ndarray       # (H, nb)
+    theta: np.ndarray   # (H, nth)
+
+    @property
+    def H(self):
+        return self.u.shape[0]
+
+    def copy(self):
+        return Traj(*(a.copy() for a in (self.q, self.u, self.w, self.gamma, self.b, self.theta)))
+
+    def update_theta(self, dims: Dims, t=None):
+        """update_theta!, trajectory.jl:67-82 (0-based t; None = all)."""
+        ts = range(self.H) if t is None else [t]
+        for k in ts:
+            if 0 <= k < self.H:
+                self.theta[k, dims.iq0] = self.q[k]
+                self.theta[k, dims.iq1] = self.q[k + 1]
+                self.theta[k, dims.iu1] = self.u[k]
+                self.theta[k, dims.iw1] = self.w[k]
+
+
+def copy_traj(dst: Traj, src: Traj, H):
+    """copy_traj!, newton.jl:105-128 (first H steps)."""
+    dst.q[:H + 2] = src.q[:H + 2]
+    dst.u[:H] = src.u[:H]
+    dst.w[:H] = src.w[:H]
+    dst.gamma[:H] = src.gamma[:H]
+    dst.b[:H] = src.b[:H]
+    dst.theta[:H] = src.theta[:H]
+
+
+@dataclass
+class Objective:
+    """objective.jl:3-47.  q/u/gamma/b: per-step square matrices (dense allowed).
+    velocity objective iff v is not None."""
+    q: np.ndarray                      # (H, nq, nq)
+    u: np.ndarray                      # (H, nu, nu)
+    gamma: np.ndarray = None           # (H, nc, nc)
+    b: np.ndarray = None               # (H, nb, nb)
+    v: np.ndarray = None               # (H, nq, nq) or None
+    v_target: np.ndarray = None        # (H, nq)
+    q_target: np.ndarray = None        # (H, nq)
+
+    def __post_init__(self):
+        if self.v is not None:
+            H, nq = self.q.shape[0], self.q.shape[1]
+            if self.v_target is None:
+                self.v_target = np.zeros((H, nq))
+            if self.q_target is None:     # objective.jl:36-45
+                if np.any(self.v_target != 0.0):
+                    qt = np.zeros((H, nq))
+                    for t in range(1, H):
+                        qt[t] = qt[t - 1] + self.v_target[t - 1]
+                    self.q_target = qt
+                else:
+                    self.q_target = np.zeros((H, nq))
+
+
+@dataclass
+class NewtonOptions:
+    """newton.jl:2-11 (+ policy.jl:48-52 defaults)."""
+    r_tol: float = 1.0e-5
+    max_iter: int = 10
+    beta_init: float = 1.0e-5
+    solver: str = "lu"        # "lu" (reference default, dense) | "condensed"
+
+
+@dataclass
+class NewtonStats:
+    iters: int = 0
+    sweeps: int = 0
+    ip_iters: int = 0
+    ip_fail: int = 0
+    r_norm: float = 0.0
+    alphas: list = field(default_factory=list)
+
+
+# ----------------------------------------------------------------------------
+# layout helpers (0-based)
+# ----------------------------------------------------------------------------
+class Layout:
+    """Offsets inside one primal block [u | (gamma | b) | q2] and the dual segment.
+    newton_residual.jl:18-54 / 69-98, newton_jacobian.jl:24-70 / 93-134."""
+
+    def __init__(self, dims: Dims, H: int):
+        d = dims
+        self.dims, self.H = d, H
+        self.nr, self.nd = d.nr, d.nd
+        self.N = H * (d.nr + d.nd)
+        off = 0
+        self.iu = np.arange(off, off + d.nu); off += d.nu
+        if d.mode == MODE_CONFIGURATIONFORCE:
+            self.ig = np.arange(off, off + d.nc); off += d.nc
+            self.ib = np.arange(off, off + d.nb); off += d.nb
+        else:
+            self.ig = np.arange(0, 0)
+            self.ib = np.arange(0, 0)
+        self.iq = np.arange(off, off + d.nq); off += d.nq
+        self.iz = np.concatenate([self.iq, self.ig, self.ib])    # [q2, gamma1, b1]
+
+    def pu(self, i):
+        return i * self.nr + self.iu
+
+    def pg(self, i):
+        return i * self.nr + self.ig
+
+    def pb(self, i):
+        return i * self.nr + self.ib
+
+    def pq(self, i):
+        return i * self.nr + self.iq
+
+    def pz(self, i):
+        return i * self.nr + self.iz
+
+    def dual(self, i):
+        return self.H * self.nr + i * self.nd + np.arange(self.nd)
+
+
+# ----------------------------------------------------------------------------
+# residual! / gradient!
+# ----------------------------------------------------------------------------
+def gradient(lay: Layout, obj: Objective, traj: Traj, ref: Traj, r):
+    """gradient!, newton_residual.jl:178-281."""
+    d = lay.dims
+    H = lay.H
+    vel = obj.v is not None
+    for t in range(H):
+        dq = traj.q[t + 2] - (ref.q[t + 2] + (obj.q_target[t] if vel else 0.0))
+        du = traj.u[t] - ref.u[t]
+        r[lay.pq(t)] += obj.q[t] @ dq
+        r[lay.pu(t)] += obj.u[t] @ du
+        if d.mode == MODE_CONFIGURATIONFORCE:
+            r[lay.pg(t)] += obj.gamma[t] @ (traj.gamma[t] - ref.gamma[t])
+            r[lay.pb(t)] += obj.b[t] @ (traj.b[t] - ref.b[t])
+        if vel:
+            r[lay.pq(t)] += obj.v[t] @ traj.q[t + 2]
+            r[lay.pq(t)] -= obj.v[t] @ traj.q[t + 1]
+            if d.mode == MODE_CONFIGURATION:      # v_target only in the configuration variant (:264,:270)
+                r[lay.pq(t)] -= obj.v[t] @ obj.v_target[t]
+            if t == 0:
+                continue
+            r[lay.pq(t - 1)] -= obj.v[t] @ traj.q[t + 2]
+            r[lay.pq(t - 1)] += obj.v[t] @ traj.q[t + 1]
+            if d.mode == MODE_CONFIGURATION:
+                r[lay.pq(t - 1)] += obj.v[t] @ obj.v_target[t]
+
+
+def residual(lay: Layout, obj: Objective, nu_dual, im, traj: Traj, ref: Traj):
+    """residual!, newton_residual.jl:113-138.  `im` = implicit_dynamics output dict
+    (already indexed by horizon position i; the reference indexes by knot t = window[i])."""
+    r = np.zeros(lay.N)
+    gradient(lay, obj, traj, ref, r)
+    for i in range(lay.H):
+        if i >= 2:
+            r[lay.pq(i - 2)] += im["dq0"][i].T @ nu_dual[i]
+        if i >= 1:
+            r[lay.pq(i - 1)] += im["dq1"][i].T @ nu_dual[i]
+        r[lay.pu(i)] += im["du1"][i].T @ nu_dual[i]
+        r[lay.dual(i)] += im["d"][i]
+        r[lay.pz(i)] -= nu_dual[i]
+    return r
+
+
+# ----------------------------------------------------------------------------
+# jacobian!
+# ----------------------------------------------------------------------------
+def jacobian(lay: Layout, obj: Objective, im, beta, kappa):
+    """jacobian! = initialize_jacobian! + update_jacobian! (newton_jacobian.jl:148-198),
+    dense N x N.  Dual regularisation quirk: reg_du -= beta*kappa once per window
+    step, i.e. the whole dual diagonal ends at -H*beta*kappa (:169-186)."""
+    d = lay.dims
+    H, N = lay.H, lay.N
+    R = np.zeros((N, N))
+    vel = obj.v is not None
+    for t in range(H):                                          # hessian! :200-248
+        R[np.ix_(lay.pq(t), lay.pq(t))] += obj.q[t]
+        R[np.ix_(lay.pu(t), lay.pu(t))] += obj.u[t]
+        if d.mode == MODE_CONFIGURATIONFORCE:
+            R[np.ix_(lay.pg(t), lay.pg(t))] += obj.gamma[t]
+            R[np.ix_(lay.pb(t), lay.pb(t))] += obj.b[t]
+        if vel:
+            R[np.ix_(lay.pq(t), lay.pq(t))] += obj.v[t]
+            if t == 0:
+                continue
+            R[np.ix_(lay.pq(t - 1), lay.pq(t - 1))] += obj.v[t]
+            R[np.ix_(lay.pq(t - 1), lay.pq(t))] -= obj.v[t]
+            R[np.ix_(lay.pq(t), lay.pq(t - 1))] -= obj.v[t]
+    for t in range(H):                                          # IV / ITV :157-161
+        R[lay.pz(t), lay.dual(t)] -= 1.0
+        R[lay.dual(t), lay.pz(t)] -= 1.0
+    for i in range(H):                                          # update_jacobian! :166-189
+        if i >= 2:
+            R[np.ix_(lay.dual(i), lay.pq(i - 2))] += im["dq0"][i]
+            R[np.ix_(lay.pq(i - 2), lay.dual(i))] += im["dq0"][i].T
+        if i >= 1:
+            R[np.ix_(lay.dual(i), lay.pq(i - 1))] += im["dq1"][i]
+            R[np.ix_(lay.pq(i - 1), lay.dual(i))] += im["dq1"][i].T
+        R[np.ix_(lay.dual(i), lay.pu(i))] += im["du1"][i]
+        R[np.ix_(lay.pu(i), lay.dual(i))] += im["du1"][i].T
+        idx = np.arange(H * lay.nr, N)
+        R[idx, idx] -= beta * kappa
+    return R
+
+
+# ----------------------------------------------------------------------------
+# KKT solves
+# ----------------------------------------------------------------------------
+def kkt_solve_lu(R, r):
+    """Reference default `:lu_solver` (newton.jl:10, lu.jl:4-12): dense LU with
+    partial pivoting of the densified matrix."""
+    return np.linalg.solve(R, r)
+
+
+def kkt_solve_condensed(lay: Layout, obj: Objective, im, beta, kappa, r):
+    """Structure-exploiting solve of the SAME system R*Delta = r (result-equivalent
+    to kkt_solve_lu): eliminate the primal block P (block diagonal when there is no
+    velocity objective) and factor the dual Schur complement
+        Y = C P^-1 C^T + rho I   (block penta-diagonal, nd x nd blocks)
+    by block Cholesky - the condensing of newton_structure_solver/methods.jl:386-557
+    (Y = C S^-1 C^T, compute_L!, compute_beta!, compute_y!, compute_Dnu!, compute_Dz!)
+    applied to the :direct layout of newton_jacobian.jl.  Requires
+    mode == :configuration and a TrackingObjective (P block diagonal, P > 0)."""
+    d = lay.dims
+    assert d.mode == MODE_CONFIGURATION and obj.v is None
+    H, nq, nu, nd = lay.H, d.nq, d.nu, d.nd
+    rho = H * beta * kappa
+    Qi = [np.linalg.inv(obj.q[t]) for t in range(H)]
+    Ri = [np.linalg.inv(obj.u[t]) for t in range(H)]
+    rp_u = [r[lay.pu(i)] for i in range(H)]
+    rp_q = [r[lay.pq(i)] for i in range(H)]
+    rd = [r[lay.dual(i)] for i in range(H)]
+    # Row block i of C: [du1_i @ u_i, -I @ q_{i+2}(blk i), dq1_i @ blk i-1, dq0_i @ blk i-2]
+    Y = np.zeros((H, 3, nd, nd))     # Y[i,0]=Y_ii, Y[i,1]=Y_{i,i-1}, Y[i,2]=Y_{i,i-2}
+    bet = np.zeros((H, nd))
+    for i in range(H):
+        A0 = im["du1"][i]
+        Yii = A0 @ Ri[i] @ A0.T + Qi[i] + rho * np.eye(nd)
+        bi = A0 @ (Ri[i] @ rp_u[i]) - Qi[i] @ rp_q[i] - rd[i]
+        if i >= 1:
+            A1 = im["dq1"][i]
+            Yii += A1 @ Qi[i - 1] @ A1.T
+            bi += A1 @ (Qi[i - 1] @ rp_q[i - 1])
+            Y[i, 1] = -A1 @ Qi[i - 1]                   # (dq1_i)(Q^-1)(-I)^T of row i-1
+        if i >= 2:
+            A2 = im["dq0"][i]
+            Yii += A2 @ Qi[i - 2] @ A2.T
+            bi += A2 @ (Qi[i - 2] @ rp_q[i - 2])
+            Y[i, 1] += A2 @ Qi[i - 2] @ im["dq1"][i - 1].T
+            Y[i, 2] = -A2 @ Qi[i - 2]
+        Y[i, 0] = Yii
+        bet[i] = bi
+    # block Cholesky of the block-pentadiagonal SPD matrix Y = L L^T
+    L0 = np.zeros((H, nd, nd)); L1 = np.zeros((H, nd, nd)); L2 = np.zeros((H, nd, nd))
+    for i in range(H):
+        if i >= 2:
+            L2[i] = np.linalg.solve(L0[i - 2], Y[i, 2].T).T          # Y_{i,i-2} L_{i-2,i-2}^-T
+        if i >= 1:
+            M = Y[i, 1].copy()
+            if i >= 2:
+                M -= L2[i] @ L1[i - 1].T
+            L1[i] = np.linalg.solve(L0[i - 1], M.T).T
+        D = Y[i, 0].copy()
+        if i >= 1:
+            D -= L1[i] @ L1[i].T
+        if i >= 2:
+            D -= L2[i] @ L2[i].T
+        L0[i] = np.linalg.cholesky(D)
+    yv = np.zeros((H, nd))
+    for i in range(H):
+        v = bet[i].copy()
+        if i >= 1:
+            v -= L1[i] @ yv[i - 1]
+        if i >= 2:
+            v -= L2[i] @ yv[i - 2]
+        yv[i] = np.linalg.solve(L0[i], v)
+    dnu = np.zeros((H, nd))
+    for i in range(H - 1, -1, -1):
+        v = yv[i].copy()
+        if i + 1 < H:
+            v -= L1[i + 1].T @ dnu[i + 1]
+        if i + 2 < H:
+            v -= L2[i + 2].T @ dnu[i + 2]
+        dnu[i] = np.linalg.solve(L0[i].T, v)
+    # primal recovery  Delta_x = P^-1 (r_p - C^T dnu)
+    Delta = np.zeros(lay.N)
+    for i in range(H):
+        Delta[lay.pu(i)] = Ri[i] @ (rp_u[i] - im["du1"][i].T @ dnu[i])
+        cq = -dnu[i].copy()
+        if i + 1 < H:
+            cq += im["dq1"][i + 1].T @ dnu[i + 1]
+        if i + 2 < H:
+            cq += im["dq0"][i + 2].T @ dnu[i + 2]
+        Delta[lay.pq(i)] = Qi[i] @ (rp_q[i] - cq)
+        Delta[lay.dual(i)] = dnu[i]
+    return Delta
+
+
+# ----------------------------------------------------------------------------
+# update_traj! / reset! / newton_solve!
+# ----------------------------------------------------------------------------
+def update_traj(lay: Layout, cand: Traj, traj: Traj, nu_cand, nu_dual, Delta, alpha):
+    """update_traj!, newton_residual.jl:140-176 (x <- x - alpha*Delta) + update_theta!."""
+    d = lay.dims
+    for t in range(lay.H):
+        cand.q[t + 2] = traj.q[t + 2] - alpha * Delta[lay.pq(t)]
+        cand.u[t] = traj.u[t] - alpha * Delta[lay.pu(t)]
+        if d.mode == MODE_CONFIGURATIONFORCE:
+            cand.gamma[t] = traj.gamma[t] - alpha * Delta[lay.pg(t)]
+            cand.b[t] = traj.b[t] - alpha * Delta[lay.pb(t)]
+        nu_cand[t] = nu_dual[t] - alpha * Delta[lay.dual(t)]
+    cand.update_theta(d)
+
+
+class Newton:
+    """Newton (newton.jl:17-91): workspace of one rollout."""
+
+    def __init__(self, dims: Dims, H: int, obj: Objective, opts: NewtonOptions,
+                 ip_opts: ipm.IPOptions, kappa: float, template: Traj):
+        self.dims, self.H, self.obj, self.opts, self.ip_opts = dims, H, obj, opts, ip_opts
+        self.kappa = kappa
+        self.lay = Layout(dims, H)
+        z = lambda *s: np.zeros(s)
+        self.traj = Traj(z(H + 2, dims.nq), z(H, dims.nu), z(H, dims.nw), z(H, dims.nc),
+                         z(H, dims.nb), template.theta[:H].copy())
+        self.traj_cand = self.traj.copy()
+        self.nu = z(H, dims.nd)
+        self.nu_cand = z(H, dims.nd)
+        self.beta = opts.beta_init
+        self.im = None
+        self.Delta = z(self.lay.N)
+        self.res = z(self.lay.N)
+
+    def reset(self, ref: Traj, q0, q1, warm_start):
+        """reset!, newton.jl:130-167."""
+        self.beta = self.opts.beta_init
+        if not warm_start:
+            self.nu[:] = 0.0
+            self.nu_cand[:] = 0.0
+            copy_traj(self.traj, ref, self.H)
+        self.traj.q[0] = q0
+        self.traj.q[1] = q1
+        self.traj.update_theta(self.dims, 0)
+        self.traj.update_theta(self.dims, 1)
+        copy_traj(self.traj_cand, self.traj, self.H)
+
+    def _sweep(self, tables, window, traj: Traj, stats: NewtonStats):
+        im = ipm.implicit_dynamics(self.dims, tables, window, traj.q, traj.theta, self.ip_opts,
+                                   gamma=traj.gamma, b=traj.b, prev=self.im)
+        stats.sweeps += 1
+        stats.ip_iters += int(im["iters"].sum())
+        stats.ip_fail += int((im["status"] == 0).sum())
+        return im
+
+
+def newton_solve(core: Newton, q0, q1, window, tables, ref: Traj, warm_start=False):
+    """newton_solve!, newton.jl:169-288 (time budget omitted: max_time = inf).
+    Returns NewtonStats; result in core.traj / core.nu."""
+    lay, opts, obj = core.lay, core.opts, core.obj
+    st = NewtonStats()
+    core.reset(ref, q0, q1, warm_start)
+    core.im = core._sweep(tables, window, core.traj, st)                         # :191
+    core.res = residual(lay, obj, core.nu, core.im, core.traj, ref)              # :197
+    r_norm = np.sum(np.abs(core.res))                                            # :198
+    for _ in range(opts.max_iter):                                               # :202
+        if r_norm / lay.N < opts.r_tol:                                          # :206
+            break
+        st.iters += 1
+        if opts.solver == "lu":
+            R = jacobian(lay, obj, core.im, core.beta, core.kappa)               # :210
+            core.Delta = kkt_solve_lu(R, core.res)                               # :218
+        else:
+            core.Delta = kkt_solve_condensed(lay, obj, core.im, core.beta, core.kappa, core.res)
+        alpha, it = 1.0, 0
+        update_traj(lay, core.traj_cand, core.traj, core.nu_cand, core.nu, core.Delta, alpha)
+        core.im = core._sweep(tables, window, core.traj_cand, st)                # :234
+        res_cand = residual(lay, obj, core.nu_cand, core.im, core.traj_cand, ref)
+        r_cand = np.sum(np.abs(res_cand))
+        while r_cand ** 2.0 >= (1.0 - 0.001 * alpha) * r_norm ** 2.0:            # :245
+            alpha *= 0.5
+            it += 1
+            if it > 6:
+                break
+            update_traj(lay, core.traj_cand, core.traj, core.nu_cand, core.nu, core.Delta, alpha)
+            core.im = core._sweep(tables, window, core.traj_cand, st)
+            res_cand = residual(lay, obj, core.nu_cand, core.im, core.traj_cand, ref)
+            r_cand = np.sum(np.abs(res_cand))
+        update_traj(lay, core.traj, core.traj, core.nu, core.nu, core.Delta, alpha)   # :273
+        core.res = res_cand
+        r_norm = r_cand
+        st.alphas.append(alpha)
+        core.beta = min(core.beta * 1.3, 1.0e2) if it > 6 else max(1.0e1, core.beta / 1.3)  # :280
+    st.r_norm = float(r_norm)
+    return st

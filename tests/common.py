@@ -1,0 +1,53 @@
+"""Shared helpers of the parity tests: build the SAME seeded synthetic problem for the CPU
+oracle (oracle/) and for the HIP library (through the C ABI)."""
+import numpy as np
+
+from oracle import ip as oip
+from oracle import lcp, newton as onewton, synth
+from oracle.dims import Dims, QUADRUPED, HOPPER_2D, PUSHBOT, CENTROIDAL  # noqa: F401
+
+MODELS = dict(quadruped=QUADRUPED, hopper=HOPPER_2D, pushbot=PUSHBOT, centroidal=CENTROIDAL)
+
+
+def make_case(model="quadruped", mode=0, H_ref=12, H=6, B=3, seed=0, perturb=2e-2, kappa=2e-4):
+    d = Dims(**MODELS[model], mode=mode)
+    prob = synth.make_problem(d, H_ref, seed=seed, kappa=kappa)
+    tabs = [lcp.LinTable(d, prob["z0"][t], prob["th0"][t], prob["r0"][t], prob["rz0"][t], prob["rth0"][t])
+            for t in range(H_ref)]
+    rollouts = []
+    rng = np.random.default_rng(seed + 1000)
+    for b in range(B):
+        phase = int(rng.integers(0, H_ref))
+        rollouts.append(synth.make_rollout(d, prob, H, phase=phase, seed=seed * 977 + b, perturb=perturb))
+    return d, prob, tabs, rollouts
+
+
+def make_solver(d, prob, rollouts, H, ip_opts=None, newton_opts=None, obj=None):
+    from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions
+    H_ref = prob["z0"].shape[0]
+    B = len(rollouts)
+    s = CIMPCSolver(d.nq, d.nu, d.nw, d.nc, d.nb, H_ref, H, B=B, mode=d.mode,
+                    ip_opts=ip_opts or InteriorPointOptions(kappa_tol=prob["kappa"]),
+                    newton_opts=newton_opts or NewtonOptions(kappa=prob["kappa"]))
+    for t in range(H_ref):
+        s.set_linearization(t + 1, prob["z0"][t], prob["th0"][t], prob["r0"][t], prob["rz0"][t], prob["rth0"][t])
+    s.set_window(np.stack([w for (w, _, _, _) in rollouts]) + 1)
+    s.set_reference(np.stack([r.q for (_, r, _, _) in rollouts]), np.stack([r.u for (_, r, _, _) in rollouts]),
+                    np.stack([r.w for (_, r, _, _) in rollouts]), np.stack([r.gamma for (_, r, _, _) in rollouts]),
+                    np.stack([r.b for (_, r, _, _) in rollouts]), np.stack([r.theta for (_, r, _, _) in rollouts]))
+    if obj is not None:
+        s.set_objective(obj.q, obj.u, obj.gamma, obj.b)
+    return s
+
+
+def oracle_sweep(d, tabs, rollouts, opts, traj_of=None):
+    """implicit_dynamics! of the oracle for every rollout; evaluates the rollout's reference
+    trajectory with (q0, q1) substituted (the state newton_solve! sweeps first)."""
+    outs = []
+    for (window, ref, q0, q1) in rollouts:
+        tr = ref.copy()
+        tr.q[0], tr.q[1] = q0, q1
+        tr.update_theta(d, 0)
+        tr.update_theta(d, 1)
+        outs.append((tr, oip.implicit_dynamics(d, tabs, window, tr.q, tr.theta, opts, gamma=tr.gamma, b=tr.b)))
+    return outs

@@ -1,0 +1,148 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (fp64): the kernels use the reference's algorithm (Schur complement + MGS-QR,
+same association in rlin!), but reductions run in a different order (DPP trees), divisions
+by the QR diagonal are multiplications by a reciprocal, and the triangular solve runs
+column-oriented.  The Schur matrix reaches cond ~1e6..1e8 near convergence (y2/y1 on the
+diagonal), so iterates agree to ~cond*eps:  converged z to 1e-6 absolute (values O(1)), d to 1e-7, sensitivities
+to 1e-6 relative, identical iteration counts and status flags."""
+import numpy as np
+import pytest
+
+from oracle import ip as oip
+from oracle import newton as onewton, synth
+
+from common import make_case, make_solver, oracle_sweep
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("model,mode,B,H,H_ref", [
+    ("quadruped", 0, 5, 6, 12),
+    ("hopper", 0, 4, 8, 10),
+    ("pushbot", 1, 3, 5, 8),
+    ("quadruped", 1, 3, 4, 8),
+    ("centroidal", 0, 3, 4, 6),
+])
+def test_implicit_dynamics_matches_oracle(gpu_required, model, mode, B, H, H_ref):
+    d, prob, tabs, rollouts = make_case(model, mode, H_ref=H_ref, H=H, B=B, seed=3)
+    opts = oip.IPOptions(kappa_tol=prob["kappa"])
+    s = make_solver(d, prob, rollouts, H)
+    ref = oracle_sweep(d, tabs, rollouts, opts)
+    q = np.stack([tr.q for tr, _ in ref]); th = np.stack([tr.theta for tr, _ in ref])
+    g = np.stack([tr.gamma for tr, _ in ref]); bb = np.stack([tr.b for tr, _ in ref])
+    out = s.implicit_dynamics(q, th, g, bb, want_z=True)
+    for b, (tr, o) in enumerate(ref):
+        assert np.array_equal(out["status"][b], o["status"]), (out["status"][b], o["status"])
+        assert np.array_equal(out["iters"][b], o["iters"]), (out["iters"][b], o["iters"])
+        ok = o["status"] == 1          # failed solves (status = false) only have to agree on the flag
+        assert ok.mean() >= 0.75
+        np.testing.assert_allclose(out["z"][b][ok], o["z"][ok], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(out["d"][b][ok], o["d"][ok], rtol=0, atol=1e-7)
+        for k in ("dq0", "dq1", "du1"):
+            scale = np.abs(o[k]).max()
+            np.testing.assert_allclose(out[k][b][ok], o[k][ok], rtol=0, atol=1e-6 * max(scale, 1.0))
+
+
+def _newton_case(perturb, r_tol, max_iter, seed, B=6, H=10, H_ref=16):
+    d, prob, tabs, rollouts = make_case("quadruped", 0, H_ref=H_ref, H=H, B=B, seed=seed, perturb=perturb)
+    from contactimplicitmpc.jl_amd import NewtonOptions
+    obj = synth.make_objective(d, H)
+    s = make_solver(d, prob, rollouts, H, obj=obj,
+                    newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=r_tol, max_iter=max_iter))
+    u1, it, rn = s.newton_solve(np.stack([r[2] for r in rollouts]), np.stack([r[3] for r in rollouts]))
+    traj = s.trajectory()
+    cnt = s.rollout_counters()
+    res = []
+    for b, (window, ref, q0, q1) in enumerate(rollouts):
+        core = onewton.Newton(d, H, obj, onewton.NewtonOptions(r_tol=r_tol, max_iter=max_iter, solver="lu"),
+                              oip.IPOptions(kappa_tol=prob["kappa"]), prob["kappa"], ref)
+        st = onewton.newton_solve(core, q0, q1, window, tabs, ref)
+        res.append((core, st))
+    return u1, it, rn, traj, cnt, res
+
+
+def test_newton_solve_matches_oracle(gpu_required):
+    """newton_solve! against the oracle running the reference-default dense-LU KKT backend.
+    Moderate perturbation: every rollout converges with mostly full steps."""
+    u1, it, rn, traj, cnt, res = _newton_case(perturb=1e-2, r_tol=1e-5, max_iter=5, seed=11)
+    for b, (core, st) in enumerate(res):
+        assert it[b] == st.iters
+        assert cnt["sweeps"][b] == st.sweeps
+        assert cnt["ip_iters"][b] == st.ip_iters
+        np.testing.assert_allclose(rn[b], st.r_norm / core.lay.N, rtol=1e-6, atol=1e-12)
+        np.testing.assert_allclose(traj["q"][b], core.traj.q, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(traj["u"][b], core.traj.u, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(traj["nu"][b], core.nu, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(u1[b], core.traj.u[0], rtol=0, atol=1e-8)
+
+
+def test_newton_solve_backtracking_regime(gpu_required):
+    """Large perturbation: heavy backtracking, residual at the IP-termination noise floor.
+    Every discrete decision inside an IP solve (iteration count, regularisation switch,
+    line-search back-off) can flip under ~cond*eps roundoff at such candidates, after which a
+    rollout legitimately follows a different path.  Required: identical Newton iteration
+    counts everywhere, and at least half of the rollouts on the oracle's path to 1e-7."""
+    u1, it, rn, traj, cnt, res = _newton_case(perturb=3e-2, r_tol=1e-6, max_iter=4, seed=11)
+    same = 0
+    for b, (core, st) in enumerate(res):
+        assert it[b] == st.iters
+        if np.abs(traj["q"][b] - core.traj.q).max() < 1e-7 and np.abs(traj["u"][b] - core.traj.u).max() < 1e-7:
+            same += 1
+    assert same >= len(res) // 2
+
+
+def test_implicit_dynamics_stress(gpu_required):
+    """Hard interior-point instances (large parameter perturbations): exercises the
+    regularisation switch, the residual line search and failing solves.  Flags and
+    iteration counts must agree on >= 95 % of the solves, and those agree to 1e-6."""
+    from oracle.newton import Traj
+    B, H, H_ref = 16, 8, 10
+    d, prob, tabs, rollouts = make_case("quadruped", 0, H_ref=H_ref, H=H, B=B, seed=21, perturb=0.15)
+    rng = np.random.default_rng(5)
+    hard = []
+    for (window, ref, q0, q1) in rollouts:          # perturb the whole trajectory, not only (q0, q1)
+        tr = ref.copy()
+        tr.q += rng.uniform(-0.05, 0.05, tr.q.shape)
+        tr.u += rng.uniform(-0.5, 0.5, tr.u.shape)
+        tr.update_theta(d)
+        hard.append((window, tr, tr.q[0].copy(), tr.q[1].copy()))
+    opts = oip.IPOptions(kappa_tol=prob["kappa"])
+    s = make_solver(d, prob, hard, H)
+    ref = oracle_sweep(d, tabs, hard, opts)
+    q = np.stack([tr.q for tr, _ in ref]); th = np.stack([tr.theta for tr, _ in ref])
+    out = s.implicit_dynamics(q, th, want_z=True)
+    n = agree = 0
+    for b, (tr, o) in enumerate(ref):
+        for i in range(H):
+            n += 1
+            if out["status"][b, i] == o["status"][i] and out["iters"][b, i] == o["iters"][i]:
+                agree += 1
+                if o["status"][i]:
+                    np.testing.assert_allclose(out["z"][b, i], o["z"][i], rtol=0, atol=1e-6)
+                    np.testing.assert_allclose(out["d"][b, i], o["d"][i], rtol=0, atol=1e-6)
+    assert agree >= 0.95 * n, (agree, n)
+    its = np.concatenate([o["iters"] for _, o in ref])
+    assert its.max() >= 9          # the instances really are harder than the nominal 5-6 iterations
+
+
+def test_kkt_solve_matches_dense_lu(gpu_required):
+    """B1 seam: the condensed device solve against numpy's dense LU of the assembled R
+    (the reference default :lu_solver)."""
+    H, H_ref, B = 8, 10, 4
+    d, prob, tabs, rollouts = make_case("quadruped", 0, H_ref=H_ref, H=H, B=B, seed=5)
+    obj = synth.make_objective(d, H, dense_q=True)
+    s = make_solver(d, prob, rollouts, H, obj=obj)
+    opts = oip.IPOptions(kappa_tol=prob["kappa"])
+    ref = oracle_sweep(d, tabs, rollouts, opts)
+    q = np.stack([tr.q for tr, _ in ref]); th = np.stack([tr.theta for tr, _ in ref])
+    s.implicit_dynamics(q, th)          # leaves the sensitivities resident on the device
+    lay = onewton.Layout(d, H)
+    rng = np.random.default_rng(0)
+    r = rng.standard_normal((B, lay.N))
+    for beta in (1e-5, 10.0):
+        delta = s.kkt_solve(r, beta)
+        for b, (tr, o) in enumerate(ref):
+            R = onewton.jacobian(lay, obj, o, beta, prob["kappa"])
+            x = np.linalg.solve(R, r[b])
+            np.testing.assert_allclose(delta[b], x, rtol=0, atol=1e-7 * max(1.0, np.abs(x).max()))
