@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py - MPC steps/s of the MI355X solver core on BASELINE.json's headline workload.
+
+A "step" = one `newton_solve!` (cold start) for every rollout of the batch: quadruped
+dimensions (nq 11, nu 8, nw 2, nc 4, nb 8), mode :configuration, H = 40, H_ref = 60,
+fp64, B Monte-Carlo rollouts per GPU (synthetic horizons, seeded - SURVEY.md section 8d).
+`value` = rollouts * steps / wall time, inputs resident in HBM before the timed region.
+
+    python bench.py --gpus N --steps K --warmup W [--rollouts B]
+For N > 1 the driver launches one rank per GPU with torch.distributed.run; rollouts are
+independent, so ranks never exchange data inside the solve (weak scaling: B per GPU fixed).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+QUADRUPED = dict(nq=11, nu=8, nw=2, nc=4, nb=8)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # SURVEY.md section 8d (fp64 vector/matrix nominal)
+
+
+def algorithmic_sizes(nq, nu, nw, nc, nb, mode=0):
+    """algorithmic doubles per IP solve and flops per solve."""
+    nx, ny = nq, 2 * nc + nb
+    nz, nth = nq + 4 * nc + 2 * nb, 2 * nq + nu + nw + 2
+    nd = nq if mode == 0 else nq + nc + nb
+    n_lin = nx * nx + 2 * nx * ny + ny * ny + ny + (nx + ny) * nth + nx * nx + nx * ny + ny * ny \
+        + (nx + 2 * ny + nth) + (nx + ny)
+    io_shared = nth + nq + nz + nd * (2 * nq + nu)
+    flop_iter = 2 * ny ** 3 + ny * ny + 2 * (4 * nx * ny + 3 * ny * ny + 2 * nx * nx) + 3 * 2 * (nx + ny) * (nx + ny + nth)
+    flop_tail = 2 * ny ** 3 + ny * ny + nth * (4 * nx * ny + 3 * ny * ny + 2 * nx * nx)
+    return dict(n_lin=n_lin, bytes_per_solve=8 * (n_lin + io_shared), bytes_per_solve_shared_table=8 * io_shared,
+                flop_iter=flop_iter, flop_tail=flop_tail)
+
+
+def build_inputs(B, H, H_ref, seed, perturb):
+    from oracle import synth
+    from oracle.dims import Dims
+    d = Dims(**QUADRUPED)
+    prob = synth.make_problem(d, H_ref, seed=1)            # shared linearization table (all ranks)
+    obj = synth.make_objective(d, H)
+    rng = np.random.default_rng(seed)
+    rollouts = []
+    for b in range(B):
+        phase = int(rng.integers(0, H_ref))
+        rollouts.append(synth.make_rollout(d, prob, H, phase=phase, seed=seed * 100003 + b, perturb=perturb))
+    return d, prob, obj, rollouts
+
+
+def cpu_baseline(d, prob, obj, rollouts, H, H_ref, budget_s=12.0):
+    """Single-thread C restatement of the reference algorithm (oracle/cimpc_ref.c) on a bounded
+    sample of the same rollouts.  Two KKT backends, as the reference offers both:
+    condensed/banded (the :ldl_solver analogue) and dense LU (the default :lu_solver)."""
+    from oracle import ip as oip, newton as onewton
+    from oracle.cref import CRef
+    cr = CRef(d, H_ref, H, prob, obj, oip.IPOptions(kappa_tol=prob["kappa"]),
+              onewton.NewtonOptions(r_tol=3e-4, max_iter=5), prob["kappa"])
+    out = {}
+    for name, solver, share in (("condensed", 1, 0.6), ("dense_lu", 0, 0.4)):
+        t0 = time.perf_counter()
+        n = 0
+        while n < len(rollouts) and (time.perf_counter() - t0) < budget_s * share:
+            window, ref, q0, q1 = rollouts[n]
+            cr.newton_solve(window, ref, q0, q1, solver=solver)
+            n += 1
+        dt = time.perf_counter() - t0
+        out[name] = (n / dt, n)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rollouts", type=int, default=512, help="Monte-Carlo rollouts per GPU")
+    ap.add_argument("--horizon", type=int, default=40)
+    ap.add_argument("--perturb", type=float, default=0.05)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--latency", action="store_true", help="also time the B = 1 single-rollout loop")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions
+    H, H_ref, B = args.horizon, 60, args.rollouts
+    d, prob, obj, rollouts = build_inputs(B, H, H_ref, seed=1234 + rank, perturb=args.perturb)
+
+    def make(Bn, ro):
+        s = CIMPCSolver(d.nq, d.nu, d.nw, d.nc, d.nb, H_ref, H, B=Bn, mode=0,
+                        ip_opts=InteriorPointOptions(kappa_tol=prob["kappa"]),
+                        newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=3e-4, max_iter=5), device=local_rank)
+        for t in range(H_ref):
+            s.set_linearization(t + 1, prob["z0"][t], prob["th0"][t], prob["r0"][t], prob["rz0"][t], prob["rth0"][t])
+        s.set_objective(obj.q, obj.u)
+        s.set_window(np.stack([w for (w, _, _, _) in ro]) + 1)
+        s.set_reference(np.stack([r.q for (_, r, _, _) in ro]), np.stack([r.u for (_, r, _, _) in ro]),
+                        np.stack([r.w for (_, r, _, _) in ro]), np.stack([r.gamma for (_, r, _, _) in ro]),
+                        np.stack([r.b for (_, r, _, _) in ro]), np.stack([r.theta for (_, r, _, _) in ro]))
+        q0 = torch.tensor(np.stack([r[2] for r in ro]), dtype=torch.float64, device="cuda")
+        q1 = torch.tensor(np.stack([r[3] for r in ro]), dtype=torch.float64, device="cuda")
+        return s, q0, q1
+
+    s, q0, q1 = make(B, rollouts)
+    torch.cuda.synchronize()
+
+    def step():
+        s.newton_solve_dev(q0.data_ptr(), q1.data_ptr(), warm_start=False)
+
+    for _ in range(args.warmup):
+        step()
+    s.profile_enable(True)
+    s.profile_reset()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    sweeps = ip_solves = ip_iters = newton_iters = rounds = 0
+    for _ in range(args.steps):
+        step()
+        st = s.stats()
+        sweeps += st["sweeps"]; ip_solves += st["ip_solves"]; ip_iters += st["ip_iters"]
+        newton_iters += st["newton_iters"]; rounds += st["rounds"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = s.profile_read()
+    s.profile_enable(False)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    alg = algorithmic_sizes(**QUADRUPED)
+    K = ip_iters / max(ip_solves, 1)
+    L = newton_iters / (B * args.steps)
+    S = sweeps / max(newton_iters + B * args.steps, 1)
+    ip_ms = prof["ip_sweep_ms"]
+    launches = max(prof["ip_sweep_launches"], 1)
+    solves_per_launch = prof["ip_sweep_problems"] / launches
+    avg_launch_ms = ip_ms / launches
+    bytes_per_launch = solves_per_launch * alg["bytes_per_solve"]
+    achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if ip_ms > 0 else 0.0
+    flops_per_solve = K * alg["flop_iter"] + alg["flop_tail"]
+    tflops = solves_per_launch * flops_per_solve / (avg_launch_ms * 1e-3) / 1e12 if ip_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "ip_sweep_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("rollouts") == B and tj.get("horizon") == H:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "MPC steps/s (quadruped, H=40, fp64)",
+        "value": world * B * args.steps / dt,
+        "unit": "MPC steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "quadruped flat_2D_lc dims, :configuration, H=%d, H_ref=%d, fp64, "
+                               "%d Monte-Carlo rollouts per GPU batch-sharded (BASELINE configs[3]; "
+                               "configs[2] = same problem at B=1, see latency_b1)" % (H, H_ref, B),
+                   "rollouts_per_gpu": B, "horizon": H, "perturb": args.perturb,
+                   "newton": "r_tol 3e-4, max_iter 5, cold start", "ip": "r_tol 1e-8, kappa_tol 2e-4, undercut 5"},
+        "solver_iters": {"newton_iters_per_step": L, "ip_iters_per_solve": K, "sweeps_per_eval": S,
+                         "sweeps_per_step": sweeps / (B * args.steps), "lockstep_rounds_per_step": rounds / args.steps},
+        "roofline": {"bound": "hbm", "kernel": "ip_sweep_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "bytes_per_unit": alg["bytes_per_solve"], "units_per_launch": solves_per_launch,
+                     "avg_launch_ms": avg_launch_ms,
+                     "achieved_shared_table": solves_per_launch * alg["bytes_per_solve_shared_table"] / (avg_launch_ms * 1e-3) / 1e9 if ip_ms > 0 else 0.0,
+                     "fp64_tflops": tflops, "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                     "fp64_frac": tflops / FP64_VECTOR_PEAK_TFLOPS},
+        "kernel_time_ms_per_step": {"ip_sweep": prof["ip_sweep_ms"] / args.steps, "kkt": prof["kkt_ms"] / args.steps,
+                                    "resid": prof["resid_ms"] / args.steps, "other": prof["other_ms"] / args.steps},
+    }
+    if args.latency:
+        s1, a0, a1 = make(1, rollouts[:1])
+        for _ in range(3):
+            s1.newton_solve_dev(a0.data_ptr(), a1.data_ptr(), False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n1 = 20
+        for _ in range(n1):
+            s1.newton_solve_dev(a0.data_ptr(), a1.data_ptr(), False)
+        torch.cuda.synchronize()
+        out["latency_b1"] = {"ms_per_step": 1e3 * (time.perf_counter() - t1) / n1, "stats": s1.stats()}
+    if not args.no_cpu_baseline:
+        try:
+            cb = cpu_baseline(d, prob, obj, rollouts, H, H_ref)
+            out["cpu_baseline"] = {
+                "value": cb["condensed"][0], "unit": "MPC steps/s", "cores": 1, "kind": "port",
+                "sample": "%d rollouts (condensed block-Cholesky KKT, the :ldl_solver analogue) and %d rollouts "
+                          "(dense LU, reference default :lu_solver) of the same batch, oracle/cimpc_ref.c, 1 thread"
+                          % (cb["condensed"][1], cb["dense_lu"][1]),
+                "value_dense_lu": cb["dense_lu"][0],
+                "host_cores_available": os.cpu_count()}
+            out["speedup_vs_cpu_1thread"] = out["value"] / cb["condensed"][0]
+        except Exception as e:  # the baseline never blocks the GPU number
+            out["cpu_baseline"] = {"error": repr(e)}
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -56,19 +56,27 @@ __global__ __launch_bounds__(256) void ip_sweep_kernel(IpParams p) {
     const int4 desc = reinterpret_cast<const int4*>(p.wg_desc)[blockIdx.x];
     const int knot = desc.x, start = desc.y, count = desc.z;
 
+    const int grp = tid / G;
+    const int l = tid % G;
+    int b = 0, i = 0;
+    bool active = false;
+    if (grp < count) {
+        const int prob = p.plist[start + grp];
+        b = prob / p.H;
+        i = prob - b * p.H;
+        active = (p.need_sweep == nullptr) || (p.need_sweep[b] != 0);
+    }
+    // rollouts that are not being evaluated in this round (line search finished or still
+    // backtracking elsewhere) leave holes: skip the table staging when the whole workgroup is idle
+    if (!__syncthreads_or(active ? 1 : 0)) return;
+
     {   // stage the knot's table: 16 B per lane, fully coalesced
         const double2* src = reinterpret_cast<const double2*>(p.tab + (size_t)knot * L.size);
         double2* dst = reinterpret_cast<double2*>(tab);
         for (int k = tid; k < L.size / 2; k += (int)blockDim.x) dst[k] = src[k];
     }
     __syncthreads();
-
-    const int grp = tid / G;
-    const int l = tid % G;
-    if (grp >= count) return;
-    const int prob = p.plist[start + grp];
-    const int b = prob / p.H, i = prob - b * p.H;
-    if (p.need_sweep != nullptr && p.need_sweep[b] == 0) return;
+    if (!active) return;
 
     double* Rst = smem + L.size + (size_t)grp * M::LDS_GROUP;   // [NY][G+1]
     double* dth = Rst + NY * M::RST_LD;                          // [NTH]

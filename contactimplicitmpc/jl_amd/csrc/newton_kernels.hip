@@ -264,33 +264,18 @@ __global__ __launch_bounds__(256) void resid_decide_kernel(NewtonDev S) {
 }
 
 // -------------------------------------------------------------------------------------------
-// KKT: condensed solve, one wavefront per rollout, blocks staged in LDS (v1: scalar loops).
+// KKT: condensed solve, one wavefront per rollout.  Every operand of the block recursion is
+// staged in LDS tiles with leading dimension LD (>= nd, nq, nu; multiple of 4); global memory
+// is touched only to stream the step's sensitivities / objective inverses in (coalesced) and
+// to spill the factors L1_i, L2_i, L0_i^-1, y_i for the backward pass.
+//
+//   Y_ii     = du1 R^-1 du1^T + Q_i^-1 + dq1 Q_{i-1}^-1 dq1^T + dq0 Q_{i-2}^-1 dq0^T + rho I
+//   Y_i,i-1  = -dq1_i Q_{i-1}^-1 + dq0_i Q_{i-2}^-1 dq1_{i-1}^T ,   Y_i,i-2 = -dq0_i Q_{i-2}^-1
+//   beta_i   = (C P^-1 r_p - r_d)_i                      (methods.jl:386-446, 487-504)
+//   L2_i = Y_i,i-2 L0_{i-2}^-T ; L1_i = (Y_i,i-1 - L2_i L1_{i-1}^T) L0_{i-1}^-T ;
+//   L0_i L0_i^T = Y_ii - L1_i L1_i^T - L2_i L2_i^T        (compute_L!, methods.jl:466-485)
+//   forward / backward block substitution, Delta_x = P^-1 (r_p - C^T dnu)   (:506-557)
 // -------------------------------------------------------------------------------------------
-// C[m x n] = alpha * A[m x k] * op(B) + betaC * C ;  op(B) = B^T (B is n x k) or B (k x n)
-__device__ __forceinline__ void mm(double* C, int ldc, const double* A, int lda, const double* B,
-                                   int ldb, int mrows, int ncols, int kk, bool transB,
-                                   double alpha, double betaC, int lane) {
-    for (int idx = lane; idx < mrows * ncols; idx += 64) {
-        const int r = idx % mrows, c = idx / mrows;
-        double s = 0.0;
-        if (transB) for (int k = 0; k < kk; ++k) s = fma(A[r + k * lda], B[c + k * ldb], s);
-        else for (int k = 0; k < kk; ++k) s = fma(A[r + k * lda], B[k + c * ldb], s);
-        const double old = (betaC != 0.0) ? betaC * C[r + c * ldc] : 0.0;
-        C[r + c * ldc] = alpha * s + old;
-    }
-}
-// y[m] = alpha * op(A) x + betaY*y ; A is m x k (or k x m when trans)
-__device__ __forceinline__ void mv(double* y, const double* A, int lda, const double* x, int mrows,
-                                   int kk, bool transA, double alpha, double betaY, int lane) {
-    for (int r = lane; r < mrows; r += 64) {
-        double s = 0.0;
-        if (transA) for (int k = 0; k < kk; ++k) s = fma(A[k + r * lda], x[k], s);
-        else for (int k = 0; k < kk; ++k) s = fma(A[r + k * lda], x[k], s);
-        const double old = (betaY != 0.0) ? betaY * y[r] : 0.0;
-        y[r] = alpha * s + old;
-    }
-}
-
 struct KktArgs {
     const double* r;     // [B][N] right-hand side
     double* delta;       // [B][N]
@@ -300,190 +285,285 @@ struct KktArgs {
     int finish;          // 1: set alpha/ls_iter/cand/stage after the solve (newton loop)
 };
 
+__device__ __forceinline__ void lds_sync() { __syncthreads(); }
+
+// number of LDS tiles used by kkt_kernel
+constexpr int KKT_TILES = 21;
+
+template <int LD>
 __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
     const cimpc_dims& m = S.dm;
     const int b = blockIdx.x, lane = threadIdx.x;
     if (K.stage != nullptr && K.stage[b] != STAGE_KKT) return;
     const int H = m.H, nq = m.nq, nu = m.nu, nr = S.nr, nd = S.nd, nths = S.nths;
-    const int n2 = nd * nd;
+    constexpr int T2D = LD * LD;
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    // LDS carve (doubles); nd == nq in :configuration mode
-    double* A0 = sm;                 // nd x nu   du1_i
-    double* A1 = A0 + nd * nu;       // nd x nq   dq1_i
-    double* A2 = A1 + nd * nq;       // nd x nq   dq0_i
-    double* A1p = A2 + nd * nq;      // dq1_{i-1}
-    double* T0 = A1p + nd * nq;      // A0 * Rinv_i
-    double* T1 = T0 + nd * nu;       // A1 * Qinv_{i-1}
-    double* T2 = T1 + nd * nq;       // A2 * Qinv_{i-2}
-    double* Y0 = T2 + nd * nq;       // nd x nd
-    double* Y1 = Y0 + n2;
-    double* Y2 = Y1 + n2;
-    double* Lc = Y2 + n2;            // L0_i then scratch
-    double* Li = Lc + n2;            // L0inv_i
-    double* Li1 = Li + n2;           // L0inv_{i-1}
-    double* Li2 = Li1 + n2;          // L0inv_{i-2}
-    double* L1c = Li2 + n2;          // L1_i
-    double* L1p = L1c + n2;          // L1_{i-1}
-    double* L2c = L1p + n2;          // L2_i
-    double* Mt = L2c + n2;           // temp
-    double* bet = Mt + n2;           // nd
-    double* yc = bet + nd;           // y_i
-    double* y1 = yc + nd;            // y_{i-1}
-    double* y2 = y1 + nd;            // y_{i-2}
-    double* tv = y2 + nd;            // temp vec (max(nq,nu,nd))
+    double* A0 = sm;                  // du1_i      nd x nu
+    double* A1 = A0 + T2D;            // dq1_i      nd x nq
+    double* A2 = A1 + T2D;            // dq0_i      nd x nq
+    double* A1p = A2 + T2D;           // dq1_{i-1}
+    double* T0 = A1p + T2D;           // du1 Rinv_i
+    double* T1 = T0 + T2D;            // dq1 Qinv_{i-1}
+    double* T2 = T1 + T2D;            // dq0 Qinv_{i-2}
+    double* Y0 = T2 + T2D;
+    double* Y1 = Y0 + T2D;
+    double* Y2 = Y1 + T2D;
+    double* Lc = Y2 + T2D;            // chol factor of the step
+    double* Lbuf[3] = {Lc + T2D, Lc + 2 * T2D, Lc + 3 * T2D};      // L0inv ring (i, i-1, i-2)
+    double* L1buf[2] = {Lc + 4 * T2D, Lc + 5 * T2D};               // L1 ring (i, i-1)
+    double* L2c = Lc + 6 * T2D;
+    double* Qbuf[3] = {Lc + 7 * T2D, Lc + 8 * T2D, Lc + 9 * T2D};  // Qinv ring (i, i-1, i-2)
+    double* Ri = Lc + 10 * T2D;       // Rinv_i   (tile 21)
+    double* vec = sm + KKT_TILES * T2D;
+    double* bet = vec;                // LD each
+    double* ybuf[3] = {vec + LD, vec + 2 * LD, vec + 3 * LD};      // y ring
+    double* rpu = vec + 4 * LD;       // r_p(u) of step i
+    double* rpq[3] = {vec + 5 * LD, vec + 6 * LD, vec + 7 * LD};   // r_p(q) ring (i, i-1, i-2)
+    double* tv = vec + 8 * LD;
     const double* rb = K.r + (size_t)b * S.N;
     const double beta = K.beta ? K.beta[b] : K.beta_scalar;
     const double rho = (double)H * beta * S.kappa;     // newton_jacobian.jl:169-186 quirk
     const double* dzb = S.dz + (size_t)b * H * nths * nd;
+    const int n2 = nd * nd;
     double* ws = S.kkt_ws + (size_t)b * H * (3 * n2 + nd);
     const int oq = nu;   // offset of q2 inside a primal block (:configuration)
 
     for (int i = 0; i < H; ++i) {
-        // ---- load sensitivities of step i --------------------------------------------------
+        double* Li = Lbuf[i % 3];      double* Li1 = Lbuf[(i + 2) % 3];  double* Li2 = Lbuf[(i + 1) % 3];
+        double* L1c = L1buf[i % 2];    double* L1p = L1buf[(i + 1) % 2];
+        double* Qi0 = Qbuf[i % 3];     double* Qi1 = Qbuf[(i + 2) % 3];  double* Qi2 = Qbuf[(i + 1) % 3];
+        double* yc = ybuf[i % 3];      double* y1 = ybuf[(i + 2) % 3];   double* y2 = ybuf[(i + 1) % 3];
+        double* q0r = rpq[i % 3];      double* q1r = rpq[(i + 2) % 3];   double* q2r = rpq[(i + 1) % 3];
+        // ---- phase 1: stream step i in (A1p keeps dq1_{i-1}: swap roles of A1/A1p) ----------
+        {
+            double* t = A1; A1 = A1p; A1p = t;
+        }
         const double* dzi = dzb + (size_t)i * nths * nd;
-        for (int k = lane; k < nd * nq; k += 64) { A2[k] = dzi[k]; A1[k] = dzi[nd * nq + k]; }
-        for (int k = lane; k < nd * nu; k += 64) A0[k] = dzi[2 * nd * nq + k];
-        __syncthreads();
-        // ---- Y blocks and beta_i ------------------------------------------------------------
-        mm(T0, nd, A0, nd, S.Rinv + (size_t)i * nu * nu, nu, nd, nu, nu, false, 1.0, 0.0, lane);
-        if (i >= 1) mm(T1, nd, A1, nd, S.Qinv + (size_t)(i - 1) * nq * nq, nq, nd, nq, nq, false, 1.0, 0.0, lane);
-        if (i >= 2) mm(T2, nd, A2, nd, S.Qinv + (size_t)(i - 2) * nq * nq, nq, nd, nq, nq, false, 1.0, 0.0, lane);
-        __syncthreads();
-        for (int k = lane; k < n2; k += 64) {
+        for (int k = lane; k < nd * nq; k += 64) {
             const int r = k % nd, c = k / nd;
-            Y0[k] = S.Qinv[(size_t)i * nq * nq + k] + ((r == c) ? rho : 0.0);
+            A2[r + c * LD] = dzi[k];
+            A1[r + c * LD] = dzi[nd * nq + k];
         }
-        __syncthreads();
-        mm(Y0, nd, T0, nd, A0, nd, nd, nd, nu, true, 1.0, 1.0, lane);
-        __syncthreads();
-        if (i >= 1) { mm(Y0, nd, T1, nd, A1, nd, nd, nd, nq, true, 1.0, 1.0, lane); __syncthreads(); }
-        if (i >= 2) { mm(Y0, nd, T2, nd, A2, nd, nd, nd, nq, true, 1.0, 1.0, lane); __syncthreads(); }
-        // beta_i = T0 rp_u[i] - Qinv_i rp_q[i] + T1 rp_q[i-1] + T2 rp_q[i-2] - rd[i]
-        mv(bet, T0, nd, rb + i * nr, nd, nu, false, 1.0, 0.0, lane);
-        __syncthreads();
-        mv(bet, S.Qinv + (size_t)i * nq * nq, nq, rb + i * nr + oq, nd, nq, false, -1.0, 1.0, lane);
-        __syncthreads();
-        if (i >= 1) { mv(bet, T1, nd, rb + (i - 1) * nr + oq, nd, nq, false, 1.0, 1.0, lane); __syncthreads(); }
-        if (i >= 2) { mv(bet, T2, nd, rb + (i - 2) * nr + oq, nd, nq, false, 1.0, 1.0, lane); __syncthreads(); }
-        for (int k = lane; k < nd; k += 64) bet[k] -= rb[H * nr + i * nd + k];
-        // Y1 = -T1 + T2 * dq1_{i-1}^T ;  Y2 = -T2
+        for (int k = lane; k < nd * nu; k += 64) A0[(k % nd) + (k / nd) * LD] = dzi[2 * nd * nq + k];
+        for (int k = lane; k < nq * nq; k += 64) Qi0[(k % nq) + (k / nq) * LD] = S.Qinv[(size_t)i * nq * nq + k];
+        for (int k = lane; k < nu * nu; k += 64) Ri[(k % nu) + (k / nu) * LD] = S.Rinv[(size_t)i * nu * nu + k];
+        for (int k = lane; k < nu; k += 64) rpu[k] = rb[i * nr + k];
+        for (int k = lane; k < nq; k += 64) q0r[k] = rb[i * nr + oq + k];
+        lds_sync();
+        // ---- phase 2: T0 = A0 Ri, T1 = A1 Qi1, T2 = A2 Qi2 -----------------------------------
+        for (int idx = lane; idx < nd * (nu + 2 * nq); idx += 64) {
+            const int r = idx % nd;
+            int c = idx / nd;
+            double s = 0.0;
+            if (c < nu) {
+                for (int k = 0; k < nu; ++k) s = fma(A0[r + k * LD], Ri[k + c * LD], s);
+                T0[r + c * LD] = s;
+            } else if (c < nu + nq) {
+                c -= nu;
+                if (i >= 1) for (int k = 0; k < nq; ++k) s = fma(A1[r + k * LD], Qi1[k + c * LD], s);
+                T1[r + c * LD] = s;
+            } else {
+                c -= nu + nq;
+                if (i >= 2) for (int k = 0; k < nq; ++k) s = fma(A2[r + k * LD], Qi2[k + c * LD], s);
+                T2[r + c * LD] = s;
+            }
+        }
+        lds_sync();
+        // ---- phase 3: Y0, Y1, Y2, beta_i -----------------------------------------------------
+        for (int idx = lane; idx < 3 * n2 + nd; idx += 64) {
+            if (idx < n2) {
+                const int r = idx % nd, c = idx / nd;
+                double s = Qi0[r + c * LD] + ((r == c) ? rho : 0.0);
+                for (int k = 0; k < nu; ++k) s = fma(T0[r + k * LD], A0[c + k * LD], s);
+                if (i >= 1) for (int k = 0; k < nq; ++k) s = fma(T1[r + k * LD], A1[c + k * LD], s);
+                if (i >= 2) for (int k = 0; k < nq; ++k) s = fma(T2[r + k * LD], A2[c + k * LD], s);
+                Y0[r + c * LD] = s;
+            } else if (idx < 2 * n2) {
+                const int e = idx - n2, r = e % nd, c = e / nd;
+                double s = -T1[r + c * LD];
+                if (i >= 2) for (int k = 0; k < nq; ++k) s = fma(T2[r + k * LD], A1p[c + k * LD], s);
+                Y1[r + c * LD] = s;
+            } else if (idx < 3 * n2) {
+                const int e = idx - 2 * n2, r = e % nd, c = e / nd;
+                Y2[r + c * LD] = -T2[r + c * LD];
+            } else {
+                const int r = idx - 3 * n2;
+                double s = 0.0;
+                for (int k = 0; k < nu; ++k) s = fma(T0[r + k * LD], rpu[k], s);
+                double t = 0.0;
+                for (int k = 0; k < nq; ++k) t = fma(Qi0[r + k * LD], q0r[k], t);
+                s -= t;
+                if (i >= 1) { t = 0.0; for (int k = 0; k < nq; ++k) t = fma(T1[r + k * LD], q1r[k], t); s += t; }
+                if (i >= 2) { t = 0.0; for (int k = 0; k < nq; ++k) t = fma(T2[r + k * LD], q2r[k], t); s += t; }
+                bet[r] = s - rb[H * nr + i * nd + r];
+            }
+        }
+        lds_sync();
+        // ---- phase 4: L2c = Y2 Li2^T (Li2 lower triangular: k <= c) --------------------------
+        if (i >= 2) {
+            for (int idx = lane; idx < n2; idx += 64) {
+                const int r = idx % nd, c = idx / nd;
+                double s = 0.0;
+                for (int k = 0; k <= c; ++k) s = fma(Y2[r + k * LD], Li2[c + k * LD], s);
+                L2c[r + c * LD] = s;
+            }
+            lds_sync();
+            // ---- phase 5: Y1 -= L2c L1p^T ----------------------------------------------------
+            for (int idx = lane; idx < n2; idx += 64) {
+                const int r = idx % nd, c = idx / nd;
+                double s = Y1[r + c * LD];
+                for (int k = 0; k < nd; ++k) s = fma(-L2c[r + k * LD], L1p[c + k * LD], s);
+                Y1[r + c * LD] = s;
+            }
+            lds_sync();
+        }
+        // ---- phase 6: L1c = Y1 Li1^T ----------------------------------------------------------
         if (i >= 1) {
-            for (int k = lane; k < n2; k += 64) Y1[k] = -T1[k];
-            __syncthreads();
-            if (i >= 2) { mm(Y1, nd, T2, nd, A1p, nd, nd, nd, nq, true, 1.0, 1.0, lane); }
+            for (int idx = lane; idx < n2; idx += 64) {
+                const int r = idx % nd, c = idx / nd;
+                double s = 0.0;
+                for (int k = 0; k <= c; ++k) s = fma(Y1[r + k * LD], Li1[c + k * LD], s);
+                L1c[r + c * LD] = s;
+            }
+            lds_sync();
         }
-        if (i >= 2) for (int k = lane; k < n2; k += 64) Y2[k] = -T2[k];
-        __syncthreads();
-        // ---- block Cholesky step ------------------------------------------------------------
-        // L2_i = Y2 * L0inv_{i-2}^T ;  L1_i = (Y1 - L2_i L1_{i-1}^T) * L0inv_{i-1}^T
-        if (i >= 2) { mm(L2c, nd, Y2, nd, Li2, nd, nd, nd, nd, true, 1.0, 0.0, lane); __syncthreads(); }
-        if (i >= 1) {
-            if (i >= 2) { mm(Y1, nd, L2c, nd, L1p, nd, nd, nd, nd, true, -1.0, 1.0, lane); __syncthreads(); }
-            mm(L1c, nd, Y1, nd, Li1, nd, nd, nd, nd, true, 1.0, 0.0, lane);
-            __syncthreads();
-            mm(Y0, nd, L1c, nd, L1c, nd, nd, nd, nd, true, -1.0, 1.0, lane);
-            __syncthreads();
+        // ---- phase 7: Lc = Y0 - L1c L1c^T - L2c L2c^T (lower triangle) ------------------------
+        for (int idx = lane; idx < n2; idx += 64) {
+            const int r = idx % nd, c = idx / nd;
+            if (r < c) continue;
+            double s = Y0[r + c * LD];
+            if (i >= 1) for (int k = 0; k < nd; ++k) s = fma(-L1c[r + k * LD], L1c[c + k * LD], s);
+            if (i >= 2) for (int k = 0; k < nd; ++k) s = fma(-L2c[r + k * LD], L2c[c + k * LD], s);
+            Lc[r + c * LD] = s;
         }
-        if (i >= 2) { mm(Y0, nd, L2c, nd, L2c, nd, nd, nd, nd, true, -1.0, 1.0, lane); __syncthreads(); }
-        // chol(Y0) -> Lc (lower), right-looking
-        for (int k = lane; k < n2; k += 64) Lc[k] = Y0[k];
-        __syncthreads();
+        lds_sync();
+        // ---- phase 8: Cholesky, right-looking, in place --------------------------------------
         for (int k = 0; k < nd; ++k) {
-            const double dkk = sqrt(Lc[k + k * nd]);
-            __syncthreads();
-            for (int r = k + lane; r < nd; r += 64) Lc[r + k * nd] = (r == k) ? dkk : Lc[r + k * nd] / dkk;
-            __syncthreads();
+            const double dkk = sqrt(Lc[k + k * LD]);
+            const double inv = 1.0 / dkk;
+            lds_sync();
+            for (int r = k + lane; r < nd; r += 64) Lc[r + k * LD] = (r == k) ? dkk : Lc[r + k * LD] * inv;
+            lds_sync();
             const int rem = nd - k - 1;
             for (int idx = lane; idx < rem * rem; idx += 64) {
                 const int r = k + 1 + idx % rem, c = k + 1 + idx / rem;
-                if (r >= c) Lc[r + c * nd] -= Lc[r + k * nd] * Lc[c + k * nd];
+                if (r >= c) Lc[r + c * LD] = fma(-Lc[r + k * LD], Lc[c + k * LD], Lc[r + c * LD]);
             }
-            __syncthreads();
+            lds_sync();
         }
-        // Li = inv(Lc) (lower triangular), one column per lane
+        // ---- phase 9: Li = inv(Lc), one column per lane; bet -= L1c y1 + L2c y2 (lanes >= nd..) -
         for (int c = lane; c < nd; c += 64) {
             for (int r = 0; r < nd; ++r) {
-                if (r < c) { Li[r + c * nd] = 0.0; continue; }
+                if (r < c) { Li[r + c * LD] = 0.0; continue; }
                 double s = (r == c) ? 1.0 : 0.0;
-                for (int k = c; k < r; ++k) s -= Lc[r + k * nd] * Li[k + c * nd];
-                Li[r + c * nd] = s / Lc[r + r * nd];
+                for (int k = c; k < r; ++k) s = fma(-Lc[r + k * LD], Li[k + c * LD], s);
+                Li[r + c * LD] = s / Lc[r + r * LD];
             }
         }
-        __syncthreads();
-        // y_i = Li * (beta_i - L1_i y_{i-1} - L2_i y_{i-2})
-        if (i >= 1) { mv(bet, L1c, nd, y1, nd, nd, false, -1.0, 1.0, lane); __syncthreads(); }
-        if (i >= 2) { mv(bet, L2c, nd, y2, nd, nd, false, -1.0, 1.0, lane); __syncthreads(); }
-        mv(yc, Li, nd, bet, nd, nd, false, 1.0, 0.0, lane);
-        __syncthreads();
-        // ---- spill factors for the backward pass, rotate the window ------------------------
+        for (int r = lane - 32; r >= 0 && r < nd; r += 64) {     // lanes 32.. do the rhs update meanwhile
+            double s = bet[r];
+            if (i >= 1) for (int k = 0; k < nd; ++k) s = fma(-L1c[r + k * LD], y1[k], s);
+            if (i >= 2) for (int k = 0; k < nd; ++k) s = fma(-L2c[r + k * LD], y2[k], s);
+            tv[r] = s;
+        }
+        lds_sync();
+        // ---- phase 10: y_i = Li * tv ; spill factors ------------------------------------------
+        for (int r = lane; r < nd; r += 64) {
+            double s = 0.0;
+            for (int k = 0; k <= r; ++k) s = fma(Li[r + k * LD], tv[k], s);
+            yc[r] = s;
+        }
         double* wsi = ws + (size_t)i * (3 * n2 + nd);
         for (int k = lane; k < n2; k += 64) {
-            wsi[k] = L1c[k];
-            wsi[n2 + k] = L2c[k];
-            wsi[2 * n2 + k] = Li[k];
-            Li2[k] = Li1[k];
-            Li1[k] = Li[k];
-            L1p[k] = L1c[k];
+            const int r = k % nd, c = k / nd;
+            wsi[k] = (i >= 1) ? L1c[r + c * LD] : 0.0;
+            wsi[n2 + k] = (i >= 2) ? L2c[r + c * LD] : 0.0;
+            wsi[2 * n2 + k] = Li[r + c * LD];
         }
-        for (int k = lane; k < nd * nq; k += 64) A1p[k] = A1[k];
-        for (int k = lane; k < nd; k += 64) { wsi[3 * n2 + k] = yc[k]; y2[k] = y1[k]; y1[k] = yc[k]; }
-        __syncthreads();
-    }
-    // ---- backward substitution: dnu_i = Li_i^T (y_i - L1_{i+1}^T dnu_{i+1} - L2_{i+2}^T dnu_{i+2})
-    double* D = K.delta + (size_t)b * S.N;
-    double* dn1 = y1;   // dnu_{i+1}
-    double* dn2 = y2;   // dnu_{i+2}
-    for (int i = H - 1; i >= 0; --i) {
-        const double* wsi = ws + (size_t)i * (3 * n2 + nd);
-        for (int k = lane; k < nd; k += 64) bet[k] = wsi[3 * n2 + k];
-        __syncthreads();
-        if (i + 1 < H) { mv(bet, ws + (size_t)(i + 1) * (3 * n2 + nd), nd, dn1, nd, nd, true, -1.0, 1.0, lane); __syncthreads(); }
-        if (i + 2 < H) { mv(bet, ws + (size_t)(i + 2) * (3 * n2 + nd) + n2, nd, dn2, nd, nd, true, -1.0, 1.0, lane); __syncthreads(); }
-        mv(yc, wsi + 2 * n2, nd, bet, nd, nd, true, 1.0, 0.0, lane);
-        __syncthreads();
-        for (int k = lane; k < nd; k += 64) { D[H * nr + i * nd + k] = yc[k]; dn2[k] = dn1[k]; dn1[k] = yc[k]; }
-        __syncthreads();
+        lds_sync();
+        for (int k = lane; k < nd; k += 64) wsi[3 * n2 + k] = yc[k];
     }
     __threadfence_block();
-    __syncthreads();
+    lds_sync();
+    // ---- backward substitution: dnu_i = Li_i^T (y_i - L1_{i+1}^T dnu_{i+1} - L2_{i+2}^T dnu_{i+2})
+    double* D = K.delta + (size_t)b * S.N;
+    double* Wt[3] = {A0, A1, A2};            // LDS staging of (L1_{i+1}, L2_{i+2}, Li_i)
+    double* dnr[3] = {ybuf[0], ybuf[1], ybuf[2]};
+    for (int i = H - 1; i >= 0; --i) {
+        const double* wsi = ws + (size_t)i * (3 * n2 + nd);
+        double* dnc = dnr[i % 3]; double* dn1 = dnr[(i + 1) % 3]; double* dn2 = dnr[(i + 2) % 3];
+        for (int k = lane; k < n2; k += 64) {
+            const int r = k % nd, c = k / nd;
+            Wt[2][r + c * LD] = wsi[2 * n2 + k];
+            if (i + 1 < H) Wt[0][r + c * LD] = ws[(size_t)(i + 1) * (3 * n2 + nd) + k];
+            if (i + 2 < H) Wt[1][r + c * LD] = ws[(size_t)(i + 2) * (3 * n2 + nd) + n2 + k];
+        }
+        for (int k = lane; k < nd; k += 64) bet[k] = wsi[3 * n2 + k];
+        lds_sync();
+        for (int r = lane; r < nd; r += 64) {
+            double s = bet[r];
+            if (i + 1 < H) for (int k = 0; k < nd; ++k) s = fma(-Wt[0][k + r * LD], dn1[k], s);
+            if (i + 2 < H) for (int k = 0; k < nd; ++k) s = fma(-Wt[1][k + r * LD], dn2[k], s);
+            tv[r] = s;
+        }
+        lds_sync();
+        for (int r = lane; r < nd; r += 64) {
+            double s = 0.0;
+            for (int k = r; k < nd; ++k) s = fma(Wt[2][k + r * LD], tv[k], s);
+            dnc[r] = s;
+            D[H * nr + i * nd + r] = s;
+        }
+        lds_sync();
+    }
+    __threadfence_block();
+    lds_sync();
     // ---- primal recovery: Delta_x = P^-1 (r_p - C^T dnu) ----------------------------------
     const double* dn = D + H * nr;
     for (int i = 0; i < H; ++i) {
         const double* dzi = dzb + (size_t)i * nths * nd;
-        // u block
-        for (int c = lane; c < nu; c += 64) {
+        for (int c = lane; c < nu + nq; c += 64) {
+            if (c < nu) {
+                double s = 0.0;
+                const double* a0 = dzi + (size_t)(2 * nq + c) * nd;
+                for (int k = 0; k < nd; ++k) s = fma(a0[k], dn[i * nd + k], s);
+                tv[c] = rb[i * nr + c] - s;
+            } else {
+                const int cq = c - nu;
+                double s = -dn[i * nd + cq];
+                if (i + 1 < H) {
+                    const double* a1 = dzb + ((size_t)(i + 1) * nths + nq + cq) * nd;
+                    double t = 0.0;
+                    for (int k = 0; k < nd; ++k) t = fma(a1[k], dn[(i + 1) * nd + k], t);
+                    s += t;
+                }
+                if (i + 2 < H) {
+                    const double* a2 = dzb + ((size_t)(i + 2) * nths + cq) * nd;
+                    double t = 0.0;
+                    for (int k = 0; k < nd; ++k) t = fma(a2[k], dn[(i + 2) * nd + k], t);
+                    s += t;
+                }
+                tv[c] = rb[i * nr + oq + cq] - s;
+            }
+        }
+        lds_sync();
+        for (int c = lane; c < nu + nq; c += 64) {
             double s = 0.0;
-            const double* a0 = dzi + (size_t)(2 * nq + c) * nd;
-            for (int k = 0; k < nd; ++k) s = fma(a0[k], dn[i * nd + k], s);
-            tv[c] = rb[i * nr + c] - s;
-        }
-        __syncthreads();
-        mv(D + i * nr, S.Rinv + (size_t)i * nu * nu, nu, tv, nu, nu, false, 1.0, 0.0, lane);
-        __syncthreads();
-        // q block: r_q - (-dnu_i + dq1_{i+1}^T dnu_{i+1} + dq0_{i+2}^T dnu_{i+2})
-        for (int c = lane; c < nq; c += 64) {
-            double s = -dn[i * nd + c];
-            if (i + 1 < H) {
-                const double* a1 = dzb + ((size_t)(i + 1) * nths + nq + c) * nd;
-                double t = 0.0;
-                for (int k = 0; k < nd; ++k) t = fma(a1[k], dn[(i + 1) * nd + k], t);
-                s += t;
+            if (c < nu) {
+                const double* Rm = S.Rinv + (size_t)i * nu * nu;
+                for (int k = 0; k < nu; ++k) s = fma(Rm[c + k * nu], tv[k], s);
+                D[i * nr + c] = s;
+            } else {
+                const int cq = c - nu;
+                const double* Qm = S.Qinv + (size_t)i * nq * nq;
+                for (int k = 0; k < nq; ++k) s = fma(Qm[cq + k * nq], tv[nu + k], s);
+                D[i * nr + oq + cq] = s;
             }
-            if (i + 2 < H) {
-                const double* a2 = dzb + ((size_t)(i + 2) * nths + c) * nd;
-                double t = 0.0;
-                for (int k = 0; k < nd; ++k) t = fma(a2[k], dn[(i + 2) * nd + k], t);
-                s += t;
-            }
-            tv[c] = rb[i * nr + oq + c] - s;
         }
-        __syncthreads();
-        mv(D + i * nr + oq, S.Qinv + (size_t)i * nq * nq, nq, tv, nq, nq, false, 1.0, 0.0, lane);
-        __syncthreads();
+        lds_sync();
     }
     if (K.finish) {
         __threadfence_block();
-        __syncthreads();
+        lds_sync();
         // line search start (newton.jl:223-228): alpha = 1, candidate = traj - Delta
         apply_step(S, S.cand, S.nu_cand, b, 1.0, lane, 64);
         if (lane == 0) {
@@ -496,11 +576,33 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
     }
 }
 
-static size_t kkt_lds_bytes(const NewtonDev& S) {
+static int kkt_ld(const NewtonDev& S) {
     const int nd = S.nd, nq = S.dm.nq, nu = S.dm.nu;
     const int mx = nd > nq ? (nd > nu ? nd : nu) : (nq > nu ? nq : nu);
-    size_t dbl = 2 * (size_t)nd * nu + 5 * (size_t)nd * nq + 11 * (size_t)nd * nd + 4 * nd + mx;
-    return dbl * sizeof(double);
+    return (mx + 3) & ~3;
+}
+
+template <int LD>
+static int launch_kkt_ld(const NewtonDev& S, const KktArgs& K, hipStream_t s) {
+    const size_t lds = (size_t)(KKT_TILES * LD * LD + 10 * LD) * sizeof(double);
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)kkt_kernel<LD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return CIMPC_ERR_HIP;
+    }
+    hipLaunchKernelGGL((kkt_kernel<LD>), dim3(S.dm.B), dim3(64), lds, s, S, K);
+    return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+}
+
+static int launch_kkt_any(const NewtonDev& S, const KktArgs& K, hipStream_t s) {
+    const int ld = kkt_ld(S);
+    if (ld <= 4) return launch_kkt_ld<4>(S, K, s);
+    if (ld <= 8) return launch_kkt_ld<8>(S, K, s);
+    if (ld <= 12) return launch_kkt_ld<12>(S, K, s);
+    if (ld <= 16) return launch_kkt_ld<16>(S, K, s);
+    if (ld <= 20) return launch_kkt_ld<20>(S, K, s);
+    if (ld <= 24) return launch_kkt_ld<24>(S, K, s);
+    return CIMPC_ERR_INVALID;
 }
 
 int launch_reset(const NewtonDev& S, const double* q0, const double* q1, int warm, hipStream_t s) {
@@ -513,14 +615,12 @@ int launch_resid_decide(const NewtonDev& S, hipStream_t s) {
 }
 int launch_kkt(const NewtonDev& S, hipStream_t s) {
     KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 1};
-    hipLaunchKernelGGL(kkt_kernel, dim3(S.dm.B), dim3(64), kkt_lds_bytes(S), s, S, K);
-    return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+    return launch_kkt_any(S, K, s);
 }
 int launch_kkt_raw(const NewtonDev& S, const double* r_dev, double beta, double* delta_dev,
                    hipStream_t s) {
     KktArgs K{r_dev, delta_dev, nullptr, beta, nullptr, 0};
-    hipLaunchKernelGGL(kkt_kernel, dim3(S.dm.B), dim3(64), kkt_lds_bytes(S), s, S, K);
-    return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+    return launch_kkt_any(S, K, s);
 }
 
 }  // namespace cimpc
