@@ -290,12 +290,14 @@ __device__ __forceinline__ void lds_sync() { __syncthreads(); }
 // number of LDS tiles used by kkt_kernel
 constexpr int KKT_TILES = 21;
 
-template <int LD>
+template <int NQ, int NU>
 __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
+    constexpr int LD = ((NQ > NU ? NQ : NU) + 3) & ~3;
     const cimpc_dims& m = S.dm;
     const int b = blockIdx.x, lane = threadIdx.x;
     if (K.stage != nullptr && K.stage[b] != STAGE_KKT) return;
-    const int H = m.H, nq = m.nq, nu = m.nu, nr = S.nr, nd = S.nd, nths = S.nths;
+    constexpr int nq = NQ, nu = NU, nd = NQ, nr = NQ + NU, nths = 2 * NQ + NU;
+    const int H = m.H;
     constexpr int T2D = LD * LD;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* A0 = sm;                  // du1_i      nd x nu
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
     const double beta = K.beta ? K.beta[b] : K.beta_scalar;
     const double rho = (double)H * beta * S.kappa;     // newton_jacobian.jl:169-186 quirk
     const double* dzb = S.dz + (size_t)b * H * nths * nd;
-    const int n2 = nd * nd;
+    constexpr int n2 = nd * nd;
     double* ws = S.kkt_ws + (size_t)b * H * (3 * n2 + nd);
     const int oq = nu;   // offset of q2 inside a primal block (:configuration)
 
@@ -576,32 +578,26 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
     }
 }
 
-static int kkt_ld(const NewtonDev& S) {
-    const int nd = S.nd, nq = S.dm.nq, nu = S.dm.nu;
-    const int mx = nd > nq ? (nd > nu ? nd : nu) : (nq > nu ? nq : nu);
-    return (mx + 3) & ~3;
-}
-
-template <int LD>
-static int launch_kkt_ld(const NewtonDev& S, const KktArgs& K, hipStream_t s) {
+template <int NQ, int NU>
+static int launch_kkt_t(const NewtonDev& S, const KktArgs& K, hipStream_t s) {
+    constexpr int LD = ((NQ > NU ? NQ : NU) + 3) & ~3;
     const size_t lds = (size_t)(KKT_TILES * LD * LD + 10 * LD) * sizeof(double);
     if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)kkt_kernel<LD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)kkt_kernel<NQ, NU>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return CIMPC_ERR_HIP;
     }
-    hipLaunchKernelGGL((kkt_kernel<LD>), dim3(S.dm.B), dim3(64), lds, s, S, K);
+    hipLaunchKernelGGL((kkt_kernel<NQ, NU>), dim3(S.dm.B), dim3(64), lds, s, S, K);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
 
 static int launch_kkt_any(const NewtonDev& S, const KktArgs& K, hipStream_t s) {
-    const int ld = kkt_ld(S);
-    if (ld <= 4) return launch_kkt_ld<4>(S, K, s);
-    if (ld <= 8) return launch_kkt_ld<8>(S, K, s);
-    if (ld <= 12) return launch_kkt_ld<12>(S, K, s);
-    if (ld <= 16) return launch_kkt_ld<16>(S, K, s);
-    if (ld <= 20) return launch_kkt_ld<20>(S, K, s);
-    if (ld <= 24) return launch_kkt_ld<24>(S, K, s);
+    if (S.dm.mode != CIMPC_MODE_CONFIGURATION) return CIMPC_ERR_INVALID;
+    const int nq = S.dm.nq, nu = S.dm.nu;
+    if (nq == 2 && nu == 2) return launch_kkt_t<2, 2>(S, K, s);       // pushbot
+    if (nq == 4 && nu == 2) return launch_kkt_t<4, 2>(S, K, s);       // hopper_2D
+    if (nq == 11 && nu == 8) return launch_kkt_t<11, 8>(S, K, s);     // quadruped
+    if (nq == 18 && nu == 12) return launch_kkt_t<18, 12>(S, K, s);   // centroidal_quadruped
     return CIMPC_ERR_INVALID;
 }
 
