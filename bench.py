@@ -41,17 +41,16 @@ def algorithmic_sizes(nq, nu, nw, nc, nb, mode=0):
                 flop_iter=flop_iter, flop_tail=flop_tail)
 
 
-def build_inputs(B, H, H_ref, seed, perturb):
+def build_inputs(B, H, H_ref, seed, perturb, first=0):
     from oracle import synth
     from oracle.dims import Dims
     d = Dims(**QUADRUPED)
     prob = synth.make_problem(d, H_ref, seed=1)            # shared linearization table (all ranks)
     obj = synth.make_objective(d, H)
-    rng = np.random.default_rng(seed)
     rollouts = []
-    for b in range(B):
-        phase = int(rng.integers(0, H_ref))
-        rollouts.append(synth.make_rollout(d, prob, H, phase=phase, seed=seed * 100003 + b, perturb=perturb))
+    for g in range(first, first + B):     # g = GLOBAL rollout index: the batch does not depend on the sharding
+        phase = int(np.random.default_rng(seed * 7919 + g).integers(0, H_ref))
+        rollouts.append(synth.make_rollout(d, prob, H, phase=phase, seed=seed * 100003 + g, perturb=perturb))
     return d, prob, obj, rollouts
 
 
@@ -103,7 +102,9 @@ def main():
 
     from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions
     H, H_ref, B = args.horizon, 60, args.rollouts
-    d, prob, obj, rollouts = build_inputs(B, H, H_ref, seed=1234 + rank, perturb=args.perturb)
+    from contactimplicitmpc.jl_amd.sharding import rollout_shard
+    first, count = rollout_shard(world * B, rank, world)      # weak scaling: B rollouts per GPU
+    d, prob, obj, rollouts = build_inputs(count, H, H_ref, seed=1234, perturb=args.perturb, first=first)
 
     def make(Bn, ro):
         s = CIMPCSolver(d.nq, d.nu, d.nw, d.nc, d.nb, H_ref, H, B=Bn, mode=0,

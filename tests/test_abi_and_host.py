@@ -1,0 +1,58 @@
+"""CPU-only checks of the product boundary: the C-ABI library loads and exports every symbol
+include/cimpc.h declares, argument validation fails loudly, and there is no CPU fallback."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "cimpc.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(cimpc_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from contactimplicitmpc.jl_amd import _lib
+    lib = _lib.load()
+    names = _declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/cimpc.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in _lib.SIGNATURES"
+    assert lib.cimpc_version() >= 100
+
+
+def test_default_options_match_reference_defaults():
+    from contactimplicitmpc.jl_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    ip = _lib.IpOpts(); nt = _lib.NewtonOpts()
+    lib.cimpc_default_ip_opts(C.byref(ip)); lib.cimpc_default_newton_opts(C.byref(nt))
+    # policy.jl:48-61
+    assert (ip.r_tol, ip.kappa_tol, ip.undercut, ip.gamma_reg) == (1e-8, 2e-4, 5.0, 0.1)
+    assert (nt.r_tol, nt.max_iter, nt.beta_init) == (3e-4, 5, 1e-5)
+
+
+def test_no_cpu_fallback_and_loud_errors():
+    import torch
+    from contactimplicitmpc.jl_amd import CIMPCSolver, CimpcError
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the no-device path cannot be exercised")
+    with pytest.raises(CimpcError) as e:
+        CIMPCSolver(11, 8, 2, 4, 8, H_ref=4, H=2, B=1)
+    assert "no HIP device" in str(e.value) or "NO_DEVICE" in str(e.value) or "-2" in str(e.value)
+
+
+def test_product_does_not_import_oracle():
+    """The shipped path may not import / link anything under oracle/."""
+    pkg = os.path.join(ROOT, "contactimplicitmpc")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
+                src = open(os.path.join(dp, f), errors="ignore").read()
+                assert "oracle" not in src.replace("test oracle", ""), f"{f} mentions oracle/"
+    src = open(os.path.join(ROOT, "include", "cimpc.h")).read()
+    assert "oracle" not in src

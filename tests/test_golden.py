@@ -1,0 +1,75 @@
+"""Committed golden fixtures (tests/golden/*.npz, produced by tests/golden/make_golden.py):
+ * CPU: the oracle and its C restatement reproduce them (regression pin of the checker);
+ * GPU (-m gpu): the HIP path through the C ABI reproduces them - the GPU box has no
+   /root/reference and needs no generator, only the committed data."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ip as oip
+from oracle import lcp
+from oracle.dims import Dims
+
+from common import MODELS
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIXTURES = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+
+
+def _load(path):
+    g = np.load(path)
+    d = Dims(**MODELS[str(g["model"])], mode=int(g["mode"]))
+    return g, d
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p) for p in FIXTURES])
+def test_oracle_reproduces_golden(path):
+    g, d = _load(path)
+    H_ref, H, B = int(g["H_ref"]), int(g["H"]), int(g["B"])
+    tabs = [lcp.LinTable(d, g["z0"][t], g["th0"][t], g["r0"][t], g["rz0"][t], g["rth0"][t]) for t in range(H_ref)]
+    opts = oip.IPOptions(kappa_tol=float(g["kappa"]))
+    for b in range(B):
+        o = oip.implicit_dynamics(d, tabs, g["window"][b], g["sweep_q"][b], g["sweep_theta"][b], opts,
+                                  gamma=g["sweep_gamma"][b], b=g["sweep_b"][b])
+        assert np.array_equal(o["iters"], g["sweep_iters"][b])
+        assert np.abs(o["z"] - g["sweep_z"][b]).max() < 1e-10
+        assert np.abs(o["dq1"] - g["sweep_dq1"][b]).max() < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p) for p in FIXTURES])
+def test_hip_reproduces_golden(gpu_required, path):
+    from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions
+    g, d = _load(path)
+    H_ref, H, B = int(g["H_ref"]), int(g["H"]), int(g["B"])
+    has_newton = "newton_iters" in g.files
+    s = CIMPCSolver(d.nq, d.nu, d.nw, d.nc, d.nb, H_ref, H, B=B, mode=d.mode,
+                    ip_opts=InteriorPointOptions(kappa_tol=float(g["kappa"])),
+                    newton_opts=NewtonOptions(kappa=float(g["kappa"]), r_tol=float(g["newton_r_tol"]) if has_newton else 3e-4,
+                                              max_iter=int(g["newton_max_iter"]) if has_newton else 5))
+    for t in range(H_ref):
+        s.set_linearization(t + 1, g["z0"][t], g["th0"][t], g["r0"][t], g["rz0"][t], g["rth0"][t])
+    s.set_window(g["window"] + 1)
+    s.set_reference(g["q_ref"], g["u_ref"], g["w_ref"], g["gamma_ref"], g["b_ref"], g["theta_ref"])
+    out = s.implicit_dynamics(g["sweep_q"], g["sweep_theta"], g["sweep_gamma"], g["sweep_b"], want_z=True)
+    same = (out["iters"] == g["sweep_iters"]) & (out["status"] == g["sweep_status"])
+    assert same.mean() >= 0.9
+    ok = same & (g["sweep_status"] == 1)
+    assert np.abs(out["z"][ok] - g["sweep_z"][ok]).max() < 1e-6
+    assert np.abs(out["d"][ok] - g["sweep_d"][ok]).max() < 1e-7
+    for k in ("dq0", "dq1", "du1"):
+        ref = g["sweep_" + k][ok]
+        assert np.abs(out[k][ok] - ref).max() < 1e-6 * max(1.0, np.abs(ref).max())
+    if has_newton:
+        s.set_objective(g["obj_q"], g["obj_u"])
+        u1, it, rn = s.newton_solve(g["q0"], g["q1"])
+        tr = s.trajectory(); cnt = s.rollout_counters()
+        assert np.array_equal(it, g["newton_iters"])
+        for b in range(B):
+            if cnt["ip_iters"][b] == g["newton_ip_iters"][b]:
+                assert np.abs(tr["q"][b] - g["newton_q"][b]).max() < 1e-7
+                assert np.abs(tr["u"][b] - g["newton_u"][b]).max() < 1e-7
+                assert np.abs(rn[b] - g["newton_rnorm"][b]) < 1e-6 * max(1e-6, g["newton_rnorm"][b]) + 1e-12
+        assert (cnt["ip_iters"] == g["newton_ip_iters"]).sum() >= B - 1
