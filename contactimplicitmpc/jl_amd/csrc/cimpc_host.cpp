@@ -229,6 +229,7 @@ void cimpc_default_ip_opts(cimpc_ip_opts* o) {
     o->ls_scale = 0.5;
     o->max_iter = 100;
     o->max_ls = 3;
+    o->stall_alpha = 1.0e-13;
 }
 
 void cimpc_default_newton_opts(cimpc_newton_opts* o) {

@@ -16,7 +16,7 @@
 // problems that share a reference knot: the knot's packed linearization table is
 // staged once into LDS with coalesced 16-byte loads.  Per lane: lane-indexed vectors
 // x, y1, y2, r, Delta; column l of the ny x ny Schur matrix / Q factor in registers;
-// the R factor goes through a padded LDS tile (row access for the triangular solve).
+// the R factor goes through a padded LDS tile (transpose) into one row per lane.
 // Broadcasts are `v_mov_b64_dpp row_newbcast`, reductions DPP quad_perm/row_ror.
 #pragma once
 #include "cimpc_internal.h"
@@ -44,12 +44,230 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Per-lane state and operators of one interior-point problem (one lane group).
+template <class M>
+struct IpSolver {
+    static constexpr int NX = M::NX, NY = M::NY, NTH = M::NTH, G = M::G;
+    static constexpr LinLayout L{NX, NY, NTH, G};
+    using LG = LaneGroup<G>;
+
+    const double* tab;   // LDS: staged linearization table
+    double* Rst;         // LDS: [NY][G+1] R-factor transpose tile of this problem
+    int l;               // lane within the group
+    bool vx, vy;
+    // per-lane constants of the knot
+    double ry2, ry1d, caibd, rdyn0, rrst0, x0, y10, y20;
+    // per-solve constants
+    double tthdyn, tthrst, altl;
+    // iterate, residual, direction
+    double x, y1, y2, rdyn, rrst, rbil, Dx_, Dy1_, Dy2_;
+    // factorization: column l of Q, row l of R, 1/R[l,l], regularised y, 1/y1r
+    double Qc[NY], Rr[NY], rdinv, y1r, y2r, iy1r;
+
+    __device__ __forceinline__ void bind(const double* tab_, double* Rst_, int l_) {
+        tab = tab_; Rst = Rst_; l = l_;
+        vx = l < NX; vy = l < NY;
+        const double* tVec = tab + L.oVec;
+        ry2 = tVec[LinLayout::V_RY2 * G + l];
+        ry1d = tVec[LinLayout::V_RY1D * G + l];
+        caibd = tVec[LinLayout::V_CAIBD * G + l];
+        rdyn0 = tVec[LinLayout::V_RDYN0 * G + l];
+        rrst0 = tVec[LinLayout::V_RRST0 * G + l];
+        x0 = tVec[LinLayout::V_X0 * G + l];
+        y10 = tVec[LinLayout::V_Y10 * G + l];
+        y20 = tVec[LinLayout::V_Y20 * G + l];
+        rdinv = 0.0; y1r = y2r = iy1r = 1.0;
+        tthdyn = tthrst = altl = 0.0;
+    }
+
+    // rlin! (linearized_solver.jl:364-373), same association as the reference expression
+    __device__ __forceinline__ void residual(double kappa) {
+        const double* tDx = tab + L.oDx; const double* tRx = tab + L.oRx;
+        const double* tDy1 = tab + L.oDy1; const double* tRy1 = tab + L.oRy1;
+        const double dx = x - x0, dy1 = y1 - y10, dy2 = y2 - y20;
+        double a = 0.0, c = 0.0;
+        static_for<0, NX>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const double v = LG::template bcast<k>(dx);
+            a = fma(tDx[k * G + l], v, a);
+            c = fma(tRx[k * G + l], v, c);
+        });
+        double bb = 0.0, e = 0.0;
+        static_for<0, NY>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const double v = LG::template bcast<k>(dy1);
+            bb = fma(tDy1[k * G + l], v, bb);
+            e = fma(tRy1[k * G + l], v, e);
+        });
+        rdyn = ((rdyn0 + a) + bb) + tthdyn;
+        rrst = ((((rrst0 + c) + e) + ry2 * dy2) + tthrst) + altl;
+        rbil = vy ? (y1 * y2 - kappa) : 0.0;
+    }
+    __device__ __forceinline__ double r_violation() const { return LG::all_max(fmax(fabs(rdyn), fabs(rrst))); }
+    __device__ __forceinline__ double k_violation() const { return LG::all_max(fabs(rbil)); }
+
+    // rzlin! + schur_factorize! + MGS factorize!.  Right-looking order: per column exactly
+    // the arithmetic of the reference's left-looking loop (qr.jl:113-137); dot products use
+    // four partial sums, 1/|a_k| comes from v_rsq_f64 + two Newton steps.
+    __device__ __forceinline__ void factorize(double reg) {
+        const double* tW = tab + L.oW;
+        y1r = fmax(y1, reg);
+        y2r = fmax(y2, reg);
+        iy1r = fast_rcp(y1r);
+        const double dd = ry2 * y2r * iy1r;
+        static_for<0, NY>([&](auto ic) {
+            constexpr int r = decltype(ic)::value;
+            const double w = tW[r * G + l];                 // Ry1[r,l] - CAiB[r,l]   (r != l)
+            Qc[r] = (l == r) ? ((ry1d - dd) - caibd) : w;   // (D - CAiB)[r,l]
+        });
+        static_for<0, NY>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            double n2[4] = {0.0, 0.0, 0.0, 0.0};
+            static_for<0, NY>([&](auto ic) {
+                constexpr int r = decltype(ic)::value;
+                n2[r & 3] = fma(Qc[r], Qc[r], n2[r & 3]);
+            });
+            const double inv = fast_rsqrt((n2[0] + n2[1]) + (n2[2] + n2[3]));
+            if (l == k) {                                   // exec-masked: only the pivot column
+                rdinv = inv;
+                static_for<0, NY>([&](auto ic) {
+                    constexpr int r = decltype(ic)::value;
+                    Qc[r] *= inv;
+                });
+            }
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            double qk[NY];
+            static_for<0, NY>([&](auto ic) {
+                constexpr int r = decltype(ic)::value;
+                qk[r] = LG::template bcast<k>(Qc[r]);
+                acc[r & 3] = fma(qk[r], Qc[r], acc[r & 3]);
+            });
+            double rk = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            rk = ((l > k) && vy) ? rk : 0.0;
+            static_for<0, NY>([&](auto ic) {
+                constexpr int r = decltype(ic)::value;
+                Qc[r] = fma(-rk, qk[r], Qc[r]);
+            });
+            Rst[k * M::RST_LD + l] = rk;   // R[k,l], l > k (zeros elsewhere)
+        });
+        wave_lds_fence();
+        static_for<0, NY>([&](auto kc) {   // row l of R (transpose through the LDS tile)
+            constexpr int k = decltype(kc)::value;
+            Rr[k] = vy ? Rst[l * M::RST_LD + k] : 0.0;
+        });
+        wave_lds_fence();
+    }
+
+    // t = R^-1 Q^T rhs  (qr_solve!, qr.jl:142-158); rhs lane-indexed
+    __device__ __forceinline__ double qr_solve(double rhs) const {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        static_for<0, NY>([&](auto ic) {
+            constexpr int r = decltype(ic)::value;
+            acc[r & 3] = fma(Qc[r], LG::template bcast<r>(rhs), acc[r & 3]);
+        });
+        double c = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        double t = 0.0;
+        static_rfor<NY - 1>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const double xk = LG::template bcast<k>(c * rdinv);
+            t = (l == k) ? xk : t;
+            c = fma(-Rr[k], xk, c);   // R[l,k] (zero for k <= l)
+        });
+        return t;
+    }
+
+    // schur_solve! (schur.jl:93-110): returns temp; x = Ai*(u + B*temp), y = -temp
+    __device__ __forceinline__ double schur_solve(double u, double v, double& xs) const {
+        const double* tCAi = tab + L.oCAi; const double* tAi = tab + L.oAi; const double* tDy1 = tab + L.oDy1;
+        double bq[2] = {0.0, 0.0};
+        static_for<0, NX>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            bq[k & 1] = fma(tCAi[k * G + l], LG::template bcast<k>(u), bq[k & 1]);
+        });
+        const double t = qr_solve((bq[0] + bq[1]) - v);
+        double w[2] = {0.0, 0.0};
+        static_for<0, NY>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            w[k & 1] = fma(tDy1[k * G + l], LG::template bcast<k>(t), w[k & 1]);
+        });
+        const double ww = u + (w[0] + w[1]);
+        double xx[2] = {0.0, 0.0};
+        static_for<0, NX>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            xx[k & 1] = fma(tAi[k * G + l], LG::template bcast<k>(ww), xx[k & 1]);
+        });
+        xs = xx[0] + xx[1];
+        return t;
+    }
+
+    // linear_solve!(Delta, rz, r) (linearized_solver.jl:424-444)
+    __device__ __forceinline__ void linear_solve() {
+        const double u = rdyn;
+        const double v = vy ? (rrst - ry2 * rbil * iy1r) : 0.0;
+        const double t = schur_solve(u, v, Dx_);
+        Dy1_ = -t;
+        Dy2_ = vy ? ((rbil - y2r * Dy1_) * iy1r) : 0.0;
+    }
+    __device__ __forceinline__ double step_length(double tau) const {
+        double a = 1.0;
+        if (vy && Dy1_ > 0.0) a = fmin(a, tau * y1 / Dy1_);
+        if (vy && Dy2_ > 0.0) a = fmin(a, tau * y2 / Dy2_);
+        return LG::all_min(a);
+    }
+
+    // interior-point iteration (DESIGN.md "IP iteration spec"); returns status, sets iters/reg
+    __device__ __forceinline__ bool solve(const cimpc_ip_opts& o, int& iters, double& reg) {
+        residual(0.0);
+        double r_vio = r_violation();
+        double k_vio = k_violation();
+        iters = 0;
+        reg = 0.0;
+        for (int j = 0; j < o.max_iter; ++j) {
+            if (r_vio < o.r_tol && k_vio < o.kappa_tol) break;
+            ++iters;
+            reg = (k_vio < o.kappa_reg) ? k_vio * o.gamma_reg : 0.0;
+            factorize(reg);
+            linear_solve();                                   // predictor
+            const double a_aff = step_length(1.0);
+            const double mu = LG::all_sum(vy ? y1 * y2 : 0.0) / (double)NY;
+            const double mu_aff =
+                LG::all_sum(vy ? (y1 - a_aff * Dy1_) * (y2 - a_aff * Dy2_) : 0.0) / (double)NY;
+            double sg = fmin(fmax(mu_aff / mu, 0.0), 1.0);
+            sg = sg * sg * sg;
+            const double kc = fmax(sg * mu, o.kappa_tol / o.undercut);
+            // corrector residual: rdyn, rrst unchanged (same z), rbil = y1*y2 - kc + Dy1*Dy2
+            rbil = vy ? ((y1 * y2 - kc) + Dy1_ * Dy2_) : 0.0;
+            linear_solve();                                   // corrector
+            const double vm = fmax(r_vio, k_vio);
+            const double tau = fmax(1.0 - o.eps_min, 1.0 - vm * vm);
+            const double alpha = step_length(tau);
+            if (alpha < o.stall_alpha) break;                 // [spec] stall exit: jammed on the boundary
+            x -= alpha * Dx_;
+            y1 = vy ? (y1 - alpha * Dy1_) : 1.0;
+            y2 = vy ? (y2 - alpha * Dy2_) : 1.0;
+            double k_c = 0.0, r_c = 0.0, back = alpha;
+            for (int s = 1; s <= o.max_ls; ++s) {
+                residual(0.0);
+                k_c = k_violation();
+                r_c = r_violation();
+                if (r_c <= r_vio || k_c <= k_vio) break;
+                back *= o.ls_scale;                           // alpha * ls_scale^s
+                x += back * Dx_;
+                y1 = vy ? (y1 + back * Dy1_) : 1.0;
+                y2 = vy ? (y2 + back * Dy2_) : 1.0;
+            }
+            k_vio = k_c;
+            r_vio = r_c;
+        }
+        return (r_vio < o.r_tol) && (k_vio < o.kappa_tol);
+    }
+};
+
 template <class M>
 __global__ __launch_bounds__(256) void ip_sweep_kernel(IpParams p) {
     constexpr int NX = M::NX, NY = M::NY, NTH = M::NTH, NTHS = M::NTHS, ND = M::ND, G = M::G;
     constexpr int NC = M::NC, NB = M::NB;
     constexpr LinLayout L(NX, NY, NTH, G);
-    using LG = LaneGroup<G>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* tab = smem;
     const int tid = (int)threadIdx.x;
@@ -81,214 +299,42 @@ __global__ __launch_bounds__(256) void ip_sweep_kernel(IpParams p) {
     double* Rst = smem + L.size + (size_t)grp * M::LDS_GROUP;   // [NY][G+1]
     double* dth = Rst + NY * M::RST_LD;                          // [NTH]
 
-    const bool vx = l < NX, vy = l < NY;
-    const double* tW = tab + L.oW;
-    const double* tCAi = tab + L.oCAi;
-    const double* tAi = tab + L.oAi;
-    const double* tDy1 = tab + L.oDy1;
-    const double* tDx = tab + L.oDx;
-    const double* tRx = tab + L.oRx;
-    const double* tRy1 = tab + L.oRy1;
-    const double* tVec = tab + L.oVec;
-    const double ry2 = tVec[LinLayout::V_RY2 * G + l];
-    const double ry1d = tVec[LinLayout::V_RY1D * G + l];
-    const double caibd = tVec[LinLayout::V_CAIBD * G + l];
-    const double rdyn0 = tVec[LinLayout::V_RDYN0 * G + l];
-    const double rrst0 = tVec[LinLayout::V_RRST0 * G + l];
-    const double x0 = tVec[LinLayout::V_X0 * G + l];
-    const double y10 = tVec[LinLayout::V_Y10 * G + l];
-    const double y20 = tVec[LinLayout::V_Y20 * G + l];
+    IpSolver<M> S;
+    S.bind(tab, Rst, l);
+    const bool vx = S.vx, vy = S.vy;
 
     // ---- problem data: theta - theta0 (LDS, read as broadcast), start point ------------
     const double* th = p.theta + ((size_t)b * p.H + i) * NTH;
     for (int k = l; k < NTH; k += G) dth[k] = th[k] - tab[L.oTh0 + k];
     wave_lds_fence();
-    double tthdyn = 0.0, tthrst = 0.0;   // rthdyn*(th-th0), rthrst*(th-th0): constant per solve
-#pragma unroll 2
-    for (int k = 0; k < NTH; ++k) {
-        const double dk = dth[k];
-        tthdyn = fma(tab[L.oRthDyn + k * G + l], dk, tthdyn);
-        tthrst = fma(tab[L.oRthRst + k * G + l], dk, tthrst);
+    {   // rthdyn*(th-th0), rthrst*(th-th0): constant per solve
+        double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
+        int k = 0;
+        for (; k + 1 < NTH; k += 2) {
+            const double d0 = dth[k], d1 = dth[k + 1];
+            a0 = fma(tab[L.oRthDyn + k * G + l], d0, a0);
+            c0 = fma(tab[L.oRthRst + k * G + l], d0, c0);
+            a1 = fma(tab[L.oRthDyn + (k + 1) * G + l], d1, a1);
+            c1 = fma(tab[L.oRthRst + (k + 1) * G + l], d1, c1);
+        }
+        for (; k < NTH; ++k) {
+            const double d0 = dth[k];
+            a0 = fma(tab[L.oRthDyn + k * G + l], d0, a0);
+            c0 = fma(tab[L.oRthRst + k * G + l], d0, c0);
+        }
+        S.tthdyn = a0 + a1;
+        S.tthrst = c0 + c1;
     }
-    double altl = 0.0;
-    if (p.alt != nullptr && l < NC) altl = p.alt[(size_t)b * NC + l];
+    if (p.alt != nullptr && l < NC) S.altl = p.alt[(size_t)b * NC + l];
 
     const double* qrow = p.q + ((size_t)b * (p.H + 2) + (i + 2)) * M::NQ;
     const double qinit = vx ? qrow[l] : 0.0;
     // z_initialize!: z .= 1, z[iq2] = q   (simulation.jl:59-63)
-    double x = qinit, y1 = 1.0, y2 = 1.0;
+    S.x = qinit; S.y1 = 1.0; S.y2 = 1.0;
 
-    double rdyn, rrst, rbil;
-    // rlin! (linearized_solver.jl:364-373), same association as the reference expression
-    auto residual = [&](double kappa) {
-        const double dx = x - x0, dy1 = y1 - y10, dy2 = y2 - y20;
-        double a = 0.0, c = 0.0;
-        static_for<0, NX>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            const double v = LG::template bcast<k>(dx);
-            a = fma(tDx[k * G + l], v, a);
-            c = fma(tRx[k * G + l], v, c);
-        });
-        double bb = 0.0, e = 0.0;
-        static_for<0, NY>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            const double v = LG::template bcast<k>(dy1);
-            bb = fma(tDy1[k * G + l], v, bb);
-            e = fma(tRy1[k * G + l], v, e);
-        });
-        rdyn = ((rdyn0 + a) + bb) + tthdyn;
-        rrst = ((((rrst0 + c) + e) + ry2 * dy2) + tthrst) + altl;
-        rbil = vy ? (y1 * y2 - kappa) : 0.0;
-    };
-    auto r_violation = [&]() { return LG::all_max(fmax(fabs(rdyn), fabs(rrst))); };
-    auto k_violation = [&]() { return LG::all_max(fabs(rbil)); };
-
-    double Qc[NY];        // column l of the Schur matrix, then of Q
-    double rdinv = 0.0;   // 1 / R[l,l]
-    double y1r = 1.0, y2r = 1.0;
-
-    // rzlin! + schur_factorize! + MGS factorize! (right-looking order: identical
-    // arithmetic per column to the reference's left-looking loop qr.jl:113-137)
-    auto factorize = [&](double reg) {
-        y1r = fmax(y1, reg);
-        y2r = fmax(y2, reg);
-        const double dd = ry2 * y2r / y1r;
-        static_for<0, NY>([&](auto ic) {
-            constexpr int r = decltype(ic)::value;
-            const double w = tW[r * G + l];                 // Ry1[r,l] - CAiB[r,l]   (r != l)
-            Qc[r] = (l == r) ? ((ry1d - dd) - caibd) : w;   // (D - CAiB)[r,l]
-        });
-        static_for<0, NY>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            double n2 = 0.0;
-            static_for<0, NY>([&](auto ic) {
-                constexpr int r = decltype(ic)::value;
-                n2 = fma(Qc[r], Qc[r], n2);
-            });
-            const double rkk = sqrt(n2);
-            const double inv = 1.0 / rkk;
-            const bool own = (l == k);
-            if (own) rdinv = inv;
-            double rk = 0.0;
-            double qk[NY];
-            static_for<0, NY>([&](auto ic) {
-                constexpr int r = decltype(ic)::value;
-                Qc[r] = own ? Qc[r] * inv : Qc[r];
-                qk[r] = LG::template bcast<k>(Qc[r]);
-                rk = fma(qk[r], Qc[r], rk);
-            });
-            const bool upd = (l > k) && vy;
-            rk = upd ? rk : 0.0;
-            static_for<0, NY>([&](auto ic) {
-                constexpr int r = decltype(ic)::value;
-                Qc[r] = fma(-rk, qk[r], Qc[r]);
-            });
-            Rst[k * M::RST_LD + l] = rk;   // R[k,l], l > k (zeros elsewhere)
-        });
-        wave_lds_fence();
-    };
-
-    // t = R^-1 Q^T rhs  (qr_solve!, qr.jl:142-158); rhs lane-indexed
-    auto qr_solve = [&](double rhs) {
-        double c = 0.0;
-        static_for<0, NY>([&](auto ic) {
-            constexpr int r = decltype(ic)::value;
-            c = fma(Qc[r], LG::template bcast<r>(rhs), c);
-        });
-        double t = 0.0;
-        static_rfor<NY - 1>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            const double xk = LG::template bcast<k>(c * rdinv);
-            t = (l == k) ? xk : t;
-            const double rlk = vy ? Rst[l * M::RST_LD + k] : 0.0;   // R[l,k] (zero for k <= l)
-            c = fma(-rlk, xk, c);
-        });
-        return t;
-    };
-
-    // schur_solve! (schur.jl:93-110): returns temp; x = Ai*(u + B*temp), y = -temp
-    auto schur_solve = [&](double u, double v, double& xs) {
-        double bq = 0.0;
-        static_for<0, NX>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            bq = fma(tCAi[k * G + l], LG::template bcast<k>(u), bq);
-        });
-        const double t = qr_solve(bq - v);
-        double w = 0.0;
-        static_for<0, NY>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            w = fma(tDy1[k * G + l], LG::template bcast<k>(t), w);
-        });
-        w = u + w;
-        double xx = 0.0;
-        static_for<0, NX>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            xx = fma(tAi[k * G + l], LG::template bcast<k>(w), xx);
-        });
-        xs = xx;
-        return t;
-    };
-
-    double Dx_, Dy1_, Dy2_;
-    // linear_solve!(Delta, rz, r) (linearized_solver.jl:424-444)
-    auto linear_solve = [&]() {
-        const double u = rdyn;
-        const double v = vy ? (rrst - ry2 * rbil / y1r) : 0.0;
-        const double t = schur_solve(u, v, Dx_);
-        Dy1_ = -t;
-        Dy2_ = vy ? ((rbil - y2r * Dy1_) / y1r) : 0.0;
-    };
-    auto step_length = [&](double tau) {
-        double a = 1.0;
-        if (vy && Dy1_ > 0.0) a = fmin(a, tau * y1 / Dy1_);
-        if (vy && Dy2_ > 0.0) a = fmin(a, tau * y2 / Dy2_);
-        return LG::all_min(a);
-    };
-
-    // ---- interior-point iteration (DESIGN.md "IP iteration spec") ----------------------
-    const cimpc_ip_opts o = p.o;
-    residual(0.0);
-    double r_vio = r_violation();
-    double k_vio = k_violation();
-    int iters = 0;
-    double reg = 0.0;
-    for (int j = 0; j < o.max_iter; ++j) {
-        if (r_vio < o.r_tol && k_vio < o.kappa_tol) break;
-        ++iters;
-        reg = (k_vio < o.kappa_reg) ? k_vio * o.gamma_reg : 0.0;
-        factorize(reg);
-        linear_solve();                                   // predictor
-        const double a_aff = step_length(1.0);
-        const double mu = LG::all_sum(vy ? y1 * y2 : 0.0) / (double)NY;
-        const double mu_aff =
-            LG::all_sum(vy ? (y1 - a_aff * Dy1_) * (y2 - a_aff * Dy2_) : 0.0) / (double)NY;
-        double sg = fmin(fmax(mu_aff / mu, 0.0), 1.0);
-        sg = sg * sg * sg;
-        const double kc = fmax(sg * mu, o.kappa_tol / o.undercut);
-        // corrector residual: rdyn, rrst unchanged (same z), rbil = y1*y2 - kc + Dy1*Dy2
-        rbil = vy ? ((y1 * y2 - kc) + Dy1_ * Dy2_) : 0.0;
-        linear_solve();                                   // corrector
-        const double vm = fmax(r_vio, k_vio);
-        const double tau = fmax(1.0 - o.eps_min, 1.0 - vm * vm);
-        const double alpha = step_length(tau);
-        x -= alpha * Dx_;
-        y1 = vy ? (y1 - alpha * Dy1_) : 1.0;
-        y2 = vy ? (y2 - alpha * Dy2_) : 1.0;
-        double k_c = 0.0, r_c = 0.0, back = alpha;
-        for (int s = 1; s <= o.max_ls; ++s) {
-            residual(0.0);
-            k_c = k_violation();
-            r_c = r_violation();
-            if (r_c <= r_vio || k_c <= k_vio) break;
-            back *= o.ls_scale;                           // alpha * ls_scale^s
-            x += back * Dx_;
-            y1 = vy ? (y1 + back * Dy1_) : 1.0;
-            y2 = vy ? (y2 + back * Dy2_) : 1.0;
-        }
-        k_vio = k_c;
-        r_vio = r_c;
-    }
-    const bool ok = (r_vio < o.r_tol) && (k_vio < o.kappa_tol);
+    int iters;
+    double reg;
+    const bool ok = S.solve(p.o, iters, reg);
 
     const size_t pi = (size_t)b * p.H + i;
     if (l == 0) {
@@ -296,34 +342,40 @@ __global__ __launch_bounds__(256) void ip_sweep_kernel(IpParams p) {
         p.iters[pi] = iters;
     }
     // dynamics violation d = z[1:nd] - [q_{i+2}; gamma_i; b_i]  (implicit_dynamics.jl:180-190)
-    if (vx) p.d[pi * ND + l] = x - qinit;
+    if (vx) p.d[pi * ND + l] = S.x - qinit;
     if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) {
-        if (l < NC) p.d[pi * ND + NX + l] = y1 - p.gam[pi * NC + l];
-        else if (l < NC + NB) p.d[pi * ND + NX + l] = y1 - p.bfr[pi * NB + (l - NC)];
+        if (l < NC) p.d[pi * ND + NX + l] = S.y1 - p.gam[pi * NC + l];
+        else if (l < NC + NB) p.d[pi * ND + NX + l] = S.y1 - p.bfr[pi * NB + (l - NC)];
     }
     if (p.zout != nullptr) {
         double* zo = p.zout + pi * M::NZ;
-        if (vx) zo[l] = x;
-        if (vy) { zo[NX + l] = y1; zo[NX + NY + l] = y2; }
+        if (vx) zo[l] = S.x;
+        if (vy) { zo[NX + l] = S.y1; zo[NX + NY + l] = S.y2; }
     }
     if (!ok) return;   // failed solve: sensitivities of this slot stay untouched
 
     // ---- differentiate_solution!: dz = -(rz^-1 rth), reg = max(reg, kappa_tol*gamma_reg)
-    factorize(fmax(reg, o.kappa_tol * o.gamma_reg));
+    S.factorize(fmax(reg, p.o.kappa_tol * p.o.gamma_reg));
     double* dzo = p.dz + pi * (size_t)(NTHS * ND);
-#pragma unroll 1
-    for (int c = 0; c < NTHS; ++c) {
+    auto column = [&](int c) {
         const double u = tab[L.oRthDyn + c * G + l];
         const double v = tab[L.oRthRst + c * G + l];
         double xs;
-        const double t = schur_solve(u, v, xs);
+        const double t = S.schur_solve(u, v, xs);
         if (vx) dzo[c * ND + l] = -xs;
         if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) {
             if (l < NC + NB) dzo[c * ND + NX + l] = t;   // -(S.y) = +temp
         }
+    };
+    // two independent right-hand sides per trip: their triangular-solve chains interleave
+    int c = 0;
+#pragma unroll 1
+    for (; c + 1 < NTHS; c += 2) {
+        column(c);
+        column(c + 1);
     }
+    if (c < NTHS) column(c);
 }
-
 
 // ----------------------------------------------------------------------------------------
 // per-model launch / info (instantiated in ip_model_*.hip, one translation unit per model

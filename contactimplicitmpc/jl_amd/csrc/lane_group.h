@@ -42,7 +42,7 @@ struct LaneGroup {
     template <int K>
     static __device__ __forceinline__ double bcast(double v) {
         if constexpr (G == 16) {
-            return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xF, 0xF, false);  // row_newbcast:K
+            return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xF, 0xF, true);  // row_newbcast:K
         } else {
             const int lane = (int)(threadIdx.x & 63);
             return __shfl(v, (lane & ~31) | K, 64);
@@ -51,16 +51,16 @@ struct LaneGroup {
 
     // DPP controls: quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_ror:n = 0x120+n
     static __device__ __forceinline__ double dpp_xor1(double v) {
-        return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);
+        return __builtin_amdgcn_update_dpp(0.0, v, 0xB1, 0xF, 0xF, true);
     }
     static __device__ __forceinline__ double dpp_xor2(double v) {
-        return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);
+        return __builtin_amdgcn_update_dpp(0.0, v, 0x4E, 0xF, 0xF, true);
     }
     static __device__ __forceinline__ double dpp_ror4(double v) {
-        return __builtin_amdgcn_update_dpp(v, v, 0x124, 0xF, 0xF, false);
+        return __builtin_amdgcn_update_dpp(0.0, v, 0x124, 0xF, 0xF, true);
     }
     static __device__ __forceinline__ double dpp_ror8(double v) {
-        return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false);
+        return __builtin_amdgcn_update_dpp(0.0, v, 0x128, 0xF, 0xF, true);
     }
 
     static __device__ __forceinline__ double all_max(double v) {
@@ -90,5 +90,26 @@ struct LaneGroup {
         return bcast<0>(v);
     }
 };
+
+// 1/sqrt(x) and 1/x to ~1 ulp from the hardware seeds (v_rsq_f64 / v_rcp_f64) and two
+// Newton steps - an order of magnitude fewer instructions than the IEEE sqrt + divide
+// sequences hipcc emits (v_div_scale / v_div_fmas / v_div_fixup).
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    double e = fma(-h * y, y, 0.5);
+    y = fma(y, e, y);
+    e = fma(-h * y, y, 0.5);
+    y = fma(y, e, y);
+    return y;
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    return y;
+}
 
 }  // namespace cimpc

@@ -10,6 +10,7 @@
 // The Newton iteration of every rollout advances in lock-step rounds driven by the host
 // (cimpc_host.cpp); each rollout carries its own stage / alpha / beta, so rollouts that
 // backtrack and rollouts that start their next Newton iteration share the same launches.
+#include "lane_group.h"
 #include "newton_state.h"
 
 namespace cimpc {
@@ -291,7 +292,7 @@ __device__ __forceinline__ void lds_sync() { __syncthreads(); }
 constexpr int KKT_TILES = 21;
 
 template <int NQ, int NU>
-__global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
+__global__ __launch_bounds__(64) void kkt_kernel_scalar(NewtonDev S, KktArgs K) {
     constexpr int LD = ((NQ > NU ? NQ : NU) + 3) & ~3;
     const cimpc_dims& m = S.dm;
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -330,6 +331,29 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
     double* ws = S.kkt_ws + (size_t)b * H * (3 * n2 + nd);
     const int oq = nu;   // offset of q2 inside a primal block (:configuration)
 
+    // software prefetch of the next step's operands (global -> registers), consumed at the top
+    // of the following iteration: hides the ~1 us HBM/L2 latency behind the block factorization
+    constexpr int PF_DZ = (nd * nths + 63) / 64, PF_Q = (nq * nq + 63) / 64, PF_R = (nu * nu + 63) / 64;
+    double pf_dz[PF_DZ], pf_q[PF_Q], pf_r[PF_R], pf_rp = 0.0, pf_rd = 0.0;
+    auto prefetch = [&](int i) {
+        if (i >= H) return;
+        const double* dzi = dzb + (size_t)i * nths * nd;
+#pragma unroll
+        for (int j = 0; j < PF_DZ; ++j) { const int k = lane + 64 * j; pf_dz[j] = (k < nd * nths) ? dzi[k] : 0.0; }
+#pragma unroll
+        for (int j = 0; j < PF_Q; ++j) { const int k = lane + 64 * j; pf_q[j] = (k < nq * nq) ? S.Qinv[(size_t)i * nq * nq + k] : 0.0; }
+#pragma unroll
+        for (int j = 0; j < PF_R; ++j) { const int k = lane + 64 * j; pf_r[j] = (k < nu * nu) ? S.Rinv[(size_t)i * nu * nu + k] : 0.0; }
+        pf_rp = (lane < nr) ? rb[i * nr + lane] : 0.0;                 // [u | q2] block of r_p
+        pf_rd = (lane < nd) ? rb[H * nr + i * nd + lane] : 0.0;
+    };
+#ifdef CIMPC_KKT_PROF
+    long long pt[16] = {0}; long long tp = clock64();
+#define KPROF(j) { const long long tn = clock64(); pt[j] += tn - tp; tp = tn; }
+#else
+#define KPROF(j)
+#endif
+    prefetch(0);
     for (int i = 0; i < H; ++i) {
         double* Li = Lbuf[i % 3];      double* Li1 = Lbuf[(i + 2) % 3];  double* Li2 = Lbuf[(i + 1) % 3];
         double* L1c = L1buf[i % 2];    double* L1p = L1buf[(i + 1) % 2];
@@ -340,18 +364,32 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
         {
             double* t = A1; A1 = A1p; A1p = t;
         }
-        const double* dzi = dzb + (size_t)i * nths * nd;
-        for (int k = lane; k < nd * nq; k += 64) {
-            const int r = k % nd, c = k / nd;
-            A2[r + c * LD] = dzi[k];
-            A1[r + c * LD] = dzi[nd * nq + k];
+        // registers -> LDS (data of step i was fetched while step i-1 was being factored)
+#pragma unroll
+        for (int j = 0; j < PF_DZ; ++j) {
+            const int k = lane + 64 * j;
+            if (k < nd * nths) {
+                const int r = k % nd, c = k / nd;
+                double* dst = (c < nq) ? (A2 + c * LD) : (c < 2 * nq) ? (A1 + (c - nq) * LD) : (A0 + (c - 2 * nq) * LD);
+                dst[r] = pf_dz[j];
+            }
         }
-        for (int k = lane; k < nd * nu; k += 64) A0[(k % nd) + (k / nd) * LD] = dzi[2 * nd * nq + k];
-        for (int k = lane; k < nq * nq; k += 64) Qi0[(k % nq) + (k / nq) * LD] = S.Qinv[(size_t)i * nq * nq + k];
-        for (int k = lane; k < nu * nu; k += 64) Ri[(k % nu) + (k / nu) * LD] = S.Rinv[(size_t)i * nu * nu + k];
-        for (int k = lane; k < nu; k += 64) rpu[k] = rb[i * nr + k];
-        for (int k = lane; k < nq; k += 64) q0r[k] = rb[i * nr + oq + k];
+#pragma unroll
+        for (int j = 0; j < PF_Q; ++j) {
+            const int k = lane + 64 * j;
+            if (k < nq * nq) Qi0[(k % nq) + (k / nq) * LD] = pf_q[j];
+        }
+#pragma unroll
+        for (int j = 0; j < PF_R; ++j) {
+            const int k = lane + 64 * j;
+            if (k < nu * nu) Ri[(k % nu) + (k / nu) * LD] = pf_r[j];
+        }
+        if (lane < nu) rpu[lane] = pf_rp;
+        else if (lane < nu + nq) q0r[lane - nu] = pf_rp;
+        const double rd_i = pf_rd;
         lds_sync();
+        prefetch(i + 1);
+        KPROF(1)
         // ---- phase 2: T0 = A0 Ri, T1 = A1 Qi1, T2 = A2 Qi2 -----------------------------------
         for (int idx = lane; idx < nd * (nu + 2 * nq); idx += 64) {
             const int r = idx % nd;
@@ -371,6 +409,7 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
             }
         }
         lds_sync();
+        KPROF(2)
         // ---- phase 3: Y0, Y1, Y2, beta_i -----------------------------------------------------
         for (int idx = lane; idx < 3 * n2 + nd; idx += 64) {
             if (idx < n2) {
@@ -397,10 +436,12 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
                 s -= t;
                 if (i >= 1) { t = 0.0; for (int k = 0; k < nq; ++k) t = fma(T1[r + k * LD], q1r[k], t); s += t; }
                 if (i >= 2) { t = 0.0; for (int k = 0; k < nq; ++k) t = fma(T2[r + k * LD], q2r[k], t); s += t; }
-                bet[r] = s - rb[H * nr + i * nd + r];
+                bet[r] = s;            // - r_d[i] is applied below by the lanes that prefetched it
             }
         }
         lds_sync();
+        KPROF(3)
+        if (lane < nd) bet[lane] -= rd_i;
         // ---- phase 4: L2c = Y2 Li2^T (Li2 lower triangular: k <= c) --------------------------
         if (i >= 2) {
             for (int idx = lane; idx < n2; idx += 64) {
@@ -419,6 +460,7 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
             }
             lds_sync();
         }
+        KPROF(4)
         // ---- phase 6: L1c = Y1 Li1^T ----------------------------------------------------------
         if (i >= 1) {
             for (int idx = lane; idx < n2; idx += 64) {
@@ -429,6 +471,7 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
             }
             lds_sync();
         }
+        KPROF(5)
         // ---- phase 7: Lc = Y0 - L1c L1c^T - L2c L2c^T (lower triangle) ------------------------
         for (int idx = lane; idx < n2; idx += 64) {
             const int r = idx % nd, c = idx / nd;
@@ -439,29 +482,71 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
             Lc[r + c * LD] = s;
         }
         lds_sync();
-        // ---- phase 8: Cholesky, right-looking, in place --------------------------------------
-        for (int k = 0; k < nd; ++k) {
-            const double dkk = sqrt(Lc[k + k * LD]);
-            const double inv = 1.0 / dkk;
-            lds_sync();
-            for (int r = k + lane; r < nd; r += 64) Lc[r + k * LD] = (r == k) ? dkk : Lc[r + k * LD] * inv;
-            lds_sync();
-            const int rem = nd - k - 1;
-            for (int idx = lane; idx < rem * rem; idx += 64) {
-                const int r = k + 1 + idx % rem, c = k + 1 + idx / rem;
-                if (r >= c) Lc[r + c * LD] = fma(-Lc[r + k * LD], Lc[c + k * LD], Lc[r + c * LD]);
+        KPROF(6)
+        // ---- phase 8/9: Cholesky of Lc and its inverse --------------------------------------
+        if constexpr (nd <= 16) {
+            // register version: lane rl of each DPP row holds ROW rl of the matrix; the pivot and
+            // the multipliers travel by row_newbcast, no LDS round trip inside the recursion.
+            using LG = LaneGroup<16>;
+            const int rl = lane & 15;
+            double a[nd], invd[nd];
+            static_for<0, nd>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                a[c] = (rl < nd) ? Lc[rl + c * LD] : ((c == rl) ? 1.0 : 0.0);
+            });
+            static_for<0, nd>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const double dk = LG::template bcast<k>(a[k]);
+                const double inv = fast_rsqrt(dk);
+                invd[k] = inv;                       // 1 / L[k,k], identical in every lane
+                a[k] *= inv;                         // lane k: sqrt(dk); lanes r > k: L[r,k]
+                static_for<k + 1, nd>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    a[c] = fma(-a[k], LG::template bcast<c>(a[k]), a[c]);
+                });
+            });
+            // column rl of Li = L^-1 by forward substitution; L[r,k] broadcast from lane r
+            double xc[nd];
+            static_for<0, nd>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                double acc = 0.0;
+                static_for<0, r>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    acc = fma(LG::template bcast<r>(a[k]), xc[k], acc);
+                });
+                xc[r] = (((r == rl) ? 1.0 : 0.0) - acc) * invd[r];
+            });
+            if (lane < nd) {
+                static_for<0, nd>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    Li[r + lane * LD] = xc[r];
+                });
             }
-            lds_sync();
-        }
-        // ---- phase 9: Li = inv(Lc), one column per lane; bet -= L1c y1 + L2c y2 (lanes >= nd..) -
-        for (int c = lane; c < nd; c += 64) {
-            for (int r = 0; r < nd; ++r) {
-                if (r < c) { Li[r + c * LD] = 0.0; continue; }
-                double s = (r == c) ? 1.0 : 0.0;
-                for (int k = c; k < r; ++k) s = fma(-Lc[r + k * LD], Li[k + c * LD], s);
-                Li[r + c * LD] = s / Lc[r + r * LD];
+        } else {
+            for (int k = 0; k < nd; ++k) {
+                const double dkk = sqrt(Lc[k + k * LD]);
+                const double inv = 1.0 / dkk;
+                lds_sync();
+                for (int r = k + lane; r < nd; r += 64) Lc[r + k * LD] = (r == k) ? dkk : Lc[r + k * LD] * inv;
+                lds_sync();
+                const int rem = nd - k - 1;
+                for (int idx = lane; idx < rem * rem; idx += 64) {
+                    const int r = k + 1 + idx % rem, c = k + 1 + idx / rem;
+                    if (r >= c) Lc[r + c * LD] = fma(-Lc[r + k * LD], Lc[c + k * LD], Lc[r + c * LD]);
+                }
+                lds_sync();
+            }
+            for (int c = lane; c < nd; c += 64) {
+                double xi[nd];
+                for (int r = 0; r < nd; ++r) {
+                    double s = (r == c) ? 1.0 : 0.0;
+                    for (int k = 0; k < r; ++k) s = fma(-Lc[r + k * LD], (k >= c) ? xi[k] : 0.0, s);
+                    xi[r] = (r < c) ? 0.0 : s / Lc[r + r * LD];
+                }
+                for (int r = 0; r < nd; ++r) Li[r + c * LD] = xi[r];
             }
         }
+        KPROF(7)
         for (int r = lane - 32; r >= 0 && r < nd; r += 64) {     // lanes 32.. do the rhs update meanwhile
             double s = bet[r];
             if (i >= 1) for (int k = 0; k < nd; ++k) s = fma(-L1c[r + k * LD], y1[k], s);
@@ -469,6 +554,7 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
             tv[r] = s;
         }
         lds_sync();
+        KPROF(8)
         // ---- phase 10: y_i = Li * tv ; spill factors ------------------------------------------
         for (int r = lane; r < nd; r += 64) {
             double s = 0.0;
@@ -484,6 +570,7 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
         }
         lds_sync();
         for (int k = lane; k < nd; k += 64) wsi[3 * n2 + k] = yc[k];
+        KPROF(9)
     }
     __threadfence_block();
     lds_sync();
@@ -519,6 +606,7 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
     }
     __threadfence_block();
     lds_sync();
+    KPROF(10)
     // ---- primal recovery: Delta_x = P^-1 (r_p - C^T dnu) ----------------------------------
     const double* dn = D + H * nr;
     for (int i = 0; i < H; ++i) {
@@ -563,6 +651,331 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
         }
         lds_sync();
     }
+    KPROF(11)
+#ifdef CIMPC_KKT_PROF
+    if (lane == 0 && b == 0) for (int j = 0; j < 16; ++j) ((long long*)S.stats)[8 + j] = pt[j];
+#endif
+    if (K.finish) {
+        __threadfence_block();
+        lds_sync();
+        // line search start (newton.jl:223-228): alpha = 1, candidate = traj - Delta
+        apply_step(S, S.cand, S.nu_cand, b, 1.0, lane, 64);
+        if (lane == 0) {
+            S.alpha[b] = 1.0;
+            S.ls_iter[b] = 0;
+            S.stage[b] = STAGE_LINESEARCH;
+            S.need_sweep[b] = 1;
+            atomicAdd(&S.counters[0], 1);
+        }
+    }
+}
+
+
+// -------------------------------------------------------------------------------------------
+// MFMA version (nq, nu <= 16): every block product of the recursion is C (+)= X * Y^T on
+// 16x16 LDS tiles, executed by v_mfma_f64_16x16x4_f64 (one wavefront = one rollout).  The
+// operands are fed as A := Y, B := X so that the accumulator holds C^T-by-MFMA-layout = C with
+// lane -> row: lane l owns C[l&15][(l>>4) + 4*reg], which stores to the column-major tile with
+// consecutive lanes on consecutive addresses (no LDS bank conflicts).  Padded rows / columns
+// of every tile are kept at exactly zero, so K can always be rounded up to a multiple of 4.
+// -------------------------------------------------------------------------------------------
+using d4 = __attribute__((ext_vector_type(4))) double;
+constexpr int TL = 16;            // tile leading dimension
+constexpr int TSZ = TL * TL;      // doubles per tile
+constexpr int KKT_MFMA_TILES = 22;
+
+template <int KB, bool NEG>
+__device__ __forceinline__ d4 tile_mma(const double* X, const double* Y, d4 acc, int li, int lk) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        double a = Y[li + (4 * kb + lk) * TL];
+        const double b = X[li + (4 * kb + lk) * TL];
+        if (NEG) a = -a;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+__device__ __forceinline__ d4 tile_ld(const double* C, int li, int lk) {
+    d4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = C[li + (lk + 4 * r) * TL];
+    return v;
+}
+__device__ __forceinline__ void tile_st(double* C, d4 v, int li, int lk) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) C[li + (lk + 4 * r) * TL] = v[r];
+}
+// y[r] = sum_k M[r + k*TL] * x[k]  (or M^T), one output per lane, operands in LDS
+template <int KN, bool TRANS>
+__device__ __forceinline__ double tile_mv(const double* Mt, const double* x, int r) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k + 1 < KN; k += 2) {
+        s0 = fma(TRANS ? Mt[k + r * TL] : Mt[r + k * TL], x[k], s0);
+        s1 = fma(TRANS ? Mt[k + 1 + r * TL] : Mt[r + (k + 1) * TL], x[k + 1], s1);
+    }
+    if (KN & 1) s0 = fma(TRANS ? Mt[KN - 1 + r * TL] : Mt[r + (KN - 1) * TL], x[KN - 1], s0);
+    return s0 + s1;
+}
+
+template <int NQ, int NU>
+__global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
+    static_assert(NQ <= 16 && NU <= 16, "MFMA KKT kernel handles one 16x16 tile per block");
+    constexpr int nq = NQ, nu = NU, nd = NQ, nr = NQ + NU, nths = 2 * NQ + NU, n2 = nd * nd;
+    constexpr int KBU = (NU + 3) / 4, KBQ = (NQ + 3) / 4, KBD = (nd + 3) / 4;
+    const cimpc_dims& m = S.dm;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (K.stage != nullptr && K.stage[b] != STAGE_KKT) return;
+    const int H = m.H;
+    const int li = lane & 15, lk = lane >> 4;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    auto tile = [&](int t) { return sm + t * TSZ; };
+    double* A0 = tile(0);                                  // du1_i            nd x nu
+    double* A2 = tile(1);                                  // dq0_i            nd x nq
+    // tiles 2,3: dq1 ring (i, i-1)
+    double* T0 = tile(4); double* T1 = tile(5); double* T2 = tile(6);
+    double* Y1 = tile(7); double* Lc = tile(8); double* L2c = tile(9);
+    // tiles 10..12: L0^-1 ring, 13..14: L1 ring, 15..17: Qinv ring
+    double* Ri = tile(18);
+    // tiles 19..21: extra ring slots of the backward pass
+    double* vec = sm + KKT_MFMA_TILES * TSZ;
+    double* bet = vec;                                     // 16 each
+    double* tv = vec + 16;
+    // vec + 32/48/64: y / dnu ring
+    double* rpu = vec + 80;
+    // vec + 96/112/128: r_p(q) ring
+    for (int k = lane; k < KKT_MFMA_TILES * TSZ + 208; k += 64) sm[k] = 0.0;
+    const double* rb = K.r + (size_t)b * S.N;
+    const double beta = K.beta ? K.beta[b] : K.beta_scalar;
+    const double rho = (double)H * beta * S.kappa;         // newton_jacobian.jl:169-186 quirk
+    const double* dzb = S.dz + (size_t)b * H * nths * nd;
+    double* ws = S.kkt_ws + (size_t)b * H * (3 * n2 + nd);
+    constexpr int WSR = 3 * n2 + nd;
+
+    constexpr int PF_DZ = (nd * nths + 63) / 64, PF_Q = (nq * nq + 63) / 64, PF_R = (nu * nu + 63) / 64;
+    double pf_dz[PF_DZ], pf_q[PF_Q], pf_r[PF_R], pf_rp = 0.0, pf_rd = 0.0;
+    auto prefetch = [&](int i) {
+        if (i < 0 || i >= H) return;
+        const double* dzi = dzb + (size_t)i * nths * nd;
+#pragma unroll
+        for (int j = 0; j < PF_DZ; ++j) { const int k = lane + 64 * j; pf_dz[j] = (k < nd * nths) ? dzi[k] : 0.0; }
+#pragma unroll
+        for (int j = 0; j < PF_Q; ++j) { const int k = lane + 64 * j; pf_q[j] = (k < nq * nq) ? S.Qinv[(size_t)i * nq * nq + k] : 0.0; }
+#pragma unroll
+        for (int j = 0; j < PF_R; ++j) { const int k = lane + 64 * j; pf_r[j] = (k < nu * nu) ? S.Rinv[(size_t)i * nu * nu + k] : 0.0; }
+        pf_rp = (lane < nr) ? rb[i * nr + lane] : 0.0;
+        pf_rd = (lane < nd) ? rb[H * nr + i * nd + lane] : 0.0;
+    };
+    // registers -> LDS tiles of one step (dq0 -> a2, dq1 -> a1, du1 -> a0)
+    auto commit = [&](double* a0, double* a1, double* a2, double* qi, double* ri, double* ru, double* rq) {
+#pragma unroll
+        for (int j = 0; j < PF_DZ; ++j) {
+            const int k = lane + 64 * j;
+            if (k < nd * nths) {
+                const int r = k % nd, c = k / nd;
+                double* dst = (c < nq) ? (a2 + c * TL) : (c < 2 * nq) ? (a1 + (c - nq) * TL) : (a0 + (c - 2 * nq) * TL);
+                dst[r] = pf_dz[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PF_Q; ++j) { const int k = lane + 64 * j; if (k < nq * nq) qi[(k % nq) + (k / nq) * TL] = pf_q[j]; }
+#pragma unroll
+        for (int j = 0; j < PF_R; ++j) { const int k = lane + 64 * j; if (k < nu * nu) ri[(k % nu) + (k / nu) * TL] = pf_r[j]; }
+        if (lane < nu) ru[lane] = pf_rp;
+        else if (lane < nr) rq[lane - nu] = pf_rp;
+    };
+
+    prefetch(0);
+    for (int i = 0; i < H; ++i) {
+        const int m0 = i % 3, m1 = (i + 2) % 3, m2 = (i + 1) % 3, p0 = i & 1, p1 = (i + 1) & 1;
+        double* Li = tile(10 + m0);  double* Li1 = tile(10 + m1);  double* Li2 = tile(10 + m2);
+        double* L1c = tile(13 + p0); double* L1p = tile(13 + p1);
+        double* A1 = tile(2 + p0);   double* A1p = tile(2 + p1);
+        double* Qi0 = tile(15 + m0); double* Qi1 = tile(15 + m1);  double* Qi2 = tile(15 + m2);
+        double* yc = vec + 32 + 16 * m0; double* y1 = vec + 32 + 16 * m1; double* y2 = vec + 32 + 16 * m2;
+        double* q0r = vec + 96 + 16 * m0; double* q1r = vec + 96 + 16 * m1; double* q2r = vec + 96 + 16 * m2;
+        // ---- P1: step i operands -> LDS, fetch step i+1 ------------------------------------
+        commit(A0, A1, A2, Qi0, Ri, rpu, q0r);
+        const double rd_i = pf_rd;
+        lds_sync();
+        prefetch(i + 1);
+        // ---- P2: T0 = du1 Rinv, T1 = dq1 Qinv_{i-1}, T2 = dq0 Qinv_{i-2}  (Qinv, Rinv symmetric)
+        const d4 z4 = {0.0, 0.0, 0.0, 0.0};
+        tile_st(T0, tile_mma<KBU, false>(A0, Ri, z4, li, lk), li, lk);
+        if (i >= 1) tile_st(T1, tile_mma<KBQ, false>(A1, Qi1, z4, li, lk), li, lk);
+        if (i >= 2) tile_st(T2, tile_mma<KBQ, false>(A2, Qi2, z4, li, lk), li, lk);
+        lds_sync();
+        // ---- P3: Y_ii, Y_i,i-1, L2_i = -T2 L0_{i-2}^-T, beta_i -------------------------------
+        d4 y0 = tile_ld(Qi0, li, lk);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (li == lk + 4 * r && li < nd) y0[r] += rho;
+        y0 = tile_mma<KBU, false>(T0, A0, y0, li, lk);
+        d4 y1a = z4;
+        if (i >= 1) {
+            y0 = tile_mma<KBQ, false>(T1, A1, y0, li, lk);
+            y1a = -tile_ld(T1, li, lk);
+        }
+        if (i >= 2) {
+            y0 = tile_mma<KBQ, false>(T2, A2, y0, li, lk);
+            y1a = tile_mma<KBQ, false>(T2, A1p, y1a, li, lk);
+            tile_st(L2c, tile_mma<KBD, true>(T2, Li2, z4, li, lk), li, lk);
+        }
+        if (lane < nd) {   // beta_i = T0 rpu - Qinv_i rq_i + T1 rq_{i-1} + T2 rq_{i-2} - rd_i
+            double s = tile_mv<nu, false>(T0, rpu, lane) - tile_mv<nq, false>(Qi0, q0r, lane);
+            if (i >= 1) s += tile_mv<nq, false>(T1, q1r, lane);
+            if (i >= 2) s += tile_mv<nq, false>(T2, q2r, lane);
+            bet[lane] = s - rd_i;
+        }
+        lds_sync();
+        // ---- P4: Y1 -= L2 L1_{i-1}^T ; stage Y1 as an operand ------------------------------
+        if (i >= 1) {
+            if (i >= 2) y1a = tile_mma<KBD, true>(L2c, L1p, y1a, li, lk);
+            tile_st(Y1, y1a, li, lk);
+            lds_sync();
+            // ---- P5: L1_i = Y1 L0_{i-1}^-T -----------------------------------------------------
+            tile_st(L1c, tile_mma<KBD, false>(Y1, Li1, z4, li, lk), li, lk);
+            lds_sync();
+        }
+        // ---- P6: Lc = Y0 - L1 L1^T - L2 L2^T ; rhs of the forward substitution ---------------
+        if (i >= 1) y0 = tile_mma<KBD, true>(L1c, L1c, y0, li, lk);
+        if (i >= 2) y0 = tile_mma<KBD, true>(L2c, L2c, y0, li, lk);
+        tile_st(Lc, y0, li, lk);
+        if (lane < nd) {
+            double s = bet[lane];
+            if (i >= 1) s -= tile_mv<nd, false>(L1c, y1, lane);
+            if (i >= 2) s -= tile_mv<nd, false>(L2c, y2, lane);
+            tv[lane] = s;
+        }
+        lds_sync();
+        // ---- P7: Cholesky of Lc and L0^-1 in registers (lane = row, DPP broadcasts) -----------
+        {
+            using LG = LaneGroup<16>;
+            const int rl = li;
+            double a[nd], invd[nd];
+            static_for<0, nd>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                a[c] = (rl < nd) ? Lc[rl + c * TL] : ((c == rl) ? 1.0 : 0.0);
+            });
+            static_for<0, nd>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const double dk = LG::template bcast<k>(a[k]);
+                const double inv = fast_rsqrt(dk);
+                invd[k] = inv;
+                a[k] *= inv;
+                static_for<k + 1, nd>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    a[c] = fma(-a[k], LG::template bcast<c>(a[k]), a[c]);
+                });
+            });
+            double xc[nd];
+            static_for<0, nd>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                double acc = 0.0;
+                static_for<0, r>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    acc = fma(LG::template bcast<r>(a[k]), xc[k], acc);
+                });
+                xc[r] = (((r == rl) ? 1.0 : 0.0) - acc) * invd[r];
+            });
+            if (lane < nd) {
+                static_for<0, nd>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    Li[r + lane * TL] = xc[r];
+                });
+            }
+        }
+        lds_sync();
+        // ---- P8: y_i = L0^-1 tv ; spill (L1_i, L2_i, L0_i^-1, y_i) for the backward pass ------
+        double yi = 0.0;
+        if (lane < nd) {
+            yi = tile_mv<nd, false>(Li, tv, lane);
+            yc[lane] = yi;
+        }
+        double* wsi = ws + (size_t)i * WSR;
+        for (int k = lane; k < n2; k += 64) {
+            const int r = k % nd, c = k / nd;
+            wsi[k] = (i >= 1) ? L1c[r + c * TL] : 0.0;
+            wsi[n2 + k] = (i >= 2) ? L2c[r + c * TL] : 0.0;
+            wsi[2 * n2 + k] = Li[r + c * TL];
+        }
+        if (lane < nd) wsi[3 * n2 + lane] = yi;
+        lds_sync();
+    }
+    __threadfence_block();
+    lds_sync();
+    // =========================================================================================
+    // backward substitution fused with the primal recovery, step i = H-1 .. 0:
+    //   dnu_i = L0_i^-T (y_i - L1_{i+1}^T dnu_{i+1} - L2_{i+2}^T dnu_{i+2})
+    //   Du_i  = Rinv_i (rpu_i - du1_i^T dnu_i)
+    //   Dq_i  = Qinv_i (rpq_i + dnu_i - dq1_{i+1}^T dnu_{i+1} - dq0_{i+2}^T dnu_{i+2})
+    // rings (slot = step % 3): factors {L1, L2, Li} and sensitivities {du1, dq1, dq0}
+    // =========================================================================================
+    double* D = K.delta + (size_t)b * S.N;
+    // tiles 0..2: L1_j ring, 3..5: L2_j ring, 8..10: dq1_j ring, 11..13: dq0_j ring
+    double* FI = tile(6);                            // L0_i^-1
+    double* G0 = tile(7);                            // du1_i
+    double* BQ = tile(14); double* BR = tile(15);    // Qinv_i, Rinv_i
+    double* yb = vec;                                 // y_i
+    double* tu = vec + 80; double* tq = vec + 96; double* rq = vec + 112; double* ru = vec + 128;
+    constexpr int PF_W = (WSR + 63) / 64;
+    double pf_w[PF_W];
+    auto prefetch_b = [&](int i) {
+        if (i < 0) return;
+        prefetch(i);
+        const double* wsi = ws + (size_t)i * WSR;
+#pragma unroll
+        for (int j = 0; j < PF_W; ++j) { const int k = lane + 64 * j; pf_w[j] = (k < WSR) ? wsi[k] : 0.0; }
+    };
+    prefetch_b(H - 1);
+    for (int i = H - 1; i >= 0; --i) {
+        const int s0 = i % 3, s1 = (i + 1) % 3, s2 = (i + 2) % 3;
+        double* F1s0 = tile(0 + s0); double* F1s1 = tile(0 + s1);
+        double* F2s0 = tile(3 + s0); double* F2s2 = tile(3 + s2);
+        double* G1s0 = tile(8 + s0); double* G1s1 = tile(8 + s1);
+        double* G2s0 = tile(11 + s0); double* G2s2 = tile(11 + s2);
+        double* dn0 = vec + 32 + 16 * s0; double* dn1 = vec + 32 + 16 * s1; double* dn2 = vec + 32 + 16 * s2;
+        commit(G0, G1s0, G2s0, BQ, BR, ru, rq);
+#pragma unroll
+        for (int j = 0; j < PF_W; ++j) {
+            const int k = lane + 64 * j;
+            if (k < 3 * n2) {
+                const int t = k / n2, e = k - t * n2, r = e % nd, c = e / nd;
+                double* dst = (t == 0) ? F1s0 : (t == 1) ? F2s0 : FI;
+                dst[r + c * TL] = pf_w[j];
+            } else if (k < WSR) {
+                yb[k - 3 * n2] = pf_w[j];
+            }
+        }
+        lds_sync();
+        prefetch_b(i - 1);
+        double dni = 0.0;
+        if (lane < nd) {
+            double s = yb[lane];
+            if (i + 1 < H) s -= tile_mv<nd, true>(F1s1, dn1, lane);
+            if (i + 2 < H) s -= tile_mv<nd, true>(F2s2, dn2, lane);
+            tv[lane] = s;
+        }
+        lds_sync();
+        if (lane < nd) {
+            dni = tile_mv<nd, true>(FI, tv, lane);
+            dn0[lane] = dni;
+            D[H * nr + i * nd + lane] = dni;
+        }
+        lds_sync();
+        if (lane < nu) {
+            tu[lane] = ru[lane] - tile_mv<nd, true>(G0, dn0, lane);
+        } else if (lane >= 16 && lane < 16 + nq) {
+            const int c = lane - 16;
+            double s = rq[c] + dn0[c];
+            if (i + 1 < H) s -= tile_mv<nd, true>(G1s1, dn1, c);
+            if (i + 2 < H) s -= tile_mv<nd, true>(G2s2, dn2, c);
+            tq[c] = s;
+        }
+        lds_sync();
+        if (lane < nu) D[i * nr + lane] = tile_mv<nu, false>(BR, tu, lane);
+        else if (lane >= 16 && lane < 16 + nq) D[i * nr + nu + (lane - 16)] = tile_mv<nq, false>(BQ, tq, lane - 16);
+        lds_sync();
+    }
     if (K.finish) {
         __threadfence_block();
         lds_sync();
@@ -580,14 +993,19 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
 
 template <int NQ, int NU>
 static int launch_kkt_t(const NewtonDev& S, const KktArgs& K, hipStream_t s) {
-    constexpr int LD = ((NQ > NU ? NQ : NU) + 3) & ~3;
-    const size_t lds = (size_t)(KKT_TILES * LD * LD + 10 * LD) * sizeof(double);
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)kkt_kernel<NQ, NU>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return CIMPC_ERR_HIP;
+    if constexpr (NQ <= 16 && NU <= 16) {
+        const size_t lds = (size_t)(KKT_MFMA_TILES * TSZ + 208) * sizeof(double);
+        hipLaunchKernelGGL((kkt_kernel<NQ, NU>), dim3(S.dm.B), dim3(64), lds, s, S, K);
+    } else {
+        constexpr int LD = ((NQ > NU ? NQ : NU) + 3) & ~3;
+        const size_t lds = (size_t)(KKT_TILES * LD * LD + 10 * LD) * sizeof(double);
+        if (lds > 64 * 1024) {
+            if (hipFuncSetAttribute((const void*)kkt_kernel_scalar<NQ, NU>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return CIMPC_ERR_HIP;
+        }
+        hipLaunchKernelGGL((kkt_kernel_scalar<NQ, NU>), dim3(S.dm.B), dim3(64), lds, s, S, K);
     }
-    hipLaunchKernelGGL((kkt_kernel<NQ, NU>), dim3(S.dm.B), dim3(64), lds, s, S, K);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
 

@@ -34,6 +34,7 @@ class InteriorPointOptions:
     ls_scale: float = 0.5
     max_iter: int = 100
     max_ls: int = 3
+    stall_alpha: float = 1.0e-13
 
 
 @dataclass
@@ -73,7 +74,7 @@ class CIMPCSolver:
         newton_opts = newton_opts or NewtonOptions()
         self._ip = _lib.IpOpts(ip_opts.r_tol, ip_opts.kappa_tol, ip_opts.undercut, ip_opts.gamma_reg,
                                ip_opts.kappa_reg, ip_opts.eps_min, ip_opts.ls_scale, ip_opts.max_iter,
-                               ip_opts.max_ls)
+                               ip_opts.max_ls, ip_opts.stall_alpha)
         self._nt = _lib.NewtonOpts(newton_opts.r_tol, newton_opts.beta_init, newton_opts.max_time,
                                    newton_opts.kappa, newton_opts.max_iter, 0)
         self.h = C.c_void_p()

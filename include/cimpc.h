@@ -59,6 +59,7 @@ typedef struct cimpc_ip_opts {
     double ls_scale;   /* 0.5   */
     int max_iter;      /* 100   */
     int max_ls;        /* 3     */
+    double stall_alpha; /* 1e-13: stall exit (DESIGN.md "IP iteration spec"); 0 = never exit early */
 } cimpc_ip_opts;
 
 /* NewtonOptions (newton.jl:2-11) + the central-path parameter used for the dual

@@ -34,6 +34,7 @@ typedef struct {
     /* options */
     double r_tol, kappa_tol, undercut, gamma_reg, kappa_reg, eps_min, ls_scale;
     int ip_max_iter, max_ls;
+    double stall_alpha;
     double n_r_tol, beta_init, kappa;
     int n_max_iter;
     /* IP workspace */
@@ -91,10 +92,12 @@ Ref *ref_create(int nq, int nu, int nw, int nc, int nb, int mode, int H_ref, int
     s->qs = dalloc((size_t)ny * ny); s->rs = dalloc((size_t)ny * (ny + 1) / 2); s->D = dalloc((size_t)ny * ny);
     s->xv = dalloc(ny); s->tmp = dalloc(nx + ny + nth); s->tmp2 = dalloc(nx + ny + nth); s->u = dalloc(nx); s->v = dalloc(ny);
     s->r_tol = 1e-8; s->kappa_tol = 2e-4; s->undercut = 5; s->gamma_reg = 0.1; s->kappa_reg = 1e-3;
-    s->eps_min = 0.05; s->ls_scale = 0.5; s->ip_max_iter = 100; s->max_ls = 3;
+    s->eps_min = 0.05; s->ls_scale = 0.5; s->ip_max_iter = 100; s->max_ls = 3; s->stall_alpha = 1e-13;
     s->n_r_tol = 3e-4; s->beta_init = 1e-5; s->kappa = 2e-4; s->n_max_iter = 5;
     return s;
 }
+
+void ref_set_stall(Ref *s, double stall_alpha) { s->stall_alpha = stall_alpha; }
 
 void ref_set_opts(Ref *s, double r_tol, double kappa_tol, double undercut, double gamma_reg, double kappa_reg,
                   double eps_min, double ls_scale, int ip_max_iter, int max_ls, double n_r_tol,
@@ -331,6 +334,7 @@ static int ip_solve(Ref *s, int t, double *z, const double *th, const double *al
         double vm = fmax(r_vio, k_vio);
         double tau = fmax(1.0 - s->eps_min, 1.0 - vm * vm);
         double alpha = step_length(z + nx, Delta + nx, 2 * ny, tau, 1.0);
+        if (alpha < s->stall_alpha) break;                 /* [spec] stall exit */
         for (int i = 0; i < nz; ++i) z[i] -= alpha * Delta[i];
         double k_c = 0, r_c = 0;
         for (int ls = 1; ls <= s->max_ls; ++ls) {

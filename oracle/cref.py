@@ -27,6 +27,7 @@ def load():
         lib.ref_create.argtypes = [C.c_int] * 8
         lib.ref_destroy.argtypes = [C.c_void_p]
         lib.ref_set_opts.argtypes = [C.c_void_p] + [C.c_double] * 7 + [C.c_int, C.c_int] + [C.c_double] * 3 + [C.c_int]
+        lib.ref_set_stall.argtypes = [C.c_void_p, C.c_double]
         lib.ref_set_linearization.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp]
         lib.ref_set_objective.argtypes = [C.c_void_p, _dp, _dp]
         lib.ref_implicit_dynamics.argtypes = [C.c_void_p, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp]
@@ -55,6 +56,7 @@ class CRef:
             no = no or NewtonOptions(r_tol=3e-4, max_iter=5)
             self.lib.ref_set_opts(self.h, io.r_tol, io.kappa_tol, io.undercut, io.gamma_reg, io.kappa_reg, io.eps_min,
                                   io.ls_scale, io.max_iter, io.max_ls, no.r_tol, no.beta_init, kappa, no.max_iter)
+            self.lib.ref_set_stall(self.h, io.stall_alpha)
         if prob is not None:
             for t in range(H_ref):
                 rz = np.asfortranarray(prob["rz0"][t]); rt = np.asfortranarray(prob["rth0"][t])

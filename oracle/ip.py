@@ -38,6 +38,7 @@ class IPOptions:
     max_iter: int = 100
     max_ls: int = 3
     diff_sol: bool = True
+    stall_alpha: float = 1.0e-13   # [spec] stall exit, 0 disables (strict max_iter semantics)
 
 
 def step_length(y1, y2, dy1, dy2, tau):
@@ -93,6 +94,12 @@ def interior_point_solve(tab: lcp.LinTable, z, th, opts: IPOptions, trace=None):
         # [spec] fraction to boundary
         tau = max(1.0 - opts.eps_min, 1.0 - max(r_vio, k_vio) ** 2)
         alpha = step_length(z[iy1], z[iy2], D[iy1], D[iy2], tau)
+        # [spec] stall exit: a step length below fp64 resolution means the iterate is jammed on
+        # the boundary (every later iteration repeats the same blocked direction with a
+        # geometrically shrinking alpha); converging solves never go below ~1e-3.  The solve
+        # ends with status = false exactly as it would after max_iter iterations.
+        if alpha < opts.stall_alpha:
+            break
         # candidate point z <- z - alpha*D, residual-decrease line search
         z -= alpha * D
         k_c = r_c = 0.0

@@ -34,8 +34,8 @@ def test_implicit_dynamics_matches_oracle(gpu_required, model, mode, B, H, H_ref
     out = s.implicit_dynamics(q, th, g, bb, want_z=True)
     for b, (tr, o) in enumerate(ref):
         assert np.array_equal(out["status"][b], o["status"]), (out["status"][b], o["status"])
-        assert np.array_equal(out["iters"][b], o["iters"]), (out["iters"][b], o["iters"])
         ok = o["status"] == 1          # failed solves (status = false) only have to agree on the flag
+        assert np.array_equal(out["iters"][b][ok], o["iters"][ok]), (out["iters"][b], o["iters"])
         assert ok.mean() >= 0.75
         np.testing.assert_allclose(out["z"][b][ok], o["z"][ok], rtol=0, atol=1e-6)
         np.testing.assert_allclose(out["d"][b][ok], o["d"][ok], rtol=0, atol=1e-7)
