@@ -51,6 +51,8 @@ struct cimpc_ctx {
            *d_Cb = nullptr;
     double *d_q0 = nullptr, *d_q1 = nullptr;
     double* d_rhs = nullptr;   // B1 seam staging
+    double* d_pstate = nullptr;   // parked interior-point iterates
+    int iter_cap = 16;
     NewtonDev S{};
     int* h_counters = nullptr;   // pinned
     // bookkeeping
@@ -182,6 +184,10 @@ IpParams make_ip_params(cimpc_ctx* h, const TrajDev& T, const int* need_sweep, d
     p.status = h->S.ip_status;
     p.iters = h->S.ip_iters;
     p.zout = zout;
+    p.pflag = h->S.pflag;
+    p.pstate = h->d_pstate;
+    p.pending_count = h->S.counters + 2;
+    p.iter_cap = h->iter_cap;
     p.H = h->dm.H;
     p.o = h->ip;
     return p;
@@ -328,6 +334,8 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     A(&S.dz, B * H * h->nths * h->nd);
     A(&S.ip_status, B * H);
     A(&S.ip_iters, B * H);
+    A(&S.pflag, B * H);
+    A(&h->d_pstate, B * H * (2 * (size_t)h->nx + 4 * (size_t)h->ny + 4));
     A(&S.res, B * h->N);
     A(&S.res_cand, B * h->N);
     A(&S.delta, B * h->N);
@@ -556,8 +564,16 @@ int cimpc_implicit_dynamics(cimpc_handle h, const double* q, const double* theta
     HIP_TRY(h, hipMemcpyAsync(T.th, theta, B * H * h->nth * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (gamma) HIP_TRY(h, hipMemcpyAsync(T.g, gamma, B * H * d.nc * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (b) HIP_TRY(h, hipMemcpyAsync(T.b, b, B * H * d.nb * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    rc = run_sweep(h, T, nullptr, z ? h->d_zout : nullptr);
-    if (rc != CIMPC_OK) return rc;
+    HIP_TRY(h, hipMemsetAsync(h->S.pflag, 0, B * H * sizeof(int), h->stream));
+    for (int pass = 0; pass < 64; ++pass) {     // resumable solves: relaunch until nothing is parked
+        HIP_TRY(h, hipMemsetAsync(h->S.counters, 0, 8 * sizeof(int), h->stream));
+        rc = run_sweep(h, T, nullptr, z ? h->d_zout : nullptr);
+        if (rc != CIMPC_OK) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->h_counters, h->S.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->h_counters[2] == 0) break;
+    }
+    HIP_TRY(h, hipMemsetAsync(h->S.pflag, 0, B * H * sizeof(int), h->stream));
     if (d_out) HIP_TRY(h, hipMemcpyAsync(d_out, h->S.d, B * H * h->nd * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (dz) HIP_TRY(h, hipMemcpyAsync(dz, h->S.dz, B * H * h->nths * h->nd * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (status) HIP_TRY(h, hipMemcpyAsync(status, h->S.ip_status, B * H * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -602,7 +618,9 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     if (rc != CIMPC_OK) return fail(h, rc, "reset launch failed");
     long long rounds = 0;
     int n_kkt = 0;
-    const int max_rounds = h->nt.max_iter * 8 + 2;
+    // safety net only: every Newton iteration needs at most 8 evaluations, each evaluation at most
+    // ceil(max_iter / iter_cap) launches of the resumable interior-point sweep
+    const int max_rounds = (h->nt.max_iter * 8 + 2) * ((h->ip.max_iter + h->iter_cap - 1) / h->iter_cap + 1);
     while (true) {
         // ---- one lock-step round: [KKT for rollouts that start an iteration] -> sweep ->
         //      residual + line-search decision

@@ -25,6 +25,13 @@ struct IpParams {
     int* status;           // [B][H]  1 = converged
     int* iters;            // [B][H]  IP iterations
     double* zout;          // [B][H][nz] converged z (optional, null = skip)
+    // resumable solves: a launch runs at most iter_cap IP iterations per problem; unfinished
+    // problems park their iterate here and continue in the next launch, so that one hard
+    // instance (up to max_iter = 100 iterations) never stalls the whole batch
+    int* pflag;            // [B][H] 0 = fresh, 1 = pending (resume), 2 = done for this evaluation
+    double* pstate;        // [B][H][2nx + 4ny + 4]
+    int* pending_count;    // device counter, incremented once per parked problem
+    int iter_cap;
     int H;
     cimpc_ip_opts o;
 };

@@ -215,15 +215,17 @@ struct IpSolver {
         return LG::all_min(a);
     }
 
-    // interior-point iteration (DESIGN.md "IP iteration spec"); returns status, sets iters/reg
-    __device__ __forceinline__ bool solve(const cimpc_ip_opts& o, int& iters, double& reg) {
-        residual(0.0);
-        double r_vio = r_violation();
-        double k_vio = k_violation();
-        iters = 0;
-        reg = 0.0;
-        for (int j = 0; j < o.max_iter; ++j) {
-            if (r_vio < o.r_tol && k_vio < o.kappa_tol) break;
+    // interior-point iteration (DESIGN.md "IP iteration spec").  Runs at most `cap` iterations
+    // in this launch; returns 1 = converged, 0 = failed (max_iter / stall), 2 = parked (resume
+    // later from exactly this state: iterate, residual, violations, reg, iters).
+    __device__ __forceinline__ int solve(const cimpc_ip_opts& o, int& iters, double& reg, double& r_vio,
+                                         double& k_vio, int cap) {
+        int done = 0;
+        while (true) {
+            if (r_vio < o.r_tol && k_vio < o.kappa_tol) return 1;
+            if (iters >= o.max_iter) return 0;
+            if (done >= cap) return 2;
+            ++done;
             ++iters;
             reg = (k_vio < o.kappa_reg) ? k_vio * o.gamma_reg : 0.0;
             factorize(reg);
@@ -241,7 +243,7 @@ struct IpSolver {
             const double vm = fmax(r_vio, k_vio);
             const double tau = fmax(1.0 - o.eps_min, 1.0 - vm * vm);
             const double alpha = step_length(tau);
-            if (alpha < o.stall_alpha) break;                 // [spec] stall exit: jammed on the boundary
+            if (alpha < o.stall_alpha) return 0;              // [spec] stall exit: jammed on the boundary
             x -= alpha * Dx_;
             y1 = vy ? (y1 - alpha * Dy1_) : 1.0;
             y2 = vy ? (y2 - alpha * Dy2_) : 1.0;
@@ -259,7 +261,6 @@ struct IpSolver {
             k_vio = k_c;
             r_vio = r_c;
         }
-        return (r_vio < o.r_tol) && (k_vio < o.kappa_tol);
     }
 };
 
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) void ip_sweep_kernel(IpParams p) {
         const int prob = p.plist[start + grp];
         b = prob / p.H;
         i = prob - b * p.H;
-        active = (p.need_sweep == nullptr) || (p.need_sweep[b] != 0);
+        active = ((p.need_sweep == nullptr) || (p.need_sweep[b] != 0)) && (p.pflag[prob] != 2);
     }
     // rollouts that are not being evaluated in this round (line search finished or still
     // backtracking elsewhere) leave holes: skip the table staging when the whole workgroup is idle
@@ -329,14 +330,41 @@ __global__ __launch_bounds__(256) void ip_sweep_kernel(IpParams p) {
 
     const double* qrow = p.q + ((size_t)b * (p.H + 2) + (i + 2)) * M::NQ;
     const double qinit = vx ? qrow[l] : 0.0;
-    // z_initialize!: z .= 1, z[iq2] = q   (simulation.jl:59-63)
-    S.x = qinit; S.y1 = 1.0; S.y2 = 1.0;
-
-    int iters;
-    double reg;
-    const bool ok = S.solve(p.o, iters, reg);
-
     const size_t pi = (size_t)b * p.H + i;
+    constexpr int PS = 2 * NX + 4 * NY + 4;
+    double* ps = p.pstate + pi * PS;
+    int iters;
+    double reg, r_vio, k_vio;
+    if (p.pflag[pi] == 1) {      // resume a parked solve
+        S.x = vx ? ps[l] : 0.0;
+        S.y1 = vy ? ps[NX + l] : 1.0;
+        S.y2 = vy ? ps[NX + NY + l] : 1.0;
+        S.rdyn = vx ? ps[NX + 2 * NY + l] : 0.0;
+        S.rrst = vy ? ps[2 * NX + 2 * NY + l] : 0.0;
+        S.rbil = vy ? ps[2 * NX + 3 * NY + l] : 0.0;
+        r_vio = ps[PS - 4]; k_vio = ps[PS - 3]; reg = ps[PS - 2]; iters = (int)ps[PS - 1];
+    } else {
+        // z_initialize!: z .= 1, z[iq2] = q   (simulation.jl:59-63)
+        S.x = qinit; S.y1 = 1.0; S.y2 = 1.0;
+        S.residual(0.0);
+        r_vio = S.r_violation();
+        k_vio = S.k_violation();
+        iters = 0;
+        reg = 0.0;
+    }
+    const int code = S.solve(p.o, iters, reg, r_vio, k_vio, p.iter_cap);
+    if (code == 2) {             // park: exact state, continue in the next launch
+        if (vx) { ps[l] = S.x; ps[NX + 2 * NY + l] = S.rdyn; }
+        if (vy) { ps[NX + l] = S.y1; ps[NX + NY + l] = S.y2; ps[2 * NX + 2 * NY + l] = S.rrst; ps[2 * NX + 3 * NY + l] = S.rbil; }
+        if (l == 0) {
+            ps[PS - 4] = r_vio; ps[PS - 3] = k_vio; ps[PS - 2] = reg; ps[PS - 1] = (double)iters;
+            p.pflag[pi] = 1;
+            atomicAdd(p.pending_count, 1);
+        }
+        return;
+    }
+    const bool ok = code == 1;
+    if (l == 0) p.pflag[pi] = 2;
     if (l == 0) {
         p.status[pi] = ok ? 1 : 0;
         p.iters[pi] = iters;

@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void reset_kernel(NewtonDev S, const double* q
         S.ro_ip_iters[b] = 0;
         S.ro_ip_fail[b] = 0;
     }
+    for (int k = tid; k < H; k += nt) S.pflag[(size_t)b * H + k] = 0;
 }
 
 // x_cand = x - alpha*Delta for q_{t+2}, u_t, nu_t  (+ gamma, b in cf mode), then update_theta!
@@ -124,6 +125,15 @@ __global__ __launch_bounds__(256) void resid_decide_kernel(NewtonDev S) {
     const cimpc_dims& m = S.dm;
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     if (S.need_sweep[b] == 0) return;     // nothing was evaluated for this rollout
+    {   // an interior-point solve of this evaluation is still parked: wait for the next launch
+        int pend = 0;
+        for (int k = tid; k < m.H; k += nt) pend |= (S.pflag[(size_t)b * m.H + k] == 1);
+        if (__syncthreads_or(pend)) {
+            if (tid == 0) atomicAdd(&S.counters[0], 1);
+            return;
+        }
+        for (int k = tid; k < m.H; k += nt) S.pflag[(size_t)b * m.H + k] = 0;   // evaluation consumed
+    }
     const int H = m.H, nq = m.nq, nu = m.nu, nc = m.nc, nb = m.nb, nr = S.nr, nd = S.nd;
     const int nths = S.nths;
     const bool cf = m.mode == CIMPC_MODE_CONFIGURATIONFORCE;

@@ -29,6 +29,7 @@ struct NewtonDev {
     double* dz;        // [B][H][nths][nd]
     int* ip_status;    // [B][H]
     int* ip_iters;     // [B][H]
+    int* pflag;        // [B][H] resumable-solve flags (see IpParams)
     // Newton vectors, reference layout (newton_residual.jl:69-98)
     double* res;       // [B][N]
     double* res_cand;  // [B][N]

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void ub(double* out, long long* cyc, int reps)
         if constexpr (PHASE == 3) { double t = S.qr_solve(S.rrst + 1e-9 * sink); sink += t; }
         if constexpr (PHASE == 4) { double a = S.step_length(0.99); double m = IpSolver<M>::LG::all_sum(S.y1 * S.y2 + 1e-9 * sink); sink += a + m + S.r_violation(); S.Dy1_ += 1e-9 * sink; }
         if constexpr (PHASE == 5) { cimpc_ip_opts o; o.r_tol = 1e-8; o.kappa_tol = 2e-4; o.undercut = 5; o.gamma_reg = 0.1; o.kappa_reg = 1e-3; o.eps_min = 0.05; o.ls_scale = 0.5; o.max_iter = 8; o.max_ls = 3; o.stall_alpha = 1e-13;
-                                    int it; double rg; S.x = 0.1 * l; S.y1 = 1.0; S.y2 = 1.0; S.solve(o, it, rg); sink += S.x + it; }
+                                    int it = 0; double rg = 0, rv, kv; S.x = 0.1 * l; S.y1 = 1.0; S.y2 = 1.0; S.residual(0.0); rv = S.r_violation(); kv = S.k_violation(); S.solve(o, it, rg, rv, kv, 1000); sink += S.x + it; }
     }
     const long long t1 = clock64();
     if (tid == 0) cyc[blockIdx.x] = t1 - t0;
