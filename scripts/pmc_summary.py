@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 --pmc counter_collection CSVs per kernel: dispatches, sum, average.
+usage: pmc_summary.py <counter_collection.csv>... > summary.csv"""
+import collections
+import csv
+import sys
+
+print("kernel,counter,dispatches,sum,avg_per_dispatch")
+for path in sys.argv[1:]:
+    tot = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        k = (r["Kernel_Name"].split("(")[0].replace(",", ";"), r["Counter_Name"])
+        tot[k][0] += 1
+        tot[k][1] += float(r["Counter_Value"])
+    for (kn, cn), (n, s) in sorted(tot.items()):
+        if kn.startswith("__amd_rocclr"):
+            continue
+        print('"%s",%s,%d,%.6g,%.6g' % (kn, cn, n, s, s / n))
