@@ -52,6 +52,7 @@ struct cimpc_ctx {
     double *d_q0 = nullptr, *d_q1 = nullptr;
     double* d_rhs = nullptr;   // B1 seam staging
     double* d_pstate = nullptr;   // parked interior-point iterates
+    int* d_need_first = nullptr;  // need_sweep pattern {1,0,0,0} per rollout (B3 seam)
     int iter_cap = 16;
     NewtonDev S{};
     int* h_counters = nullptr;   // pinned
@@ -188,6 +189,7 @@ IpParams make_ip_params(cimpc_ctx* h, const TrajDev& T, const int* need_sweep, d
     p.pstate = h->d_pstate;
     p.pending_count = h->S.counters + 2;
     p.iter_cap = h->iter_cap;
+    p.slots = CS;
     p.H = h->dm.H;
     p.o = h->ip;
     return p;
@@ -303,11 +305,11 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     auto A = [&](auto** p, size_t n) { if (rc == CIMPC_OK) rc = dev_alloc(h, p, n); };
     A(&h->d_tab, (size_t)d.H_ref * h->ki.tab_size);
     const int ppw = 64 / h->ki.G;
-    const size_t max_wg = (B * H + 0) / 1 + d.H_ref;   // generous upper bound (1 problem / wg)
+    const size_t max_wg = B * CS * H + (size_t)d.H_ref * CS;   // generous upper bound (1 problem / wg)
     A(&h->d_wg_desc, 4 * max_wg);
-    A(&h->d_plist, B * H);
+    A(&h->d_plist, B * CS * H);
     A(&h->d_alt, B * d.nc);
-    A(&h->d_zout, B * H * h->nz);
+    A(&h->d_zout, B * CS * H * h->nz);
     A(&h->d_Q, H * d.nq * d.nq);
     A(&h->d_R, H * d.nu * d.nu);
     A(&h->d_Qinv, H * d.nq * d.nq);
@@ -320,27 +322,31 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     NewtonDev& S = h->S;
     S.dm = d;
     S.nd = h->nd; S.nr = h->nr; S.nth = h->nth; S.nths = h->nths; S.N = h->N;
+    const size_t BS = B * CS;     // evaluation slots (speculative line search)
     for (TrajDev* T : {&S.traj, &S.cand, &S.ref}) {
-        A(&T->q, B * (H + 2) * d.nq);
-        A(&T->u, B * H * d.nu);
-        A(&T->w, B * H * d.nw);
-        A(&T->g, B * H * d.nc);
-        A(&T->b, B * H * d.nb);
-        A(&T->th, B * H * h->nth);
+        const size_t n = (T == &S.cand) ? BS : B;
+        A(&T->q, n * (H + 2) * d.nq);
+        A(&T->u, n * H * d.nu);
+        A(&T->w, n * H * d.nw);
+        A(&T->g, n * H * d.nc);
+        A(&T->b, n * H * d.nb);
+        A(&T->th, n * H * h->nth);
     }
     A(&S.nu, B * H * h->nd);
-    A(&S.nu_cand, B * H * h->nd);
-    A(&S.d, B * H * h->nd);
-    A(&S.dz, B * H * h->nths * h->nd);
-    A(&S.ip_status, B * H);
-    A(&S.ip_iters, B * H);
-    A(&S.pflag, B * H);
-    A(&h->d_pstate, B * H * (2 * (size_t)h->nx + 4 * (size_t)h->ny + 4));
+    A(&S.nu_cand, BS * H * h->nd);
+    A(&S.d, BS * H * h->nd);
+    A(&S.dz, BS * H * h->nths * h->nd);
+    A(&S.ip_status, BS * H);
+    A(&S.ip_iters, BS * H);
+    A(&S.pflag, BS * H);
+    A(&S.cur_slot, B);
+    A(&h->d_pstate, BS * H * (2 * (size_t)h->nx + 4 * (size_t)h->ny + 4));
     A(&S.res, B * h->N);
-    A(&S.res_cand, B * h->N);
+    A(&S.res_cand, BS * h->N);
     A(&S.delta, B * h->N);
-    A(&S.r_norm, B); A(&S.r_cand, B); A(&S.alpha, B); A(&S.beta, B);
-    A(&S.ls_iter, B); A(&S.newton_l, B); A(&S.stage, B); A(&S.need_sweep, B);
+    A(&S.r_norm, B); A(&S.r_cand, BS); A(&S.alpha, B); A(&S.beta, B);
+    A(&S.ls_iter, B); A(&S.newton_l, B); A(&S.stage, B); A(&S.need_sweep, BS);
+    A(&h->d_need_first, BS);
     A(&S.counters, 8);
     A(&S.stats, 4);
     A(&S.ro_sweeps, B); A(&S.ro_ip_iters, B); A(&S.ro_ip_fail, B);
@@ -497,7 +503,9 @@ int cimpc_set_window(cimpc_handle h, const int* window) {
     if (!h || !window) return fail(h, CIMPC_ERR_INVALID, "null argument");
     const cimpc_dims& d = h->dm;
     const int B = d.B, H = d.H, K = d.H_ref;
-    // bucket problems (b, i) by reference knot window[b][i] (counting sort)
+    // bucket problems (slot sb = b*CS + c, i) by reference knot window[b][i]; inside a knot the
+    // order is (c, b) so that the slots evaluated together (c = 0 in most rounds) fill whole
+    // workgroups and the others form workgroups that exit before staging anything
     std::vector<int> cnt(K + 1, 0);
     for (int b = 0; b < B; ++b)
         for (int i = 0; i < H; ++i) {
@@ -505,22 +513,26 @@ int cimpc_set_window(cimpc_handle h, const int* window) {
             if (t < 1 || t > K) return fail(h, CIMPC_ERR_INVALID, "window entry out of range (1-based knot index)");
             cnt[t]++;
         }
-    std::vector<int> off(K + 2, 0);
-    for (int t = 1; t <= K; ++t) off[t + 1] = off[t] + cnt[t];
-    std::vector<int> plist((size_t)B * H), fill(off.begin(), off.end());
-    for (int b = 0; b < B; ++b)
-        for (int i = 0; i < H; ++i) {
-            const int t = window[(size_t)b * (H + 2) + i];
-            plist[fill[t]++] = b * H + i;
-        }
     const int pw = (64 / h->ki.G) * h->waves;   // problems per workgroup
+    std::vector<int> plist;
+    plist.reserve((size_t)B * CS * H);
     std::vector<int> desc;
+    std::vector<std::vector<int>> per_knot(K + 1);
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < H; ++i) per_knot[window[(size_t)b * (H + 2) + i]].push_back(b * H + i);
     for (int t = 1; t <= K; ++t)
-        for (int s = 0; s < cnt[t]; s += pw) {
-            desc.push_back(t - 1);
-            desc.push_back(off[t] + s);
-            desc.push_back(std::min(pw, cnt[t] - s));
-            desc.push_back(0);
+        for (int c = 0; c < CS; ++c) {
+            const int first = (int)plist.size();
+            for (int e : per_knot[t]) {
+                const int b = e / H, i = e - b * H;
+                plist.push_back((b * CS + c) * H + i);
+            }
+            for (int s0 = 0; s0 < cnt[t]; s0 += pw) {
+                desc.push_back(t - 1);
+                desc.push_back(first + s0);
+                desc.push_back(std::min(pw, cnt[t] - s0));
+                desc.push_back(0);
+            }
         }
     h->n_wg = (int)desc.size() / 4;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -560,25 +572,40 @@ int cimpc_implicit_dynamics(cimpc_handle h, const double* q, const double* theta
         return fail(h, CIMPC_ERR_INVALID, "gamma and b are required in configurationforce mode");
     HIP_TRY(h, hipSetDevice(h->device));
     TrajDev& T = h->S.cand;
-    HIP_TRY(h, hipMemcpyAsync(T.q, q, B * (H + 2) * d.nq * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(T.th, theta, B * H * h->nth * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (gamma) HIP_TRY(h, hipMemcpyAsync(T.g, gamma, B * H * d.nc * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (b) HIP_TRY(h, hipMemcpyAsync(T.b, b, B * H * d.nb * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->S.pflag, 0, B * H * sizeof(int), h->stream));
+    // evaluation slot 0 of every rollout (slot stride = CS rows)
+    auto up = [&](double* dst, const double* src, size_t row_doubles) {
+        return hipMemcpy2DAsync(dst, CS * row_doubles * sizeof(double), src, row_doubles * sizeof(double),
+                                row_doubles * sizeof(double), B, hipMemcpyHostToDevice, h->stream);
+    };
+    HIP_TRY(h, up(T.q, q, (H + 2) * d.nq));
+    HIP_TRY(h, up(T.th, theta, H * h->nth));
+    if (gamma) HIP_TRY(h, up(T.g, gamma, H * d.nc));
+    if (b) HIP_TRY(h, up(T.b, b, H * d.nb));
+    {
+        std::vector<int> pat(B * CS, 0);
+        for (size_t r = 0; r < B; ++r) pat[r * CS] = 1;
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipMemcpy(h->d_need_first, pat.data(), pat.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(h, hipMemsetAsync(h->S.pflag, 0, B * CS * H * sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->S.cur_slot, 0, B * sizeof(int), h->stream));
     for (int pass = 0; pass < 64; ++pass) {     // resumable solves: relaunch until nothing is parked
         HIP_TRY(h, hipMemsetAsync(h->S.counters, 0, 8 * sizeof(int), h->stream));
-        rc = run_sweep(h, T, nullptr, z ? h->d_zout : nullptr);
+        rc = run_sweep(h, T, h->d_need_first, z ? h->d_zout : nullptr);
         if (rc != CIMPC_OK) return rc;
         HIP_TRY(h, hipMemcpyAsync(h->h_counters, h->S.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         if (h->h_counters[2] == 0) break;
     }
-    HIP_TRY(h, hipMemsetAsync(h->S.pflag, 0, B * H * sizeof(int), h->stream));
-    if (d_out) HIP_TRY(h, hipMemcpyAsync(d_out, h->S.d, B * H * h->nd * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    if (dz) HIP_TRY(h, hipMemcpyAsync(dz, h->S.dz, B * H * h->nths * h->nd * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    if (status) HIP_TRY(h, hipMemcpyAsync(status, h->S.ip_status, B * H * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    if (iters) HIP_TRY(h, hipMemcpyAsync(iters, h->S.ip_iters, B * H * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    if (z) HIP_TRY(h, hipMemcpyAsync(z, h->d_zout, B * H * h->nz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->S.pflag, 0, B * CS * H * sizeof(int), h->stream));
+    auto down = [&](void* dst, const void* src, size_t row_bytes) {
+        return hipMemcpy2DAsync(dst, row_bytes, src, CS * row_bytes, row_bytes, B, hipMemcpyDeviceToHost, h->stream);
+    };
+    if (d_out) HIP_TRY(h, down(d_out, h->S.d, H * h->nd * sizeof(double)));
+    if (dz) HIP_TRY(h, down(dz, h->S.dz, H * h->nths * h->nd * sizeof(double)));
+    if (status) HIP_TRY(h, down(status, h->S.ip_status, H * sizeof(int)));
+    if (iters) HIP_TRY(h, down(iters, h->S.ip_iters, H * sizeof(int)));
+    if (z) HIP_TRY(h, down(z, h->d_zout, H * h->nz * sizeof(double)));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return CIMPC_OK;
 }

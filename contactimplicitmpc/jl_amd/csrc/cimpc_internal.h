@@ -32,6 +32,7 @@ struct IpParams {
     double* pstate;        // [B][H][2nx + 4ny + 4]
     int* pending_count;    // device counter, incremented once per parked problem
     int iter_cap;
+    int slots;             // evaluation slots per rollout: the index b below is a slot, rollout = b / slots
     int H;
     cimpc_ip_opts o;
 };

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void ip_sweep_kernel(IpParams p) {
         S.tthdyn = a0 + a1;
         S.tthrst = c0 + c1;
     }
-    if (p.alt != nullptr && l < NC) S.altl = p.alt[(size_t)b * NC + l];
+    if (p.alt != nullptr && l < NC) S.altl = p.alt[(size_t)(b / p.slots) * NC + l];
 
     const double* qrow = p.q + ((size_t)b * (p.H + 2) + (i + 2)) * M::NQ;
     const double qinit = vx ? qrow[l] : 0.0;

@@ -32,16 +32,30 @@ __device__ __forceinline__ void copy_n(double* dst, const double* src, int n, in
     for (int k = tid; k < n; k += nt) dst[k] = src[k];
 }
 
+// Candidate slots.  The reference's backtracking line search (newton.jl:223-269) evaluates
+// alpha = 1, 1/2, ..., 1/64 one after the other, each evaluation being a full implicit_dynamics!
+// sweep.  Here a rollout owns CS = 4 evaluation slots and the SAME sequence is evaluated
+// speculatively in at most three lock-step rounds:
+//     round A: alpha = 1                      (slot 0)
+//     round B: alpha = 1/2, 1/4               (slots 0-1)
+//     round C: alpha = 1/8, 1/16, 1/32, 1/64  (slots 0-3)
+// and the first alpha (in the reference's order) that passes the Armijo-type test is taken, so the
+// accepted step, residual and implicit-dynamics data are exactly those the sequential loop would
+// have produced.  Every "evaluation" array (candidate trajectory, nu_cand, d, dz, status,
+// res_cand, ...) is indexed by slot sb = b*CS + c; cur_slot[b] names the slot whose d / dz are the
+// current im_traj of rollout b.
+__device__ __forceinline__ double ls_alpha(int iter) { return ldexp(1.0, -iter); }
+
 __global__ __launch_bounds__(256) void reset_kernel(NewtonDev S, const double* q0,
                                                     const double* q1, int warm) {
     const cimpc_dims& m = S.dm;
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int H = m.H;
     const size_t oq = (size_t)b * (H + 2) * m.nq;
+    const size_t sb0 = (size_t)b * CS;
     if (!warm) {
         for (int k = tid; k < H * S.nd; k += nt) {
             S.nu[(size_t)b * H * S.nd + k] = 0.0;
-            S.nu_cand[(size_t)b * H * S.nd + k] = 0.0;
         }
         copy_n(S.traj.q + oq, S.ref.q + oq, (H + 2) * m.nq, tid, nt);
         copy_n(S.traj.u + (size_t)b * H * m.nu, S.ref.u + (size_t)b * H * m.nu, H * m.nu, tid, nt);
@@ -59,18 +73,21 @@ __global__ __launch_bounds__(256) void reset_kernel(NewtonDev S, const double* q
     theta_update(S, S.traj, b, 0, tid, nt);
     if (H > 1) theta_update(S, S.traj, b, 1, tid, nt);
     __syncthreads();
-    // copy_traj!(traj_cand, traj)
-    copy_n(S.cand.q + oq, S.traj.q + oq, (H + 2) * m.nq, tid, nt);
-    copy_n(S.cand.u + (size_t)b * H * m.nu, S.traj.u + (size_t)b * H * m.nu, H * m.nu, tid, nt);
-    copy_n(S.cand.w + (size_t)b * H * m.nw, S.traj.w + (size_t)b * H * m.nw, H * m.nw, tid, nt);
-    copy_n(S.cand.g + (size_t)b * H * m.nc, S.traj.g + (size_t)b * H * m.nc, H * m.nc, tid, nt);
-    copy_n(S.cand.b + (size_t)b * H * m.nb, S.traj.b + (size_t)b * H * m.nb, H * m.nb, tid, nt);
-    copy_n(S.cand.th + (size_t)b * H * S.nth, S.traj.th + (size_t)b * H * S.nth, H * S.nth, tid, nt);
-    if (warm) copy_n(S.nu_cand + (size_t)b * H * S.nd, S.nu + (size_t)b * H * S.nd, H * S.nd, tid, nt);
+    // copy_traj!(traj_cand, traj): evaluation slot 0 <- traj, nu_cand <- nu
+    copy_n(S.cand.q + sb0 * (H + 2) * m.nq, S.traj.q + oq, (H + 2) * m.nq, tid, nt);
+    copy_n(S.cand.u + sb0 * H * m.nu, S.traj.u + (size_t)b * H * m.nu, H * m.nu, tid, nt);
+    copy_n(S.cand.w + sb0 * H * m.nw, S.traj.w + (size_t)b * H * m.nw, H * m.nw, tid, nt);
+    copy_n(S.cand.g + sb0 * H * m.nc, S.traj.g + (size_t)b * H * m.nc, H * m.nc, tid, nt);
+    copy_n(S.cand.b + sb0 * H * m.nb, S.traj.b + (size_t)b * H * m.nb, H * m.nb, tid, nt);
+    copy_n(S.cand.th + sb0 * H * S.nth, S.traj.th + (size_t)b * H * S.nth, H * S.nth, tid, nt);
+    copy_n(S.nu_cand + sb0 * H * S.nd, S.nu + (size_t)b * H * S.nd, H * S.nd, tid, nt);
+    for (int c = 1; c < CS; ++c)       // w (disturbance) never changes during a solve
+        copy_n(S.cand.w + (sb0 + c) * H * m.nw, S.traj.w + (size_t)b * H * m.nw, H * m.nw, tid, nt);
     if (tid == 0) {
         S.beta[b] = S.beta_init;
         S.stage[b] = STAGE_INIT;
-        S.need_sweep[b] = 1;
+        for (int c = 0; c < CS; ++c) S.need_sweep[sb0 + c] = (c == 0);
+        S.cur_slot[b] = 0;
         S.newton_l[b] = 0;
         S.alpha[b] = 1.0;
         S.ls_iter[b] = 0;
@@ -79,11 +96,12 @@ __global__ __launch_bounds__(256) void reset_kernel(NewtonDev S, const double* q
         S.ro_ip_iters[b] = 0;
         S.ro_ip_fail[b] = 0;
     }
-    for (int k = tid; k < H; k += nt) S.pflag[(size_t)b * H + k] = 0;
+    for (int k = tid; k < CS * H; k += nt) S.pflag[sb0 * H + k] = 0;
 }
 
-// x_cand = x - alpha*Delta for q_{t+2}, u_t, nu_t  (+ gamma, b in cf mode), then update_theta!
-__device__ void apply_step(const NewtonDev& S, const TrajDev& dst, double* nu_dst, int b,
+// x_dst = traj - alpha*Delta for q_{t+2}, u_t, nu_t (+ gamma, b in cf mode), then update_theta!.
+// dst arrays are indexed by `di` (a rollout index for traj, a slot index for candidates).
+__device__ void apply_step(const NewtonDev& S, const TrajDev& dst, double* nu_dst_base, size_t di, int b,
                            double alpha, int tid, int nt) {
     const cimpc_dims& m = S.dm;
     const int H = m.H, nq = m.nq, nu = m.nu, nr = S.nr, nd = S.nd;
@@ -92,68 +110,63 @@ __device__ void apply_step(const NewtonDev& S, const TrajDev& dst, double* nu_ds
     const int oq_in_block = cf ? nu + m.nc + m.nb : nu;
     for (int k = tid; k < H * nq; k += nt) {
         const int t = k / nq, c = k - t * nq;
-        const size_t iq = ((size_t)b * (H + 2) + t + 2) * nq + c;
-        dst.q[iq] = S.traj.q[iq] - alpha * D[t * nr + oq_in_block + c];
+        dst.q[(di * (H + 2) + t + 2) * nq + c] =
+            S.traj.q[((size_t)b * (H + 2) + t + 2) * nq + c] - alpha * D[t * nr + oq_in_block + c];
     }
+    for (int k = tid; k < 2 * nq; k += nt)       // q_1, q_2 are fixed by (q0, q1)
+        dst.q[di * (H + 2) * nq + k] = S.traj.q[(size_t)b * (H + 2) * nq + k];
     for (int k = tid; k < H * nu; k += nt) {
         const int t = k / nu, c = k - t * nu;
-        const size_t iu = ((size_t)b * H + t) * nu + c;
-        dst.u[iu] = S.traj.u[iu] - alpha * D[t * nr + c];
+        dst.u[(di * H + t) * nu + c] = S.traj.u[((size_t)b * H + t) * nu + c] - alpha * D[t * nr + c];
     }
     if (cf) {
         for (int k = tid; k < H * m.nc; k += nt) {
             const int t = k / m.nc, c = k - t * m.nc;
-            const size_t ig = ((size_t)b * H + t) * m.nc + c;
-            dst.g[ig] = S.traj.g[ig] - alpha * D[t * nr + nu + c];
+            dst.g[(di * H + t) * m.nc + c] = S.traj.g[((size_t)b * H + t) * m.nc + c] - alpha * D[t * nr + nu + c];
         }
         for (int k = tid; k < H * m.nb; k += nt) {
             const int t = k / m.nb, c = k - t * m.nb;
-            const size_t ib = ((size_t)b * H + t) * m.nb + c;
-            dst.b[ib] = S.traj.b[ib] - alpha * D[t * nr + nu + m.nc + c];
+            dst.b[(di * H + t) * m.nb + c] = S.traj.b[((size_t)b * H + t) * m.nb + c] - alpha * D[t * nr + nu + m.nc + c];
         }
     }
-    for (int k = tid; k < H * nd; k += nt) {
-        const size_t in = (size_t)b * H * nd + k;
-        nu_dst[in] = S.nu[in] - alpha * D[H * nr + k];
-    }
+    for (int k = tid; k < H * nd; k += nt)
+        nu_dst_base[di * H * nd + k] = S.nu[(size_t)b * H * nd + k] - alpha * D[H * nr + k];
     __syncthreads();
-    for (int t = 0; t < H; ++t) theta_update(S, dst, b, t, tid, nt);
+    {   // update_theta!(dst): th_t = [q_t; q_{t+1}; u_t; w_t; mu; h]; mu, h come from traj
+        const int nth = S.nth, nw = m.nw;
+        for (int k = tid; k < H * nth; k += nt) {
+            const int t = k / nth, c = k - t * nth;
+            double v;
+            if (c < 2 * nq) v = dst.q[(di * (H + 2) + t) * nq + c];
+            else if (c < 2 * nq + nu) v = dst.u[(di * H + t) * nu + (c - 2 * nq)];
+            else if (c < 2 * nq + nu + nw) v = S.traj.w[((size_t)b * H + t) * nw + (c - 2 * nq - nu)];
+            else v = S.traj.th[((size_t)b * H + t) * nth + c];
+            dst.th[(di * H + t) * nth + c] = v;
+        }
+    }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void resid_decide_kernel(NewtonDev S) {
+// residual! on evaluation slot sb (candidate trajectory, nu_cand, d, dz of that slot); returns |r|_1
+__device__ double slot_residual(const NewtonDev& S, size_t sb, int b, double* red, int tid, int nt) {
     const cimpc_dims& m = S.dm;
-    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    if (S.need_sweep[b] == 0) return;     // nothing was evaluated for this rollout
-    {   // an interior-point solve of this evaluation is still parked: wait for the next launch
-        int pend = 0;
-        for (int k = tid; k < m.H; k += nt) pend |= (S.pflag[(size_t)b * m.H + k] == 1);
-        if (__syncthreads_or(pend)) {
-            if (tid == 0) atomicAdd(&S.counters[0], 1);
-            return;
-        }
-        for (int k = tid; k < m.H; k += nt) S.pflag[(size_t)b * m.H + k] = 0;   // evaluation consumed
-    }
     const int H = m.H, nq = m.nq, nu = m.nu, nc = m.nc, nb = m.nb, nr = S.nr, nd = S.nd;
     const int nths = S.nths;
     const bool cf = m.mode == CIMPC_MODE_CONFIGURATIONFORCE;
     const int oq_in_block = cf ? nu + nc + nb : nu;
-    __shared__ double red[256];
-    __shared__ int action;
-    double* r = S.res_cand + (size_t)b * S.N;
-    const double* nuc = S.nu_cand + (size_t)b * H * nd;
-    const double* dzb = S.dz + (size_t)b * H * nths * nd;
+    double* r = S.res_cand + sb * S.N;
+    const double* nuc = S.nu_cand + sb * H * nd;
+    const double* dzb = S.dz + sb * H * nths * nd;
     double part = 0.0;
-    // ---- residual! on (cand, nu_cand) -----------------------------------------------------
     for (int e = tid; e < S.N; e += nt) {
         double v = 0.0;
         if (e >= H * nr) {                       // rd[i] = d_i
-            v = S.d[(size_t)b * H * nd + (e - H * nr)];
+            v = S.d[sb * H * nd + (e - H * nr)];
         } else {
             const int i = e / nr, c = e - i * nr;
             if (c < nu) {                         // u1[i]: R_i (u - u_ref) + du1_i^T nu_i
                 const double* Rm = S.R + (size_t)i * nu * nu;
-                const double* uu = S.cand.u + ((size_t)b * H + i) * nu;
+                const double* uu = S.cand.u + (sb * H + i) * nu;
                 const double* ur = S.ref.u + ((size_t)b * H + i) * nu;
                 for (int k = 0; k < nu; ++k) v = fma(Rm[c + k * nu], uu[k] - ur[k], v);
                 const double* A0 = dzb + ((size_t)i * nths + 2 * nq + c) * nd;   // column c of du1_i
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(256) void resid_decide_kernel(NewtonDev S) {
             } else if (c >= oq_in_block) {        // q2[i]
                 const int cq = c - oq_in_block;
                 const double* Qm = S.Q + (size_t)i * nq * nq;
-                const double* qq = S.cand.q + ((size_t)b * (H + 2) + i + 2) * nq;
+                const double* qq = S.cand.q + (sb * (H + 2) + i + 2) * nq;
                 const double* qr = S.ref.q + ((size_t)b * (H + 2) + i + 2) * nq;
                 for (int k = 0; k < nq; ++k) v = fma(Qm[cq + k * nq], qq[k] - qr[k], v);
                 v -= nuc[i * nd + cq];                                      // rI[i] -= nu_i
@@ -182,14 +195,14 @@ __global__ __launch_bounds__(256) void resid_decide_kernel(NewtonDev S) {
             } else if (c < nu + nc) {             // gamma1[i] (cf)
                 const int cg = c - nu;
                 const double* Cm = S.Cg + (size_t)i * nc * nc;
-                const double* gg = S.cand.g + ((size_t)b * H + i) * nc;
+                const double* gg = S.cand.g + (sb * H + i) * nc;
                 const double* gr = S.ref.g + ((size_t)b * H + i) * nc;
                 for (int k = 0; k < nc; ++k) v = fma(Cm[cg + k * nc], gg[k] - gr[k], v);
                 v -= nuc[i * nd + nq + cg];
             } else {                              // b1[i] (cf)
                 const int cb = c - nu - nc;
                 const double* Cm = S.Cb + (size_t)i * nb * nb;
-                const double* bb = S.cand.b + ((size_t)b * H + i) * nb;
+                const double* bb = S.cand.b + (sb * H + i) * nb;
                 const double* br = S.ref.b + ((size_t)b * H + i) * nb;
                 for (int k = 0; k < nb; ++k) v = fma(Cm[cb + k * nb], bb[k] - br[k], v);
                 v -= nuc[i * nd + nq + nc + cb];
@@ -204,67 +217,109 @@ __global__ __launch_bounds__(256) void resid_decide_kernel(NewtonDev S) {
         if (tid < s) red[tid] += red[tid + s];
         __syncthreads();
     }
+    const double out = red[0];
+    __syncthreads();
+    return out;
+}
+
+__global__ __launch_bounds__(256) void resid_decide_kernel(NewtonDev S) {
+    const cimpc_dims& m = S.dm;
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int H = m.H;
+    const size_t sb0 = (size_t)b * CS;
+    const int stage = S.stage[b];
+    if (stage == STAGE_DONE || stage == STAGE_KKT) return;
+    if (S.need_sweep[sb0] == 0) return;          // nothing was evaluated for this rollout
+    const int ncand = (stage == STAGE_LS1) ? 2 : (stage == STAGE_LS2) ? 4 : 1;
+    {   // an interior-point solve of this evaluation is still parked: wait for the next launch
+        int pend = 0;
+        for (int k = tid; k < ncand * H; k += nt) pend |= (S.pflag[sb0 * H + k] == 1);
+        if (__syncthreads_or(pend)) {
+            if (tid == 0) atomicAdd(&S.counters[0], 1);
+            return;
+        }
+        for (int k = tid; k < ncand * H; k += nt) S.pflag[sb0 * H + k] = 0;   // evaluation consumed
+    }
+    __shared__ double red[256];
+    __shared__ double rc[CS];
+    __shared__ int s_act, s_slot, s_iter;
+    for (int c = 0; c < ncand; ++c) {
+        const double v = slot_residual(S, sb0 + c, b, red, tid, nt);
+        if (tid == 0) { rc[c] = v; S.r_cand[sb0 + c] = v; }
+    }
+    __syncthreads();
     // ---- decision (newton.jl:198-280) ------------------------------------------------------
     if (tid == 0) {
-        const double r_cand = red[0];
-        S.r_cand[b] = r_cand;
-        int act;   // 0 = accept initial evaluation, 1 = accept step, 2 = backtrack
-        if (S.stage[b] == STAGE_INIT) {
+        int act = 2, slot = 0, iter = 0;   // act: 0 accept initial evaluation, 1 accept step, 2 more candidates
+        if (stage == STAGE_INIT) {
             act = 0;
         } else {
-            const double rn = S.r_norm[b];
-            double a = S.alpha[b];
-            if (r_cand * r_cand >= (1.0 - 0.001 * a) * rn * rn) {
-                a *= 0.5;
-                const int it = S.ls_iter[b] + 1;
-                S.alpha[b] = a;
-                S.ls_iter[b] = it;
-                act = (it > 6) ? 1 : 2;
-            } else {
-                act = 1;
+            const double rn2 = S.r_norm[b] * S.r_norm[b];
+            const int it0 = (stage == STAGE_LS0) ? 0 : (stage == STAGE_LS1) ? 1 : 3;
+            for (int c = 0; c < ncand; ++c) {
+                const double a = ls_alpha(it0 + c);
+                if (!(rc[c] * rc[c] >= (1.0 - 0.001 * a) * rn2)) { act = 1; slot = c; iter = it0 + c; break; }
+            }
+            if (act == 2 && stage == STAGE_LS2) {   // iter = 7 > 6: break out, halved alpha, last evaluation
+                act = 1; slot = 3; iter = 7;
             }
         }
-        action = act;
-        // statistics of the sweep that was just consumed
-        long long its = 0, fails = 0;
-        for (int i = 0; i < H; ++i) {
-            its += S.ip_iters[(size_t)b * H + i];
-            fails += (S.ip_status[(size_t)b * H + i] == 0);
+        s_act = act; s_slot = slot; s_iter = iter;
+        // statistics.  Global counters: every evaluation that ran (speculative ones included).
+        // Per-rollout counters: only the evaluations the reference's sequential line search
+        // would have performed (candidates up to and including the accepted one).
+        const int nref = (act == 1 && iter <= 6) ? slot + 1 : ncand;
+        long long its = 0, fails = 0, its_ref = 0, fails_ref = 0;
+        for (int k = 0; k < ncand * H; ++k) {
+            const int it = S.ip_iters[sb0 * H + k], fl = (S.ip_status[sb0 * H + k] == 0);
+            its += it; fails += fl;
+            if (k < nref * H) { its_ref += it; fails_ref += fl; }
         }
-        S.ro_sweeps[b] += 1;
-        S.ro_ip_iters[b] += (int)its;
-        S.ro_ip_fail[b] += (int)fails;
-        atomicAdd((unsigned long long*)&S.stats[0], 1ull);
-        atomicAdd((unsigned long long*)&S.stats[1], (unsigned long long)H);
+        S.ro_sweeps[b] += nref;
+        S.ro_ip_iters[b] += (int)its_ref;
+        S.ro_ip_fail[b] += (int)fails_ref;
+        atomicAdd((unsigned long long*)&S.stats[0], (unsigned long long)ncand);
+        atomicAdd((unsigned long long*)&S.stats[1], (unsigned long long)(ncand * H));
         atomicAdd((unsigned long long*)&S.stats[2], (unsigned long long)its);
         atomicAdd((unsigned long long*)&S.stats[3], (unsigned long long)fails);
     }
     __syncthreads();
-    const int act = action;
-    if (act == 2) {                       // backtrack: new candidate with the halved alpha
-        apply_step(S, S.cand, S.nu_cand, b, S.alpha[b], tid, nt);
-        if (tid == 0) atomicAdd(&S.counters[0], 1);
-        return;                           // stage stays LINESEARCH, need_sweep stays 1
+    const int act = s_act, slot = s_slot, iter = s_iter;
+    if (act == 2) {                       // next batch of candidates: (1/2, 1/4) or (1/8 .. 1/64)
+        const int nstage = (stage == STAGE_LS0) ? STAGE_LS1 : STAGE_LS2;
+        const int it0 = (nstage == STAGE_LS1) ? 1 : 3, nn = (nstage == STAGE_LS1) ? 2 : 4;
+        for (int c = 0; c < nn; ++c) apply_step(S, S.cand, S.nu_cand, sb0 + c, b, ls_alpha(it0 + c), tid, nt);
+        if (tid == 0) {
+            S.stage[b] = nstage;
+            for (int c = 0; c < CS; ++c) S.need_sweep[sb0 + c] = (c < nn);
+            atomicAdd(&S.counters[0], 1);
+        }
+        return;
     }
+    const double alpha = ls_alpha(iter);
     if (act == 1) {                       // accept: traj <- traj - alpha*Delta (newton.jl:273)
-        apply_step(S, S.traj, S.nu, b, S.alpha[b], tid, nt);
+        apply_step(S, S.traj, S.nu, (size_t)b, b, alpha, tid, nt);
     }
     {   // res <- res_cand ; r_norm <- r_cand
         double* rr = S.res + (size_t)b * S.N;
+        const double* r = S.res_cand + (sb0 + slot) * S.N;
         for (int e = tid; e < S.N; e += nt) rr[e] = r[e];
     }
     if (tid == 0) {
-        const double rn = S.r_cand[b];
+        const double rn = rc[slot];
         S.r_norm[b] = rn;
+        S.cur_slot[b] = slot;
+        S.alpha[b] = alpha;
+        S.ls_iter[b] = iter;
         int l = S.newton_l[b];
         if (act == 1) {
             l += 1;
             S.newton_l[b] = l;
             const double be = S.beta[b];
-            S.beta[b] = (S.ls_iter[b] > 6) ? fmin(be * 1.3, 1.0e2) : fmax(1.0e1, be / 1.3);
+            S.beta[b] = (iter > 6) ? fmin(be * 1.3, 1.0e2) : fmax(1.0e1, be / 1.3);
         }
         const bool done = (l >= S.max_iter) || (rn / (double)S.N < S.r_tol);
-        S.need_sweep[b] = 0;
+        for (int c = 0; c < CS; ++c) S.need_sweep[sb0 + c] = 0;
         if (done) {
             S.stage[b] = STAGE_DONE;
         } else {
@@ -336,7 +391,7 @@ __global__ __launch_bounds__(64) void kkt_kernel_scalar(NewtonDev S, KktArgs K) 
     const double* rb = K.r + (size_t)b * S.N;
     const double beta = K.beta ? K.beta[b] : K.beta_scalar;
     const double rho = (double)H * beta * S.kappa;     // newton_jacobian.jl:169-186 quirk
-    const double* dzb = S.dz + (size_t)b * H * nths * nd;
+    const double* dzb = S.dz + ((size_t)b * CS + (K.stage ? S.cur_slot[b] : 0)) * H * nths * nd;
     constexpr int n2 = nd * nd;
     double* ws = S.kkt_ws + (size_t)b * H * (3 * n2 + nd);
     const int oq = nu;   // offset of q2 inside a primal block (:configuration)
@@ -669,12 +724,12 @@ __global__ __launch_bounds__(64) void kkt_kernel_scalar(NewtonDev S, KktArgs K) 
         __threadfence_block();
         lds_sync();
         // line search start (newton.jl:223-228): alpha = 1, candidate = traj - Delta
-        apply_step(S, S.cand, S.nu_cand, b, 1.0, lane, 64);
+        apply_step(S, S.cand, S.nu_cand, (size_t)b * CS, b, 1.0, lane, 64);
         if (lane == 0) {
             S.alpha[b] = 1.0;
             S.ls_iter[b] = 0;
-            S.stage[b] = STAGE_LINESEARCH;
-            S.need_sweep[b] = 1;
+            S.stage[b] = STAGE_LS0;
+            for (int c = 0; c < CS; ++c) S.need_sweep[(size_t)b * CS + c] = (c == 0);
             atomicAdd(&S.counters[0], 1);
         }
     }
@@ -758,7 +813,7 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
     const double* rb = K.r + (size_t)b * S.N;
     const double beta = K.beta ? K.beta[b] : K.beta_scalar;
     const double rho = (double)H * beta * S.kappa;         // newton_jacobian.jl:169-186 quirk
-    const double* dzb = S.dz + (size_t)b * H * nths * nd;
+    const double* dzb = S.dz + ((size_t)b * CS + (K.stage ? S.cur_slot[b] : 0)) * H * nths * nd;
     double* ws = S.kkt_ws + (size_t)b * H * (3 * n2 + nd);
     constexpr int WSR = 3 * n2 + nd;
 
@@ -990,12 +1045,12 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
         __threadfence_block();
         lds_sync();
         // line search start (newton.jl:223-228): alpha = 1, candidate = traj - Delta
-        apply_step(S, S.cand, S.nu_cand, b, 1.0, lane, 64);
+        apply_step(S, S.cand, S.nu_cand, (size_t)b * CS, b, 1.0, lane, 64);
         if (lane == 0) {
             S.alpha[b] = 1.0;
             S.ls_iter[b] = 0;
-            S.stage[b] = STAGE_LINESEARCH;
-            S.need_sweep[b] = 1;
+            S.stage[b] = STAGE_LS0;
+            for (int c = 0; c < CS; ++c) S.need_sweep[(size_t)b * CS + c] = (c == 0);
             atomicAdd(&S.counters[0], 1);
         }
     }

@@ -7,7 +7,8 @@
 
 namespace cimpc {
 
-enum Stage : int { STAGE_DONE = 0, STAGE_INIT = 1, STAGE_LINESEARCH = 2, STAGE_KKT = 3 };
+enum Stage : int { STAGE_DONE = 0, STAGE_INIT = 1, STAGE_LS0 = 2, STAGE_KKT = 3, STAGE_LS1 = 4, STAGE_LS2 = 5 };
+constexpr int CS = 4;   // evaluation slots per rollout (speculative line search, newton_kernels.hip)
 
 struct TrajDev {
     double* q;    // [B][H+2][nq]
@@ -21,28 +22,29 @@ struct TrajDev {
 struct NewtonDev {
     cimpc_dims dm;
     int nd, nr, nth, nths, N;
-    TrajDev traj, cand, ref;
+    TrajDev traj, cand, ref;   // cand: [B*CS] evaluation slots; traj, ref: [B]
     double* nu;        // [B][H][nd]
-    double* nu_cand;   // [B][H][nd]
+    double* nu_cand;   // [B*CS][H][nd]
     // implicit dynamics of the last sweep
-    double* d;         // [B][H][nd]
-    double* dz;        // [B][H][nths][nd]
-    int* ip_status;    // [B][H]
-    int* ip_iters;     // [B][H]
-    int* pflag;        // [B][H] resumable-solve flags (see IpParams)
+    double* d;         // [B*CS][H][nd]
+    double* dz;        // [B*CS][H][nths][nd]
+    int* ip_status;    // [B*CS][H]
+    int* ip_iters;     // [B*CS][H]
+    int* pflag;        // [B*CS][H] resumable-solve flags (see IpParams)
+    int* cur_slot;     // [B] slot holding the current im_traj (d, dz) of the rollout
     // Newton vectors, reference layout (newton_residual.jl:69-98)
     double* res;       // [B][N]
-    double* res_cand;  // [B][N]
+    double* res_cand;  // [B*CS][N]
     double* delta;     // [B][N]
     // per-rollout scalars
     double* r_norm;    // [B]  |res|_1
-    double* r_cand;    // [B]
+    double* r_cand;    // [B*CS]
     double* alpha;     // [B]
     double* beta;      // [B]
     int* ls_iter;      // [B]
     int* newton_l;     // [B]  Newton iterations done
     int* stage;        // [B]
-    int* need_sweep;   // [B]
+    int* need_sweep;   // [B*CS]
     int* counters;     // [8]: 0 = #rollouts needing a sweep, 1 = #needing KKT
     long long* stats;  // [4]: sweeps, ip_solves, ip_iters, ip_failures (accumulated)
     int* ro_sweeps;    // [B] implicit_dynamics! evaluations of the last solve
