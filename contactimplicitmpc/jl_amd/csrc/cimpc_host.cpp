@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -29,6 +30,21 @@ struct ProfRec {
 };
 
 }  // namespace
+
+// Independent sub-batches of rollouts, each driven through its own HIP stream: while one
+// sub-batch sits in a latency-bound phase (KKT recursion, the tail of a sweep, the host
+// round trip) the others keep the CUs busy.  Rollouts never interact, so this is scheduling only.
+struct SubBatch {
+    int b0 = 0, nb = 0;          // rollout range
+    int wg0 = 0, nwg = 0;        // workgroup descriptors of the sweep
+    hipStream_t st = nullptr;
+    hipEvent_t ev = nullptr;
+    int* d_cnt = nullptr;        // 8 device counters
+    int* h_cnt = nullptr;        // pinned mirror
+    bool running = false;
+    int n_kkt = 0;
+    long long rounds = 0;
+};
 
 struct cimpc_ctx {
     cimpc_dims dm{};
@@ -62,6 +78,8 @@ struct cimpc_ctx {
     bool objective_set = false, window_set = false, reference_set = false, alt_set = false;
     bool velocity_objective = false;
     int n_wg = 0, waves = 4;
+    std::vector<SubBatch> subs;
+    bool external_stream = false;
     std::vector<double> h_tab;       // one knot staging
     cimpc_stats last_stats{};
     // profiling
@@ -131,8 +149,9 @@ bool invert(const double* A, double* Ai, int n) {
     return true;
 }
 
-void prof_begin(cimpc_ctx* h, int cls) {
+void prof_begin(cimpc_ctx* h, int cls, hipStream_t st = nullptr) {
     if (!h->prof_on) return;
+    if (!st) st = h->stream;
     ProfRec r;
     auto get = [&]() {
         if (!h->ev_pool.empty()) {
@@ -147,16 +166,17 @@ void prof_begin(cimpc_ctx* h, int cls) {
     r.a = get();
     r.b = get();
     r.cls = cls;
-    (void)hipEventRecord(r.a, h->stream);
+    (void)hipEventRecord(r.a, st);
     h->prof_recs.push_back(r);
 }
-void prof_end(cimpc_ctx* h) {
+void prof_end(cimpc_ctx* h, hipStream_t st = nullptr) {
     if (!h->prof_on) return;
-    (void)hipEventRecord(h->prof_recs.back().b, h->stream);
+    (void)hipEventRecord(h->prof_recs.back().b, st ? st : h->stream);
 }
 void prof_collect(cimpc_ctx* h) {
     if (h->prof_recs.empty()) return;
     (void)hipStreamSynchronize(h->stream);
+    for (auto& sb : h->subs) if (sb.st) (void)hipStreamSynchronize(sb.st);
     for (auto& r : h->prof_recs) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
@@ -200,6 +220,17 @@ int run_sweep(cimpc_ctx* h, const TrajDev& T, const int* need_sweep, double* zou
     prof_begin(h, PC_IP);
     int rc = launch_ip_sweep(&h->dm, p, h->n_wg, h->waves, h->stream);
     prof_end(h);
+    if (rc != CIMPC_OK) return fail(h, rc, "ip sweep launch failed");
+    return CIMPC_OK;
+}
+
+int run_sweep_sub(cimpc_ctx* h, const SubBatch& sb) {
+    IpParams p = make_ip_params(h, h->S.cand, h->S.need_sweep, nullptr);
+    p.wg_desc = h->d_wg_desc + 4 * (size_t)sb.wg0;
+    p.pending_count = sb.d_cnt + 2;
+    prof_begin(h, PC_IP, sb.st);
+    int rc = launch_ip_sweep(&h->dm, p, sb.nwg, h->waves, sb.st);
+    prof_end(h, sb.st);
     if (rc != CIMPC_OK) return fail(h, rc, "ip sweep launch failed");
     return CIMPC_OK;
 }
@@ -321,6 +352,8 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     A(&h->d_rhs, B * h->N);
     NewtonDev& S = h->S;
     S.dm = d;
+    S.b0 = 0;
+    S.nb_launch = d.B;
     S.nd = h->nd; S.nr = h->nr; S.nth = h->nth; S.nths = h->nths; S.N = h->N;
     const size_t BS = B * CS;     // evaluation slots (speculative line search)
     for (TrajDev* T : {&S.traj, &S.cand, &S.ref}) {
@@ -364,6 +397,31 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     // small batches: one wave per workgroup keeps every problem on its own CU (latency);
     // large batches: 4 waves share one staged table (throughput)
     h->waves = (B * H >= 4096) ? 4 : 1;
+    {   // sub-batches: >= 64 rollouts each, at most 4 (host launch rate bounds the useful count)
+        // default 1: on MI355X a sweep launch of >= 64 rollouts already fills the 2 workgroups/CU the
+        // kernel's LDS footprint allows, so extra streams only multiply the per-launch latency floor
+        // (measured: 4 sub-batches 34.8 ms/step vs 28.2 ms single batch at B = 512).  CIMPC_SUBBATCHES
+        // overrides for experiments.
+        int nsub = 1;
+        if (const char* e = std::getenv("CIMPC_SUBBATCHES")) nsub = std::max(1, std::atoi(e));
+        nsub = (int)std::min<size_t>((size_t)nsub, std::max<size_t>(1, B / 32));
+        h->subs.resize(nsub);
+        int* dc = nullptr;
+        if (dev_alloc(h, &dc, 8 * (size_t)nsub) != CIMPC_OK) { g_create_error = h->err; cimpc_destroy(h); return CIMPC_ERR_HIP; }
+        for (int k = 0; k < nsub; ++k) {
+            SubBatch& sb = h->subs[k];
+            sb.b0 = (int)(B * k / nsub);
+            sb.nb = (int)(B * (k + 1) / nsub) - sb.b0;
+            sb.d_cnt = dc + 8 * k;
+            if (hipStreamCreateWithFlags(&sb.st, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&sb.ev, hipEventDisableTiming) != hipSuccess ||
+                hipHostMalloc((void**)&sb.h_cnt, 8 * sizeof(int)) != hipSuccess) {
+                g_create_error = "sub-batch stream/event creation failed";
+                cimpc_destroy(h);
+                return CIMPC_ERR_HIP;
+            }
+        }
+    }
     *out = h;
     return CIMPC_OK;
 }
@@ -376,6 +434,11 @@ int cimpc_destroy(cimpc_handle h) {
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->h_counters) (void)hipHostFree(h->h_counters);
+    for (auto& sb : h->subs) {
+        if (sb.st) { (void)hipStreamSynchronize(sb.st); (void)hipStreamDestroy(sb.st); }
+        if (sb.ev) (void)hipEventDestroy(sb.ev);
+        if (sb.h_cnt) (void)hipHostFree(sb.h_cnt);
+    }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return CIMPC_OK;
@@ -387,6 +450,7 @@ int cimpc_set_stream(cimpc_handle h, void* hip_stream) {
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     h->stream = static_cast<hipStream_t>(hip_stream);
     h->own_stream = false;
+    h->external_stream = true;   // caller-ordered stream: the solve runs as ONE batch on it
     return CIMPC_OK;
 }
 
@@ -517,23 +581,28 @@ int cimpc_set_window(cimpc_handle h, const int* window) {
     std::vector<int> plist;
     plist.reserve((size_t)B * CS * H);
     std::vector<int> desc;
-    std::vector<std::vector<int>> per_knot(K + 1);
-    for (int b = 0; b < B; ++b)
-        for (int i = 0; i < H; ++i) per_knot[window[(size_t)b * (H + 2) + i]].push_back(b * H + i);
-    for (int t = 1; t <= K; ++t)
-        for (int c = 0; c < CS; ++c) {
-            const int first = (int)plist.size();
-            for (int e : per_knot[t]) {
-                const int b = e / H, i = e - b * H;
-                plist.push_back((b * CS + c) * H + i);
+    for (auto& sbt : h->subs) {                 // descriptors grouped per sub-batch
+        std::vector<std::vector<int>> per_knot(K + 1);
+        for (int b = sbt.b0; b < sbt.b0 + sbt.nb; ++b)
+            for (int i = 0; i < H; ++i) per_knot[window[(size_t)b * (H + 2) + i]].push_back(b * H + i);
+        sbt.wg0 = (int)desc.size() / 4;
+        for (int t = 1; t <= K; ++t)
+            for (int c = 0; c < CS; ++c) {
+                const int first = (int)plist.size();
+                const int n = (int)per_knot[t].size();
+                for (int e : per_knot[t]) {
+                    const int b = e / H, i = e - b * H;
+                    plist.push_back((b * CS + c) * H + i);
+                }
+                for (int s0 = 0; s0 < n; s0 += pw) {
+                    desc.push_back(t - 1);
+                    desc.push_back(first + s0);
+                    desc.push_back(std::min(pw, n - s0));
+                    desc.push_back(0);
+                }
             }
-            for (int s0 = 0; s0 < cnt[t]; s0 += pw) {
-                desc.push_back(t - 1);
-                desc.push_back(first + s0);
-                desc.push_back(std::min(pw, cnt[t] - s0));
-                desc.push_back(0);
-            }
-        }
+        sbt.nwg = (int)desc.size() / 4 - sbt.wg0;
+    }
     h->n_wg = (int)desc.size() / 4;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpy(h->d_plist, plist.data(), plist.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -639,41 +708,75 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         return el >= h->nt.max_time;
     };
     HIP_TRY(h, hipMemsetAsync(S.stats, 0, 4 * sizeof(long long), h->stream));
-    prof_begin(h, PC_OTHER);
-    rc = launch_reset(S, q0_dev, q1_dev, warm_start, h->stream);
-    prof_end(h);
-    if (rc != CIMPC_OK) return fail(h, rc, "reset launch failed");
-    long long rounds = 0;
-    int n_kkt = 0;
-    // safety net only: every Newton iteration needs at most 8 evaluations, each evaluation at most
-    // ceil(max_iter / iter_cap) launches of the resumable interior-point sweep
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // safety net only: every Newton iteration needs at most 3 (speculative) rounds, each evaluation at
+    // most ceil(max_iter / iter_cap) launches of the resumable interior-point sweep
     const int max_rounds = (h->nt.max_iter * 8 + 2) * ((h->ip.max_iter + h->iter_cap - 1) / h->iter_cap + 1);
-    while (true) {
-        // ---- one lock-step round: [KKT for rollouts that start an iteration] -> sweep ->
-        //      residual + line-search decision
-        HIP_TRY(h, hipMemsetAsync(S.counters, 0, 8 * sizeof(int), h->stream));
-        if (n_kkt > 0) {
-            prof_begin(h, PC_KKT);
-            rc = launch_kkt(S, h->stream);
-            prof_end(h);
-            if (rc != CIMPC_OK) return fail(h, rc, "kkt launch failed");
-            h->prof_kkt_systems += n_kkt;
-        }
-        rc = run_sweep(h, S.cand, S.need_sweep, nullptr);
-        if (rc != CIMPC_OK) return rc;
-        prof_begin(h, PC_RESID);
-        rc = launch_resid_decide(S, h->stream);
-        prof_end(h);
-        if (rc != CIMPC_OK) return fail(h, rc, "residual launch failed");
-        HIP_TRY(h, hipMemcpyAsync(h->h_counters, S.counters, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        ++rounds;
-        const int n_sweep = h->h_counters[0];
-        n_kkt = h->h_counters[1];
-        if (n_sweep == 0 && n_kkt == 0) break;
-        if (rounds >= max_rounds) break;
-        if (over_budget()) break;          // newton.jl:187-277: silent early return
+    // one batch on the caller's stream, or independent sub-batches on private streams
+    std::vector<SubBatch> single(1);
+    if (h->external_stream) {
+        single[0] = h->subs[0];
+        single[0].b0 = 0; single[0].nb = h->dm.B; single[0].wg0 = 0; single[0].nwg = h->n_wg;
+        single[0].st = h->stream;
     }
+    std::vector<SubBatch>& subs = h->external_stream ? single : h->subs;
+    auto launch_round = [&](SubBatch& sb) -> int {
+        // [KKT for rollouts that start an iteration] -> sweep -> residual + line-search decision
+        NewtonDev Sk = S;
+        Sk.b0 = sb.b0; Sk.nb_launch = sb.nb; Sk.counters = sb.d_cnt;
+        if (hipMemsetAsync(sb.d_cnt, 0, 8 * sizeof(int), sb.st) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "memset failed");
+        if (sb.n_kkt > 0) {
+            prof_begin(h, PC_KKT, sb.st);
+            int r = launch_kkt(Sk, sb.st);
+            prof_end(h, sb.st);
+            if (r != CIMPC_OK) return fail(h, r, "kkt launch failed");
+            h->prof_kkt_systems += sb.n_kkt;
+        }
+        int r = run_sweep_sub(h, sb);
+        if (r != CIMPC_OK) return r;
+        prof_begin(h, PC_RESID, sb.st);
+        r = launch_resid_decide(Sk, sb.st);
+        prof_end(h, sb.st);
+        if (r != CIMPC_OK) return fail(h, r, "residual launch failed");
+        if (hipMemcpyAsync(sb.h_cnt, sb.d_cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, sb.st) != hipSuccess ||
+            hipEventRecord(sb.ev, sb.st) != hipSuccess)
+            return fail(h, CIMPC_ERR_HIP, "counter read-back failed");
+        return CIMPC_OK;
+    };
+    int active = 0;
+    for (SubBatch& sb : subs) {
+        NewtonDev Sk = S;
+        Sk.b0 = sb.b0; Sk.nb_launch = sb.nb; Sk.counters = sb.d_cnt;
+        prof_begin(h, PC_OTHER, sb.st);
+        rc = launch_reset(Sk, q0_dev, q1_dev, warm_start, sb.st);
+        prof_end(h, sb.st);
+        if (rc != CIMPC_OK) return fail(h, rc, "reset launch failed");
+        sb.n_kkt = 0; sb.rounds = 0; sb.running = true;
+        rc = launch_round(sb);
+        if (rc != CIMPC_OK) return rc;
+        ++active;
+    }
+    long long rounds = 0;
+    while (active > 0) {
+        for (SubBatch& sb : subs) {
+            if (!sb.running) continue;
+            const hipError_t q = hipEventQuery(sb.ev);
+            if (q == hipErrorNotReady) continue;
+            if (q != hipSuccess) return fail(h, CIMPC_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+            ++sb.rounds;
+            const int n_sweep = sb.h_cnt[0];
+            sb.n_kkt = sb.h_cnt[1];
+            if ((n_sweep == 0 && sb.n_kkt == 0) || sb.rounds >= max_rounds || over_budget()) {
+                sb.running = false;     // newton.jl:187-277: the time budget ends the solve silently
+                --active;
+                rounds = std::max(rounds, sb.rounds);
+                continue;
+            }
+            rc = launch_round(sb);
+            if (rc != CIMPC_OK) return rc;
+        }
+    }
+    for (SubBatch& sb : subs) HIP_TRY(h, hipStreamSynchronize(sb.st));
     long long st[4];
     HIP_TRY(h, hipMemcpy(st, S.stats, sizeof(st), hipMemcpyDeviceToHost));
     std::vector<int> l(h->dm.B);

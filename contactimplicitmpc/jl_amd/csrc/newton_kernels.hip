@@ -49,7 +49,7 @@ __device__ __forceinline__ double ls_alpha(int iter) { return ldexp(1.0, -iter);
 __global__ __launch_bounds__(256) void reset_kernel(NewtonDev S, const double* q0,
                                                     const double* q1, int warm) {
     const cimpc_dims& m = S.dm;
-    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int b = blockIdx.x + S.b0, tid = threadIdx.x, nt = blockDim.x;
     const int H = m.H;
     const size_t oq = (size_t)b * (H + 2) * m.nq;
     const size_t sb0 = (size_t)b * CS;
@@ -224,7 +224,7 @@ __device__ double slot_residual(const NewtonDev& S, size_t sb, int b, double* re
 
 __global__ __launch_bounds__(256) void resid_decide_kernel(NewtonDev S) {
     const cimpc_dims& m = S.dm;
-    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int b = blockIdx.x + S.b0, tid = threadIdx.x, nt = blockDim.x;
     const int H = m.H;
     const size_t sb0 = (size_t)b * CS;
     const int stage = S.stage[b];
@@ -360,7 +360,7 @@ template <int NQ, int NU>
 __global__ __launch_bounds__(64) void kkt_kernel_scalar(NewtonDev S, KktArgs K) {
     constexpr int LD = ((NQ > NU ? NQ : NU) + 3) & ~3;
     const cimpc_dims& m = S.dm;
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int b = blockIdx.x + S.b0, lane = threadIdx.x;
     if (K.stage != nullptr && K.stage[b] != STAGE_KKT) return;
     constexpr int nq = NQ, nu = NU, nd = NQ, nr = NQ + NU, nths = 2 * NQ + NU;
     const int H = m.H;
@@ -789,7 +789,7 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
     constexpr int nq = NQ, nu = NU, nd = NQ, nr = NQ + NU, nths = 2 * NQ + NU, n2 = nd * nd;
     constexpr int KBU = (NU + 3) / 4, KBQ = (NQ + 3) / 4, KBD = (nd + 3) / 4;
     const cimpc_dims& m = S.dm;
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int b = blockIdx.x + S.b0, lane = threadIdx.x;
     if (K.stage != nullptr && K.stage[b] != STAGE_KKT) return;
     const int H = m.H;
     const int li = lane & 15, lk = lane >> 4;
@@ -1060,7 +1060,7 @@ template <int NQ, int NU>
 static int launch_kkt_t(const NewtonDev& S, const KktArgs& K, hipStream_t s) {
     if constexpr (NQ <= 16 && NU <= 16) {
         const size_t lds = (size_t)(KKT_MFMA_TILES * TSZ + 208) * sizeof(double);
-        hipLaunchKernelGGL((kkt_kernel<NQ, NU>), dim3(S.dm.B), dim3(64), lds, s, S, K);
+        hipLaunchKernelGGL((kkt_kernel<NQ, NU>), dim3(S.nb_launch), dim3(64), lds, s, S, K);
     } else {
         constexpr int LD = ((NQ > NU ? NQ : NU) + 3) & ~3;
         const size_t lds = (size_t)(KKT_TILES * LD * LD + 10 * LD) * sizeof(double);
@@ -1069,7 +1069,7 @@ static int launch_kkt_t(const NewtonDev& S, const KktArgs& K, hipStream_t s) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return CIMPC_ERR_HIP;
         }
-        hipLaunchKernelGGL((kkt_kernel_scalar<NQ, NU>), dim3(S.dm.B), dim3(64), lds, s, S, K);
+        hipLaunchKernelGGL((kkt_kernel_scalar<NQ, NU>), dim3(S.nb_launch), dim3(64), lds, s, S, K);
     }
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
@@ -1085,11 +1085,11 @@ static int launch_kkt_any(const NewtonDev& S, const KktArgs& K, hipStream_t s) {
 }
 
 int launch_reset(const NewtonDev& S, const double* q0, const double* q1, int warm, hipStream_t s) {
-    hipLaunchKernelGGL(reset_kernel, dim3(S.dm.B), dim3(256), 0, s, S, q0, q1, warm);
+    hipLaunchKernelGGL(reset_kernel, dim3(S.nb_launch), dim3(256), 0, s, S, q0, q1, warm);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
 int launch_resid_decide(const NewtonDev& S, hipStream_t s) {
-    hipLaunchKernelGGL(resid_decide_kernel, dim3(S.dm.B), dim3(256), 0, s, S);
+    hipLaunchKernelGGL(resid_decide_kernel, dim3(S.nb_launch), dim3(256), 0, s, S);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
 int launch_kkt(const NewtonDev& S, hipStream_t s) {

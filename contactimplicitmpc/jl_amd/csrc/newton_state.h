@@ -21,6 +21,8 @@ struct TrajDev {
 
 struct NewtonDev {
     cimpc_dims dm;
+    int b0;            // first rollout served by this launch (sub-batch offset)
+    int nb_launch;     // rollouts served by this launch
     int nd, nr, nth, nths, N;
     TrajDev traj, cand, ref;   // cand: [B*CS] evaluation slots; traj, ref: [B]
     double* nu;        // [B][H][nd]

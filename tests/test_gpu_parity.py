@@ -44,10 +44,10 @@ def test_implicit_dynamics_matches_oracle(gpu_required, model, mode, B, H, H_ref
             np.testing.assert_allclose(out[k][b][ok], o[k][ok], rtol=0, atol=1e-6 * max(scale, 1.0))
 
 
-def _newton_case(perturb, r_tol, max_iter, seed, B=6, H=10, H_ref=16):
-    d, prob, tabs, rollouts = make_case("quadruped", 0, H_ref=H_ref, H=H, B=B, seed=seed, perturb=perturb)
+def _newton_case(perturb, r_tol, max_iter, seed, B=6, H=10, H_ref=16, model="quadruped", dense_q=False):
+    d, prob, tabs, rollouts = make_case(model, 0, H_ref=H_ref, H=H, B=B, seed=seed, perturb=perturb)
     from contactimplicitmpc.jl_amd import NewtonOptions
-    obj = synth.make_objective(d, H)
+    obj = synth.make_objective(d, H, kind=model, dense_q=dense_q)
     s = make_solver(d, prob, rollouts, H, obj=obj,
                     newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=r_tol, max_iter=max_iter))
     u1, it, rn = s.newton_solve(np.stack([r[2] for r in rollouts]), np.stack([r[3] for r in rollouts]))
@@ -75,6 +75,23 @@ def test_newton_solve_matches_oracle(gpu_required):
         np.testing.assert_allclose(traj["u"][b], core.traj.u, rtol=0, atol=1e-8)
         np.testing.assert_allclose(traj["nu"][b], core.nu, rtol=0, atol=1e-8)
         np.testing.assert_allclose(u1[b], core.traj.u[0], rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("model,H,H_ref,dense_q", [
+    ("hopper", 20, 24, False),       # BASELINE configs[1]: hopper flat, H = 20
+    ("centroidal", 6, 8, True),      # nq = 18 > 16: scalar (non-MFMA) KKT kernel, dense Q (relative_state_cost)
+])
+def test_newton_solve_other_models(gpu_required, model, H, H_ref, dense_q):
+    u1, it, rn, traj, cnt, res = _newton_case(perturb=5e-3, r_tol=1e-5, max_iter=4, seed=23, B=4, H=H, H_ref=H_ref,
+                                              model=model, dense_q=dense_q)
+    same = 0
+    for b, (core, st) in enumerate(res):
+        assert it[b] == st.iters
+        if cnt["ip_iters"][b] == st.ip_iters and cnt["sweeps"][b] == st.sweeps:
+            same += 1
+            np.testing.assert_allclose(traj["q"][b], core.traj.q, rtol=0, atol=1e-7)
+            np.testing.assert_allclose(traj["u"][b], core.traj.u, rtol=0, atol=1e-6)
+    assert same >= len(res) - 1
 
 
 def test_newton_solve_backtracking_regime(gpu_required):
