@@ -59,8 +59,9 @@ struct cimpc_ctx {
     // device memory
     std::vector<void*> allocs;
     double* d_tab = nullptr;
-    int* d_wg_desc = nullptr;
-    int* d_plist = nullptr;
+    IpQueues Q{};                // device work queues (par is set per launch)
+    int* d_window = nullptr;
+    int wpk = 1;                 // persistent workgroups per knot
     double* d_alt = nullptr;
     double* d_zout = nullptr;
     double *d_Q = nullptr, *d_R = nullptr, *d_Qinv = nullptr, *d_Rinv = nullptr, *d_Cg = nullptr,
@@ -77,7 +78,7 @@ struct cimpc_ctx {
     int n_knots_set = 0;
     bool objective_set = false, window_set = false, reference_set = false, alt_set = false;
     bool velocity_objective = false;
-    int n_wg = 0, waves = 4;
+    int waves = 4;
     std::vector<SubBatch> subs;
     bool external_stream = false;
     std::vector<double> h_tab;       // one knot staging
@@ -189,17 +190,17 @@ void prof_collect(cimpc_ctx* h) {
     h->prof_recs.clear();
 }
 
-IpParams make_ip_params(cimpc_ctx* h, const TrajDev& T, const int* need_sweep, double* zout) {
+IpParams make_ip_params(cimpc_ctx* h, const TrajDev& T, int par, int* pending_counter, double* zout) {
     IpParams p{};
     p.tab = h->d_tab;
-    p.wg_desc = h->d_wg_desc;
-    p.plist = h->d_plist;
+    p.Q = h->Q;
+    p.Q.par = par;
+    p.wpk = h->wpk;
     p.q = T.q;
     p.theta = T.th;
     p.gam = T.g;
     p.bfr = T.b;
     p.alt = h->alt_set ? h->d_alt : nullptr;
-    p.need_sweep = need_sweep;
     p.d = h->S.d;
     p.dz = h->S.dz;
     p.status = h->S.ip_status;
@@ -207,7 +208,7 @@ IpParams make_ip_params(cimpc_ctx* h, const TrajDev& T, const int* need_sweep, d
     p.zout = zout;
     p.pflag = h->S.pflag;
     p.pstate = h->d_pstate;
-    p.pending_count = h->S.counters + 2;
+    p.pending_count = pending_counter;
     p.iter_cap = h->iter_cap;
     p.slots = CS;
     p.H = h->dm.H;
@@ -215,22 +216,12 @@ IpParams make_ip_params(cimpc_ctx* h, const TrajDev& T, const int* need_sweep, d
     return p;
 }
 
-int run_sweep(cimpc_ctx* h, const TrajDev& T, const int* need_sweep, double* zout) {
-    IpParams p = make_ip_params(h, T, need_sweep, zout);
-    prof_begin(h, PC_IP);
-    int rc = launch_ip_sweep(&h->dm, p, h->n_wg, h->waves, h->stream);
-    prof_end(h);
-    if (rc != CIMPC_OK) return fail(h, rc, "ip sweep launch failed");
-    return CIMPC_OK;
-}
-
-int run_sweep_sub(cimpc_ctx* h, const SubBatch& sb) {
-    IpParams p = make_ip_params(h, h->S.cand, h->S.need_sweep, nullptr);
-    p.wg_desc = h->d_wg_desc + 4 * (size_t)sb.wg0;
-    p.pending_count = sb.d_cnt + 2;
-    prof_begin(h, PC_IP, sb.st);
-    int rc = launch_ip_sweep(&h->dm, p, sb.nwg, h->waves, sb.st);
-    prof_end(h, sb.st);
+// queue kernel + sensitivity kernel of one round
+int run_sweep(cimpc_ctx* h, int par, int* pending_counter, double* zout, hipStream_t st) {
+    IpParams p = make_ip_params(h, h->S.cand, par, pending_counter, zout);
+    prof_begin(h, PC_IP, st);
+    int rc = launch_ip_sweep(&h->dm, p, h->waves, st);
+    prof_end(h, st);
     if (rc != CIMPC_OK) return fail(h, rc, "ip sweep launch failed");
     return CIMPC_OK;
 }
@@ -336,9 +327,16 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     auto A = [&](auto** p, size_t n) { if (rc == CIMPC_OK) rc = dev_alloc(h, p, n); };
     A(&h->d_tab, (size_t)d.H_ref * h->ki.tab_size);
     const int ppw = 64 / h->ki.G;
-    const size_t max_wg = B * CS * H + (size_t)d.H_ref * CS;   // generous upper bound (1 problem / wg)
-    A(&h->d_wg_desc, 4 * max_wg);
-    A(&h->d_plist, B * CS * H);
+    {   // work queues: a knot can appear ceil(H / H_ref) times in one window
+        const size_t K = d.H_ref;
+        const size_t cap = B * CS * ((H + K - 1) / K + 1);
+        h->Q.K = (int)K; h->Q.cap = (int)cap; h->Q.par = 0;
+        A(&h->Q.items, 2 * K * cap); A(&h->Q.count, 2 * K); A(&h->Q.head, K);
+        A(&h->Q.s_items, K * cap); A(&h->Q.s_count, K); A(&h->Q.s_head, K);
+        A(&h->Q.done_count, B * CS);
+        A(&h->d_window, B * (H + 2));
+        h->Q.window = h->d_window;
+    }
     A(&h->d_alt, B * d.nc);
     A(&h->d_zout, B * CS * H * h->nz);
     A(&h->d_Q, H * d.nq * d.nq);
@@ -397,14 +395,19 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     // small batches: one wave per workgroup keeps every problem on its own CU (latency);
     // large batches: 4 waves share one staged table (throughput)
     h->waves = (B * H >= 4096) ? 4 : 1;
+    {   // persistent workgroups per knot: ~2 problems per lane group and round, all workgroups resident
+        const size_t groups_per_wg = (64 / h->ki.G) * h->waves;
+        const size_t per_knot = (B * H + d.H_ref - 1) / d.H_ref;
+        size_t w = (per_knot + 2 * groups_per_wg - 1) / (2 * groups_per_wg);
+        const size_t resident = std::max<size_t>(1, 512 / d.H_ref);
+        h->wpk = (int)std::max<size_t>(1, std::min<size_t>(w, std::min<size_t>(8, resident)));
+    }
     {   // sub-batches: >= 64 rollouts each, at most 4 (host launch rate bounds the useful count)
         // default 1: on MI355X a sweep launch of >= 64 rollouts already fills the 2 workgroups/CU the
         // kernel's LDS footprint allows, so extra streams only multiply the per-launch latency floor
         // (measured: 4 sub-batches 34.8 ms/step vs 28.2 ms single batch at B = 512).  CIMPC_SUBBATCHES
         // overrides for experiments.
-        int nsub = 1;
-        if (const char* e = std::getenv("CIMPC_SUBBATCHES")) nsub = std::max(1, std::atoi(e));
-        nsub = (int)std::min<size_t>((size_t)nsub, std::max<size_t>(1, B / 32));
+        int nsub = 1;      // the device work queues are shared by the whole batch
         h->subs.resize(nsub);
         int* dc = nullptr;
         if (dev_alloc(h, &dc, 8 * (size_t)nsub) != CIMPC_OK) { g_create_error = h->err; cimpc_destroy(h); return CIMPC_ERR_HIP; }
@@ -567,46 +570,14 @@ int cimpc_set_window(cimpc_handle h, const int* window) {
     if (!h || !window) return fail(h, CIMPC_ERR_INVALID, "null argument");
     const cimpc_dims& d = h->dm;
     const int B = d.B, H = d.H, K = d.H_ref;
-    // bucket problems (slot sb = b*CS + c, i) by reference knot window[b][i]; inside a knot the
-    // order is (c, b) so that the slots evaluated together (c = 0 in most rounds) fill whole
-    // workgroups and the others form workgroups that exit before staging anything
-    std::vector<int> cnt(K + 1, 0);
-    for (int b = 0; b < B; ++b)
-        for (int i = 0; i < H; ++i) {
-            const int t = window[(size_t)b * (H + 2) + i];
-            if (t < 1 || t > K) return fail(h, CIMPC_ERR_INVALID, "window entry out of range (1-based knot index)");
-            cnt[t]++;
-        }
-    const int pw = (64 / h->ki.G) * h->waves;   // problems per workgroup
-    std::vector<int> plist;
-    plist.reserve((size_t)B * CS * H);
-    std::vector<int> desc;
-    for (auto& sbt : h->subs) {                 // descriptors grouped per sub-batch
-        std::vector<std::vector<int>> per_knot(K + 1);
-        for (int b = sbt.b0; b < sbt.b0 + sbt.nb; ++b)
-            for (int i = 0; i < H; ++i) per_knot[window[(size_t)b * (H + 2) + i]].push_back(b * H + i);
-        sbt.wg0 = (int)desc.size() / 4;
-        for (int t = 1; t <= K; ++t)
-            for (int c = 0; c < CS; ++c) {
-                const int first = (int)plist.size();
-                const int n = (int)per_knot[t].size();
-                for (int e : per_knot[t]) {
-                    const int b = e / H, i = e - b * H;
-                    plist.push_back((b * CS + c) * H + i);
-                }
-                for (int s0 = 0; s0 < n; s0 += pw) {
-                    desc.push_back(t - 1);
-                    desc.push_back(first + s0);
-                    desc.push_back(std::min(pw, n - s0));
-                    desc.push_back(0);
-                }
-            }
-        sbt.nwg = (int)desc.size() / 4 - sbt.wg0;
+    std::vector<int> w0((size_t)B * (H + 2));
+    for (size_t k = 0; k < w0.size(); ++k) {
+        const int t = window[k];
+        if (t < 1 || t > K) return fail(h, CIMPC_ERR_INVALID, "window entry out of range (1-based knot index)");
+        w0[k] = t - 1;                 // the device buckets problems by 0-based knot (newton_kernels.hip: enqueue_eval)
     }
-    h->n_wg = (int)desc.size() / 4;
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipMemcpy(h->d_plist, plist.data(), plist.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->d_wg_desc, desc.data(), desc.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_window, w0.data(), w0.size() * sizeof(int), hipMemcpyHostToDevice));
     h->window_set = true;
     return CIMPC_OK;
 }
@@ -650,23 +621,30 @@ int cimpc_implicit_dynamics(cimpc_handle h, const double* q, const double* theta
     HIP_TRY(h, up(T.th, theta, H * h->nth));
     if (gamma) HIP_TRY(h, up(T.g, gamma, H * d.nc));
     if (b) HIP_TRY(h, up(T.b, b, H * d.nb));
+    // queue slot 0 of every rollout, then run rounds until no solve is parked
+    HIP_TRY(h, hipMemsetAsync(h->Q.count, 0, 2 * h->Q.K * sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->Q.head, 0, h->Q.K * sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->Q.s_count, 0, h->Q.K * sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->Q.s_head, 0, h->Q.K * sizeof(int), h->stream));
     {
-        std::vector<int> pat(B * CS, 0);
-        for (size_t r = 0; r < B; ++r) pat[r * CS] = 1;
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        HIP_TRY(h, hipMemcpy(h->d_need_first, pat.data(), pat.size() * sizeof(int), hipMemcpyHostToDevice));
+        NewtonDev Sk = h->S;
+        Sk.WQ = h->Q; Sk.WQ.par = 0;
+        rc = launch_enqueue_all(Sk, h->stream);
+        if (rc != CIMPC_OK) return fail(h, rc, "enqueue launch failed");
     }
-    HIP_TRY(h, hipMemsetAsync(h->S.pflag, 0, B * CS * H * sizeof(int), h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->S.cur_slot, 0, B * sizeof(int), h->stream));
-    for (int pass = 0; pass < 64; ++pass) {     // resumable solves: relaunch until nothing is parked
+    for (int pass = 0; pass < 64; ++pass) {
+        const int par = pass & 1;
         HIP_TRY(h, hipMemsetAsync(h->S.counters, 0, 8 * sizeof(int), h->stream));
-        rc = run_sweep(h, T, h->d_need_first, z ? h->d_zout : nullptr);
+        rc = run_sweep(h, par, h->S.counters + 2, z ? h->d_zout : nullptr, h->stream);
         if (rc != CIMPC_OK) return rc;
+        HIP_TRY(h, hipMemsetAsync(h->Q.count + par * h->Q.K, 0, h->Q.K * sizeof(int), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->Q.head, 0, h->Q.K * sizeof(int), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->Q.s_count, 0, h->Q.K * sizeof(int), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->Q.s_head, 0, h->Q.K * sizeof(int), h->stream));
         HIP_TRY(h, hipMemcpyAsync(h->h_counters, h->S.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         if (h->h_counters[2] == 0) break;
     }
-    HIP_TRY(h, hipMemsetAsync(h->S.pflag, 0, B * CS * H * sizeof(int), h->stream));
     auto down = [&](void* dst, const void* src, size_t row_bytes) {
         return hipMemcpy2DAsync(dst, row_bytes, src, CS * row_bytes, row_bytes, B, hipMemcpyDeviceToHost, h->stream);
     };
@@ -716,7 +694,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     std::vector<SubBatch> single(1);
     if (h->external_stream) {
         single[0] = h->subs[0];
-        single[0].b0 = 0; single[0].nb = h->dm.B; single[0].wg0 = 0; single[0].nwg = h->n_wg;
+        single[0].b0 = 0; single[0].nb = h->dm.B;
         single[0].st = h->stream;
     }
     std::vector<SubBatch>& subs = h->external_stream ? single : h->subs;
@@ -724,6 +702,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         // [KKT for rollouts that start an iteration] -> sweep -> residual + line-search decision
         NewtonDev Sk = S;
         Sk.b0 = sb.b0; Sk.nb_launch = sb.nb; Sk.counters = sb.d_cnt;
+        Sk.WQ = h->Q; Sk.WQ.par = (int)(sb.rounds & 1);       // round parity selects the queue being consumed
         if (hipMemsetAsync(sb.d_cnt, 0, 8 * sizeof(int), sb.st) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "memset failed");
         if (sb.n_kkt > 0) {
             prof_begin(h, PC_KKT, sb.st);
@@ -732,7 +711,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             if (r != CIMPC_OK) return fail(h, r, "kkt launch failed");
             h->prof_kkt_systems += sb.n_kkt;
         }
-        int r = run_sweep_sub(h, sb);
+        int r = run_sweep(h, Sk.WQ.par, sb.d_cnt + 2, nullptr, sb.st);
         if (r != CIMPC_OK) return r;
         prof_begin(h, PC_RESID, sb.st);
         r = launch_resid_decide(Sk, sb.st);
@@ -744,9 +723,15 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         return CIMPC_OK;
     };
     int active = 0;
+    HIP_TRY(h, hipMemsetAsync(h->Q.count, 0, 2 * h->Q.K * sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->Q.head, 0, h->Q.K * sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->Q.s_count, 0, h->Q.K * sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->Q.s_head, 0, h->Q.K * sizeof(int), h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     for (SubBatch& sb : subs) {
         NewtonDev Sk = S;
         Sk.b0 = sb.b0; Sk.nb_launch = sb.nb; Sk.counters = sb.d_cnt;
+        Sk.WQ = h->Q; Sk.WQ.par = 0;
         prof_begin(h, PC_OTHER, sb.st);
         rc = launch_reset(Sk, q0_dev, q1_dev, warm_start, sb.st);
         prof_end(h, sb.st);

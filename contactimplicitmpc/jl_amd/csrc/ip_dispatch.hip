@@ -11,7 +11,7 @@ namespace cimpc {
     X(centroidal, 18, 12, 3, 4, 16)
 
 #define X(name, q, u, w, c, b)                                                               \
-    int ip_launch_##name(int mode, const IpParams& p, int n_wg, int waves, hipStream_t s);   \
+    int ip_launch_##name(int mode, const IpParams& p, int waves, hipStream_t s);   \
     void ip_info_##name(int mode, KernelInfo* info);
 CIMPC_MODELS(X)
 #undef X
@@ -27,10 +27,10 @@ int ip_kernel_info(const cimpc_dims* dm, KernelInfo* info) {
     return CIMPC_ERR_INVALID;
 }
 
-int launch_ip_sweep(const cimpc_dims* dm, const IpParams& p, int n_wg, int waves, hipStream_t s) {
+int launch_ip_sweep(const cimpc_dims* dm, const IpParams& p, int waves, hipStream_t s) {
 #define X(name, q, u, w, c, b)                                                          \
     if (dm->nq == q && dm->nu == u && dm->nw == w && dm->nc == c && dm->nb == b)        \
-        return ip_launch_##name(dm->mode, p, n_wg, waves, s);
+        return ip_launch_##name(dm->mode, p, waves, s);
     CIMPC_MODELS(X)
 #undef X
     return CIMPC_ERR_INVALID;

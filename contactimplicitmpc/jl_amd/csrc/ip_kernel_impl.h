@@ -215,194 +215,280 @@ struct IpSolver {
         return LG::all_min(a);
     }
 
-    // interior-point iteration (DESIGN.md "IP iteration spec").  Runs at most `cap` iterations
-    // in this launch; returns 1 = converged, 0 = failed (max_iter / stall), 2 = parked (resume
-    // later from exactly this state: iterate, residual, violations, reg, iters).
-    __device__ __forceinline__ int solve(const cimpc_ip_opts& o, int& iters, double& reg, double& r_vio,
-                                         double& k_vio, int cap) {
-        int done = 0;
-        while (true) {
-            if (r_vio < o.r_tol && k_vio < o.kappa_tol) return 1;
-            if (iters >= o.max_iter) return 0;
-            if (done >= cap) return 2;
-            ++done;
-            ++iters;
-            reg = (k_vio < o.kappa_reg) ? k_vio * o.gamma_reg : 0.0;
-            factorize(reg);
-            linear_solve();                                   // predictor
-            const double a_aff = step_length(1.0);
-            const double mu = LG::all_sum(vy ? y1 * y2 : 0.0) / (double)NY;
-            const double mu_aff =
-                LG::all_sum(vy ? (y1 - a_aff * Dy1_) * (y2 - a_aff * Dy2_) : 0.0) / (double)NY;
-            double sg = fmin(fmax(mu_aff / mu, 0.0), 1.0);
-            sg = sg * sg * sg;
-            const double kc = fmax(sg * mu, o.kappa_tol / o.undercut);
-            // corrector residual: rdyn, rrst unchanged (same z), rbil = y1*y2 - kc + Dy1*Dy2
-            rbil = vy ? ((y1 * y2 - kc) + Dy1_ * Dy2_) : 0.0;
-            linear_solve();                                   // corrector
-            const double vm = fmax(r_vio, k_vio);
-            const double tau = fmax(1.0 - o.eps_min, 1.0 - vm * vm);
-            const double alpha = step_length(tau);
-            if (alpha < o.stall_alpha) return 0;              // [spec] stall exit: jammed on the boundary
-            x -= alpha * Dx_;
-            y1 = vy ? (y1 - alpha * Dy1_) : 1.0;
-            y2 = vy ? (y2 - alpha * Dy2_) : 1.0;
-            double k_c = 0.0, r_c = 0.0, back = alpha;
-            for (int s = 1; s <= o.max_ls; ++s) {
-                residual(0.0);
-                k_c = k_violation();
-                r_c = r_violation();
-                if (r_c <= r_vio || k_c <= k_vio) break;
-                back *= o.ls_scale;                           // alpha * ls_scale^s
-                x += back * Dx_;
-                y1 = vy ? (y1 + back * Dy1_) : 1.0;
-                y2 = vy ? (y2 + back * Dy2_) : 1.0;
-            }
-            k_vio = k_c;
-            r_vio = r_c;
+    // ONE interior-point iteration (DESIGN.md "IP iteration spec").  Returns true when the step
+    // length stalled (the solve fails).  Convergence / iteration-budget checks are the caller's.
+    __device__ __forceinline__ bool iterate(const cimpc_ip_opts& o, double& reg, double& r_vio, double& k_vio) {
+        reg = (k_vio < o.kappa_reg) ? k_vio * o.gamma_reg : 0.0;
+        factorize(reg);
+        linear_solve();                                   // predictor
+        const double a_aff = step_length(1.0);
+        const double mu = LG::all_sum(vy ? y1 * y2 : 0.0) / (double)NY;
+        const double mu_aff =
+            LG::all_sum(vy ? (y1 - a_aff * Dy1_) * (y2 - a_aff * Dy2_) : 0.0) / (double)NY;
+        double sg = fmin(fmax(mu_aff / mu, 0.0), 1.0);
+        sg = sg * sg * sg;
+        const double kc = fmax(sg * mu, o.kappa_tol / o.undercut);
+        // corrector residual: rdyn, rrst unchanged (same z), rbil = y1*y2 - kc + Dy1*Dy2
+        rbil = vy ? ((y1 * y2 - kc) + Dy1_ * Dy2_) : 0.0;
+        linear_solve();                                   // corrector
+        const double vm = fmax(r_vio, k_vio);
+        const double tau = fmax(1.0 - o.eps_min, 1.0 - vm * vm);
+        const double alpha = step_length(tau);
+        if (alpha < o.stall_alpha) return true;           // [spec] stall exit: jammed on the boundary
+        x -= alpha * Dx_;
+        y1 = vy ? (y1 - alpha * Dy1_) : 1.0;
+        y2 = vy ? (y2 - alpha * Dy2_) : 1.0;
+        double k_c = 0.0, r_c = 0.0, back = alpha;
+        for (int s = 1; s <= o.max_ls; ++s) {
+            residual(0.0);
+            k_c = k_violation();
+            r_c = r_violation();
+            if (r_c <= r_vio || k_c <= k_vio) break;
+            back *= o.ls_scale;                           // alpha * ls_scale^s
+            x += back * Dx_;
+            y1 = vy ? (y1 + back * Dy1_) : 1.0;
+            y2 = vy ? (y2 + back * Dy2_) : 1.0;
         }
+        k_vio = k_c;
+        r_vio = r_c;
+        return false;
     }
 };
 
+// one value of lane 0 of the group to the whole group
+template <int G>
+__device__ __forceinline__ int group_bcast0(int v) {
+    if constexpr (G == 16) return __builtin_amdgcn_update_dpp(0, v, 0x150, 0xF, 0xF, true);
+    else return __shfl(v, (int)(threadIdx.x & 63) & ~31, 64);
+}
+
 template <class M>
-__global__ __launch_bounds__(256) void ip_sweep_kernel(IpParams p) {
-    constexpr int NX = M::NX, NY = M::NY, NTH = M::NTH, NTHS = M::NTHS, ND = M::ND, G = M::G;
+__device__ __forceinline__ void stage_table(double* tab, const double* src_tab, int knot, int tid) {
+    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G);
+    const double2* src = reinterpret_cast<const double2*>(src_tab + (size_t)knot * L.size);
+    double2* dst = reinterpret_cast<double2*>(tab);
+    for (int k = tid; k < L.size / 2; k += (int)blockDim.x) dst[k] = src[k];   // 16 B per lane, coalesced
+}
+
+// ----------------------------------------------------------------------------------------
+// Queue kernel: persistent workgroups, `wpk` per reference knot.  Every 16-lane group pulls
+// problems of its knot until the queue is empty; all groups of a wave run the same iteration
+// body, a group whose solve ends (converged / failed / parked) finalises it and pulls the next
+// problem while its neighbours keep iterating.
+// ----------------------------------------------------------------------------------------
+template <class M>
+__global__ __launch_bounds__(256, 2) void ip_queue_kernel(IpParams p) {
+    constexpr int NX = M::NX, NY = M::NY, NTH = M::NTH, ND = M::ND, G = M::G;
     constexpr int NC = M::NC, NB = M::NB;
     constexpr LinLayout L(NX, NY, NTH, G);
+    constexpr int PS = 2 * NX + 4 * NY + 4;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* tab = smem;
     const int tid = (int)threadIdx.x;
-    const int4 desc = reinterpret_cast<const int4*>(p.wg_desc)[blockIdx.x];
-    const int knot = desc.x, start = desc.y, count = desc.z;
+    const int knot = (int)blockIdx.x / p.wpk;
+    const int K = p.Q.K, cap = p.Q.cap, par = p.Q.par;
+    const int n = p.Q.count[par * K + knot];
+    if (n == 0) return;
+    stage_table<M>(tab, p.tab, knot, tid);
+    __syncthreads();
 
     const int grp = tid / G;
     const int l = tid % G;
-    int b = 0, i = 0;
-    bool active = false;
-    if (grp < count) {
-        const int prob = p.plist[start + grp];
-        b = prob / p.H;
-        i = prob - b * p.H;
-        active = ((p.need_sweep == nullptr) || (p.need_sweep[b] != 0)) && (p.pflag[prob] != 2);
-    }
-    // rollouts that are not being evaluated in this round (line search finished or still
-    // backtracking elsewhere) leave holes: skip the table staging when the whole workgroup is idle
-    if (!__syncthreads_or(active ? 1 : 0)) return;
-
-    {   // stage the knot's table: 16 B per lane, fully coalesced
-        const double2* src = reinterpret_cast<const double2*>(p.tab + (size_t)knot * L.size);
-        double2* dst = reinterpret_cast<double2*>(tab);
-        for (int k = tid; k < L.size / 2; k += (int)blockDim.x) dst[k] = src[k];
-    }
-    __syncthreads();
-    if (!active) return;
-
     double* Rst = smem + L.size + (size_t)grp * M::LDS_GROUP;   // [NY][G+1]
     double* dth = Rst + NY * M::RST_LD;                          // [NTH]
+    const int* items = p.Q.items + ((size_t)par * K + knot) * cap;
+    int* head = p.Q.head + knot;
 
     IpSolver<M> S;
     S.bind(tab, Rst, l);
     const bool vx = S.vx, vy = S.vy;
+    const cimpc_ip_opts o = p.o;
 
-    // ---- problem data: theta - theta0 (LDS, read as broadcast), start point ------------
-    const double* th = p.theta + ((size_t)b * p.H + i) * NTH;
-    for (int k = l; k < NTH; k += G) dth[k] = th[k] - tab[L.oTh0 + k];
-    wave_lds_fence();
-    {   // rthdyn*(th-th0), rthrst*(th-th0): constant per solve
-        double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
-        int k = 0;
-        for (; k + 1 < NTH; k += 2) {
-            const double d0 = dth[k], d1 = dth[k + 1];
-            a0 = fma(tab[L.oRthDyn + k * G + l], d0, a0);
-            c0 = fma(tab[L.oRthRst + k * G + l], d0, c0);
-            a1 = fma(tab[L.oRthDyn + (k + 1) * G + l], d1, a1);
-            c1 = fma(tab[L.oRthRst + (k + 1) * G + l], d1, c1);
+    bool have = false, exhausted = false, stalled = false;
+    int prob = 0, iters = 0, done_here = 0;
+    double reg = 0.0, r_vio = 0.0, k_vio = 0.0, qinit = 0.0;
+
+    while (true) {
+        // ---- 1. end of a solve? ---------------------------------------------------------------
+        if (have) {
+            int code = -1;
+            if (stalled) code = 0;
+            else if (r_vio < o.r_tol && k_vio < o.kappa_tol) code = 1;
+            else if (iters >= o.max_iter) code = 0;
+            else if (done_here >= p.iter_cap) code = 2;
+            if (code >= 0) {
+                const size_t pi = (size_t)prob;
+                const int sb = prob / p.H;
+                double* ps = p.pstate + pi * PS;
+                if (code == 2) {             // park: exact state, re-queued for the next round
+                    if (vx) { ps[l] = S.x; ps[NX + 2 * NY + l] = S.rdyn; }
+                    if (vy) { ps[NX + l] = S.y1; ps[NX + NY + l] = S.y2; ps[2 * NX + 2 * NY + l] = S.rrst; ps[2 * NX + 3 * NY + l] = S.rbil; }
+                    if (l == 0) {
+                        ps[PS - 4] = r_vio; ps[PS - 3] = k_vio; ps[PS - 2] = reg; ps[PS - 1] = (double)iters;
+                        p.pflag[pi] = 1;
+                        const int pos = atomicAdd(&p.Q.count[(par ^ 1) * K + knot], 1);
+                        p.Q.items[((size_t)(par ^ 1) * K + knot) * cap + pos] = prob;
+                        atomicAdd(p.pending_count, 1);
+                    }
+                } else {
+                    if (l == 0) { p.status[pi] = code; p.iters[pi] = iters; }
+                    // d = z[1:nd] - [q_{i+2}; gamma_i; b_i]  (implicit_dynamics.jl:180-190)
+                    if (vx) p.d[pi * ND + l] = S.x - qinit;
+                    if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) {
+                        if (l < NC) p.d[pi * ND + NX + l] = S.y1 - p.gam[pi * NC + l];
+                        else if (l < NC + NB) p.d[pi * ND + NX + l] = S.y1 - p.bfr[pi * NB + (l - NC)];
+                    }
+                    if (p.zout != nullptr) {
+                        double* zo = p.zout + pi * M::NZ;
+                        if (vx) zo[l] = S.x;
+                        if (vy) { zo[NX + l] = S.y1; zo[NX + NY + l] = S.y2; }
+                    }
+                    if (code == 1) {         // converged: hand z* to the sensitivity pass
+                        if (vx) ps[l] = S.x;
+                        if (vy) { ps[NX + l] = S.y1; ps[NX + NY + l] = S.y2; }
+                        if (l == 0) {
+                            ps[PS - 2] = reg;
+                            const int pos = atomicAdd(&p.Q.s_count[knot], 1);
+                            p.Q.s_items[(size_t)knot * cap + pos] = prob;
+                        }
+                    } else if (l == 0) {     // failed: the slot keeps its previous sensitivities
+                        atomicAdd(&p.Q.done_count[sb], 1);
+                    }
+                }
+                have = false;
+            }
         }
-        for (; k < NTH; ++k) {
-            const double d0 = dth[k];
-            a0 = fma(tab[L.oRthDyn + k * G + l], d0, a0);
-            c0 = fma(tab[L.oRthRst + k * G + l], d0, c0);
+        // ---- 2. pull the next problem of this knot -----------------------------------------
+        if (!have && !exhausted) {
+            int idx = 0;
+            if (l == 0) idx = atomicAdd(head, 1);
+            idx = group_bcast0<G>(idx);
+            if (idx < n) {
+                prob = items[idx];
+                const int sb = prob / p.H, i = prob - sb * p.H;
+                const size_t pi = (size_t)prob;
+                const double* th = p.theta + pi * NTH;
+                for (int k = l; k < NTH; k += G) dth[k] = th[k] - tab[L.oTh0 + k];
+                wave_lds_fence();
+                {   // rthdyn*(th-th0), rthrst*(th-th0): constant per solve
+                    double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
+                    int k = 0;
+                    for (; k + 1 < NTH; k += 2) {
+                        const double d0 = dth[k], d1 = dth[k + 1];
+                        a0 = fma(tab[L.oRthDyn + k * G + l], d0, a0);
+                        c0 = fma(tab[L.oRthRst + k * G + l], d0, c0);
+                        a1 = fma(tab[L.oRthDyn + (k + 1) * G + l], d1, a1);
+                        c1 = fma(tab[L.oRthRst + (k + 1) * G + l], d1, c1);
+                    }
+                    for (; k < NTH; ++k) {
+                        const double d0 = dth[k];
+                        a0 = fma(tab[L.oRthDyn + k * G + l], d0, a0);
+                        c0 = fma(tab[L.oRthRst + k * G + l], d0, c0);
+                    }
+                    S.tthdyn = a0 + a1;
+                    S.tthrst = c0 + c1;
+                }
+                S.altl = (p.alt != nullptr && l < NC) ? p.alt[(size_t)(sb / p.slots) * NC + l] : 0.0;
+                const double* qrow = p.q + ((size_t)sb * (p.H + 2) + (i + 2)) * M::NQ;
+                qinit = vx ? qrow[l] : 0.0;
+                const double* ps = p.pstate + pi * PS;
+                if (p.pflag[pi] == 1) {      // resume a parked solve
+                    S.x = vx ? ps[l] : 0.0;
+                    S.y1 = vy ? ps[NX + l] : 1.0;
+                    S.y2 = vy ? ps[NX + NY + l] : 1.0;
+                    S.rdyn = vx ? ps[NX + 2 * NY + l] : 0.0;
+                    S.rrst = vy ? ps[2 * NX + 2 * NY + l] : 0.0;
+                    S.rbil = vy ? ps[2 * NX + 3 * NY + l] : 0.0;
+                    r_vio = ps[PS - 4]; k_vio = ps[PS - 3]; reg = ps[PS - 2]; iters = (int)ps[PS - 1];
+                    wave_lds_fence();
+                    if (l == 0) p.pflag[pi] = 0;
+                } else {
+                    // z_initialize!: z .= 1, z[iq2] = q   (simulation.jl:59-63)
+                    S.x = qinit; S.y1 = 1.0; S.y2 = 1.0;
+                    S.residual(0.0);
+                    r_vio = S.r_violation();
+                    k_vio = S.k_violation();
+                    iters = 0;
+                    reg = 0.0;
+                }
+                done_here = 0;
+                stalled = false;
+                have = true;
+            } else {
+                exhausted = true;
+            }
         }
-        S.tthdyn = a0 + a1;
-        S.tthrst = c0 + c1;
+        // ---- 3. one iteration for every group that holds a problem ------------------------------
+        if (!__any(have ? 1 : 0)) break;
+        if (have && !(r_vio < o.r_tol && k_vio < o.kappa_tol) && iters < o.max_iter && done_here < p.iter_cap) {
+            ++done_here;
+            ++iters;
+            stalled = S.iterate(o, reg, r_vio, k_vio);
+        }
     }
-    if (p.alt != nullptr && l < NC) S.altl = p.alt[(size_t)(b / p.slots) * NC + l];
+}
 
-    const double* qrow = p.q + ((size_t)b * (p.H + 2) + (i + 2)) * M::NQ;
-    const double qinit = vx ? qrow[l] : 0.0;
-    const size_t pi = (size_t)b * p.H + i;
+// ----------------------------------------------------------------------------------------
+// Sensitivity kernel: differentiate_solution! for the problems that converged in the queue kernel.
+// dz = -(rz^-1 rth) at z*, reg = max(reg, kappa_tol*gamma_reg); only the consumed block
+// (rows 1:nd, columns q0,q1,u1 - implicit_dynamics.jl:84-86) is computed.
+// ----------------------------------------------------------------------------------------
+template <class M>
+__global__ __launch_bounds__(256, 2) void ip_sens_kernel(IpParams p) {
+    constexpr int NX = M::NX, NY = M::NY, NTH = M::NTH, NTHS = M::NTHS, ND = M::ND, G = M::G;
+    constexpr int NC = M::NC, NB = M::NB;
+    constexpr LinLayout L(NX, NY, NTH, G);
     constexpr int PS = 2 * NX + 4 * NY + 4;
-    double* ps = p.pstate + pi * PS;
-    int iters;
-    double reg, r_vio, k_vio;
-    if (p.pflag[pi] == 1) {      // resume a parked solve
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* tab = smem;
+    const int tid = (int)threadIdx.x;
+    const int knot = (int)blockIdx.x / p.wpk;
+    const int cap = p.Q.cap;
+    const int n = p.Q.s_count[knot];
+    if (n == 0) return;
+    stage_table<M>(tab, p.tab, knot, tid);
+    __syncthreads();
+    const int grp = tid / G;
+    const int l = tid % G;
+    double* Rst = smem + L.size + (size_t)grp * M::LDS_GROUP;
+    const int* items = p.Q.s_items + (size_t)knot * cap;
+    IpSolver<M> S;
+    S.bind(tab, Rst, l);
+    const bool vx = S.vx, vy = S.vy;
+    while (true) {
+        int idx = 0;
+        if (l == 0) idx = atomicAdd(p.Q.s_head + knot, 1);
+        idx = group_bcast0<G>(idx);
+        if (idx >= n) break;
+        const int prob = items[idx];
+        const size_t pi = (size_t)prob;
+        const double* ps = p.pstate + pi * PS;
         S.x = vx ? ps[l] : 0.0;
         S.y1 = vy ? ps[NX + l] : 1.0;
         S.y2 = vy ? ps[NX + NY + l] : 1.0;
-        S.rdyn = vx ? ps[NX + 2 * NY + l] : 0.0;
-        S.rrst = vy ? ps[2 * NX + 2 * NY + l] : 0.0;
-        S.rbil = vy ? ps[2 * NX + 3 * NY + l] : 0.0;
-        r_vio = ps[PS - 4]; k_vio = ps[PS - 3]; reg = ps[PS - 2]; iters = (int)ps[PS - 1];
-    } else {
-        // z_initialize!: z .= 1, z[iq2] = q   (simulation.jl:59-63)
-        S.x = qinit; S.y1 = 1.0; S.y2 = 1.0;
-        S.residual(0.0);
-        r_vio = S.r_violation();
-        k_vio = S.k_violation();
-        iters = 0;
-        reg = 0.0;
-    }
-    const int code = S.solve(p.o, iters, reg, r_vio, k_vio, p.iter_cap);
-    if (code == 2) {             // park: exact state, continue in the next launch
-        if (vx) { ps[l] = S.x; ps[NX + 2 * NY + l] = S.rdyn; }
-        if (vy) { ps[NX + l] = S.y1; ps[NX + NY + l] = S.y2; ps[2 * NX + 2 * NY + l] = S.rrst; ps[2 * NX + 3 * NY + l] = S.rbil; }
-        if (l == 0) {
-            ps[PS - 4] = r_vio; ps[PS - 3] = k_vio; ps[PS - 2] = reg; ps[PS - 1] = (double)iters;
-            p.pflag[pi] = 1;
-            atomicAdd(p.pending_count, 1);
-        }
-        return;
-    }
-    const bool ok = code == 1;
-    if (l == 0) p.pflag[pi] = 2;
-    if (l == 0) {
-        p.status[pi] = ok ? 1 : 0;
-        p.iters[pi] = iters;
-    }
-    // dynamics violation d = z[1:nd] - [q_{i+2}; gamma_i; b_i]  (implicit_dynamics.jl:180-190)
-    if (vx) p.d[pi * ND + l] = S.x - qinit;
-    if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) {
-        if (l < NC) p.d[pi * ND + NX + l] = S.y1 - p.gam[pi * NC + l];
-        else if (l < NC + NB) p.d[pi * ND + NX + l] = S.y1 - p.bfr[pi * NB + (l - NC)];
-    }
-    if (p.zout != nullptr) {
-        double* zo = p.zout + pi * M::NZ;
-        if (vx) zo[l] = S.x;
-        if (vy) { zo[NX + l] = S.y1; zo[NX + NY + l] = S.y2; }
-    }
-    if (!ok) return;   // failed solve: sensitivities of this slot stay untouched
-
-    // ---- differentiate_solution!: dz = -(rz^-1 rth), reg = max(reg, kappa_tol*gamma_reg)
-    S.factorize(fmax(reg, p.o.kappa_tol * p.o.gamma_reg));
-    double* dzo = p.dz + pi * (size_t)(NTHS * ND);
-    auto column = [&](int c) {
-        const double u = tab[L.oRthDyn + c * G + l];
-        const double v = tab[L.oRthRst + c * G + l];
-        double xs;
-        const double t = S.schur_solve(u, v, xs);
-        if (vx) dzo[c * ND + l] = -xs;
-        if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) {
-            if (l < NC + NB) dzo[c * ND + NX + l] = t;   // -(S.y) = +temp
-        }
-    };
-    // two independent right-hand sides per trip: their triangular-solve chains interleave
-    int c = 0;
+        const double reg = ps[PS - 2];
+        S.factorize(fmax(reg, p.o.kappa_tol * p.o.gamma_reg));
+        double* dzo = p.dz + pi * (size_t)(NTHS * ND);
+        auto column = [&](int c) {
+            const double u = tab[L.oRthDyn + c * G + l];
+            const double v = tab[L.oRthRst + c * G + l];
+            double xs;
+            const double t = S.schur_solve(u, v, xs);
+            if (vx) dzo[c * ND + l] = -xs;
+            if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) {
+                if (l < NC + NB) dzo[c * ND + NX + l] = t;   // -(S.y) = +temp
+            }
+        };
+        // two independent right-hand sides per trip: their triangular-solve chains interleave
+        int c = 0;
 #pragma unroll 1
-    for (; c + 1 < NTHS; c += 2) {
-        column(c);
-        column(c + 1);
+        for (; c + 1 < NTHS; c += 2) {
+            column(c);
+            column(c + 1);
+        }
+        if (c < NTHS) column(c);
+        if (l == 0) atomicAdd(&p.Q.done_count[prob / p.H], 1);
     }
-    if (c < NTHS) column(c);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -410,17 +496,20 @@ __global__ __launch_bounds__(256) void ip_sweep_kernel(IpParams p) {
 // so that the models build in parallel)
 // ----------------------------------------------------------------------------------------
 template <class M>
-int launch_model(const IpParams& p, int n_wg, int waves, hipStream_t s) {
+int launch_model(const IpParams& p, int waves, hipStream_t s) {
     constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G);
     if (waves != 1 && waves != 2 && waves != 4) return CIMPC_ERR_INVALID;
     const int ppw = 64 / M::G;
     const size_t lds = (size_t)(L.size + waves * ppw * M::LDS_GROUP) * sizeof(double);
     if (lds > 64 * 1024) {   // opt in to the full 160 KiB LDS of a gfx950 CU
-        if (hipFuncSetAttribute((const void*)ip_sweep_kernel<M>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)ip_queue_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)ip_sens_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return CIMPC_ERR_HIP;
     }
-    hipLaunchKernelGGL((ip_sweep_kernel<M>), dim3(n_wg), dim3(64 * waves), lds, s, p);
+    const int grid = p.Q.K * p.wpk;
+    hipLaunchKernelGGL((ip_queue_kernel<M>), dim3(grid), dim3(64 * waves), lds, s, p);
+    if (hipGetLastError() != hipSuccess) return CIMPC_ERR_HIP;
+    hipLaunchKernelGGL((ip_sens_kernel<M>), dim3(grid), dim3(64 * waves), lds, s, p);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
 
@@ -434,9 +523,9 @@ void info_model(KernelInfo* info) {
 }
 
 #define CIMPC_DEFINE_MODEL(name, q, u, w, c, b)                                              \
-    int ip_launch_##name(int mode, const IpParams& p, int n_wg, int waves, hipStream_t s) {  \
-        if (mode == 0) return launch_model<Model<q, u, w, c, b, 0>>(p, n_wg, waves, s);      \
-        return launch_model<Model<q, u, w, c, b, 1>>(p, n_wg, waves, s);                     \
+    int ip_launch_##name(int mode, const IpParams& p, int waves, hipStream_t s) {            \
+        if (mode == 0) return launch_model<Model<q, u, w, c, b, 0>>(p, waves, s);            \
+        return launch_model<Model<q, u, w, c, b, 1>>(p, waves, s);                           \
     }                                                                                        \
     void ip_info_##name(int mode, KernelInfo* info) {                                        \
         if (mode == 0) info_model<Model<q, u, w, c, b, 0>>(info);                            \

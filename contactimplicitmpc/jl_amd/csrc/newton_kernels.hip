@@ -46,6 +46,21 @@ __device__ __forceinline__ void copy_n(double* dst, const double* src, int n, in
 // current im_traj of rollout b.
 __device__ __forceinline__ double ls_alpha(int iter) { return ldexp(1.0, -iter); }
 
+// Request the evaluation (implicit_dynamics! sweep) of slot sb: one queue entry per horizon step,
+// bucketed by the reference knot of that step.
+__device__ __forceinline__ void enqueue_eval(const NewtonDev& S, size_t sb, int b, int par, int tid, int nt) {
+    const int H = S.dm.H, K = S.WQ.K;
+    for (int k = tid; k < H; k += nt) {
+        const int t = S.WQ.window[(size_t)b * (H + 2) + k];
+        const int pos = atomicAdd(&S.WQ.count[par * K + t], 1);
+        S.WQ.items[((size_t)par * K + t) * S.WQ.cap + pos] = (int)(sb * H + k);
+    }
+    if (tid == 0) {
+        S.WQ.done_count[sb] = 0;
+        S.need_sweep[sb] = 1;
+    }
+}
+
 __global__ __launch_bounds__(256) void reset_kernel(NewtonDev S, const double* q0,
                                                     const double* q1, int warm) {
     const cimpc_dims& m = S.dm;
@@ -86,7 +101,7 @@ __global__ __launch_bounds__(256) void reset_kernel(NewtonDev S, const double* q
     if (tid == 0) {
         S.beta[b] = S.beta_init;
         S.stage[b] = STAGE_INIT;
-        for (int c = 0; c < CS; ++c) S.need_sweep[sb0 + c] = (c == 0);
+        for (int c = 1; c < CS; ++c) S.need_sweep[sb0 + c] = 0;
         S.cur_slot[b] = 0;
         S.newton_l[b] = 0;
         S.alpha[b] = 1.0;
@@ -97,6 +112,8 @@ __global__ __launch_bounds__(256) void reset_kernel(NewtonDev S, const double* q
         S.ro_ip_fail[b] = 0;
     }
     for (int k = tid; k < CS * H; k += nt) S.pflag[sb0 * H + k] = 0;
+    __syncthreads();
+    enqueue_eval(S, sb0, b, S.WQ.par, tid, nt);
 }
 
 // x_dst = traj - alpha*Delta for q_{t+2}, u_t, nu_t (+ gamma, b in cf mode), then update_theta!.
@@ -227,18 +244,21 @@ __global__ __launch_bounds__(256) void resid_decide_kernel(NewtonDev S) {
     const int b = blockIdx.x + S.b0, tid = threadIdx.x, nt = blockDim.x;
     const int H = m.H;
     const size_t sb0 = (size_t)b * CS;
+    if (blockIdx.x == 0) {   // the queue of this round has been consumed: recycle it
+        const int K = S.WQ.K, par = S.WQ.par;
+        for (int k = tid; k < K; k += nt) { S.WQ.count[par * K + k] = 0; S.WQ.head[k] = 0; S.WQ.s_count[k] = 0; S.WQ.s_head[k] = 0; }
+    }
     const int stage = S.stage[b];
     if (stage == STAGE_DONE || stage == STAGE_KKT) return;
     if (S.need_sweep[sb0] == 0) return;          // nothing was evaluated for this rollout
     const int ncand = (stage == STAGE_LS1) ? 2 : (stage == STAGE_LS2) ? 4 : 1;
-    {   // an interior-point solve of this evaluation is still parked: wait for the next launch
+    {   // an interior-point solve of this evaluation is still parked: wait for the next round
         int pend = 0;
-        for (int k = tid; k < ncand * H; k += nt) pend |= (S.pflag[sb0 * H + k] == 1);
+        if (tid < ncand) pend = (S.WQ.done_count[sb0 + tid] < H);
         if (__syncthreads_or(pend)) {
             if (tid == 0) atomicAdd(&S.counters[0], 1);
             return;
         }
-        for (int k = tid; k < ncand * H; k += nt) S.pflag[sb0 * H + k] = 0;   // evaluation consumed
     }
     __shared__ double red[256];
     __shared__ double rc[CS];
@@ -288,10 +308,13 @@ __global__ __launch_bounds__(256) void resid_decide_kernel(NewtonDev S) {
     if (act == 2) {                       // next batch of candidates: (1/2, 1/4) or (1/8 .. 1/64)
         const int nstage = (stage == STAGE_LS0) ? STAGE_LS1 : STAGE_LS2;
         const int it0 = (nstage == STAGE_LS1) ? 1 : 3, nn = (nstage == STAGE_LS1) ? 2 : 4;
-        for (int c = 0; c < nn; ++c) apply_step(S, S.cand, S.nu_cand, sb0 + c, b, ls_alpha(it0 + c), tid, nt);
+        for (int c = 0; c < nn; ++c) {
+            apply_step(S, S.cand, S.nu_cand, sb0 + c, b, ls_alpha(it0 + c), tid, nt);
+            enqueue_eval(S, sb0 + c, b, S.WQ.par ^ 1, tid, nt);      // evaluated in the next round
+        }
         if (tid == 0) {
             S.stage[b] = nstage;
-            for (int c = 0; c < CS; ++c) S.need_sweep[sb0 + c] = (c < nn);
+            for (int c = nn; c < CS; ++c) S.need_sweep[sb0 + c] = 0;
             atomicAdd(&S.counters[0], 1);
         }
         return;
@@ -725,11 +748,12 @@ __global__ __launch_bounds__(64) void kkt_kernel_scalar(NewtonDev S, KktArgs K) 
         lds_sync();
         // line search start (newton.jl:223-228): alpha = 1, candidate = traj - Delta
         apply_step(S, S.cand, S.nu_cand, (size_t)b * CS, b, 1.0, lane, 64);
+        enqueue_eval(S, (size_t)b * CS, b, S.WQ.par, lane, 64);      // swept later in this round
         if (lane == 0) {
             S.alpha[b] = 1.0;
             S.ls_iter[b] = 0;
             S.stage[b] = STAGE_LS0;
-            for (int c = 0; c < CS; ++c) S.need_sweep[(size_t)b * CS + c] = (c == 0);
+            for (int c = 1; c < CS; ++c) S.need_sweep[(size_t)b * CS + c] = 0;
             atomicAdd(&S.counters[0], 1);
         }
     }
@@ -1046,11 +1070,12 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
         lds_sync();
         // line search start (newton.jl:223-228): alpha = 1, candidate = traj - Delta
         apply_step(S, S.cand, S.nu_cand, (size_t)b * CS, b, 1.0, lane, 64);
+        enqueue_eval(S, (size_t)b * CS, b, S.WQ.par, lane, 64);      // swept later in this round
         if (lane == 0) {
             S.alpha[b] = 1.0;
             S.ls_iter[b] = 0;
             S.stage[b] = STAGE_LS0;
-            for (int c = 0; c < CS; ++c) S.need_sweep[(size_t)b * CS + c] = (c == 0);
+            for (int c = 1; c < CS; ++c) S.need_sweep[(size_t)b * CS + c] = 0;
             atomicAdd(&S.counters[0], 1);
         }
     }
@@ -1084,6 +1109,16 @@ static int launch_kkt_any(const NewtonDev& S, const KktArgs& K, hipStream_t s) {
     return CIMPC_ERR_INVALID;
 }
 
+__global__ __launch_bounds__(64) void enqueue_all_kernel(NewtonDev S) {
+    const int b = blockIdx.x + S.b0;
+    enqueue_eval(S, (size_t)b * CS, b, S.WQ.par, threadIdx.x, 64);
+    if (threadIdx.x == 0) S.cur_slot[b] = 0;
+    for (int k = threadIdx.x; k < S.dm.H; k += 64) S.pflag[(size_t)b * CS * S.dm.H + k] = 0;
+}
+int launch_enqueue_all(const NewtonDev& S, hipStream_t s) {
+    hipLaunchKernelGGL(enqueue_all_kernel, dim3(S.nb_launch), dim3(64), 0, s, S);
+    return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+}
 int launch_reset(const NewtonDev& S, const double* q0, const double* q1, int warm, hipStream_t s) {
     hipLaunchKernelGGL(reset_kernel, dim3(S.nb_launch), dim3(256), 0, s, S, q0, q1, warm);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;

@@ -34,6 +34,7 @@ struct NewtonDev {
     int* ip_iters;     // [B*CS][H]
     int* pflag;        // [B*CS][H] resumable-solve flags (see IpParams)
     int* cur_slot;     // [B] slot holding the current im_traj (d, dz) of the rollout
+    IpQueues WQ;       // device work queues of the sweep (WQ.par = parity of the running round)
     // Newton vectors, reference layout (newton_residual.jl:69-98)
     double* res;       // [B][N]
     double* res_cand;  // [B*CS][N]
@@ -68,6 +69,7 @@ struct NewtonDev {
 
 int launch_reset(const NewtonDev& nd, const double* q0, const double* q1, int warm, hipStream_t s);
 int launch_resid_decide(const NewtonDev& nd, hipStream_t s);
+int launch_enqueue_all(const NewtonDev& nd, hipStream_t s);   // B3 seam: queue slot 0 of every rollout
 int launch_kkt(const NewtonDev& nd, hipStream_t s);
 // B1 seam: solve with caller-provided residual / beta for all rollouts, no state change
 int launch_kkt_raw(const NewtonDev& nd, const double* r_dev, double beta, double* delta_dev,
