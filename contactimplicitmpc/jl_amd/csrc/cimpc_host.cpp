@@ -38,7 +38,8 @@ struct SubBatch {
     int b0 = 0, nb = 0;          // rollout range
     int wg0 = 0, nwg = 0;        // workgroup descriptors of the sweep
     hipStream_t st = nullptr;
-    hipEvent_t ev = nullptr;
+    hipStream_t st_kkt = nullptr;   // the KKT recursion overlaps the sweep of the other rollouts
+    hipEvent_t ev = nullptr, ev_fork = nullptr, ev_join = nullptr;
     int* d_cnt = nullptr;        // 8 device counters
     int* h_cnt = nullptr;        // pinned mirror
     bool running = false;
@@ -177,7 +178,7 @@ void prof_end(cimpc_ctx* h, hipStream_t st = nullptr) {
 void prof_collect(cimpc_ctx* h) {
     if (h->prof_recs.empty()) return;
     (void)hipStreamSynchronize(h->stream);
-    for (auto& sb : h->subs) if (sb.st) (void)hipStreamSynchronize(sb.st);
+    for (auto& sb : h->subs) { if (sb.st) (void)hipStreamSynchronize(sb.st); if (sb.st_kkt) (void)hipStreamSynchronize(sb.st_kkt); }
     for (auto& r : h->prof_recs) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
@@ -417,7 +418,10 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
             sb.nb = (int)(B * (k + 1) / nsub) - sb.b0;
             sb.d_cnt = dc + 8 * k;
             if (hipStreamCreateWithFlags(&sb.st, hipStreamNonBlocking) != hipSuccess ||
+                hipStreamCreateWithFlags(&sb.st_kkt, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&sb.ev, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&sb.ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&sb.ev_join, hipEventDisableTiming) != hipSuccess ||
                 hipHostMalloc((void**)&sb.h_cnt, 8 * sizeof(int)) != hipSuccess) {
                 g_create_error = "sub-batch stream/event creation failed";
                 cimpc_destroy(h);
@@ -439,7 +443,10 @@ int cimpc_destroy(cimpc_handle h) {
     if (h->h_counters) (void)hipHostFree(h->h_counters);
     for (auto& sb : h->subs) {
         if (sb.st) { (void)hipStreamSynchronize(sb.st); (void)hipStreamDestroy(sb.st); }
+        if (sb.st_kkt) { (void)hipStreamSynchronize(sb.st_kkt); (void)hipStreamDestroy(sb.st_kkt); }
         if (sb.ev) (void)hipEventDestroy(sb.ev);
+        if (sb.ev_fork) (void)hipEventDestroy(sb.ev_fork);
+        if (sb.ev_join) (void)hipEventDestroy(sb.ev_join);
         if (sb.h_cnt) (void)hipHostFree(sb.h_cnt);
     }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -704,15 +711,20 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         Sk.b0 = sb.b0; Sk.nb_launch = sb.nb; Sk.counters = sb.d_cnt;
         Sk.WQ = h->Q; Sk.WQ.par = (int)(sb.rounds & 1);       // round parity selects the queue being consumed
         if (hipMemsetAsync(sb.d_cnt, 0, 8 * sizeof(int), sb.st) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "memset failed");
-        if (sb.n_kkt > 0) {
-            prof_begin(h, PC_KKT, sb.st);
-            int r = launch_kkt(Sk, sb.st);
-            prof_end(h, sb.st);
+        const bool kkt = sb.n_kkt > 0;
+        if (kkt) {   // fork: KKT of the rollouts that start a Newton iteration, next to the sweep
+            if (hipEventRecord(sb.ev_fork, sb.st) != hipSuccess ||
+                hipStreamWaitEvent(sb.st_kkt, sb.ev_fork, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "fork failed");
+            prof_begin(h, PC_KKT, sb.st_kkt);
+            int r = launch_kkt(Sk, sb.st_kkt);
+            prof_end(h, sb.st_kkt);
             if (r != CIMPC_OK) return fail(h, r, "kkt launch failed");
+            if (hipEventRecord(sb.ev_join, sb.st_kkt) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join record failed");
             h->prof_kkt_systems += sb.n_kkt;
         }
         int r = run_sweep(h, Sk.WQ.par, sb.d_cnt + 2, nullptr, sb.st);
         if (r != CIMPC_OK) return r;
+        if (kkt && hipStreamWaitEvent(sb.st, sb.ev_join, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join failed");
         prof_begin(h, PC_RESID, sb.st);
         r = launch_resid_decide(Sk, sb.st);
         prof_end(h, sb.st);

@@ -748,7 +748,9 @@ __global__ __launch_bounds__(64) void kkt_kernel_scalar(NewtonDev S, KktArgs K) 
         lds_sync();
         // line search start (newton.jl:223-228): alpha = 1, candidate = traj - Delta
         apply_step(S, S.cand, S.nu_cand, (size_t)b * CS, b, 1.0, lane, 64);
-        enqueue_eval(S, (size_t)b * CS, b, S.WQ.par, lane, 64);      // swept later in this round
+        // the KKT kernel runs on its own stream NEXT TO the sweep of the running round: its
+        // candidates join the queue of the next round
+        enqueue_eval(S, (size_t)b * CS, b, S.WQ.par ^ 1, lane, 64);
         if (lane == 0) {
             S.alpha[b] = 1.0;
             S.ls_iter[b] = 0;
@@ -1070,7 +1072,9 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
         lds_sync();
         // line search start (newton.jl:223-228): alpha = 1, candidate = traj - Delta
         apply_step(S, S.cand, S.nu_cand, (size_t)b * CS, b, 1.0, lane, 64);
-        enqueue_eval(S, (size_t)b * CS, b, S.WQ.par, lane, 64);      // swept later in this round
+        // the KKT kernel runs on its own stream NEXT TO the sweep of the running round: its
+        // candidates join the queue of the next round
+        enqueue_eval(S, (size_t)b * CS, b, S.WQ.par ^ 1, lane, 64);
         if (lane == 0) {
             S.alpha[b] = 1.0;
             S.ls_iter[b] = 0;
