@@ -80,6 +80,7 @@ struct cimpc_ctx {
     bool objective_set = false, window_set = false, reference_set = false, alt_set = false;
     bool velocity_objective = false;
     int waves = 4;
+    bool kkt_overlap = true;
     std::vector<SubBatch> subs;
     bool external_stream = false;
     std::vector<double> h_tab;       // one knot staging
@@ -396,6 +397,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     // small batches: one wave per workgroup keeps every problem on its own CU (latency);
     // large batches: 4 waves share one staged table (throughput)
     h->waves = (B * H >= 4096) ? 4 : 1;
+    h->kkt_overlap = B >= 64;
     {   // persistent workgroups per knot: ~2 problems per lane group and round, all workgroups resident
         const size_t groups_per_wg = (64 / h->ki.G) * h->waves;
         const size_t per_knot = (B * H + d.H_ref - 1) / d.H_ref;
@@ -712,7 +714,14 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         Sk.WQ = h->Q; Sk.WQ.par = (int)(sb.rounds & 1);       // round parity selects the queue being consumed
         if (hipMemsetAsync(sb.d_cnt, 0, 8 * sizeof(int), sb.st) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "memset failed");
         const bool kkt = sb.n_kkt > 0;
-        if (kkt) {   // fork: KKT of the rollouts that start a Newton iteration, next to the sweep
+        if (kkt && !h->kkt_overlap) {   // small batches: latency matters, keep the KKT result in this round
+            Sk.kkt_same_round = 1;
+            prof_begin(h, PC_KKT, sb.st);
+            int r = launch_kkt(Sk, sb.st);
+            prof_end(h, sb.st);
+            if (r != CIMPC_OK) return fail(h, r, "kkt launch failed");
+            h->prof_kkt_systems += sb.n_kkt;
+        } else if (kkt) {   // fork: KKT of the rollouts that start a Newton iteration, next to the sweep
             if (hipEventRecord(sb.ev_fork, sb.st) != hipSuccess ||
                 hipStreamWaitEvent(sb.st_kkt, sb.ev_fork, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "fork failed");
             prof_begin(h, PC_KKT, sb.st_kkt);
@@ -724,7 +733,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         }
         int r = run_sweep(h, Sk.WQ.par, sb.d_cnt + 2, nullptr, sb.st);
         if (r != CIMPC_OK) return r;
-        if (kkt && hipStreamWaitEvent(sb.st, sb.ev_join, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join failed");
+        if (kkt && h->kkt_overlap && hipStreamWaitEvent(sb.st, sb.ev_join, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join failed");
         prof_begin(h, PC_RESID, sb.st);
         r = launch_resid_decide(Sk, sb.st);
         prof_end(h, sb.st);

@@ -165,11 +165,14 @@ __device__ void apply_step(const NewtonDev& S, const TrajDev& dst, double* nu_ds
 }
 
 // residual! on evaluation slot sb (candidate trajectory, nu_cand, d, dz of that slot); returns |r|_1
+template <int NQ, int NU, bool CF>
 __device__ double slot_residual(const NewtonDev& S, size_t sb, int b, double* red, int tid, int nt) {
     const cimpc_dims& m = S.dm;
-    const int H = m.H, nq = m.nq, nu = m.nu, nc = m.nc, nb = m.nb, nr = S.nr, nd = S.nd;
-    const int nths = S.nths;
-    const bool cf = m.mode == CIMPC_MODE_CONFIGURATIONFORCE;
+    constexpr int nq = NQ, nu = NU;
+    constexpr bool cf = CF;
+    const int H = m.H, nc = m.nc, nb = m.nb, nr = S.nr;
+    const int nd = cf ? nq + nc + nb : nq;       // compile-time in :configuration mode
+    constexpr int nths = 2 * NQ + NU;
     const int oq_in_block = cf ? nu + nc + nb : nu;
     double* r = S.res_cand + sb * S.N;
     const double* nuc = S.nu_cand + sb * H * nd;
@@ -185,28 +188,36 @@ __device__ double slot_residual(const NewtonDev& S, size_t sb, int b, double* re
                 const double* Rm = S.R + (size_t)i * nu * nu;
                 const double* uu = S.cand.u + (sb * H + i) * nu;
                 const double* ur = S.ref.u + ((size_t)b * H + i) * nu;
+#pragma unroll
                 for (int k = 0; k < nu; ++k) v = fma(Rm[c + k * nu], uu[k] - ur[k], v);
                 const double* A0 = dzb + ((size_t)i * nths + 2 * nq + c) * nd;   // column c of du1_i
                 double s = 0.0;
-                for (int k = 0; k < nd; ++k) s = fma(A0[k], nuc[i * nd + k], s);
+#pragma unroll
+                for (int k = 0; k < nq; ++k) s = fma(A0[k], nuc[i * nd + k], s);
+                for (int k = nq; k < nd; ++k) s = fma(A0[k], nuc[i * nd + k], s);
                 v += s;
             } else if (c >= oq_in_block) {        // q2[i]
                 const int cq = c - oq_in_block;
                 const double* Qm = S.Q + (size_t)i * nq * nq;
                 const double* qq = S.cand.q + (sb * (H + 2) + i + 2) * nq;
                 const double* qr = S.ref.q + ((size_t)b * (H + 2) + i + 2) * nq;
+#pragma unroll
                 for (int k = 0; k < nq; ++k) v = fma(Qm[cq + k * nq], qq[k] - qr[k], v);
                 v -= nuc[i * nd + cq];                                      // rI[i] -= nu_i
                 if (i + 1 < H) {                                            // dq1_{i+1}^T nu_{i+1}
                     const double* A1 = dzb + ((size_t)(i + 1) * nths + nq + cq) * nd;
                     double s = 0.0;
-                    for (int k = 0; k < nd; ++k) s = fma(A1[k], nuc[(i + 1) * nd + k], s);
+#pragma unroll
+                    for (int k = 0; k < nq; ++k) s = fma(A1[k], nuc[(i + 1) * nd + k], s);
+                    for (int k = nq; k < nd; ++k) s = fma(A1[k], nuc[(i + 1) * nd + k], s);
                     v += s;
                 }
                 if (i + 2 < H) {                                            // dq0_{i+2}^T nu_{i+2}
                     const double* A2 = dzb + ((size_t)(i + 2) * nths + cq) * nd;
                     double s = 0.0;
-                    for (int k = 0; k < nd; ++k) s = fma(A2[k], nuc[(i + 2) * nd + k], s);
+#pragma unroll
+                    for (int k = 0; k < nq; ++k) s = fma(A2[k], nuc[(i + 2) * nd + k], s);
+                    for (int k = nq; k < nd; ++k) s = fma(A2[k], nuc[(i + 2) * nd + k], s);
                     v += s;
                 }
             } else if (c < nu + nc) {             // gamma1[i] (cf)
@@ -239,6 +250,7 @@ __device__ double slot_residual(const NewtonDev& S, size_t sb, int b, double* re
     return out;
 }
 
+template <int NQ, int NU, bool CF>
 __global__ __launch_bounds__(256) void resid_decide_kernel(NewtonDev S) {
     const cimpc_dims& m = S.dm;
     const int b = blockIdx.x + S.b0, tid = threadIdx.x, nt = blockDim.x;
@@ -264,7 +276,7 @@ __global__ __launch_bounds__(256) void resid_decide_kernel(NewtonDev S) {
     __shared__ double rc[CS];
     __shared__ int s_act, s_slot, s_iter;
     for (int c = 0; c < ncand; ++c) {
-        const double v = slot_residual(S, sb0 + c, b, red, tid, nt);
+        const double v = slot_residual<NQ, NU, CF>(S, sb0 + c, b, red, tid, nt);
         if (tid == 0) { rc[c] = v; S.r_cand[sb0 + c] = v; }
     }
     __syncthreads();
@@ -750,7 +762,7 @@ __global__ __launch_bounds__(64) void kkt_kernel_scalar(NewtonDev S, KktArgs K) 
         apply_step(S, S.cand, S.nu_cand, (size_t)b * CS, b, 1.0, lane, 64);
         // the KKT kernel runs on its own stream NEXT TO the sweep of the running round: its
         // candidates join the queue of the next round
-        enqueue_eval(S, (size_t)b * CS, b, S.WQ.par ^ 1, lane, 64);
+        enqueue_eval(S, (size_t)b * CS, b, S.kkt_same_round ? S.WQ.par : (S.WQ.par ^ 1), lane, 64);
         if (lane == 0) {
             S.alpha[b] = 1.0;
             S.ls_iter[b] = 0;
@@ -1074,7 +1086,7 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
         apply_step(S, S.cand, S.nu_cand, (size_t)b * CS, b, 1.0, lane, 64);
         // the KKT kernel runs on its own stream NEXT TO the sweep of the running round: its
         // candidates join the queue of the next round
-        enqueue_eval(S, (size_t)b * CS, b, S.WQ.par ^ 1, lane, 64);
+        enqueue_eval(S, (size_t)b * CS, b, S.kkt_same_round ? S.WQ.par : (S.WQ.par ^ 1), lane, 64);
         if (lane == 0) {
             S.alpha[b] = 1.0;
             S.ls_iter[b] = 0;
@@ -1127,9 +1139,21 @@ int launch_reset(const NewtonDev& S, const double* q0, const double* q1, int war
     hipLaunchKernelGGL(reset_kernel, dim3(S.nb_launch), dim3(256), 0, s, S, q0, q1, warm);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
-int launch_resid_decide(const NewtonDev& S, hipStream_t s) {
-    hipLaunchKernelGGL(resid_decide_kernel, dim3(S.nb_launch), dim3(256), 0, s, S);
+template <int NQ, int NU>
+static int launch_resid_t(const NewtonDev& S, hipStream_t s) {
+    if (S.dm.mode == CIMPC_MODE_CONFIGURATIONFORCE)
+        hipLaunchKernelGGL((resid_decide_kernel<NQ, NU, true>), dim3(S.nb_launch), dim3(256), 0, s, S);
+    else
+        hipLaunchKernelGGL((resid_decide_kernel<NQ, NU, false>), dim3(S.nb_launch), dim3(256), 0, s, S);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+}
+int launch_resid_decide(const NewtonDev& S, hipStream_t s) {
+    const int nq = S.dm.nq, nu = S.dm.nu;
+    if (nq == 2 && nu == 2) return launch_resid_t<2, 2>(S, s);
+    if (nq == 4 && nu == 2) return launch_resid_t<4, 2>(S, s);
+    if (nq == 11 && nu == 8) return launch_resid_t<11, 8>(S, s);
+    if (nq == 18 && nu == 12) return launch_resid_t<18, 12>(S, s);
+    return CIMPC_ERR_INVALID;
 }
 int launch_kkt(const NewtonDev& S, hipStream_t s) {
     KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 1};

@@ -23,6 +23,7 @@ struct NewtonDev {
     cimpc_dims dm;
     int b0;            // first rollout served by this launch (sub-batch offset)
     int nb_launch;     // rollouts served by this launch
+    int kkt_same_round; // 1: KKT runs before the sweep on the same stream (small batches)
     int nd, nr, nth, nths, N;
     TrajDev traj, cand, ref;   // cand: [B*CS] evaluation slots; traj, ref: [B]
     double* nu;        // [B][H][nd]
