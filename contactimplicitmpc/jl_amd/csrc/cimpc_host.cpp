@@ -81,6 +81,10 @@ struct cimpc_ctx {
     bool velocity_objective = false;
     int waves = 4;
     bool kkt_overlap = true;
+    int pipeline_depth = 1;
+    int* d_ring = nullptr;       // [MAX_DEPTH][8] device counters per in-flight round
+    int* h_ring = nullptr;       // pinned mirror
+    hipEvent_t ev_ring[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<SubBatch> subs;
     bool external_stream = false;
     std::vector<double> h_tab;       // one knot staging
@@ -398,6 +402,17 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     // large batches: 4 waves share one staged table (throughput)
     h->waves = (B * H >= 4096) ? 4 : 1;
     h->kkt_overlap = B >= 64;
+    // depth 1 measured fastest on MI355X (B = 512: 16.9 ms/step vs 17.8 ms at depth 3, because a deeper
+    // pipeline has to launch the KKT kernel every round); the ring stays for experiments
+    h->pipeline_depth = 1;
+    if (const char* e = std::getenv("CIMPC_PIPELINE_DEPTH")) h->pipeline_depth = std::min(4, std::max(1, std::atoi(e)));
+    if (dev_alloc(h, &h->d_ring, 32) != CIMPC_OK || hipHostMalloc((void**)&h->h_ring, 32 * sizeof(int)) != hipSuccess) {
+        g_create_error = "ring allocation failed"; cimpc_destroy(h); return CIMPC_ERR_HIP;
+    }
+    for (int k = 0; k < 4; ++k)
+        if (hipEventCreateWithFlags(&h->ev_ring[k], hipEventDisableTiming) != hipSuccess) {
+            g_create_error = "event creation failed"; cimpc_destroy(h); return CIMPC_ERR_HIP;
+        }
     {   // persistent workgroups per knot: ~2 problems per lane group and round, all workgroups resident
         const size_t groups_per_wg = (64 / h->ki.G) * h->waves;
         const size_t per_knot = (B * H + d.H_ref - 1) / d.H_ref;
@@ -443,6 +458,8 @@ int cimpc_destroy(cimpc_handle h) {
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->h_counters) (void)hipHostFree(h->h_counters);
+    if (h->h_ring) (void)hipHostFree(h->h_ring);
+    for (int k = 0; k < 4; ++k) if (h->ev_ring[k]) (void)hipEventDestroy(h->ev_ring[k]);
     for (auto& sb : h->subs) {
         if (sb.st) { (void)hipStreamSynchronize(sb.st); (void)hipStreamDestroy(sb.st); }
         if (sb.st_kkt) { (void)hipStreamSynchronize(sb.st_kkt); (void)hipStreamDestroy(sb.st_kkt); }
@@ -707,82 +724,83 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         single[0].st = h->stream;
     }
     std::vector<SubBatch>& subs = h->external_stream ? single : h->subs;
-    auto launch_round = [&](SubBatch& sb) -> int {
-        // [KKT for rollouts that start an iteration] -> sweep -> residual + line-search decision
+    SubBatch& sb = subs[0];
+    // Pipelined lock-step rounds.  Every kernel of a round is driven by device-side state (work
+    // queues, per-rollout stage), so rounds can be enqueued AHEAD of the host's knowledge: up to
+    // `depth` rounds are in flight, the host only looks at the counters of the oldest one, and
+    // rounds launched after the batch has finished find empty queues and return immediately.
+    const int depth = h->pipeline_depth;
+    long long launched = 0, completed = 0, rounds = 0;
+    int last_kkt = 0;
+    auto launch_round = [&](long long r) -> int {
+        // [KKT for rollouts that start an iteration] || sweep -> residual + line-search decision
+        const int slot = (int)(r % depth);
+        int* d_cnt = h->d_ring + 8 * slot;
         NewtonDev Sk = S;
-        Sk.b0 = sb.b0; Sk.nb_launch = sb.nb; Sk.counters = sb.d_cnt;
-        Sk.WQ = h->Q; Sk.WQ.par = (int)(sb.rounds & 1);       // round parity selects the queue being consumed
-        if (hipMemsetAsync(sb.d_cnt, 0, 8 * sizeof(int), sb.st) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "memset failed");
-        const bool kkt = sb.n_kkt > 0;
+        Sk.b0 = 0; Sk.nb_launch = h->dm.B; Sk.counters = d_cnt;
+        Sk.WQ = h->Q; Sk.WQ.par = (int)(r & 1);       // round parity selects the queue being consumed
+        if (hipMemsetAsync(d_cnt, 0, 8 * sizeof(int), sb.st) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "memset failed");
+        const bool kkt = (r > 0) && (depth > 1 || last_kkt > 0);
         if (kkt && !h->kkt_overlap) {   // small batches: latency matters, keep the KKT result in this round
             Sk.kkt_same_round = 1;
             prof_begin(h, PC_KKT, sb.st);
-            int r = launch_kkt(Sk, sb.st);
+            int rr = launch_kkt(Sk, sb.st);
             prof_end(h, sb.st);
-            if (r != CIMPC_OK) return fail(h, r, "kkt launch failed");
-            h->prof_kkt_systems += sb.n_kkt;
+            if (rr != CIMPC_OK) return fail(h, rr, "kkt launch failed");
         } else if (kkt) {   // fork: KKT of the rollouts that start a Newton iteration, next to the sweep
             if (hipEventRecord(sb.ev_fork, sb.st) != hipSuccess ||
                 hipStreamWaitEvent(sb.st_kkt, sb.ev_fork, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "fork failed");
             prof_begin(h, PC_KKT, sb.st_kkt);
-            int r = launch_kkt(Sk, sb.st_kkt);
+            int rr = launch_kkt(Sk, sb.st_kkt);
             prof_end(h, sb.st_kkt);
-            if (r != CIMPC_OK) return fail(h, r, "kkt launch failed");
+            if (rr != CIMPC_OK) return fail(h, rr, "kkt launch failed");
             if (hipEventRecord(sb.ev_join, sb.st_kkt) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join record failed");
-            h->prof_kkt_systems += sb.n_kkt;
         }
-        int r = run_sweep(h, Sk.WQ.par, sb.d_cnt + 2, nullptr, sb.st);
-        if (r != CIMPC_OK) return r;
+        int rr = run_sweep(h, Sk.WQ.par, d_cnt + 2, nullptr, sb.st);
+        if (rr != CIMPC_OK) return rr;
         if (kkt && h->kkt_overlap && hipStreamWaitEvent(sb.st, sb.ev_join, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join failed");
         prof_begin(h, PC_RESID, sb.st);
-        r = launch_resid_decide(Sk, sb.st);
+        rr = launch_resid_decide(Sk, sb.st);
         prof_end(h, sb.st);
-        if (r != CIMPC_OK) return fail(h, r, "residual launch failed");
-        if (hipMemcpyAsync(sb.h_cnt, sb.d_cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, sb.st) != hipSuccess ||
-            hipEventRecord(sb.ev, sb.st) != hipSuccess)
+        if (rr != CIMPC_OK) return fail(h, rr, "residual launch failed");
+        if (hipMemcpyAsync(h->h_ring + 8 * slot, d_cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, sb.st) != hipSuccess ||
+            hipEventRecord(h->ev_ring[slot], sb.st) != hipSuccess)
             return fail(h, CIMPC_ERR_HIP, "counter read-back failed");
         return CIMPC_OK;
     };
-    int active = 0;
-    HIP_TRY(h, hipMemsetAsync(h->Q.count, 0, 2 * h->Q.K * sizeof(int), h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->Q.head, 0, h->Q.K * sizeof(int), h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->Q.s_count, 0, h->Q.K * sizeof(int), h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->Q.s_head, 0, h->Q.K * sizeof(int), h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    for (SubBatch& sb : subs) {
+    HIP_TRY(h, hipMemsetAsync(h->Q.count, 0, 2 * h->Q.K * sizeof(int), sb.st));
+    HIP_TRY(h, hipMemsetAsync(h->Q.head, 0, h->Q.K * sizeof(int), sb.st));
+    HIP_TRY(h, hipMemsetAsync(h->Q.s_count, 0, h->Q.K * sizeof(int), sb.st));
+    HIP_TRY(h, hipMemsetAsync(h->Q.s_head, 0, h->Q.K * sizeof(int), sb.st));
+    {
         NewtonDev Sk = S;
-        Sk.b0 = sb.b0; Sk.nb_launch = sb.nb; Sk.counters = sb.d_cnt;
+        Sk.b0 = 0; Sk.nb_launch = h->dm.B; Sk.counters = h->d_ring;
         Sk.WQ = h->Q; Sk.WQ.par = 0;
         prof_begin(h, PC_OTHER, sb.st);
         rc = launch_reset(Sk, q0_dev, q1_dev, warm_start, sb.st);
         prof_end(h, sb.st);
         if (rc != CIMPC_OK) return fail(h, rc, "reset launch failed");
-        sb.n_kkt = 0; sb.rounds = 0; sb.running = true;
-        rc = launch_round(sb);
-        if (rc != CIMPC_OK) return rc;
-        ++active;
     }
-    long long rounds = 0;
-    while (active > 0) {
-        for (SubBatch& sb : subs) {
-            if (!sb.running) continue;
-            const hipError_t q = hipEventQuery(sb.ev);
-            if (q == hipErrorNotReady) continue;
-            if (q != hipSuccess) return fail(h, CIMPC_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
-            ++sb.rounds;
-            const int n_sweep = sb.h_cnt[0];
-            sb.n_kkt = sb.h_cnt[1];
-            if ((n_sweep == 0 && sb.n_kkt == 0) || sb.rounds >= max_rounds || over_budget()) {
-                sb.running = false;     // newton.jl:187-277: the time budget ends the solve silently
-                --active;
-                rounds = std::max(rounds, sb.rounds);
-                continue;
-            }
-            rc = launch_round(sb);
+    while (true) {
+        while (launched - completed < depth && launched < max_rounds) {
+            rc = launch_round(launched);
             if (rc != CIMPC_OK) return rc;
+            ++launched;
         }
+        if (completed >= launched) break;     // max_rounds reached
+        const int slot = (int)(completed % depth);
+        hipError_t q;
+        while ((q = hipEventQuery(h->ev_ring[slot])) == hipErrorNotReady) {}
+        if (q != hipSuccess) return fail(h, CIMPC_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+        const int n_sweep = h->h_ring[8 * slot + 0];
+        last_kkt = h->h_ring[8 * slot + 1];
+        h->prof_kkt_systems += last_kkt;
+        ++completed;
+        rounds = completed;
+        if ((n_sweep == 0 && last_kkt == 0) || over_budget()) break;   // newton.jl:187-277: budget ends silently
     }
-    for (SubBatch& sb : subs) HIP_TRY(h, hipStreamSynchronize(sb.st));
+    HIP_TRY(h, hipStreamSynchronize(sb.st));
+    HIP_TRY(h, hipStreamSynchronize(sb.st_kkt));
     long long st[4];
     HIP_TRY(h, hipMemcpy(st, S.stats, sizeof(st), hipMemcpyDeviceToHost));
     std::vector<int> l(h->dm.B);

@@ -34,7 +34,8 @@ struct Model {
     static constexpr int G = (NX <= 16 && NY <= 16) ? 16 : 32;
     static_assert(NX <= 32 && NY <= 32, "lane group holds at most 32 rows");
     static constexpr int RST_LD = G + 1;                       // padded row stride of the R tile
-    static constexpr int LDS_GROUP = ((NY * RST_LD + NTH) + 1) & ~1;  // doubles / problem
+    static constexpr int SENS_MAX = 16;                         // converged problems a group may defer
+    static constexpr int LDS_GROUP = ((NY * RST_LD + NTH + SENS_MAX / 2) + 1) & ~1;  // doubles / problem
 };
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -271,10 +272,54 @@ __device__ __forceinline__ void stage_table(double* tab, const double* src_tab, 
 }
 
 // ----------------------------------------------------------------------------------------
+// Sensitivities of one converged problem: differentiate_solution!, dz = -(rz^-1 rth) at z*,
+// reg = max(reg, kappa_tol*gamma_reg); only the consumed block (rows 1:nd, columns q0,q1,u1 -
+// implicit_dynamics.jl:84-86) is computed.  Always executed by the lane group that solved the
+// problem (z* is re-read by the very lanes that stored it, so no cross-workgroup hand-off).
+// ----------------------------------------------------------------------------------------
+template <class M>
+__device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S, const double* tab, int prob, int l) {
+    constexpr int NX = M::NX, NY = M::NY, NTH = M::NTH, NTHS = M::NTHS, ND = M::ND, G = M::G;
+    constexpr int NC = M::NC, NB = M::NB;
+    constexpr LinLayout L(NX, NY, NTH, G);
+    constexpr int PS = 2 * NX + 4 * NY + 4;
+    using LG = LaneGroup<G>;
+    const bool vx = S.vx, vy = S.vy;
+    const size_t pi = (size_t)prob;
+    const double* ps = p.pstate + pi * PS;
+    S.x = vx ? ps[l] : 0.0;
+    S.y1 = vy ? ps[NX + l] : 1.0;
+    S.y2 = vy ? ps[NX + NY + l] : 1.0;
+    const double reg = LG::template bcast<0>((l == 0) ? ps[PS - 2] : 0.0);
+    S.factorize(fmax(reg, p.o.kappa_tol * p.o.gamma_reg));
+    double* dzo = p.dz + pi * (size_t)(NTHS * ND);
+    auto column = [&](int c) {
+        const double u = tab[L.oRthDyn + c * G + l];
+        const double v = tab[L.oRthRst + c * G + l];
+        double xs;
+        const double t = S.schur_solve(u, v, xs);
+        if (vx) dzo[c * ND + l] = -xs;
+        if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) {
+            if (l < NC + NB) dzo[c * ND + NX + l] = t;   // -(S.y) = +temp
+        }
+    };
+    // two independent right-hand sides per trip: their triangular-solve chains interleave
+    int c = 0;
+#pragma unroll 1
+    for (; c + 1 < NTHS; c += 2) {
+        column(c);
+        column(c + 1);
+    }
+    if (c < NTHS) column(c);
+    if (l == 0) atomicAdd(&p.Q.done_count[prob / p.H], 1);
+}
+
+// ----------------------------------------------------------------------------------------
 // Queue kernel: persistent workgroups, `wpk` per reference knot.  Every 16-lane group pulls
 // problems of its knot until the queue is empty; all groups of a wave run the same iteration
 // body, a group whose solve ends (converged / failed / parked) finalises it and pulls the next
-// problem while its neighbours keep iterating.
+// problem while its neighbours keep iterating.  The sensitivities of converged problems are
+// kept in a per-group backlog and computed when the group has no interior-point work left.
 // ----------------------------------------------------------------------------------------
 template <class M>
 __global__ __launch_bounds__(256, 2) void ip_queue_kernel(IpParams p) {
@@ -296,6 +341,8 @@ __global__ __launch_bounds__(256, 2) void ip_queue_kernel(IpParams p) {
     const int l = tid % G;
     double* Rst = smem + L.size + (size_t)grp * M::LDS_GROUP;   // [NY][G+1]
     double* dth = Rst + NY * M::RST_LD;                          // [NTH]
+    int* backlog = reinterpret_cast<int*>(dth + NTH);            // [SENS_MAX] converged, sensitivities pending
+    int nback = 0;
     const int* items = p.Q.items + ((size_t)par * K + knot) * cap;
     int* head = p.Q.head + knot;
 
@@ -343,14 +390,11 @@ __global__ __launch_bounds__(256, 2) void ip_queue_kernel(IpParams p) {
                         if (vx) zo[l] = S.x;
                         if (vy) { zo[NX + l] = S.y1; zo[NX + NY + l] = S.y2; }
                     }
-                    if (code == 1) {         // converged: hand z* to the sensitivity pass
+                    if (code == 1) {         // converged: z* parked, sensitivities deferred to an idle moment
                         if (vx) ps[l] = S.x;
                         if (vy) { ps[NX + l] = S.y1; ps[NX + NY + l] = S.y2; }
-                        if (l == 0) {
-                            ps[PS - 2] = reg;
-                            const int pos = atomicAdd(&p.Q.s_count[knot], 1);
-                            p.Q.s_items[(size_t)knot * cap + pos] = prob;
-                        }
+                        if (l == 0) { ps[PS - 2] = reg; backlog[nback] = prob; }
+                        ++nback;
                     } else if (l == 0) {     // failed: the slot keeps its previous sensitivities
                         atomicAdd(&p.Q.done_count[sb], 1);
                     }
@@ -418,76 +462,29 @@ __global__ __launch_bounds__(256, 2) void ip_queue_kernel(IpParams p) {
                 exhausted = true;
             }
         }
-        // ---- 3. one iteration for every group that holds a problem ------------------------------
-        if (!__any(have ? 1 : 0)) break;
-        if (have && !(r_vio < o.r_tol && k_vio < o.kappa_tol) && iters < o.max_iter && done_here < p.iter_cap) {
-            ++done_here;
-            ++iters;
-            stalled = S.iterate(o, reg, r_vio, k_vio);
-        }
-    }
-}
-
-// ----------------------------------------------------------------------------------------
-// Sensitivity kernel: differentiate_solution! for the problems that converged in the queue kernel.
-// dz = -(rz^-1 rth) at z*, reg = max(reg, kappa_tol*gamma_reg); only the consumed block
-// (rows 1:nd, columns q0,q1,u1 - implicit_dynamics.jl:84-86) is computed.
-// ----------------------------------------------------------------------------------------
-template <class M>
-__global__ __launch_bounds__(256, 2) void ip_sens_kernel(IpParams p) {
-    constexpr int NX = M::NX, NY = M::NY, NTH = M::NTH, NTHS = M::NTHS, ND = M::ND, G = M::G;
-    constexpr int NC = M::NC, NB = M::NB;
-    constexpr LinLayout L(NX, NY, NTH, G);
-    constexpr int PS = 2 * NX + 4 * NY + 4;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* tab = smem;
-    const int tid = (int)threadIdx.x;
-    const int knot = (int)blockIdx.x / p.wpk;
-    const int cap = p.Q.cap;
-    const int n = p.Q.s_count[knot];
-    if (n == 0) return;
-    stage_table<M>(tab, p.tab, knot, tid);
-    __syncthreads();
-    const int grp = tid / G;
-    const int l = tid % G;
-    double* Rst = smem + L.size + (size_t)grp * M::LDS_GROUP;
-    const int* items = p.Q.s_items + (size_t)knot * cap;
-    IpSolver<M> S;
-    S.bind(tab, Rst, l);
-    const bool vx = S.vx, vy = S.vy;
-    while (true) {
-        int idx = 0;
-        if (l == 0) idx = atomicAdd(p.Q.s_head + knot, 1);
-        idx = group_bcast0<G>(idx);
-        if (idx >= n) break;
-        const int prob = items[idx];
-        const size_t pi = (size_t)prob;
-        const double* ps = p.pstate + pi * PS;
-        S.x = vx ? ps[l] : 0.0;
-        S.y1 = vy ? ps[NX + l] : 1.0;
-        S.y2 = vy ? ps[NX + NY + l] : 1.0;
-        const double reg = ps[PS - 2];
-        S.factorize(fmax(reg, p.o.kappa_tol * p.o.gamma_reg));
-        double* dzo = p.dz + pi * (size_t)(NTHS * ND);
-        auto column = [&](int c) {
-            const double u = tab[L.oRthDyn + c * G + l];
-            const double v = tab[L.oRthRst + c * G + l];
-            double xs;
-            const double t = S.schur_solve(u, v, xs);
-            if (vx) dzo[c * ND + l] = -xs;
-            if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) {
-                if (l < NC + NB) dzo[c * ND + NX + l] = t;   // -(S.y) = +temp
+        // ---- 3. wave-uniform trip: EITHER one interior-point iteration for every group that holds a
+        //         problem, OR one deferred sensitivity pass.  The sensitivity trip is taken when
+        //         every group of the wave has something in its backlog (all four groups then run
+        //         the same code on their own problem - no SIMT divergence), when the wave has no
+        //         interior-point work left, or when a backlog is full.
+        const bool any_ip = __any(have ? 1 : 0);
+        if (!any_ip && !__any(nback > 0 ? 1 : 0)) break;
+        const bool sens_trip = !any_ip || __all(nback > 0 ? 1 : 0) || __any(nback >= M::SENS_MAX ? 1 : 0);
+        if (!sens_trip) {
+            if (have && !(r_vio < o.r_tol && k_vio < o.kappa_tol) && iters < o.max_iter && done_here < p.iter_cap) {
+                ++done_here;
+                ++iters;
+                stalled = S.iterate(o, reg, r_vio, k_vio);
             }
-        };
-        // two independent right-hand sides per trip: their triangular-solve chains interleave
-        int c = 0;
-#pragma unroll 1
-        for (; c + 1 < NTHS; c += 2) {
-            column(c);
-            column(c + 1);
+        } else if (nback > 0) {
+            // the live iterate (if any) survives in registers; factorization registers are scratch
+            const double sx = S.x, sy1 = S.y1, sy2 = S.y2, sd = S.rdyn, sr = S.rrst, sb_ = S.rbil, st = S.tthdyn, su = S.tthrst, sa = S.altl;
+            --nback;
+            wave_lds_fence();
+            const int pr = group_bcast0<G>((l == 0) ? backlog[nback] : 0);
+            sensitivities<M>(p, S, tab, pr, l);
+            S.x = sx; S.y1 = sy1; S.y2 = sy2; S.rdyn = sd; S.rrst = sr; S.rbil = sb_; S.tthdyn = st; S.tthrst = su; S.altl = sa;
         }
-        if (c < NTHS) column(c);
-        if (l == 0) atomicAdd(&p.Q.done_count[prob / p.H], 1);
     }
 }
 
@@ -502,14 +499,11 @@ int launch_model(const IpParams& p, int waves, hipStream_t s) {
     const int ppw = 64 / M::G;
     const size_t lds = (size_t)(L.size + waves * ppw * M::LDS_GROUP) * sizeof(double);
     if (lds > 64 * 1024) {   // opt in to the full 160 KiB LDS of a gfx950 CU
-        if (hipFuncSetAttribute((const void*)ip_queue_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)ip_sens_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)ip_queue_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return CIMPC_ERR_HIP;
     }
     const int grid = p.Q.K * p.wpk;
     hipLaunchKernelGGL((ip_queue_kernel<M>), dim3(grid), dim3(64 * waves), lds, s, p);
-    if (hipGetLastError() != hipSuccess) return CIMPC_ERR_HIP;
-    hipLaunchKernelGGL((ip_sens_kernel<M>), dim3(grid), dim3(64 * waves), lds, s, p);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
 

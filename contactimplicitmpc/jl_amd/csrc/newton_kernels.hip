@@ -888,6 +888,12 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
         else if (lane < nr) rq[lane - nu] = pf_rp;
     };
 
+#ifdef CIMPC_KKT_PROF
+    long long pt[16] = {0}; long long tp = clock64();
+#define KPROF(j) { const long long tn = clock64(); pt[j] += tn - tp; tp = tn; }
+#else
+#define KPROF(j)
+#endif
     prefetch(0);
     for (int i = 0; i < H; ++i) {
         const int m0 = i % 3, m1 = (i + 2) % 3, m2 = (i + 1) % 3, p0 = i & 1, p1 = (i + 1) & 1;
@@ -902,12 +908,14 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
         const double rd_i = pf_rd;
         lds_sync();
         prefetch(i + 1);
+        KPROF(1)
         // ---- P2: T0 = du1 Rinv, T1 = dq1 Qinv_{i-1}, T2 = dq0 Qinv_{i-2}  (Qinv, Rinv symmetric)
         const d4 z4 = {0.0, 0.0, 0.0, 0.0};
         tile_st(T0, tile_mma<KBU, false>(A0, Ri, z4, li, lk), li, lk);
         if (i >= 1) tile_st(T1, tile_mma<KBQ, false>(A1, Qi1, z4, li, lk), li, lk);
         if (i >= 2) tile_st(T2, tile_mma<KBQ, false>(A2, Qi2, z4, li, lk), li, lk);
         lds_sync();
+        KPROF(2)
         // ---- P3: Y_ii, Y_i,i-1, L2_i = -T2 L0_{i-2}^-T, beta_i -------------------------------
         d4 y0 = tile_ld(Qi0, li, lk);
 #pragma unroll
@@ -930,6 +938,7 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
             bet[lane] = s - rd_i;
         }
         lds_sync();
+        KPROF(3)
         // ---- P4: Y1 -= L2 L1_{i-1}^T ; stage Y1 as an operand ------------------------------
         if (i >= 1) {
             if (i >= 2) y1a = tile_mma<KBD, true>(L2c, L1p, y1a, li, lk);
@@ -939,6 +948,7 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
             tile_st(L1c, tile_mma<KBD, false>(Y1, Li1, z4, li, lk), li, lk);
             lds_sync();
         }
+        KPROF(4)
         // ---- P6: Lc = Y0 - L1 L1^T - L2 L2^T ; rhs of the forward substitution ---------------
         if (i >= 1) y0 = tile_mma<KBD, true>(L1c, L1c, y0, li, lk);
         if (i >= 2) y0 = tile_mma<KBD, true>(L2c, L2c, y0, li, lk);
@@ -950,6 +960,7 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
             tv[lane] = s;
         }
         lds_sync();
+        KPROF(5)
         // ---- P7: Cholesky of Lc and L0^-1 in registers (lane = row, DPP broadcasts) -----------
         {
             using LG = LaneGroup<16>;
@@ -988,6 +999,7 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
             }
         }
         lds_sync();
+        KPROF(6)
         // ---- P8: y_i = L0^-1 tv ; spill (L1_i, L2_i, L0_i^-1, y_i) for the backward pass ------
         double yi = 0.0;
         if (lane < nd) {
@@ -1003,6 +1015,7 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
         }
         if (lane < nd) wsi[3 * n2 + lane] = yi;
         lds_sync();
+        KPROF(7)
     }
     __threadfence_block();
     lds_sync();
@@ -1079,6 +1092,10 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
         else if (lane >= 16 && lane < 16 + nq) D[i * nr + nu + (lane - 16)] = tile_mv<nq, false>(BQ, tq, lane - 16);
         lds_sync();
     }
+    KPROF(8)
+#ifdef CIMPC_KKT_PROF
+    if (lane == 0 && b == 0) for (int j = 0; j < 16; ++j) ((long long*)S.stats)[8 + j] = pt[j];
+#endif
     if (K.finish) {
         __threadfence_block();
         lds_sync();

@@ -12,7 +12,7 @@ int main() {
         S.dm = cimpc_dims{nq, nu, 2, 4, 8, 0, 60, H, B};
         S.nd = nq; S.nr = nq + nu; S.nth = 34; S.nths = 30; S.N = H * 30; S.kappa = 2e-4;
         std::mt19937 g(1); std::normal_distribution<double> nd(0, 0.3);
-        std::vector<double> dz((size_t)B * H * 30 * 11), r((size_t)B * S.N), Qi((size_t)H * 121, 0.0), Ri((size_t)H * 64, 0.0);
+        std::vector<double> dz((size_t)B * CS * H * 30 * 11), r((size_t)B * S.N), Qi((size_t)H * 121, 0.0), Ri((size_t)H * 64, 0.0);
         for (auto& v : dz) v = nd(g);
         for (auto& v : r) v = nd(g);
         for (int i = 0; i < H; ++i) { for (int k = 0; k < 11; ++k) Qi[i * 121 + k * 12] = 2.0; for (int k = 0; k < 8; ++k) Ri[i * 64 + k * 9] = 3.0; }
@@ -22,7 +22,7 @@ int main() {
         hipMalloc(&d_stats, 32 * 8); hipMemset(d_stats, 0, 32 * 8);
         hipMemcpy(d_dz, dz.data(), dz.size() * 8, hipMemcpyHostToDevice); hipMemcpy(d_r, r.data(), r.size() * 8, hipMemcpyHostToDevice);
         hipMemcpy(d_Qi, Qi.data(), Qi.size() * 8, hipMemcpyHostToDevice); hipMemcpy(d_Ri, Ri.data(), Ri.size() * 8, hipMemcpyHostToDevice);
-        S.dz = d_dz; S.Qinv = d_Qi; S.Rinv = d_Ri; S.kkt_ws = d_ws; S.stats = d_stats;
+        S.dz = d_dz; S.Qinv = d_Qi; S.Rinv = d_Ri; S.kkt_ws = d_ws; S.stats = d_stats; S.b0 = 0; S.nb_launch = B;
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
         launch_kkt_raw(S, d_r, 10.0, d_delta, 0); hipDeviceSynchronize();
         hipEventRecord(a);
