@@ -297,23 +297,35 @@ __global__ __launch_bounds__(256) void resid_decide_kernel(NewtonDev S) {
             }
         }
         s_act = act; s_slot = slot; s_iter = iter;
-        // statistics.  Global counters: every evaluation that ran (speculative ones included).
-        // Per-rollout counters: only the evaluations the reference's sequential line search
-        // would have performed (candidates up to and including the accepted one).
-        const int nref = (act == 1 && iter <= 6) ? slot + 1 : ncand;
-        long long its = 0, fails = 0, its_ref = 0, fails_ref = 0;
-        for (int k = 0; k < ncand * H; ++k) {
+    }
+    __syncthreads();
+    {   // statistics (parallel reduction).  Global counters: every evaluation that ran (speculative
+        // ones included).  Per-rollout counters: only the evaluations the reference's sequential line
+        // search would have performed (candidates up to and including the accepted one).
+        const int nref = (s_act == 1 && s_iter <= 6) ? s_slot + 1 : ncand;
+        int its = 0, fails = 0, its_ref = 0, fails_ref = 0;
+        for (int k = tid; k < ncand * H; k += nt) {
             const int it = S.ip_iters[sb0 * H + k], fl = (S.ip_status[sb0 * H + k] == 0);
             its += it; fails += fl;
             if (k < nref * H) { its_ref += it; fails_ref += fl; }
         }
-        S.ro_sweeps[b] += nref;
-        S.ro_ip_iters[b] += (int)its_ref;
-        S.ro_ip_fail[b] += (int)fails_ref;
-        atomicAdd((unsigned long long*)&S.stats[0], (unsigned long long)ncand);
-        atomicAdd((unsigned long long*)&S.stats[1], (unsigned long long)(ncand * H));
-        atomicAdd((unsigned long long*)&S.stats[2], (unsigned long long)its);
-        atomicAdd((unsigned long long*)&S.stats[3], (unsigned long long)fails);
+        // pack four small counters into the double reduction buffer (exact up to 2^53)
+        red[tid] = (double)its; __syncthreads();
+        for (int st = nt / 2; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+        const double t_its = red[0]; __syncthreads();
+        red[tid] = (double)fails + 4096.0 * (double)fails_ref + 16777216.0 * (double)its_ref; __syncthreads();
+        for (int st = nt / 2; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+        if (tid == 0) {
+            const long long packed = (long long)red[0];
+            const long long t_fails = packed & 4095, t_fails_ref = (packed >> 12) & 4095, t_its_ref = packed >> 24;
+            S.ro_sweeps[b] += nref;
+            S.ro_ip_iters[b] += (int)t_its_ref;
+            S.ro_ip_fail[b] += (int)t_fails_ref;
+            atomicAdd((unsigned long long*)&S.stats[0], (unsigned long long)ncand);
+            atomicAdd((unsigned long long*)&S.stats[1], (unsigned long long)(ncand * H));
+            atomicAdd((unsigned long long*)&S.stats[2], (unsigned long long)t_its);
+            atomicAdd((unsigned long long*)&S.stats[3], (unsigned long long)t_fails);
+        }
     }
     __syncthreads();
     const int act = s_act, slot = s_slot, iter = s_iter;
