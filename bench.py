@@ -129,7 +129,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    s.profile_enable(True)
+    s.profile_enable(not os.environ.get("CIMPC_BENCH_NOPROF"))
     s.profile_reset()
     torch.cuda.synchronize()
     if dist is not None:

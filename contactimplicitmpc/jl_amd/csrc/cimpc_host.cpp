@@ -83,7 +83,8 @@ struct cimpc_ctx {
     bool kkt_overlap = true;
     int pipeline_depth = 1;
     int* d_ring = nullptr;       // [MAX_DEPTH][8] device counters per in-flight round
-    int* h_ring = nullptr;       // pinned mirror
+    int* h_ring = nullptr;       // pinned, host-mapped: {n_sweep, n_kkt, stamp}
+    int* h_ring_dev = nullptr;   // device pointer of h_ring
     hipEvent_t ev_ring[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<SubBatch> subs;
     bool external_stream = false;
@@ -405,8 +406,9 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     // depth 1 measured fastest on MI355X (B = 512: 16.9 ms/step vs 17.8 ms at depth 3, because a deeper
     // pipeline has to launch the KKT kernel every round); the ring stays for experiments
     h->pipeline_depth = 1;
-    if (const char* e = std::getenv("CIMPC_PIPELINE_DEPTH")) h->pipeline_depth = std::min(4, std::max(1, std::atoi(e)));
-    if (dev_alloc(h, &h->d_ring, 32) != CIMPC_OK || hipHostMalloc((void**)&h->h_ring, 32 * sizeof(int)) != hipSuccess) {
+    if (dev_alloc(h, &h->d_ring, 32) != CIMPC_OK ||
+        hipHostMalloc((void**)&h->h_ring, 32 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&h->h_ring_dev, h->h_ring, 0) != hipSuccess) {
         g_create_error = "ring allocation failed"; cimpc_destroy(h); return CIMPC_ERR_HIP;
     }
     for (int k = 0; k < 4; ++k)
@@ -734,12 +736,14 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     int last_kkt = 0;
     auto launch_round = [&](long long r) -> int {
         // [KKT for rollouts that start an iteration] || sweep -> residual + line-search decision
-        const int slot = (int)(r % depth);
+        const int slot = (int)(r & 1);
         int* d_cnt = h->d_ring + 8 * slot;
         NewtonDev Sk = S;
         Sk.b0 = 0; Sk.nb_launch = h->dm.B; Sk.counters = d_cnt;
+        Sk.counters_next = h->d_ring + 8 * (slot ^ 1);
+        Sk.host_flag = h->h_ring_dev;
+        Sk.round_stamp = (int)(r + 1);
         Sk.WQ = h->Q; Sk.WQ.par = (int)(r & 1);       // round parity selects the queue being consumed
-        if (hipMemsetAsync(d_cnt, 0, 8 * sizeof(int), sb.st) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "memset failed");
         const bool kkt = (r > 0) && (depth > 1 || last_kkt > 0);
         if (kkt && !h->kkt_overlap) {   // small batches: latency matters, keep the KKT result in this round
             Sk.kkt_same_round = 1;
@@ -763,15 +767,14 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         rr = launch_resid_decide(Sk, sb.st);
         prof_end(h, sb.st);
         if (rr != CIMPC_OK) return fail(h, rr, "residual launch failed");
-        if (hipMemcpyAsync(h->h_ring + 8 * slot, d_cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, sb.st) != hipSuccess ||
-            hipEventRecord(h->ev_ring[slot], sb.st) != hipSuccess)
-            return fail(h, CIMPC_ERR_HIP, "counter read-back failed");
         return CIMPC_OK;
     };
     HIP_TRY(h, hipMemsetAsync(h->Q.count, 0, 2 * h->Q.K * sizeof(int), sb.st));
     HIP_TRY(h, hipMemsetAsync(h->Q.head, 0, h->Q.K * sizeof(int), sb.st));
     HIP_TRY(h, hipMemsetAsync(h->Q.s_count, 0, h->Q.K * sizeof(int), sb.st));
     HIP_TRY(h, hipMemsetAsync(h->Q.s_head, 0, h->Q.K * sizeof(int), sb.st));
+    HIP_TRY(h, hipMemsetAsync(h->d_ring, 0, 16 * sizeof(int), sb.st));
+    ((volatile int*)h->h_ring)[2] = 0;
     {
         NewtonDev Sk = S;
         Sk.b0 = 0; Sk.nb_launch = h->dm.B; Sk.counters = h->d_ring;
@@ -788,12 +791,17 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             ++launched;
         }
         if (completed >= launched) break;     // max_rounds reached
-        const int slot = (int)(completed % depth);
-        hipError_t q;
-        while ((q = hipEventQuery(h->ev_ring[slot])) == hipErrorNotReady) {}
-        if (q != hipSuccess) return fail(h, CIMPC_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
-        const int n_sweep = h->h_ring[8 * slot + 0];
-        last_kkt = h->h_ring[8 * slot + 1];
+        {   // the residual kernel's last block stamps the mapped flag when round `completed` is done
+            volatile int* hm = (volatile int*)h->h_ring;
+            const int want = (int)(completed + 1);
+            long long spins = 0;
+            while (hm[2] != want) {
+                if ((++spins & 0xFFFFF) == 0 && hipStreamQuery(sb.st) != hipErrorNotReady && hm[2] != want)
+                    return fail(h, CIMPC_ERR_HIP, "round finished without publishing its counters");
+            }
+        }
+        const int n_sweep = ((volatile int*)h->h_ring)[0];
+        last_kkt = ((volatile int*)h->h_ring)[1];
         h->prof_kkt_systems += last_kkt;
         ++completed;
         rounds = completed;

@@ -251,7 +251,7 @@ __device__ double slot_residual(const NewtonDev& S, size_t sb, int b, double* re
 }
 
 template <int NQ, int NU, bool CF>
-__global__ __launch_bounds__(256) void resid_decide_kernel(NewtonDev S) {
+__device__ __forceinline__ void resid_decide_body(const NewtonDev& S, double* red, double* rc, int* sh) {
     const cimpc_dims& m = S.dm;
     const int b = blockIdx.x + S.b0, tid = threadIdx.x, nt = blockDim.x;
     const int H = m.H;
@@ -259,6 +259,7 @@ __global__ __launch_bounds__(256) void resid_decide_kernel(NewtonDev S) {
     if (blockIdx.x == 0) {   // the queue of this round has been consumed: recycle it
         const int K = S.WQ.K, par = S.WQ.par;
         for (int k = tid; k < K; k += nt) { S.WQ.count[par * K + k] = 0; S.WQ.head[k] = 0; S.WQ.s_count[k] = 0; S.WQ.s_head[k] = 0; }
+        if (tid < 8) S.counters_next[tid] = 0;      // counter block of the next round
     }
     const int stage = S.stage[b];
     if (stage == STAGE_DONE || stage == STAGE_KKT) return;
@@ -272,9 +273,7 @@ __global__ __launch_bounds__(256) void resid_decide_kernel(NewtonDev S) {
             return;
         }
     }
-    __shared__ double red[256];
-    __shared__ double rc[CS];
-    __shared__ int s_act, s_slot, s_iter;
+    int& s_act = sh[0]; int& s_slot = sh[1]; int& s_iter = sh[2];
     for (int c = 0; c < ncand; ++c) {
         const double v = slot_residual<NQ, NU, CF>(S, sb0 + c, b, red, tid, nt);
         if (tid == 0) { rc[c] = v; S.r_cand[sb0 + c] = v; }
@@ -372,6 +371,30 @@ __global__ __launch_bounds__(256) void resid_decide_kernel(NewtonDev S) {
         } else {
             S.stage[b] = STAGE_KKT;
             atomicAdd(&S.counters[1], 1);
+        }
+    }
+}
+
+template <int NQ, int NU, bool CF>
+__global__ __launch_bounds__(256) void resid_decide_kernel(NewtonDev S) {
+    __shared__ double red[256];
+    __shared__ double rc[CS];
+    __shared__ int sh[4];
+    resid_decide_body<NQ, NU, CF>(S, red, rc, sh);
+    // ---- epilogue: the LAST block to finish publishes the round's counters to host-mapped pinned
+    //      memory (the host polls the stamp; no memcpy / event on the critical path)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int ticket = atomicAdd(&S.counters[7], 1);
+        if (ticket == (int)gridDim.x - 1) {
+            const int n_sweep = atomicAdd(&S.counters[0], 0), n_kkt = atomicAdd(&S.counters[1], 0);
+            volatile int* hm = S.host_flag;
+            hm[0] = n_sweep;
+            hm[1] = n_kkt;
+            __threadfence_system();
+            hm[2] = S.round_stamp;
+            __threadfence_system();
         }
     }
 }

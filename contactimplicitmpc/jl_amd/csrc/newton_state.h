@@ -49,7 +49,10 @@ struct NewtonDev {
     int* newton_l;     // [B]  Newton iterations done
     int* stage;        // [B]
     int* need_sweep;   // [B*CS]
-    int* counters;     // [8]: 0 = #rollouts needing a sweep, 1 = #needing KKT
+    int* counters;     // [8]: 0 = #rollouts needing a sweep, 1 = #needing KKT, 2 = parked solves, 7 = block ticket
+    int* counters_next; // counter block of the next round (zeroed by the residual kernel)
+    int* host_flag;    // host-mapped pinned {n_sweep, n_kkt, stamp}
+    int round_stamp;   // value published to host_flag[2] when the round is complete
     long long* stats;  // [4]: sweeps, ip_solves, ip_iters, ip_failures (accumulated)
     int* ro_sweeps;    // [B] implicit_dynamics! evaluations of the last solve
     int* ro_ip_iters;  // [B] interior-point iterations of the last solve
