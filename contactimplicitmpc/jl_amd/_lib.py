@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcimpc_hip.so")
+LIB_PATH = os.environ.get("CIMPC_LIB") or os.path.join(_HERE, "libcimpc_hip.so")   # CIMPC_LIB: A/B builds
 
 
 class CimpcError(RuntimeError):

@@ -224,8 +224,9 @@ IpParams make_ip_params(cimpc_ctx* h, const TrajDev& T, int par, int* pending_co
 }
 
 // queue kernel + sensitivity kernel of one round
-int run_sweep(cimpc_ctx* h, int par, int* pending_counter, double* zout, hipStream_t st) {
+int run_sweep(cimpc_ctx* h, int par, int* pending_counter, double* zout, hipStream_t st, int iter_cap = 0) {
     IpParams p = make_ip_params(h, h->S.cand, par, pending_counter, zout);
+    if (iter_cap > 0) p.iter_cap = iter_cap;
     prof_begin(h, PC_IP, st);
     int rc = launch_ip_sweep(&h->dm, p, h->waves, st);
     prof_end(h, st);
@@ -733,7 +734,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     // rounds launched after the batch has finished find empty queues and return immediately.
     const int depth = h->pipeline_depth;
     long long launched = 0, completed = 0, rounds = 0;
-    int last_kkt = 0;
+    int last_kkt = 0, last_sweep = h->dm.B;
     auto launch_round = [&](long long r) -> int {
         // [KKT for rollouts that start an iteration] || sweep -> residual + line-search decision
         const int slot = (int)(r & 1);
@@ -760,7 +761,11 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             if (rr != CIMPC_OK) return fail(h, rr, "kkt launch failed");
             if (hipEventRecord(sb.ev_join, sb.st_kkt) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join record failed");
         }
-        int rr = run_sweep(h, Sk.WQ.par, d_cnt + 2, nullptr, sb.st);
+        // parking (iter_cap) protects a busy round from one long solve; in the sparse tail of a solve
+        // it only adds rounds, so a round that serves few rollouts lets every solve run to the end
+        static const int tail_div = getenv("CIMPC_TAIL_DIV") ? atoi(getenv("CIMPC_TAIL_DIV")) : 8;
+        const int cap = (tail_div > 0 && last_sweep * tail_div <= h->dm.B) ? h->ip.max_iter : h->iter_cap;
+        int rr = run_sweep(h, Sk.WQ.par, d_cnt + 2, nullptr, sb.st, cap);
         if (rr != CIMPC_OK) return rr;
         if (kkt && h->kkt_overlap && hipStreamWaitEvent(sb.st, sb.ev_join, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join failed");
         prof_begin(h, PC_RESID, sb.st);
@@ -801,6 +806,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             }
         }
         const int n_sweep = ((volatile int*)h->h_ring)[0];
+        last_sweep = n_sweep;
         last_kkt = ((volatile int*)h->h_ring)[1];
         h->prof_kkt_systems += last_kkt;
         ++completed;

@@ -1055,24 +1055,22 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
     __threadfence_block();
     lds_sync();
     // =========================================================================================
-    // backward substitution fused with the primal recovery, step i = H-1 .. 0:
+    // backward substitution, step i = H-1 .. 0 (sequential):
     //   dnu_i = L0_i^-T (y_i - L1_{i+1}^T dnu_{i+1} - L2_{i+2}^T dnu_{i+2})
+    // then the primal recovery for ALL steps at once (no dependency between steps):
     //   Du_i  = Rinv_i (rpu_i - du1_i^T dnu_i)
     //   Dq_i  = Qinv_i (rpq_i + dnu_i - dq1_{i+1}^T dnu_{i+1} - dq0_{i+2}^T dnu_{i+2})
-    // rings (slot = step % 3): factors {L1, L2, Li} and sensitivities {du1, dq1, dq0}
     // =========================================================================================
     double* D = K.delta + (size_t)b * S.N;
-    // tiles 0..2: L1_j ring, 3..5: L2_j ring, 8..10: dq1_j ring, 11..13: dq0_j ring
-    double* FI = tile(6);                            // L0_i^-1
-    double* G0 = tile(7);                            // du1_i
-    double* BQ = tile(14); double* BR = tile(15);    // Qinv_i, Rinv_i
+    // tiles 0..2: L1_j ring, 3..5: L2_j ring (slot = step % 3), tile 6: L0_i^-1
+    double* FI = tile(6);
     double* yb = vec;                                 // y_i
-    double* tu = vec + 80; double* tq = vec + 96; double* rq = vec + 112; double* ru = vec + 128;
+    double* dn_all = tile(16);                        // [H][16] all dnu (tiles 16..18; H <= 48)
+    double* t_all = tile(7);                          // [H][nr] first level of the recovery (tiles 7..)
     constexpr int PF_W = (WSR + 63) / 64;
     double pf_w[PF_W];
     auto prefetch_b = [&](int i) {
         if (i < 0) return;
-        prefetch(i);
         const double* wsi = ws + (size_t)i * WSR;
 #pragma unroll
         for (int j = 0; j < PF_W; ++j) { const int k = lane + 64 * j; pf_w[j] = (k < WSR) ? wsi[k] : 0.0; }
@@ -1082,10 +1080,6 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
         const int s0 = i % 3, s1 = (i + 1) % 3, s2 = (i + 2) % 3;
         double* F1s0 = tile(0 + s0); double* F1s1 = tile(0 + s1);
         double* F2s0 = tile(3 + s0); double* F2s2 = tile(3 + s2);
-        double* G1s0 = tile(8 + s0); double* G1s1 = tile(8 + s1);
-        double* G2s0 = tile(11 + s0); double* G2s2 = tile(11 + s2);
-        double* dn0 = vec + 32 + 16 * s0; double* dn1 = vec + 32 + 16 * s1; double* dn2 = vec + 32 + 16 * s2;
-        commit(G0, G1s0, G2s0, BQ, BR, ru, rq);
 #pragma unroll
         for (int j = 0; j < PF_W; ++j) {
             const int k = lane + 64 * j;
@@ -1099,34 +1093,71 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
         }
         lds_sync();
         prefetch_b(i - 1);
-        double dni = 0.0;
         if (lane < nd) {
             double s = yb[lane];
-            if (i + 1 < H) s -= tile_mv<nd, true>(F1s1, dn1, lane);
-            if (i + 2 < H) s -= tile_mv<nd, true>(F2s2, dn2, lane);
+            if (i + 1 < H) s -= tile_mv<nd, true>(F1s1, dn_all + (i + 1) * 16, lane);
+            if (i + 2 < H) s -= tile_mv<nd, true>(F2s2, dn_all + (i + 2) * 16, lane);
             tv[lane] = s;
         }
         lds_sync();
         if (lane < nd) {
-            dni = tile_mv<nd, true>(FI, tv, lane);
-            dn0[lane] = dni;
+            const double dni = tile_mv<nd, true>(FI, tv, lane);
+            dn_all[i * 16 + lane] = dni;
             D[H * nr + i * nd + lane] = dni;
         }
         lds_sync();
-        if (lane < nu) {
-            tu[lane] = ru[lane] - tile_mv<nd, true>(G0, dn0, lane);
-        } else if (lane >= 16 && lane < 16 + nq) {
-            const int c = lane - 16;
-            double s = rq[c] + dn0[c];
-            if (i + 1 < H) s -= tile_mv<nd, true>(G1s1, dn1, c);
-            if (i + 2 < H) s -= tile_mv<nd, true>(G2s2, dn2, c);
-            tq[c] = s;
-        }
-        lds_sync();
-        if (lane < nu) D[i * nr + lane] = tile_mv<nu, false>(BR, tu, lane);
-        else if (lane >= 16 && lane < 16 + nq) D[i * nr + nu + (lane - 16)] = tile_mv<nq, false>(BQ, tq, lane - 16);
-        lds_sync();
     }
+    // ---- primal recovery, level 1: t = r_p - C^T dnu, one output per lane and trip ---------------
+    for (int idx = lane; idx < H * nr; idx += 64) {
+        const int i = idx / nr, c = idx - i * nr;
+        double s = rb[idx];
+        if (c < nu) {
+            const double* a0 = dzb + ((size_t)i * nths + 2 * nq + c) * nd;
+            const double* dn0 = dn_all + i * 16;
+            double t0 = 0.0;
+#pragma unroll
+            for (int k = 0; k < nd; ++k) t0 = fma(a0[k], dn0[k], t0);
+            s -= t0;
+        } else {
+            const int cq = c - nu;
+            s += dn_all[i * 16 + cq];
+            if (i + 1 < H) {
+                const double* a1 = dzb + ((size_t)(i + 1) * nths + nq + cq) * nd;
+                const double* dn1 = dn_all + (i + 1) * 16;
+                double t1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < nd; ++k) t1 = fma(a1[k], dn1[k], t1);
+                s -= t1;
+            }
+            if (i + 2 < H) {
+                const double* a2 = dzb + ((size_t)(i + 2) * nths + cq) * nd;
+                const double* dn2 = dn_all + (i + 2) * 16;
+                double t2 = 0.0;
+#pragma unroll
+                for (int k = 0; k < nd; ++k) t2 = fma(a2[k], dn2[k], t2);
+                s -= t2;
+            }
+        }
+        t_all[idx] = s;
+    }
+    lds_sync();
+    // ---- level 2: Delta_x = P^-1 t ----------------------------------------------------------------
+    for (int idx = lane; idx < H * nr; idx += 64) {
+        const int i = idx / nr, c = idx - i * nr;
+        double s = 0.0;
+        if (c < nu) {
+            const double* Rm = S.Rinv + (size_t)i * nu * nu;
+#pragma unroll
+            for (int k = 0; k < nu; ++k) s = fma(Rm[c + k * nu], t_all[i * nr + k], s);
+        } else {
+            const int cq = c - nu;
+            const double* Qm = S.Qinv + (size_t)i * nq * nq;
+#pragma unroll
+            for (int k = 0; k < nq; ++k) s = fma(Qm[cq + k * nq], t_all[i * nr + nu + k], s);
+        }
+        D[idx] = s;
+    }
+    lds_sync();
     KPROF(8)
 #ifdef CIMPC_KKT_PROF
     if (lane == 0 && b == 0) for (int j = 0; j < 16; ++j) ((long long*)S.stats)[8 + j] = pt[j];
@@ -1151,9 +1182,10 @@ __global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
 
 template <int NQ, int NU>
 static int launch_kkt_t(const NewtonDev& S, const KktArgs& K, hipStream_t s) {
-    if constexpr (NQ <= 16 && NU <= 16) {
+    if (NQ <= 16 && NU <= 16 && S.dm.H <= 96) {     // dnu / recovery staging of the MFMA kernel holds H <= 96 steps
         const size_t lds = (size_t)(KKT_MFMA_TILES * TSZ + 208) * sizeof(double);
-        hipLaunchKernelGGL((kkt_kernel<NQ, NU>), dim3(S.nb_launch), dim3(64), lds, s, S, K);
+        if constexpr (NQ <= 16 && NU <= 16)
+            hipLaunchKernelGGL((kkt_kernel<NQ, NU>), dim3(S.nb_launch), dim3(64), lds, s, S, K);
     } else {
         constexpr int LD = ((NQ > NU ? NQ : NU) + 3) & ~3;
         const size_t lds = (size_t)(KKT_TILES * LD * LD + 10 * LD) * sizeof(double);
