@@ -192,7 +192,7 @@ def main():
                    "newton": "r_tol 3e-4, max_iter 5, cold start", "ip": "r_tol 1e-8, kappa_tol 2e-4, undercut 5"},
         "solver_iters": {"newton_iters_per_step": L, "ip_iters_per_solve": K, "sweeps_per_eval": S,
                          "sweeps_per_step": sweeps / (B * args.steps), "lockstep_rounds_per_step": rounds / args.steps},
-        "roofline": {"bound": "hbm", "kernel": "ip_sweep_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "ip_queue_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "bytes_per_unit": alg["bytes_per_solve"], "units_per_launch": solves_per_launch,
                      "avg_launch_ms": avg_launch_ms,
