@@ -62,7 +62,7 @@ struct cimpc_ctx {
     double* d_tab = nullptr;
     IpQueues Q{};                // device work queues (par is set per launch)
     int* d_window = nullptr;
-    int wpk = 1;                 // persistent workgroups per knot
+    int wpk = 1;                 // persistent workgroups of a sweep launch
     double* d_alt = nullptr;
     double* d_zout = nullptr;
     double *d_Q = nullptr, *d_R = nullptr, *d_Qinv = nullptr, *d_Rinv = nullptr, *d_Cg = nullptr,
@@ -416,12 +416,16 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         if (hipEventCreateWithFlags(&h->ev_ring[k], hipEventDisableTiming) != hipSuccess) {
             g_create_error = "event creation failed"; cimpc_destroy(h); return CIMPC_ERR_HIP;
         }
-    {   // persistent workgroups per knot: ~2 problems per lane group and round, all workgroups resident
+    {   // persistent workgroups of a sweep launch: all resident (256 VGPRs -> 8 waves per CU), about two
+        // problems per lane group in a full round, and never fewer workgroups than busy knots (a
+        // workgroup serves one knot at a time)
         const size_t groups_per_wg = (64 / h->ki.G) * h->waves;
-        const size_t per_knot = (B * H + d.H_ref - 1) / d.H_ref;
-        size_t w = (per_knot + 2 * groups_per_wg - 1) / (2 * groups_per_wg);
-        const size_t resident = std::max<size_t>(1, 512 / d.H_ref);
-        h->wpk = (int)std::max<size_t>(1, std::min<size_t>(w, std::min<size_t>(8, resident)));
+        const size_t nprob = B * H;
+        size_t w = (nprob + 2 * groups_per_wg - 1) / (2 * groups_per_wg);
+        w = std::max<size_t>(w, std::min<size_t>(d.H_ref, nprob));
+        const size_t resident = (size_t)256 * (8 / h->waves);
+        h->wpk = (int)std::max<size_t>(1, std::min<size_t>(w, resident));
+        if (getenv("CIMPC_SWEEP_WGS")) h->wpk = std::max(1, atoi(getenv("CIMPC_SWEEP_WGS")));
     }
     {   // sub-batches: >= 64 rollouts each, at most 4 (host launch rate bounds the useful count)
         // default 1: on MI355X a sweep launch of >= 64 rollouts already fills the 2 workgroups/CU the

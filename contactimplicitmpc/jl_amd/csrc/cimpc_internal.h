@@ -29,7 +29,7 @@ struct IpQueues {
 struct IpParams {
     const double* tab;     // [H_ref][LinLayout::size]   packed linearization tables
     IpQueues Q;
-    int wpk;               // persistent workgroups per knot
+    int wpk;               // persistent workgroups of the launch (each serves one knot at a time)
     const double* q;       // [B*slots][H+2][nq]   trajectory being evaluated (q_{i+2} = IP start)
     const double* theta;   // [B*slots][H][nth]
     const double* gam;     // [B*slots][H][nc]   (configurationforce mode) or null

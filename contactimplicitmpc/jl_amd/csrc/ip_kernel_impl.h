@@ -330,12 +330,9 @@ __global__ __launch_bounds__(256, 2) void ip_queue_kernel(IpParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* tab = smem;
     const int tid = (int)threadIdx.x;
-    const int knot = (int)blockIdx.x / p.wpk;
     const int K = p.Q.K, cap = p.Q.cap, par = p.Q.par;
-    const int n = p.Q.count[par * K + knot];
-    if (n == 0) return;
-    stage_table<M>(tab, p.tab, knot, tid);
-    __syncthreads();
+    constexpr int MAXK = 256;
+    __shared__ int s_knot, s_total, s_rem[MAXK];
 
     const int grp = tid / G;
     const int l = tid % G;
@@ -343,17 +340,58 @@ __global__ __launch_bounds__(256, 2) void ip_queue_kernel(IpParams p) {
     double* dth = Rst + NY * M::RST_LD;                          // [NTH]
     int* backlog = reinterpret_cast<int*>(dth + NTH);            // [SENS_MAX] converged, sensitivities pending
     int nback = 0;
-    const int* items = p.Q.items + ((size_t)par * K + knot) * cap;
-    int* head = p.Q.head + knot;
 
     IpSolver<M> S;
-    S.bind(tab, Rst, l);
-    const bool vx = S.vx, vy = S.vy;
+    const bool vx = l < NX, vy = l < NY;
     const cimpc_ip_opts o = p.o;
 
     bool have = false, exhausted = false, stalled = false;
     int prob = 0, iters = 0, done_here = 0;
     double reg = 0.0, r_vio = 0.0, k_vio = 0.0, qinit = 0.0;
+
+    // Knot hopping: the workgroup serves one knot (its table staged in LDS) until that queue is
+    // empty, then moves to another knot that still has work.  The pick is proportional to the
+    // remaining work: workgroup b takes the knot holding quantile b/gridDim of the problems not
+    // yet pulled, so the workgroups spread over the knots like the work does - initially and after
+    // every hop - whatever the windows of the rollouts look like.
+    while (true) {
+    __syncthreads();            // every wave is done with the staged table and with s_knot
+    if (tid == 0) s_total = 0;
+    __syncthreads();
+    {   // remaining work per knot: parallel loads, LDS copy
+        int part = 0;
+        for (int k = tid; k < K; k += (int)blockDim.x) {
+            int rem = p.Q.count[par * K + k] - __atomic_load_n(p.Q.head + k, __ATOMIC_RELAXED);
+            rem = rem > 0 ? rem : 0;
+            if (k < MAXK) s_rem[k] = rem;
+            part += rem;
+        }
+        if (part > 0) atomicAdd(&s_total, part);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int total = s_total;
+        int pick = -1;
+        if (total > 0) {
+            const long long target = ((long long)blockIdx.x * total) / (long long)gridDim.x;
+            long long acc = 0;
+            for (int k = 0; k < K; ++k) {
+                const int rem = k < MAXK ? s_rem[k] : max(0, p.Q.count[par * K + k] - __atomic_load_n(p.Q.head + k, __ATOMIC_RELAXED));
+                if (rem > 0) { pick = k; acc += rem; if (acc > target) break; }
+            }
+        }
+        s_knot = pick;
+    }
+    __syncthreads();
+    const int knot = s_knot;
+    if (knot < 0) break;
+    const int n = p.Q.count[par * K + knot];
+    stage_table<M>(tab, p.tab, knot, tid);
+    __syncthreads();
+    const int* items = p.Q.items + ((size_t)par * K + knot) * cap;
+    int* head = p.Q.head + knot;
+    S.bind(tab, Rst, l);        // caches the per-lane constants of this knot's table
+    have = false; exhausted = false;
 
     while (true) {
         // ---- 1. end of a solve? ---------------------------------------------------------------
@@ -486,6 +524,7 @@ __global__ __launch_bounds__(256, 2) void ip_queue_kernel(IpParams p) {
             S.x = sx; S.y1 = sy1; S.y2 = sy2; S.rdyn = sd; S.rrst = sr; S.rbil = sb_; S.tthdyn = st; S.tthrst = su; S.altl = sa;
         }
     }
+    }   // hop
 }
 
 // ----------------------------------------------------------------------------------------
@@ -502,7 +541,7 @@ int launch_model(const IpParams& p, int waves, hipStream_t s) {
         if (hipFuncSetAttribute((const void*)ip_queue_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return CIMPC_ERR_HIP;
     }
-    const int grid = p.Q.K * p.wpk;
+    const int grid = p.wpk;      // persistent workgroups of the launch
     hipLaunchKernelGGL((ip_queue_kernel<M>), dim3(grid), dim3(64 * waves), lds, s, p);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
