@@ -86,6 +86,15 @@ struct cimpc_ctx {
     int* h_ring = nullptr;       // pinned, host-mapped: {n_sweep, n_kkt, stamp}
     int* h_ring_dev = nullptr;   // device pointer of h_ring
     hipEvent_t ev_ring[4] = {nullptr, nullptr, nullptr, nullptr};
+    // asynchronous single-launch solve (newton_async_impl.h)
+    bool async_on = false, async_dirty = true;
+    int* a_items = nullptr;      // [K][a_cap] live interior-point queues
+    int* a_jobs = nullptr;       // residual job entries, then KKT job entries
+    int* a_ctrl = nullptr;       // [count K][head K][rq_head rq_tail kq_head kq_tail n_done ...]
+    int* a_evals = nullptr;      // [B]
+    long long* a_dbg = nullptr;  // [16] diagnostics (CIMPC_ASYNC_DEBUG)
+    size_t a_cap = 0, a_rq_cap = 0, a_kq_cap = 0;
+    int a_grid = 0, a_service = 0;
     std::vector<SubBatch> subs;
     bool external_stream = false;
     std::vector<double> h_tab;       // one knot staging
@@ -115,10 +124,12 @@ int fail(cimpc_ctx* h, int code, const std::string& msg) {
     } while (0)
 
 template <class T>
-int dev_alloc(cimpc_ctx* h, T** p, size_t count) {
+int dev_alloc(cimpc_ctx* h, T** p, size_t count, int mem = 0) {
+    // mem: 0 = ordinary device memory; 1 = uncached, 2 = fine-grained device memory (experiments only)
     void* v = nullptr;
     if (count == 0) count = 1;
-    hipError_t e = hipMalloc(&v, count * sizeof(T));
+    hipError_t e = mem == 0 ? hipMalloc(&v, count * sizeof(T))
+                            : hipExtMallocWithFlags(&v, count * sizeof(T), mem == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
     if (e != hipSuccess) return fail(h, CIMPC_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
     e = hipMemset(v, 0, count * sizeof(T));
     if (e != hipSuccess) return fail(h, CIMPC_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e));
@@ -332,7 +343,23 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
 
     const size_t B = d.B, H = d.H;
     int rc = CIMPC_OK;
+    {   // asynchronous single-launch solve? (queues sized for every push of one solve: they never wrap)
+        // Opt-in (CIMPC_ASYNC=1).  Measured on MI355X, quadruped H = 40, B = 512: the
+        // single launch is correct but 2x slower than the lock-step rounds (33 ms vs 16.5 ms per batch
+        // step at its best occupancy of ~192 workgroups; it degrades further with more resident workgroups).
+        const char* ev = getenv("CIMPC_ASYNC");
+        const bool want = ev ? atoi(ev) != 0 : false;
+        const size_t K = d.H_ref;
+        const size_t evals = 1 + 7 * (size_t)std::max(1, h->nt.max_iter);       // per rollout and solve
+        h->a_cap = B * evals * ((H + K - 1) / K + 1);
+        h->a_rq_cap = B * (2 + 3 * (size_t)std::max(1, h->nt.max_iter));
+        h->a_kq_cap = B * (1 + (size_t)std::max(1, h->nt.max_iter));
+        const size_t bytes = (K * h->a_cap + h->a_rq_cap + h->a_kq_cap) * sizeof(int);
+        h->async_on = want && newton_async_available(&d) && K <= 256 && bytes <= ((size_t)1 << 30);
+    }
+    const int xm = (h->async_on && getenv("CIMPC_ASYNC_MEM")) ? atoi(getenv("CIMPC_ASYNC_MEM")) : 0;   // experiments: 1 uncached, 2 fine-grained
     auto A = [&](auto** p, size_t n) { if (rc == CIMPC_OK) rc = dev_alloc(h, p, n); };
+    auto AX = [&](auto** p, size_t n) { if (rc == CIMPC_OK) rc = dev_alloc(h, p, n, xm); };   // exchanged state
     A(&h->d_tab, (size_t)d.H_ref * h->ki.tab_size);
     const int ppw = 64 / h->ki.G;
     {   // work queues: a knot can appear ceil(H / H_ref) times in one window
@@ -341,7 +368,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         h->Q.K = (int)K; h->Q.cap = (int)cap; h->Q.par = 0;
         A(&h->Q.items, 2 * K * cap); A(&h->Q.count, 2 * K); A(&h->Q.head, K);
         A(&h->Q.s_items, K * cap); A(&h->Q.s_count, K); A(&h->Q.s_head, K);
-        A(&h->Q.done_count, B * CS);
+        AX(&h->Q.done_count, B * CS);
         A(&h->d_window, B * (H + 2));
         h->Q.window = h->d_window;
     }
@@ -364,31 +391,32 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     const size_t BS = B * CS;     // evaluation slots (speculative line search)
     for (TrajDev* T : {&S.traj, &S.cand, &S.ref}) {
         const size_t n = (T == &S.cand) ? BS : B;
-        A(&T->q, n * (H + 2) * d.nq);
-        A(&T->u, n * H * d.nu);
-        A(&T->w, n * H * d.nw);
-        A(&T->g, n * H * d.nc);
-        A(&T->b, n * H * d.nb);
-        A(&T->th, n * H * h->nth);
+        if (T == &S.ref) {       // read-only during a solve
+            A(&T->q, n * (H + 2) * d.nq); A(&T->u, n * H * d.nu); A(&T->w, n * H * d.nw);
+            A(&T->g, n * H * d.nc); A(&T->b, n * H * d.nb); A(&T->th, n * H * h->nth);
+        } else {
+            AX(&T->q, n * (H + 2) * d.nq); AX(&T->u, n * H * d.nu); AX(&T->w, n * H * d.nw);
+            AX(&T->g, n * H * d.nc); AX(&T->b, n * H * d.nb); AX(&T->th, n * H * h->nth);
+        }
     }
-    A(&S.nu, B * H * h->nd);
-    A(&S.nu_cand, BS * H * h->nd);
-    A(&S.d, BS * H * h->nd);
-    A(&S.dz, BS * H * h->nths * h->nd);
-    A(&S.ip_status, BS * H);
-    A(&S.ip_iters, BS * H);
-    A(&S.pflag, BS * H);
-    A(&S.cur_slot, B);
+    AX(&S.nu, B * H * h->nd);
+    AX(&S.nu_cand, BS * H * h->nd);
+    AX(&S.d, BS * H * h->nd);
+    AX(&S.dz, BS * H * h->nths * h->nd);
+    AX(&S.ip_status, BS * H);
+    AX(&S.ip_iters, BS * H);
+    AX(&S.pflag, BS * H);
+    AX(&S.cur_slot, B);
     A(&h->d_pstate, BS * H * (2 * (size_t)h->nx + 4 * (size_t)h->ny + 4));
-    A(&S.res, B * h->N);
-    A(&S.res_cand, BS * h->N);
-    A(&S.delta, B * h->N);
-    A(&S.r_norm, B); A(&S.r_cand, BS); A(&S.alpha, B); A(&S.beta, B);
-    A(&S.ls_iter, B); A(&S.newton_l, B); A(&S.stage, B); A(&S.need_sweep, BS);
+    AX(&S.res, B * h->N);
+    AX(&S.res_cand, BS * h->N);
+    AX(&S.delta, B * h->N);
+    AX(&S.r_norm, B); AX(&S.r_cand, BS); AX(&S.alpha, B); AX(&S.beta, B);
+    AX(&S.ls_iter, B); AX(&S.newton_l, B); AX(&S.stage, B); AX(&S.need_sweep, BS);
     A(&h->d_need_first, BS);
-    A(&S.counters, 8);
-    A(&S.stats, 4);
-    A(&S.ro_sweeps, B); A(&S.ro_ip_iters, B); A(&S.ro_ip_fail, B);
+    AX(&S.counters, 8);
+    AX(&S.stats, 4);
+    AX(&S.ro_sweeps, B); AX(&S.ro_ip_iters, B); AX(&S.ro_ip_fail, B);
     A(&S.kkt_ws, B * H * (3 * (size_t)h->nd * h->nd + h->nd));
     (void)ppw;
     if (rc == CIMPC_OK && hipHostMalloc((void**)&h->h_counters, 8 * sizeof(int)) != hipSuccess)
@@ -403,6 +431,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     // small batches: one wave per workgroup keeps every problem on its own CU (latency);
     // large batches: 4 waves share one staged table (throughput)
     h->waves = (B * H >= 4096) ? 4 : 1;
+    if (getenv("CIMPC_WAVES")) { const int w = atoi(getenv("CIMPC_WAVES")); if (w == 1 || w == 2 || w == 4) h->waves = w; }
     h->kkt_overlap = B >= 64;
     // depth 1 measured fastest on MI355X (B = 512: 16.9 ms/step vs 17.8 ms at depth 3, because a deeper
     // pipeline has to launch the KKT kernel every round); the ring stays for experiments
@@ -416,6 +445,17 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         if (hipEventCreateWithFlags(&h->ev_ring[k], hipEventDisableTiming) != hipSuccess) {
             g_create_error = "event creation failed"; cimpc_destroy(h); return CIMPC_ERR_HIP;
         }
+    {
+        const size_t K = d.H_ref;
+        if (h->async_on) {
+            if (dev_alloc(h, &h->a_items, K * h->a_cap, xm) != CIMPC_OK || dev_alloc(h, &h->a_jobs, h->a_rq_cap + h->a_kq_cap, xm) != CIMPC_OK ||
+                dev_alloc(h, &h->a_ctrl, 2 * K + 16, xm) != CIMPC_OK || dev_alloc(h, &h->a_evals, B, xm) != CIMPC_OK) {
+                g_create_error = h->err; cimpc_destroy(h); return CIMPC_ERR_HIP;
+            }
+            if (getenv("CIMPC_ASYNC_DEBUG") && dev_alloc(h, &h->a_dbg, 16) != CIMPC_OK) { g_create_error = h->err; cimpc_destroy(h); return CIMPC_ERR_HIP; }
+            h->async_dirty = true;
+        }
+    }
     {   // persistent workgroups of a sweep launch: all resident (256 VGPRs -> 8 waves per CU), about two
         // problems per lane group in a full round, and never fewer workgroups than busy knots (a
         // workgroup serves one knot at a time)
@@ -426,6 +466,11 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         const size_t resident = (size_t)256 * (8 / h->waves);
         h->wpk = (int)std::max<size_t>(1, std::min<size_t>(w, resident));
         if (getenv("CIMPC_SWEEP_WGS")) h->wpk = std::max(1, atoi(getenv("CIMPC_SWEEP_WGS")));
+        // asynchronous solve: the same resident set plus dedicated residual/KKT workgroups
+        h->a_service = std::max(1, h->wpk / 8);
+        if (getenv("CIMPC_ASYNC_SERVICE")) h->a_service = std::max(1, atoi(getenv("CIMPC_ASYNC_SERVICE")));
+        h->a_grid = (int)std::min<size_t>(resident, (size_t)h->wpk + h->a_service);
+        if (h->a_grid <= h->a_service) h->a_grid = h->a_service + 1;
     }
     {   // sub-batches: >= 64 rollouts each, at most 4 (host launch rate bounds the useful count)
         // default 1: on MI355X a sweep launch of >= 64 rollouts already fills the 2 workgroups/CU the
@@ -720,6 +765,77 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     };
     HIP_TRY(h, hipMemsetAsync(S.stats, 0, 4 * sizeof(long long), h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->async_on) {
+        // ---- one persistent launch: every rollout advances on its own chain (newton_async_impl.h) ----
+        hipStream_t st = h->external_stream ? h->stream : h->subs[0].st;
+        const size_t K = h->Q.K;
+        if (h->async_dirty) {     // entries are reset by their consumers; only an aborted solve leaves some behind
+            HIP_TRY(h, hipMemsetAsync(h->a_items, 0xFF, K * h->a_cap * sizeof(int), st));
+            HIP_TRY(h, hipMemsetAsync(h->a_jobs, 0xFF, (h->a_rq_cap + h->a_kq_cap) * sizeof(int), st));
+            h->async_dirty = false;
+        }
+        HIP_TRY(h, hipMemsetAsync(h->a_ctrl, 0, (2 * K + 16) * sizeof(int), st));
+        volatile int* hm = (volatile int*)h->h_ring;
+        hm[3] = 0;
+        NewtonDev Sk = S;
+        Sk.b0 = 0; Sk.nb_launch = h->dm.B; Sk.counters = h->d_ring; Sk.counters_next = h->d_ring + 8;
+        Sk.host_flag = h->h_ring_dev;
+        Sk.WQ = h->Q; Sk.WQ.par = 0;
+        Sk.WQ.items = h->a_items; Sk.WQ.cap = (int)h->a_cap;
+        Sk.WQ.count = h->a_ctrl; Sk.WQ.head = h->a_ctrl + K;
+        AsyncQ& A = Sk.A;
+        A.on = 1;
+        int* c = h->a_ctrl + 2 * K;
+        A.rq_items = h->a_jobs; A.rq_head = c + 0; A.rq_tail = c + 1;
+        A.kq_items = h->a_jobs + h->a_rq_cap; A.kq_head = c + 2; A.kq_tail = c + 3;
+        A.n_done = c + 4;
+        A.evals_left = h->a_evals;
+        A.abort_flag = (volatile int*)(h->h_ring_dev + 3);
+        A.n_service = h->a_service;
+        A.flags = getenv("CIMPC_ASYNC_FLAGS") ? atoi(getenv("CIMPC_ASYNC_FLAGS")) : 0;
+        A.idle_sleep = getenv("CIMPC_ASYNC_SLEEP") ? atoi(getenv("CIMPC_ASYNC_SLEEP")) : 2;
+        A.dbg = h->a_dbg;
+        if (h->a_dbg) HIP_TRY(h, hipMemsetAsync(h->a_dbg, 0, 16 * sizeof(long long), st));
+        A.B = h->dm.B;
+        prof_begin(h, PC_OTHER, st);
+        rc = launch_reset(Sk, q0_dev, q1_dev, warm_start, st);
+        prof_end(h, st);
+        if (rc != CIMPC_OK) return fail(h, rc, "reset launch failed");
+        IpParams p = make_ip_params(h, S.cand, 0, h->d_ring + 2, nullptr);
+        p.Q = Sk.WQ;
+        p.iter_cap = h->ip.max_iter + 1;      // no solve is parked
+        p.A = A;
+        prof_begin(h, PC_IP, st);
+        rc = launch_newton_async(&h->dm, p, Sk, h->waves, h->a_grid, st);
+        prof_end(h, st);
+        if (rc != CIMPC_OK) return fail(h, rc, "asynchronous newton launch failed");
+        if (h->nt.max_time > 0.0 && h->nt.max_time < 1.0e6) {      // newton.jl:187-277: the time budget ends the loop silently
+            while (hipStreamQuery(st) == hipErrorNotReady) {
+                if (over_budget()) { hm[3] = 1; h->async_dirty = true; break; }
+            }
+        }
+        HIP_TRY(h, hipStreamSynchronize(st));
+        if (h->a_dbg) {
+            long long dv[16];
+            HIP_TRY(h, hipMemcpy(dv, h->a_dbg, sizeof(dv), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[cimpc async] WG-ms: other %.2f kkt %.2f resid %.2f ip %.2f | jobs: kkt %lld resid %lld serve %lld | grid %d service %d\n",
+                    dv[0] * 1e-5, dv[1] * 1e-5, dv[2] * 1e-5, dv[3] * 1e-5, dv[9], dv[10], dv[11], h->a_grid, h->a_service);
+        }
+        long long stv[4];
+        HIP_TRY(h, hipMemcpy(stv, S.stats, sizeof(stv), hipMemcpyDeviceToHost));
+        std::vector<int> l(h->dm.B);
+        HIP_TRY(h, hipMemcpy(l.data(), S.newton_l, l.size() * sizeof(int), hipMemcpyDeviceToHost));
+        h->last_stats.sweeps = stv[0];
+        h->last_stats.ip_solves = stv[1];
+        h->last_stats.ip_iters = stv[2];
+        h->last_stats.ip_failures = stv[3];
+        h->last_stats.rounds = 1;
+        h->last_stats.newton_iters = 0;
+        for (int v : l) h->last_stats.newton_iters += v;
+        h->prof_ip_problems += stv[1];
+        h->prof_kkt_systems += h->last_stats.newton_iters;
+        return CIMPC_OK;
+    }
     // safety net only: every Newton iteration needs at most 3 (speculative) rounds, each evaluation at
     // most ceil(max_iter / iter_cap) launches of the resumable interior-point sweep
     const int max_rounds = (h->nt.max_iter * 8 + 2) * ((h->ip.max_iter + h->iter_cap - 1) / h->iter_cap + 1);

@@ -26,6 +26,70 @@ struct IpQueues {
     int cap, K, par;
 };
 
+// Asynchronous (single-launch) Newton solve: every rollout advances on its own dependency chain
+// sweep -> residual/decision -> KKT -> sweep ... inside ONE persistent kernel.  The stages hand work
+// to each other through these device queues.  Queues never wrap within a solve (capacity = upper
+// bound of the pushes of one solve); entries are pre-set to -1 so that a consumer that claimed an
+// index can wait for the producer's store.
+struct AsyncQ {
+    int on;             // 0: lock-step rounds (queues above are snapshots), 1: asynchronous solve
+    int* rq_items;      // residual/decision jobs: rollout index
+    int* rq_head;
+    int* rq_tail;
+    int* kq_items;      // KKT jobs: rollout index
+    int* kq_head;
+    int* kq_tail;
+    int* evals_left;    // [B] evaluation slots of the rollout's running line-search batch not yet complete
+    int* n_done;        // rollouts whose Newton solve has ended
+    volatile int* abort_flag;   // host-mapped: nonzero = time budget exhausted, leave
+    long long* dbg;     // [16] diagnostics (busy ticks / job counts per kind of work) or null
+    int n_service;      // workgroups [0, n_service) only take residual / KKT jobs
+    int flags;          // experiment switches, see xfence()
+    int idle_sleep;     // back-off of an idle workgroup between polls, units of s_sleep(64) (~2 us)
+    int B;
+};
+
+// Hand-offs of the asynchronous solve follow the HIP memory model literally: the producer issues an
+// agent-scope release fence (__threadfence) after writing its results and before the queue push /
+// counter update, the consumer an agent-scope acquire fence after claiming the entry.  (Measured on
+// MI355X: replacing the per-problem fences by write-through stores + s_waitcnt was neither faster
+// nor reliably correct across XCDs, so the plain, portable form stays.)
+// flags: experiment switches (CIMPC_ASYNC_FLAGS): 1 = wave-local fences only (timing experiments: NOT coherent),
+// 2 = no in-serve retry of idle groups
+__device__ __forceinline__ void xfence(int flags) {
+    if (flags & 1) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    else __threadfence();
+}
+template <bool X>
+__device__ __forceinline__ double xld(const double* p) { return *p; }
+template <bool X>
+__device__ __forceinline__ void xst(double* p, double v) { *p = v; }
+template <bool X>
+__device__ __forceinline__ void xst(int* p, int v) { *p = v; }
+
+__device__ __forceinline__ int aload(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void astore(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// multi-producer push: reserve a position, then store the entry (consumers wait on the -1 sentinel)
+__device__ __forceinline__ void aq_push(int* items, int* tail, int v) {
+    const int pos = atomicAdd(tail, 1);
+    astore(items + pos, v);
+}
+// multi-consumer pop by ONE lane: -1 when the queue is empty
+__device__ __forceinline__ int aq_pop(int* items, int* head, const int* tail) {
+    int h = aload(head);
+    while (true) {
+        if (h >= aload(tail)) return -1;
+        const int old = atomicCAS(head, h, h + 1);
+        if (old == h) break;
+        h = old;
+    }
+    int v;
+    while ((v = aload(items + h)) < 0) __builtin_amdgcn_s_sleep(1);
+    astore(items + h, -1);        // the queue is clean again when every entry has been consumed
+    return v;
+}
+
 struct IpParams {
     const double* tab;     // [H_ref][LinLayout::size]   packed linearization tables
     IpQueues Q;
@@ -50,6 +114,7 @@ struct IpParams {
     int slots;             // evaluation slots per rollout: rollout = slot index / slots
     int H;
     cimpc_ip_opts o;
+    AsyncQ A;
 };
 
 struct KernelInfo {

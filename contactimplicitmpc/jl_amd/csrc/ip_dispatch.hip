@@ -1,6 +1,6 @@
 // Dimension dispatch of the interior-point sweep kernel (one instantiation per model the
 // reference ships dimensions for; SURVEY.md section 2 "Problem dimensions").
-#include "cimpc_internal.h"
+#include "newton_state.h"
 
 namespace cimpc {
 
@@ -34,6 +34,25 @@ int launch_ip_sweep(const cimpc_dims* dm, const IpParams& p, int waves, hipStrea
     CIMPC_MODELS(X)
 #undef X
     return CIMPC_ERR_INVALID;
+}
+
+// asynchronous single-launch Newton solve (newton_async_impl.h): :configuration mode, nq, nu <= 16
+int async_launch_pushbot(const IpParams& p, const NewtonDev& S, int waves, int grid, hipStream_t s);
+int async_launch_hopper(const IpParams& p, const NewtonDev& S, int waves, int grid, hipStream_t s);
+int async_launch_quadruped(const IpParams& p, const NewtonDev& S, int waves, int grid, hipStream_t s);
+
+bool newton_async_available(const cimpc_dims* dm) {
+    if (dm->mode != CIMPC_MODE_CONFIGURATION || dm->H > 96) return false;
+    return (dm->nq == 2 && dm->nu == 2 && dm->nw == 2 && dm->nc == 2 && dm->nb == 4) ||
+           (dm->nq == 4 && dm->nu == 2 && dm->nw == 2 && dm->nc == 1 && dm->nb == 2) ||
+           (dm->nq == 11 && dm->nu == 8 && dm->nw == 2 && dm->nc == 4 && dm->nb == 8);
+}
+
+int launch_newton_async(const cimpc_dims* dm, const IpParams& p, const NewtonDev& S, int waves, int grid, hipStream_t s) {
+    if (!newton_async_available(dm)) return CIMPC_ERR_INVALID;
+    if (dm->nq == 2) return async_launch_pushbot(p, S, waves, grid, s);
+    if (dm->nq == 4) return async_launch_hopper(p, S, waves, grid, s);
+    return async_launch_quadruped(p, S, waves, grid, s);
 }
 
 }  // namespace cimpc

@@ -277,7 +277,28 @@ __device__ __forceinline__ void stage_table(double* tab, const double* src_tab, 
 // implicit_dynamics.jl:84-86) is computed.  Always executed by the lane group that solved the
 // problem (z* is re-read by the very lanes that stored it, so no cross-workgroup hand-off).
 // ----------------------------------------------------------------------------------------
-template <class M>
+// One problem of evaluation slot sb is finished (its d / dz / status are written).  Lock-step
+// rounds only count; the asynchronous solve hands the rollout to the residual stage when the last
+// problem of the last outstanding slot of its line-search batch completes.
+template <bool ASYNC>
+__device__ __forceinline__ void problem_done(const IpParams& p, int sb, int l) {
+    if constexpr (ASYNC) xfence(p.A.flags);             // release this group's d / dz / status stores
+    if (l == 0) {
+        const int old = atomicAdd(&p.Q.done_count[sb], 1);
+        if constexpr (ASYNC) {
+            if (old == p.H - 1) {
+                xfence(p.A.flags);
+                const int b = sb / p.slots;
+                if (atomicSub(&p.A.evals_left[b], 1) == 1) {
+                    xfence(p.A.flags);
+                    aq_push(p.A.rq_items, p.A.rq_tail, b);
+                }
+            }
+        }
+    }
+}
+
+template <class M, bool ASYNC>
 __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S, const double* tab, int prob, int l) {
     constexpr int NX = M::NX, NY = M::NY, NTH = M::NTH, NTHS = M::NTHS, ND = M::ND, G = M::G;
     constexpr int NC = M::NC, NB = M::NB;
@@ -298,9 +319,9 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
         const double v = tab[L.oRthRst + c * G + l];
         double xs;
         const double t = S.schur_solve(u, v, xs);
-        if (vx) dzo[c * ND + l] = -xs;
+        if (vx) xst<ASYNC>(dzo + c * ND + l, -xs);
         if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) {
-            if (l < NC + NB) dzo[c * ND + NX + l] = t;   // -(S.y) = +temp
+            if (l < NC + NB) xst<ASYNC>(dzo + c * ND + NX + l, t);   // -(S.y) = +temp
         }
     };
     // two independent right-hand sides per trip: their triangular-solve chains interleave
@@ -311,87 +332,80 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
         column(c + 1);
     }
     if (c < NTHS) column(c);
-    if (l == 0) atomicAdd(&p.Q.done_count[prob / p.H], 1);
+    problem_done<ASYNC>(p, prob / p.H, l);
 }
 
 // ----------------------------------------------------------------------------------------
-// Queue kernel: persistent workgroups, `wpk` per reference knot.  Every 16-lane group pulls
-// problems of its knot until the queue is empty; all groups of a wave run the same iteration
-// body, a group whose solve ends (converged / failed / parked) finalises it and pulls the next
-// problem while its neighbours keep iterating.  The sensitivities of converged problems are
-// kept in a per-group backlog and computed when the group has no interior-point work left.
-// ----------------------------------------------------------------------------------------
-template <class M>
-__global__ __launch_bounds__(256, 2) void ip_queue_kernel(IpParams p) {
+// Remaining-work proportional knot pick (WG-uniform result in *s_knot, -1 = no work anywhere):
+// workgroup b takes the knot holding quantile b/gridDim of the problems not yet pulled, so the
+// workgroups spread over the knots like the work does - initially and after every hop.
+constexpr int PICK_MAXK = 256;
+__device__ __forceinline__ int pick_knot(const IpParams& p, int* s_rem, int* s_total, int* s_knot, int tid, int wg, int nwg) {
+    const int K = p.Q.K, par = p.Q.par;
+    if (tid == 0) *s_total = 0;
+    __syncthreads();
+    {
+        int part = 0;
+        for (int k = tid; k < K; k += (int)blockDim.x) {
+            int rem = aload(p.Q.count + par * K + k) - aload(p.Q.head + k);
+            rem = rem > 0 ? rem : 0;
+            if (k < PICK_MAXK) s_rem[k] = rem;
+            part += rem;
+        }
+        if (part > 0) atomicAdd(s_total, part);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int total = *s_total;
+        int pick = -1;
+        if (total > 0) {
+            const long long target = ((long long)wg * total) / (long long)nwg;
+            long long acc = 0;
+            for (int k = 0; k < K; ++k) {
+                const int rem = k < PICK_MAXK ? s_rem[k] : max(0, aload(p.Q.count + par * K + k) - aload(p.Q.head + k));
+                if (rem > 0) { pick = k; acc += rem; if (acc > target) break; }
+            }
+        }
+        *s_knot = pick;
+    }
+    __syncthreads();
+    return *s_knot;
+}
+
+// Serve one knot: stage its table, then every lane group pulls problems of the knot until the queue
+// is empty (ASYNC: momentarily empty).  All groups of a wave run the same iteration body, a group
+// whose solve ends (converged / failed / parked) finalises it and pulls the next problem while its
+// neighbours keep iterating.  Converged problems wait in a per-group backlog for a wave-uniform
+// sensitivity trip.  Must be entered by the whole workgroup; ends with every wave drained.
+template <class M, bool ASYNC>
+__device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int knot, int tid) {
     constexpr int NX = M::NX, NY = M::NY, NTH = M::NTH, ND = M::ND, G = M::G;
     constexpr int NC = M::NC, NB = M::NB;
     constexpr LinLayout L(NX, NY, NTH, G);
     constexpr int PS = 2 * NX + 4 * NY + 4;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     double* tab = smem;
-    const int tid = (int)threadIdx.x;
     const int K = p.Q.K, cap = p.Q.cap, par = p.Q.par;
-    constexpr int MAXK = 256;
-    __shared__ int s_knot, s_total, s_rem[MAXK];
-
     const int grp = tid / G;
     const int l = tid % G;
     double* Rst = smem + L.size + (size_t)grp * M::LDS_GROUP;   // [NY][G+1]
     double* dth = Rst + NY * M::RST_LD;                          // [NTH]
     int* backlog = reinterpret_cast<int*>(dth + NTH);            // [SENS_MAX] converged, sensitivities pending
     int nback = 0;
-
-    IpSolver<M> S;
     const bool vx = l < NX, vy = l < NY;
     const cimpc_ip_opts o = p.o;
 
-    bool have = false, exhausted = false, stalled = false;
-    int prob = 0, iters = 0, done_here = 0;
-    double reg = 0.0, r_vio = 0.0, k_vio = 0.0, qinit = 0.0;
-
-    // Knot hopping: the workgroup serves one knot (its table staged in LDS) until that queue is
-    // empty, then moves to another knot that still has work.  The pick is proportional to the
-    // remaining work: workgroup b takes the knot holding quantile b/gridDim of the problems not
-    // yet pulled, so the workgroups spread over the knots like the work does - initially and after
-    // every hop - whatever the windows of the rollouts look like.
-    while (true) {
-    __syncthreads();            // every wave is done with the staged table and with s_knot
-    if (tid == 0) s_total = 0;
-    __syncthreads();
-    {   // remaining work per knot: parallel loads, LDS copy
-        int part = 0;
-        for (int k = tid; k < K; k += (int)blockDim.x) {
-            int rem = p.Q.count[par * K + k] - __atomic_load_n(p.Q.head + k, __ATOMIC_RELAXED);
-            rem = rem > 0 ? rem : 0;
-            if (k < MAXK) s_rem[k] = rem;
-            part += rem;
-        }
-        if (part > 0) atomicAdd(&s_total, part);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const int total = s_total;
-        int pick = -1;
-        if (total > 0) {
-            const long long target = ((long long)blockIdx.x * total) / (long long)gridDim.x;
-            long long acc = 0;
-            for (int k = 0; k < K; ++k) {
-                const int rem = k < MAXK ? s_rem[k] : max(0, p.Q.count[par * K + k] - __atomic_load_n(p.Q.head + k, __ATOMIC_RELAXED));
-                if (rem > 0) { pick = k; acc += rem; if (acc > target) break; }
-            }
-        }
-        s_knot = pick;
-    }
-    __syncthreads();
-    const int knot = s_knot;
-    if (knot < 0) break;
-    const int n = p.Q.count[par * K + knot];
+    const int n = ASYNC ? 1 : p.Q.count[par * K + knot];
     stage_table<M>(tab, p.tab, knot, tid);
     __syncthreads();
     const int* items = p.Q.items + ((size_t)par * K + knot) * cap;
     int* head = p.Q.head + knot;
+    [[maybe_unused]] const int* tailp = p.Q.count + par * K + knot;
+    IpSolver<M> S;
     S.bind(tab, Rst, l);        // caches the per-lane constants of this knot's table
-    have = false; exhausted = false;
+    bool have = false, exhausted = false, stalled = false;
+    int prob = 0, iters = 0, done_here = 0;
+    [[maybe_unused]] int idle_trips = 0;
+    double reg = 0.0, r_vio = 0.0, k_vio = 0.0, qinit = 0.0;
 
     while (true) {
         // ---- 1. end of a solve? ---------------------------------------------------------------
@@ -416,12 +430,12 @@ __global__ __launch_bounds__(256, 2) void ip_queue_kernel(IpParams p) {
                         atomicAdd(p.pending_count, 1);
                     }
                 } else {
-                    if (l == 0) { p.status[pi] = code; p.iters[pi] = iters; }
+                    if (l == 0) { xst<ASYNC>(p.status + pi, code); xst<ASYNC>(p.iters + pi, iters); }
                     // d = z[1:nd] - [q_{i+2}; gamma_i; b_i]  (implicit_dynamics.jl:180-190)
-                    if (vx) p.d[pi * ND + l] = S.x - qinit;
+                    if (vx) xst<ASYNC>(p.d + pi * ND + l, S.x - qinit);
                     if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) {
-                        if (l < NC) p.d[pi * ND + NX + l] = S.y1 - p.gam[pi * NC + l];
-                        else if (l < NC + NB) p.d[pi * ND + NX + l] = S.y1 - p.bfr[pi * NB + (l - NC)];
+                        if (l < NC) xst<ASYNC>(p.d + pi * ND + NX + l, S.y1 - xld<ASYNC>(p.gam + pi * NC + l));
+                        else if (l < NC + NB) xst<ASYNC>(p.d + pi * ND + NX + l, S.y1 - xld<ASYNC>(p.bfr + pi * NB + (l - NC)));
                     }
                     if (p.zout != nullptr) {
                         double* zo = p.zout + pi * M::NZ;
@@ -433,24 +447,32 @@ __global__ __launch_bounds__(256, 2) void ip_queue_kernel(IpParams p) {
                         if (vy) { ps[NX + l] = S.y1; ps[NX + NY + l] = S.y2; }
                         if (l == 0) { ps[PS - 2] = reg; backlog[nback] = prob; }
                         ++nback;
-                    } else if (l == 0) {     // failed: the slot keeps its previous sensitivities
-                        atomicAdd(&p.Q.done_count[sb], 1);
+                    } else {                 // failed: the slot keeps its previous sensitivities
+                        problem_done<ASYNC>(p, sb, l);
                     }
                 }
                 have = false;
             }
         }
         // ---- 2. pull the next problem of this knot -----------------------------------------
-        if (!have && !exhausted) {
-            int idx = 0;
-            if (l == 0) idx = atomicAdd(head, 1);
-            idx = group_bcast0<G>(idx);
+        // (ASYNC: the queue is live - an idle group looks again every few trips while its wave is busy)
+        if (!have && (!exhausted || (ASYNC && !(p.A.flags & 2) && (++idle_trips & 3) == 0))) {
+            int idx = 0, item = 0;
+            if constexpr (ASYNC) {       // live queue: claim only what has been published
+                if (l == 0) item = aq_pop(const_cast<int*>(items), head, tailp);
+                item = group_bcast0<G>(item);
+                idx = item < 0 ? n : 0;
+                if (item >= 0) xfence(p.A.flags);      // acquire the candidate trajectory of the producer
+            } else {
+                if (l == 0) idx = atomicAdd(head, 1);
+                idx = group_bcast0<G>(idx);
+            }
             if (idx < n) {
-                prob = items[idx];
+                prob = ASYNC ? item : items[idx];
                 const int sb = prob / p.H, i = prob - sb * p.H;
                 const size_t pi = (size_t)prob;
                 const double* th = p.theta + pi * NTH;
-                for (int k = l; k < NTH; k += G) dth[k] = th[k] - tab[L.oTh0 + k];
+                for (int k = l; k < NTH; k += G) dth[k] = xld<ASYNC>(th + k) - tab[L.oTh0 + k];
                 wave_lds_fence();
                 {   // rthdyn*(th-th0), rthrst*(th-th0): constant per solve
                     double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
@@ -472,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void ip_queue_kernel(IpParams p) {
                 }
                 S.altl = (p.alt != nullptr && l < NC) ? p.alt[(size_t)(sb / p.slots) * NC + l] : 0.0;
                 const double* qrow = p.q + ((size_t)sb * (p.H + 2) + (i + 2)) * M::NQ;
-                qinit = vx ? qrow[l] : 0.0;
+                qinit = vx ? xld<ASYNC>(qrow + l) : 0.0;
                 const double* ps = p.pstate + pi * PS;
                 if (p.pflag[pi] == 1) {      // resume a parked solve
                     S.x = vx ? ps[l] : 0.0;
@@ -507,7 +529,10 @@ __global__ __launch_bounds__(256, 2) void ip_queue_kernel(IpParams p) {
         //         interior-point work left, or when a backlog is full.
         const bool any_ip = __any(have ? 1 : 0);
         if (!any_ip && !__any(nback > 0 ? 1 : 0)) break;
-        const bool sens_trip = !any_ip || __all(nback > 0 ? 1 : 0) || __any(nback >= M::SENS_MAX ? 1 : 0);
+        // (ASYNC: a finished solve must not wait for its neighbours' work to dry up - the rollout's next
+        //  stage hangs on it; a group that has a backlog and nothing else to do gets its trip at once)
+        const bool sens_trip = !any_ip || __all(nback > 0 ? 1 : 0) || __any(nback >= M::SENS_MAX ? 1 : 0) ||
+                               (ASYNC && __any((nback > 0 && !have) ? 1 : 0));
         if (!sens_trip) {
             if (have && !(r_vio < o.r_tol && k_vio < o.kappa_tol) && iters < o.max_iter && done_here < p.iter_cap) {
                 ++done_here;
@@ -520,11 +545,27 @@ __global__ __launch_bounds__(256, 2) void ip_queue_kernel(IpParams p) {
             --nback;
             wave_lds_fence();
             const int pr = group_bcast0<G>((l == 0) ? backlog[nback] : 0);
-            sensitivities<M>(p, S, tab, pr, l);
+            sensitivities<M, ASYNC>(p, S, tab, pr, l);
             S.x = sx; S.y1 = sy1; S.y2 = sy2; S.rdyn = sd; S.rrst = sr; S.rbil = sb_; S.tthdyn = st; S.tthrst = su; S.altl = sa;
         }
     }
-    }   // hop
+}
+
+// ----------------------------------------------------------------------------------------
+// Queue kernel of the lock-step rounds: persistent workgroups; each serves one knot at a time and
+// hops to another knot that still has work when its queue is empty.
+// ----------------------------------------------------------------------------------------
+template <class M>
+__global__ __launch_bounds__(256, 2) void ip_queue_kernel(IpParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int s_knot, s_total, s_rem[PICK_MAXK];
+    const int tid = (int)threadIdx.x;
+    while (true) {
+        __syncthreads();            // every wave is done with the staged table
+        const int knot = pick_knot(p, s_rem, &s_total, &s_knot, tid, (int)blockIdx.x, (int)gridDim.x);
+        if (knot < 0) break;
+        serve_knot<M, false>(p, smem, knot, tid);
+    }
 }
 
 // ----------------------------------------------------------------------------------------

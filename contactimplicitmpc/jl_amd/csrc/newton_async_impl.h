@@ -1,0 +1,160 @@
+// Single-launch asynchronous Newton solve.
+//
+// The lock-step driver (cimpc_host.cpp) advances ALL rollouts of a batch round by round:
+// {sweep || KKT} -> residual/decision, one launch each, ~30-50 rounds per MPC step, every round
+// paying the tail of its slowest interior-point solve plus launch gaps.  Here the whole
+// newton_solve! (/root/reference/src/controller/newton.jl:169-288) of the batch is ONE persistent
+// kernel: workgroups loop over three kinds of work,
+//     KKT job        (rollout)   one wavefront, kkt_body            -> pushes the alpha = 1 evaluation
+//     residual job   (rollout)   whole workgroup, resid_decide_body -> pushes line-search evaluations,
+//                                                                     a KKT job, or ends the rollout
+//     knot service   (knot)      serve_knot: interior-point solves + sensitivities; the group that
+//                                completes a rollout's outstanding evaluations pushes its residual job
+// so every rollout advances along its own dependency chain and the GPU is kept busy by the other
+// rollouts.  The results per rollout are those of the lock-step rounds (same bodies, same arithmetic;
+// no solve is ever parked).  Hand-offs: release fence -> queue push / counter, claim -> acquire fence
+// (agent scope; the queues are in device memory).
+//
+// Deadlock freedom: no unit ever waits for a specific other unit - only for queue entries whose
+// producer has already reserved the slot (aq_pop) - and any workgroup can execute any job, so the
+// solve progresses with however many workgroups the hardware keeps resident.
+#pragma once
+#include <cstddef>
+#include "ip_kernel_impl.h"
+#include "newton_impl.h"
+
+namespace cimpc {
+
+struct AsyncArgs {     // the kernel's only argument
+    IpParams p;
+    NewtonDev S;
+};
+
+// The two horizon-level jobs are compiled as real functions: their register allocation stays out of
+// the interior-point loop (which needs all 256 VGPRs of the 2-waves-per-SIMD budget for itself).  They
+// read the solver state straight from the kernel-argument segment (scalar loads), exactly like a
+// kernel of their own would.
+// (the kernel passes the address of its argument segment; the callee makes it wave-uniform again so
+// that the fields are fetched with scalar loads from the constant address space)
+__device__ __forceinline__ NewtonDev uniform_state(unsigned long long v) {
+    NewtonDev S;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    const unsigned long long u = (((unsigned long long)hi << 32) | lo) + offsetof(AsyncArgs, S);
+    __builtin_memcpy(&S, (const __attribute__((address_space(4))) NewtonDev*)u, sizeof(NewtonDev));
+#else
+    (void)v;
+#endif
+    return S;
+}
+template <int NQ, int NU>
+__device__ __noinline__ void async_kkt_job(unsigned long long ka, int b, double* smem, int lane) {
+    const NewtonDev S = uniform_state(ka);
+    const KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 2};
+    kkt_body<NQ, NU, WaveSync>(S, K, b, smem, lane);
+}
+template <int NQ, int NU>
+__device__ __noinline__ void async_resid_job(unsigned long long ka, int b, double* red, double* rc, int* sh) {
+    const NewtonDev S = uniform_state(ka);
+    resid_decide_body<NQ, NU, false, true>(S, b, red, rc, sh);
+}
+
+template <class M>
+__global__ __launch_bounds__(256, 2) void newton_async_kernel(AsyncArgs args) {
+    const IpParams& p = args.p;
+    const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    static_assert(M::MODE == CIMPC_MODE_CONFIGURATION, "the KKT stage implements :configuration");
+    constexpr int NQ = M::NQ, NU = M::NU;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int s_knot, s_total, s_rem[PICK_MAXK], s_job[2];
+    __shared__ double red[256];
+    __shared__ double rc[CS];
+    __shared__ int sh[4];
+    const int tid = (int)threadIdx.x;
+    const AsyncQ& A = p.A;
+    const bool service = (int)blockIdx.x < A.n_service;        // these only take residual / KKT jobs
+    const int nwork = max(1, (int)gridDim.x - A.n_service), wg = max(0, (int)blockIdx.x - A.n_service);
+    unsigned trip = 0;
+    long long tk = wall_clock64();
+    auto account = [&](int slot) {          // busy time per kind of work, 100 MHz ticks (diagnostics)
+        if (tid == 0 && A.dbg != nullptr) {
+            const long long tn = wall_clock64();
+            atomicAdd((unsigned long long*)A.dbg + slot, (unsigned long long)(tn - tk));
+            atomicAdd((unsigned long long*)A.dbg + 8 + slot, 1ull);
+            tk = tn;
+        }
+    };
+    while (true) {
+        __syncthreads();
+        if (tid == 0) {
+            int type = 0, job = -1;
+            // the abort flag lives in host memory (one PCIe read): looked at now and then only
+            if ((trip++ & 31u) == 31u && *A.abort_flag != 0) {
+                type = 3;
+            } else if ((job = aq_pop(A.kq_items, A.kq_head, A.kq_tail)) >= 0) {
+                type = 1;       // KKT first: it heads the longest chain of a rollout
+            } else if ((job = aq_pop(A.rq_items, A.rq_head, A.rq_tail)) >= 0) {
+                type = 2;
+            }
+            s_job[0] = type; s_job[1] = job;
+        }
+        __syncthreads();
+        const int type = s_job[0], job = s_job[1];
+        if (type == 3) break;
+        if (type == 1) {
+            xfence(A.flags);                             // acquire res / traj / dz of the rollout
+            account(0);
+            if (tid < 64) async_kkt_job<NQ, NU>(ka, job, smem, tid);
+            __syncthreads();
+            account(1);
+            continue;
+        }
+        if (type == 2) {
+            xfence(A.flags);                             // acquire d / dz / status of the evaluations
+            account(0);
+            async_resid_job<NQ, NU>(ka, job, red, rc, sh);
+            __syncthreads();
+            account(2);
+            continue;
+        }
+        if (!service) {
+            const int knot = pick_knot(p, s_rem, &s_total, &s_knot, tid, wg, nwork);
+            if (knot >= 0) {
+                account(0);
+                serve_knot<M, true>(p, smem, knot, tid);
+                __syncthreads();
+                account(3);
+                continue;
+            }
+        }
+        if (tid == 0) s_job[0] = (aload(A.n_done) >= A.B) || ((trip & 7u) == 0 && *A.abort_flag != 0);
+        __syncthreads();
+        if (s_job[0]) break;
+        for (int k = 0; k < A.idle_sleep; ++k) __builtin_amdgcn_s_sleep(64);    // back off: idle pollers must not crowd the queue counters
+    }
+}
+
+template <class M>
+int launch_async_model(const IpParams& p, const NewtonDev& S, int waves, int grid, hipStream_t s) {
+    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G);
+    if (waves != 1 && waves != 2 && waves != 4) return CIMPC_ERR_INVALID;
+    const int ppw = 64 / M::G;
+    const size_t lds_ip = (size_t)(L.size + waves * ppw * M::LDS_GROUP) * sizeof(double);
+    const size_t lds_kkt = (size_t)(KKT_MFMA_TILES * TSZ + 208) * sizeof(double);
+    const size_t lds = lds_ip > lds_kkt ? lds_ip : lds_kkt;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)newton_async_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return CIMPC_ERR_HIP;
+    }
+    AsyncArgs args{p, S};
+    hipLaunchKernelGGL((newton_async_kernel<M>), dim3(grid), dim3(64 * waves), lds, s, args);
+    return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+}
+
+#define CIMPC_DEFINE_ASYNC_MODEL(name, q, u, w, c, b)                                                   \
+    int async_launch_##name(const IpParams& p, const NewtonDev& S, int waves, int grid, hipStream_t s) { \
+        return launch_async_model<Model<q, u, w, c, b, 0>>(p, S, waves, grid, s);                       \
+    }
+
+}  // namespace cimpc

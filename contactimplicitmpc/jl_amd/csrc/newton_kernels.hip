@@ -10,56 +10,9 @@
 // The Newton iteration of every rollout advances in lock-step rounds driven by the host
 // (cimpc_host.cpp); each rollout carries its own stage / alpha / beta, so rollouts that
 // backtrack and rollouts that start their next Newton iteration share the same launches.
-#include "lane_group.h"
-#include "newton_state.h"
+#include "newton_impl.h"
 
 namespace cimpc {
-
-__device__ __forceinline__ void theta_update(const NewtonDev& S, const TrajDev& T, int b, int i,
-                                             int tid, int nthreads) {
-    // update_theta!(traj, i) (trajectory.jl:67-82): th_i = [q_i; q_{i+1}; u_i; w_i; mu; h]
-    const cimpc_dims& m = S.dm;
-    double* th = T.th + ((size_t)b * m.H + i) * S.nth;
-    const double* q = T.q + ((size_t)b * (m.H + 2) + i) * m.nq;
-    const double* u = T.u + ((size_t)b * m.H + i) * m.nu;
-    const double* w = T.w + ((size_t)b * m.H + i) * m.nw;
-    for (int k = tid; k < 2 * m.nq; k += nthreads) th[k] = q[k];   // q_i, q_{i+1} contiguous
-    for (int k = tid; k < m.nu; k += nthreads) th[2 * m.nq + k] = u[k];
-    for (int k = tid; k < m.nw; k += nthreads) th[2 * m.nq + m.nu + k] = w[k];
-}
-
-__device__ __forceinline__ void copy_n(double* dst, const double* src, int n, int tid, int nt) {
-    for (int k = tid; k < n; k += nt) dst[k] = src[k];
-}
-
-// Candidate slots.  The reference's backtracking line search (newton.jl:223-269) evaluates
-// alpha = 1, 1/2, ..., 1/64 one after the other, each evaluation being a full implicit_dynamics!
-// sweep.  Here a rollout owns CS = 4 evaluation slots and the SAME sequence is evaluated
-// speculatively in at most three lock-step rounds:
-//     round A: alpha = 1                      (slot 0)
-//     round B: alpha = 1/2, 1/4               (slots 0-1)
-//     round C: alpha = 1/8, 1/16, 1/32, 1/64  (slots 0-3)
-// and the first alpha (in the reference's order) that passes the Armijo-type test is taken, so the
-// accepted step, residual and implicit-dynamics data are exactly those the sequential loop would
-// have produced.  Every "evaluation" array (candidate trajectory, nu_cand, d, dz, status,
-// res_cand, ...) is indexed by slot sb = b*CS + c; cur_slot[b] names the slot whose d / dz are the
-// current im_traj of rollout b.
-__device__ __forceinline__ double ls_alpha(int iter) { return ldexp(1.0, -iter); }
-
-// Request the evaluation (implicit_dynamics! sweep) of slot sb: one queue entry per horizon step,
-// bucketed by the reference knot of that step.
-__device__ __forceinline__ void enqueue_eval(const NewtonDev& S, size_t sb, int b, int par, int tid, int nt) {
-    const int H = S.dm.H, K = S.WQ.K;
-    for (int k = tid; k < H; k += nt) {
-        const int t = S.WQ.window[(size_t)b * (H + 2) + k];
-        const int pos = atomicAdd(&S.WQ.count[par * K + t], 1);
-        S.WQ.items[((size_t)par * K + t) * S.WQ.cap + pos] = (int)(sb * H + k);
-    }
-    if (tid == 0) {
-        S.WQ.done_count[sb] = 0;
-        S.need_sweep[sb] = 1;
-    }
-}
 
 __global__ __launch_bounds__(256) void reset_kernel(NewtonDev S, const double* q0,
                                                     const double* q1, int warm) {
@@ -113,1071 +66,8 @@ __global__ __launch_bounds__(256) void reset_kernel(NewtonDev S, const double* q
     }
     for (int k = tid; k < CS * H; k += nt) S.pflag[sb0 * H + k] = 0;
     __syncthreads();
-    enqueue_eval(S, sb0, b, S.WQ.par, tid, nt);
-}
-
-// x_dst = traj - alpha*Delta for q_{t+2}, u_t, nu_t (+ gamma, b in cf mode), then update_theta!.
-// dst arrays are indexed by `di` (a rollout index for traj, a slot index for candidates).
-__device__ void apply_step(const NewtonDev& S, const TrajDev& dst, double* nu_dst_base, size_t di, int b,
-                           double alpha, int tid, int nt) {
-    const cimpc_dims& m = S.dm;
-    const int H = m.H, nq = m.nq, nu = m.nu, nr = S.nr, nd = S.nd;
-    const double* D = S.delta + (size_t)b * S.N;
-    const bool cf = m.mode == CIMPC_MODE_CONFIGURATIONFORCE;
-    const int oq_in_block = cf ? nu + m.nc + m.nb : nu;
-    for (int k = tid; k < H * nq; k += nt) {
-        const int t = k / nq, c = k - t * nq;
-        dst.q[(di * (H + 2) + t + 2) * nq + c] =
-            S.traj.q[((size_t)b * (H + 2) + t + 2) * nq + c] - alpha * D[t * nr + oq_in_block + c];
-    }
-    for (int k = tid; k < 2 * nq; k += nt)       // q_1, q_2 are fixed by (q0, q1)
-        dst.q[di * (H + 2) * nq + k] = S.traj.q[(size_t)b * (H + 2) * nq + k];
-    for (int k = tid; k < H * nu; k += nt) {
-        const int t = k / nu, c = k - t * nu;
-        dst.u[(di * H + t) * nu + c] = S.traj.u[((size_t)b * H + t) * nu + c] - alpha * D[t * nr + c];
-    }
-    if (cf) {
-        for (int k = tid; k < H * m.nc; k += nt) {
-            const int t = k / m.nc, c = k - t * m.nc;
-            dst.g[(di * H + t) * m.nc + c] = S.traj.g[((size_t)b * H + t) * m.nc + c] - alpha * D[t * nr + nu + c];
-        }
-        for (int k = tid; k < H * m.nb; k += nt) {
-            const int t = k / m.nb, c = k - t * m.nb;
-            dst.b[(di * H + t) * m.nb + c] = S.traj.b[((size_t)b * H + t) * m.nb + c] - alpha * D[t * nr + nu + m.nc + c];
-        }
-    }
-    for (int k = tid; k < H * nd; k += nt)
-        nu_dst_base[di * H * nd + k] = S.nu[(size_t)b * H * nd + k] - alpha * D[H * nr + k];
-    __syncthreads();
-    {   // update_theta!(dst): th_t = [q_t; q_{t+1}; u_t; w_t; mu; h]; mu, h come from traj
-        const int nth = S.nth, nw = m.nw;
-        for (int k = tid; k < H * nth; k += nt) {
-            const int t = k / nth, c = k - t * nth;
-            double v;
-            if (c < 2 * nq) v = dst.q[(di * (H + 2) + t) * nq + c];
-            else if (c < 2 * nq + nu) v = dst.u[(di * H + t) * nu + (c - 2 * nq)];
-            else if (c < 2 * nq + nu + nw) v = S.traj.w[((size_t)b * H + t) * nw + (c - 2 * nq - nu)];
-            else v = S.traj.th[((size_t)b * H + t) * nth + c];
-            dst.th[(di * H + t) * nth + c] = v;
-        }
-    }
-    __syncthreads();
-}
-
-// residual! on evaluation slot sb (candidate trajectory, nu_cand, d, dz of that slot); returns |r|_1
-template <int NQ, int NU, bool CF>
-__device__ double slot_residual(const NewtonDev& S, size_t sb, int b, double* red, int tid, int nt) {
-    const cimpc_dims& m = S.dm;
-    constexpr int nq = NQ, nu = NU;
-    constexpr bool cf = CF;
-    const int H = m.H, nc = m.nc, nb = m.nb, nr = S.nr;
-    const int nd = cf ? nq + nc + nb : nq;       // compile-time in :configuration mode
-    constexpr int nths = 2 * NQ + NU;
-    const int oq_in_block = cf ? nu + nc + nb : nu;
-    double* r = S.res_cand + sb * S.N;
-    const double* nuc = S.nu_cand + sb * H * nd;
-    const double* dzb = S.dz + sb * H * nths * nd;
-    double part = 0.0;
-    for (int e = tid; e < S.N; e += nt) {
-        double v = 0.0;
-        if (e >= H * nr) {                       // rd[i] = d_i
-            v = S.d[sb * H * nd + (e - H * nr)];
-        } else {
-            const int i = e / nr, c = e - i * nr;
-            if (c < nu) {                         // u1[i]: R_i (u - u_ref) + du1_i^T nu_i
-                const double* Rm = S.R + (size_t)i * nu * nu;
-                const double* uu = S.cand.u + (sb * H + i) * nu;
-                const double* ur = S.ref.u + ((size_t)b * H + i) * nu;
-#pragma unroll
-                for (int k = 0; k < nu; ++k) v = fma(Rm[c + k * nu], uu[k] - ur[k], v);
-                const double* A0 = dzb + ((size_t)i * nths + 2 * nq + c) * nd;   // column c of du1_i
-                double s = 0.0;
-#pragma unroll
-                for (int k = 0; k < nq; ++k) s = fma(A0[k], nuc[i * nd + k], s);
-                for (int k = nq; k < nd; ++k) s = fma(A0[k], nuc[i * nd + k], s);
-                v += s;
-            } else if (c >= oq_in_block) {        // q2[i]
-                const int cq = c - oq_in_block;
-                const double* Qm = S.Q + (size_t)i * nq * nq;
-                const double* qq = S.cand.q + (sb * (H + 2) + i + 2) * nq;
-                const double* qr = S.ref.q + ((size_t)b * (H + 2) + i + 2) * nq;
-#pragma unroll
-                for (int k = 0; k < nq; ++k) v = fma(Qm[cq + k * nq], qq[k] - qr[k], v);
-                v -= nuc[i * nd + cq];                                      // rI[i] -= nu_i
-                if (i + 1 < H) {                                            // dq1_{i+1}^T nu_{i+1}
-                    const double* A1 = dzb + ((size_t)(i + 1) * nths + nq + cq) * nd;
-                    double s = 0.0;
-#pragma unroll
-                    for (int k = 0; k < nq; ++k) s = fma(A1[k], nuc[(i + 1) * nd + k], s);
-                    for (int k = nq; k < nd; ++k) s = fma(A1[k], nuc[(i + 1) * nd + k], s);
-                    v += s;
-                }
-                if (i + 2 < H) {                                            // dq0_{i+2}^T nu_{i+2}
-                    const double* A2 = dzb + ((size_t)(i + 2) * nths + cq) * nd;
-                    double s = 0.0;
-#pragma unroll
-                    for (int k = 0; k < nq; ++k) s = fma(A2[k], nuc[(i + 2) * nd + k], s);
-                    for (int k = nq; k < nd; ++k) s = fma(A2[k], nuc[(i + 2) * nd + k], s);
-                    v += s;
-                }
-            } else if (c < nu + nc) {             // gamma1[i] (cf)
-                const int cg = c - nu;
-                const double* Cm = S.Cg + (size_t)i * nc * nc;
-                const double* gg = S.cand.g + (sb * H + i) * nc;
-                const double* gr = S.ref.g + ((size_t)b * H + i) * nc;
-                for (int k = 0; k < nc; ++k) v = fma(Cm[cg + k * nc], gg[k] - gr[k], v);
-                v -= nuc[i * nd + nq + cg];
-            } else {                              // b1[i] (cf)
-                const int cb = c - nu - nc;
-                const double* Cm = S.Cb + (size_t)i * nb * nb;
-                const double* bb = S.cand.b + (sb * H + i) * nb;
-                const double* br = S.ref.b + ((size_t)b * H + i) * nb;
-                for (int k = 0; k < nb; ++k) v = fma(Cm[cb + k * nb], bb[k] - br[k], v);
-                v -= nuc[i * nd + nq + nc + cb];
-            }
-        }
-        r[e] = v;
-        part += fabs(v);
-    }
-    red[tid] = part;
-    __syncthreads();
-    for (int s = nt / 2; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
-        __syncthreads();
-    }
-    const double out = red[0];
-    __syncthreads();
-    return out;
-}
-
-template <int NQ, int NU, bool CF>
-__device__ __forceinline__ void resid_decide_body(const NewtonDev& S, double* red, double* rc, int* sh) {
-    const cimpc_dims& m = S.dm;
-    const int b = blockIdx.x + S.b0, tid = threadIdx.x, nt = blockDim.x;
-    const int H = m.H;
-    const size_t sb0 = (size_t)b * CS;
-    if (blockIdx.x == 0) {   // the queue of this round has been consumed: recycle it
-        const int K = S.WQ.K, par = S.WQ.par;
-        for (int k = tid; k < K; k += nt) { S.WQ.count[par * K + k] = 0; S.WQ.head[k] = 0; S.WQ.s_count[k] = 0; S.WQ.s_head[k] = 0; }
-        if (tid < 8) S.counters_next[tid] = 0;      // counter block of the next round
-    }
-    const int stage = S.stage[b];
-    if (stage == STAGE_DONE || stage == STAGE_KKT) return;
-    if (S.need_sweep[sb0] == 0) return;          // nothing was evaluated for this rollout
-    const int ncand = (stage == STAGE_LS1) ? 2 : (stage == STAGE_LS2) ? 4 : 1;
-    {   // an interior-point solve of this evaluation is still parked: wait for the next round
-        int pend = 0;
-        if (tid < ncand) pend = (S.WQ.done_count[sb0 + tid] < H);
-        if (__syncthreads_or(pend)) {
-            if (tid == 0) atomicAdd(&S.counters[0], 1);
-            return;
-        }
-    }
-    int& s_act = sh[0]; int& s_slot = sh[1]; int& s_iter = sh[2];
-    for (int c = 0; c < ncand; ++c) {
-        const double v = slot_residual<NQ, NU, CF>(S, sb0 + c, b, red, tid, nt);
-        if (tid == 0) { rc[c] = v; S.r_cand[sb0 + c] = v; }
-    }
-    __syncthreads();
-    // ---- decision (newton.jl:198-280) ------------------------------------------------------
-    if (tid == 0) {
-        int act = 2, slot = 0, iter = 0;   // act: 0 accept initial evaluation, 1 accept step, 2 more candidates
-        if (stage == STAGE_INIT) {
-            act = 0;
-        } else {
-            const double rn2 = S.r_norm[b] * S.r_norm[b];
-            const int it0 = (stage == STAGE_LS0) ? 0 : (stage == STAGE_LS1) ? 1 : 3;
-            for (int c = 0; c < ncand; ++c) {
-                const double a = ls_alpha(it0 + c);
-                if (!(rc[c] * rc[c] >= (1.0 - 0.001 * a) * rn2)) { act = 1; slot = c; iter = it0 + c; break; }
-            }
-            if (act == 2 && stage == STAGE_LS2) {   // iter = 7 > 6: break out, halved alpha, last evaluation
-                act = 1; slot = 3; iter = 7;
-            }
-        }
-        s_act = act; s_slot = slot; s_iter = iter;
-    }
-    __syncthreads();
-    {   // statistics (parallel reduction).  Global counters: every evaluation that ran (speculative
-        // ones included).  Per-rollout counters: only the evaluations the reference's sequential line
-        // search would have performed (candidates up to and including the accepted one).
-        const int nref = (s_act == 1 && s_iter <= 6) ? s_slot + 1 : ncand;
-        int its = 0, fails = 0, its_ref = 0, fails_ref = 0;
-        for (int k = tid; k < ncand * H; k += nt) {
-            const int it = S.ip_iters[sb0 * H + k], fl = (S.ip_status[sb0 * H + k] == 0);
-            its += it; fails += fl;
-            if (k < nref * H) { its_ref += it; fails_ref += fl; }
-        }
-        // pack four small counters into the double reduction buffer (exact up to 2^53)
-        red[tid] = (double)its; __syncthreads();
-        for (int st = nt / 2; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
-        const double t_its = red[0]; __syncthreads();
-        red[tid] = (double)fails + 4096.0 * (double)fails_ref + 16777216.0 * (double)its_ref; __syncthreads();
-        for (int st = nt / 2; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
-        if (tid == 0) {
-            const long long packed = (long long)red[0];
-            const long long t_fails = packed & 4095, t_fails_ref = (packed >> 12) & 4095, t_its_ref = packed >> 24;
-            S.ro_sweeps[b] += nref;
-            S.ro_ip_iters[b] += (int)t_its_ref;
-            S.ro_ip_fail[b] += (int)t_fails_ref;
-            atomicAdd((unsigned long long*)&S.stats[0], (unsigned long long)ncand);
-            atomicAdd((unsigned long long*)&S.stats[1], (unsigned long long)(ncand * H));
-            atomicAdd((unsigned long long*)&S.stats[2], (unsigned long long)t_its);
-            atomicAdd((unsigned long long*)&S.stats[3], (unsigned long long)t_fails);
-        }
-    }
-    __syncthreads();
-    const int act = s_act, slot = s_slot, iter = s_iter;
-    if (act == 2) {                       // next batch of candidates: (1/2, 1/4) or (1/8 .. 1/64)
-        const int nstage = (stage == STAGE_LS0) ? STAGE_LS1 : STAGE_LS2;
-        const int it0 = (nstage == STAGE_LS1) ? 1 : 3, nn = (nstage == STAGE_LS1) ? 2 : 4;
-        for (int c = 0; c < nn; ++c) {
-            apply_step(S, S.cand, S.nu_cand, sb0 + c, b, ls_alpha(it0 + c), tid, nt);
-            enqueue_eval(S, sb0 + c, b, S.WQ.par ^ 1, tid, nt);      // evaluated in the next round
-        }
-        if (tid == 0) {
-            S.stage[b] = nstage;
-            for (int c = nn; c < CS; ++c) S.need_sweep[sb0 + c] = 0;
-            atomicAdd(&S.counters[0], 1);
-        }
-        return;
-    }
-    const double alpha = ls_alpha(iter);
-    if (act == 1) {                       // accept: traj <- traj - alpha*Delta (newton.jl:273)
-        apply_step(S, S.traj, S.nu, (size_t)b, b, alpha, tid, nt);
-    }
-    {   // res <- res_cand ; r_norm <- r_cand
-        double* rr = S.res + (size_t)b * S.N;
-        const double* r = S.res_cand + (sb0 + slot) * S.N;
-        for (int e = tid; e < S.N; e += nt) rr[e] = r[e];
-    }
-    if (tid == 0) {
-        const double rn = rc[slot];
-        S.r_norm[b] = rn;
-        S.cur_slot[b] = slot;
-        S.alpha[b] = alpha;
-        S.ls_iter[b] = iter;
-        int l = S.newton_l[b];
-        if (act == 1) {
-            l += 1;
-            S.newton_l[b] = l;
-            const double be = S.beta[b];
-            S.beta[b] = (iter > 6) ? fmin(be * 1.3, 1.0e2) : fmax(1.0e1, be / 1.3);
-        }
-        const bool done = (l >= S.max_iter) || (rn / (double)S.N < S.r_tol);
-        for (int c = 0; c < CS; ++c) S.need_sweep[sb0 + c] = 0;
-        if (done) {
-            S.stage[b] = STAGE_DONE;
-        } else {
-            S.stage[b] = STAGE_KKT;
-            atomicAdd(&S.counters[1], 1);
-        }
-    }
-}
-
-template <int NQ, int NU, bool CF>
-__global__ __launch_bounds__(256) void resid_decide_kernel(NewtonDev S) {
-    __shared__ double red[256];
-    __shared__ double rc[CS];
-    __shared__ int sh[4];
-    resid_decide_body<NQ, NU, CF>(S, red, rc, sh);
-    // ---- epilogue: the LAST block to finish publishes the round's counters to host-mapped pinned
-    //      memory (the host polls the stamp; no memcpy / event on the critical path)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const int ticket = atomicAdd(&S.counters[7], 1);
-        if (ticket == (int)gridDim.x - 1) {
-            const int n_sweep = atomicAdd(&S.counters[0], 0), n_kkt = atomicAdd(&S.counters[1], 0);
-            volatile int* hm = S.host_flag;
-            hm[0] = n_sweep;
-            hm[1] = n_kkt;
-            __threadfence_system();
-            hm[2] = S.round_stamp;
-            __threadfence_system();
-        }
-    }
-}
-
-// -------------------------------------------------------------------------------------------
-// KKT: condensed solve, one wavefront per rollout.  Every operand of the block recursion is
-// staged in LDS tiles with leading dimension LD (>= nd, nq, nu; multiple of 4); global memory
-// is touched only to stream the step's sensitivities / objective inverses in (coalesced) and
-// to spill the factors L1_i, L2_i, L0_i^-1, y_i for the backward pass.
-//
-//   Y_ii     = du1 R^-1 du1^T + Q_i^-1 + dq1 Q_{i-1}^-1 dq1^T + dq0 Q_{i-2}^-1 dq0^T + rho I
-//   Y_i,i-1  = -dq1_i Q_{i-1}^-1 + dq0_i Q_{i-2}^-1 dq1_{i-1}^T ,   Y_i,i-2 = -dq0_i Q_{i-2}^-1
-//   beta_i   = (C P^-1 r_p - r_d)_i                      (methods.jl:386-446, 487-504)
-//   L2_i = Y_i,i-2 L0_{i-2}^-T ; L1_i = (Y_i,i-1 - L2_i L1_{i-1}^T) L0_{i-1}^-T ;
-//   L0_i L0_i^T = Y_ii - L1_i L1_i^T - L2_i L2_i^T        (compute_L!, methods.jl:466-485)
-//   forward / backward block substitution, Delta_x = P^-1 (r_p - C^T dnu)   (:506-557)
-// -------------------------------------------------------------------------------------------
-struct KktArgs {
-    const double* r;     // [B][N] right-hand side
-    double* delta;       // [B][N]
-    const double* beta;  // [B] or null (then beta_scalar)
-    double beta_scalar;
-    const int* stage;    // only rollouts with stage == STAGE_KKT (null = all)
-    int finish;          // 1: set alpha/ls_iter/cand/stage after the solve (newton loop)
-};
-
-__device__ __forceinline__ void lds_sync() { __syncthreads(); }
-
-// number of LDS tiles used by kkt_kernel
-constexpr int KKT_TILES = 21;
-
-template <int NQ, int NU>
-__global__ __launch_bounds__(64) void kkt_kernel_scalar(NewtonDev S, KktArgs K) {
-    constexpr int LD = ((NQ > NU ? NQ : NU) + 3) & ~3;
-    const cimpc_dims& m = S.dm;
-    const int b = blockIdx.x + S.b0, lane = threadIdx.x;
-    if (K.stage != nullptr && K.stage[b] != STAGE_KKT) return;
-    constexpr int nq = NQ, nu = NU, nd = NQ, nr = NQ + NU, nths = 2 * NQ + NU;
-    const int H = m.H;
-    constexpr int T2D = LD * LD;
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    double* A0 = sm;                  // du1_i      nd x nu
-    double* A1 = A0 + T2D;            // dq1_i      nd x nq
-    double* A2 = A1 + T2D;            // dq0_i      nd x nq
-    double* A1p = A2 + T2D;           // dq1_{i-1}
-    double* T0 = A1p + T2D;           // du1 Rinv_i
-    double* T1 = T0 + T2D;            // dq1 Qinv_{i-1}
-    double* T2 = T1 + T2D;            // dq0 Qinv_{i-2}
-    double* Y0 = T2 + T2D;
-    double* Y1 = Y0 + T2D;
-    double* Y2 = Y1 + T2D;
-    double* Lc = Y2 + T2D;            // chol factor of the step
-    double* Lbuf[3] = {Lc + T2D, Lc + 2 * T2D, Lc + 3 * T2D};      // L0inv ring (i, i-1, i-2)
-    double* L1buf[2] = {Lc + 4 * T2D, Lc + 5 * T2D};               // L1 ring (i, i-1)
-    double* L2c = Lc + 6 * T2D;
-    double* Qbuf[3] = {Lc + 7 * T2D, Lc + 8 * T2D, Lc + 9 * T2D};  // Qinv ring (i, i-1, i-2)
-    double* Ri = Lc + 10 * T2D;       // Rinv_i   (tile 21)
-    double* vec = sm + KKT_TILES * T2D;
-    double* bet = vec;                // LD each
-    double* ybuf[3] = {vec + LD, vec + 2 * LD, vec + 3 * LD};      // y ring
-    double* rpu = vec + 4 * LD;       // r_p(u) of step i
-    double* rpq[3] = {vec + 5 * LD, vec + 6 * LD, vec + 7 * LD};   // r_p(q) ring (i, i-1, i-2)
-    double* tv = vec + 8 * LD;
-    const double* rb = K.r + (size_t)b * S.N;
-    const double beta = K.beta ? K.beta[b] : K.beta_scalar;
-    const double rho = (double)H * beta * S.kappa;     // newton_jacobian.jl:169-186 quirk
-    const double* dzb = S.dz + ((size_t)b * CS + (K.stage ? S.cur_slot[b] : 0)) * H * nths * nd;
-    constexpr int n2 = nd * nd;
-    double* ws = S.kkt_ws + (size_t)b * H * (3 * n2 + nd);
-    const int oq = nu;   // offset of q2 inside a primal block (:configuration)
-
-    // software prefetch of the next step's operands (global -> registers), consumed at the top
-    // of the following iteration: hides the ~1 us HBM/L2 latency behind the block factorization
-    constexpr int PF_DZ = (nd * nths + 63) / 64, PF_Q = (nq * nq + 63) / 64, PF_R = (nu * nu + 63) / 64;
-    double pf_dz[PF_DZ], pf_q[PF_Q], pf_r[PF_R], pf_rp = 0.0, pf_rd = 0.0;
-    auto prefetch = [&](int i) {
-        if (i >= H) return;
-        const double* dzi = dzb + (size_t)i * nths * nd;
-#pragma unroll
-        for (int j = 0; j < PF_DZ; ++j) { const int k = lane + 64 * j; pf_dz[j] = (k < nd * nths) ? dzi[k] : 0.0; }
-#pragma unroll
-        for (int j = 0; j < PF_Q; ++j) { const int k = lane + 64 * j; pf_q[j] = (k < nq * nq) ? S.Qinv[(size_t)i * nq * nq + k] : 0.0; }
-#pragma unroll
-        for (int j = 0; j < PF_R; ++j) { const int k = lane + 64 * j; pf_r[j] = (k < nu * nu) ? S.Rinv[(size_t)i * nu * nu + k] : 0.0; }
-        pf_rp = (lane < nr) ? rb[i * nr + lane] : 0.0;                 // [u | q2] block of r_p
-        pf_rd = (lane < nd) ? rb[H * nr + i * nd + lane] : 0.0;
-    };
-#ifdef CIMPC_KKT_PROF
-    long long pt[16] = {0}; long long tp = clock64();
-#define KPROF(j) { const long long tn = clock64(); pt[j] += tn - tp; tp = tn; }
-#else
-#define KPROF(j)
-#endif
-    prefetch(0);
-    for (int i = 0; i < H; ++i) {
-        double* Li = Lbuf[i % 3];      double* Li1 = Lbuf[(i + 2) % 3];  double* Li2 = Lbuf[(i + 1) % 3];
-        double* L1c = L1buf[i % 2];    double* L1p = L1buf[(i + 1) % 2];
-        double* Qi0 = Qbuf[i % 3];     double* Qi1 = Qbuf[(i + 2) % 3];  double* Qi2 = Qbuf[(i + 1) % 3];
-        double* yc = ybuf[i % 3];      double* y1 = ybuf[(i + 2) % 3];   double* y2 = ybuf[(i + 1) % 3];
-        double* q0r = rpq[i % 3];      double* q1r = rpq[(i + 2) % 3];   double* q2r = rpq[(i + 1) % 3];
-        // ---- phase 1: stream step i in (A1p keeps dq1_{i-1}: swap roles of A1/A1p) ----------
-        {
-            double* t = A1; A1 = A1p; A1p = t;
-        }
-        // registers -> LDS (data of step i was fetched while step i-1 was being factored)
-#pragma unroll
-        for (int j = 0; j < PF_DZ; ++j) {
-            const int k = lane + 64 * j;
-            if (k < nd * nths) {
-                const int r = k % nd, c = k / nd;
-                double* dst = (c < nq) ? (A2 + c * LD) : (c < 2 * nq) ? (A1 + (c - nq) * LD) : (A0 + (c - 2 * nq) * LD);
-                dst[r] = pf_dz[j];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < PF_Q; ++j) {
-            const int k = lane + 64 * j;
-            if (k < nq * nq) Qi0[(k % nq) + (k / nq) * LD] = pf_q[j];
-        }
-#pragma unroll
-        for (int j = 0; j < PF_R; ++j) {
-            const int k = lane + 64 * j;
-            if (k < nu * nu) Ri[(k % nu) + (k / nu) * LD] = pf_r[j];
-        }
-        if (lane < nu) rpu[lane] = pf_rp;
-        else if (lane < nu + nq) q0r[lane - nu] = pf_rp;
-        const double rd_i = pf_rd;
-        lds_sync();
-        prefetch(i + 1);
-        KPROF(1)
-        // ---- phase 2: T0 = A0 Ri, T1 = A1 Qi1, T2 = A2 Qi2 -----------------------------------
-        for (int idx = lane; idx < nd * (nu + 2 * nq); idx += 64) {
-            const int r = idx % nd;
-            int c = idx / nd;
-            double s = 0.0;
-            if (c < nu) {
-                for (int k = 0; k < nu; ++k) s = fma(A0[r + k * LD], Ri[k + c * LD], s);
-                T0[r + c * LD] = s;
-            } else if (c < nu + nq) {
-                c -= nu;
-                if (i >= 1) for (int k = 0; k < nq; ++k) s = fma(A1[r + k * LD], Qi1[k + c * LD], s);
-                T1[r + c * LD] = s;
-            } else {
-                c -= nu + nq;
-                if (i >= 2) for (int k = 0; k < nq; ++k) s = fma(A2[r + k * LD], Qi2[k + c * LD], s);
-                T2[r + c * LD] = s;
-            }
-        }
-        lds_sync();
-        KPROF(2)
-        // ---- phase 3: Y0, Y1, Y2, beta_i -----------------------------------------------------
-        for (int idx = lane; idx < 3 * n2 + nd; idx += 64) {
-            if (idx < n2) {
-                const int r = idx % nd, c = idx / nd;
-                double s = Qi0[r + c * LD] + ((r == c) ? rho : 0.0);
-                for (int k = 0; k < nu; ++k) s = fma(T0[r + k * LD], A0[c + k * LD], s);
-                if (i >= 1) for (int k = 0; k < nq; ++k) s = fma(T1[r + k * LD], A1[c + k * LD], s);
-                if (i >= 2) for (int k = 0; k < nq; ++k) s = fma(T2[r + k * LD], A2[c + k * LD], s);
-                Y0[r + c * LD] = s;
-            } else if (idx < 2 * n2) {
-                const int e = idx - n2, r = e % nd, c = e / nd;
-                double s = -T1[r + c * LD];
-                if (i >= 2) for (int k = 0; k < nq; ++k) s = fma(T2[r + k * LD], A1p[c + k * LD], s);
-                Y1[r + c * LD] = s;
-            } else if (idx < 3 * n2) {
-                const int e = idx - 2 * n2, r = e % nd, c = e / nd;
-                Y2[r + c * LD] = -T2[r + c * LD];
-            } else {
-                const int r = idx - 3 * n2;
-                double s = 0.0;
-                for (int k = 0; k < nu; ++k) s = fma(T0[r + k * LD], rpu[k], s);
-                double t = 0.0;
-                for (int k = 0; k < nq; ++k) t = fma(Qi0[r + k * LD], q0r[k], t);
-                s -= t;
-                if (i >= 1) { t = 0.0; for (int k = 0; k < nq; ++k) t = fma(T1[r + k * LD], q1r[k], t); s += t; }
-                if (i >= 2) { t = 0.0; for (int k = 0; k < nq; ++k) t = fma(T2[r + k * LD], q2r[k], t); s += t; }
-                bet[r] = s;            // - r_d[i] is applied below by the lanes that prefetched it
-            }
-        }
-        lds_sync();
-        KPROF(3)
-        if (lane < nd) bet[lane] -= rd_i;
-        // ---- phase 4: L2c = Y2 Li2^T (Li2 lower triangular: k <= c) --------------------------
-        if (i >= 2) {
-            for (int idx = lane; idx < n2; idx += 64) {
-                const int r = idx % nd, c = idx / nd;
-                double s = 0.0;
-                for (int k = 0; k <= c; ++k) s = fma(Y2[r + k * LD], Li2[c + k * LD], s);
-                L2c[r + c * LD] = s;
-            }
-            lds_sync();
-            // ---- phase 5: Y1 -= L2c L1p^T ----------------------------------------------------
-            for (int idx = lane; idx < n2; idx += 64) {
-                const int r = idx % nd, c = idx / nd;
-                double s = Y1[r + c * LD];
-                for (int k = 0; k < nd; ++k) s = fma(-L2c[r + k * LD], L1p[c + k * LD], s);
-                Y1[r + c * LD] = s;
-            }
-            lds_sync();
-        }
-        KPROF(4)
-        // ---- phase 6: L1c = Y1 Li1^T ----------------------------------------------------------
-        if (i >= 1) {
-            for (int idx = lane; idx < n2; idx += 64) {
-                const int r = idx % nd, c = idx / nd;
-                double s = 0.0;
-                for (int k = 0; k <= c; ++k) s = fma(Y1[r + k * LD], Li1[c + k * LD], s);
-                L1c[r + c * LD] = s;
-            }
-            lds_sync();
-        }
-        KPROF(5)
-        // ---- phase 7: Lc = Y0 - L1c L1c^T - L2c L2c^T (lower triangle) ------------------------
-        for (int idx = lane; idx < n2; idx += 64) {
-            const int r = idx % nd, c = idx / nd;
-            if (r < c) continue;
-            double s = Y0[r + c * LD];
-            if (i >= 1) for (int k = 0; k < nd; ++k) s = fma(-L1c[r + k * LD], L1c[c + k * LD], s);
-            if (i >= 2) for (int k = 0; k < nd; ++k) s = fma(-L2c[r + k * LD], L2c[c + k * LD], s);
-            Lc[r + c * LD] = s;
-        }
-        lds_sync();
-        KPROF(6)
-        // ---- phase 8/9: Cholesky of Lc and its inverse --------------------------------------
-        if constexpr (nd <= 16) {
-            // register version: lane rl of each DPP row holds ROW rl of the matrix; the pivot and
-            // the multipliers travel by row_newbcast, no LDS round trip inside the recursion.
-            using LG = LaneGroup<16>;
-            const int rl = lane & 15;
-            double a[nd], invd[nd];
-            static_for<0, nd>([&](auto cc) {
-                constexpr int c = decltype(cc)::value;
-                a[c] = (rl < nd) ? Lc[rl + c * LD] : ((c == rl) ? 1.0 : 0.0);
-            });
-            static_for<0, nd>([&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                const double dk = LG::template bcast<k>(a[k]);
-                const double inv = fast_rsqrt(dk);
-                invd[k] = inv;                       // 1 / L[k,k], identical in every lane
-                a[k] *= inv;                         // lane k: sqrt(dk); lanes r > k: L[r,k]
-                static_for<k + 1, nd>([&](auto cc) {
-                    constexpr int c = decltype(cc)::value;
-                    a[c] = fma(-a[k], LG::template bcast<c>(a[k]), a[c]);
-                });
-            });
-            // column rl of Li = L^-1 by forward substitution; L[r,k] broadcast from lane r
-            double xc[nd];
-            static_for<0, nd>([&](auto rc) {
-                constexpr int r = decltype(rc)::value;
-                double acc = 0.0;
-                static_for<0, r>([&](auto kc) {
-                    constexpr int k = decltype(kc)::value;
-                    acc = fma(LG::template bcast<r>(a[k]), xc[k], acc);
-                });
-                xc[r] = (((r == rl) ? 1.0 : 0.0) - acc) * invd[r];
-            });
-            if (lane < nd) {
-                static_for<0, nd>([&](auto rc) {
-                    constexpr int r = decltype(rc)::value;
-                    Li[r + lane * LD] = xc[r];
-                });
-            }
-        } else {
-            for (int k = 0; k < nd; ++k) {
-                const double dkk = sqrt(Lc[k + k * LD]);
-                const double inv = 1.0 / dkk;
-                lds_sync();
-                for (int r = k + lane; r < nd; r += 64) Lc[r + k * LD] = (r == k) ? dkk : Lc[r + k * LD] * inv;
-                lds_sync();
-                const int rem = nd - k - 1;
-                for (int idx = lane; idx < rem * rem; idx += 64) {
-                    const int r = k + 1 + idx % rem, c = k + 1 + idx / rem;
-                    if (r >= c) Lc[r + c * LD] = fma(-Lc[r + k * LD], Lc[c + k * LD], Lc[r + c * LD]);
-                }
-                lds_sync();
-            }
-            for (int c = lane; c < nd; c += 64) {
-                double xi[nd];
-                for (int r = 0; r < nd; ++r) {
-                    double s = (r == c) ? 1.0 : 0.0;
-                    for (int k = 0; k < r; ++k) s = fma(-Lc[r + k * LD], (k >= c) ? xi[k] : 0.0, s);
-                    xi[r] = (r < c) ? 0.0 : s / Lc[r + r * LD];
-                }
-                for (int r = 0; r < nd; ++r) Li[r + c * LD] = xi[r];
-            }
-        }
-        KPROF(7)
-        for (int r = lane - 32; r >= 0 && r < nd; r += 64) {     // lanes 32.. do the rhs update meanwhile
-            double s = bet[r];
-            if (i >= 1) for (int k = 0; k < nd; ++k) s = fma(-L1c[r + k * LD], y1[k], s);
-            if (i >= 2) for (int k = 0; k < nd; ++k) s = fma(-L2c[r + k * LD], y2[k], s);
-            tv[r] = s;
-        }
-        lds_sync();
-        KPROF(8)
-        // ---- phase 10: y_i = Li * tv ; spill factors ------------------------------------------
-        for (int r = lane; r < nd; r += 64) {
-            double s = 0.0;
-            for (int k = 0; k <= r; ++k) s = fma(Li[r + k * LD], tv[k], s);
-            yc[r] = s;
-        }
-        double* wsi = ws + (size_t)i * (3 * n2 + nd);
-        for (int k = lane; k < n2; k += 64) {
-            const int r = k % nd, c = k / nd;
-            wsi[k] = (i >= 1) ? L1c[r + c * LD] : 0.0;
-            wsi[n2 + k] = (i >= 2) ? L2c[r + c * LD] : 0.0;
-            wsi[2 * n2 + k] = Li[r + c * LD];
-        }
-        lds_sync();
-        for (int k = lane; k < nd; k += 64) wsi[3 * n2 + k] = yc[k];
-        KPROF(9)
-    }
-    __threadfence_block();
-    lds_sync();
-    // ---- backward substitution: dnu_i = Li_i^T (y_i - L1_{i+1}^T dnu_{i+1} - L2_{i+2}^T dnu_{i+2})
-    double* D = K.delta + (size_t)b * S.N;
-    double* Wt[3] = {A0, A1, A2};            // LDS staging of (L1_{i+1}, L2_{i+2}, Li_i)
-    double* dnr[3] = {ybuf[0], ybuf[1], ybuf[2]};
-    for (int i = H - 1; i >= 0; --i) {
-        const double* wsi = ws + (size_t)i * (3 * n2 + nd);
-        double* dnc = dnr[i % 3]; double* dn1 = dnr[(i + 1) % 3]; double* dn2 = dnr[(i + 2) % 3];
-        for (int k = lane; k < n2; k += 64) {
-            const int r = k % nd, c = k / nd;
-            Wt[2][r + c * LD] = wsi[2 * n2 + k];
-            if (i + 1 < H) Wt[0][r + c * LD] = ws[(size_t)(i + 1) * (3 * n2 + nd) + k];
-            if (i + 2 < H) Wt[1][r + c * LD] = ws[(size_t)(i + 2) * (3 * n2 + nd) + n2 + k];
-        }
-        for (int k = lane; k < nd; k += 64) bet[k] = wsi[3 * n2 + k];
-        lds_sync();
-        for (int r = lane; r < nd; r += 64) {
-            double s = bet[r];
-            if (i + 1 < H) for (int k = 0; k < nd; ++k) s = fma(-Wt[0][k + r * LD], dn1[k], s);
-            if (i + 2 < H) for (int k = 0; k < nd; ++k) s = fma(-Wt[1][k + r * LD], dn2[k], s);
-            tv[r] = s;
-        }
-        lds_sync();
-        for (int r = lane; r < nd; r += 64) {
-            double s = 0.0;
-            for (int k = r; k < nd; ++k) s = fma(Wt[2][k + r * LD], tv[k], s);
-            dnc[r] = s;
-            D[H * nr + i * nd + r] = s;
-        }
-        lds_sync();
-    }
-    __threadfence_block();
-    lds_sync();
-    KPROF(10)
-    // ---- primal recovery: Delta_x = P^-1 (r_p - C^T dnu) ----------------------------------
-    const double* dn = D + H * nr;
-    for (int i = 0; i < H; ++i) {
-        const double* dzi = dzb + (size_t)i * nths * nd;
-        for (int c = lane; c < nu + nq; c += 64) {
-            if (c < nu) {
-                double s = 0.0;
-                const double* a0 = dzi + (size_t)(2 * nq + c) * nd;
-                for (int k = 0; k < nd; ++k) s = fma(a0[k], dn[i * nd + k], s);
-                tv[c] = rb[i * nr + c] - s;
-            } else {
-                const int cq = c - nu;
-                double s = -dn[i * nd + cq];
-                if (i + 1 < H) {
-                    const double* a1 = dzb + ((size_t)(i + 1) * nths + nq + cq) * nd;
-                    double t = 0.0;
-                    for (int k = 0; k < nd; ++k) t = fma(a1[k], dn[(i + 1) * nd + k], t);
-                    s += t;
-                }
-                if (i + 2 < H) {
-                    const double* a2 = dzb + ((size_t)(i + 2) * nths + cq) * nd;
-                    double t = 0.0;
-                    for (int k = 0; k < nd; ++k) t = fma(a2[k], dn[(i + 2) * nd + k], t);
-                    s += t;
-                }
-                tv[c] = rb[i * nr + oq + cq] - s;
-            }
-        }
-        lds_sync();
-        for (int c = lane; c < nu + nq; c += 64) {
-            double s = 0.0;
-            if (c < nu) {
-                const double* Rm = S.Rinv + (size_t)i * nu * nu;
-                for (int k = 0; k < nu; ++k) s = fma(Rm[c + k * nu], tv[k], s);
-                D[i * nr + c] = s;
-            } else {
-                const int cq = c - nu;
-                const double* Qm = S.Qinv + (size_t)i * nq * nq;
-                for (int k = 0; k < nq; ++k) s = fma(Qm[cq + k * nq], tv[nu + k], s);
-                D[i * nr + oq + cq] = s;
-            }
-        }
-        lds_sync();
-    }
-    KPROF(11)
-#ifdef CIMPC_KKT_PROF
-    if (lane == 0 && b == 0) for (int j = 0; j < 16; ++j) ((long long*)S.stats)[8 + j] = pt[j];
-#endif
-    if (K.finish) {
-        __threadfence_block();
-        lds_sync();
-        // line search start (newton.jl:223-228): alpha = 1, candidate = traj - Delta
-        apply_step(S, S.cand, S.nu_cand, (size_t)b * CS, b, 1.0, lane, 64);
-        // the KKT kernel runs on its own stream NEXT TO the sweep of the running round: its
-        // candidates join the queue of the next round
-        enqueue_eval(S, (size_t)b * CS, b, S.kkt_same_round ? S.WQ.par : (S.WQ.par ^ 1), lane, 64);
-        if (lane == 0) {
-            S.alpha[b] = 1.0;
-            S.ls_iter[b] = 0;
-            S.stage[b] = STAGE_LS0;
-            for (int c = 1; c < CS; ++c) S.need_sweep[(size_t)b * CS + c] = 0;
-            atomicAdd(&S.counters[0], 1);
-        }
-    }
-}
-
-
-// -------------------------------------------------------------------------------------------
-// MFMA version (nq, nu <= 16): every block product of the recursion is C (+)= X * Y^T on
-// 16x16 LDS tiles, executed by v_mfma_f64_16x16x4_f64 (one wavefront = one rollout).  The
-// operands are fed as A := Y, B := X so that the accumulator holds C^T-by-MFMA-layout = C with
-// lane -> row: lane l owns C[l&15][(l>>4) + 4*reg], which stores to the column-major tile with
-// consecutive lanes on consecutive addresses (no LDS bank conflicts).  Padded rows / columns
-// of every tile are kept at exactly zero, so K can always be rounded up to a multiple of 4.
-// -------------------------------------------------------------------------------------------
-using d4 = __attribute__((ext_vector_type(4))) double;
-constexpr int TL = 16;            // tile leading dimension
-constexpr int TSZ = TL * TL;      // doubles per tile
-constexpr int KKT_MFMA_TILES = 22;
-
-template <int KB, bool NEG>
-__device__ __forceinline__ d4 tile_mma(const double* X, const double* Y, d4 acc, int li, int lk) {
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-        double a = Y[li + (4 * kb + lk) * TL];
-        const double b = X[li + (4 * kb + lk) * TL];
-        if (NEG) a = -a;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
-    return acc;
-}
-__device__ __forceinline__ d4 tile_ld(const double* C, int li, int lk) {
-    d4 v;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = C[li + (lk + 4 * r) * TL];
-    return v;
-}
-__device__ __forceinline__ void tile_st(double* C, d4 v, int li, int lk) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) C[li + (lk + 4 * r) * TL] = v[r];
-}
-// y[r] = sum_k M[r + k*TL] * x[k]  (or M^T), one output per lane, operands in LDS
-template <int KN, bool TRANS>
-__device__ __forceinline__ double tile_mv(const double* Mt, const double* x, int r) {
-    double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-    for (int k = 0; k + 1 < KN; k += 2) {
-        s0 = fma(TRANS ? Mt[k + r * TL] : Mt[r + k * TL], x[k], s0);
-        s1 = fma(TRANS ? Mt[k + 1 + r * TL] : Mt[r + (k + 1) * TL], x[k + 1], s1);
-    }
-    if (KN & 1) s0 = fma(TRANS ? Mt[KN - 1 + r * TL] : Mt[r + (KN - 1) * TL], x[KN - 1], s0);
-    return s0 + s1;
-}
-
-template <int NQ, int NU>
-__global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
-    static_assert(NQ <= 16 && NU <= 16, "MFMA KKT kernel handles one 16x16 tile per block");
-    constexpr int nq = NQ, nu = NU, nd = NQ, nr = NQ + NU, nths = 2 * NQ + NU, n2 = nd * nd;
-    constexpr int KBU = (NU + 3) / 4, KBQ = (NQ + 3) / 4, KBD = (nd + 3) / 4;
-    const cimpc_dims& m = S.dm;
-    const int b = blockIdx.x + S.b0, lane = threadIdx.x;
-    if (K.stage != nullptr && K.stage[b] != STAGE_KKT) return;
-    const int H = m.H;
-    const int li = lane & 15, lk = lane >> 4;
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    auto tile = [&](int t) { return sm + t * TSZ; };
-    double* A0 = tile(0);                                  // du1_i            nd x nu
-    double* A2 = tile(1);                                  // dq0_i            nd x nq
-    // tiles 2,3: dq1 ring (i, i-1)
-    double* T0 = tile(4); double* T1 = tile(5); double* T2 = tile(6);
-    double* Y1 = tile(7); double* Lc = tile(8); double* L2c = tile(9);
-    // tiles 10..12: L0^-1 ring, 13..14: L1 ring, 15..17: Qinv ring
-    double* Ri = tile(18);
-    // tiles 19..21: extra ring slots of the backward pass
-    double* vec = sm + KKT_MFMA_TILES * TSZ;
-    double* bet = vec;                                     // 16 each
-    double* tv = vec + 16;
-    // vec + 32/48/64: y / dnu ring
-    double* rpu = vec + 80;
-    // vec + 96/112/128: r_p(q) ring
-    for (int k = lane; k < KKT_MFMA_TILES * TSZ + 208; k += 64) sm[k] = 0.0;
-    const double* rb = K.r + (size_t)b * S.N;
-    const double beta = K.beta ? K.beta[b] : K.beta_scalar;
-    const double rho = (double)H * beta * S.kappa;         // newton_jacobian.jl:169-186 quirk
-    const double* dzb = S.dz + ((size_t)b * CS + (K.stage ? S.cur_slot[b] : 0)) * H * nths * nd;
-    double* ws = S.kkt_ws + (size_t)b * H * (3 * n2 + nd);
-    constexpr int WSR = 3 * n2 + nd;
-
-    constexpr int PF_DZ = (nd * nths + 63) / 64, PF_Q = (nq * nq + 63) / 64, PF_R = (nu * nu + 63) / 64;
-    double pf_dz[PF_DZ], pf_q[PF_Q], pf_r[PF_R], pf_rp = 0.0, pf_rd = 0.0;
-    auto prefetch = [&](int i) {
-        if (i < 0 || i >= H) return;
-        const double* dzi = dzb + (size_t)i * nths * nd;
-#pragma unroll
-        for (int j = 0; j < PF_DZ; ++j) { const int k = lane + 64 * j; pf_dz[j] = (k < nd * nths) ? dzi[k] : 0.0; }
-#pragma unroll
-        for (int j = 0; j < PF_Q; ++j) { const int k = lane + 64 * j; pf_q[j] = (k < nq * nq) ? S.Qinv[(size_t)i * nq * nq + k] : 0.0; }
-#pragma unroll
-        for (int j = 0; j < PF_R; ++j) { const int k = lane + 64 * j; pf_r[j] = (k < nu * nu) ? S.Rinv[(size_t)i * nu * nu + k] : 0.0; }
-        pf_rp = (lane < nr) ? rb[i * nr + lane] : 0.0;
-        pf_rd = (lane < nd) ? rb[H * nr + i * nd + lane] : 0.0;
-    };
-    // registers -> LDS tiles of one step (dq0 -> a2, dq1 -> a1, du1 -> a0)
-    auto commit = [&](double* a0, double* a1, double* a2, double* qi, double* ri, double* ru, double* rq) {
-#pragma unroll
-        for (int j = 0; j < PF_DZ; ++j) {
-            const int k = lane + 64 * j;
-            if (k < nd * nths) {
-                const int r = k % nd, c = k / nd;
-                double* dst = (c < nq) ? (a2 + c * TL) : (c < 2 * nq) ? (a1 + (c - nq) * TL) : (a0 + (c - 2 * nq) * TL);
-                dst[r] = pf_dz[j];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < PF_Q; ++j) { const int k = lane + 64 * j; if (k < nq * nq) qi[(k % nq) + (k / nq) * TL] = pf_q[j]; }
-#pragma unroll
-        for (int j = 0; j < PF_R; ++j) { const int k = lane + 64 * j; if (k < nu * nu) ri[(k % nu) + (k / nu) * TL] = pf_r[j]; }
-        if (lane < nu) ru[lane] = pf_rp;
-        else if (lane < nr) rq[lane - nu] = pf_rp;
-    };
-
-#ifdef CIMPC_KKT_PROF
-    long long pt[16] = {0}; long long tp = clock64();
-#define KPROF(j) { const long long tn = clock64(); pt[j] += tn - tp; tp = tn; }
-#else
-#define KPROF(j)
-#endif
-    prefetch(0);
-    for (int i = 0; i < H; ++i) {
-        const int m0 = i % 3, m1 = (i + 2) % 3, m2 = (i + 1) % 3, p0 = i & 1, p1 = (i + 1) & 1;
-        double* Li = tile(10 + m0);  double* Li1 = tile(10 + m1);  double* Li2 = tile(10 + m2);
-        double* L1c = tile(13 + p0); double* L1p = tile(13 + p1);
-        double* A1 = tile(2 + p0);   double* A1p = tile(2 + p1);
-        double* Qi0 = tile(15 + m0); double* Qi1 = tile(15 + m1);  double* Qi2 = tile(15 + m2);
-        double* yc = vec + 32 + 16 * m0; double* y1 = vec + 32 + 16 * m1; double* y2 = vec + 32 + 16 * m2;
-        double* q0r = vec + 96 + 16 * m0; double* q1r = vec + 96 + 16 * m1; double* q2r = vec + 96 + 16 * m2;
-        // ---- P1: step i operands -> LDS, fetch step i+1 ------------------------------------
-        commit(A0, A1, A2, Qi0, Ri, rpu, q0r);
-        const double rd_i = pf_rd;
-        lds_sync();
-        prefetch(i + 1);
-        KPROF(1)
-        // ---- P2: T0 = du1 Rinv, T1 = dq1 Qinv_{i-1}, T2 = dq0 Qinv_{i-2}  (Qinv, Rinv symmetric)
-        const d4 z4 = {0.0, 0.0, 0.0, 0.0};
-        tile_st(T0, tile_mma<KBU, false>(A0, Ri, z4, li, lk), li, lk);
-        if (i >= 1) tile_st(T1, tile_mma<KBQ, false>(A1, Qi1, z4, li, lk), li, lk);
-        if (i >= 2) tile_st(T2, tile_mma<KBQ, false>(A2, Qi2, z4, li, lk), li, lk);
-        lds_sync();
-        KPROF(2)
-        // ---- P3: Y_ii, Y_i,i-1, L2_i = -T2 L0_{i-2}^-T, beta_i -------------------------------
-        d4 y0 = tile_ld(Qi0, li, lk);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (li == lk + 4 * r && li < nd) y0[r] += rho;
-        y0 = tile_mma<KBU, false>(T0, A0, y0, li, lk);
-        d4 y1a = z4;
-        if (i >= 1) {
-            y0 = tile_mma<KBQ, false>(T1, A1, y0, li, lk);
-            y1a = -tile_ld(T1, li, lk);
-        }
-        if (i >= 2) {
-            y0 = tile_mma<KBQ, false>(T2, A2, y0, li, lk);
-            y1a = tile_mma<KBQ, false>(T2, A1p, y1a, li, lk);
-            tile_st(L2c, tile_mma<KBD, true>(T2, Li2, z4, li, lk), li, lk);
-        }
-        if (lane < nd) {   // beta_i = T0 rpu - Qinv_i rq_i + T1 rq_{i-1} + T2 rq_{i-2} - rd_i
-            double s = tile_mv<nu, false>(T0, rpu, lane) - tile_mv<nq, false>(Qi0, q0r, lane);
-            if (i >= 1) s += tile_mv<nq, false>(T1, q1r, lane);
-            if (i >= 2) s += tile_mv<nq, false>(T2, q2r, lane);
-            bet[lane] = s - rd_i;
-        }
-        lds_sync();
-        KPROF(3)
-        // ---- P4: Y1 -= L2 L1_{i-1}^T ; stage Y1 as an operand ------------------------------
-        if (i >= 1) {
-            if (i >= 2) y1a = tile_mma<KBD, true>(L2c, L1p, y1a, li, lk);
-            tile_st(Y1, y1a, li, lk);
-            lds_sync();
-            // ---- P5: L1_i = Y1 L0_{i-1}^-T -----------------------------------------------------
-            tile_st(L1c, tile_mma<KBD, false>(Y1, Li1, z4, li, lk), li, lk);
-            lds_sync();
-        }
-        KPROF(4)
-        // ---- P6: Lc = Y0 - L1 L1^T - L2 L2^T ; rhs of the forward substitution ---------------
-        if (i >= 1) y0 = tile_mma<KBD, true>(L1c, L1c, y0, li, lk);
-        if (i >= 2) y0 = tile_mma<KBD, true>(L2c, L2c, y0, li, lk);
-        tile_st(Lc, y0, li, lk);
-        if (lane < nd) {
-            double s = bet[lane];
-            if (i >= 1) s -= tile_mv<nd, false>(L1c, y1, lane);
-            if (i >= 2) s -= tile_mv<nd, false>(L2c, y2, lane);
-            tv[lane] = s;
-        }
-        lds_sync();
-        KPROF(5)
-        // ---- P7: Cholesky of Lc and L0^-1 in registers (lane = row, DPP broadcasts) -----------
-        {
-            using LG = LaneGroup<16>;
-            const int rl = li;
-            double a[nd], invd[nd];
-            static_for<0, nd>([&](auto cc) {
-                constexpr int c = decltype(cc)::value;
-                a[c] = (rl < nd) ? Lc[rl + c * TL] : ((c == rl) ? 1.0 : 0.0);
-            });
-            static_for<0, nd>([&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                const double dk = LG::template bcast<k>(a[k]);
-                const double inv = fast_rsqrt(dk);
-                invd[k] = inv;
-                a[k] *= inv;
-                static_for<k + 1, nd>([&](auto cc) {
-                    constexpr int c = decltype(cc)::value;
-                    a[c] = fma(-a[k], LG::template bcast<c>(a[k]), a[c]);
-                });
-            });
-            double xc[nd];
-            static_for<0, nd>([&](auto rc) {
-                constexpr int r = decltype(rc)::value;
-                double acc = 0.0;
-                static_for<0, r>([&](auto kc) {
-                    constexpr int k = decltype(kc)::value;
-                    acc = fma(LG::template bcast<r>(a[k]), xc[k], acc);
-                });
-                xc[r] = (((r == rl) ? 1.0 : 0.0) - acc) * invd[r];
-            });
-            if (lane < nd) {
-                static_for<0, nd>([&](auto rc) {
-                    constexpr int r = decltype(rc)::value;
-                    Li[r + lane * TL] = xc[r];
-                });
-            }
-        }
-        lds_sync();
-        KPROF(6)
-        // ---- P8: y_i = L0^-1 tv ; spill (L1_i, L2_i, L0_i^-1, y_i) for the backward pass ------
-        double yi = 0.0;
-        if (lane < nd) {
-            yi = tile_mv<nd, false>(Li, tv, lane);
-            yc[lane] = yi;
-        }
-        double* wsi = ws + (size_t)i * WSR;
-        for (int k = lane; k < n2; k += 64) {
-            const int r = k % nd, c = k / nd;
-            wsi[k] = (i >= 1) ? L1c[r + c * TL] : 0.0;
-            wsi[n2 + k] = (i >= 2) ? L2c[r + c * TL] : 0.0;
-            wsi[2 * n2 + k] = Li[r + c * TL];
-        }
-        if (lane < nd) wsi[3 * n2 + lane] = yi;
-        lds_sync();
-        KPROF(7)
-    }
-    __threadfence_block();
-    lds_sync();
-    // =========================================================================================
-    // backward substitution, step i = H-1 .. 0 (sequential):
-    //   dnu_i = L0_i^-T (y_i - L1_{i+1}^T dnu_{i+1} - L2_{i+2}^T dnu_{i+2})
-    // then the primal recovery for ALL steps at once (no dependency between steps):
-    //   Du_i  = Rinv_i (rpu_i - du1_i^T dnu_i)
-    //   Dq_i  = Qinv_i (rpq_i + dnu_i - dq1_{i+1}^T dnu_{i+1} - dq0_{i+2}^T dnu_{i+2})
-    // =========================================================================================
-    double* D = K.delta + (size_t)b * S.N;
-    // tiles 0..2: L1_j ring, 3..5: L2_j ring (slot = step % 3), tile 6: L0_i^-1
-    double* FI = tile(6);
-    double* yb = vec;                                 // y_i
-    double* dn_all = tile(16);                        // [H][16] all dnu (tiles 16..18; H <= 48)
-    double* t_all = tile(7);                          // [H][nr] first level of the recovery (tiles 7..)
-    constexpr int PF_W = (WSR + 63) / 64;
-    double pf_w[PF_W];
-    auto prefetch_b = [&](int i) {
-        if (i < 0) return;
-        const double* wsi = ws + (size_t)i * WSR;
-#pragma unroll
-        for (int j = 0; j < PF_W; ++j) { const int k = lane + 64 * j; pf_w[j] = (k < WSR) ? wsi[k] : 0.0; }
-    };
-    prefetch_b(H - 1);
-    for (int i = H - 1; i >= 0; --i) {
-        const int s0 = i % 3, s1 = (i + 1) % 3, s2 = (i + 2) % 3;
-        double* F1s0 = tile(0 + s0); double* F1s1 = tile(0 + s1);
-        double* F2s0 = tile(3 + s0); double* F2s2 = tile(3 + s2);
-#pragma unroll
-        for (int j = 0; j < PF_W; ++j) {
-            const int k = lane + 64 * j;
-            if (k < 3 * n2) {
-                const int t = k / n2, e = k - t * n2, r = e % nd, c = e / nd;
-                double* dst = (t == 0) ? F1s0 : (t == 1) ? F2s0 : FI;
-                dst[r + c * TL] = pf_w[j];
-            } else if (k < WSR) {
-                yb[k - 3 * n2] = pf_w[j];
-            }
-        }
-        lds_sync();
-        prefetch_b(i - 1);
-        if (lane < nd) {
-            double s = yb[lane];
-            if (i + 1 < H) s -= tile_mv<nd, true>(F1s1, dn_all + (i + 1) * 16, lane);
-            if (i + 2 < H) s -= tile_mv<nd, true>(F2s2, dn_all + (i + 2) * 16, lane);
-            tv[lane] = s;
-        }
-        lds_sync();
-        if (lane < nd) {
-            const double dni = tile_mv<nd, true>(FI, tv, lane);
-            dn_all[i * 16 + lane] = dni;
-            D[H * nr + i * nd + lane] = dni;
-        }
-        lds_sync();
-    }
-    // ---- primal recovery, level 1: t = r_p - C^T dnu, one output per lane and trip ---------------
-    for (int idx = lane; idx < H * nr; idx += 64) {
-        const int i = idx / nr, c = idx - i * nr;
-        double s = rb[idx];
-        if (c < nu) {
-            const double* a0 = dzb + ((size_t)i * nths + 2 * nq + c) * nd;
-            const double* dn0 = dn_all + i * 16;
-            double t0 = 0.0;
-#pragma unroll
-            for (int k = 0; k < nd; ++k) t0 = fma(a0[k], dn0[k], t0);
-            s -= t0;
-        } else {
-            const int cq = c - nu;
-            s += dn_all[i * 16 + cq];
-            if (i + 1 < H) {
-                const double* a1 = dzb + ((size_t)(i + 1) * nths + nq + cq) * nd;
-                const double* dn1 = dn_all + (i + 1) * 16;
-                double t1 = 0.0;
-#pragma unroll
-                for (int k = 0; k < nd; ++k) t1 = fma(a1[k], dn1[k], t1);
-                s -= t1;
-            }
-            if (i + 2 < H) {
-                const double* a2 = dzb + ((size_t)(i + 2) * nths + cq) * nd;
-                const double* dn2 = dn_all + (i + 2) * 16;
-                double t2 = 0.0;
-#pragma unroll
-                for (int k = 0; k < nd; ++k) t2 = fma(a2[k], dn2[k], t2);
-                s -= t2;
-            }
-        }
-        t_all[idx] = s;
-    }
-    lds_sync();
-    // ---- level 2: Delta_x = P^-1 t ----------------------------------------------------------------
-    for (int idx = lane; idx < H * nr; idx += 64) {
-        const int i = idx / nr, c = idx - i * nr;
-        double s = 0.0;
-        if (c < nu) {
-            const double* Rm = S.Rinv + (size_t)i * nu * nu;
-#pragma unroll
-            for (int k = 0; k < nu; ++k) s = fma(Rm[c + k * nu], t_all[i * nr + k], s);
-        } else {
-            const int cq = c - nu;
-            const double* Qm = S.Qinv + (size_t)i * nq * nq;
-#pragma unroll
-            for (int k = 0; k < nq; ++k) s = fma(Qm[cq + k * nq], t_all[i * nr + nu + k], s);
-        }
-        D[idx] = s;
-    }
-    lds_sync();
-    KPROF(8)
-#ifdef CIMPC_KKT_PROF
-    if (lane == 0 && b == 0) for (int j = 0; j < 16; ++j) ((long long*)S.stats)[8 + j] = pt[j];
-#endif
-    if (K.finish) {
-        __threadfence_block();
-        lds_sync();
-        // line search start (newton.jl:223-228): alpha = 1, candidate = traj - Delta
-        apply_step(S, S.cand, S.nu_cand, (size_t)b * CS, b, 1.0, lane, 64);
-        // the KKT kernel runs on its own stream NEXT TO the sweep of the running round: its
-        // candidates join the queue of the next round
-        enqueue_eval(S, (size_t)b * CS, b, S.kkt_same_round ? S.WQ.par : (S.WQ.par ^ 1), lane, 64);
-        if (lane == 0) {
-            S.alpha[b] = 1.0;
-            S.ls_iter[b] = 0;
-            S.stage[b] = STAGE_LS0;
-            for (int c = 1; c < CS; ++c) S.need_sweep[(size_t)b * CS + c] = 0;
-            atomicAdd(&S.counters[0], 1);
-        }
-    }
+    if (S.A.on) enqueue_eval_async<BlockSync>(S, sb0, 1, b, tid, nt);
+    else enqueue_eval(S, sb0, b, S.WQ.par, tid, nt);
 }
 
 template <int NQ, int NU>

@@ -36,6 +36,7 @@ struct NewtonDev {
     int* pflag;        // [B*CS][H] resumable-solve flags (see IpParams)
     int* cur_slot;     // [B] slot holding the current im_traj (d, dz) of the rollout
     IpQueues WQ;       // device work queues of the sweep (WQ.par = parity of the running round)
+    AsyncQ A;          // hand-off queues of the asynchronous single-launch solve (A.on = 0: lock-step rounds)
     // Newton vectors, reference layout (newton_residual.jl:69-98)
     double* res;       // [B][N]
     double* res_cand;  // [B*CS][N]
@@ -71,6 +72,9 @@ struct NewtonDev {
     int max_iter;
 };
 
+// single-launch asynchronous solve (newton_async_impl.h)
+bool newton_async_available(const cimpc_dims* dm);
+int launch_newton_async(const cimpc_dims* dm, const IpParams& p, const NewtonDev& S, int waves, int grid, hipStream_t s);
 int launch_reset(const NewtonDev& nd, const double* q0, const double* q1, int warm, hipStream_t s);
 int launch_resid_decide(const NewtonDev& nd, hipStream_t s);
 int launch_enqueue_all(const NewtonDev& nd, hipStream_t s);   // B3 seam: queue slot 0 of every rollout
