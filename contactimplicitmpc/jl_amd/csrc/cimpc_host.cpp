@@ -87,7 +87,9 @@ struct cimpc_ctx {
     int* h_ring_dev = nullptr;   // device pointer of h_ring
     hipEvent_t ev_ring[4] = {nullptr, nullptr, nullptr, nullptr};
     // asynchronous single-launch solve (newton_async_impl.h)
-    bool async_on = false, async_dirty = true;
+    bool async_on = false, async_dirty = true;   // async_on: buffers allocated, kernel available
+    int async_mode = 2;          // 0 lock-step only, 1 always the single launch, 2 auto (by batch size / hybrid tail)
+    int async_tail = 96;         // hybrid: hand over to the asynchronous kernel when at most this many rollouts are active
     int* a_items = nullptr;      // [K][a_cap] live interior-point queues
     int* a_jobs = nullptr;       // residual job entries, then KKT job entries
     int* a_ctrl = nullptr;       // [count K][head K][rq_head rq_tail kq_head kq_tail n_done ...]
@@ -344,11 +346,15 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     const size_t B = d.B, H = d.H;
     int rc = CIMPC_OK;
     {   // asynchronous single-launch solve? (queues sized for every push of one solve: they never wrap)
-        // Opt-in (CIMPC_ASYNC=1).  Measured on MI355X, quadruped H = 40, B = 512: the
-        // single launch is correct but 2x slower than the lock-step rounds (33 ms vs 16.5 ms per batch
-        // step at its best occupancy of ~192 workgroups; it degrades further with more resident workgroups).
+        // CIMPC_ASYNC: 0 = lock-step rounds only, 1 = always the single launch, unset / 2 = auto.  Measured on
+        // MI355X (quadruped, H = 40): the single launch wins for 8 <= B <= 128 rollouts
+        // (B = 64: 8.1 vs 11.2 ms), the rounds win for large batches (B = 512: 16.5 vs 21.7 ms) - except for
+        // their sparse tail, which auto mode hands over to the asynchronous kernel.
         const char* ev = getenv("CIMPC_ASYNC");
-        const bool want = ev ? atoi(ev) != 0 : false;
+        h->async_mode = ev ? atoi(ev) : 2;
+        h->async_tail = std::min(256, std::max(64, d.B / 4));     // measured: B = 512 -> 128, B = 2048 -> 256
+        if (getenv("CIMPC_ASYNC_TAIL")) h->async_tail = atoi(getenv("CIMPC_ASYNC_TAIL"));
+        const bool want = h->async_mode != 0;
         const size_t K = d.H_ref;
         const size_t evals = 1 + 7 * (size_t)std::max(1, h->nt.max_iter);       // per rollout and solve
         h->a_cap = B * evals * ((H + K - 1) / K + 1);
@@ -366,8 +372,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         const size_t K = d.H_ref;
         const size_t cap = B * CS * ((H + K - 1) / K + 1);
         h->Q.K = (int)K; h->Q.cap = (int)cap; h->Q.par = 0;
-        A(&h->Q.items, 2 * K * cap); A(&h->Q.count, 2 * K); A(&h->Q.head, K);
-        A(&h->Q.s_items, K * cap); A(&h->Q.s_count, K); A(&h->Q.s_head, K);
+        A(&h->Q.items, 2 * K * cap); A(&h->Q.count, 2 * K * QPAD); A(&h->Q.head, K * QPAD);
         AX(&h->Q.done_count, B * CS);
         A(&h->d_window, B * (H + 2));
         h->Q.window = h->d_window;
@@ -428,6 +433,9 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     }
     S.Q = h->d_Q; S.R = h->d_R; S.Qinv = h->d_Qinv; S.Rinv = h->d_Rinv; S.Cg = h->d_Cg; S.Cb = h->d_Cb;
     S.r_tol = h->nt.r_tol; S.beta_init = h->nt.beta_init; S.kappa = h->nt.kappa; S.max_iter = h->nt.max_iter;
+    // all-seven-step-lengths speculation: shortens the chain of rollouts that exhaust their line search; pays
+    // when the solve is latency-bound (small batches), costs throughput otherwise (B = 2048: -8 %)
+    S.spec_all = getenv("CIMPC_SPEC_ALL") ? atoi(getenv("CIMPC_SPEC_ALL")) : (d.B <= 128 ? 3 : 8);
     // small batches: one wave per workgroup keeps every problem on its own CU (latency);
     // large batches: 4 waves share one staged table (throughput)
     h->waves = (B * H >= 4096) ? 4 : 1;
@@ -449,7 +457,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         const size_t K = d.H_ref;
         if (h->async_on) {
             if (dev_alloc(h, &h->a_items, K * h->a_cap, xm) != CIMPC_OK || dev_alloc(h, &h->a_jobs, h->a_rq_cap + h->a_kq_cap, xm) != CIMPC_OK ||
-                dev_alloc(h, &h->a_ctrl, 2 * K + 16, xm) != CIMPC_OK || dev_alloc(h, &h->a_evals, B, xm) != CIMPC_OK) {
+                dev_alloc(h, &h->a_ctrl, 2 * K * QPAD + 64 + 32 * 16, xm) != CIMPC_OK || dev_alloc(h, &h->a_evals, B, xm) != CIMPC_OK) {
                 g_create_error = h->err; cimpc_destroy(h); return CIMPC_ERR_HIP;
             }
             if (getenv("CIMPC_ASYNC_DEBUG") && dev_alloc(h, &h->a_dbg, 16) != CIMPC_OK) { g_create_error = h->err; cimpc_destroy(h); return CIMPC_ERR_HIP; }
@@ -700,10 +708,8 @@ int cimpc_implicit_dynamics(cimpc_handle h, const double* q, const double* theta
     if (gamma) HIP_TRY(h, up(T.g, gamma, H * d.nc));
     if (b) HIP_TRY(h, up(T.b, b, H * d.nb));
     // queue slot 0 of every rollout, then run rounds until no solve is parked
-    HIP_TRY(h, hipMemsetAsync(h->Q.count, 0, 2 * h->Q.K * sizeof(int), h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->Q.head, 0, h->Q.K * sizeof(int), h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->Q.s_count, 0, h->Q.K * sizeof(int), h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->Q.s_head, 0, h->Q.K * sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->Q.count, 0, 2 * h->Q.K * QPAD * sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->Q.head, 0, h->Q.K * QPAD * sizeof(int), h->stream));
     {
         NewtonDev Sk = h->S;
         Sk.WQ = h->Q; Sk.WQ.par = 0;
@@ -715,10 +721,8 @@ int cimpc_implicit_dynamics(cimpc_handle h, const double* q, const double* theta
         HIP_TRY(h, hipMemsetAsync(h->S.counters, 0, 8 * sizeof(int), h->stream));
         rc = run_sweep(h, par, h->S.counters + 2, z ? h->d_zout : nullptr, h->stream);
         if (rc != CIMPC_OK) return rc;
-        HIP_TRY(h, hipMemsetAsync(h->Q.count + par * h->Q.K, 0, h->Q.K * sizeof(int), h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->Q.head, 0, h->Q.K * sizeof(int), h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->Q.s_count, 0, h->Q.K * sizeof(int), h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->Q.s_head, 0, h->Q.K * sizeof(int), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->Q.count + (size_t)par * h->Q.K * QPAD, 0, h->Q.K * QPAD * sizeof(int), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->Q.head, 0, h->Q.K * QPAD * sizeof(int), h->stream));
         HIP_TRY(h, hipMemcpyAsync(h->h_counters, h->S.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         if (h->h_counters[2] == 0) break;
@@ -765,8 +769,10 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     };
     HIP_TRY(h, hipMemsetAsync(S.stats, 0, 4 * sizeof(long long), h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (h->async_on) {
-        // ---- one persistent launch: every rollout advances on its own chain (newton_async_impl.h) ----
+    // ---- one persistent launch: every rollout advances on its own chain (newton_async_impl.h).  Entered
+    //      from the start (from_reset) or with the rollouts the lock-step rounds left active (hybrid). ----
+    auto run_async = [&](bool from_reset, long long rounds_before) -> int {
+        IpQueues LQ = h->Q; LQ.par = (int)(rounds_before & 1);      // lock-step queue of the round that would come next
         hipStream_t st = h->external_stream ? h->stream : h->subs[0].st;
         const size_t K = h->Q.K;
         if (h->async_dirty) {     // entries are reset by their consumers; only an aborted solve leaves some behind
@@ -774,7 +780,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             HIP_TRY(h, hipMemsetAsync(h->a_jobs, 0xFF, (h->a_rq_cap + h->a_kq_cap) * sizeof(int), st));
             h->async_dirty = false;
         }
-        HIP_TRY(h, hipMemsetAsync(h->a_ctrl, 0, (2 * K + 16) * sizeof(int), st));
+        HIP_TRY(h, hipMemsetAsync(h->a_ctrl, 0, (2 * K * QPAD + 64 + 32 * 16) * sizeof(int), st));
         volatile int* hm = (volatile int*)h->h_ring;
         hm[3] = 0;
         NewtonDev Sk = S;
@@ -782,13 +788,14 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         Sk.host_flag = h->h_ring_dev;
         Sk.WQ = h->Q; Sk.WQ.par = 0;
         Sk.WQ.items = h->a_items; Sk.WQ.cap = (int)h->a_cap;
-        Sk.WQ.count = h->a_ctrl; Sk.WQ.head = h->a_ctrl + K;
+        Sk.WQ.count = h->a_ctrl; Sk.WQ.head = h->a_ctrl + K * QPAD;
         AsyncQ& A = Sk.A;
         A.on = 1;
-        int* c = h->a_ctrl + 2 * K;
-        A.rq_items = h->a_jobs; A.rq_head = c + 0; A.rq_tail = c + 1;
-        A.kq_items = h->a_jobs + h->a_rq_cap; A.kq_head = c + 2; A.kq_tail = c + 3;
-        A.n_done = c + 4;
+        int* c = h->a_ctrl + 2 * K * QPAD;
+        A.rq_items = h->a_jobs; A.rq_head = c + 0; A.rq_tail = c + 16;
+        A.kq_items = h->a_jobs + h->a_rq_cap; A.kq_head = c + 32; A.kq_tail = c + 48;
+        A.n_done = c + 8;
+        A.epoch = c + 64;
         A.evals_left = h->a_evals;
         A.abort_flag = (volatile int*)(h->h_ring_dev + 3);
         A.n_service = h->a_service;
@@ -798,17 +805,17 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         if (h->a_dbg) HIP_TRY(h, hipMemsetAsync(h->a_dbg, 0, 16 * sizeof(long long), st));
         A.B = h->dm.B;
         prof_begin(h, PC_OTHER, st);
-        rc = launch_reset(Sk, q0_dev, q1_dev, warm_start, st);
+        int rc2 = from_reset ? launch_reset(Sk, q0_dev, q1_dev, warm_start, st) : launch_async_handoff(Sk, LQ, st);
         prof_end(h, st);
-        if (rc != CIMPC_OK) return fail(h, rc, "reset launch failed");
+        if (rc2 != CIMPC_OK) return fail(h, rc2, "reset / hand-off launch failed");
         IpParams p = make_ip_params(h, S.cand, 0, h->d_ring + 2, nullptr);
         p.Q = Sk.WQ;
-        p.iter_cap = h->ip.max_iter + 1;      // no solve is parked
+        p.iter_cap = h->ip.max_iter + 1;      // no solve is parked (solves parked by the lock-step rounds resume and finish)
         p.A = A;
         prof_begin(h, PC_IP, st);
-        rc = launch_newton_async(&h->dm, p, Sk, h->waves, h->a_grid, st);
+        rc2 = launch_newton_async(&h->dm, p, Sk, h->waves, h->a_grid, st);
         prof_end(h, st);
-        if (rc != CIMPC_OK) return fail(h, rc, "asynchronous newton launch failed");
+        if (rc2 != CIMPC_OK) return fail(h, rc2, "asynchronous newton launch failed");
         if (h->nt.max_time > 0.0 && h->nt.max_time < 1.0e6) {      // newton.jl:187-277: the time budget ends the loop silently
             while (hipStreamQuery(st) == hipErrorNotReady) {
                 if (over_budget()) { hm[3] = 1; h->async_dirty = true; break; }
@@ -818,8 +825,8 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         if (h->a_dbg) {
             long long dv[16];
             HIP_TRY(h, hipMemcpy(dv, h->a_dbg, sizeof(dv), hipMemcpyDeviceToHost));
-            fprintf(stderr, "[cimpc async] WG-ms: other %.2f kkt %.2f resid %.2f ip %.2f | jobs: kkt %lld resid %lld serve %lld | grid %d service %d\n",
-                    dv[0] * 1e-5, dv[1] * 1e-5, dv[2] * 1e-5, dv[3] * 1e-5, dv[9], dv[10], dv[11], h->a_grid, h->a_service);
+            fprintf(stderr, "[cimpc async] WG-ms: other %.2f kkt %.2f resid %.2f ip %.2f | jobs: kkt %lld resid %lld serve %lld | grid %d service %d | group-trips %.2fM active %.1f%% | group-ms pop %.1f fence %.1f | pop: cas %lld spins %lld claim-ms %.1f wait-ms %.1f\n",
+                    dv[0] * 1e-5, dv[1] * 1e-5, dv[2] * 1e-5, dv[3] * 1e-5, dv[9], dv[10], dv[11], h->a_grid, h->a_service, dv[5] * 1e-6, dv[5] ? 100.0 * dv[4] / dv[5] : 0.0, dv[6] * 1e-5, dv[7] * 1e-5, dv[12], dv[13], dv[14] * 1e-5, dv[15] * 1e-5);
         }
         long long stv[4];
         HIP_TRY(h, hipMemcpy(stv, S.stats, sizeof(stv), hipMemcpyDeviceToHost));
@@ -829,13 +836,16 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         h->last_stats.ip_solves = stv[1];
         h->last_stats.ip_iters = stv[2];
         h->last_stats.ip_failures = stv[3];
-        h->last_stats.rounds = 1;
+        h->last_stats.rounds = rounds_before + 1;
         h->last_stats.newton_iters = 0;
         for (int v : l) h->last_stats.newton_iters += v;
         h->prof_ip_problems += stv[1];
-        h->prof_kkt_systems += h->last_stats.newton_iters;
+        if (from_reset) h->prof_kkt_systems += h->last_stats.newton_iters;
         return CIMPC_OK;
-    }
+    };
+    const bool full_async = h->async_on && (h->async_mode == 1 || (h->async_mode == 2 && h->dm.B >= 8 && h->dm.B <= 128));
+    const bool hybrid = h->async_on && h->async_mode == 2 && !full_async && h->dm.B > 128;
+    if (full_async) return run_async(true, 0);
     // safety net only: every Newton iteration needs at most 3 (speculative) rounds, each evaluation at
     // most ceil(max_iter / iter_cap) launches of the resumable interior-point sweep
     const int max_rounds = (h->nt.max_iter * 8 + 2) * ((h->ip.max_iter + h->iter_cap - 1) / h->iter_cap + 1);
@@ -854,6 +864,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     // rounds launched after the batch has finished find empty queues and return immediately.
     const int depth = h->pipeline_depth;
     long long launched = 0, completed = 0, rounds = 0;
+    static const bool dbg_rounds = getenv("CIMPC_DEBUG_ROUNDS") != nullptr;
     int last_kkt = 0, last_sweep = h->dm.B;
     auto launch_round = [&](long long r) -> int {
         // [KKT for rollouts that start an iteration] || sweep -> residual + line-search decision
@@ -863,6 +874,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         Sk.b0 = 0; Sk.nb_launch = h->dm.B; Sk.counters = d_cnt;
         Sk.counters_next = h->d_ring + 8 * (slot ^ 1);
         Sk.host_flag = h->h_ring_dev;
+        Sk.A.n_done = hybrid ? h->a_ctrl + 2 * (size_t)h->Q.K * QPAD + 8 : nullptr;
         Sk.round_stamp = (int)(r + 1);
         Sk.WQ = h->Q; Sk.WQ.par = (int)(r & 1);       // round parity selects the queue being consumed
         const bool kkt = (r > 0) && (depth > 1 || last_kkt > 0);
@@ -894,11 +906,10 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         if (rr != CIMPC_OK) return fail(h, rr, "residual launch failed");
         return CIMPC_OK;
     };
-    HIP_TRY(h, hipMemsetAsync(h->Q.count, 0, 2 * h->Q.K * sizeof(int), sb.st));
-    HIP_TRY(h, hipMemsetAsync(h->Q.head, 0, h->Q.K * sizeof(int), sb.st));
-    HIP_TRY(h, hipMemsetAsync(h->Q.s_count, 0, h->Q.K * sizeof(int), sb.st));
-    HIP_TRY(h, hipMemsetAsync(h->Q.s_head, 0, h->Q.K * sizeof(int), sb.st));
+    HIP_TRY(h, hipMemsetAsync(h->Q.count, 0, 2 * h->Q.K * QPAD * sizeof(int), sb.st));
+    HIP_TRY(h, hipMemsetAsync(h->Q.head, 0, h->Q.K * QPAD * sizeof(int), sb.st));
     HIP_TRY(h, hipMemsetAsync(h->d_ring, 0, 16 * sizeof(int), sb.st));
+    if (hybrid) HIP_TRY(h, hipMemsetAsync(h->a_ctrl + 2 * (size_t)h->Q.K * QPAD, 0, 64 * sizeof(int), sb.st));
     ((volatile int*)h->h_ring)[2] = 0;
     {
         NewtonDev Sk = S;
@@ -928,10 +939,25 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         const int n_sweep = ((volatile int*)h->h_ring)[0];
         last_sweep = n_sweep;
         last_kkt = ((volatile int*)h->h_ring)[1];
+        if (dbg_rounds) fprintf(stderr, "[cimpc round %lld] t %.3f ms: next sweep %d rollouts, next kkt %d, parked %d, finished %d\n", completed,
+                                1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), n_sweep, last_kkt,
+                                ((volatile int*)h->h_ring)[4], ((volatile int*)h->h_ring)[5]);
         h->prof_kkt_systems += last_kkt;
         ++completed;
         rounds = completed;
         if ((n_sweep == 0 && last_kkt == 0) || over_budget()) break;   // newton.jl:187-277: budget ends silently
+        if (hybrid && launched == completed) {
+            // sparse tail: few rollouts left, every round pays its fixed latency for them -> the persistent
+            // kernel finishes them along their own chains (needs a round boundary with no parked solve)
+            const int parked = ((volatile int*)h->h_ring)[4], active = h->dm.B - ((volatile int*)h->h_ring)[5];
+            (void)parked;
+            if (active > 0 && active <= h->async_tail) {
+                HIP_TRY(h, hipStreamSynchronize(sb.st));
+                HIP_TRY(h, hipStreamSynchronize(sb.st_kkt));
+                h->prof_kkt_systems += 0;
+                return run_async(false, rounds);
+            }
+        }
     }
     HIP_TRY(h, hipStreamSynchronize(sb.st));
     HIP_TRY(h, hipStreamSynchronize(sb.st_kkt));

@@ -14,13 +14,12 @@ namespace cimpc {
 // balance: solves take 4..100 iterations).  Queues are double buffered by round parity: round r
 // consumes items[par], solves parked after iter_cap iterations and the evaluations requested by
 // the line search are appended to items[par ^ 1].
+constexpr int QPAD = 32;   // ints between two queue counters
+
 struct IpQueues {
     int* items;         // [2][K][cap]  problem id = sb*H + i
-    int* count;         // [2][K]
-    int* head;          // [K]      consumption cursor of items[par]
-    int* s_items;       // [K][cap] converged problems waiting for their sensitivities
-    int* s_count;       // [K]
-    int* s_head;        // [K]
+    int* count;         // [2][K] * QPAD   (every counter on its own 128-byte line: same-line atomics
+    int* head;          // [K] * QPAD       serialise at ~50 ns each and all lane groups of a knot hit them)
     int* done_count;    // [B*slots] finished problems of the evaluation held by each slot
     const int* window;  // [B][H+2] 0-based reference-knot indices
     int cap, K, par;
@@ -41,6 +40,8 @@ struct AsyncQ {
     int* kq_tail;
     int* evals_left;    // [B] evaluation slots of the rollout's running line-search batch not yet complete
     int* n_done;        // rollouts whose Newton solve has ended
+    int* epoch;         // wake-up words, 64 B apart: [0,16) interior-point work, [16,32) jobs; bucket = rollout % 16.
+                        // An idle workgroup polls only the two words of its own bucket (blockIdx % 16).
     volatile int* abort_flag;   // host-mapped: nonzero = time budget exhausted, leave
     long long* dbg;     // [16] diagnostics (busy ticks / job counts per kind of work) or null
     int n_service;      // workgroups [0, n_service) only take residual / KKT jobs
@@ -75,20 +76,33 @@ __device__ __forceinline__ void aq_push(int* items, int* tail, int v) {
     const int pos = atomicAdd(tail, 1);
     astore(items + pos, v);
 }
-// multi-consumer pop by ONE lane: -1 when the queue is empty
-__device__ __forceinline__ int aq_pop(int* items, int* head, const int* tail) {
+// multi-consumer pop by ONE lane: -1 when the queue is empty.  dbg (optional): [0] CAS attempts, [1] sentinel spins,
+// [2] ticks in the claim loop, [3] ticks waiting for the entry
+__device__ __forceinline__ int aq_pop(int* items, int* head, const int* tail, long long* dbg = nullptr) {
+    const long long t0 = dbg ? wall_clock64() : 0;
     int h = aload(head);
+    int cas = 0;
     while (true) {
-        if (h >= aload(tail)) return -1;
+        if (h >= aload(tail)) { if (dbg) { dbg[0] += cas; dbg[2] += wall_clock64() - t0; } return -1; }
         const int old = atomicCAS(head, h, h + 1);
+        ++cas;
         if (old == h) break;
         h = old;
     }
-    int v;
-    while ((v = aload(items + h)) < 0) __builtin_amdgcn_s_sleep(1);
+    const long long t1 = dbg ? wall_clock64() : 0;
+    int v, spins = 0;
+    while ((v = aload(items + h)) < 0) { __builtin_amdgcn_s_sleep(1); ++spins; }
     astore(items + h, -1);        // the queue is clean again when every entry has been consumed
+    if (dbg) { dbg[0] += cas; dbg[1] += spins; dbg[2] += t1 - t0; dbg[3] += wall_clock64() - t1; }
     return v;
 }
+
+__device__ __forceinline__ void wake_ip(const AsyncQ& A, int b) { atomicAdd(A.epoch + (b & 15) * 16, 1); }
+__device__ __forceinline__ void wake_job(const AsyncQ& A, int b) { atomicAdd(A.epoch + (16 + (b & 15)) * 16, 1); }
+__device__ __forceinline__ void wake_all(const AsyncQ& A) { for (int k = 0; k < 32; ++k) atomicAdd(A.epoch + k * 16, 1); }
+
+__device__ __forceinline__ int* qcount(const IpQueues& Q, int par, int k) { return Q.count + ((size_t)par * Q.K + k) * QPAD; }
+__device__ __forceinline__ int* qhead(const IpQueues& Q, int k) { return Q.head + (size_t)k * QPAD; }
 
 struct IpParams {
     const double* tab;     // [H_ref][LinLayout::size]   packed linearization tables

@@ -292,6 +292,7 @@ __device__ __forceinline__ void problem_done(const IpParams& p, int sb, int l) {
                 if (atomicSub(&p.A.evals_left[b], 1) == 1) {
                     xfence(p.A.flags);
                     aq_push(p.A.rq_items, p.A.rq_tail, b);
+                    wake_job(p.A, b);
                 }
             }
         }
@@ -347,7 +348,7 @@ __device__ __forceinline__ int pick_knot(const IpParams& p, int* s_rem, int* s_t
     {
         int part = 0;
         for (int k = tid; k < K; k += (int)blockDim.x) {
-            int rem = aload(p.Q.count + par * K + k) - aload(p.Q.head + k);
+            int rem = aload(qcount(p.Q, par, k)) - aload(qhead(p.Q, k));
             rem = rem > 0 ? rem : 0;
             if (k < PICK_MAXK) s_rem[k] = rem;
             part += rem;
@@ -362,7 +363,7 @@ __device__ __forceinline__ int pick_knot(const IpParams& p, int* s_rem, int* s_t
             const long long target = ((long long)wg * total) / (long long)nwg;
             long long acc = 0;
             for (int k = 0; k < K; ++k) {
-                const int rem = k < PICK_MAXK ? s_rem[k] : max(0, aload(p.Q.count + par * K + k) - aload(p.Q.head + k));
+                const int rem = k < PICK_MAXK ? s_rem[k] : max(0, aload(qcount(p.Q, par, k)) - aload(qhead(p.Q, k)));
                 if (rem > 0) { pick = k; acc += rem; if (acc > target) break; }
             }
         }
@@ -394,17 +395,19 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
     const bool vx = l < NX, vy = l < NY;
     const cimpc_ip_opts o = p.o;
 
-    const int n = ASYNC ? 1 : p.Q.count[par * K + knot];
+    const int n = ASYNC ? 1 : *qcount(p.Q, par, knot);
     stage_table<M>(tab, p.tab, knot, tid);
     __syncthreads();
     const int* items = p.Q.items + ((size_t)par * K + knot) * cap;
-    int* head = p.Q.head + knot;
-    [[maybe_unused]] const int* tailp = p.Q.count + par * K + knot;
+    int* head = qhead(p.Q, knot);
+    [[maybe_unused]] const int* tailp = qcount(p.Q, par, knot);
     IpSolver<M> S;
     S.bind(tab, Rst, l);        // caches the per-lane constants of this knot's table
     bool have = false, exhausted = false, stalled = false;
     int prob = 0, iters = 0, done_here = 0;
-    [[maybe_unused]] int idle_trips = 0;
+    [[maybe_unused]] int idle_trips = 0, dbg_trips = 0, dbg_act = 0;
+    [[maybe_unused]] long long dbg_tpop = 0, dbg_tfence = 0;
+    [[maybe_unused]] long long dbg_pop[4] = {0, 0, 0, 0};
     double reg = 0.0, r_vio = 0.0, k_vio = 0.0, qinit = 0.0;
 
     while (true) {
@@ -425,7 +428,7 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
                     if (l == 0) {
                         ps[PS - 4] = r_vio; ps[PS - 3] = k_vio; ps[PS - 2] = reg; ps[PS - 1] = (double)iters;
                         p.pflag[pi] = 1;
-                        const int pos = atomicAdd(&p.Q.count[(par ^ 1) * K + knot], 1);
+                        const int pos = atomicAdd(qcount(p.Q, par ^ 1, knot), 1);
                         p.Q.items[((size_t)(par ^ 1) * K + knot) * cap + pos] = prob;
                         atomicAdd(p.pending_count, 1);
                     }
@@ -448,7 +451,7 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
                         if (l == 0) { ps[PS - 2] = reg; backlog[nback] = prob; }
                         ++nback;
                     } else {                 // failed: the slot keeps its previous sensitivities
-                        problem_done<ASYNC>(p, sb, l);
+                        { const long long t0 = wall_clock64(); problem_done<ASYNC>(p, sb, l); if constexpr (ASYNC) dbg_tfence += wall_clock64() - t0; }
                     }
                 }
                 have = false;
@@ -456,13 +459,16 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
         }
         // ---- 2. pull the next problem of this knot -----------------------------------------
         // (ASYNC: the queue is live - an idle group looks again every few trips while its wave is busy)
-        if (!have && (!exhausted || (ASYNC && !(p.A.flags & 2) && (++idle_trips & 3) == 0))) {
+        if (!have && (!exhausted || (ASYNC && !(p.A.flags & 2) && (++idle_trips & 7) == 0))) {
             int idx = 0, item = 0;
             if constexpr (ASYNC) {       // live queue: claim only what has been published
-                if (l == 0) item = aq_pop(const_cast<int*>(items), head, tailp);
+                const long long tq0 = wall_clock64();
+                if (l == 0) item = aq_pop(const_cast<int*>(items), head, tailp, p.A.dbg ? dbg_pop : nullptr);
                 item = group_bcast0<G>(item);
                 idx = item < 0 ? n : 0;
+                const long long tq1 = wall_clock64();
                 if (item >= 0) xfence(p.A.flags);      // acquire the candidate trajectory of the producer
+                dbg_tpop += tq1 - tq0; dbg_tfence += wall_clock64() - tq1;
             } else {
                 if (l == 0) idx = atomicAdd(head, 1);
                 idx = group_bcast0<G>(idx);
@@ -527,6 +533,7 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
         //         every group of the wave has something in its backlog (all four groups then run
         //         the same code on their own problem - no SIMT divergence), when the wave has no
         //         interior-point work left, or when a backlog is full.
+        if constexpr (ASYNC) { dbg_trips += 1; dbg_act += have ? 1 : 0; }
         const bool any_ip = __any(have ? 1 : 0);
         if (!any_ip && !__any(nback > 0 ? 1 : 0)) break;
         // (ASYNC: a finished solve must not wait for its neighbours' work to dry up - the rollout's next
@@ -547,6 +554,15 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
             const int pr = group_bcast0<G>((l == 0) ? backlog[nback] : 0);
             sensitivities<M, ASYNC>(p, S, tab, pr, l);
             S.x = sx; S.y1 = sy1; S.y2 = sy2; S.rdyn = sd; S.rrst = sr; S.rbil = sb_; S.tthdyn = st; S.tthrst = su; S.altl = sa;
+        }
+    }
+    if constexpr (ASYNC) {      // diagnostics: group-trips with / without a problem
+        if (p.A.dbg != nullptr && l == 0) {
+            atomicAdd((unsigned long long*)p.A.dbg + 4, (unsigned long long)dbg_act);
+            atomicAdd((unsigned long long*)p.A.dbg + 5, (unsigned long long)dbg_trips);
+            atomicAdd((unsigned long long*)p.A.dbg + 6, (unsigned long long)dbg_tpop);
+            atomicAdd((unsigned long long*)p.A.dbg + 7, (unsigned long long)dbg_tfence);
+            for (int k = 0; k < 4; ++k) atomicAdd((unsigned long long*)p.A.dbg + 12 + k, (unsigned long long)dbg_pop[k]);
         }
     }
 }

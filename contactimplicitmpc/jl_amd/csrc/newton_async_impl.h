@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void newton_async_kernel(AsyncArgs args) {
     static_assert(M::MODE == CIMPC_MODE_CONFIGURATION, "the KKT stage implements :configuration");
     constexpr int NQ = M::NQ, NU = M::NU;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ int s_knot, s_total, s_rem[PICK_MAXK], s_job[2];
+    __shared__ int s_knot, s_total, s_rem[PICK_MAXK], s_job[2], s_epoch[2];
     __shared__ double red[256];
     __shared__ double rc[CS];
     __shared__ int sh[4];
@@ -89,6 +89,9 @@ __global__ __launch_bounds__(256, 2) void newton_async_kernel(AsyncArgs args) {
         __syncthreads();
         if (tid == 0) {
             int type = 0, job = -1;
+            // wake-up words of this workgroup's bucket, read BEFORE looking for work (a push during the scan changes them)
+            s_epoch[0] = aload(A.epoch + ((int)blockIdx.x & 15) * 16);
+            s_epoch[1] = aload(A.epoch + (16 + ((int)blockIdx.x & 15)) * 16);
             // the abort flag lives in host memory (one PCIe read): looked at now and then only
             if ((trip++ & 31u) == 31u && *A.abort_flag != 0) {
                 type = 3;
@@ -128,10 +131,24 @@ __global__ __launch_bounds__(256, 2) void newton_async_kernel(AsyncArgs args) {
                 continue;
             }
         }
-        if (tid == 0) s_job[0] = (aload(A.n_done) >= A.B) || ((trip & 7u) == 0 && *A.abort_flag != 0);
+        // Nothing to do right now.  Idle workgroups must stay off the queue counters (hundreds of
+        // pollers on a handful of cache lines inflate the memory latency of the working ones ~10x:
+        // measured SQ_INST_LEVEL_VMEM / SQ_INSTS_VMEM 16 -> 200).  They wait on the two wake-up words of
+        // their bucket, which producers bump after publishing, and look around anyway every ~100 us.
+        if (tid == 0) {
+            int leave = aload(A.n_done) >= A.B;
+            const int* wi = A.epoch + ((int)blockIdx.x & 15) * 16;
+            const int* wj = A.epoch + (16 + ((int)blockIdx.x & 15)) * 16;
+            unsigned spins = 0;
+            while (!leave && (service || aload(wi) == s_epoch[0]) && aload(wj) == s_epoch[1]) {
+                for (int k = 0; k < A.idle_sleep; ++k) __builtin_amdgcn_s_sleep(64);
+                if (++spins >= 48u) break;
+            }
+            if (!leave && *A.abort_flag != 0) leave = 1;
+            s_job[0] = leave;
+        }
         __syncthreads();
         if (s_job[0]) break;
-        for (int k = 0; k < A.idle_sleep; ++k) __builtin_amdgcn_s_sleep(64);    // back off: idle pollers must not crowd the queue counters
     }
 }
 

@@ -47,6 +47,9 @@ __device__ __forceinline__ void copy_n(double* dst, const double* src, int n, in
 //     round A: alpha = 1                      (slot 0)
 //     round B: alpha = 1/2, 1/4               (slots 0-1)
 //     round C: alpha = 1/8, 1/16, 1/32, 1/64  (slots 0-3)
+// or, for a rollout whose PREVIOUS line search needed round C (typically one sitting at its
+// residual floor, which exhausts the search in every iteration), all seven step lengths in one
+// round (STAGE_LS7, slots 0-6):
 // and the first alpha (in the reference's order) that passes the Armijo-type test is taken, so the
 // accepted step, residual and implicit-dynamics data are exactly those the sequential loop would
 // have produced.  Every "evaluation" array (candidate trajectory, nu_cand, d, dz, status,
@@ -60,7 +63,7 @@ __device__ __forceinline__ void enqueue_eval(const NewtonDev& S, size_t sb, int 
     const int H = S.dm.H, K = S.WQ.K;
     for (int k = tid; k < H; k += nt) {
         const int t = S.WQ.window[(size_t)b * (H + 2) + k];
-        const int pos = atomicAdd(&S.WQ.count[par * K + t], 1);
+        const int pos = atomicAdd(qcount(S.WQ, par, t), 1);
         S.WQ.items[((size_t)par * K + t) * S.WQ.cap + pos] = (int)(sb * H + k);
     }
     if (tid == 0) {
@@ -84,8 +87,10 @@ __device__ __forceinline__ void enqueue_eval_async(const NewtonDev& S, size_t sb
     for (int e = tid; e < nslots * H; e += nt) {
         const int c = e / H, k = e - c * H;
         const int t = S.WQ.window[(size_t)b * (H + 2) + k];
-        aq_push(S.WQ.items + (size_t)t * S.WQ.cap, S.WQ.count + t, (int)((sb0 + c) * H + k));
+        aq_push(S.WQ.items + (size_t)t * S.WQ.cap, qcount(S.WQ, 0, t), (int)((sb0 + c) * H + k));
     }
+    Sync::sync();
+    if (tid == 0) wake_ip(S.A, b);      // wake (a sixteenth of) the idle workgroups
 }
 
 // x_dst = traj - alpha*Delta for q_{t+2}, u_t, nu_t (+ gamma, b in cf mode), then update_theta!.
@@ -136,6 +141,31 @@ __device__ __forceinline__ void apply_step(const NewtonDev& S, const TrajDev& ds
     }
     Sync::sync();
 }
+
+// Line-search start after the KKT solve (newton.jl:223-228): candidate(s) = traj - alpha*Delta.  One
+// candidate (alpha = 1), or all seven when the rollout's previous search went deep (see above).
+// mode 1: lock-step (queue `par`), mode 2: asynchronous solve (live queues).
+template <class Sync>
+__device__ __forceinline__ void start_line_search(const NewtonDev& S, int b, int mode, int lane, int nt) {
+    const size_t sb0 = (size_t)b * CS;
+    const int n = (S.newton_l[b] > 0 && S.ls_iter[b] >= S.spec_all) ? 7 : 1;
+    Sync::sync();
+    for (int c = 0; c < n; ++c) apply_step<Sync>(S, S.cand, S.nu_cand, sb0 + c, b, ls_alpha(c), lane, nt);
+    if (lane == 0) { S.alpha[b] = 1.0; S.ls_iter[b] = 0; S.stage[b] = (n == 7) ? STAGE_LS7 : STAGE_LS0; }
+    if (mode == 2) {
+        enqueue_eval_async<Sync>(S, sb0, n, b, lane, nt);
+    } else {
+        // the KKT kernel runs on its own stream NEXT TO the sweep of the running round: its
+        // candidates join the queue of the next round
+        const int par = S.kkt_same_round ? S.WQ.par : (S.WQ.par ^ 1);
+        for (int c = 0; c < n; ++c) enqueue_eval(S, sb0 + c, b, par, lane, nt);
+        if (lane == 0) {
+            for (int c = n; c < CS; ++c) S.need_sweep[sb0 + c] = 0;
+            atomicAdd(&S.counters[0], 1);
+        }
+    }
+}
+
 
 // residual! on evaluation slot sb (candidate trajectory, nu_cand, d, dz of that slot); returns |r|_1
 template <int NQ, int NU, bool CF>
@@ -231,13 +261,13 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
     const size_t sb0 = (size_t)b * CS;
     if (!ASYNC && blockIdx.x == 0) {   // the queue of this round has been consumed: recycle it
         const int K = S.WQ.K, par = S.WQ.par;
-        for (int k = tid; k < K; k += nt) { S.WQ.count[par * K + k] = 0; S.WQ.head[k] = 0; S.WQ.s_count[k] = 0; S.WQ.s_head[k] = 0; }
+        for (int k = tid; k < K; k += nt) { *qcount(S.WQ, par, k) = 0; *qhead(S.WQ, k) = 0; }
         if (tid < 8) S.counters_next[tid] = 0;      // counter block of the next round
     }
     const int stage = S.stage[b];
     if (stage == STAGE_DONE || stage == STAGE_KKT) return;
     if (S.need_sweep[sb0] == 0) return;          // nothing was evaluated for this rollout
-    const int ncand = (stage == STAGE_LS1) ? 2 : (stage == STAGE_LS2) ? 4 : 1;
+    const int ncand = (stage == STAGE_LS1) ? 2 : (stage == STAGE_LS2) ? 4 : (stage == STAGE_LS7) ? 7 : 1;
     if constexpr (!ASYNC) {   // an interior-point solve of this evaluation is still parked: wait for the next round
         int pend = 0;
         if (tid < ncand) pend = (S.WQ.done_count[sb0 + tid] < H);
@@ -259,13 +289,13 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
             act = 0;
         } else {
             const double rn2 = S.r_norm[b] * S.r_norm[b];
-            const int it0 = (stage == STAGE_LS0) ? 0 : (stage == STAGE_LS1) ? 1 : 3;
+            const int it0 = (stage == STAGE_LS1) ? 1 : (stage == STAGE_LS2) ? 3 : 0;
             for (int c = 0; c < ncand; ++c) {
                 const double a = ls_alpha(it0 + c);
                 if (!(rc[c] * rc[c] >= (1.0 - 0.001 * a) * rn2)) { act = 1; slot = c; iter = it0 + c; break; }
             }
-            if (act == 2 && stage == STAGE_LS2) {   // iter = 7 > 6: break out, halved alpha, last evaluation
-                act = 1; slot = 3; iter = 7;
+            if (act == 2 && (stage == STAGE_LS2 || stage == STAGE_LS7)) {   // iter = 7 > 6: break out, halved alpha, last evaluation
+                act = 1; slot = ncand - 1; iter = 7;
             }
         }
         s_act = act; s_slot = slot; s_iter = iter;
@@ -347,6 +377,7 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
         for (int c = 0; c < CS; ++c) S.need_sweep[sb0 + c] = 0;
         if (done) {
             S.stage[b] = STAGE_DONE;
+            if (!ASYNC && S.A.n_done != nullptr) atomicAdd(S.A.n_done, 1);    // finished rollouts of this solve (hybrid hand-off)
         } else {
             S.stage[b] = STAGE_KKT;
             if constexpr (!ASYNC) atomicAdd(&S.counters[1], 1);
@@ -357,8 +388,12 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
         xfence(S.A.flags);
         __syncthreads();
         if (tid == 0) {
-            if (sh[3]) atomicAdd(S.A.n_done, 1);
-            else aq_push(S.A.kq_items, S.A.kq_tail, b);
+            if (sh[3]) {
+                if (atomicAdd(S.A.n_done, 1) == S.A.B - 1) wake_all(S.A);     // the solve is over: everybody leaves
+            } else {
+                aq_push(S.A.kq_items, S.A.kq_tail, b);
+                wake_job(S.A, b);
+            }
         }
     }
 }
@@ -380,6 +415,8 @@ __global__ __launch_bounds__(256) void resid_decide_kernel(NewtonDev S) {
             volatile int* hm = S.host_flag;
             hm[0] = n_sweep;
             hm[1] = n_kkt;
+            hm[4] = atomicAdd(&S.counters[2], 0);                                   // solves parked by this round
+            hm[5] = S.A.n_done != nullptr ? atomicAdd(S.A.n_done, 0) : 0;            // rollouts finished so far
             __threadfence_system();
             hm[2] = S.round_stamp;
             __threadfence_system();
@@ -780,19 +817,7 @@ __global__ __launch_bounds__(64) void kkt_kernel_scalar(NewtonDev S, KktArgs K) 
 #endif
     if (K.finish) {
         __threadfence_block();
-        lds_sync();
-        // line search start (newton.jl:223-228): alpha = 1, candidate = traj - Delta
-        apply_step<BlockSync>(S, S.cand, S.nu_cand, (size_t)b * CS, b, 1.0, lane, 64);
-        // the KKT kernel runs on its own stream NEXT TO the sweep of the running round: its
-        // candidates join the queue of the next round
-        enqueue_eval(S, (size_t)b * CS, b, S.kkt_same_round ? S.WQ.par : (S.WQ.par ^ 1), lane, 64);
-        if (lane == 0) {
-            S.alpha[b] = 1.0;
-            S.ls_iter[b] = 0;
-            S.stage[b] = STAGE_LS0;
-            for (int c = 1; c < CS; ++c) S.need_sweep[(size_t)b * CS + c] = 0;
-            atomicAdd(&S.counters[0], 1);
-        }
+        start_line_search<BlockSync>(S, b, 1, lane, 64);
     }
 }
 
@@ -1148,27 +1173,9 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
 #ifdef CIMPC_KKT_PROF
     if (lane == 0 && b == 0) for (int j = 0; j < 16; ++j) ((long long*)S.stats)[8 + j] = pt[j];
 #endif
-    if (K.finish == 2) {      // asynchronous solve: candidate alpha = 1 -> live queues
+    if (K.finish) {
         __threadfence_block();
-        lds_sync();
-        apply_step<Sync>(S, S.cand, S.nu_cand, (size_t)b * CS, b, 1.0, lane, 64);
-        if (lane == 0) { S.alpha[b] = 1.0; S.ls_iter[b] = 0; S.stage[b] = STAGE_LS0; }
-        enqueue_eval_async<Sync>(S, (size_t)b * CS, 1, b, lane, 64);
-    } else if (K.finish) {
-        __threadfence_block();
-        lds_sync();
-        // line search start (newton.jl:223-228): alpha = 1, candidate = traj - Delta
-        apply_step<Sync>(S, S.cand, S.nu_cand, (size_t)b * CS, b, 1.0, lane, 64);
-        // the KKT kernel runs on its own stream NEXT TO the sweep of the running round: its
-        // candidates join the queue of the next round
-        enqueue_eval(S, (size_t)b * CS, b, S.kkt_same_round ? S.WQ.par : (S.WQ.par ^ 1), lane, 64);
-        if (lane == 0) {
-            S.alpha[b] = 1.0;
-            S.ls_iter[b] = 0;
-            S.stage[b] = STAGE_LS0;
-            for (int c = 1; c < CS; ++c) S.need_sweep[(size_t)b * CS + c] = 0;
-            atomicAdd(&S.counters[0], 1);
-        }
+        start_line_search<Sync>(S, b, K.finish, lane, 64);
     }
 }
 

@@ -109,6 +109,41 @@ int launch_enqueue_all(const NewtonDev& S, hipStream_t s) {
     hipLaunchKernelGGL(enqueue_all_kernel, dim3(S.nb_launch), dim3(64), 0, s, S);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
+// Hybrid solve: the lock-step rounds hand the still-active rollouts over to the asynchronous kernel
+// (newton_async_impl.h) once few are left.  Called between two rounds.  The lock-step queue of the
+// NEXT round (LQ, parity LQ.par) already holds everything that is still to be solved - evaluations
+// requested by the residual / KKT kernels and solves parked by the last sweep - so it is copied
+// entry by entry into the live queues; per rollout only the bookkeeping of the asynchronous stages
+// is set up: finished -> counted, waiting for KKT -> KKT job, in a line search -> number of
+// evaluation slots that are not complete yet.
+__global__ __launch_bounds__(64) void async_handoff_kernel(NewtonDev S, IpQueues LQ) {
+    const int i = blockIdx.x, tid = threadIdx.x;
+    if (i < S.WQ.K) {      // knot i: copy the pending entries
+        const int n = *qcount(LQ, LQ.par, i);
+        const int* src = LQ.items + ((size_t)LQ.par * LQ.K + i) * LQ.cap;
+        int* dst = S.WQ.items + (size_t)i * S.WQ.cap;
+        for (int k = tid; k < n; k += 64) dst[k] = src[k];
+        if (tid == 0) *qcount(S.WQ, 0, i) = n;
+    }
+    if (i < S.dm.B && tid == 0) {
+        const int b = i, stage = S.stage[b];
+        if (stage == STAGE_DONE) {
+            atomicAdd(S.A.n_done, 1);
+        } else if (stage == STAGE_KKT) {
+            aq_push(S.A.kq_items, S.A.kq_tail, b);
+        } else {
+            const size_t sb0 = (size_t)b * CS;
+            int n = 0;
+            for (int c = 0; c < CS; ++c) n += (S.need_sweep[sb0 + c] != 0 && S.WQ.done_count[sb0 + c] < S.dm.H);
+            S.A.evals_left[b] = n;
+        }
+    }
+}
+int launch_async_handoff(const NewtonDev& S, const IpQueues& LQ, hipStream_t s) {
+    const int grid = S.dm.B > S.WQ.K ? S.dm.B : S.WQ.K;
+    hipLaunchKernelGGL(async_handoff_kernel, dim3(grid), dim3(64), 0, s, S, LQ);
+    return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+}
 int launch_reset(const NewtonDev& S, const double* q0, const double* q1, int warm, hipStream_t s) {
     hipLaunchKernelGGL(reset_kernel, dim3(S.nb_launch), dim3(256), 0, s, S, q0, q1, warm);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;

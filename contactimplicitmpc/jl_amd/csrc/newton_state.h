@@ -7,8 +7,8 @@
 
 namespace cimpc {
 
-enum Stage : int { STAGE_DONE = 0, STAGE_INIT = 1, STAGE_LS0 = 2, STAGE_KKT = 3, STAGE_LS1 = 4, STAGE_LS2 = 5 };
-constexpr int CS = 4;   // evaluation slots per rollout (speculative line search, newton_kernels.hip)
+enum Stage : int { STAGE_DONE = 0, STAGE_INIT = 1, STAGE_LS0 = 2, STAGE_KKT = 3, STAGE_LS1 = 4, STAGE_LS2 = 5, STAGE_LS7 = 6 };
+constexpr int CS = 7;   // evaluation slots per rollout (speculative line search, newton_impl.h)
 
 struct TrajDev {
     double* q;    // [B][H+2][nq]
@@ -70,11 +70,13 @@ struct NewtonDev {
     // options
     double r_tol, beta_init, kappa;
     int max_iter;
+    int spec_all;      // a rollout whose previous line search ended at iter >= spec_all evaluates all 7 step lengths at once
 };
 
 // single-launch asynchronous solve (newton_async_impl.h)
 bool newton_async_available(const cimpc_dims* dm);
 int launch_newton_async(const cimpc_dims* dm, const IpParams& p, const NewtonDev& S, int waves, int grid, hipStream_t s);
+int launch_async_handoff(const NewtonDev& S, const IpQueues& lockstep_next, hipStream_t s);
 int launch_reset(const NewtonDev& nd, const double* q0, const double* q1, int warm, hipStream_t s);
 int launch_resid_decide(const NewtonDev& nd, hipStream_t s);
 int launch_enqueue_all(const NewtonDev& nd, hipStream_t s);   // B3 seam: queue slot 0 of every rollout

@@ -169,22 +169,31 @@ def test_kkt_solve_matches_dense_lu(gpu_required):
             np.testing.assert_allclose(delta[b], x, rtol=0, atol=1e-7 * max(1.0, np.abs(x).max()))
 
 
-def test_async_single_launch_matches_lockstep(gpu_required, monkeypatch):
-    """The opt-in single-launch asynchronous solve (CIMPC_ASYNC=1, newton_async_impl.h) runs the same
-    per-rollout arithmetic as the lock-step rounds: identical iterates, counters and trajectories."""
+@pytest.mark.parametrize("mode,B,tail", [("1", 24, None), ("2", 160, "120")])
+def test_async_single_launch_matches_lockstep(gpu_required, monkeypatch, mode, B, tail):
+    """The single-launch asynchronous solve (CIMPC_ASYNC=1, newton_async_impl.h) and the hybrid schedule
+    (auto mode: lock-step rounds, then the asynchronous kernel for the last `tail` active rollouts, solves
+    parked by the rounds included) run the same per-rollout arithmetic as the lock-step rounds alone:
+    identical iteration counts, counters and trajectories."""
     from contactimplicitmpc.jl_amd import NewtonOptions
-    d, prob, tabs, rollouts = make_case("quadruped", 0, H_ref=16, H=10, B=24, seed=5, perturb=3e-2)
+    d, prob, tabs, rollouts = make_case("quadruped", 0, H_ref=16, H=10, B=B, seed=5, perturb=3e-2)
     obj = synth.make_objective(d, 10, kind="quadruped")
     q0 = np.stack([r[2] for r in rollouts]); q1 = np.stack([r[3] for r in rollouts])
+    if tail is not None:
+        monkeypatch.setenv("CIMPC_ASYNC_TAIL", tail)
     outs = []
-    for flag in ("0", "1"):
+    for flag in ("0", mode):
         monkeypatch.setenv("CIMPC_ASYNC", flag)
         s = make_solver(d, prob, rollouts, 10, obj=obj,
                         newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=1e-5, max_iter=5))
         u1, it, rn = s.newton_solve(q0, q1)
         outs.append((u1, it, rn, s.trajectory(), s.rollout_counters(), s.stats()))
     a, b = outs
-    assert b[5]["rounds"] == 1 and a[5]["rounds"] > 1          # the second solver really took the single launch
+    assert b[5]["rounds"] < a[5]["rounds"]          # the second solver really left the lock-step rounds
+    if mode == "1":
+        assert b[5]["rounds"] == 1
+    else:
+        assert b[5]["rounds"] > 2                    # ... after running some of them (hybrid)
     np.testing.assert_array_equal(a[1], b[1])
     for k in ("sweeps", "ip_iters", "ip_failures"):
         np.testing.assert_array_equal(a[4][k], b[4][k])
