@@ -200,7 +200,12 @@ def main():
                      "fp64_tflops": tflops, "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
                      "fp64_frac": tflops / FP64_VECTOR_PEAK_TFLOPS},
         "kernel_time_ms_per_step": {"ip_sweep": prof["ip_sweep_ms"] / args.steps, "kkt": prof["kkt_ms"] / args.steps,
-                                    "resid": prof["resid_ms"] / args.steps, "other": prof["other_ms"] / args.steps},
+                                    "resid": prof["resid_ms"] / args.steps, "other": prof["other_ms"] / args.steps,
+                                    "async_tail": prof["async_ms"] / args.steps},
+        "schedule": {"lockstep_rounds_per_step": rounds / args.steps - (1 if prof["async_launches"] else 0),
+                     "async_tail_launches_per_step": prof["async_launches"] / args.steps,
+                     "ip_problems_in_rounds": prof["ip_sweep_problems"] / args.steps,
+                     "ip_problems_in_async_tail": prof["async_problems"] / args.steps},
     }
     if args.latency:
         s1, a0, a1 = make(1, rollouts[:1])

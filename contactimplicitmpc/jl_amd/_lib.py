@@ -45,7 +45,8 @@ class Profile(C.Structure):
                 ("ip_sweep_problems", C.c_longlong),
                 ("kkt_ms", C.c_double), ("kkt_launches", C.c_longlong), ("kkt_systems", C.c_longlong),
                 ("resid_ms", C.c_double), ("resid_launches", C.c_longlong),
-                ("other_ms", C.c_double), ("other_launches", C.c_longlong)]
+                ("other_ms", C.c_double), ("other_launches", C.c_longlong),
+                ("async_ms", C.c_double), ("async_launches", C.c_longlong), ("async_problems", C.c_longlong)]
 
 
 _dp = C.POINTER(C.c_double)

@@ -22,7 +22,7 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum ProfClass { PC_IP = 0, PC_KKT = 1, PC_RESID = 2, PC_OTHER = 3, PC_COUNT = 4 };
+enum ProfClass { PC_IP = 0, PC_KKT = 1, PC_RESID = 2, PC_OTHER = 3, PC_ASYNC = 4, PC_COUNT = 5 };
 
 struct ProfRec {
     hipEvent_t a, b;
@@ -105,8 +105,9 @@ struct cimpc_ctx {
     bool prof_on = false;
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> ev_pool;
-    double prof_ms[PC_COUNT] = {0, 0, 0, 0};
-    long long prof_n[PC_COUNT] = {0, 0, 0, 0};
+    double prof_ms[PC_COUNT] = {0, 0, 0, 0, 0};
+    long long prof_n[PC_COUNT] = {0, 0, 0, 0, 0};
+    long long prof_async_problems = 0;
     long long prof_ip_problems = 0, prof_kkt_systems = 0;
 };
 
@@ -812,7 +813,9 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         p.Q = Sk.WQ;
         p.iter_cap = h->ip.max_iter + 1;      // no solve is parked (solves parked by the lock-step rounds resume and finish)
         p.A = A;
-        prof_begin(h, PC_IP, st);
+        long long solved_before = 0;      // interior-point problems the lock-step rounds had solved (profiling only)
+        if (h->prof_on && !from_reset) HIP_TRY(h, hipMemcpy(&solved_before, S.stats + 1, sizeof(long long), hipMemcpyDeviceToHost));
+        prof_begin(h, PC_ASYNC, st);
         rc2 = launch_newton_async(&h->dm, p, Sk, h->waves, h->a_grid, st);
         prof_end(h, st);
         if (rc2 != CIMPC_OK) return fail(h, rc2, "asynchronous newton launch failed");
@@ -839,7 +842,8 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         h->last_stats.rounds = rounds_before + 1;
         h->last_stats.newton_iters = 0;
         for (int v : l) h->last_stats.newton_iters += v;
-        h->prof_ip_problems += stv[1];
+        h->prof_ip_problems += solved_before;
+        h->prof_async_problems += stv[1] - solved_before;
         if (from_reset) h->prof_kkt_systems += h->last_stats.newton_iters;
         return CIMPC_OK;
     };
@@ -1048,6 +1052,7 @@ int cimpc_profile_reset(cimpc_handle h) {
     prof_collect(h);
     for (int c = 0; c < PC_COUNT; ++c) { h->prof_ms[c] = 0.0; h->prof_n[c] = 0; }
     h->prof_ip_problems = 0;
+    h->prof_async_problems = 0;
     h->prof_kkt_systems = 0;
     return CIMPC_OK;
 }
@@ -1060,6 +1065,7 @@ int cimpc_profile_read(cimpc_handle h, cimpc_profile* p) {
     p->kkt_ms = h->prof_ms[PC_KKT]; p->kkt_launches = h->prof_n[PC_KKT]; p->kkt_systems = h->prof_kkt_systems;
     p->resid_ms = h->prof_ms[PC_RESID]; p->resid_launches = h->prof_n[PC_RESID];
     p->other_ms = h->prof_ms[PC_OTHER]; p->other_launches = h->prof_n[PC_OTHER];
+    p->async_ms = h->prof_ms[PC_ASYNC]; p->async_launches = h->prof_n[PC_ASYNC]; p->async_problems = h->prof_async_problems;
     return CIMPC_OK;
 }
 

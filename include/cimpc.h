@@ -88,6 +88,8 @@ typedef struct cimpc_profile {
     double kkt_ms;       long long kkt_launches;       long long kkt_systems;
     double resid_ms;     long long resid_launches;
     double other_ms;     long long other_launches;
+    /* asynchronous kernel (single launch / hybrid tail): interior-point + residual + KKT work inside */
+    double async_ms;     long long async_launches;     long long async_problems;
 } cimpc_profile;
 
 void cimpc_default_ip_opts(cimpc_ip_opts* o);
