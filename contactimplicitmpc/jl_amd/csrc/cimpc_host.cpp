@@ -79,6 +79,9 @@ struct cimpc_ctx {
     int n_knots_set = 0;
     bool objective_set = false, window_set = false, reference_set = false, alt_set = false;
     bool velocity_objective = false;
+    bool use_dense = false;        // KKT through the reference-default dense LU (any mode / objective), kkt_dense.hip
+    double* d_dense_ws = nullptr;  // [B][N*N + 2N], allocated on first use
+    double *d_V = nullptr, *d_qt = nullptr, *d_vt = nullptr;
     int waves = 4;
     bool kkt_overlap = true;
     int pipeline_depth = 1;
@@ -248,6 +251,11 @@ int run_sweep(cimpc_ctx* h, int par, int* pending_counter, double* zout, hipStre
     return CIMPC_OK;
 }
 
+int ensure_dense_ws(cimpc_ctx* h) {
+    if (h->d_dense_ws) return CIMPC_OK;
+    return dev_alloc(h, &h->d_dense_ws, kkt_dense_workspace_doubles(h->S));
+}
+
 int check_ready(cimpc_ctx* h, bool need_newton) {
     if (!h) return CIMPC_ERR_INVALID;
     if (h->n_knots_set != h->dm.H_ref)
@@ -256,10 +264,6 @@ int check_ready(cimpc_ctx* h, bool need_newton) {
     if (need_newton) {
         if (!h->objective_set) return fail(h, CIMPC_ERR_STATE, "set_objective has not been called");
         if (!h->reference_set) return fail(h, CIMPC_ERR_STATE, "set_reference has not been called");
-        if (h->dm.mode != CIMPC_MODE_CONFIGURATION)
-            return fail(h, CIMPC_ERR_INVALID,
-                        "newton_solve / kkt_solve: only mode = :configuration is implemented "
-                        "(the :configurationforce KKT needs an indefinite solver; see DESIGN.md)");
     }
     return CIMPC_OK;
 }
@@ -386,6 +390,9 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     A(&h->d_Rinv, H * d.nu * d.nu);
     A(&h->d_Cg, H * d.nc * d.nc);
     A(&h->d_Cb, H * d.nb * d.nb);
+    A(&h->d_V, H * d.nq * d.nq);
+    A(&h->d_qt, H * d.nq);
+    A(&h->d_vt, H * d.nq);
     A(&h->d_q0, B * d.nq);
     A(&h->d_q1, B * d.nq);
     A(&h->d_rhs, B * h->N);
@@ -436,6 +443,9 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     S.r_tol = h->nt.r_tol; S.beta_init = h->nt.beta_init; S.kappa = h->nt.kappa; S.max_iter = h->nt.max_iter;
     // all-seven-step-lengths speculation: shortens the chain of rollouts that exhaust their line search; pays
     // when the solve is latency-bound (small batches), costs throughput otherwise (B = 2048: -8 %)
+    // condensed MFMA/scalar solve: :configuration + TrackingObjective; everything else (and kkt_backend = dense LU)
+    // goes through the reference-default dense LU
+    h->use_dense = d.mode != CIMPC_MODE_CONFIGURATION || h->nt.kkt_backend == CIMPC_KKT_DENSE_LU;
     S.spec_all = getenv("CIMPC_SPEC_ALL") ? atoi(getenv("CIMPC_SPEC_ALL")) : (d.B <= 128 ? 3 : 8);
     // small batches: one wave per workgroup keeps every problem on its own CU (latency);
     // large batches: 4 waves share one staged table (throughput)
@@ -620,20 +630,37 @@ int cimpc_set_objective(cimpc_handle h, const double* Q, const double* R, const 
                         const double* Cb, const double* V, const double* q_target,
                         const double* v_target) {
     if (!h || !Q || !R) return fail(h, CIMPC_ERR_INVALID, "Q and R are required");
-    (void)q_target; (void)v_target;
-    if (V != nullptr)
-        return fail(h, CIMPC_ERR_INVALID,
-                    "TrackingVelocityObjective (V != NULL) is not implemented in this build (DESIGN.md, next)");
     const cimpc_dims& d = h->dm;
     const size_t H = d.H;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (V != nullptr) {      // TrackingVelocityObjective (objective.jl:18-47): q_target integrates v_target when not given
+        std::vector<double> vt(H * d.nq, 0.0), qt(H * d.nq, 0.0);
+        if (v_target) std::copy(v_target, v_target + H * d.nq, vt.begin());
+        if (q_target) std::copy(q_target, q_target + H * d.nq, qt.begin());
+        else {
+            bool any = false;
+            for (double x : vt) any = any || x != 0.0;
+            if (any) for (size_t t = 1; t < H; ++t) for (int k = 0; k < d.nq; ++k) qt[t * d.nq + k] = qt[(t - 1) * d.nq + k] + vt[(t - 1) * d.nq + k];
+        }
+        HIP_TRY(h, hipMemcpy(h->d_V, V, H * d.nq * d.nq * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_qt, qt.data(), qt.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_vt, vt.data(), vt.size() * sizeof(double), hipMemcpyHostToDevice));
+        h->S.V = h->d_V; h->S.q_target = h->d_qt; h->S.v_target = h->d_vt;
+        h->velocity_objective = true;
+        h->use_dense = true;       // P is block tridiagonal: the condensed solve does not apply
+    } else {
+        h->S.V = nullptr; h->S.q_target = nullptr; h->S.v_target = nullptr;
+        h->velocity_objective = false;
+        h->use_dense = d.mode != CIMPC_MODE_CONFIGURATION || h->nt.kkt_backend == CIMPC_KKT_DENSE_LU;
+    }
     std::vector<double> Qi(H * d.nq * d.nq), Ri(H * d.nu * d.nu);
     for (size_t i = 0; i < H; ++i) {
-        if (!invert(Q + i * d.nq * d.nq, Qi.data() + i * d.nq * d.nq, d.nq))
+        // (the inverses feed the condensed solve only)
+        if (!invert(Q + i * d.nq * d.nq, Qi.data() + i * d.nq * d.nq, d.nq) && !h->use_dense)
             return fail(h, CIMPC_ERR_INVALID, "objective block Q[i] is singular");
-        if (d.nu > 0 && !invert(R + i * d.nu * d.nu, Ri.data() + i * d.nu * d.nu, d.nu))
+        if (d.nu > 0 && !invert(R + i * d.nu * d.nu, Ri.data() + i * d.nu * d.nu, d.nu) && !h->use_dense)
             return fail(h, CIMPC_ERR_INVALID, "objective block R[i] is singular");
     }
-    HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpy(h->d_Q, Q, H * d.nq * d.nq * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_R, R, H * d.nu * d.nu * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_Qinv, Qi.data(), Qi.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -748,7 +775,13 @@ int cimpc_kkt_solve(cimpc_handle h, const double* r, double beta, double* delta)
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpyAsync(h->d_rhs, r, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     prof_begin(h, PC_KKT);
-    rc = launch_kkt_raw(h->S, h->d_rhs, beta, h->S.delta, h->stream);
+    if (h->use_dense) {
+        rc = ensure_dense_ws(h);
+        if (rc != CIMPC_OK) return rc;
+        rc = launch_kkt_dense_raw(h->S, h->d_rhs, beta, h->S.delta, h->d_dense_ws, h->stream);
+    } else {
+        rc = launch_kkt_raw(h->S, h->d_rhs, beta, h->S.delta, h->stream);
+    }
     prof_end(h);
     if (rc != CIMPC_OK) return fail(h, rc, "kkt launch failed");
     HIP_TRY(h, hipMemcpyAsync(delta, h->S.delta, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -847,8 +880,9 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         if (from_reset) h->prof_kkt_systems += h->last_stats.newton_iters;
         return CIMPC_OK;
     };
-    const bool full_async = h->async_on && (h->async_mode == 1 || (h->async_mode == 2 && h->dm.B >= 8 && h->dm.B <= 128));
-    const bool hybrid = h->async_on && h->async_mode == 2 && !full_async && h->dm.B > 128;
+    if (h->use_dense) { rc = ensure_dense_ws(h); if (rc != CIMPC_OK) return rc; }
+    const bool full_async = h->async_on && !h->use_dense && (h->async_mode == 1 || (h->async_mode == 2 && h->dm.B >= 8 && h->dm.B <= 128));
+    const bool hybrid = h->async_on && !h->use_dense && h->async_mode == 2 && !full_async && h->dm.B > 128;
     if (full_async) return run_async(true, 0);
     // safety net only: every Newton iteration needs at most 3 (speculative) rounds, each evaluation at
     // most ceil(max_iter / iter_cap) launches of the resumable interior-point sweep
@@ -885,14 +919,14 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         if (kkt && !h->kkt_overlap) {   // small batches: latency matters, keep the KKT result in this round
             Sk.kkt_same_round = 1;
             prof_begin(h, PC_KKT, sb.st);
-            int rr = launch_kkt(Sk, sb.st);
+            int rr = h->use_dense ? launch_kkt_dense_newton(Sk, h->d_dense_ws, sb.st) : launch_kkt(Sk, sb.st);
             prof_end(h, sb.st);
             if (rr != CIMPC_OK) return fail(h, rr, "kkt launch failed");
         } else if (kkt) {   // fork: KKT of the rollouts that start a Newton iteration, next to the sweep
             if (hipEventRecord(sb.ev_fork, sb.st) != hipSuccess ||
                 hipStreamWaitEvent(sb.st_kkt, sb.ev_fork, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "fork failed");
             prof_begin(h, PC_KKT, sb.st_kkt);
-            int rr = launch_kkt(Sk, sb.st_kkt);
+            int rr = h->use_dense ? launch_kkt_dense_newton(Sk, h->d_dense_ws, sb.st_kkt) : launch_kkt(Sk, sb.st_kkt);
             prof_end(h, sb.st_kkt);
             if (rr != CIMPC_OK) return fail(h, rr, "kkt launch failed");
             if (hipEventRecord(sb.ev_join, sb.st_kkt) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join record failed");

@@ -204,8 +204,23 @@ __device__ double slot_residual(const NewtonDev& S, size_t sb, int b, double* re
                 const double* Qm = S.Q + (size_t)i * nq * nq;
                 const double* qq = S.cand.q + (sb * (H + 2) + i + 2) * nq;
                 const double* qr = S.ref.q + ((size_t)b * (H + 2) + i + 2) * nq;
+                if (S.V == nullptr) {
 #pragma unroll
-                for (int k = 0; k < nq; ++k) v = fma(Qm[cq + k * nq], qq[k] - qr[k], v);
+                    for (int k = 0; k < nq; ++k) v = fma(Qm[cq + k * nq], qq[k] - qr[k], v);
+                } else {   // TrackingVelocityObjective (newton_residual.jl:221-281): q tracks q_ref + q_target,
+                           // V_i penalises w_i = q_{i+2} - q_{i+1} (- v_target_i in :configuration mode)
+                    const double* qt = S.q_target + (size_t)i * nq;
+                    for (int k = 0; k < nq; ++k) v = fma(Qm[cq + k * nq], qq[k] - (qr[k] + qt[k]), v);
+                    const double* Vi = S.V + (size_t)i * nq * nq;
+                    const double* vt = S.v_target + (size_t)i * nq;
+                    for (int k = 0; k < nq; ++k)
+                        v = fma(Vi[cq + k * nq], qq[k] - qq[k - nq] - (cf ? 0.0 : vt[k]), v);
+                    if (i + 1 < H) {
+                        const double* Vn = Vi + nq * nq;
+                        for (int k = 0; k < nq; ++k)
+                            v = fma(-Vn[cq + k * nq], qq[k + nq] - qq[k] - (cf ? 0.0 : vt[k + nq]), v);
+                    }
+                }
                 v -= nuc[i * nd + cq];                                      // rI[i] -= nu_i
                 if (i + 1 < H) {                                            // dq1_{i+1}^T nu_{i+1}
                     const double* A1 = dzb + ((size_t)(i + 1) * nths + nq + cq) * nd;

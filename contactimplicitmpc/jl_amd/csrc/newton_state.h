@@ -65,6 +65,9 @@ struct NewtonDev {
     const double* Rinv;  // [H][nu*nu]
     const double* Cg;    // [H][nc*nc] (cf) or null
     const double* Cb;    // [H][nb*nb] (cf) or null
+    const double* V;        // [H][nq*nq] TrackingVelocityObjective weights or null (objective.jl:18-47)
+    const double* q_target; // [H][nq] (velocity objective) or null
+    const double* v_target; // [H][nq] (velocity objective) or null
     // KKT workspace: per rollout H * (3*nd*nd + nd) doubles (L1, L2, L0inv, y)
     double* kkt_ws;
     // options
@@ -81,6 +84,10 @@ int launch_reset(const NewtonDev& nd, const double* q0, const double* q1, int wa
 int launch_resid_decide(const NewtonDev& nd, hipStream_t s);
 int launch_enqueue_all(const NewtonDev& nd, hipStream_t s);   // B3 seam: queue slot 0 of every rollout
 int launch_kkt(const NewtonDev& nd, hipStream_t s);
+// reference-default backend (dense jacobian! + LU with partial pivoting), any mode / objective (kkt_dense.hip)
+size_t kkt_dense_workspace_doubles(const NewtonDev& S);
+int launch_kkt_dense_newton(const NewtonDev& S, double* ws, hipStream_t s);
+int launch_kkt_dense_raw(const NewtonDev& S, const double* r_dev, double beta, double* delta_dev, double* ws, hipStream_t s);
 // B1 seam: solve with caller-provided residual / beta for all rollouts, no state change
 int launch_kkt_raw(const NewtonDev& nd, const double* r_dev, double beta, double* delta_dev,
                    hipStream_t s);

@@ -44,6 +44,7 @@ class NewtonOptions:
     beta_init: float = 1.0e-5
     max_time: float = 0.0
     kappa: float = 2.0e-4
+    kkt_backend: int = 0      # 0 condensed (falls back to dense LU where it does not apply), 1 dense LU (reference default)
 
 
 def _dp(a):
@@ -76,7 +77,7 @@ class CIMPCSolver:
                                ip_opts.kappa_reg, ip_opts.eps_min, ip_opts.ls_scale, ip_opts.max_iter,
                                ip_opts.max_ls, ip_opts.stall_alpha)
         self._nt = _lib.NewtonOpts(newton_opts.r_tol, newton_opts.beta_init, newton_opts.max_time,
-                                   newton_opts.kappa, newton_opts.max_iter, 0)
+                                   newton_opts.kappa, newton_opts.max_iter, newton_opts.kkt_backend)
         self.h = C.c_void_p()
         rc = self.lib.cimpc_create(C.byref(self.dims), C.byref(self._ip), C.byref(self._nt), device,
                                    C.byref(self.h))

@@ -35,7 +35,10 @@ extern "C" {
 #define CIMPC_MODE_CONFIGURATIONFORCE 1  /* mode = :configurationforce (nd = nq+nc+nb)  */
 
 #define CIMPC_KKT_CONDENSED 0  /* dual Schur complement + block Cholesky (structure of
-                                  newton_structure_solver/methods.jl:386-557)            */
+                                  newton_structure_solver/methods.jl:386-557); :configuration
+                                  mode + TrackingObjective, otherwise the dense LU is used */
+#define CIMPC_KKT_DENSE_LU 1   /* reference default: dense jacobian! + LU with partial pivoting
+                                  (newton.jl:10,218; lu.jl:4-12), any mode / objective     */
 
 typedef struct cimpc_ctx* cimpc_handle;
 

@@ -36,7 +36,8 @@ def make_solver(d, prob, rollouts, H, ip_opts=None, newton_opts=None, obj=None):
                     np.stack([r.w for (_, r, _, _) in rollouts]), np.stack([r.gamma for (_, r, _, _) in rollouts]),
                     np.stack([r.b for (_, r, _, _) in rollouts]), np.stack([r.theta for (_, r, _, _) in rollouts]))
     if obj is not None:
-        s.set_objective(obj.q, obj.u, obj.gamma, obj.b)
+        s.set_objective(obj.q, obj.u, obj.gamma, obj.b, V=obj.v, q_target=obj.q_target if obj.v is not None else None,
+                        v_target=obj.v_target if obj.v is not None else None)
     return s
 
 

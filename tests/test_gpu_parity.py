@@ -169,6 +169,71 @@ def test_kkt_solve_matches_dense_lu(gpu_required):
             np.testing.assert_allclose(delta[b], x, rtol=0, atol=1e-7 * max(1.0, np.abs(x).max()))
 
 
+@pytest.mark.parametrize("model,mode,velocity,backend", [
+    ("quadruped", 0, False, 1),     # :configuration through the reference-default backend
+    ("pushbot", 1, False, 0),       # BASELINE configs[0] dimensions, :configurationforce (policy.jl:46 default)
+    ("hopper", 1, True, 0),         # :configurationforce + TrackingVelocityObjective
+    ("hopper", 0, True, 0),         # velocity objective in :configuration mode (v_target terms)
+])
+def test_kkt_dense_lu_backend(gpu_required, model, mode, velocity, backend):
+    """B1 seam through kkt_dense.hip: dense jacobian! + LU with partial pivoting (the reference default
+    :lu_solver) against numpy's solve of the oracle's jacobian!, for the modes / objectives the condensed
+    solve does not cover."""
+    from contactimplicitmpc.jl_amd import NewtonOptions
+    H, H_ref, B = 6, 8, 3
+    d, prob, tabs, rollouts = make_case(model, mode, H_ref=H_ref, H=H, B=B, seed=9)
+    obj = synth.make_objective(d, H, kind=model, velocity=velocity)
+    if velocity:
+        obj.v = obj.v * 1e3                      # make the velocity blocks numerically visible
+        obj.v_target = 0.01 * np.random.default_rng(3).standard_normal((H, d.nq))
+        obj.q_target = None
+        obj.__post_init__()
+    s = make_solver(d, prob, rollouts, H, obj=obj, newton_opts=NewtonOptions(kappa=prob["kappa"], kkt_backend=backend))
+    opts = oip.IPOptions(kappa_tol=prob["kappa"])
+    ref = oracle_sweep(d, tabs, rollouts, opts)
+    q = np.stack([tr.q for tr, _ in ref]); th = np.stack([tr.theta for tr, _ in ref])
+    g = np.stack([tr.gamma for tr, _ in ref]); bb = np.stack([tr.b for tr, _ in ref])
+    out = s.implicit_dynamics(q, th, g, bb)       # leaves the sensitivities resident on the device
+    lay = onewton.Layout(d, H)
+    r = np.random.default_rng(0).standard_normal((B, lay.N))
+    for beta in (1e-5, 10.0):
+        delta = s.kkt_solve(r, beta)
+        for b in range(B):
+            # R from the DEVICE's own sensitivities: isolates the assembly + LU from the interior-point parity
+            im = {k: out[k][b] for k in ("d", "dq0", "dq1", "du1")}
+            R = onewton.jacobian(lay, obj, im, beta, prob["kappa"])
+            x = np.linalg.solve(R, r[b])
+            back = np.abs(R @ delta[b] - r[b]).max() / (np.abs(R).sum(axis=1).max() * np.abs(delta[b]).max() + np.abs(r[b]).max())
+            assert back < 1e-13, back             # backward stable (lu.jl's own test pins the residual to 1e-10)
+            np.testing.assert_allclose(delta[b], x, rtol=0, atol=1e-13 * np.linalg.cond(R) * max(1.0, np.abs(x).max()))
+
+
+@pytest.mark.parametrize("model,mode,velocity", [("hopper", 1, False), ("quadruped", 1, False), ("hopper", 0, True)])
+def test_newton_solve_configurationforce_and_velocity(gpu_required, model, mode, velocity):
+    """newton_solve! in :configurationforce mode / with a TrackingVelocityObjective (dense LU KKT) against
+    the oracle running the reference-default dense-LU backend."""
+    from contactimplicitmpc.jl_amd import NewtonOptions
+    H, H_ref, B = 8, 12, 4
+    d, prob, tabs, rollouts = make_case(model, mode, H_ref=H_ref, H=H, B=B, seed=31, perturb=5e-3)
+    obj = synth.make_objective(d, H, kind=model, velocity=velocity)
+    if velocity:
+        obj.v = obj.v * 1e3
+    s = make_solver(d, prob, rollouts, H, obj=obj, newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=1e-5, max_iter=4))
+    u1, it, rn = s.newton_solve(np.stack([r[2] for r in rollouts]), np.stack([r[3] for r in rollouts]))
+    traj = s.trajectory(); cnt = s.rollout_counters()
+    same = 0
+    for b, (window, ref, q0, q1) in enumerate(rollouts):
+        core = onewton.Newton(d, H, obj, onewton.NewtonOptions(r_tol=1e-5, max_iter=4, solver="lu"),
+                              oip.IPOptions(kappa_tol=prob["kappa"]), prob["kappa"], ref)
+        st = onewton.newton_solve(core, q0, q1, window, tabs, ref)
+        if it[b] == st.iters and cnt["sweeps"][b] == st.sweeps and cnt["ip_iters"][b] == st.ip_iters:
+            same += 1       # same discrete path (see DESIGN.md section 2 on roundoff-level flips)
+            np.testing.assert_allclose(traj["q"][b], core.traj.q, rtol=0, atol=1e-7)
+            np.testing.assert_allclose(traj["u"][b], core.traj.u, rtol=0, atol=1e-7)
+            np.testing.assert_allclose(rn[b], st.r_norm / core.lay.N, rtol=1e-3, atol=1e-9)
+    assert same >= B - 1
+
+
 @pytest.mark.parametrize("mode,B,tail", [("1", 24, None), ("2", 160, "120")])
 def test_async_single_launch_matches_lockstep(gpu_required, monkeypatch, mode, B, tail):
     """The single-launch asynchronous solve (CIMPC_ASYNC=1, newton_async_impl.h) and the hybrid schedule
