@@ -19,7 +19,7 @@ from oracle import ip as oip, newton as onewton, synth  # noqa: E402
 from common import make_case, oracle_sweep  # noqa: E402
 
 
-def one(name, model, mode, H_ref, H, B, seed, perturb, newton):
+def one(name, model, mode, H_ref, H, B, seed, perturb, newton, velocity=False):
     d, prob, tabs, rollouts = make_case(model, mode, H_ref=H_ref, H=H, B=B, seed=seed, perturb=perturb)
     opts = oip.IPOptions(kappa_tol=prob["kappa"])
     ref = oracle_sweep(d, tabs, rollouts, opts)
@@ -35,8 +35,16 @@ def one(name, model, mode, H_ref, H, B, seed, perturb, newton):
     for k in ("d", "dq0", "dq1", "du1", "status", "iters", "z"):
         out["sweep_" + k] = np.stack([o[k] for _, o in ref])
     if newton:
-        obj = synth.make_objective(d, H)
+        obj = synth.make_objective(d, H, kind=model, velocity=velocity)
         out["obj_q"], out["obj_u"] = obj.q, obj.u
+        if mode == 1:
+            out["obj_gamma"], out["obj_b"] = obj.gamma, obj.b
+        if velocity:
+            obj.v = obj.v * 1e3
+            obj.v_target = 0.01 * np.random.default_rng(seed).standard_normal((H, d.nq))
+            obj.q_target = None
+            obj.__post_init__()
+            out["obj_v"], out["obj_q_target"], out["obj_v_target"] = obj.v, obj.q_target, obj.v_target
         qs, us, nus, its, rns, ipit = [], [], [], [], [], []
         for (window, rf, q0, q1) in rollouts:
             core = onewton.Newton(d, H, obj, onewton.NewtonOptions(r_tol=1e-5, max_iter=5, solver="lu"), opts, prob["kappa"], rf)
@@ -54,3 +62,6 @@ if __name__ == "__main__":
     one("hopper_cfg", "hopper", 0, 6, 5, 3, 31, 1e-2, True)
     one("quadruped_cfg", "quadruped", 0, 8, 6, 3, 32, 1e-2, True)
     one("pushbot_cf", "pushbot", 1, 5, 4, 2, 33, 1e-2, False)
+    # newton_solve! through the reference-default dense-LU KKT: :configurationforce, and the velocity objective
+    one("hopper_cf_newton", "hopper", 1, 8, 6, 3, 34, 5e-3, True)
+    one("hopper_velocity_newton", "hopper", 0, 8, 6, 3, 35, 5e-3, True, velocity=True)

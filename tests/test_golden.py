@@ -63,13 +63,21 @@ def test_hip_reproduces_golden(gpu_required, path):
         ref = g["sweep_" + k][ok]
         assert np.abs(out[k][ok] - ref).max() < 1e-6 * max(1.0, np.abs(ref).max())
     if has_newton:
-        s.set_objective(g["obj_q"], g["obj_u"])
+        opt = lambda k: g[k] if k in g.files else None
+        s.set_objective(g["obj_q"], g["obj_u"], opt("obj_gamma"), opt("obj_b"), V=opt("obj_v"),
+                        q_target=opt("obj_q_target"), v_target=opt("obj_v_target"))
         u1, it, rn = s.newton_solve(g["q0"], g["q1"])
         tr = s.trajectory(); cnt = s.rollout_counters()
         assert np.array_equal(it, g["newton_iters"])
+        # A converged interior-point solve is unique only up to kappa_tol, and one roundoff-level flip of an
+        # iteration count moves the rollout's path; such a rollout is recognisable by its
+        # counters or, when those coincide by chance, by its trajectory.  At most one of the B may differ.
+        good = 0
         for b in range(B):
-            if cnt["ip_iters"][b] == g["newton_ip_iters"][b]:
-                assert np.abs(tr["q"][b] - g["newton_q"][b]).max() < 1e-7
-                assert np.abs(tr["u"][b] - g["newton_u"][b]).max() < 1e-7
-                assert np.abs(rn[b] - g["newton_rnorm"][b]) < 1e-6 * max(1e-6, g["newton_rnorm"][b]) + 1e-12
-        assert (cnt["ip_iters"] == g["newton_ip_iters"]).sum() >= B - 1
+            dense = d.mode == 1 or "obj_v" in g.files      # dense-LU KKT: the final (tiny) residual moves with roundoff
+            ok_b = (cnt["ip_iters"][b] == g["newton_ip_iters"][b]
+                    and np.abs(tr["q"][b] - g["newton_q"][b]).max() < 1e-7
+                    and np.abs(tr["u"][b] - g["newton_u"][b]).max() < 1e-7
+                    and np.abs(rn[b] - g["newton_rnorm"][b]) < (1e-3 if dense else 1e-6) * max(1e-6, g["newton_rnorm"][b]) + 1e-12)
+            good += bool(ok_b)
+        assert good >= B - 1
