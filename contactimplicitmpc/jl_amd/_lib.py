@@ -75,6 +75,8 @@ SIGNATURES = {
     "cimpc_newton_solve_dev": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_int]),
     "cimpc_get_trajectory": (C.c_int, [_h, _dp, _dp, _dp, _dp, _dp]),
     "cimpc_get_newton_info": (C.c_int, [_h, _ip, _dp, _dp]),
+    "cimpc_mpc_advance": (C.c_int, [_h, _dp]),
+    "cimpc_get_reference": (C.c_int, [_h, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
     "cimpc_get_stats": (C.c_int, [_h, C.POINTER(Stats)]),
     "cimpc_get_rollout_counters": (C.c_int, [_h, _ip, _ip, _ip]),
     "cimpc_profile_enable": (C.c_int, [_h, C.c_int]),

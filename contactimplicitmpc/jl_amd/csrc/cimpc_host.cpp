@@ -1068,6 +1068,37 @@ int cimpc_get_rollout_counters(cimpc_handle h, int* sweeps, int* ip_iters, int* 
     return CIMPC_OK;
 }
 
+int cimpc_mpc_advance(cimpc_handle h, const double* stride) {
+    if (!h || !stride) return fail(h, CIMPC_ERR_INVALID, "null argument");
+    if (!h->window_set || !h->reference_set) return fail(h, CIMPC_ERR_STATE, "set_window / set_reference have not been called");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(h->d_q0, stride, (size_t)h->dm.nq * sizeof(double), hipMemcpyHostToDevice, h->stream));   // d_q0: staging
+    int rc = launch_mpc_advance(h->S, h->d_window, h->d_q0, h->dm.H_ref, h->stream);
+    if (rc != CIMPC_OK) return fail(h, rc, "mpc_advance launch failed");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CIMPC_OK;
+}
+
+int cimpc_get_reference(cimpc_handle h, double* q_ref, double* u_ref, double* w_ref, double* gamma_ref,
+                        double* b_ref, double* theta_ref, int* window) {
+    if (!h) return CIMPC_ERR_INVALID;
+    const cimpc_dims& d = h->dm;
+    const size_t B = d.B, H = d.H;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (q_ref) HIP_TRY(h, hipMemcpy(q_ref, h->S.ref.q, B * (H + 2) * d.nq * sizeof(double), hipMemcpyDeviceToHost));
+    if (u_ref) HIP_TRY(h, hipMemcpy(u_ref, h->S.ref.u, B * H * d.nu * sizeof(double), hipMemcpyDeviceToHost));
+    if (w_ref) HIP_TRY(h, hipMemcpy(w_ref, h->S.ref.w, B * H * d.nw * sizeof(double), hipMemcpyDeviceToHost));
+    if (gamma_ref) HIP_TRY(h, hipMemcpy(gamma_ref, h->S.ref.g, B * H * d.nc * sizeof(double), hipMemcpyDeviceToHost));
+    if (b_ref) HIP_TRY(h, hipMemcpy(b_ref, h->S.ref.b, B * H * d.nb * sizeof(double), hipMemcpyDeviceToHost));
+    if (theta_ref) HIP_TRY(h, hipMemcpy(theta_ref, h->S.ref.th, B * H * h->nth * sizeof(double), hipMemcpyDeviceToHost));
+    if (window) {
+        HIP_TRY(h, hipMemcpy(window, h->d_window, B * (H + 2) * sizeof(int), hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < B * (H + 2); ++k) window[k] += 1;     // 1-based at the boundary
+    }
+    return CIMPC_OK;
+}
+
 int cimpc_get_stats(cimpc_handle h, cimpc_stats* s) {
     if (!h || !s) return CIMPC_ERR_INVALID;
     *s = h->last_stats;

@@ -144,6 +144,49 @@ int launch_async_handoff(const NewtonDev& S, const IpQueues& LQ, hipStream_t s) 
     hipLaunchKernelGGL(async_handoff_kernel, dim3(grid), dim3(64), 0, s, S, LQ);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
+// MPC-loop glue between two solves, per rollout: rot_n_stride! (mpc_utils.jl:1-101) on the controller's
+// copy of the reference trajectory - every array moves one step to the left, the first entry goes last
+// (rotate!), the last two configurations repeat the first two shifted by `stride` and the theta slices
+// that read them are refreshed (mpc_stride!) - and update_window! (policy.jl:162-171).
+__global__ __launch_bounds__(64) void mpc_advance_kernel(NewtonDev S, int* window, const double* stride, int H_ref) {
+    const cimpc_dims& m = S.dm;
+    const int b = blockIdx.x, c = threadIdx.x, H = m.H, nq = m.nq, nth = S.nth;
+    auto rot = [&](double* a, int rows, int n) {          // column c of a [rows][n] array, in place
+        if (c >= n) return;
+        const double first = a[c];
+        for (int t = 0; t + 1 < rows; ++t) a[(size_t)t * n + c] = a[(size_t)(t + 1) * n + c];
+        a[(size_t)(rows - 1) * n + c] = first;
+    };
+    double* q = S.ref.q + (size_t)b * (H + 2) * nq;
+    double* th = S.ref.th + (size_t)b * H * nth;
+    rot(q, H + 2, nq);
+    rot(S.ref.u + (size_t)b * H * m.nu, H, m.nu);
+    rot(S.ref.w + (size_t)b * H * m.nw, H, m.nw);
+    rot(S.ref.g + (size_t)b * H * m.nc, H, m.nc);
+    rot(S.ref.b + (size_t)b * H * m.nb, H, m.nb);
+    rot(th, H, nth);
+    __syncthreads();
+    if (c < nq) {                                          // mpc_stride!: q_{H+1}, q_{H+2} (1-based)
+        q[(size_t)H * nq + c] = q[c] + stride[c];
+        q[(size_t)(H + 1) * nq + c] = q[nq + c] + stride[c];
+    }
+    __syncthreads();
+    if (c < nq) {                                          // update_theta! of steps H-2, H-1, H (1-based): q0, q1 slices
+        for (int tau = H - 2; tau <= H; ++tau) {
+            if (tau < 1) continue;
+            th[(size_t)(tau - 1) * nth + c] = q[(size_t)(tau - 1) * nq + c];
+            th[(size_t)(tau - 1) * nth + nq + c] = q[(size_t)tau * nq + c];
+        }
+    }
+    for (int i = c; i < H + 2; i += 64) {                  // update_window! (0-based knots)
+        int* w = window + (size_t)b * (H + 2) + i;
+        *w = (*w + 1) % H_ref;
+    }
+}
+int launch_mpc_advance(const NewtonDev& S, int* window, const double* stride, int H_ref, hipStream_t s) {
+    hipLaunchKernelGGL(mpc_advance_kernel, dim3(S.dm.B), dim3(64), 0, s, S, window, stride, H_ref);
+    return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+}
 int launch_reset(const NewtonDev& S, const double* q0, const double* q1, int warm, hipStream_t s) {
     hipLaunchKernelGGL(reset_kernel, dim3(S.nb_launch), dim3(256), 0, s, S, q0, q1, warm);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;

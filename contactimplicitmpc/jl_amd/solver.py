@@ -219,6 +219,20 @@ class CIMPCSolver:
                     "get_trajectory")
         return dict(q=q, u=u, gamma=g, b=b, nu=nu_dual)
 
+    def mpc_advance(self, stride):
+        """rot_n_stride!(p.traj, ..., p.stride, p.window) + update_window! (policy.jl:136-139) on the device."""
+        st = _f64(stride, (self.nq,))
+        self._check(self.lib.cimpc_mpc_advance(self.h, _dp(st)), "mpc_advance")
+
+    def reference(self):
+        B, H = self.B, self.H
+        q = np.zeros((B, H + 2, self.nq)); u = np.zeros((B, H, self.nu)); w = np.zeros((B, H, self.nw))
+        g = np.zeros((B, H, self.nc)); b = np.zeros((B, H, self.nb)); th = np.zeros((B, H, self.nth))
+        win = np.zeros((B, H + 2), dtype=np.int32)
+        self._check(self.lib.cimpc_get_reference(self.h, _dp(q), _dp(u), _dp(w), _dp(g), _dp(b), _dp(th), _ipt(win)),
+                    "get_reference")
+        return dict(q=q, u=u, w=w, gamma=g, b=b, theta=th, window=win)
+
     def rollout_counters(self):
         sw = np.zeros(self.B, dtype=np.int32); it = np.zeros(self.B, dtype=np.int32)
         fl = np.zeros(self.B, dtype=np.int32)

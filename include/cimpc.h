@@ -176,6 +176,18 @@ int cimpc_get_stats(cimpc_handle h, cimpc_stats* s);
  * ("solver iterations to tolerance"), failed IP solves.  Each B ints; any may be NULL. */
 int cimpc_get_rollout_counters(cimpc_handle h, int* sweeps, int* ip_iters, int* ip_failures);
 
+/* ---- MPC-loop glue between two solves (device side, no host round trip of the trajectories) ---------
+ * Replaces, for every rollout, what policy() does after newton_solve! (policy.jl:133-141):
+ *   rot_n_stride!(p.traj, p.traj_cache, p.stride, p.window)   mpc_utils.jl:1-101
+ *   update_window!(p.window, p.ref_traj.H)                     policy.jl:162-171
+ * on the reference trajectory / window last given by cimpc_set_reference / cimpc_set_window.
+ * stride: nq doubles (get_stride, mpc_utils.jl:103-107), shared by the rollouts.
+ * The Newton iterate (core.traj, nu) stays resident for warm_start = 1, as in the reference. */
+int cimpc_mpc_advance(cimpc_handle h, const double* stride);
+/* reads the controller's reference trajectory and 1-based window back (any pointer may be NULL) */
+int cimpc_get_reference(cimpc_handle h, double* q_ref, double* u_ref, double* w_ref, double* gamma_ref,
+                        double* b_ref, double* theta_ref, int* window);
+
 /* ---- measurement -------------------------------------------------------------------- */
 int cimpc_profile_enable(cimpc_handle h, int on);  /* HIP-event timing of every launch */
 int cimpc_profile_reset(cimpc_handle h);

@@ -1,0 +1,89 @@
+"""MPC-loop glue between two solves: rot_n_stride! / update_window!
+(/root/reference/src/controller/mpc_utils.jl:1-101, policy.jl:133-141,162-171).
+CPU: the oracle restatement against the properties the reference code has by construction.
+GPU: cimpc_mpc_advance against the oracle, and a warm-started three-step MPC loop."""
+import numpy as np
+import pytest
+
+from oracle import ip as oip, mpc as ompc, newton as onewton, synth
+
+from common import make_case, make_solver
+
+
+def test_oracle_rot_n_stride_properties():
+    d, prob, tabs, rollouts = make_case("quadruped", 0, H_ref=12, H=8, B=1, seed=3)
+    window, ref, q0, q1 = rollouts[0]
+    H = ref.H
+    tr = ref.copy()
+    stride = np.zeros(d.nq); stride[0] = 0.37
+    ompc.rot_n_stride(d, tr, stride)
+    # rotate!: everything moves one step to the left ...
+    np.testing.assert_array_equal(tr.q[:H], ref.q[1:H + 1])
+    np.testing.assert_array_equal(tr.u[:H - 1], ref.u[1:])
+    np.testing.assert_array_equal(tr.u[H - 1], ref.u[0])                  # ... and the first entry goes last
+    np.testing.assert_array_equal(tr.theta[:H - 3], ref.theta[1:H - 2])
+    # mpc_stride!: the last two configurations repeat the first two (after the rotation) plus the stride
+    np.testing.assert_array_equal(tr.q[H], tr.q[0] + stride)
+    np.testing.assert_array_equal(tr.q[H + 1], tr.q[1] + stride)
+    # theta of the last steps reads the new configurations; its u / w / mu / h part is the rotated one
+    for tau in (H - 3, H - 2, H - 1):
+        np.testing.assert_array_equal(tr.theta[tau, d.iq0], tr.q[tau])
+        np.testing.assert_array_equal(tr.theta[tau, d.iq1], tr.q[tau + 1])
+    np.testing.assert_array_equal(tr.theta[H - 1, 2 * d.nq:], ref.theta[0, 2 * d.nq:])
+    # update_window!: wraps at the reference length (policy.jl:162-171)
+    w = np.array([10, 11, 0, 1])
+    np.testing.assert_array_equal(ompc.update_window(w, 12), [11, 0, 1, 2])
+
+
+@pytest.mark.gpu
+def test_mpc_advance_matches_oracle(gpu_required):
+    d, prob, tabs, rollouts = make_case("quadruped", 0, H_ref=12, H=8, B=5, seed=4)
+    s = make_solver(d, prob, rollouts, 8)
+    stride = np.zeros(d.nq); stride[0] = 0.21; stride[3] = -0.05
+    refs = [r.copy() for (_, r, _, _) in rollouts]
+    wins = [np.array(w) for (w, _, _, _) in rollouts]
+    for _ in range(3):
+        s.mpc_advance(stride)
+        for k in range(len(refs)):
+            ompc.rot_n_stride(d, refs[k], stride)
+            wins[k] = ompc.update_window(wins[k], 12)
+    got = s.reference()
+    for k in range(len(refs)):
+        for name in ("q", "u", "w", "gamma", "b", "theta"):
+            np.testing.assert_array_equal(got[name][k], getattr(refs[k], name))
+        np.testing.assert_array_equal(got["window"][k], wins[k] + 1)
+
+
+@pytest.mark.gpu
+def test_mpc_loop_three_steps_warm_start(gpu_required):
+    """policy() cadence (policy.jl:119-141) without the plant: solve, apply the first control of a perfect
+    model (q1_next = planned q_3), rot_n_stride!, update_window!, q0 <- q1, warm-started next solve."""
+    from contactimplicitmpc.jl_amd import NewtonOptions
+    H, H_ref, B = 8, 12, 3
+    d, prob, tabs, rollouts = make_case("quadruped", 0, H_ref=H_ref, H=H, B=B, seed=21, perturb=5e-3)
+    obj = synth.make_objective(d, H)
+    s = make_solver(d, prob, rollouts, H, obj=obj, newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=1e-5, max_iter=4))
+    stride = np.zeros(d.nq); stride[0] = 0.05
+    q0 = np.stack([r[2] for r in rollouts]); q1 = np.stack([r[3] for r in rollouts])
+    cores, refs, wins, oq0, oq1 = [], [], [], [], []
+    for (window, ref, a, b_) in rollouts:
+        refs.append(ref.copy()); wins.append(np.array(window)); oq0.append(a.copy()); oq1.append(b_.copy())
+        cores.append(onewton.Newton(d, H, obj, onewton.NewtonOptions(r_tol=1e-5, max_iter=4, solver="lu"),
+                                    oip.IPOptions(kappa_tol=prob["kappa"]), prob["kappa"], ref))
+    agree = np.ones(B, dtype=bool)
+    for step in range(3):
+        u1, it, rn = s.newton_solve(q0, q1, warm_start=step > 0)
+        tr = s.trajectory(); cnt = s.rollout_counters()
+        for b in range(B):
+            st = onewton.newton_solve(cores[b], oq0[b], oq1[b], wins[b], tabs, refs[b], warm_start=step > 0)
+            same = it[b] == st.iters and cnt["ip_iters"][b] == st.ip_iters
+            agree[b] &= same
+            if agree[b]:      # same discrete path so far
+                np.testing.assert_allclose(u1[b], cores[b].traj.u[0], rtol=0, atol=1e-7)
+                np.testing.assert_allclose(tr["q"][b], cores[b].traj.q, rtol=0, atol=1e-7)
+            ompc.rot_n_stride(d, refs[b], stride)
+            wins[b] = ompc.update_window(wins[b], H_ref)
+            oq0[b], oq1[b] = oq1[b], cores[b].traj.q[2].copy()
+        s.mpc_advance(stride)
+        q0, q1 = q1, tr["q"][:, 2].copy()
+    assert agree.sum() >= B - 1
