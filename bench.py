@@ -100,6 +100,40 @@ def cpu_baseline(d, prob, obj, rollouts, H, H_ref, budget_s=12.0):
     return out
 
 
+def mpc_loop_latency(dims, kind, H, H_ref, device, steps=40):
+    """Warm-started single-rollout MPC loop: newton_solve! -> rot_n_stride! / update_window! -> q0 <- q1."""
+    from oracle import synth
+    from oracle.dims import Dims
+    from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions
+    d = Dims(**dims)
+    prob = synth.make_problem(d, H_ref, seed=1)
+    obj = synth.make_objective(d, H, kind=kind)
+    window, ref, q0, q1 = synth.make_rollout(d, prob, H, phase=0, seed=7, perturb=0.01)
+    s = CIMPCSolver(d.nq, d.nu, d.nw, d.nc, d.nb, H_ref, H, B=1, mode=0, ip_opts=InteriorPointOptions(kappa_tol=prob["kappa"]),
+                    newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=3e-4, max_iter=5), device=device)
+    for t in range(H_ref):
+        s.set_linearization(t + 1, prob["z0"][t], prob["th0"][t], prob["r0"][t], prob["rz0"][t], prob["rth0"][t])
+    s.set_objective(obj.q, obj.u)
+    s.set_window(window[None] + 1)
+    s.set_reference(ref.q[None], ref.u[None], ref.w[None], ref.gamma[None], ref.b[None], ref.theta[None])
+    stride = np.zeros(d.nq)
+    stride[0] = ref.q[-2][0] - ref.q[0][0]          # get_stride, mpc_utils.jl:103-107
+    a, b = q0[None].copy(), q1[None].copy()
+    its = 0
+    t0 = None
+    for k in range(steps + 3):
+        if k == 3:
+            t0 = time.perf_counter()
+            its = 0
+        u1, it, rn = s.newton_solve(a, b, warm_start=k > 0)
+        its += int(it[0])
+        nxt = s.trajectory()["q"][:, 2].copy()
+        s.mpc_advance(stride)
+        a, b = b, nxt
+    dt = time.perf_counter() - t0
+    return {"ms_per_mpc_step": 1e3 * dt / steps, "mpc_steps_per_s": steps / dt, "newton_iters_per_step": its / steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -243,6 +277,10 @@ def main():
             s1.newton_solve_dev(a0.data_ptr(), a1.data_ptr(), False)
         torch.cuda.synchronize()
         out["latency_b1"] = {"ms_per_step": 1e3 * (time.perf_counter() - t1) / n1, "stats": s1.stats()}
+        # the reference's own use: ONE robot, warm-started MPC steps in a loop (policy.jl:98-146 cadence without the
+        # plant: q1_next = planned q_3), reference / window advanced on the device (cimpc_mpc_advance)
+        out["mpc_loop_b1"] = {"quadruped_h40": mpc_loop_latency(QUADRUPED, "quadruped", 40, 60, local_rank),
+                              "hopper_h20 (BASELINE configs[1])": mpc_loop_latency(dict(nq=4, nu=2, nw=2, nc=1, nb=2), "hopper", 20, 30, local_rank)}
     if not args.no_cpu_baseline:
         try:
             cb = cpu_baseline(d, prob, obj, rollouts, H, H_ref)
