@@ -31,20 +31,12 @@ struct ProfRec {
 
 }  // namespace
 
-// Independent sub-batches of rollouts, each driven through its own HIP stream: while one
-// sub-batch sits in a latency-bound phase (KKT recursion, the tail of a sweep, the host
-// round trip) the others keep the CUs busy.  Rollouts never interact, so this is scheduling only.
-struct SubBatch {
-    int b0 = 0, nb = 0;          // rollout range
-    int wg0 = 0, nwg = 0;        // workgroup descriptors of the sweep
+// Streams of the lock-step rounds: the sweep / residual chain runs on `st`, the KKT recursion of the
+// rollouts that start a Newton iteration on `st_kkt` next to it (fork / join by events).
+struct RoundStreams {
     hipStream_t st = nullptr;
-    hipStream_t st_kkt = nullptr;   // the KKT recursion overlaps the sweep of the other rollouts
-    hipEvent_t ev = nullptr, ev_fork = nullptr, ev_join = nullptr;
-    int* d_cnt = nullptr;        // 8 device counters
-    int* h_cnt = nullptr;        // pinned mirror
-    bool running = false;
-    int n_kkt = 0;
-    long long rounds = 0;
+    hipStream_t st_kkt = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 struct cimpc_ctx {
@@ -70,7 +62,6 @@ struct cimpc_ctx {
     double *d_q0 = nullptr, *d_q1 = nullptr;
     double* d_rhs = nullptr;   // B1 seam staging
     double* d_pstate = nullptr;   // parked interior-point iterates
-    int* d_need_first = nullptr;  // need_sweep pattern {1,0,0,0} per rollout (B3 seam)
     int iter_cap = 16;
     NewtonDev S{};
     int* h_counters = nullptr;   // pinned
@@ -84,11 +75,9 @@ struct cimpc_ctx {
     double *d_V = nullptr, *d_qt = nullptr, *d_vt = nullptr;
     int waves = 4;
     bool kkt_overlap = true;
-    int pipeline_depth = 1;
     int* d_ring = nullptr;       // [MAX_DEPTH][8] device counters per in-flight round
     int* h_ring = nullptr;       // pinned, host-mapped: {n_sweep, n_kkt, stamp}
     int* h_ring_dev = nullptr;   // device pointer of h_ring
-    hipEvent_t ev_ring[4] = {nullptr, nullptr, nullptr, nullptr};
     // asynchronous single-launch solve (newton_async_impl.h)
     bool async_on = false, async_dirty = true;   // async_on: buffers allocated, kernel available
     int async_mode = 2;          // 0 lock-step only, 1 always the single launch, 2 auto (by batch size / hybrid tail)
@@ -100,7 +89,7 @@ struct cimpc_ctx {
     long long* a_dbg = nullptr;  // [16] diagnostics (CIMPC_ASYNC_DEBUG)
     size_t a_cap = 0, a_rq_cap = 0, a_kq_cap = 0;
     int a_grid = 0, a_service = 0;
-    std::vector<SubBatch> subs;
+    RoundStreams rs;
     bool external_stream = false;
     std::vector<double> h_tab;       // one knot staging
     cimpc_stats last_stats{};
@@ -201,7 +190,8 @@ void prof_end(cimpc_ctx* h, hipStream_t st = nullptr) {
 void prof_collect(cimpc_ctx* h) {
     if (h->prof_recs.empty()) return;
     (void)hipStreamSynchronize(h->stream);
-    for (auto& sb : h->subs) { if (sb.st) (void)hipStreamSynchronize(sb.st); if (sb.st_kkt) (void)hipStreamSynchronize(sb.st_kkt); }
+    if (h->rs.st) (void)hipStreamSynchronize(h->rs.st);
+    if (h->rs.st_kkt) (void)hipStreamSynchronize(h->rs.st_kkt);
     for (auto& r : h->prof_recs) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
@@ -426,7 +416,6 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     AX(&S.delta, B * h->N);
     AX(&S.r_norm, B); AX(&S.r_cand, BS); AX(&S.alpha, B); AX(&S.beta, B);
     AX(&S.ls_iter, B); AX(&S.newton_l, B); AX(&S.stage, B); AX(&S.need_sweep, BS);
-    A(&h->d_need_first, BS);
     AX(&S.counters, 8);
     AX(&S.stats, 4);
     AX(&S.ro_sweeps, B); AX(&S.ro_ip_iters, B); AX(&S.ro_ip_fail, B);
@@ -452,18 +441,11 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     h->waves = (B * H >= 4096) ? 4 : 1;
     if (getenv("CIMPC_WAVES")) { const int w = atoi(getenv("CIMPC_WAVES")); if (w == 1 || w == 2 || w == 4) h->waves = w; }
     h->kkt_overlap = B >= 64;
-    // depth 1 measured fastest on MI355X (B = 512: 16.9 ms/step vs 17.8 ms at depth 3, because a deeper
-    // pipeline has to launch the KKT kernel every round); the ring stays for experiments
-    h->pipeline_depth = 1;
     if (dev_alloc(h, &h->d_ring, 32) != CIMPC_OK ||
         hipHostMalloc((void**)&h->h_ring, 32 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&h->h_ring_dev, h->h_ring, 0) != hipSuccess) {
         g_create_error = "ring allocation failed"; cimpc_destroy(h); return CIMPC_ERR_HIP;
     }
-    for (int k = 0; k < 4; ++k)
-        if (hipEventCreateWithFlags(&h->ev_ring[k], hipEventDisableTiming) != hipSuccess) {
-            g_create_error = "event creation failed"; cimpc_destroy(h); return CIMPC_ERR_HIP;
-        }
     {
         const size_t K = d.H_ref;
         if (h->async_on) {
@@ -491,30 +473,14 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         h->a_grid = (int)std::min<size_t>(resident, (size_t)h->wpk + h->a_service);
         if (h->a_grid <= h->a_service) h->a_grid = h->a_service + 1;
     }
-    {   // sub-batches: >= 64 rollouts each, at most 4 (host launch rate bounds the useful count)
-        // default 1: on MI355X a sweep launch of >= 64 rollouts already fills the 2 workgroups/CU the
-        // kernel's LDS footprint allows, so extra streams only multiply the per-launch latency floor
-        // (measured: 4 sub-batches 34.8 ms/step vs 28.2 ms single batch at B = 512).  CIMPC_SUBBATCHES
-        // overrides for experiments.
-        int nsub = 1;      // the device work queues are shared by the whole batch
-        h->subs.resize(nsub);
-        int* dc = nullptr;
-        if (dev_alloc(h, &dc, 8 * (size_t)nsub) != CIMPC_OK) { g_create_error = h->err; cimpc_destroy(h); return CIMPC_ERR_HIP; }
-        for (int k = 0; k < nsub; ++k) {
-            SubBatch& sb = h->subs[k];
-            sb.b0 = (int)(B * k / nsub);
-            sb.nb = (int)(B * (k + 1) / nsub) - sb.b0;
-            sb.d_cnt = dc + 8 * k;
-            if (hipStreamCreateWithFlags(&sb.st, hipStreamNonBlocking) != hipSuccess ||
-                hipStreamCreateWithFlags(&sb.st_kkt, hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&sb.ev, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&sb.ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&sb.ev_join, hipEventDisableTiming) != hipSuccess ||
-                hipHostMalloc((void**)&sb.h_cnt, 8 * sizeof(int)) != hipSuccess) {
-                g_create_error = "sub-batch stream/event creation failed";
-                cimpc_destroy(h);
-                return CIMPC_ERR_HIP;
-            }
+    {   // streams of the rounds (one batch: sub-batch streams were measured and only multiply the per-launch
+        // latency floor - 4 sub-batches 34.8 ms/step vs 28.2 ms single batch at B = 512)
+        RoundStreams& r = h->rs;
+        if (hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&r.st_kkt, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&r.ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&r.ev_join, hipEventDisableTiming) != hipSuccess) {
+            g_create_error = "stream creation failed"; cimpc_destroy(h); return CIMPC_ERR_HIP;
         }
     }
     *out = h;
@@ -530,14 +496,12 @@ int cimpc_destroy(cimpc_handle h) {
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->h_counters) (void)hipHostFree(h->h_counters);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
-    for (int k = 0; k < 4; ++k) if (h->ev_ring[k]) (void)hipEventDestroy(h->ev_ring[k]);
-    for (auto& sb : h->subs) {
-        if (sb.st) { (void)hipStreamSynchronize(sb.st); (void)hipStreamDestroy(sb.st); }
-        if (sb.st_kkt) { (void)hipStreamSynchronize(sb.st_kkt); (void)hipStreamDestroy(sb.st_kkt); }
-        if (sb.ev) (void)hipEventDestroy(sb.ev);
-        if (sb.ev_fork) (void)hipEventDestroy(sb.ev_fork);
-        if (sb.ev_join) (void)hipEventDestroy(sb.ev_join);
-        if (sb.h_cnt) (void)hipHostFree(sb.h_cnt);
+    {
+        RoundStreams& r = h->rs;
+        if (r.st) { (void)hipStreamSynchronize(r.st); (void)hipStreamDestroy(r.st); }
+        if (r.st_kkt) { (void)hipStreamSynchronize(r.st_kkt); (void)hipStreamDestroy(r.st_kkt); }
+        if (r.ev_fork) (void)hipEventDestroy(r.ev_fork);
+        if (r.ev_join) (void)hipEventDestroy(r.ev_join);
     }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -807,7 +771,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     //      from the start (from_reset) or with the rollouts the lock-step rounds left active (hybrid). ----
     auto run_async = [&](bool from_reset, long long rounds_before) -> int {
         IpQueues LQ = h->Q; LQ.par = (int)(rounds_before & 1);      // lock-step queue of the round that would come next
-        hipStream_t st = h->external_stream ? h->stream : h->subs[0].st;
+        hipStream_t st = h->external_stream ? h->stream : h->rs.st;
         const size_t K = h->Q.K;
         if (h->async_dirty) {     // entries are reset by their consumers; only an aborted solve leaves some behind
             HIP_TRY(h, hipMemsetAsync(h->a_items, 0xFF, K * h->a_cap * sizeof(int), st));
@@ -820,6 +784,9 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         NewtonDev Sk = S;
         Sk.b0 = 0; Sk.nb_launch = h->dm.B; Sk.counters = h->d_ring; Sk.counters_next = h->d_ring + 8;
         Sk.host_flag = h->h_ring_dev;
+        // the tail is latency-bound: its stragglers (rollouts that exhaust the line search in every iteration)
+        // evaluate all seven step lengths at once there, whatever the throughput-oriented setting of the rounds
+        if (!from_reset) Sk.spec_all = getenv("CIMPC_SPEC_TAIL") ? atoi(getenv("CIMPC_SPEC_TAIL")) : 3;
         Sk.WQ = h->Q; Sk.WQ.par = 0;
         Sk.WQ.items = h->a_items; Sk.WQ.cap = (int)h->a_cap;
         Sk.WQ.count = h->a_ctrl; Sk.WQ.head = h->a_ctrl + K * QPAD;
@@ -887,20 +854,13 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     // safety net only: every Newton iteration needs at most 3 (speculative) rounds, each evaluation at
     // most ceil(max_iter / iter_cap) launches of the resumable interior-point sweep
     const int max_rounds = (h->nt.max_iter * 8 + 2) * ((h->ip.max_iter + h->iter_cap - 1) / h->iter_cap + 1);
-    // one batch on the caller's stream, or independent sub-batches on private streams
-    std::vector<SubBatch> single(1);
-    if (h->external_stream) {
-        single[0] = h->subs[0];
-        single[0].b0 = 0; single[0].nb = h->dm.B;
-        single[0].st = h->stream;
-    }
-    std::vector<SubBatch>& subs = h->external_stream ? single : h->subs;
-    SubBatch& sb = subs[0];
-    // Pipelined lock-step rounds.  Every kernel of a round is driven by device-side state (work
-    // queues, per-rollout stage), so rounds can be enqueued AHEAD of the host's knowledge: up to
-    // `depth` rounds are in flight, the host only looks at the counters of the oldest one, and
-    // rounds launched after the batch has finished find empty queues and return immediately.
-    const int depth = h->pipeline_depth;
+    // the rounds run on the library's private streams, or on the caller's stream when one was given
+    RoundStreams sb = h->rs;
+    if (h->external_stream) sb.st = h->stream;
+    // Lock-step rounds.  Every kernel of a round is driven by device-side state (work queues, per-rollout
+    // stage); the host only looks at the counters the last residual block publishes.  (Enqueueing rounds
+    // ahead of the host's knowledge was measured: slower, the KKT kernel then has to be launched every round.)
+    const int depth = 1;
     long long launched = 0, completed = 0, rounds = 0;
     static const bool dbg_rounds = getenv("CIMPC_DEBUG_ROUNDS") != nullptr;
     int last_kkt = 0, last_sweep = h->dm.B;
