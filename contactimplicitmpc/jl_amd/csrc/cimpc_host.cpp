@@ -819,12 +819,23 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         rc2 = launch_newton_async(&h->dm, p, Sk, h->waves, h->a_grid, st);
         prof_end(h, st);
         if (rc2 != CIMPC_OK) return fail(h, rc2, "asynchronous newton launch failed");
-        if (h->nt.max_time > 0.0 && h->nt.max_time < 1.0e6) {      // newton.jl:187-277: the time budget ends the loop silently
-            while (hipStreamQuery(st) == hipErrorNotReady) {
-                if (over_budget()) { hm[3] = 1; h->async_dirty = true; break; }
+        // The host watches the persistent kernel: the reference's wall-clock budget ends the loop silently
+        // (newton.jl:187-277), and a watchdog turns a kernel that stopped making progress into an error
+        // instead of a hang (the kernel polls the host-mapped abort flag).
+        static const double watchdog_s = getenv("CIMPC_ASYNC_WATCHDOG_S") ? atof(getenv("CIMPC_ASYNC_WATCHDOG_S")) : 30.0;
+        const bool budget = h->nt.max_time > 0.0 && h->nt.max_time < 1.0e6;
+        bool timed_out = false;
+        const auto tw = std::chrono::steady_clock::now();
+        long long polls = 0;
+        while (hipStreamQuery(st) == hipErrorNotReady) {
+            if (budget && over_budget()) { hm[3] = 1; h->async_dirty = true; break; }
+            if ((++polls & 0x3FF) == 0 &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count() > watchdog_s) {
+                hm[3] = 1; h->async_dirty = true; timed_out = true; break;
             }
         }
         HIP_TRY(h, hipStreamSynchronize(st));
+        if (timed_out) return fail(h, CIMPC_ERR_HIP, "asynchronous solve: watchdog expired (no completion within CIMPC_ASYNC_WATCHDOG_S)");
         if (h->a_dbg) {
             long long dv[16];
             HIP_TRY(h, hipMemcpy(dv, h->a_dbg, sizeof(dv), hipMemcpyDeviceToHost));

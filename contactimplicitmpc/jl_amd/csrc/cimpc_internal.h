@@ -78,7 +78,8 @@ __device__ __forceinline__ void aq_push(int* items, int* tail, int v) {
 }
 // multi-consumer pop by ONE lane: -1 when the queue is empty.  dbg (optional): [0] CAS attempts, [1] sentinel spins,
 // [2] ticks in the claim loop, [3] ticks waiting for the entry
-__device__ __forceinline__ int aq_pop(int* items, int* head, const int* tail, long long* dbg = nullptr) {
+__device__ __forceinline__ int aq_pop(int* items, int* head, const int* tail, long long* dbg = nullptr,
+                                      volatile int* abort_flag = nullptr) {
     const long long t0 = dbg ? wall_clock64() : 0;
     int h = aload(head);
     int cas = 0;
@@ -91,7 +92,12 @@ __device__ __forceinline__ int aq_pop(int* items, int* head, const int* tail, lo
     }
     const long long t1 = dbg ? wall_clock64() : 0;
     int v, spins = 0;
-    while ((v = aload(items + h)) < 0) { __builtin_amdgcn_s_sleep(1); ++spins; }
+    while ((v = aload(items + h)) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        // (the producer reserved this entry before we could claim it, so the wait is short; the host's
+        //  watchdog / time budget can still end it)
+        if ((++spins & 0xFFFF) == 0 && abort_flag != nullptr && *abort_flag != 0) return -1;
+    }
     astore(items + h, -1);        // the queue is clean again when every entry has been consumed
     if (dbg) { dbg[0] += cas; dbg[1] += spins; dbg[2] += t1 - t0; dbg[3] += wall_clock64() - t1; }
     return v;

@@ -463,7 +463,7 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
             int idx = 0, item = 0;
             if constexpr (ASYNC) {       // live queue: claim only what has been published
                 const long long tq0 = wall_clock64();
-                if (l == 0) item = aq_pop(const_cast<int*>(items), head, tailp, p.A.dbg ? dbg_pop : nullptr);
+                if (l == 0) item = aq_pop(const_cast<int*>(items), head, tailp, p.A.dbg ? dbg_pop : nullptr, p.A.abort_flag);
                 item = group_bcast0<G>(item);
                 idx = item < 0 ? n : 0;
                 const long long tq1 = wall_clock64();

@@ -95,9 +95,9 @@ __global__ __launch_bounds__(256, 2) void newton_async_kernel(AsyncArgs args) {
             // the abort flag lives in host memory (one PCIe read): looked at now and then only
             if ((trip++ & 31u) == 31u && *A.abort_flag != 0) {
                 type = 3;
-            } else if ((job = aq_pop(A.kq_items, A.kq_head, A.kq_tail)) >= 0) {
+            } else if ((job = aq_pop(A.kq_items, A.kq_head, A.kq_tail, nullptr, A.abort_flag)) >= 0) {
                 type = 1;       // KKT first: it heads the longest chain of a rollout
-            } else if ((job = aq_pop(A.rq_items, A.rq_head, A.rq_tail)) >= 0) {
+            } else if ((job = aq_pop(A.rq_items, A.rq_head, A.rq_tail, nullptr, A.abort_flag)) >= 0) {
                 type = 2;
             }
             s_job[0] = type; s_job[1] = job;
