@@ -441,6 +441,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     h->waves = (B * H >= 4096) ? 4 : 1;
     if (getenv("CIMPC_WAVES")) { const int w = atoi(getenv("CIMPC_WAVES")); if (w == 1 || w == 2 || w == 4) h->waves = w; }
     h->kkt_overlap = B >= 64;
+    if (getenv("CIMPC_KKT_OVERLAP")) h->kkt_overlap = atoi(getenv("CIMPC_KKT_OVERLAP")) != 0;
     if (dev_alloc(h, &h->d_ring, 32) != CIMPC_OK ||
         hipHostMalloc((void**)&h->h_ring, 32 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&h->h_ring_dev, h->h_ring, 0) != hipSuccess) {
@@ -802,6 +803,9 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         A.n_service = h->a_service;
         A.flags = getenv("CIMPC_ASYNC_FLAGS") ? atoi(getenv("CIMPC_ASYNC_FLAGS")) : 0;
         A.idle_sleep = getenv("CIMPC_ASYNC_SLEEP") ? atoi(getenv("CIMPC_ASYNC_SLEEP")) : 2;
+        A.idle_spins = getenv("CIMPC_ASYNC_SPINS") ? std::max(1, atoi(getenv("CIMPC_ASYNC_SPINS"))) : 48;
+        A.wake_fan = getenv("CIMPC_ASYNC_FAN") ? atoi(getenv("CIMPC_ASYNC_FAN")) : 1;
+        if (A.wake_fan != 1 && A.wake_fan != 2 && A.wake_fan != 4 && A.wake_fan != 8 && A.wake_fan != 16) A.wake_fan = 1;
         A.dbg = h->a_dbg;
         if (h->a_dbg) HIP_TRY(h, hipMemsetAsync(h->a_dbg, 0, 16 * sizeof(long long), st));
         A.B = h->dm.B;

@@ -47,6 +47,8 @@ struct AsyncQ {
     int n_service;      // workgroups [0, n_service) only take residual / KKT jobs
     int flags;          // experiment switches, see xfence()
     int idle_sleep;     // back-off of an idle workgroup between polls, units of s_sleep(64) (~2 us)
+    int idle_spins;     // polls before an idle workgroup looks around unprompted
+    int wake_fan;       // buckets woken per evaluation request (each bucket = 1/16 of the workgroups)
     int B;
 };
 
@@ -103,7 +105,10 @@ __device__ __forceinline__ int aq_pop(int* items, int* head, const int* tail, lo
     return v;
 }
 
-__device__ __forceinline__ void wake_ip(const AsyncQ& A, int b) { atomicAdd(A.epoch + (b & 15) * 16, 1); }
+// an evaluation spreads over up to H knots and every knot needs a workgroup of its own: wake `wake_fan` buckets
+__device__ __forceinline__ void wake_ip(const AsyncQ& A, int b) {
+    for (int k = 0; k < A.wake_fan; ++k) atomicAdd(A.epoch + ((b + k * (16 / A.wake_fan)) & 15) * 16, 1);
+}
 __device__ __forceinline__ void wake_job(const AsyncQ& A, int b) { atomicAdd(A.epoch + (16 + (b & 15)) * 16, 1); }
 __device__ __forceinline__ void wake_all(const AsyncQ& A) { for (int k = 0; k < 32; ++k) atomicAdd(A.epoch + k * 16, 1); }
 

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void newton_async_kernel(AsyncArgs args) {
             unsigned spins = 0;
             while (!leave && (service || aload(wi) == s_epoch[0]) && aload(wj) == s_epoch[1]) {
                 for (int k = 0; k < A.idle_sleep; ++k) __builtin_amdgcn_s_sleep(64);
-                if (++spins >= 48u) break;
+                if (++spins >= (unsigned)A.idle_spins) break;
             }
             if (!leave && *A.abort_flag != 0) leave = 1;
             s_job[0] = leave;
