@@ -469,9 +469,12 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         h->wpk = (int)std::max<size_t>(1, std::min<size_t>(w, resident));
         if (getenv("CIMPC_SWEEP_WGS")) h->wpk = std::max(1, atoi(getenv("CIMPC_SWEEP_WGS")));
         // asynchronous solve: the same resident set plus dedicated residual/KKT workgroups
-        h->a_service = std::max(1, h->wpk / 8);
+        // (a line-search burst is up to 7 evaluations x H knots per rollout and every knot needs a workgroup of
+        //  its own: small batches get at least 240 - measured B = 8: 6.4 -> 5.1 ms, B = 128: 11.1 -> 10.3 ms)
+        const int a_wgs = getenv("CIMPC_SWEEP_WGS") ? h->wpk : std::max(h->wpk, 240);
+        h->a_service = std::max(1, a_wgs / 8);
         if (getenv("CIMPC_ASYNC_SERVICE")) h->a_service = std::max(1, atoi(getenv("CIMPC_ASYNC_SERVICE")));
-        h->a_grid = (int)std::min<size_t>(resident, (size_t)h->wpk + h->a_service);
+        h->a_grid = (int)std::min<size_t>(resident, (size_t)a_wgs + h->a_service);
         if (h->a_grid <= h->a_service) h->a_grid = h->a_service + 1;
     }
     {   // streams of the rounds (one batch: sub-batch streams were measured and only multiply the per-launch
