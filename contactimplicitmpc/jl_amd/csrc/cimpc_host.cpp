@@ -451,7 +451,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         const size_t K = d.H_ref;
         if (h->async_on) {
             if (dev_alloc(h, &h->a_items, K * h->a_cap, xm) != CIMPC_OK || dev_alloc(h, &h->a_jobs, h->a_rq_cap + h->a_kq_cap, xm) != CIMPC_OK ||
-                dev_alloc(h, &h->a_ctrl, 2 * K * QPAD + 64 + 32 * 16, xm) != CIMPC_OK || dev_alloc(h, &h->a_evals, B, xm) != CIMPC_OK) {
+                dev_alloc(h, &h->a_ctrl, 2 * K * QPAD + 64 + 33 * 16, xm) != CIMPC_OK || dev_alloc(h, &h->a_evals, B, xm) != CIMPC_OK) {
                 g_create_error = h->err; cimpc_destroy(h); return CIMPC_ERR_HIP;
             }
             if (getenv("CIMPC_ASYNC_DEBUG") && dev_alloc(h, &h->a_dbg, 16) != CIMPC_OK) { g_create_error = h->err; cimpc_destroy(h); return CIMPC_ERR_HIP; }
@@ -782,7 +782,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             HIP_TRY(h, hipMemsetAsync(h->a_jobs, 0xFF, (h->a_rq_cap + h->a_kq_cap) * sizeof(int), st));
             h->async_dirty = false;
         }
-        HIP_TRY(h, hipMemsetAsync(h->a_ctrl, 0, (2 * K * QPAD + 64 + 32 * 16) * sizeof(int), st));
+        HIP_TRY(h, hipMemsetAsync(h->a_ctrl, 0, (2 * K * QPAD + 64 + 33 * 16) * sizeof(int), st));
         volatile int* hm = (volatile int*)h->h_ring;
         hm[3] = 0;
         NewtonDev Sk = S;

@@ -40,7 +40,7 @@ struct AsyncQ {
     int* kq_tail;
     int* evals_left;    // [B] evaluation slots of the rollout's running line-search batch not yet complete
     int* n_done;        // rollouts whose Newton solve has ended
-    int* epoch;         // wake-up words, 64 B apart: [0,16) interior-point work, [16,32) jobs; bucket = rollout % 16.
+    int* epoch;         // wake-up words, 64 B apart: [0,16) interior-point work, [16,32) jobs, 32 = any job; bucket = rollout % 16.
                         // An idle workgroup polls only the two words of its own bucket (blockIdx % 16).
     volatile int* abort_flag;   // host-mapped: nonzero = time budget exhausted, leave
     long long* dbg;     // [16] diagnostics (busy ticks / job counts per kind of work) or null
@@ -109,8 +109,13 @@ __device__ __forceinline__ int aq_pop(int* items, int* head, const int* tail, lo
 __device__ __forceinline__ void wake_ip(const AsyncQ& A, int b) {
     for (int k = 0; k < A.wake_fan; ++k) atomicAdd(A.epoch + ((b + k * (16 / A.wake_fan)) & 15) * 16, 1);
 }
-__device__ __forceinline__ void wake_job(const AsyncQ& A, int b) { atomicAdd(A.epoch + (16 + (b & 15)) * 16, 1); }
-__device__ __forceinline__ void wake_all(const AsyncQ& A) { for (int k = 0; k < 32; ++k) atomicAdd(A.epoch + k * 16, 1); }
+// jobs head the rollout's chain: the (few) dedicated service workgroups all wake on word 32, the
+// interior-point workgroups of the rollout's bucket on their job word
+__device__ __forceinline__ void wake_job(const AsyncQ& A, int b) {
+    atomicAdd(A.epoch + 32 * 16, 1);
+    atomicAdd(A.epoch + (16 + (b & 15)) * 16, 1);
+}
+__device__ __forceinline__ void wake_all(const AsyncQ& A) { for (int k = 0; k <= 32; ++k) atomicAdd(A.epoch + k * 16, 1); }
 
 __device__ __forceinline__ int* qcount(const IpQueues& Q, int par, int k) { return Q.count + ((size_t)par * Q.K + k) * QPAD; }
 __device__ __forceinline__ int* qhead(const IpQueues& Q, int k) { return Q.head + (size_t)k * QPAD; }

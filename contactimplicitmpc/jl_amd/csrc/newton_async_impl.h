@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void newton_async_kernel(AsyncArgs args) {
             int type = 0, job = -1;
             // wake-up words of this workgroup's bucket, read BEFORE looking for work (a push during the scan changes them)
             s_epoch[0] = aload(A.epoch + ((int)blockIdx.x & 15) * 16);
-            s_epoch[1] = aload(A.epoch + (16 + ((int)blockIdx.x & 15)) * 16);
+            s_epoch[1] = aload(A.epoch + (service ? 32 : 16 + ((int)blockIdx.x & 15)) * 16);
             // the abort flag lives in host memory (one PCIe read): looked at now and then only
             if ((trip++ & 31u) == 31u && *A.abort_flag != 0) {
                 type = 3;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void newton_async_kernel(AsyncArgs args) {
         if (tid == 0) {
             int leave = aload(A.n_done) >= A.B;
             const int* wi = A.epoch + ((int)blockIdx.x & 15) * 16;
-            const int* wj = A.epoch + (16 + ((int)blockIdx.x & 15)) * 16;
+            const int* wj = A.epoch + (service ? 32 : 16 + ((int)blockIdx.x & 15)) * 16;
             unsigned spins = 0;
             while (!leave && (service || aload(wi) == s_epoch[0]) && aload(wj) == s_epoch[1]) {
                 for (int k = 0; k < A.idle_sleep; ++k) __builtin_amdgcn_s_sleep(64);
