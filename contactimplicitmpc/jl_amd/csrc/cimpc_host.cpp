@@ -439,6 +439,9 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     // small batches: one wave per workgroup keeps every problem on its own CU (latency);
     // large batches: 4 waves share one staged table (throughput)
     h->waves = (B * H >= 4096) ? 4 : 1;
+    // the single-launch solve runs its residual jobs on the whole workgroup: 4 waves also for small batches
+    // (measured B = 8: 5.2 -> 4.4 ms, B = 64: 8.5 -> 7.5 ms)
+    if (h->async_on && (h->async_mode == 1 || (h->async_mode == 2 && B >= 8 && B <= 128))) h->waves = 4;
     if (getenv("CIMPC_WAVES")) { const int w = atoi(getenv("CIMPC_WAVES")); if (w == 1 || w == 2 || w == 4) h->waves = w; }
     h->kkt_overlap = B >= 64;
     if (getenv("CIMPC_KKT_OVERLAP")) h->kkt_overlap = atoi(getenv("CIMPC_KKT_OVERLAP")) != 0;
