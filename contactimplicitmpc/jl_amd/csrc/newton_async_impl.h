@@ -68,7 +68,6 @@ __global__ __launch_bounds__(256, 2) void newton_async_kernel(AsyncArgs args) {
     constexpr int NQ = M::NQ, NU = M::NU;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int s_knot, s_total, s_rem[PICK_MAXK], s_job[2], s_epoch[2];
-    __shared__ double red[256];
     __shared__ double rc[CS];
     __shared__ int sh[4];
     const int tid = (int)threadIdx.x;
@@ -116,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void newton_async_kernel(AsyncArgs args) {
         if (type == 2) {
             xfence(A.flags);                             // acquire d / dz / status of the evaluations
             account(0);
-            async_resid_job<NQ, NU>(ka, job, red, rc, sh);
+            async_resid_job<NQ, NU>(ka, job, smem, rc, sh);      // reduction scratch [CS][256] in the (idle) table area
             __syncthreads();
             account(2);
             continue;

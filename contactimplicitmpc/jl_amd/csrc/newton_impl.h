@@ -167,9 +167,10 @@ __device__ __forceinline__ void start_line_search(const NewtonDev& S, int b, int
 }
 
 
-// residual! on evaluation slot sb (candidate trajectory, nu_cand, d, dz of that slot); returns |r|_1
+// residual! on evaluation slot sb (candidate trajectory, nu_cand, d, dz of that slot): writes res_cand of the
+// slot and returns THIS THREAD's share of |r|_1 (the caller reduces all candidate slots in one pass)
 template <int NQ, int NU, bool CF>
-__device__ double slot_residual(const NewtonDev& S, size_t sb, int b, double* red, int tid, int nt) {
+__device__ double slot_residual(const NewtonDev& S, size_t sb, int b, int tid, int nt) {
     const cimpc_dims& m = S.dm;
     constexpr int nq = NQ, nu = NU;
     constexpr bool cf = CF;
@@ -257,15 +258,7 @@ __device__ double slot_residual(const NewtonDev& S, size_t sb, int b, double* re
         r[e] = v;
         part += fabs(v);
     }
-    red[tid] = part;
-    __syncthreads();
-    for (int s = nt / 2; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
-        __syncthreads();
-    }
-    const double out = red[0];
-    __syncthreads();
-    return out;
+    return part;
 }
 
 template <int NQ, int NU, bool CF, bool ASYNC>
@@ -292,11 +285,20 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
         }
     }
     int& s_act = sh[0]; int& s_slot = sh[1]; int& s_iter = sh[2];
-    for (int c = 0; c < ncand; ++c) {
-        const double v = slot_residual<NQ, NU, CF>(S, sb0 + c, b, red, tid, nt);
-        if (tid == 0) { rc[c] = v; S.r_cand[sb0 + c] = v; }
+    {   // all candidate slots, ONE reduction pass (red: [CS][nt]; per slot the same pairwise tree as a single
+        // reduction, so the norms do not depend on how many candidates share the pass)
+#pragma unroll
+        for (int c = 0; c < CS; ++c)
+            if (c < ncand) red[c * nt + tid] = slot_residual<NQ, NU, CF>(S, sb0 + c, b, tid, nt);
+        __syncthreads();
+        for (int st = nt / 2; st > 0; st >>= 1) {
+            if (tid < st)
+                for (int c = 0; c < ncand; ++c) red[c * nt + tid] += red[c * nt + tid + st];
+            __syncthreads();
+        }
+        if (tid < ncand) { rc[tid] = red[tid * nt]; S.r_cand[sb0 + tid] = red[tid * nt]; }
+        __syncthreads();
     }
-    __syncthreads();
     // ---- decision (newton.jl:198-280) ------------------------------------------------------
     if (tid == 0) {
         int act = 2, slot = 0, iter = 0;   // act: 0 accept initial evaluation, 1 accept step, 2 more candidates
@@ -327,13 +329,16 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
             if (k < nref * H) { its_ref += it; fails_ref += fl; }
         }
         // pack four small counters into the double reduction buffer (exact up to 2^53)
-        red[tid] = (double)its; __syncthreads();
-        for (int st = nt / 2; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
-        const double t_its = red[0]; __syncthreads();
-        red[tid] = (double)fails + 4096.0 * (double)fails_ref + 16777216.0 * (double)its_ref; __syncthreads();
-        for (int st = nt / 2; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+        red[tid] = (double)its;
+        red[nt + tid] = (double)fails + 4096.0 * (double)fails_ref + 16777216.0 * (double)its_ref;
+        __syncthreads();
+        for (int st = nt / 2; st > 0; st >>= 1) {
+            if (tid < st) { red[tid] += red[tid + st]; red[nt + tid] += red[nt + tid + st]; }
+            __syncthreads();
+        }
+        const double t_its = red[0];
         if (tid == 0) {
-            const long long packed = (long long)red[0];
+            const long long packed = (long long)red[nt];
             const long long t_fails = packed & 4095, t_fails_ref = (packed >> 12) & 4095, t_its_ref = packed >> 24;
             S.ro_sweeps[b] += nref;
             S.ro_ip_iters[b] += (int)t_its_ref;
@@ -415,7 +420,7 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
 
 template <int NQ, int NU, bool CF>
 __global__ __launch_bounds__(256) void resid_decide_kernel(NewtonDev S) {
-    __shared__ double red[256];
+    __shared__ double red[CS * 256];
     __shared__ double rc[CS];
     __shared__ int sh[4];
     resid_decide_body<NQ, NU, CF, false>(S, (int)blockIdx.x + S.b0, red, rc, sh);
