@@ -1,0 +1,105 @@
+"""Edge cases and error behaviour of the C ABI on the device (SURVEY.md section 8b contract: int status,
+no exceptions across the boundary, messages through cimpc_last_error)."""
+import numpy as np
+import pytest
+
+from oracle import ip as oip, newton as onewton, synth
+
+from common import make_case, make_solver
+
+pytestmark = pytest.mark.gpu
+
+
+def _fresh(model="hopper", H_ref=8, H=6, B=2, seed=3, set_tables=True):
+    from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions
+    d, prob, tabs, rollouts = make_case(model, 0, H_ref=H_ref, H=H, B=B, seed=seed)
+    s = CIMPCSolver(d.nq, d.nu, d.nw, d.nc, d.nb, H_ref, H, B=B, mode=0,
+                    ip_opts=InteriorPointOptions(kappa_tol=prob["kappa"]), newton_opts=NewtonOptions(kappa=prob["kappa"]))
+    if set_tables:
+        for t in range(H_ref):
+            s.set_linearization(t + 1, prob["z0"][t], prob["th0"][t], prob["r0"][t], prob["rz0"][t], prob["rth0"][t])
+    return s, d, prob, tabs, rollouts
+
+
+def test_call_order_is_enforced(gpu_required):
+    from contactimplicitmpc.jl_amd import CimpcError
+    s, d, prob, tabs, rollouts = _fresh(set_tables=False)
+    q0 = np.stack([r[2] for r in rollouts]); q1 = np.stack([r[3] for r in rollouts])
+    with pytest.raises(CimpcError, match="set_linearization"):
+        s.newton_solve(q0, q1)
+    for t in range(8):
+        s.set_linearization(t + 1, prob["z0"][t], prob["th0"][t], prob["r0"][t], prob["rz0"][t], prob["rth0"][t])
+    with pytest.raises(CimpcError, match="set_window"):
+        s.newton_solve(q0, q1)
+    s.set_window(np.stack([w for (w, _, _, _) in rollouts]) + 1)
+    with pytest.raises(CimpcError, match="set_objective"):
+        s.newton_solve(q0, q1)
+
+
+def test_bad_arguments_are_rejected(gpu_required):
+    from contactimplicitmpc.jl_amd import CIMPCSolver, CimpcError
+    s, d, prob, tabs, rollouts = _fresh()
+    w = np.stack([w for (w, _, _, _) in rollouts]) + 1
+    bad = w.copy(); bad[0, 0] = 0                       # 1-based knots: 0 is out of range
+    with pytest.raises(CimpcError, match="window"):
+        s.set_window(bad)
+    bad[0, 0] = 9                                       # H_ref = 8
+    with pytest.raises(CimpcError, match="window"):
+        s.set_window(bad)
+    with pytest.raises(CimpcError):
+        s.set_linearization(0, prob["z0"][0], prob["th0"][0], prob["r0"][0], prob["rz0"][0], prob["rth0"][0])
+    with pytest.raises(CimpcError):                     # dimensions no kernel is instantiated for
+        CIMPCSolver(5, 3, 2, 1, 2, 8, 6, B=1, mode=0)
+
+
+def test_single_rollout_minimum_horizon_and_wrapping_window(gpu_required):
+    """B = 1, H = 1 (the shortest horizon) and a window that wraps around the reference."""
+    from contactimplicitmpc.jl_amd import NewtonOptions
+    for H, H_ref, phase in ((1, 4, 3), (3, 4, 2)):
+        d, prob, tabs, _ = make_case("hopper", 0, H_ref=H_ref, H=H, B=1, seed=6)
+        ro = [synth.make_rollout(d, prob, H, phase=phase, seed=66, perturb=5e-3)]
+        assert ro[0][0].max() == H_ref - 1 and np.any(np.diff(ro[0][0]) < 0)      # the window wraps
+        obj = synth.make_objective(d, H, kind="hopper")
+        s = make_solver(d, prob, ro, H, obj=obj, newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=1e-5, max_iter=3))
+        u1, it, rn = s.newton_solve(ro[0][2][None], ro[0][3][None])
+        window, ref, q0, q1 = ro[0]
+        core = onewton.Newton(d, H, obj, onewton.NewtonOptions(r_tol=1e-5, max_iter=3, solver="lu"),
+                              oip.IPOptions(kappa_tol=prob["kappa"]), prob["kappa"], ref)
+        st = onewton.newton_solve(core, q0, q1, window, tabs, ref)
+        assert it[0] == st.iters
+        np.testing.assert_allclose(u1[0], core.traj.u[0], rtol=0, atol=1e-7)
+
+
+def test_zero_newton_iterations_and_time_budget(gpu_required):
+    """max_iter = 0: only the initial evaluation; an already exhausted wall-clock budget ends the solve
+    silently like the reference (newton.jl:187-277) - the trajectory stays a valid iterate."""
+    from contactimplicitmpc.jl_amd import NewtonOptions
+    d, prob, tabs, rollouts = make_case("quadruped", 0, H_ref=10, H=8, B=12, seed=8, perturb=2e-2)
+    obj = synth.make_objective(d, 8)
+    q0 = np.stack([r[2] for r in rollouts]); q1 = np.stack([r[3] for r in rollouts])
+    s0 = make_solver(d, prob, rollouts, 8, obj=obj, newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=1e-7, max_iter=0))
+    u1, it, rn = s0.newton_solve(q0, q1)
+    assert (it == 0).all() and np.isfinite(rn).all()
+    sb = make_solver(d, prob, rollouts, 8, obj=obj, newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=1e-9, max_iter=50, max_time=1e-9))
+    u1b, itb, rnb = sb.newton_solve(q0, q1)
+    assert (itb <= 50).all() and np.isfinite(u1b).all() and np.isfinite(sb.trajectory()["q"]).all()
+    assert itb.max() < 50          # the budget, not max_iter, ended it
+
+
+def test_repeated_solves_are_deterministic(gpu_required):
+    """The same cold-start solve twice on one handle, and on a second handle: identical bits (the schedule -
+    rounds, queue order, which workgroup served what - must not leak into the arithmetic)."""
+    from contactimplicitmpc.jl_amd import NewtonOptions
+    d, prob, tabs, rollouts = make_case("quadruped", 0, H_ref=12, H=8, B=40, seed=12, perturb=3e-2)
+    obj = synth.make_objective(d, 8)
+    q0 = np.stack([r[2] for r in rollouts]); q1 = np.stack([r[3] for r in rollouts])
+    outs = []
+    for k in range(2):
+        s = make_solver(d, prob, rollouts, 8, obj=obj, newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=1e-6, max_iter=5))
+        for rep in range(2):
+            u1, it, rn = s.newton_solve(q0, q1)
+            outs.append((u1.copy(), it.copy(), s.trajectory()["q"].copy()))
+    for o in outs[1:]:
+        np.testing.assert_array_equal(o[1], outs[0][1])
+        np.testing.assert_array_equal(o[0], outs[0][0])
+        np.testing.assert_array_equal(o[2], outs[0][2])
