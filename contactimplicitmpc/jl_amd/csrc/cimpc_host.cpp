@@ -438,6 +438,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     S.spec_all = getenv("CIMPC_SPEC_ALL") ? atoi(getenv("CIMPC_SPEC_ALL")) : (d.B <= 128 ? 3 : 8);
     // small batches: one wave per workgroup keeps every problem on its own CU (latency);
     // large batches: 4 waves share one staged table (throughput)
+    if (getenv("CIMPC_ITER_CAP")) h->iter_cap = std::max(1, atoi(getenv("CIMPC_ITER_CAP")));
     h->waves = (B * H >= 4096) ? 4 : 1;
     // the single-launch solve runs its residual jobs on the whole workgroup: 4 waves also for small batches
     // (measured B = 8: 5.2 -> 4.4 ms, B = 64: 8.5 -> 7.5 ms)
