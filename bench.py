@@ -281,7 +281,7 @@ def main():
         # plant: q1_next = planned q_3), reference / window advanced on the device (cimpc_mpc_advance)
         out["mpc_loop_b1"] = {"quadruped_h40": mpc_loop_latency(QUADRUPED, "quadruped", 40, 60, local_rank),
                               "hopper_h20 (BASELINE configs[1])": mpc_loop_latency(dict(nq=4, nu=2, nw=2, nc=1, nb=2), "hopper", 20, 30, local_rank)}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a rank-0, N = 1 measurement
         try:
             cb = cpu_baseline(d, prob, obj, rollouts, H, H_ref)
             out["cpu_baseline"] = {
