@@ -35,6 +35,10 @@ struct Model {
     static_assert(NX <= 32 && NY <= 32, "lane group holds at most 32 rows");
     static constexpr int RST_LD = G + 1;                       // padded row stride of the R tile
     static constexpr int SENS_MAX = 16;                         // converged problems a group may defer
+#ifndef CIMPC_SENS_ILP
+#define CIMPC_SENS_ILP 2
+#endif
+    static constexpr int SENS_ILP = CIMPC_SENS_ILP;             // sensitivity columns solved side by side
     static constexpr int LDS_GROUP = ((NY * RST_LD + NTH + SENS_MAX / 2) + 1) & ~1;  // doubles / problem
 };
 
@@ -325,14 +329,14 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
             if (l < NC + NB) xst<ASYNC>(dzo + c * ND + NX + l, t);   // -(S.y) = +temp
         }
     };
-    // two independent right-hand sides per trip: their triangular-solve chains interleave
+    // SENS_ILP independent right-hand sides per trip: their triangular-solve chains interleave
+    constexpr int ILP = M::SENS_ILP;
     int c = 0;
 #pragma unroll 1
-    for (; c + 1 < NTHS; c += 2) {
-        column(c);
-        column(c + 1);
+    for (; c + ILP <= NTHS; c += ILP) {
+        static_for<0, ILP>([&](auto jc) { column(c + decltype(jc)::value); });
     }
-    if (c < NTHS) column(c);
+    for (; c < NTHS; ++c) column(c);
     problem_done<ASYNC>(p, prob / p.H, l);
 }
 
