@@ -32,11 +32,11 @@ struct ProfRec {
 }  // namespace
 
 // Streams of the lock-step rounds: the sweep / residual chain runs on `st`, the KKT recursion of the
-// rollouts that start a Newton iteration on `st_kkt` next to it (fork / join by events).
+// rollouts that start a Newton iteration on `st_kkt` next to it (joined by an event before the residual).
 struct RoundStreams {
     hipStream_t st = nullptr;
     hipStream_t st_kkt = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_join = nullptr;
 };
 
 struct cimpc_ctx {
@@ -486,7 +486,6 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         RoundStreams& r = h->rs;
         if (hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&r.st_kkt, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&r.ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&r.ev_join, hipEventDisableTiming) != hipSuccess) {
             g_create_error = "stream creation failed"; cimpc_destroy(h); return CIMPC_ERR_HIP;
         }
@@ -508,7 +507,6 @@ int cimpc_destroy(cimpc_handle h) {
         RoundStreams& r = h->rs;
         if (r.st) { (void)hipStreamSynchronize(r.st); (void)hipStreamDestroy(r.st); }
         if (r.st_kkt) { (void)hipStreamSynchronize(r.st_kkt); (void)hipStreamDestroy(r.st_kkt); }
-        if (r.ev_fork) (void)hipEventDestroy(r.ev_fork);
         if (r.ev_join) (void)hipEventDestroy(r.ev_join);
     }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -904,13 +902,16 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             int rr = h->use_dense ? launch_kkt_dense_newton(Sk, h->d_dense_ws, sb.st) : launch_kkt(Sk, sb.st);
             prof_end(h, sb.st);
             if (rr != CIMPC_OK) return fail(h, rr, "kkt launch failed");
-        } else if (kkt) {   // fork: KKT of the rollouts that start a Newton iteration, next to the sweep
-            if (hipEventRecord(sb.ev_fork, sb.st) != hipSuccess ||
-                hipStreamWaitEvent(sb.st_kkt, sb.ev_fork, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "fork failed");
+        }
+        if (kkt && h->kkt_overlap) {
+            // KKT of the rollouts that start a Newton iteration, next to the sweep on its own stream.  No fork
+            // event: the host has seen the previous round's stamp, so everything before is complete.  (Launched
+            // BEFORE the sweep: the other order was measured 10 % slower - the KKT recursion is the longer leg
+            // of most rounds.)
             prof_begin(h, PC_KKT, sb.st_kkt);
-            int rr = h->use_dense ? launch_kkt_dense_newton(Sk, h->d_dense_ws, sb.st_kkt) : launch_kkt(Sk, sb.st_kkt);
+            int rk = h->use_dense ? launch_kkt_dense_newton(Sk, h->d_dense_ws, sb.st_kkt) : launch_kkt(Sk, sb.st_kkt);
             prof_end(h, sb.st_kkt);
-            if (rr != CIMPC_OK) return fail(h, rr, "kkt launch failed");
+            if (rk != CIMPC_OK) return fail(h, rk, "kkt launch failed");
             if (hipEventRecord(sb.ev_join, sb.st_kkt) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join record failed");
         }
         // parking (iter_cap) protects a busy round from one long solve; in the sparse tail of a solve
