@@ -127,6 +127,9 @@ int dev_alloc(cimpc_ctx* h, T** p, size_t count, int mem = 0) {
                             : hipExtMallocWithFlags(&v, count * sizeof(T), mem == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
     if (e != hipSuccess) return fail(h, CIMPC_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
     e = hipMemset(v, 0, count * sizeof(T));
+    // the fill runs on the NULL stream, which the library's non-blocking streams do not wait for: a buffer
+    // allocated lazily right before a launch (dense KKT workspace) must be clean before anything touches it
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) return fail(h, CIMPC_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e));
     h->allocs.push_back(v);
     *p = static_cast<T*>(v);
@@ -676,7 +679,10 @@ int cimpc_set_reference(cimpc_handle h, const double* q_ref, const double* u_ref
     HIP_TRY(h, hipMemcpy(h->S.ref.q, q_ref, B * (H + 2) * d.nq * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->S.ref.u, u_ref, B * H * d.nu * sizeof(double), hipMemcpyHostToDevice));
     if (w_ref) HIP_TRY(h, hipMemcpy(h->S.ref.w, w_ref, B * H * d.nw * sizeof(double), hipMemcpyHostToDevice));
-    else HIP_TRY(h, hipMemset(h->S.ref.w, 0, B * H * d.nw * sizeof(double)));
+    else {      // NULL-stream fill: make it complete before the (non-blocking) solver streams can read it
+        HIP_TRY(h, hipMemset(h->S.ref.w, 0, B * H * d.nw * sizeof(double)));
+        HIP_TRY(h, hipStreamSynchronize(nullptr));
+    }
     if (gamma_ref) HIP_TRY(h, hipMemcpy(h->S.ref.g, gamma_ref, B * H * d.nc * sizeof(double), hipMemcpyHostToDevice));
     if (b_ref) HIP_TRY(h, hipMemcpy(h->S.ref.b, b_ref, B * H * d.nb * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->S.ref.th, theta_ref, B * H * h->nth * sizeof(double), hipMemcpyHostToDevice));
