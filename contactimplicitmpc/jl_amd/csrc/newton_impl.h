@@ -892,7 +892,13 @@ __device__ __forceinline__ double tile_mv(const double* Mt, const double* x, int
 template <int NQ, int NU, class Sync>
 __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, int b, double* sm, int lane) {
     static_assert(NQ <= 16 && NU <= 16, "MFMA KKT kernel handles one 16x16 tile per block");
-    auto lds_sync = [] { Sync::sync(); };
+    // The body runs on ONE wavefront; its phases hand data over through LDS only.  The hand-off needs the
+    // wave's LDS operations complete (lgkmcnt(0)) - NOT its global ones: a full barrier (vmcnt(0)) would
+    // expose the latency of the prefetch loads and of the factor spill stores at every phase boundary.
+    auto lds_sync = [] {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    };
     constexpr int nq = NQ, nu = NU, nd = NQ, nr = NQ + NU, nths = 2 * NQ + NU, n2 = nd * nd;
     constexpr int KBU = (NU + 3) / 4, KBQ = (NQ + 3) / 4, KBD = (nd + 3) / 4;
     const cimpc_dims& m = S.dm;
@@ -923,36 +929,66 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
 
     constexpr int PF_DZ = (nd * nths + 63) / 64, PF_Q = (nq * nq + 63) / 64, PF_R = (nu * nu + 63) / 64;
     double pf_dz[PF_DZ], pf_q[PF_Q], pf_r[PF_R], pf_rp = 0.0, pf_rd = 0.0;
+    // Per-lane marshalling plan, computed ONCE and branch-free in the loop: which element of a step's
+    // operand block this lane moves (k = lane + 64 j, clamped: surplus lanes re-load a valid element) and
+    // where it lands in LDS (surplus lanes write a scratch word).  The divisions by nd / nq / nu, the tile
+    // selection and ~35 exec-mask branches per step would otherwise be redone for every element of every
+    // step (measured: 2 k of the 14 k cycles of a step).
+    const int TRASH = KKT_MFMA_TILES * TSZ + 200;           // scratch double behind the vectors
+    int dz_src[PF_DZ], dz_dst[PF_DZ], dz_rot[PF_DZ], q_src[PF_Q], q_dst[PF_Q], r_src[PF_R], r_dst[PF_R];
+#pragma unroll
+    for (int j = 0; j < PF_DZ; ++j) {
+        const int k = lane + 64 * j, ok = k < nd * nths, kk = ok ? k : 0, r = kk % nd, c = kk / nd;
+        // dq0 -> tile 1 (A2), dq1 -> tiles 2/3 (ring by step parity), du1 -> tile 0 (A0)
+        const int base = (c < nq) ? 1 * TSZ + c * TL : (c < 2 * nq) ? 2 * TSZ + (c - nq) * TL : (c - 2 * nq) * TL;
+        dz_src[j] = kk;
+        dz_dst[j] = ok ? base + r : TRASH;
+        dz_rot[j] = (ok && c >= nq && c < 2 * nq) ? TSZ : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < PF_Q; ++j) {
+        const int k = lane + 64 * j, ok = k < nq * nq, kk = ok ? k : 0;
+        q_src[j] = kk; q_dst[j] = ok ? (kk % nq) + (kk / nq) * TL : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < PF_R; ++j) {
+        const int k = lane + 64 * j, ok = k < nu * nu, kk = ok ? k : 0;
+        r_src[j] = kk; r_dst[j] = ok ? 18 * TSZ + (kk % nu) + (kk / nu) * TL : TRASH;
+    }
+    const int rp_src = lane < nr ? lane : 0, rd_src = lane < nd ? lane : 0;
     auto prefetch = [&](int i) {
         if (i < 0 || i >= H) return;
         const double* dzi = dzb + (size_t)i * nths * nd;
 #pragma unroll
-        for (int j = 0; j < PF_DZ; ++j) { const int k = lane + 64 * j; pf_dz[j] = (k < nd * nths) ? dzi[k] : 0.0; }
+        for (int j = 0; j < PF_DZ; ++j) pf_dz[j] = dzi[dz_src[j]];
 #pragma unroll
-        for (int j = 0; j < PF_Q; ++j) { const int k = lane + 64 * j; pf_q[j] = (k < nq * nq) ? S.Qinv[(size_t)i * nq * nq + k] : 0.0; }
+        for (int j = 0; j < PF_Q; ++j) pf_q[j] = S.Qinv[(size_t)i * nq * nq + q_src[j]];
 #pragma unroll
-        for (int j = 0; j < PF_R; ++j) { const int k = lane + 64 * j; pf_r[j] = (k < nu * nu) ? S.Rinv[(size_t)i * nu * nu + k] : 0.0; }
-        pf_rp = (lane < nr) ? rb[i * nr + lane] : 0.0;
-        pf_rd = (lane < nd) ? rb[H * nr + i * nd + lane] : 0.0;
+        for (int j = 0; j < PF_R; ++j) pf_r[j] = S.Rinv[(size_t)i * nu * nu + r_src[j]];
+        pf_rp = rb[i * nr + rp_src];
+        pf_rd = rb[H * nr + i * nd + rd_src];
     };
-    // registers -> LDS tiles of one step (dq0 -> a2, dq1 -> a1, du1 -> a0)
-    auto commit = [&](double* a0, double* a1, double* a2, double* qi, double* ri, double* ru, double* rq) {
+    // registers -> LDS tiles of step i (p0 = i & 1 selects the dq1 ring slot, m0 = i % 3 the Qinv / r_p(q) slots)
+    auto commit = [&](int p0, int m0) {
 #pragma unroll
-        for (int j = 0; j < PF_DZ; ++j) {
-            const int k = lane + 64 * j;
-            if (k < nd * nths) {
-                const int r = k % nd, c = k / nd;
-                double* dst = (c < nq) ? (a2 + c * TL) : (c < 2 * nq) ? (a1 + (c - nq) * TL) : (a0 + (c - 2 * nq) * TL);
-                dst[r] = pf_dz[j];
-            }
-        }
+        for (int j = 0; j < PF_DZ; ++j) sm[dz_dst[j] + p0 * dz_rot[j]] = pf_dz[j];
 #pragma unroll
-        for (int j = 0; j < PF_Q; ++j) { const int k = lane + 64 * j; if (k < nq * nq) qi[(k % nq) + (k / nq) * TL] = pf_q[j]; }
+        for (int j = 0; j < PF_Q; ++j) sm[q_dst[j] >= 0 ? (15 + m0) * TSZ + q_dst[j] : TRASH] = pf_q[j];
 #pragma unroll
-        for (int j = 0; j < PF_R; ++j) { const int k = lane + 64 * j; if (k < nu * nu) ri[(k % nu) + (k / nu) * TL] = pf_r[j]; }
-        if (lane < nu) ru[lane] = pf_rp;
-        else if (lane < nr) rq[lane - nu] = pf_rp;
+        for (int j = 0; j < PF_R; ++j) sm[r_dst[j]] = pf_r[j];
+        // r_p: [u | q2] -> rpu (vec + 80), q ring (vec + 96 + 16 m0)
+        const int vb = KKT_MFMA_TILES * TSZ;
+        sm[lane < nu ? vb + 80 + lane : lane < nr ? vb + 96 + 16 * m0 + (lane - nu) : TRASH] = pf_rp;
     };
+    // spill of a step's factors (n2 = nd^2 entries each): element k = lane + 64 j, clamped (surplus lanes
+    // repeat the last element: same value, same address)
+    constexpr int SP = (n2 + 63) / 64;
+    int sp_k[SP], sp_off[SP];
+#pragma unroll
+    for (int j = 0; j < SP; ++j) {
+        const int k = min(lane + 64 * j, n2 - 1);
+        sp_k[j] = k; sp_off[j] = (k % nd) + (k / nd) * TL;
+    }
 
 #ifdef CIMPC_KKT_PROF
     long long pt[16] = {0}; long long tp = clock64();
@@ -970,7 +1006,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         double* yc = vec + 32 + 16 * m0; double* y1 = vec + 32 + 16 * m1; double* y2 = vec + 32 + 16 * m2;
         double* q0r = vec + 96 + 16 * m0; double* q1r = vec + 96 + 16 * m1; double* q2r = vec + 96 + 16 * m2;
         // ---- P1: step i operands -> LDS, fetch step i+1 ------------------------------------
-        commit(A0, A1, A2, Qi0, Ri, rpu, q0r);
+        commit(p0, m0);
         const double rd_i = pf_rd;
         lds_sync();
         prefetch(i + 1);
@@ -1073,11 +1109,12 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
             yc[lane] = yi;
         }
         double* wsi = ws + (size_t)i * WSR;
-        for (int k = lane; k < n2; k += 64) {
-            const int r = k % nd, c = k / nd;
-            wsi[k] = (i >= 1) ? L1c[r + c * TL] : 0.0;
-            wsi[n2 + k] = (i >= 2) ? L2c[r + c * TL] : 0.0;
-            wsi[2 * n2 + k] = Li[r + c * TL];
+#pragma unroll
+        for (int j = 0; j < SP; ++j) {
+            const double v1 = L1c[sp_off[j]], v2 = L2c[sp_off[j]];
+            wsi[sp_k[j]] = (i >= 1) ? v1 : 0.0;
+            wsi[n2 + sp_k[j]] = (i >= 2) ? v2 : 0.0;
+            wsi[2 * n2 + sp_k[j]] = Li[sp_off[j]];
         }
         if (lane < nd) wsi[3 * n2 + lane] = yi;
         lds_sync();
@@ -1100,28 +1137,31 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     double* t_all = tile(7);                          // [H][nr] first level of the recovery (tiles 7..)
     constexpr int PF_W = (WSR + 63) / 64;
     double pf_w[PF_W];
+    // marshalling plan of the backward pass (same idea): source element, LDS destination for ring slot 0
+    // and whether the destination rotates with the step (tiles 0..2: L1 ring, 3..5: L2 ring, 6: L0^-1, vec: y)
+    int bw_src[PF_W], bw_dst[PF_W], bw_rot[PF_W];
+#pragma unroll
+    for (int j = 0; j < PF_W; ++j) {
+        const int k = lane + 64 * j, ok = k < WSR, kk = ok ? k : 0;
+        const int t = kk / n2, e = kk - t * n2, r = e % nd, c = e / nd;
+        bw_src[j] = kk;
+        bw_dst[j] = !ok ? TRASH : (t == 0) ? r + c * TL : (t == 1) ? 3 * TSZ + r + c * TL : (t == 2) ? 6 * TSZ + r + c * TL
+                                                                                       : KKT_MFMA_TILES * TSZ + (kk - 3 * n2);
+        bw_rot[j] = (ok && t < 2) ? TSZ : 0;
+    }
     auto prefetch_b = [&](int i) {
         if (i < 0) return;
         const double* wsi = ws + (size_t)i * WSR;
 #pragma unroll
-        for (int j = 0; j < PF_W; ++j) { const int k = lane + 64 * j; pf_w[j] = (k < WSR) ? wsi[k] : 0.0; }
+        for (int j = 0; j < PF_W; ++j) pf_w[j] = wsi[bw_src[j]];
     };
     prefetch_b(H - 1);
     for (int i = H - 1; i >= 0; --i) {
         const int s0 = i % 3, s1 = (i + 1) % 3, s2 = (i + 2) % 3;
-        double* F1s0 = tile(0 + s0); double* F1s1 = tile(0 + s1);
-        double* F2s0 = tile(3 + s0); double* F2s2 = tile(3 + s2);
+        double* F1s1 = tile(0 + s1);      // L1_{i+1}, L2_{i+2}: fetched one / two steps ago into ring slots s1 / s2
+        double* F2s2 = tile(3 + s2);
 #pragma unroll
-        for (int j = 0; j < PF_W; ++j) {
-            const int k = lane + 64 * j;
-            if (k < 3 * n2) {
-                const int t = k / n2, e = k - t * n2, r = e % nd, c = e / nd;
-                double* dst = (t == 0) ? F1s0 : (t == 1) ? F2s0 : FI;
-                dst[r + c * TL] = pf_w[j];
-            } else if (k < WSR) {
-                yb[k - 3 * n2] = pf_w[j];
-            }
-        }
+        for (int j = 0; j < PF_W; ++j) sm[bw_dst[j] + s0 * bw_rot[j]] = pf_w[j];
         lds_sync();
         prefetch_b(i - 1);
         if (lane < nd) {
