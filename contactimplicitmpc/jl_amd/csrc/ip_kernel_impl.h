@@ -580,6 +580,9 @@ __global__ __launch_bounds__(256, 2) void ip_queue_kernel(IpParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int s_knot, s_total, s_rem[PICK_MAXK];
     const int tid = (int)threadIdx.x;
+    // The sweep heads the critical path of a round; the KKT recursion that runs next to it on the same SIMDs
+    // (one wave per rollout, second stream) does not: the sweep's waves get the issue slots first.
+    __builtin_amdgcn_s_setprio(2);
     while (true) {
         __syncthreads();            // every wave is done with the staged table
         const int knot = pick_knot(p, s_rem, &s_total, &s_knot, tid, (int)blockIdx.x, (int)gridDim.x);

@@ -36,18 +36,20 @@ struct AsyncArgs {     // the kernel's only argument
 // kernel of their own would.
 // (the kernel passes the address of its argument segment; the callee makes it wave-uniform again so
 // that the fields are fetched with scalar loads from the constant address space)
-__device__ __forceinline__ NewtonDev uniform_state(unsigned long long v) {
-    NewtonDev S;
+template <class T, size_t OFFSET>
+__device__ __forceinline__ T uniform_arg(unsigned long long v) {
+    T out;
 #if defined(__HIP_DEVICE_COMPILE__)
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    const unsigned long long u = (((unsigned long long)hi << 32) | lo) + offsetof(AsyncArgs, S);
-    __builtin_memcpy(&S, (const __attribute__((address_space(4))) NewtonDev*)u, sizeof(NewtonDev));
+    const unsigned long long u = (((unsigned long long)hi << 32) | lo) + OFFSET;
+    __builtin_memcpy(&out, (const __attribute__((address_space(4))) T*)u, sizeof(T));
 #else
     (void)v;
 #endif
-    return S;
+    return out;
 }
+__device__ __forceinline__ NewtonDev uniform_state(unsigned long long v) { return uniform_arg<NewtonDev, offsetof(AsyncArgs, S)>(v); }
 template <int NQ, int NU>
 __device__ __noinline__ void async_kkt_job(unsigned long long ka, int b, double* smem, int lane) {
     const NewtonDev S = uniform_state(ka);
@@ -58,6 +60,15 @@ template <int NQ, int NU>
 __device__ __noinline__ void async_resid_job(unsigned long long ka, int b, double* red, double* rc, int* sh) {
     const NewtonDev S = uniform_state(ka);
     resid_decide_body<NQ, NU, false, true>(S, b, red, rc, sh);
+}
+
+// The knot service is a real function too: the interior-point loop then gets the register allocation it has
+// in the lock-step kernel, undisturbed by what the job functions clobber (with the loop inlined next to the
+// job calls the allocator spilled loop-invariant values "everywhere": +30 % interior-point time).
+template <class M>
+__device__ __noinline__ void async_serve_job(unsigned long long ka, double* smem, int knot, int tid) {
+    const IpParams p = uniform_arg<IpParams, offsetof(AsyncArgs, p)>(ka);
+    serve_knot<M, true>(p, smem, knot, tid);
 }
 
 template <class M>
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void newton_async_kernel(AsyncArgs args) {
             const int knot = pick_knot(p, s_rem, &s_total, &s_knot, tid, wg, nwork);
             if (knot >= 0) {
                 account(0);
-                serve_knot<M, true>(p, smem, knot, tid);
+                async_serve_job<M>(ka, smem, knot, tid);
                 __syncthreads();
                 account(3);
                 continue;

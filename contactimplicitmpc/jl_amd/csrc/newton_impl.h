@@ -1241,7 +1241,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
 
 
 template <int NQ, int NU>
-__global__ __launch_bounds__(64) void kkt_kernel(NewtonDev S, KktArgs K) {
+__global__ __launch_bounds__(64, 2) void kkt_kernel(NewtonDev S, KktArgs K) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int b = blockIdx.x + S.b0;
     if (K.stage != nullptr && K.stage[b] != STAGE_KKT) return;
