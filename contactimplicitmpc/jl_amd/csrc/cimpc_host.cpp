@@ -345,7 +345,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     int rc = CIMPC_OK;
     {   // asynchronous single-launch solve? (queues sized for every push of one solve: they never wrap)
         // CIMPC_ASYNC: 0 = lock-step rounds only, 1 = always the single launch, unset / 2 = auto.  Measured on
-        // MI355X (quadruped, H = 40): the single launch wins for 8 <= B <= 128 rollouts
+        // MI355X (quadruped, H = 40): the single launch wins for 4 <= B <= 128 rollouts
         // (B = 64: 8.1 vs 11.2 ms), the rounds win for large batches (B = 512: 16.5 vs 21.7 ms) - except for
         // their sparse tail, which auto mode hands over to the asynchronous kernel.
         const char* ev = getenv("CIMPC_ASYNC");
@@ -445,7 +445,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     h->waves = (B * H >= 4096) ? 4 : 1;
     // the single-launch solve runs its residual jobs on the whole workgroup: 4 waves also for small batches
     // (measured B = 8: 5.2 -> 4.4 ms, B = 64: 8.5 -> 7.5 ms)
-    if (h->async_on && (h->async_mode == 1 || (h->async_mode == 2 && B >= 8 && B <= 128))) h->waves = 4;
+    if (h->async_on && (h->async_mode == 1 || (h->async_mode == 2 && B >= 4 && B <= 128))) h->waves = 4;
     if (getenv("CIMPC_WAVES")) { const int w = atoi(getenv("CIMPC_WAVES")); if (w == 1 || w == 2 || w == 4) h->waves = w; }
     h->kkt_overlap = B >= 64;
     if (getenv("CIMPC_KKT_OVERLAP")) h->kkt_overlap = atoi(getenv("CIMPC_KKT_OVERLAP")) != 0;
@@ -874,7 +874,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         return CIMPC_OK;
     };
     if (h->use_dense) { rc = ensure_dense_ws(h); if (rc != CIMPC_OK) return rc; }
-    const bool full_async = h->async_on && !h->use_dense && (h->async_mode == 1 || (h->async_mode == 2 && h->dm.B >= 8 && h->dm.B <= 128));
+    const bool full_async = h->async_on && !h->use_dense && (h->async_mode == 1 || (h->async_mode == 2 && h->dm.B >= 4 && h->dm.B <= 128));
     const bool hybrid = h->async_on && !h->use_dense && h->async_mode == 2 && !full_async && h->dm.B > 128;
     if (full_async) return run_async(true, 0);
     // safety net only: every Newton iteration needs at most 3 (speculative) rounds, each evaluation at
