@@ -419,6 +419,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     AX(&S.delta, B * h->N);
     AX(&S.r_norm, B); AX(&S.r_cand, BS); AX(&S.alpha, B); AX(&S.beta, B);
     AX(&S.ls_iter, B); AX(&S.newton_l, B); AX(&S.stage, B); AX(&S.need_sweep, BS);
+    A(&S.kkt_list, 2 * B);
     AX(&S.counters, 8);
     AX(&S.stats, 4);
     AX(&S.ro_sweeps, B); AX(&S.ro_ip_iters, B); AX(&S.ro_ip_fail, B);
@@ -915,7 +916,10 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             // BEFORE the sweep: the other order was measured 10 % slower - the KKT recursion is the longer leg
             // of most rounds.)
             prof_begin(h, PC_KKT, sb.st_kkt);
-            int rk = h->use_dense ? launch_kkt_dense_newton(Sk, h->d_dense_ws, sb.st_kkt) : launch_kkt(Sk, sb.st_kkt);
+            static const bool packed = !getenv("CIMPC_KKT_PACKED") || atoi(getenv("CIMPC_KKT_PACKED")) != 0;
+            // the list was built by the residual kernel of the previous round (its queue parity)
+            int rk = h->use_dense ? launch_kkt_dense_newton(Sk, h->d_dense_ws, sb.st_kkt)
+                                  : packed ? launch_kkt_packed(Sk, last_kkt, Sk.WQ.par ^ 1, sb.st_kkt) : launch_kkt(Sk, sb.st_kkt);
             prof_end(h, sb.st_kkt);
             if (rk != CIMPC_OK) return fail(h, rk, "kkt launch failed");
             if (hipEventRecord(sb.ev_join, sb.st_kkt) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join record failed");

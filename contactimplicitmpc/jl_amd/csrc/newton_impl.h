@@ -400,7 +400,10 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
             if (!ASYNC && S.A.n_done != nullptr) atomicAdd(S.A.n_done, 1);    // finished rollouts of this solve (hybrid hand-off)
         } else {
             S.stage[b] = STAGE_KKT;
-            if constexpr (!ASYNC) atomicAdd(&S.counters[1], 1);
+            if constexpr (!ASYNC) {
+                const int pos = atomicAdd(&S.counters[1], 1);
+                if (S.kkt_list != nullptr) S.kkt_list[(size_t)S.WQ.par * m.B + pos] = b;
+            }
         }
         sh[3] = done;
     }
@@ -1239,6 +1242,19 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     }
 }
 
+
+// Packed launch of the Newton loop: KKT_PACK rollouts per workgroup (one wavefront each, private LDS slice),
+// taken from the compact list the residual kernel built.  A lone KKT wave on a CU evicts one of the two
+// sweep workgroups the CU could hold (it needs a 256-VGPR slot on one SIMD and the sweep workgroup one on
+// each) - packing three of them fills the CU's LDS, so fewer CUs are taken away from the sweep, entirely.
+constexpr int KKT_PACK = 3;
+template <int NQ, int NU>
+__global__ __launch_bounds__(64 * KKT_PACK, 2) void kkt_kernel_packed(NewtonDev S, KktArgs K, const int* list, int n) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int wave = (int)threadIdx.x >> 6, slot = (int)blockIdx.x * KKT_PACK + wave;
+    if (slot >= n) return;
+    kkt_body<NQ, NU, WaveSync>(S, K, list[slot], sm + (size_t)wave * (KKT_MFMA_TILES * TSZ + 208), (int)threadIdx.x & 63);
+}
 
 template <int NQ, int NU>
 __global__ __launch_bounds__(64, 2) void kkt_kernel(NewtonDev S, KktArgs K) {

@@ -49,6 +49,7 @@ struct NewtonDev {
     int* ls_iter;      // [B]
     int* newton_l;     // [B]  Newton iterations done
     int* stage;        // [B]
+    int* kkt_list;     // [2][B] rollouts that entered STAGE_KKT, per round parity (compact list for the packed KKT launch)
     int* need_sweep;   // [B*CS]
     int* counters;     // [8]: 0 = #rollouts needing a sweep, 1 = #needing KKT, 2 = parked solves, 7 = block ticket
     int* counters_next; // counter block of the next round (zeroed by the residual kernel)
@@ -85,6 +86,8 @@ int launch_reset(const NewtonDev& nd, const double* q0, const double* q1, int wa
 int launch_resid_decide(const NewtonDev& nd, hipStream_t s);
 int launch_enqueue_all(const NewtonDev& nd, hipStream_t s);   // B3 seam: queue slot 0 of every rollout
 int launch_kkt(const NewtonDev& nd, hipStream_t s);
+// packed variant: n_kkt rollouts from kkt_list[list_par], KKT_PACK per workgroup (dedicates whole CUs to the recursion)
+int launch_kkt_packed(const NewtonDev& nd, int n_kkt, int list_par, hipStream_t s);
 // reference-default backend (dense jacobian! + LU with partial pivoting), any mode / objective (kkt_dense.hip)
 size_t kkt_dense_workspace_doubles(const NewtonDev& S);
 int launch_kkt_dense_newton(const NewtonDev& S, double* ws, hipStream_t s);
