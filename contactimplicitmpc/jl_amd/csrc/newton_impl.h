@@ -1245,11 +1245,18 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
 
 // Packed launch of the Newton loop: KKT_PACK rollouts per workgroup (one wavefront each, private LDS slice),
 // taken from the compact list the residual kernel built.  A lone KKT wave on a CU evicts one of the two
-// sweep workgroups the CU could hold (it needs a 256-VGPR slot on one SIMD and the sweep workgroup one on
-// each) - packing three of them fills the CU's LDS, so fewer CUs are taken away from the sweep, entirely.
-constexpr int KKT_PACK = 3;
+// sweep workgroups the CU could hold (it needs a 256-VGPR slot on one SIMD, the sweep workgroup one on
+// each).  Two per workgroup (94 KB of LDS) leave room for exactly one sweep workgroup next to them, so
+// half as many CUs lose a sweep workgroup (measured B = 512: pack 1 / 2 / 3 -> 14.0 / 13.3 / 13.6 ms).
+#ifndef CIMPC_KKT_PACK
+#define CIMPC_KKT_PACK 2
+#endif
+#ifndef CIMPC_KKT_PACK_WAVES_PER_SIMD
+#define CIMPC_KKT_PACK_WAVES_PER_SIMD 2
+#endif
+constexpr int KKT_PACK = CIMPC_KKT_PACK;
 template <int NQ, int NU>
-__global__ __launch_bounds__(64 * KKT_PACK, 2) void kkt_kernel_packed(NewtonDev S, KktArgs K, const int* list, int n) {
+__global__ __launch_bounds__(64 * KKT_PACK, CIMPC_KKT_PACK_WAVES_PER_SIMD) void kkt_kernel_packed(NewtonDev S, KktArgs K, const int* list, int n) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int wave = (int)threadIdx.x >> 6, slot = (int)blockIdx.x * KKT_PACK + wave;
     if (slot >= n) return;
