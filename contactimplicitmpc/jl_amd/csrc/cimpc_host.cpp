@@ -36,7 +36,7 @@ struct ProfRec {
 struct RoundStreams {
     hipStream_t st = nullptr;
     hipStream_t st_kkt = nullptr;
-    hipEvent_t ev_join = nullptr;
+    hipEvent_t ev_join = nullptr, ev_round = nullptr;   // ev_round: end of a round (rounds enqueued ahead of the host)
 };
 
 struct cimpc_ctx {
@@ -490,7 +490,8 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         RoundStreams& r = h->rs;
         if (hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&r.st_kkt, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&r.ev_join, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&r.ev_join, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&r.ev_round, hipEventDisableTiming) != hipSuccess) {
             g_create_error = "stream creation failed"; cimpc_destroy(h); return CIMPC_ERR_HIP;
         }
     }
@@ -512,6 +513,7 @@ int cimpc_destroy(cimpc_handle h) {
         if (r.st) { (void)hipStreamSynchronize(r.st); (void)hipStreamDestroy(r.st); }
         if (r.st_kkt) { (void)hipStreamSynchronize(r.st_kkt); (void)hipStreamDestroy(r.st_kkt); }
         if (r.ev_join) (void)hipEventDestroy(r.ev_join);
+        if (r.ev_round) (void)hipEventDestroy(r.ev_round);
     }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -887,7 +889,11 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     // Lock-step rounds.  Every kernel of a round is driven by device-side state (work queues, per-rollout
     // stage); the host only looks at the counters the last residual block publishes.  (Enqueueing rounds
     // ahead of the host's knowledge was measured: slower, the KKT kernel then has to be launched every round.)
-    const int depth = 1;
+    // CIMPC_DEPTH = 2: rounds enqueued one ahead of the host's knowledge.  Measured (B = 512): 15.9 vs 13.7 ms -
+    // the KKT kernel must then be launched blind at full grid every round; kept as an experiment switch.
+    static const int depth_env = getenv("CIMPC_DEPTH") ? std::min(2, std::max(1, atoi(getenv("CIMPC_DEPTH")))) : 1;
+    const int depth = h->kkt_overlap ? depth_env : 1;
+    bool draining = false;
     long long launched = 0, completed = 0, rounds = 0;
     static const bool dbg_rounds = getenv("CIMPC_DEBUG_ROUNDS") != nullptr;
     int last_kkt = 0, last_sweep = h->dm.B;
@@ -898,7 +904,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         NewtonDev Sk = S;
         Sk.b0 = 0; Sk.nb_launch = h->dm.B; Sk.counters = d_cnt;
         Sk.counters_next = h->d_ring + 8 * (slot ^ 1);
-        Sk.host_flag = h->h_ring_dev;
+        Sk.host_flag = h->h_ring_dev + 8 * slot;
         Sk.A.n_done = hybrid ? h->a_ctrl + 2 * (size_t)h->Q.K * QPAD + 8 : nullptr;
         Sk.round_stamp = (int)(r + 1);
         Sk.WQ = h->Q; Sk.WQ.par = (int)(r & 1);       // round parity selects the queue being consumed
@@ -915,11 +921,13 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             // event: the host has seen the previous round's stamp, so everything before is complete.  (Launched
             // BEFORE the sweep: the other order was measured 10 % slower - the KKT recursion is the longer leg
             // of most rounds.)
+            if (depth > 1 && hipStreamWaitEvent(sb.st_kkt, sb.ev_round, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "fork failed");
             prof_begin(h, PC_KKT, sb.st_kkt);
             static const bool packed = !getenv("CIMPC_KKT_PACKED") || atoi(getenv("CIMPC_KKT_PACKED")) != 0;
             // the list was built by the residual kernel of the previous round (its queue parity)
             int rk = h->use_dense ? launch_kkt_dense_newton(Sk, h->d_dense_ws, sb.st_kkt)
-                                  : packed ? launch_kkt_packed(Sk, last_kkt, Sk.WQ.par ^ 1, sb.st_kkt) : launch_kkt(Sk, sb.st_kkt);
+                                  : packed ? launch_kkt_packed(Sk, last_kkt, Sk.WQ.par ^ 1, sb.st_kkt, depth > 1 ? Sk.counters_next + 1 : nullptr)
+                                           : launch_kkt(Sk, sb.st_kkt);
             prof_end(h, sb.st_kkt);
             if (rk != CIMPC_OK) return fail(h, rk, "kkt launch failed");
             if (hipEventRecord(sb.ev_join, sb.st_kkt) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join record failed");
@@ -935,6 +943,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         rr = launch_resid_decide(Sk, sb.st);
         prof_end(h, sb.st);
         if (rr != CIMPC_OK) return fail(h, rr, "residual launch failed");
+        if (depth > 1 && hipEventRecord(sb.ev_round, sb.st) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "round event failed");
         return CIMPC_OK;
     };
     HIP_TRY(h, hipMemsetAsync(h->Q.count, 0, 2 * h->Q.K * QPAD * sizeof(int), sb.st));
@@ -942,6 +951,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     HIP_TRY(h, hipMemsetAsync(h->d_ring, 0, 16 * sizeof(int), sb.st));
     if (hybrid) HIP_TRY(h, hipMemsetAsync(h->a_ctrl + 2 * (size_t)h->Q.K * QPAD, 0, 64 * sizeof(int), sb.st));
     ((volatile int*)h->h_ring)[2] = 0;
+    ((volatile int*)h->h_ring)[10] = 0;
     {
         NewtonDev Sk = S;
         Sk.b0 = 0; Sk.nb_launch = h->dm.B; Sk.counters = h->d_ring;
@@ -952,14 +962,14 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         if (rc != CIMPC_OK) return fail(h, rc, "reset launch failed");
     }
     while (true) {
-        while (launched - completed < depth && launched < max_rounds) {
+        while (!draining && launched - completed < depth && launched < max_rounds) {
             rc = launch_round(launched);
             if (rc != CIMPC_OK) return rc;
             ++launched;
         }
         if (completed >= launched) break;     // max_rounds reached
         {   // the residual kernel's last block stamps the mapped flag when round `completed` is done
-            volatile int* hm = (volatile int*)h->h_ring;
+            volatile int* hm = (volatile int*)h->h_ring + 8 * (completed & 1);
             const int want = (int)(completed + 1);
             long long spins = 0;
             while (hm[2] != want) {
@@ -967,25 +977,24 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
                     return fail(h, CIMPC_ERR_HIP, "round finished without publishing its counters");
             }
         }
-        const int n_sweep = ((volatile int*)h->h_ring)[0];
+        volatile int* hr = (volatile int*)h->h_ring + 8 * (completed & 1);
+        const int n_sweep = hr[0];
         last_sweep = n_sweep;
-        last_kkt = ((volatile int*)h->h_ring)[1];
+        last_kkt = hr[1];
         if (dbg_rounds) fprintf(stderr, "[cimpc round %lld] t %.3f ms: next sweep %d rollouts, next kkt %d, parked %d, finished %d\n", completed,
-                                1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), n_sweep, last_kkt,
-                                ((volatile int*)h->h_ring)[4], ((volatile int*)h->h_ring)[5]);
+                                1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), n_sweep, last_kkt, hr[4], hr[5]);
         h->prof_kkt_systems += last_kkt;
         ++completed;
         rounds = completed;
         if ((n_sweep == 0 && last_kkt == 0) || over_budget()) break;   // newton.jl:187-277: budget ends silently
-        if (hybrid && launched == completed) {
+        if (hybrid) {
             // sparse tail: few rollouts left, every round pays its fixed latency for them -> the persistent
-            // kernel finishes them along their own chains (needs a round boundary with no parked solve)
-            const int parked = ((volatile int*)h->h_ring)[4], active = h->dm.B - ((volatile int*)h->h_ring)[5];
-            (void)parked;
-            if (active > 0 && active <= h->async_tail) {
+            // kernel finishes them along their own chains; rounds already enqueued are drained first
+            const int active = h->dm.B - hr[5];
+            if (active > 0 && active <= h->async_tail) draining = true;
+            if (draining && launched == completed) {
                 HIP_TRY(h, hipStreamSynchronize(sb.st));
                 HIP_TRY(h, hipStreamSynchronize(sb.st_kkt));
-                h->prof_kkt_systems += 0;
                 return run_async(false, rounds);
             }
         }

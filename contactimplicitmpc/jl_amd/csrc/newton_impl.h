@@ -1256,8 +1256,9 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
 #endif
 constexpr int KKT_PACK = CIMPC_KKT_PACK;
 template <int NQ, int NU>
-__global__ __launch_bounds__(64 * KKT_PACK, CIMPC_KKT_PACK_WAVES_PER_SIMD) void kkt_kernel_packed(NewtonDev S, KktArgs K, const int* list, int n) {
+__global__ __launch_bounds__(64 * KKT_PACK, CIMPC_KKT_PACK_WAVES_PER_SIMD) void kkt_kernel_packed(NewtonDev S, KktArgs K, const int* list, int n, const int* n_dev) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    if (n_dev != nullptr) n = *n_dev;        // rounds enqueued ahead of the host: the count is only known on the device
     const int wave = (int)threadIdx.x >> 6, slot = (int)blockIdx.x * KKT_PACK + wave;
     if (slot >= n) return;
     kkt_body<NQ, NU, WaveSync>(S, K, list[slot], sm + (size_t)wave * (KKT_MFMA_TILES * TSZ + 208), (int)threadIdx.x & 63);

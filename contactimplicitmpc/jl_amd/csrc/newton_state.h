@@ -87,7 +87,7 @@ int launch_resid_decide(const NewtonDev& nd, hipStream_t s);
 int launch_enqueue_all(const NewtonDev& nd, hipStream_t s);   // B3 seam: queue slot 0 of every rollout
 int launch_kkt(const NewtonDev& nd, hipStream_t s);
 // packed variant: n_kkt rollouts from kkt_list[list_par], KKT_PACK per workgroup (dedicates whole CUs to the recursion)
-int launch_kkt_packed(const NewtonDev& nd, int n_kkt, int list_par, hipStream_t s);
+int launch_kkt_packed(const NewtonDev& nd, int n_kkt, int list_par, hipStream_t s, const int* n_dev = nullptr);
 // reference-default backend (dense jacobian! + LU with partial pivoting), any mode / objective (kkt_dense.hip)
 size_t kkt_dense_workspace_doubles(const NewtonDev& S);
 int launch_kkt_dense_newton(const NewtonDev& S, double* ws, hipStream_t s);
