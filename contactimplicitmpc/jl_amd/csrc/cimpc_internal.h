@@ -154,6 +154,20 @@ struct KernelInfo {
     int tab_size;     // doubles per knot
 };
 
+// Opt a kernel in to more than 64 KiB of dynamic LDS (gfx950: 160 KiB per CU).  The attribute call is not free,
+// so it is made once per (kernel instantiation, device) - `cache` is a function-local static of the caller.
+struct LdsOptIn { size_t set[16] = {0}; };
+inline int lds_opt_in(LdsOptIn& cache, const void* kernel, size_t lds) {
+    if (lds <= 64 * 1024) return CIMPC_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return CIMPC_ERR_HIP;
+    dev &= 15;
+    if (lds <= cache.set[dev]) return CIMPC_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return CIMPC_ERR_HIP;
+    cache.set[dev] = lds;
+    return CIMPC_OK;
+}
+
 // dims-dispatching launchers (ip_kernel.hip / newton_kernels.hip)
 int ip_kernel_info(const cimpc_dims* dm, KernelInfo* info);
 // launches the queue kernel followed by the sensitivity kernel

@@ -601,10 +601,8 @@ int launch_model(const IpParams& p, int waves, hipStream_t s) {
     if (waves != 1 && waves != 2 && waves != 4) return CIMPC_ERR_INVALID;
     const int ppw = 64 / M::G;
     const size_t lds = (size_t)(L.size + waves * ppw * M::LDS_GROUP) * sizeof(double);
-    if (lds > 64 * 1024) {   // opt in to the full 160 KiB LDS of a gfx950 CU
-        if (hipFuncSetAttribute((const void*)ip_queue_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return CIMPC_ERR_HIP;
-    }
+    static LdsOptIn optin;
+    if (lds_opt_in(optin, (const void*)ip_queue_kernel<M>, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
     const int grid = p.wpk;      // persistent workgroups of the launch
     hipLaunchKernelGGL((ip_queue_kernel<M>), dim3(grid), dim3(64 * waves), lds, s, p);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;

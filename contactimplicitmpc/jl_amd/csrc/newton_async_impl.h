@@ -170,10 +170,8 @@ int launch_async_model(const IpParams& p, const NewtonDev& S, int waves, int gri
     const size_t lds_ip = (size_t)(L.size + waves * ppw * M::LDS_GROUP) * sizeof(double);
     const size_t lds_kkt = (size_t)(KKT_MFMA_TILES * TSZ + 208) * sizeof(double);
     const size_t lds = lds_ip > lds_kkt ? lds_ip : lds_kkt;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)newton_async_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return CIMPC_ERR_HIP;
-    }
+    static LdsOptIn optin;
+    if (lds_opt_in(optin, (const void*)newton_async_kernel<M>, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
     AsyncArgs args{p, S};
     hipLaunchKernelGGL((newton_async_kernel<M>), dim3(grid), dim3(64 * waves), lds, s, args);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;

@@ -79,11 +79,8 @@ static int launch_kkt_t(const NewtonDev& S, const KktArgs& K, hipStream_t s) {
     } else {
         constexpr int LD = ((NQ > NU ? NQ : NU) + 3) & ~3;
         const size_t lds = (size_t)(KKT_TILES * LD * LD + 10 * LD) * sizeof(double);
-        if (lds > 64 * 1024) {
-            if (hipFuncSetAttribute((const void*)kkt_kernel_scalar<NQ, NU>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return CIMPC_ERR_HIP;
-        }
+        static LdsOptIn optin;
+        if (lds_opt_in(optin, (const void*)kkt_kernel_scalar<NQ, NU>, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
         hipLaunchKernelGGL((kkt_kernel_scalar<NQ, NU>), dim3(S.nb_launch), dim3(64), lds, s, S, K);
     }
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
@@ -211,8 +208,8 @@ template <int NQ, int NU>
 static int launch_kkt_packed_t(const NewtonDev& S, const KktArgs& K, const int* list, int n, const int* n_dev, hipStream_t s) {
     if constexpr (NQ <= 16 && NU <= 16) {
         const size_t lds = (size_t)KKT_PACK * (KKT_MFMA_TILES * TSZ + 208) * sizeof(double);
-        if (hipFuncSetAttribute((const void*)kkt_kernel_packed<NQ, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return CIMPC_ERR_HIP;
+        static LdsOptIn optin;
+        if (lds_opt_in(optin, (const void*)kkt_kernel_packed<NQ, NU>, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
         hipLaunchKernelGGL((kkt_kernel_packed<NQ, NU>), dim3((n + KKT_PACK - 1) / KKT_PACK), dim3(64 * KKT_PACK), lds, s, S, K, list, n, n_dev);
         return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
     }
