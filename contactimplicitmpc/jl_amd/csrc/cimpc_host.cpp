@@ -409,6 +409,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     AX(&S.nu_cand, BS * H * h->nd);
     AX(&S.d, BS * H * h->nd);
     AX(&S.dz, BS * H * h->nths * h->nd);
+    AX(&S.dz_good, B * H * h->nths * h->nd);
     AX(&S.ip_status, BS * H);
     AX(&S.ip_iters, BS * H);
     AX(&S.pflag, BS * H);

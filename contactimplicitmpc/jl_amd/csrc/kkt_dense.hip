@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void kkt_dense_kernel(NewtonDev S, KktArgs K, 
     int* piv = reinterpret_cast<int*>(x + N);
     const double beta = K.beta ? K.beta[b] : K.beta_scalar;
     const double rho = (double)H * beta * S.kappa;  // newton_jacobian.jl:169-186 quirk
-    const double* dzb = S.dz + ((size_t)b * CS + (K.stage ? S.cur_slot[b] : 0)) * H * nths * nd;
+    const double* dzb = K.stage ? S.dz_good + (size_t)b * H * nths * nd : S.dz + (size_t)b * CS * H * nths * nd;
     __shared__ double s_val[256];
     __shared__ int s_idx[256];
 

@@ -53,8 +53,9 @@ __device__ __forceinline__ void copy_n(double* dst, const double* src, int n, in
 // and the first alpha (in the reference's order) that passes the Armijo-type test is taken, so the
 // accepted step, residual and implicit-dynamics data are exactly those the sequential loop would
 // have produced.  Every "evaluation" array (candidate trajectory, nu_cand, d, dz, status,
-// res_cand, ...) is indexed by slot sb = b*CS + c; cur_slot[b] names the slot whose d / dz are the
-// current im_traj of rollout b.
+// res_cand, ...) is indexed by slot sb = b*CS + it where `it` is the line-search iterate (alpha = 2^-it): a
+// step length always lives in the same slot, so the whole search history of the running Newton iteration
+// stays available (needed by the stale-sensitivity rule, dz_eff below).
 __device__ __forceinline__ double ls_alpha(int iter) { return ldexp(1.0, -iter); }
 
 // Request the evaluation (implicit_dynamics! sweep) of slot sb: one queue entry per horizon step,
@@ -76,16 +77,20 @@ __device__ __forceinline__ void enqueue_eval(const NewtonDev& S, size_t sb, int 
 // candidate trajectories must have been written by the calling unit; they are released before the
 // first queue entry is published (consumers acquire after claiming an entry).
 template <class Sync>
-__device__ __forceinline__ void enqueue_eval_async(const NewtonDev& S, size_t sb0, int nslots, int b, int tid, int nt) {
+__device__ __forceinline__ void enqueue_eval_async(const NewtonDev& S, size_t sb0, int first, int nslots, int b, int tid, int nt) {
     const int H = S.dm.H;
     if (tid == 0) {
-        for (int c = 0; c < CS; ++c) { S.WQ.done_count[sb0 + c] = 0; S.need_sweep[sb0 + c] = c < nslots; }
+        for (int c = 0; c < CS; ++c) {
+            const bool on = c >= first && c < first + nslots;
+            if (on) S.WQ.done_count[sb0 + c] = 0;
+            S.need_sweep[sb0 + c] = on;
+        }
         astore(S.A.evals_left + b, nslots);
     }
     xfence(S.A.flags);
     Sync::sync();
     for (int e = tid; e < nslots * H; e += nt) {
-        const int c = e / H, k = e - c * H;
+        const int c = first + e / H, k = e % H;
         const int t = S.WQ.window[(size_t)b * (H + 2) + k];
         aq_push(S.WQ.items + (size_t)t * S.WQ.cap, qcount(S.WQ, 0, t), (int)((sb0 + c) * H + k));
     }
@@ -153,7 +158,7 @@ __device__ __forceinline__ void start_line_search(const NewtonDev& S, int b, int
     for (int c = 0; c < n; ++c) apply_step<Sync>(S, S.cand, S.nu_cand, sb0 + c, b, ls_alpha(c), lane, nt);
     if (lane == 0) { S.alpha[b] = 1.0; S.ls_iter[b] = 0; S.stage[b] = (n == 7) ? STAGE_LS7 : STAGE_LS0; }
     if (mode == 2) {
-        enqueue_eval_async<Sync>(S, sb0, n, b, lane, nt);
+        enqueue_eval_async<Sync>(S, sb0, 0, n, b, lane, nt);
     } else {
         // the KKT kernel runs on its own stream NEXT TO the sweep of the running round: its
         // candidates join the queue of the next round
@@ -167,20 +172,41 @@ __device__ __forceinline__ void start_line_search(const NewtonDev& S, int b, int
 }
 
 
+// Sensitivities in effect for step i of line-search iterate `it` of rollout b.  The reference keeps ONE
+// sensitivity block per knot (ip[t].dz) that every successful solve overwrites and a failed solve leaves
+// untouched (implicit_dynamics.jl:169-176): after a failure the block still holds the most recent successful
+// solve of that knot in evaluation order - an earlier step length of the same search, else the accepted
+// evaluation of the previous Newton iteration.  With the step lengths evaluated speculatively in slots the
+// same value is found by walking back through the slots of the search, then to dz_good.  (The result does
+// not depend on how the evaluations were scheduled.)
+__device__ __forceinline__ const double* dz_eff(const NewtonDev& S, int b, int it, int i) {
+    const int H = S.dm.H;
+    const size_t sb0 = (size_t)b * CS, blk = (size_t)S.nths * S.nd;
+    int s = it;
+    while (s >= 0 && S.ip_status[(sb0 + s) * H + i] == 0) --s;
+    return s >= 0 ? S.dz + ((sb0 + s) * H + i) * blk : S.dz_good + ((size_t)b * H + i) * blk;
+}
+
 // residual! on evaluation slot sb (candidate trajectory, nu_cand, d, dz of that slot): writes res_cand of the
 // slot and returns THIS THREAD's share of |r|_1 (the caller reduces all candidate slots in one pass)
 template <int NQ, int NU, bool CF>
-__device__ double slot_residual(const NewtonDev& S, size_t sb, int b, int tid, int nt) {
+__device__ double slot_residual(const NewtonDev& S, size_t sb, int b, const int* eff, int tid, int nt) {
     const cimpc_dims& m = S.dm;
     constexpr int nq = NQ, nu = NU;
     constexpr bool cf = CF;
     const int H = m.H, nc = m.nc, nb = m.nb, nr = S.nr;
     const int nd = cf ? nq + nc + nb : nq;       // compile-time in :configuration mode
-    constexpr int nths = 2 * NQ + NU;
     const int oq_in_block = cf ? nu + nc + nb : nu;
     double* r = S.res_cand + sb * S.N;
     const double* nuc = S.nu_cand + sb * H * nd;
-    const double* dzb = S.dz + sb * H * nths * nd;
+    const int it = (int)(sb - (size_t)b * CS);      // line-search iterate held by this slot
+    const size_t blk = (size_t)(2 * nq + nu) * nd, sb0 = (size_t)b * CS;
+    // sensitivities in effect for step i: from the table the caller resolved once (LDS), or on the fly
+    auto dzp = [&](int i) -> const double* {
+        if (eff == nullptr) return dz_eff(S, b, it, i);
+        const int s_ = eff[i];
+        return s_ >= 0 ? S.dz + ((sb0 + s_) * H + i) * blk : S.dz_good + ((size_t)b * H + i) * blk;
+    };
     double part = 0.0;
     for (int e = tid; e < S.N; e += nt) {
         double v = 0.0;
@@ -194,7 +220,7 @@ __device__ double slot_residual(const NewtonDev& S, size_t sb, int b, int tid, i
                 const double* ur = S.ref.u + ((size_t)b * H + i) * nu;
 #pragma unroll
                 for (int k = 0; k < nu; ++k) v = fma(Rm[c + k * nu], uu[k] - ur[k], v);
-                const double* A0 = dzb + ((size_t)i * nths + 2 * nq + c) * nd;   // column c of du1_i
+                const double* A0 = dzp(i) + (size_t)(2 * nq + c) * nd;   // column c of du1_i
                 double s = 0.0;
 #pragma unroll
                 for (int k = 0; k < nq; ++k) s = fma(A0[k], nuc[i * nd + k], s);
@@ -224,7 +250,7 @@ __device__ double slot_residual(const NewtonDev& S, size_t sb, int b, int tid, i
                 }
                 v -= nuc[i * nd + cq];                                      // rI[i] -= nu_i
                 if (i + 1 < H) {                                            // dq1_{i+1}^T nu_{i+1}
-                    const double* A1 = dzb + ((size_t)(i + 1) * nths + nq + cq) * nd;
+                    const double* A1 = dzp(i + 1) + (size_t)(nq + cq) * nd;
                     double s = 0.0;
 #pragma unroll
                     for (int k = 0; k < nq; ++k) s = fma(A1[k], nuc[(i + 1) * nd + k], s);
@@ -232,7 +258,7 @@ __device__ double slot_residual(const NewtonDev& S, size_t sb, int b, int tid, i
                     v += s;
                 }
                 if (i + 2 < H) {                                            // dq0_{i+2}^T nu_{i+2}
-                    const double* A2 = dzb + ((size_t)(i + 2) * nths + cq) * nd;
+                    const double* A2 = dzp(i + 2) + (size_t)cq * nd;
                     double s = 0.0;
 #pragma unroll
                     for (int k = 0; k < nq; ++k) s = fma(A2[k], nuc[(i + 2) * nd + k], s);
@@ -274,29 +300,41 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
     }
     const int stage = S.stage[b];
     if (stage == STAGE_DONE || stage == STAGE_KKT) return;
-    if (S.need_sweep[sb0] == 0) return;          // nothing was evaluated for this rollout
     const int ncand = (stage == STAGE_LS1) ? 2 : (stage == STAGE_LS2) ? 4 : (stage == STAGE_LS7) ? 7 : 1;
+    const int it0 = (stage == STAGE_LS1) ? 1 : (stage == STAGE_LS2) ? 3 : 0;      // first iterate (= slot) of the batch
+    if (S.need_sweep[sb0 + it0] == 0) return;    // nothing was evaluated for this rollout
     if constexpr (!ASYNC) {   // an interior-point solve of this evaluation is still parked: wait for the next round
         int pend = 0;
-        if (tid < ncand) pend = (S.WQ.done_count[sb0 + tid] < H);
+        if (tid < ncand) pend = (S.WQ.done_count[sb0 + it0 + tid] < H);
         if (__syncthreads_or(pend)) {
             if (tid == 0) atomicAdd(&S.counters[0], 1);
             return;
         }
     }
     int& s_act = sh[0]; int& s_slot = sh[1]; int& s_iter = sh[2];
+    constexpr int EFF_H = 128;                       // horizon steps the LDS table holds (longer horizons resolve on the fly)
+    __shared__ int eff[CS * EFF_H];
+    const bool use_eff = H <= EFF_H;
     {   // all candidate slots, ONE reduction pass (red: [CS][nt]; per slot the same pairwise tree as a single
         // reduction, so the norms do not depend on how many candidates share the pass)
+        // effective sensitivity source of every (candidate, step), resolved ONCE (dz_eff): slot index or -1
+        for (int e = tid; e < ncand * H && use_eff; e += nt) {
+            const int c = e / H, i = e - c * H;
+            int s_ = it0 + c;
+            while (s_ >= 0 && S.ip_status[(sb0 + s_) * H + i] == 0) --s_;
+            eff[c * EFF_H + i] = s_;
+        }
+        __syncthreads();
 #pragma unroll
         for (int c = 0; c < CS; ++c)
-            if (c < ncand) red[c * nt + tid] = slot_residual<NQ, NU, CF>(S, sb0 + c, b, tid, nt);
+            if (c < ncand) red[c * nt + tid] = slot_residual<NQ, NU, CF>(S, sb0 + it0 + c, b, use_eff ? eff + c * EFF_H : nullptr, tid, nt);
         __syncthreads();
         for (int st = nt / 2; st > 0; st >>= 1) {
             if (tid < st)
                 for (int c = 0; c < ncand; ++c) red[c * nt + tid] += red[c * nt + tid + st];
             __syncthreads();
         }
-        if (tid < ncand) { rc[tid] = red[tid * nt]; S.r_cand[sb0 + tid] = red[tid * nt]; }
+        if (tid < ncand) { rc[tid] = red[tid * nt]; S.r_cand[sb0 + it0 + tid] = red[tid * nt]; }
         __syncthreads();
     }
     // ---- decision (newton.jl:198-280) ------------------------------------------------------
@@ -306,7 +344,6 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
             act = 0;
         } else {
             const double rn2 = S.r_norm[b] * S.r_norm[b];
-            const int it0 = (stage == STAGE_LS1) ? 1 : (stage == STAGE_LS2) ? 3 : 0;
             for (int c = 0; c < ncand; ++c) {
                 const double a = ls_alpha(it0 + c);
                 if (!(rc[c] * rc[c] >= (1.0 - 0.001 * a) * rn2)) { act = 1; slot = c; iter = it0 + c; break; }
@@ -324,7 +361,7 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
         const int nref = (s_act == 1 && s_iter <= 6) ? s_slot + 1 : ncand;
         int its = 0, fails = 0, its_ref = 0, fails_ref = 0;
         for (int k = tid; k < ncand * H; k += nt) {
-            const int it = S.ip_iters[sb0 * H + k], fl = (S.ip_status[sb0 * H + k] == 0);
+            const int it = S.ip_iters[(sb0 + it0) * H + k], fl = (S.ip_status[(sb0 + it0) * H + k] == 0);
             its += it; fails += fl;
             if (k < nref * H) { its_ref += it; fails_ref += fl; }
         }
@@ -353,20 +390,21 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
     const int act = s_act, slot = s_slot, iter = s_iter;
     if (act == 2) {                       // next batch of candidates: (1/2, 1/4) or (1/8 .. 1/64)
         const int nstage = (stage == STAGE_LS0) ? STAGE_LS1 : STAGE_LS2;
-        const int it0 = (nstage == STAGE_LS1) ? 1 : 3, nn = (nstage == STAGE_LS1) ? 2 : 4;
+        const int it1 = (nstage == STAGE_LS1) ? 1 : 3, nn = (nstage == STAGE_LS1) ? 2 : 4;      // iterates (= slots) it1 .. it1+nn-1
         if constexpr (ASYNC) {
-            for (int c = 0; c < nn; ++c) apply_step<BlockSync>(S, S.cand, S.nu_cand, sb0 + c, b, ls_alpha(it0 + c), tid, nt);
+            for (int c = 0; c < nn; ++c) apply_step<BlockSync>(S, S.cand, S.nu_cand, sb0 + it1 + c, b, ls_alpha(it1 + c), tid, nt);
             if (tid == 0) S.stage[b] = nstage;
-            enqueue_eval_async<BlockSync>(S, sb0, nn, b, tid, nt);
+            enqueue_eval_async<BlockSync>(S, sb0, it1, nn, b, tid, nt);
             return;
         }
+        if (tid == 0) for (int c = 0; c < CS; ++c) S.need_sweep[sb0 + c] = 0;
+        __syncthreads();
         for (int c = 0; c < nn; ++c) {
-            apply_step<BlockSync>(S, S.cand, S.nu_cand, sb0 + c, b, ls_alpha(it0 + c), tid, nt);
-            enqueue_eval(S, sb0 + c, b, S.WQ.par ^ 1, tid, nt);      // evaluated in the next round
+            apply_step<BlockSync>(S, S.cand, S.nu_cand, sb0 + it1 + c, b, ls_alpha(it1 + c), tid, nt);
+            enqueue_eval(S, sb0 + it1 + c, b, S.WQ.par ^ 1, tid, nt);      // evaluated in the next round
         }
         if (tid == 0) {
             S.stage[b] = nstage;
-            for (int c = nn; c < CS; ++c) S.need_sweep[sb0 + c] = 0;
             atomicAdd(&S.counters[0], 1);
         }
         return;
@@ -377,13 +415,35 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
     }
     {   // res <- res_cand ; r_norm <- r_cand
         double* rr = S.res + (size_t)b * S.N;
-        const double* r = S.res_cand + (sb0 + slot) * S.N;
+        const double* r = S.res_cand + (sb0 + it0 + slot) * S.N;
         for (int e = tid; e < S.N; e += nt) rr[e] = r[e];
+    }
+    {   // im_traj of the accepted evaluation: the sensitivities in effect (a failed step keeps what dz_eff resolves;
+        // steps that resolve to dz_good itself stay as they are).  Source slots come from the table: plain
+        // independent loads, two doubles per lane.
+        const int blk = S.nths * S.nd, ita = it0 + slot;
+        double* good = S.dz_good + (size_t)b * H * blk;
+        if (use_eff && (blk & 1) == 0) {
+            const int* ef = eff + slot * EFF_H;
+            const int hb = blk / 2;
+            for (int e = tid; e < H * hb; e += nt) {
+                const int i = e / hb, s_ = ef[i];
+                if (s_ >= 0) {
+                    const double2* src = reinterpret_cast<const double2*>(S.dz + ((sb0 + s_) * H + i) * (size_t)blk);
+                    reinterpret_cast<double2*>(good + (size_t)i * blk)[e - i * hb] = src[e - i * hb];
+                }
+            }
+        } else {
+            for (int e = tid; e < H * blk; e += nt) {
+                const int i = e / blk;
+                good[e] = dz_eff(S, b, ita, i)[e - i * blk];
+            }
+        }
     }
     if (tid == 0) {
         const double rn = rc[slot];
         S.r_norm[b] = rn;
-        S.cur_slot[b] = slot;
+        S.cur_slot[b] = it0 + slot;
         S.alpha[b] = alpha;
         S.ls_iter[b] = iter;
         int l = S.newton_l[b];
@@ -421,9 +481,12 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
     }
 }
 
+#ifndef CIMPC_RESID_THREADS
+#define CIMPC_RESID_THREADS 256
+#endif
 template <int NQ, int NU, bool CF>
-__global__ __launch_bounds__(256) void resid_decide_kernel(NewtonDev S) {
-    __shared__ double red[CS * 256];
+__global__ __launch_bounds__(CIMPC_RESID_THREADS) void resid_decide_kernel(NewtonDev S) {
+    __shared__ double red[CS * CIMPC_RESID_THREADS];
     __shared__ double rc[CS];
     __shared__ int sh[4];
     resid_decide_body<NQ, NU, CF, false>(S, (int)blockIdx.x + S.b0, red, rc, sh);
@@ -509,7 +572,8 @@ __global__ __launch_bounds__(64) void kkt_kernel_scalar(NewtonDev S, KktArgs K) 
     const double* rb = K.r + (size_t)b * S.N;
     const double beta = K.beta ? K.beta[b] : K.beta_scalar;
     const double rho = (double)H * beta * S.kappa;     // newton_jacobian.jl:169-186 quirk
-    const double* dzb = S.dz + ((size_t)b * CS + (K.stage ? S.cur_slot[b] : 0)) * H * nths * nd;
+    // Newton loop: the accepted evaluation's sensitivities; B1 seam (no stage): slot 0 of the last implicit_dynamics!
+    const double* dzb = K.stage ? S.dz_good + (size_t)b * H * nths * nd : S.dz + (size_t)b * CS * H * nths * nd;
     constexpr int n2 = nd * nd;
     double* ws = S.kkt_ws + (size_t)b * H * (3 * n2 + nd);
     const int oq = nu;   // offset of q2 inside a primal block (:configuration)
@@ -926,7 +990,8 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     const double* rb = K.r + (size_t)b * S.N;
     const double beta = K.beta ? K.beta[b] : K.beta_scalar;
     const double rho = (double)H * beta * S.kappa;         // newton_jacobian.jl:169-186 quirk
-    const double* dzb = S.dz + ((size_t)b * CS + (K.stage ? S.cur_slot[b] : 0)) * H * nths * nd;
+    // Newton loop: the accepted evaluation's sensitivities; B1 seam (no stage): slot 0 of the last implicit_dynamics!
+    const double* dzb = K.stage ? S.dz_good + (size_t)b * H * nths * nd : S.dz + (size_t)b * CS * H * nths * nd;
     double* ws = S.kkt_ws + (size_t)b * H * (3 * n2 + nd);
     constexpr int WSR = 3 * n2 + nd;
 

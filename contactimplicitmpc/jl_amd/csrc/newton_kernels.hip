@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void reset_kernel(NewtonDev S, const double* q
     }
     for (int k = tid; k < CS * H; k += nt) S.pflag[sb0 * H + k] = 0;
     __syncthreads();
-    if (S.A.on) enqueue_eval_async<BlockSync>(S, sb0, 1, b, tid, nt);
+    if (S.A.on) enqueue_eval_async<BlockSync>(S, sb0, 0, 1, b, tid, nt);
     else enqueue_eval(S, sb0, b, S.WQ.par, tid, nt);
 }
 
@@ -191,9 +191,9 @@ int launch_reset(const NewtonDev& S, const double* q0, const double* q1, int war
 template <int NQ, int NU>
 static int launch_resid_t(const NewtonDev& S, hipStream_t s) {
     if (S.dm.mode == CIMPC_MODE_CONFIGURATIONFORCE)
-        hipLaunchKernelGGL((resid_decide_kernel<NQ, NU, true>), dim3(S.nb_launch), dim3(256), 0, s, S);
+        hipLaunchKernelGGL((resid_decide_kernel<NQ, NU, true>), dim3(S.nb_launch), dim3(CIMPC_RESID_THREADS), 0, s, S);
     else
-        hipLaunchKernelGGL((resid_decide_kernel<NQ, NU, false>), dim3(S.nb_launch), dim3(256), 0, s, S);
+        hipLaunchKernelGGL((resid_decide_kernel<NQ, NU, false>), dim3(S.nb_launch), dim3(CIMPC_RESID_THREADS), 0, s, S);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
 int launch_resid_decide(const NewtonDev& S, hipStream_t s) {

@@ -31,6 +31,9 @@ struct NewtonDev {
     // implicit dynamics of the last sweep
     double* d;         // [B*CS][H][nd]
     double* dz;        // [B*CS][H][nths][nd]
+    double* dz_good;   // [B][H][nths][nd]  sensitivities of the rollout's ACCEPTED evaluation (the reference's ip[t].dz
+                       // after the last accepted implicit_dynamics!): Jacobian data of the KKT stage and the value a
+                       // failed solve falls back to (see dz_eff in newton_impl.h)
     int* ip_status;    // [B*CS][H]
     int* ip_iters;     // [B*CS][H]
     int* pflag;        // [B*CS][H] resumable-solve flags (see IpParams)

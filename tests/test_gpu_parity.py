@@ -267,3 +267,39 @@ def test_async_single_launch_matches_lockstep(gpu_required, monkeypatch, mode, B
     np.testing.assert_allclose(a[2], b[2], rtol=1e-12, atol=0)
     for k in ("q", "u", "nu"):
         np.testing.assert_allclose(a[3][k], b[3][k], rtol=1e-12, atol=1e-14)
+
+
+def test_full_size_schedules_agree(gpu_required, monkeypatch):
+    """BASELINE.json's full-size workload (quadruped, H = 40, H_ref = 60, 512 rollouts, cold start): the hybrid
+    schedule (rounds + asynchronous tail, packed KKT) and the plain lock-step rounds must produce the same
+    iteration counts, reference-equivalent counters and trajectories - a size-independent property that needs
+    no oracle run (the oracle takes minutes at this size)."""
+    import bench
+    from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions
+    H, H_ref, B = 40, 60, 512
+    d, prob, obj, ro = bench.build_inputs(B, H, H_ref, seed=1234, perturb=0.05)
+    q0 = np.stack([r[2] for r in ro]); q1 = np.stack([r[3] for r in ro])
+    outs = []
+    for flag in ("0", "2"):
+        monkeypatch.setenv("CIMPC_ASYNC", flag)
+        s = CIMPCSolver(d.nq, d.nu, d.nw, d.nc, d.nb, H_ref, H, B=B, mode=0, ip_opts=InteriorPointOptions(kappa_tol=prob["kappa"]),
+                        newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=3e-4, max_iter=5))
+        for t in range(H_ref):
+            s.set_linearization(t + 1, prob["z0"][t], prob["th0"][t], prob["r0"][t], prob["rz0"][t], prob["rth0"][t])
+        s.set_objective(obj.q, obj.u)
+        s.set_window(np.stack([w for (w, _, _, _) in ro]) + 1)
+        s.set_reference(np.stack([r.q for (_, r, _, _) in ro]), np.stack([r.u for (_, r, _, _) in ro]), np.stack([r.w for (_, r, _, _) in ro]),
+                        np.stack([r.gamma for (_, r, _, _) in ro]), np.stack([r.b for (_, r, _, _) in ro]), np.stack([r.theta for (_, r, _, _) in ro]))
+        u1, it, rn = s.newton_solve(q0, q1)
+        outs.append((u1, it, rn, s.trajectory(), s.rollout_counters(), s.stats()))
+        s.close()
+    a, b = outs
+    assert b[5]["rounds"] < a[5]["rounds"]               # the hybrid run handed its tail over
+    np.testing.assert_array_equal(a[1], b[1])
+    for k in ("sweeps", "ip_iters", "ip_failures"):
+        np.testing.assert_array_equal(a[4][k], b[4][k])
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[2], b[2])
+    for k in ("q", "u", "nu"):
+        np.testing.assert_array_equal(a[3][k], b[3][k])
+    assert np.isfinite(a[3]["q"]).all() and (a[1] <= 5).all()
