@@ -412,6 +412,7 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
     [[maybe_unused]] int idle_trips = 0, dbg_trips = 0, dbg_act = 0;
     [[maybe_unused]] long long dbg_tpop = 0, dbg_tfence = 0;
     [[maybe_unused]] long long dbg_pop[4] = {0, 0, 0, 0};
+    [[maybe_unused]] const bool dbg_on = ASYNC && p.A.dbg != nullptr;      // diagnostics only with CIMPC_ASYNC_DEBUG
     double reg = 0.0, r_vio = 0.0, k_vio = 0.0, qinit = 0.0;
 
     while (true) {
@@ -455,7 +456,11 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
                         if (l == 0) { ps[PS - 2] = reg; backlog[nback] = prob; }
                         ++nback;
                     } else {                 // failed: the slot keeps its previous sensitivities
-                        { const long long t0 = wall_clock64(); problem_done<ASYNC>(p, sb, l); if constexpr (ASYNC) dbg_tfence += wall_clock64() - t0; }
+                        {
+                            const long long t0 = dbg_on ? wall_clock64() : 0;
+                            problem_done<ASYNC>(p, sb, l);
+                            if (dbg_on) dbg_tfence += wall_clock64() - t0;
+                        }
                     }
                 }
                 have = false;
@@ -466,13 +471,13 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
         if (!have && (!exhausted || (ASYNC && !(p.A.flags & 2) && (++idle_trips & 7) == 0))) {
             int idx = 0, item = 0;
             if constexpr (ASYNC) {       // live queue: claim only what has been published
-                const long long tq0 = wall_clock64();
+                const long long tq0 = dbg_on ? wall_clock64() : 0;
                 if (l == 0) item = aq_pop(const_cast<int*>(items), head, tailp, p.A.dbg ? dbg_pop : nullptr, p.A.abort_flag);
                 item = group_bcast0<G>(item);
                 idx = item < 0 ? n : 0;
-                const long long tq1 = wall_clock64();
+                const long long tq1 = dbg_on ? wall_clock64() : 0;
                 if (item >= 0) xfence(p.A.flags);      // acquire the candidate trajectory of the producer
-                dbg_tpop += tq1 - tq0; dbg_tfence += wall_clock64() - tq1;
+                if (dbg_on) { dbg_tpop += tq1 - tq0; dbg_tfence += wall_clock64() - tq1; }
             } else {
                 if (l == 0) idx = atomicAdd(head, 1);
                 idx = group_bcast0<G>(idx);
@@ -537,7 +542,7 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
         //         every group of the wave has something in its backlog (all four groups then run
         //         the same code on their own problem - no SIMT divergence), when the wave has no
         //         interior-point work left, or when a backlog is full.
-        if constexpr (ASYNC) { dbg_trips += 1; dbg_act += have ? 1 : 0; }
+        if (dbg_on) { dbg_trips += 1; dbg_act += have ? 1 : 0; }
         const bool any_ip = __any(have ? 1 : 0);
         if (!any_ip && !__any(nback > 0 ? 1 : 0)) break;
         // (ASYNC: a finished solve must not wait for its neighbours' work to dry up - the rollout's next
