@@ -36,7 +36,7 @@ struct Model {
     static constexpr int RST_LD = G + 1;                       // padded row stride of the R tile
     static constexpr int SENS_MAX = 16;                         // converged problems a group may defer
 #ifndef CIMPC_SENS_ILP
-#define CIMPC_SENS_ILP 2
+#define CIMPC_SENS_ILP 5
 #endif
     static constexpr int SENS_ILP = CIMPC_SENS_ILP;             // sensitivity columns solved side by side
     static constexpr int LDS_GROUP = ((NY * RST_LD + NTH + SENS_MAX / 2) + 1) & ~1;  // doubles / problem
