@@ -913,7 +913,8 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         if (kkt && !h->kkt_overlap) {   // small batches: latency matters, keep the KKT result in this round
             Sk.kkt_same_round = 1;
             prof_begin(h, PC_KKT, sb.st);
-            int rr = h->use_dense ? launch_kkt_dense_newton(Sk, h->d_dense_ws, sb.st) : launch_kkt(Sk, sb.st);
+            // (same compact list / packed or pipelined kernel as the overlapped path)
+            int rr = h->use_dense ? launch_kkt_dense_newton(Sk, h->d_dense_ws, sb.st) : launch_kkt_packed(Sk, last_kkt, Sk.WQ.par ^ 1, sb.st);
             prof_end(h, sb.st);
             if (rr != CIMPC_OK) return fail(h, rr, "kkt launch failed");
         }

@@ -51,10 +51,22 @@ __device__ __forceinline__ T uniform_arg(unsigned long long v) {
 }
 __device__ __forceinline__ NewtonDev uniform_state(unsigned long long v) { return uniform_arg<NewtonDev, offsetof(AsyncArgs, S)>(v); }
 template <int NQ, int NU>
-__device__ __noinline__ void async_kkt_job(unsigned long long ka, int b, double* smem, int lane) {
+__device__ __noinline__ void async_kkt_job(unsigned long long ka, int b, double* smem, int tid) {
+    // entered by the WHOLE workgroup: waves 0 and 1 run the software-pipelined recursion (kkt_body PIPE = 2: the
+    // KKT solve heads a rollout's dependency chain here), the other waves only keep the workgroup barriers of
+    // the pipeline company (one after the LDS clear, one per tick, one before the backward pass)
     const NewtonDev S = uniform_state(ka);
-    const KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 2};
-    kkt_body<NQ, NU, WaveSync>(S, K, b, smem, lane);
+    if ((int)blockDim.x >= 128) {
+        if (tid < 128) {
+            const KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 2};
+            kkt_body<NQ, NU, WaveSync, 2>(S, K, b, smem, tid & 63, tid >> 6);
+        } else {
+            for (int k = 0; k < S.dm.H + 3; ++k) __syncthreads();
+        }
+    } else if (tid < 64) {
+        const KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 2};
+        kkt_body<NQ, NU, WaveSync>(S, K, b, smem, tid);
+    }
 }
 template <int NQ, int NU>
 __device__ __noinline__ void async_resid_job(unsigned long long ka, int b, double* red, double* rc, int* sh) {
@@ -118,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void newton_async_kernel(AsyncArgs args) {
         if (type == 1) {
             xfence(A.flags);                             // acquire res / traj / dz of the rollout
             account(0);
-            if (tid < 64) async_kkt_job<NQ, NU>(ka, job, smem, tid);
+            async_kkt_job<NQ, NU>(ka, job, smem, tid);
             __syncthreads();
             account(1);
             continue;
@@ -168,7 +180,7 @@ int launch_async_model(const IpParams& p, const NewtonDev& S, int waves, int gri
     if (waves != 1 && waves != 2 && waves != 4) return CIMPC_ERR_INVALID;
     const int ppw = 64 / M::G;
     const size_t lds_ip = (size_t)(L.size + waves * ppw * M::LDS_GROUP) * sizeof(double);
-    const size_t lds_kkt = (size_t)(KKT_MFMA_TILES * TSZ + 208) * sizeof(double);
+    const size_t lds_kkt = (size_t)((waves >= 2 ? KKT_PIPE_TILES : KKT_MFMA_TILES) * TSZ + 208) * sizeof(double);
     const size_t lds = lds_ip > lds_kkt ? lds_ip : lds_kkt;
     static LdsOptIn optin;
     if (lds_opt_in(optin, (const void*)newton_async_kernel<M>, lds) != CIMPC_OK) return CIMPC_ERR_HIP;

@@ -956,9 +956,17 @@ __device__ __forceinline__ double tile_mv(const double* Mt, const double* x, int
     return s0 + s1;
 }
 
-template <int NQ, int NU, class Sync>
-__device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, int b, double* sm, int lane) {
+// PIPE = 1: the whole recursion on one wavefront.  PIPE = 2: the forward pass is software-pipelined over TWO
+// wavefronts of the workgroup - wave 0 runs stage A of step t (operands -> LDS, the products with the inverse
+// weights, Y_ii / Y_i,i-1 / L2_i / beta_i: everything that needs factors of step <= t-2 only) while wave 1 runs
+// stage B of step t-1 (L1, the Cholesky factor and its inverse, y, spill); one workgroup barrier per step.  The
+// stages hand Y_ii, Y_i,i-1, L2_i, beta_i over in LDS tiles double-buffered by step parity.  A step then costs
+// max(A, B) instead of A + B; the backward pass and the recovery stay on wave 0.
+constexpr int KKT_PIPE_TILES = 27;       // 22 + second L2 tile + two Y_ii and two Y_i,i-1 hand-over tiles
+template <int NQ, int NU, class Sync, int PIPE = 1>
+__device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, int b, double* sm, int lane, int wave = 0) {
     static_assert(NQ <= 16 && NU <= 16, "MFMA KKT kernel handles one 16x16 tile per block");
+    constexpr int NTILES = PIPE == 2 ? KKT_PIPE_TILES : KKT_MFMA_TILES;
     // The body runs on ONE wavefront; its phases hand data over through LDS only.  The hand-off needs the
     // wave's LDS operations complete (lgkmcnt(0)) - NOT its global ones: a full barrier (vmcnt(0)) would
     // expose the latency of the prefetch loads and of the factor spill stores at every phase boundary.
@@ -980,13 +988,14 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     // tiles 10..12: L0^-1 ring, 13..14: L1 ring, 15..17: Qinv ring
     double* Ri = tile(18);
     // tiles 19..21: extra ring slots of the backward pass
-    double* vec = sm + KKT_MFMA_TILES * TSZ;
-    double* bet = vec;                                     // 16 each
+    double* vec = sm + NTILES * TSZ;
+    double* bet = vec;                                     // 16 each (PIPE = 2: second parity at vec + 144)
     double* tv = vec + 16;
     // vec + 32/48/64: y / dnu ring
     double* rpu = vec + 80;
     // vec + 96/112/128: r_p(q) ring
-    for (int k = lane; k < KKT_MFMA_TILES * TSZ + 208; k += 64) sm[k] = 0.0;
+    for (int k = lane + 64 * wave; k < NTILES * TSZ + 208; k += 64 * PIPE) sm[k] = 0.0;
+    if constexpr (PIPE == 2) __syncthreads();
     const double* rb = K.r + (size_t)b * S.N;
     const double beta = K.beta ? K.beta[b] : K.beta_scalar;
     const double rho = (double)H * beta * S.kappa;         // newton_jacobian.jl:169-186 quirk
@@ -1002,7 +1011,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     // where it lands in LDS (surplus lanes write a scratch word).  The divisions by nd / nq / nu, the tile
     // selection and ~35 exec-mask branches per step would otherwise be redone for every element of every
     // step (measured: 2 k of the 14 k cycles of a step).
-    const int TRASH = KKT_MFMA_TILES * TSZ + 200;           // scratch double behind the vectors
+    const int TRASH = NTILES * TSZ + 200;                    // scratch double behind the vectors
     int dz_src[PF_DZ], dz_dst[PF_DZ], dz_rot[PF_DZ], q_src[PF_Q], q_dst[PF_Q], r_src[PF_R], r_dst[PF_R];
 #pragma unroll
     for (int j = 0; j < PF_DZ; ++j) {
@@ -1045,7 +1054,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
 #pragma unroll
         for (int j = 0; j < PF_R; ++j) sm[r_dst[j]] = pf_r[j];
         // r_p: [u | q2] -> rpu (vec + 80), q ring (vec + 96 + 16 m0)
-        const int vb = KKT_MFMA_TILES * TSZ;
+        const int vb = NTILES * TSZ;
         sm[lane < nu ? vb + 80 + lane : lane < nr ? vb + 96 + 16 * m0 + (lane - nu) : TRASH] = pf_rp;
     };
     // spill of a step's factors (n2 = nd^2 entries each): element k = lane + 64 j, clamped (surplus lanes
@@ -1064,15 +1073,35 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
 #else
 #define KPROF(j)
 #endif
-    prefetch(0);
-    for (int i = 0; i < H; ++i) {
+    // ring / parity slots of step i
+    struct Slots { double *Li, *Li1, *Li2, *L1c, *L1p, *A1, *A1p, *Qi0, *Qi1, *Qi2, *yc, *y1, *y2, *q0r, *q1r, *q2r, *L2c, *Y0h, *Y1h, *bet; int p0, m0; };
+    auto slots = [&](int i) {
         const int m0 = i % 3, m1 = (i + 2) % 3, m2 = (i + 1) % 3, p0 = i & 1, p1 = (i + 1) & 1;
-        double* Li = tile(10 + m0);  double* Li1 = tile(10 + m1);  double* Li2 = tile(10 + m2);
-        double* L1c = tile(13 + p0); double* L1p = tile(13 + p1);
-        double* A1 = tile(2 + p0);   double* A1p = tile(2 + p1);
-        double* Qi0 = tile(15 + m0); double* Qi1 = tile(15 + m1);  double* Qi2 = tile(15 + m2);
-        double* yc = vec + 32 + 16 * m0; double* y1 = vec + 32 + 16 * m1; double* y2 = vec + 32 + 16 * m2;
-        double* q0r = vec + 96 + 16 * m0; double* q1r = vec + 96 + 16 * m1; double* q2r = vec + 96 + 16 * m2;
+        Slots t;
+        t.Li = tile(10 + m0); t.Li1 = tile(10 + m1); t.Li2 = tile(10 + m2);
+        t.L1c = tile(13 + p0); t.L1p = tile(13 + p1);
+        t.A1 = tile(2 + p0); t.A1p = tile(2 + p1);
+        t.Qi0 = tile(15 + m0); t.Qi1 = tile(15 + m1); t.Qi2 = tile(15 + m2);
+        t.yc = vec + 32 + 16 * m0; t.y1 = vec + 32 + 16 * m1; t.y2 = vec + 32 + 16 * m2;
+        t.q0r = vec + 96 + 16 * m0; t.q1r = vec + 96 + 16 * m1; t.q2r = vec + 96 + 16 * m2;
+        // hand-over buffers of the pipelined variant (by step parity); the one-wave variant keeps one set
+        t.L2c = (PIPE == 2 && p0) ? tile(22) : L2c;
+        t.Y0h = tile(23 + (PIPE == 2 ? p0 : 0));
+        t.Y1h = tile(25 + (PIPE == 2 ? p0 : 0));
+        t.bet = (PIPE == 2 && p0) ? vec + 144 : bet;
+        t.p0 = p0; t.m0 = m0;
+        return t;
+    };
+    const d4 z4 = {0.0, 0.0, 0.0, 0.0};
+    d4 y0 = z4, y1a = z4;                 // PIPE = 1: Y_ii / Y_i,i-1 accumulators stay in registers between the stages
+    // ---- stage A of step i: needs factors of steps <= i-2 only --------------------------------------------
+    auto stageA = [&](int i) {
+        const Slots t = slots(i);
+        double* const Li2 = t.Li2; double* const A1 = t.A1; double* const A1p = t.A1p;
+        double* const Qi0 = t.Qi0; double* const Qi1 = t.Qi1; double* const Qi2 = t.Qi2;
+        double* const q0r = t.q0r; double* const q1r = t.q1r; double* const q2r = t.q2r;
+        double* const L2c = t.L2c; double* const bet = t.bet;
+        const int p0 = t.p0, m0 = t.m0;
         // ---- P1: step i operands -> LDS, fetch step i+1 ------------------------------------
         commit(p0, m0);
         const double rd_i = pf_rd;
@@ -1080,18 +1109,17 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         prefetch(i + 1);
         KPROF(1)
         // ---- P2: T0 = du1 Rinv, T1 = dq1 Qinv_{i-1}, T2 = dq0 Qinv_{i-2}  (Qinv, Rinv symmetric)
-        const d4 z4 = {0.0, 0.0, 0.0, 0.0};
         tile_st(T0, tile_mma<KBU, false>(A0, Ri, z4, li, lk), li, lk);
         if (i >= 1) tile_st(T1, tile_mma<KBQ, false>(A1, Qi1, z4, li, lk), li, lk);
         if (i >= 2) tile_st(T2, tile_mma<KBQ, false>(A2, Qi2, z4, li, lk), li, lk);
         lds_sync();
         KPROF(2)
         // ---- P3: Y_ii, Y_i,i-1, L2_i = -T2 L0_{i-2}^-T, beta_i -------------------------------
-        d4 y0 = tile_ld(Qi0, li, lk);
+        y0 = tile_ld(Qi0, li, lk);
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (li == lk + 4 * r && li < nd) y0[r] += rho;
         y0 = tile_mma<KBU, false>(T0, A0, y0, li, lk);
-        d4 y1a = z4;
+        y1a = z4;
         if (i >= 1) {
             y0 = tile_mma<KBQ, false>(T1, A1, y0, li, lk);
             y1a = -tile_ld(T1, li, lk);
@@ -1107,8 +1135,15 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
             if (i >= 2) s += tile_mv<nq, false>(T2, q2r, lane);
             bet[lane] = s - rd_i;
         }
-        lds_sync();
-        KPROF(3)
+        if constexpr (PIPE == 2) { tile_st(t.Y0h, y0, li, lk); tile_st(t.Y1h, y1a, li, lk); }
+    };
+    // ---- stage B of step i: L1_i, the Cholesky factor L0_i and its inverse, y_i, spill --------------------
+    auto stageB = [&](int i) {
+        const Slots t = slots(i);
+        double* const Li = t.Li; double* const Li1 = t.Li1; double* const L1c = t.L1c; double* const L1p = t.L1p;
+        double* const yc = t.yc; double* const y1 = t.y1; double* const y2 = t.y2;
+        double* const L2c = t.L2c; double* const bet = t.bet;
+        if constexpr (PIPE == 2) { y0 = tile_ld(t.Y0h, li, lk); y1a = tile_ld(t.Y1h, li, lk); }
         // ---- P4: Y1 -= L2 L1_{i-1}^T ; stage Y1 as an operand ------------------------------
         if (i >= 1) {
             if (i >= 2) y1a = tile_mma<KBD, true>(L2c, L1p, y1a, li, lk);
@@ -1187,6 +1222,24 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         if (lane < nd) wsi[3 * n2 + lane] = yi;
         lds_sync();
         KPROF(7)
+    };
+    if constexpr (PIPE == 2) {
+        if (wave == 0) prefetch(0);
+        for (int tck = 0; tck <= H; ++tck) {      // tick: A(tck) on wave 0 next to B(tck - 1) on wave 1
+            if (wave == 0 && tck < H) stageA(tck);
+            if (wave == 1 && tck >= 1) stageB(tck - 1);
+            __syncthreads();
+        }
+        __threadfence_block();                    // wave 1's spill stores are read back by wave 0
+        __syncthreads();
+        if (wave != 0) return;
+    } else {
+        prefetch(0);
+        for (int i = 0; i < H; ++i) {
+            stageA(i);
+            lds_sync();
+            stageB(i);
+        }
     }
     __threadfence_block();
     lds_sync();
@@ -1214,7 +1267,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         const int t = kk / n2, e = kk - t * n2, r = e % nd, c = e / nd;
         bw_src[j] = kk;
         bw_dst[j] = !ok ? TRASH : (t == 0) ? r + c * TL : (t == 1) ? 3 * TSZ + r + c * TL : (t == 2) ? 6 * TSZ + r + c * TL
-                                                                                       : KKT_MFMA_TILES * TSZ + (kk - 3 * n2);
+                                                                                       : NTILES * TSZ + (kk - 3 * n2);
         bw_rot[j] = (ok && t < 2) ? TSZ : 0;
     }
     auto prefetch_b = [&](int i) {
@@ -1327,6 +1380,15 @@ __global__ __launch_bounds__(64 * KKT_PACK, CIMPC_KKT_PACK_WAVES_PER_SIMD) void 
     const int wave = (int)threadIdx.x >> 6, slot = (int)blockIdx.x * KKT_PACK + wave;
     if (slot >= n) return;
     kkt_body<NQ, NU, WaveSync>(S, K, list[slot], sm + (size_t)wave * (KKT_MFMA_TILES * TSZ + 208), (int)threadIdx.x & 63);
+}
+
+// Pipelined launch: one rollout per workgroup of two wavefronts (kkt_body<..., PIPE = 2>), from the compact list.
+template <int NQ, int NU>
+__global__ __launch_bounds__(128, 2) void kkt_kernel_pipe(NewtonDev S, KktArgs K, const int* list, int n, const int* n_dev) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    if (n_dev != nullptr) n = *n_dev;
+    if ((int)blockIdx.x >= n) return;
+    kkt_body<NQ, NU, WaveSync, 2>(S, K, list[blockIdx.x], sm, (int)threadIdx.x & 63, (int)threadIdx.x >> 6);
 }
 
 template <int NQ, int NU>

@@ -10,6 +10,7 @@
 // The Newton iteration of every rollout advances in lock-step rounds driven by the host
 // (cimpc_host.cpp); each rollout carries its own stage / alpha / beta, so rollouts that
 // backtrack and rollouts that start their next Newton iteration share the same launches.
+#include <cstdlib>
 #include "newton_impl.h"
 
 namespace cimpc {
@@ -205,26 +206,38 @@ int launch_resid_decide(const NewtonDev& S, hipStream_t s) {
     return CIMPC_ERR_INVALID;
 }
 template <int NQ, int NU>
-static int launch_kkt_packed_t(const NewtonDev& S, const KktArgs& K, const int* list, int n, const int* n_dev, hipStream_t s) {
+static int launch_kkt_packed_t(const NewtonDev& S, const KktArgs& K, const int* list, int n, const int* n_dev, hipStream_t s, bool latency) {
     if constexpr (NQ <= 16 && NU <= 16) {
         const size_t lds = (size_t)KKT_PACK * (KKT_MFMA_TILES * TSZ + 208) * sizeof(double);
         static LdsOptIn optin;
         if (lds_opt_in(optin, (const void*)kkt_kernel_packed<NQ, NU>, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
+        // CIMPC_KKT_PIPE: 0 never, 1 always, unset = where the KKT solve is on the critical path (`latency`: small
+        // batches run it in the round itself).  Next to a busy sweep the pipelined kernel takes twice the CUs
+        // for half the time - measured neutral - so the packed one-wave kernel stays there.
+        static const int pipe_env = getenv("CIMPC_KKT_PIPE") ? atoi(getenv("CIMPC_KKT_PIPE")) : 2;
+        if (pipe_env == 1 || (pipe_env == 2 && latency)) {      // two wavefronts per rollout, software-pipelined forward recursion
+            const size_t lds2 = (size_t)(KKT_PIPE_TILES * TSZ + 208) * sizeof(double);
+            static LdsOptIn optin2;
+            if (lds_opt_in(optin2, (const void*)kkt_kernel_pipe<NQ, NU>, lds2) != CIMPC_OK) return CIMPC_ERR_HIP;
+            hipLaunchKernelGGL((kkt_kernel_pipe<NQ, NU>), dim3(n), dim3(128), lds2, s, S, K, list, n, n_dev);
+            return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+        }
         hipLaunchKernelGGL((kkt_kernel_packed<NQ, NU>), dim3((n + KKT_PACK - 1) / KKT_PACK), dim3(64 * KKT_PACK), lds, s, S, K, list, n, n_dev);
         return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
     }
     return CIMPC_ERR_INVALID;
 }
 int launch_kkt_packed(const NewtonDev& S, int n_kkt, int list_par, hipStream_t s, const int* n_dev) {
+    const bool latency = S.kkt_same_round != 0;
     const int nq = S.dm.nq, nu = S.dm.nu;
     if (n_dev != nullptr) n_kkt = S.dm.B;      // upper bound of the grid; surplus workgroups leave at once
     if (n_kkt <= 0) return CIMPC_OK;
     if (S.kkt_list == nullptr || S.dm.mode != CIMPC_MODE_CONFIGURATION || nq > 16 || nu > 16 || S.dm.H > 96) return launch_kkt(S, s);
     const KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 1};
     const int* list = S.kkt_list + (size_t)list_par * S.dm.B;
-    if (nq == 2 && nu == 2) return launch_kkt_packed_t<2, 2>(S, K, list, n_kkt, n_dev, s);
-    if (nq == 4 && nu == 2) return launch_kkt_packed_t<4, 2>(S, K, list, n_kkt, n_dev, s);
-    if (nq == 11 && nu == 8) return launch_kkt_packed_t<11, 8>(S, K, list, n_kkt, n_dev, s);
+    if (nq == 2 && nu == 2) return launch_kkt_packed_t<2, 2>(S, K, list, n_kkt, n_dev, s, latency);
+    if (nq == 4 && nu == 2) return launch_kkt_packed_t<4, 2>(S, K, list, n_kkt, n_dev, s, latency);
+    if (nq == 11 && nu == 8) return launch_kkt_packed_t<11, 8>(S, K, list, n_kkt, n_dev, s, latency);
     return launch_kkt(S, s);
 }
 int launch_kkt(const NewtonDev& S, hipStream_t s) {
