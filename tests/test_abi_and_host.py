@@ -56,3 +56,29 @@ def test_product_does_not_import_oracle():
                 assert "oracle" not in src.replace("test oracle", ""), f"{f} mentions oracle/"
     src = open(os.path.join(ROOT, "include", "cimpc.h")).read()
     assert "oracle" not in src
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """The ctypes mirrors (_lib.py) must have the size and field offsets a C compiler gives the structs of
+    include/cimpc.h - an ABI drift between the header and the Python host would otherwise corrupt options
+    silently."""
+    import ctypes as C
+    import subprocess
+    from contactimplicitmpc.jl_amd import _lib
+    structs = {"cimpc_dims": _lib.Dims, "cimpc_ip_opts": _lib.IpOpts, "cimpc_newton_opts": _lib.NewtonOpts,
+               "cimpc_stats": _lib.Stats, "cimpc_profile": _lib.Profile}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cimpc.h"', 'int main(void) {']
+    for cname, py in structs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in py._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, py in structs.items():
+        assert int(got[cname]) == C.sizeof(py), cname
+        for fname, _ in py._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(py, fname).offset, f"{cname}.{fname}"
