@@ -38,7 +38,7 @@ struct Model {
 #ifndef CIMPC_SENS_ILP
 #define CIMPC_SENS_ILP 5
 #endif
-    static constexpr int SENS_ILP = CIMPC_SENS_ILP;             // sensitivity columns solved side by side
+    static constexpr int SENS_ILP = (NX <= 16 && NY <= 16) ? CIMPC_SENS_ILP : 2;   // sensitivity columns solved side by side
     static constexpr int LDS_GROUP = ((NY * RST_LD + NTH + SENS_MAX / 2) + 1) & ~1;  // doubles / problem
 };
 
@@ -580,8 +580,10 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
 // Queue kernel of the lock-step rounds: persistent workgroups; each serves one knot at a time and
 // hops to another knot that still has work when its queue is empty.
 // ----------------------------------------------------------------------------------------
+// (32-lane models: the table + group scratch fill most of a CU's LDS, one workgroup per CU is resident anyway -
+//  the kernel may then use the full 512-VGPR budget instead of spilling: centroidal 341 spilled VGPRs -> 0)
 template <class M>
-__global__ __launch_bounds__(256, 2) void ip_queue_kernel(IpParams p) {
+__global__ __launch_bounds__(256, M::G == 16 ? 2 : 1) void ip_queue_kernel(IpParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int s_knot, s_total, s_rem[PICK_MAXK];
     const int tid = (int)threadIdx.x;

@@ -1,0 +1,36 @@
+"""One-off measurement for BASELINE configs[4] dimensions (centroidal_quadruped: nq 18, nu 12, nw 3, nc 4, nb 16,
+H = 60) in fp64, TrackingObjective (the velocity objective of the example needs the dense-LU fallback, N = 2880:
+not a practical configuration yet - DESIGN.md).  Lock-step rounds, 32-lane interior-point groups, scalar KKT."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from oracle import synth
+from oracle.dims import Dims
+from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions
+d = Dims(nq=18, nu=12, nw=3, nc=4, nb=16)
+H, H_ref = 60, 71
+prob = synth.make_problem(d, H_ref, seed=1)
+obj = synth.make_objective(d, H, dense_q=True)
+for B in (1, 64, 512):
+    ro = [synth.make_rollout(d, prob, H, phase=int(np.random.default_rng(g).integers(0, H_ref)), seed=100 + g, perturb=0.02) for g in range(B)]
+    s = CIMPCSolver(d.nq, d.nu, d.nw, d.nc, d.nb, H_ref, H, B=B, mode=0, ip_opts=InteriorPointOptions(kappa_tol=prob["kappa"], r_tol=1e-4),
+                    newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=3e-5, max_iter=5))
+    for t in range(H_ref):
+        s.set_linearization(t + 1, prob["z0"][t], prob["th0"][t], prob["r0"][t], prob["rz0"][t], prob["rth0"][t])
+    s.set_objective(obj.q, obj.u)
+    s.set_window(np.stack([w for (w, _, _, _) in ro]) + 1)
+    s.set_reference(np.stack([r.q for (_, r, _, _) in ro]), np.stack([r.u for (_, r, _, _) in ro]), np.stack([r.w for (_, r, _, _) in ro]),
+                    np.stack([r.gamma for (_, r, _, _) in ro]), np.stack([r.b for (_, r, _, _) in ro]), np.stack([r.theta for (_, r, _, _) in ro]))
+    q0 = np.stack([r[2] for r in ro]); q1 = np.stack([r[3] for r in ro])
+    s.newton_solve(q0, q1)
+    s.profile_enable(True); s.profile_reset()
+    n = 3 if B > 1 else 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        u1, it, rn = s.newton_solve(q0, q1)
+    dt = (time.perf_counter() - t0) / n
+    st = s.stats(); pr = s.profile_read()
+    print({k: round(v / n, 3) for k, v in pr.items() if k.endswith('_ms')}, {k: v // n for k, v in pr.items() if k.endswith('launches')})
+    print("centroidal H=60 B=%d: %.2f ms per batch step, %.0f MPC steps/s, newton iters/step %.2f, ip iters/solve %.2f, rounds %d, ip failures %d"
+          % (B, 1e3 * dt, B / dt, it.mean(), st["ip_iters"] / max(st["ip_solves"], 1), st["rounds"], st["ip_failures"]))
+    s.close()
