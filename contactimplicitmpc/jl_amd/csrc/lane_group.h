@@ -44,6 +44,8 @@ struct LaneGroup {
         if constexpr (G == 16) {
             return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xF, 0xF, true);  // row_newbcast:K
         } else {
+            // (measured: v_readlane + select instead of ds_bpermute is 50 % SLOWER here - the VALU -> SGPR -> VALU
+            //  hazards of ~1000 broadcasts per iteration cost more than the LDS crossbar trips)
             const int lane = (int)(threadIdx.x & 63);
             return __shfl(v, (lane & ~31) | K, 64);
         }
