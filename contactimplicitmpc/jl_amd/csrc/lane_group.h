@@ -44,8 +44,8 @@ struct LaneGroup {
         if constexpr (G == 16) {
             return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xF, 0xF, true);  // row_newbcast:K
         } else {
-            // (measured: v_readlane + select instead of ds_bpermute is 50 % SLOWER here - the VALU -> SGPR -> VALU
-            //  hazards of ~1000 broadcasts per iteration cost more than the LDS crossbar trips)
+            // (measured alternatives for the 32-lane model: v_readlane + select is 50 % SLOWER - VALU -> SGPR -> VALU
+            //  hazards; DPP row_newbcast + gfx950 v_permlane16_swap gives the same sweep time as this ds_bpermute)
             const int lane = (int)(threadIdx.x & 63);
             return __shfl(v, (lane & ~31) | K, 64);
         }
