@@ -180,7 +180,7 @@ int launch_async_model(const IpParams& p, const NewtonDev& S, int waves, int gri
     if (waves != 1 && waves != 2 && waves != 4) return CIMPC_ERR_INVALID;
     const int ppw = 64 / M::G;
     const size_t lds_ip = (size_t)(L.size + waves * ppw * M::LDS_GROUP) * sizeof(double);
-    const size_t lds_kkt = (size_t)((waves >= 2 ? KKT_PIPE_TILES : KKT_MFMA_TILES) * TSZ + 208) * sizeof(double);
+    const size_t lds_kkt = (size_t)(waves >= 2 ? kkt_lds_doubles<M::NQ, M::NU, 2>() : kkt_lds_doubles<M::NQ, M::NU, 1>()) * sizeof(double);
     const size_t lds = lds_ip > lds_kkt ? lds_ip : lds_kkt;
     static LdsOptIn optin;
     if (lds_opt_in(optin, (const void*)newton_async_kernel<M>, lds) != CIMPC_OK) return CIMPC_ERR_HIP;

@@ -922,39 +922,122 @@ constexpr int TL = 16;            // tile leading dimension
 constexpr int TSZ = TL * TL;      // doubles per tile
 constexpr int KKT_MFMA_TILES = 22;
 
-template <int KB, bool NEG>
-__device__ __forceinline__ d4 tile_mma(const double* X, const double* Y, d4 acc, int li, int lk) {
+// Tiles are TLD x TLD column-major (TLD = 16, or 24 for the larger models); a product C (+)= X * Y^T runs as
+// NB x NB sub-blocks of the 16x16x4 MFMA (NB = ceil(TLD / 16)), rows / columns beyond TLD masked to zero.
+template <int NB>
+struct TAcc {
+    d4 v[NB][NB];
+};
+template <int NB>
+__device__ __forceinline__ TAcc<NB> tile_zero() {
+    TAcc<NB> z;
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) z.v[I][J] = d4{0.0, 0.0, 0.0, 0.0};
+    return z;
+}
+template <int KB, bool NEG, int TLD>
+__device__ __forceinline__ TAcc<(TLD + 15) / 16> tile_mma(const double* X, const double* Y, TAcc<(TLD + 15) / 16> acc, int li, int lk) {
+    constexpr int NB = (TLD + 15) / 16;
+    constexpr bool MASK = (TLD % 16) != 0;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-        double a = Y[li + (4 * kb + lk) * TL];
-        const double b = X[li + (4 * kb + lk) * TL];
-        if (NEG) a = -a;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        double xa[NB], ya[NB];
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            const int r = 16 * I + li;
+            const bool ok = !MASK || r < TLD;
+            xa[I] = ok ? X[r + (4 * kb + lk) * TLD] : 0.0;
+            ya[I] = ok ? Y[r + (4 * kb + lk) * TLD] : 0.0;
+            if (NEG) ya[I] = -ya[I];
+        }
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int J = 0; J < NB; ++J)
+                acc.v[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[J], xa[I], acc.v[I][J], 0, 0, 0);
     }
     return acc;
 }
-__device__ __forceinline__ d4 tile_ld(const double* C, int li, int lk) {
-    d4 v;
+template <int TLD>
+__device__ __forceinline__ TAcc<(TLD + 15) / 16> tile_ld(const double* C, int li, int lk) {
+    constexpr int NB = (TLD + 15) / 16;
+    constexpr bool MASK = (TLD % 16) != 0;
+    TAcc<NB> a;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = C[li + (lk + 4 * r) * TL];
-    return v;
-}
-__device__ __forceinline__ void tile_st(double* C, d4 v, int li, int lk) {
+    for (int I = 0; I < NB; ++I)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) C[li + (lk + 4 * r) * TL] = v[r];
+        for (int J = 0; J < NB; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * I + li, col = 16 * J + lk + 4 * r;
+                a.v[I][J][r] = (!MASK || (row < TLD && col < TLD)) ? C[row + col * TLD] : 0.0;
+            }
+    return a;
 }
-// y[r] = sum_k M[r + k*TL] * x[k]  (or M^T), one output per lane, operands in LDS
-template <int KN, bool TRANS>
+template <int TLD>
+__device__ __forceinline__ void tile_st(double* C, const TAcc<(TLD + 15) / 16>& a, int li, int lk) {
+    constexpr int NB = (TLD + 15) / 16;
+    constexpr bool MASK = (TLD % 16) != 0;
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * I + li, col = 16 * J + lk + 4 * r;
+                if (!MASK || (row < TLD && col < TLD)) C[row + col * TLD] = a.v[I][J][r];
+            }
+}
+template <int NB>
+__device__ __forceinline__ TAcc<NB> tile_neg(TAcc<NB> a) {
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) a.v[I][J] = -a.v[I][J];
+    return a;
+}
+// adds rho to the diagonal entries (row == col < n) this lane holds
+template <int NB>
+__device__ __forceinline__ void tile_add_diag(TAcc<NB>& a, double rho, int n, int li, int lk) {
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * I + li, col = 16 * I + lk + 4 * r;
+            if (row == col && row < n) a.v[I][I][r] += rho;
+        }
+}
+// y[r] = sum_k M[r + k*TLD] * x[k]  (or M^T), one output per lane, operands in LDS
+template <int KN, bool TRANS, int TLD>
 __device__ __forceinline__ double tile_mv(const double* Mt, const double* x, int r) {
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
     for (int k = 0; k + 1 < KN; k += 2) {
-        s0 = fma(TRANS ? Mt[k + r * TL] : Mt[r + k * TL], x[k], s0);
-        s1 = fma(TRANS ? Mt[k + 1 + r * TL] : Mt[r + (k + 1) * TL], x[k + 1], s1);
+        s0 = fma(TRANS ? Mt[k + r * TLD] : Mt[r + k * TLD], x[k], s0);
+        s1 = fma(TRANS ? Mt[k + 1 + r * TLD] : Mt[r + (k + 1) * TLD], x[k + 1], s1);
     }
-    if (KN & 1) s0 = fma(TRANS ? Mt[KN - 1 + r * TL] : Mt[r + (KN - 1) * TL], x[KN - 1], s0);
+    if (KN & 1) s0 = fma(TRANS ? Mt[KN - 1 + r * TLD] : Mt[r + (KN - 1) * TLD], x[KN - 1], s0);
     return s0 + s1;
 }
+
+// Broadcast of lane K's value for the in-register Cholesky.  TL = 16: four copies of the factorisation on the four
+// DPP rows; wider tiles: lane = row over the whole wavefront, broadcasts through v_readlane (ONE matrix per
+// wave: the source lane is uniform).
+template <int TLD>
+struct KktBcast {
+    template <int K2>
+    static __device__ __forceinline__ double bcast(double v) {
+        if constexpr (TLD <= 16) return LaneGroup<16>::template bcast<K2>(v);
+        else {
+            const long long u = __double_as_longlong(v);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, K2);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), K2);
+            return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        }
+    }
+};
 
 // PIPE = 1: the whole recursion on one wavefront.  PIPE = 2: the forward pass is software-pipelined over TWO
 // wavefronts of the workgroup - wave 0 runs stage A of step t (operands -> LDS, the products with the inverse
@@ -963,9 +1046,33 @@ __device__ __forceinline__ double tile_mv(const double* Mt, const double* x, int
 // stages hand Y_ii, Y_i,i-1, L2_i, beta_i over in LDS tiles double-buffered by step parity.  A step then costs
 // max(A, B) instead of A + B; the backward pass and the recovery stay on wave 0.
 constexpr int KKT_PIPE_TILES = 27;       // 22 + second L2 tile + two Y_ii and two Y_i,i-1 hand-over tiles
+// tile leading dimension for a model: 16 (one MFMA block per tile) or 24 (2 x 2 blocks, masked)
+template <int NQ, int NU>
+constexpr int kkt_tld() { return (NQ <= 16 && NU <= 16) ? 16 : 24; }
+// doubles of LDS one recursion needs
+template <int NQ, int NU, int PIPE>
+constexpr int kkt_lds_doubles() {
+    constexpr int T = kkt_tld<NQ, NU>();
+    return (PIPE == 2 ? KKT_PIPE_TILES : KKT_MFMA_TILES) * T * T + 13 * (T <= 16 ? 16 : 32);
+}
+// longest horizon the backward pass can stage: all dnu in tiles 16..21, the recovery's first level in tiles 7..15
+template <int NQ, int NU>
+constexpr int kkt_max_h() {
+    constexpr int T = kkt_tld<NQ, NU>(), a = 6 * T * T / (T <= 16 ? 16 : 32), b = 9 * T * T / (NQ + NU);
+    return a < b ? a : b;
+}
+// rollouts per workgroup of the packed launch: as many as fit 160 KB of LDS, at most KKT_PACK
+template <int NQ, int NU>
+constexpr int kkt_pack();
+
 template <int NQ, int NU, class Sync, int PIPE = 1>
 __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, int b, double* sm, int lane, int wave = 0) {
-    static_assert(NQ <= 16 && NU <= 16, "MFMA KKT kernel handles one 16x16 tile per block");
+    static_assert(NQ <= 24 && NU <= 24, "MFMA KKT kernel: tiles of at most 24 x 24");
+    constexpr int TL = kkt_tld<NQ, NU>();            // (shadow the 16-wide defaults of the file scope)
+    constexpr int TSZ = TL * TL;
+    constexpr int NB = (TL + 15) / 16;
+    constexpr int VS = TL <= 16 ? 16 : 32;           // stride of the small vectors behind the tiles
+    using Acc = TAcc<NB>;
     constexpr int NTILES = PIPE == 2 ? KKT_PIPE_TILES : KKT_MFMA_TILES;
     // The body runs on ONE wavefront; its phases hand data over through LDS only.  The hand-off needs the
     // wave's LDS operations complete (lgkmcnt(0)) - NOT its global ones: a full barrier (vmcnt(0)) would
@@ -990,11 +1097,11 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     // tiles 19..21: extra ring slots of the backward pass
     double* vec = sm + NTILES * TSZ;
     double* bet = vec;                                     // 16 each (PIPE = 2: second parity at vec + 144)
-    double* tv = vec + 16;
-    // vec + 32/48/64: y / dnu ring
-    double* rpu = vec + 80;
-    // vec + 96/112/128: r_p(q) ring
-    for (int k = lane + 64 * wave; k < NTILES * TSZ + 208; k += 64 * PIPE) sm[k] = 0.0;
+    double* tv = vec + VS;
+    // vec + (2,3,4) VS: y / dnu ring
+    double* rpu = vec + 5 * VS;
+    // vec + (6,7,8) VS: r_p(q) ring; vec + 9 VS: second beta (PIPE = 2); vec + 12 VS: scratch word
+    for (int k = lane + 64 * wave; k < NTILES * TSZ + 13 * VS; k += 64 * PIPE) sm[k] = 0.0;
     if constexpr (PIPE == 2) __syncthreads();
     const double* rb = K.r + (size_t)b * S.N;
     const double beta = K.beta ? K.beta[b] : K.beta_scalar;
@@ -1011,7 +1118,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     // where it lands in LDS (surplus lanes write a scratch word).  The divisions by nd / nq / nu, the tile
     // selection and ~35 exec-mask branches per step would otherwise be redone for every element of every
     // step (measured: 2 k of the 14 k cycles of a step).
-    const int TRASH = NTILES * TSZ + 200;                    // scratch double behind the vectors
+    const int TRASH = NTILES * TSZ + 12 * VS;                // scratch double behind the vectors
     int dz_src[PF_DZ], dz_dst[PF_DZ], dz_rot[PF_DZ], q_src[PF_Q], q_dst[PF_Q], r_src[PF_R], r_dst[PF_R];
 #pragma unroll
     for (int j = 0; j < PF_DZ; ++j) {
@@ -1053,9 +1160,9 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         for (int j = 0; j < PF_Q; ++j) sm[q_dst[j] >= 0 ? (15 + m0) * TSZ + q_dst[j] : TRASH] = pf_q[j];
 #pragma unroll
         for (int j = 0; j < PF_R; ++j) sm[r_dst[j]] = pf_r[j];
-        // r_p: [u | q2] -> rpu (vec + 80), q ring (vec + 96 + 16 m0)
+        // r_p: [u | q2] -> rpu (vec + 5 VS), q ring (vec + (6 + m0) VS)
         const int vb = NTILES * TSZ;
-        sm[lane < nu ? vb + 80 + lane : lane < nr ? vb + 96 + 16 * m0 + (lane - nu) : TRASH] = pf_rp;
+        sm[lane < nu ? vb + 5 * VS + lane : lane < nr ? vb + (6 + m0) * VS + (lane - nu) : TRASH] = pf_rp;
     };
     // spill of a step's factors (n2 = nd^2 entries each): element k = lane + 64 j, clamped (surplus lanes
     // repeat the last element: same value, same address)
@@ -1082,18 +1189,18 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         t.L1c = tile(13 + p0); t.L1p = tile(13 + p1);
         t.A1 = tile(2 + p0); t.A1p = tile(2 + p1);
         t.Qi0 = tile(15 + m0); t.Qi1 = tile(15 + m1); t.Qi2 = tile(15 + m2);
-        t.yc = vec + 32 + 16 * m0; t.y1 = vec + 32 + 16 * m1; t.y2 = vec + 32 + 16 * m2;
-        t.q0r = vec + 96 + 16 * m0; t.q1r = vec + 96 + 16 * m1; t.q2r = vec + 96 + 16 * m2;
+        t.yc = vec + (2 + m0) * VS; t.y1 = vec + (2 + m1) * VS; t.y2 = vec + (2 + m2) * VS;
+        t.q0r = vec + (6 + m0) * VS; t.q1r = vec + (6 + m1) * VS; t.q2r = vec + (6 + m2) * VS;
         // hand-over buffers of the pipelined variant (by step parity); the one-wave variant keeps one set
         t.L2c = (PIPE == 2 && p0) ? tile(22) : L2c;
         t.Y0h = tile(23 + (PIPE == 2 ? p0 : 0));
         t.Y1h = tile(25 + (PIPE == 2 ? p0 : 0));
-        t.bet = (PIPE == 2 && p0) ? vec + 144 : bet;
+        t.bet = (PIPE == 2 && p0) ? vec + 9 * VS : bet;
         t.p0 = p0; t.m0 = m0;
         return t;
     };
-    const d4 z4 = {0.0, 0.0, 0.0, 0.0};
-    d4 y0 = z4, y1a = z4;                 // PIPE = 1: Y_ii / Y_i,i-1 accumulators stay in registers between the stages
+    const Acc z4 = tile_zero<NB>();
+    Acc y0 = z4, y1a = z4;                 // PIPE = 1: Y_ii / Y_i,i-1 accumulators stay in registers between the stages
     // ---- stage A of step i: needs factors of steps <= i-2 only --------------------------------------------
     auto stageA = [&](int i) {
         const Slots t = slots(i);
@@ -1109,33 +1216,32 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         prefetch(i + 1);
         KPROF(1)
         // ---- P2: T0 = du1 Rinv, T1 = dq1 Qinv_{i-1}, T2 = dq0 Qinv_{i-2}  (Qinv, Rinv symmetric)
-        tile_st(T0, tile_mma<KBU, false>(A0, Ri, z4, li, lk), li, lk);
-        if (i >= 1) tile_st(T1, tile_mma<KBQ, false>(A1, Qi1, z4, li, lk), li, lk);
-        if (i >= 2) tile_st(T2, tile_mma<KBQ, false>(A2, Qi2, z4, li, lk), li, lk);
+        tile_st<TL>(T0, tile_mma<KBU, false, TL>(A0, Ri, z4, li, lk), li, lk);
+        if (i >= 1) tile_st<TL>(T1, tile_mma<KBQ, false, TL>(A1, Qi1, z4, li, lk), li, lk);
+        if (i >= 2) tile_st<TL>(T2, tile_mma<KBQ, false, TL>(A2, Qi2, z4, li, lk), li, lk);
         lds_sync();
         KPROF(2)
         // ---- P3: Y_ii, Y_i,i-1, L2_i = -T2 L0_{i-2}^-T, beta_i -------------------------------
-        y0 = tile_ld(Qi0, li, lk);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (li == lk + 4 * r && li < nd) y0[r] += rho;
-        y0 = tile_mma<KBU, false>(T0, A0, y0, li, lk);
+        y0 = tile_ld<TL>(Qi0, li, lk);
+        tile_add_diag<NB>(y0, rho, nd, li, lk);
+        y0 = tile_mma<KBU, false, TL>(T0, A0, y0, li, lk);
         y1a = z4;
         if (i >= 1) {
-            y0 = tile_mma<KBQ, false>(T1, A1, y0, li, lk);
-            y1a = -tile_ld(T1, li, lk);
+            y0 = tile_mma<KBQ, false, TL>(T1, A1, y0, li, lk);
+            y1a = tile_neg<NB>(tile_ld<TL>(T1, li, lk));
         }
         if (i >= 2) {
-            y0 = tile_mma<KBQ, false>(T2, A2, y0, li, lk);
-            y1a = tile_mma<KBQ, false>(T2, A1p, y1a, li, lk);
-            tile_st(L2c, tile_mma<KBD, true>(T2, Li2, z4, li, lk), li, lk);
+            y0 = tile_mma<KBQ, false, TL>(T2, A2, y0, li, lk);
+            y1a = tile_mma<KBQ, false, TL>(T2, A1p, y1a, li, lk);
+            tile_st<TL>(L2c, tile_mma<KBD, true, TL>(T2, Li2, z4, li, lk), li, lk);
         }
         if (lane < nd) {   // beta_i = T0 rpu - Qinv_i rq_i + T1 rq_{i-1} + T2 rq_{i-2} - rd_i
-            double s = tile_mv<nu, false>(T0, rpu, lane) - tile_mv<nq, false>(Qi0, q0r, lane);
-            if (i >= 1) s += tile_mv<nq, false>(T1, q1r, lane);
-            if (i >= 2) s += tile_mv<nq, false>(T2, q2r, lane);
+            double s = tile_mv<nu, false, TL>(T0, rpu, lane) - tile_mv<nq, false, TL>(Qi0, q0r, lane);
+            if (i >= 1) s += tile_mv<nq, false, TL>(T1, q1r, lane);
+            if (i >= 2) s += tile_mv<nq, false, TL>(T2, q2r, lane);
             bet[lane] = s - rd_i;
         }
-        if constexpr (PIPE == 2) { tile_st(t.Y0h, y0, li, lk); tile_st(t.Y1h, y1a, li, lk); }
+        if constexpr (PIPE == 2) { tile_st<TL>(t.Y0h, y0, li, lk); tile_st<TL>(t.Y1h, y1a, li, lk); }
     };
     // ---- stage B of step i: L1_i, the Cholesky factor L0_i and its inverse, y_i, spill --------------------
     auto stageB = [&](int i) {
@@ -1143,33 +1249,33 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         double* const Li = t.Li; double* const Li1 = t.Li1; double* const L1c = t.L1c; double* const L1p = t.L1p;
         double* const yc = t.yc; double* const y1 = t.y1; double* const y2 = t.y2;
         double* const L2c = t.L2c; double* const bet = t.bet;
-        if constexpr (PIPE == 2) { y0 = tile_ld(t.Y0h, li, lk); y1a = tile_ld(t.Y1h, li, lk); }
+        if constexpr (PIPE == 2) { y0 = tile_ld<TL>(t.Y0h, li, lk); y1a = tile_ld<TL>(t.Y1h, li, lk); }
         // ---- P4: Y1 -= L2 L1_{i-1}^T ; stage Y1 as an operand ------------------------------
         if (i >= 1) {
-            if (i >= 2) y1a = tile_mma<KBD, true>(L2c, L1p, y1a, li, lk);
-            tile_st(Y1, y1a, li, lk);
+            if (i >= 2) y1a = tile_mma<KBD, true, TL>(L2c, L1p, y1a, li, lk);
+            tile_st<TL>(Y1, y1a, li, lk);
             lds_sync();
             // ---- P5: L1_i = Y1 L0_{i-1}^-T -----------------------------------------------------
-            tile_st(L1c, tile_mma<KBD, false>(Y1, Li1, z4, li, lk), li, lk);
+            tile_st<TL>(L1c, tile_mma<KBD, false, TL>(Y1, Li1, z4, li, lk), li, lk);
             lds_sync();
         }
         KPROF(4)
         // ---- P6: Lc = Y0 - L1 L1^T - L2 L2^T ; rhs of the forward substitution ---------------
-        if (i >= 1) y0 = tile_mma<KBD, true>(L1c, L1c, y0, li, lk);
-        if (i >= 2) y0 = tile_mma<KBD, true>(L2c, L2c, y0, li, lk);
-        tile_st(Lc, y0, li, lk);
+        if (i >= 1) y0 = tile_mma<KBD, true, TL>(L1c, L1c, y0, li, lk);
+        if (i >= 2) y0 = tile_mma<KBD, true, TL>(L2c, L2c, y0, li, lk);
+        tile_st<TL>(Lc, y0, li, lk);
         if (lane < nd) {
             double s = bet[lane];
-            if (i >= 1) s -= tile_mv<nd, false>(L1c, y1, lane);
-            if (i >= 2) s -= tile_mv<nd, false>(L2c, y2, lane);
+            if (i >= 1) s -= tile_mv<nd, false, TL>(L1c, y1, lane);
+            if (i >= 2) s -= tile_mv<nd, false, TL>(L2c, y2, lane);
             tv[lane] = s;
         }
         lds_sync();
         KPROF(5)
         // ---- P7: Cholesky of Lc and L0^-1 in registers (lane = row, DPP broadcasts) -----------
         {
-            using LG = LaneGroup<16>;
-            const int rl = li;
+            using LG = KktBcast<TL>;
+            const int rl = TL <= 16 ? li : lane;
             double a[nd], invd[nd];
             static_for<0, nd>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
@@ -1208,7 +1314,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         // ---- P8: y_i = L0^-1 tv ; spill (L1_i, L2_i, L0_i^-1, y_i) for the backward pass ------
         double yi = 0.0;
         if (lane < nd) {
-            yi = tile_mv<nd, false>(Li, tv, lane);
+            yi = tile_mv<nd, false, TL>(Li, tv, lane);
             yc[lane] = yi;
         }
         double* wsi = ws + (size_t)i * WSR;
@@ -1287,14 +1393,14 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         prefetch_b(i - 1);
         if (lane < nd) {
             double s = yb[lane];
-            if (i + 1 < H) s -= tile_mv<nd, true>(F1s1, dn_all + (i + 1) * 16, lane);
-            if (i + 2 < H) s -= tile_mv<nd, true>(F2s2, dn_all + (i + 2) * 16, lane);
+            if (i + 1 < H) s -= tile_mv<nd, true, TL>(F1s1, dn_all + (i + 1) * VS, lane);
+            if (i + 2 < H) s -= tile_mv<nd, true, TL>(F2s2, dn_all + (i + 2) * VS, lane);
             tv[lane] = s;
         }
         lds_sync();
         if (lane < nd) {
-            const double dni = tile_mv<nd, true>(FI, tv, lane);
-            dn_all[i * 16 + lane] = dni;
+            const double dni = tile_mv<nd, true, TL>(FI, tv, lane);
+            dn_all[i * VS + lane] = dni;
             D[H * nr + i * nd + lane] = dni;
         }
         lds_sync();
@@ -1305,17 +1411,17 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         double s = rb[idx];
         if (c < nu) {
             const double* a0 = dzb + ((size_t)i * nths + 2 * nq + c) * nd;
-            const double* dn0 = dn_all + i * 16;
+            const double* dn0 = dn_all + i * VS;
             double t0 = 0.0;
 #pragma unroll
             for (int k = 0; k < nd; ++k) t0 = fma(a0[k], dn0[k], t0);
             s -= t0;
         } else {
             const int cq = c - nu;
-            s += dn_all[i * 16 + cq];
+            s += dn_all[i * VS + cq];
             if (i + 1 < H) {
                 const double* a1 = dzb + ((size_t)(i + 1) * nths + nq + cq) * nd;
-                const double* dn1 = dn_all + (i + 1) * 16;
+                const double* dn1 = dn_all + (i + 1) * VS;
                 double t1 = 0.0;
 #pragma unroll
                 for (int k = 0; k < nd; ++k) t1 = fma(a1[k], dn1[k], t1);
@@ -1323,7 +1429,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
             }
             if (i + 2 < H) {
                 const double* a2 = dzb + ((size_t)(i + 2) * nths + cq) * nd;
-                const double* dn2 = dn_all + (i + 2) * 16;
+                const double* dn2 = dn_all + (i + 2) * VS;
                 double t2 = 0.0;
 #pragma unroll
                 for (int k = 0; k < nd; ++k) t2 = fma(a2[k], dn2[k], t2);
@@ -1374,25 +1480,31 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
 #endif
 constexpr int KKT_PACK = CIMPC_KKT_PACK;
 template <int NQ, int NU>
-__global__ __launch_bounds__(64 * KKT_PACK, CIMPC_KKT_PACK_WAVES_PER_SIMD) void kkt_kernel_packed(NewtonDev S, KktArgs K, const int* list, int n, const int* n_dev) {
+constexpr int kkt_pack() {
+    constexpr int fit = (160 * 1024 / 8) / kkt_lds_doubles<NQ, NU, 1>();
+    return fit < 1 ? 1 : (fit < KKT_PACK ? fit : KKT_PACK);
+}
+template <int NQ, int NU>
+__global__ __launch_bounds__((64 * kkt_pack<NQ, NU>()), (kkt_tld<NQ, NU>() <= 16 ? CIMPC_KKT_PACK_WAVES_PER_SIMD : 1)) void kkt_kernel_packed(NewtonDev S, KktArgs K, const int* list, int n, const int* n_dev) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     if (n_dev != nullptr) n = *n_dev;        // rounds enqueued ahead of the host: the count is only known on the device
-    const int wave = (int)threadIdx.x >> 6, slot = (int)blockIdx.x * KKT_PACK + wave;
+    const int wave = (int)threadIdx.x >> 6, slot = (int)blockIdx.x * kkt_pack<NQ, NU>() + wave;
     if (slot >= n) return;
-    kkt_body<NQ, NU, WaveSync>(S, K, list[slot], sm + (size_t)wave * (KKT_MFMA_TILES * TSZ + 208), (int)threadIdx.x & 63);
+    kkt_body<NQ, NU, WaveSync>(S, K, list[slot], sm + (size_t)wave * kkt_lds_doubles<NQ, NU, 1>(), (int)threadIdx.x & 63);
 }
 
 // Pipelined launch: one rollout per workgroup of two wavefronts (kkt_body<..., PIPE = 2>), from the compact list.
 template <int NQ, int NU>
-__global__ __launch_bounds__(128, 2) void kkt_kernel_pipe(NewtonDev S, KktArgs K, const int* list, int n, const int* n_dev) {
+__global__ __launch_bounds__(128, (kkt_tld<NQ, NU>() <= 16 ? 2 : 1)) void kkt_kernel_pipe(NewtonDev S, KktArgs K, const int* list, int n, const int* n_dev) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     if (n_dev != nullptr) n = *n_dev;
     if ((int)blockIdx.x >= n) return;
     kkt_body<NQ, NU, WaveSync, 2>(S, K, list[blockIdx.x], sm, (int)threadIdx.x & 63, (int)threadIdx.x >> 6);
 }
 
+// (wide tiles: 105 KB of LDS allow one workgroup per CU anyway - let it use the 512-register budget)
 template <int NQ, int NU>
-__global__ __launch_bounds__(64, 2) void kkt_kernel(NewtonDev S, KktArgs K) {
+__global__ __launch_bounds__(64, (kkt_tld<NQ, NU>() <= 16 ? 2 : 1)) void kkt_kernel(NewtonDev S, KktArgs K) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int b = blockIdx.x + S.b0;
     if (K.stage != nullptr && K.stage[b] != STAGE_KKT) return;

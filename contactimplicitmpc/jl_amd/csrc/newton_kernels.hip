@@ -73,10 +73,12 @@ __global__ __launch_bounds__(256) void reset_kernel(NewtonDev S, const double* q
 
 template <int NQ, int NU>
 static int launch_kkt_t(const NewtonDev& S, const KktArgs& K, hipStream_t s) {
-    if (NQ <= 16 && NU <= 16 && S.dm.H <= 96) {     // dnu / recovery staging of the MFMA kernel holds H <= 96 steps
-        const size_t lds = (size_t)(KKT_MFMA_TILES * TSZ + 208) * sizeof(double);
-        if constexpr (NQ <= 16 && NU <= 16)
-            hipLaunchKernelGGL((kkt_kernel<NQ, NU>), dim3(S.nb_launch), dim3(64), lds, s, S, K);
+    static const bool force_scalar = getenv("CIMPC_KKT_SCALAR") && atoi(getenv("CIMPC_KKT_SCALAR")) != 0;
+    if (NQ <= 24 && NU <= 24 && S.dm.H <= kkt_max_h<NQ, NU>() && !force_scalar) {   // dnu / recovery staging bounds H
+        const size_t lds = (size_t)kkt_lds_doubles<NQ, NU, 1>() * sizeof(double);
+        static LdsOptIn optin;
+        if (lds_opt_in(optin, (const void*)kkt_kernel<NQ, NU>, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
+        hipLaunchKernelGGL((kkt_kernel<NQ, NU>), dim3(S.nb_launch), dim3(64), lds, s, S, K);
     } else {
         constexpr int LD = ((NQ > NU ? NQ : NU) + 3) & ~3;
         const size_t lds = (size_t)(KKT_TILES * LD * LD + 10 * LD) * sizeof(double);
@@ -207,8 +209,9 @@ int launch_resid_decide(const NewtonDev& S, hipStream_t s) {
 }
 template <int NQ, int NU>
 static int launch_kkt_packed_t(const NewtonDev& S, const KktArgs& K, const int* list, int n, const int* n_dev, hipStream_t s, bool latency) {
-    if constexpr (NQ <= 16 && NU <= 16) {
-        const size_t lds = (size_t)KKT_PACK * (KKT_MFMA_TILES * TSZ + 208) * sizeof(double);
+    if constexpr (NQ <= 24 && NU <= 24) {
+        constexpr int PACK = kkt_pack<NQ, NU>();
+        const size_t lds = (size_t)PACK * kkt_lds_doubles<NQ, NU, 1>() * sizeof(double);
         static LdsOptIn optin;
         if (lds_opt_in(optin, (const void*)kkt_kernel_packed<NQ, NU>, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
         // CIMPC_KKT_PIPE: 0 never, 1 always, unset = where the KKT solve is on the critical path (`latency`: small
@@ -216,13 +219,13 @@ static int launch_kkt_packed_t(const NewtonDev& S, const KktArgs& K, const int* 
         // for half the time - measured neutral - so the packed one-wave kernel stays there.
         static const int pipe_env = getenv("CIMPC_KKT_PIPE") ? atoi(getenv("CIMPC_KKT_PIPE")) : 2;
         if (pipe_env == 1 || (pipe_env == 2 && latency)) {      // two wavefronts per rollout, software-pipelined forward recursion
-            const size_t lds2 = (size_t)(KKT_PIPE_TILES * TSZ + 208) * sizeof(double);
+            const size_t lds2 = (size_t)kkt_lds_doubles<NQ, NU, 2>() * sizeof(double);
             static LdsOptIn optin2;
             if (lds_opt_in(optin2, (const void*)kkt_kernel_pipe<NQ, NU>, lds2) != CIMPC_OK) return CIMPC_ERR_HIP;
             hipLaunchKernelGGL((kkt_kernel_pipe<NQ, NU>), dim3(n), dim3(128), lds2, s, S, K, list, n, n_dev);
             return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
         }
-        hipLaunchKernelGGL((kkt_kernel_packed<NQ, NU>), dim3((n + KKT_PACK - 1) / KKT_PACK), dim3(64 * KKT_PACK), lds, s, S, K, list, n, n_dev);
+        hipLaunchKernelGGL((kkt_kernel_packed<NQ, NU>), dim3((n + PACK - 1) / PACK), dim3(64 * PACK), lds, s, S, K, list, n, n_dev);
         return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
     }
     return CIMPC_ERR_INVALID;
@@ -232,12 +235,14 @@ int launch_kkt_packed(const NewtonDev& S, int n_kkt, int list_par, hipStream_t s
     const int nq = S.dm.nq, nu = S.dm.nu;
     if (n_dev != nullptr) n_kkt = S.dm.B;      // upper bound of the grid; surplus workgroups leave at once
     if (n_kkt <= 0) return CIMPC_OK;
-    if (S.kkt_list == nullptr || S.dm.mode != CIMPC_MODE_CONFIGURATION || nq > 16 || nu > 16 || S.dm.H > 96) return launch_kkt(S, s);
+    static const bool force_scalar = getenv("CIMPC_KKT_SCALAR") && atoi(getenv("CIMPC_KKT_SCALAR")) != 0;
+    if (S.kkt_list == nullptr || S.dm.mode != CIMPC_MODE_CONFIGURATION || nq > 24 || nu > 24 || S.dm.H > 96 || force_scalar) return launch_kkt(S, s);
     const KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 1};
     const int* list = S.kkt_list + (size_t)list_par * S.dm.B;
     if (nq == 2 && nu == 2) return launch_kkt_packed_t<2, 2>(S, K, list, n_kkt, n_dev, s, latency);
     if (nq == 4 && nu == 2) return launch_kkt_packed_t<4, 2>(S, K, list, n_kkt, n_dev, s, latency);
     if (nq == 11 && nu == 8) return launch_kkt_packed_t<11, 8>(S, K, list, n_kkt, n_dev, s, latency);
+    if (nq == 18 && nu == 12) return launch_kkt_packed_t<18, 12>(S, K, list, n_kkt, n_dev, s, latency);
     return launch_kkt(S, s);
 }
 int launch_kkt(const NewtonDev& S, hipStream_t s) {

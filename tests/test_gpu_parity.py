@@ -83,7 +83,7 @@ def test_newton_solve_matches_oracle(gpu_required):
 
 @pytest.mark.parametrize("model,H,H_ref,dense_q", [
     ("hopper", 20, 24, False),       # BASELINE configs[1]: hopper flat, H = 20
-    ("centroidal", 6, 8, True),      # nq = 18 > 16: scalar (non-MFMA) KKT kernel, dense Q (relative_state_cost)
+    ("centroidal", 6, 8, True),      # nq = 18 > 16: 24 x 24 KKT tiles, dense Q (relative_state_cost)
 ])
 def test_newton_solve_other_models(gpu_required, model, H, H_ref, dense_q):
     u1, it, rn, traj, cnt, res = _newton_case(perturb=5e-3, r_tol=1e-5, max_iter=4, seed=23, B=4, H=H, H_ref=H_ref,
@@ -147,24 +147,30 @@ def test_implicit_dynamics_stress(gpu_required):
     assert its.max() >= 9          # the instances really are harder than the nominal 5-6 iterations
 
 
-def test_kkt_solve_matches_dense_lu(gpu_required):
+@pytest.mark.parametrize("model,H,H_ref", [
+    ("quadruped", 8, 10),           # 16 x 16 MFMA tiles
+    ("centroidal", 8, 10),          # nq = 18: 24 x 24 tiles (2 x 2 masked MFMA blocks), readlane Cholesky
+    ("centroidal", 60, 71),         # BASELINE configs[4] horizon: the backward pass's staging at H = 60
+])
+def test_kkt_solve_matches_dense_lu(gpu_required, model, H, H_ref):
     """B1 seam: the condensed device solve against numpy's dense LU of the assembled R
     (the reference default :lu_solver)."""
-    H, H_ref, B = 8, 10, 4
-    d, prob, tabs, rollouts = make_case("quadruped", 0, H_ref=H_ref, H=H, B=B, seed=5)
+    B = 4 if H <= 8 else 2
+    d, prob, tabs, rollouts = make_case(model, 0, H_ref=H_ref, H=H, B=B, seed=5)
     obj = synth.make_objective(d, H, dense_q=True)
     s = make_solver(d, prob, rollouts, H, obj=obj)
-    opts = oip.IPOptions(kappa_tol=prob["kappa"])
-    ref = oracle_sweep(d, tabs, rollouts, opts)
-    q = np.stack([tr.q for tr, _ in ref]); th = np.stack([tr.theta for tr, _ in ref])
-    s.implicit_dynamics(q, th)          # leaves the sensitivities resident on the device
+    q = np.stack([r.q for (_, r, _, _) in rollouts]); th = np.stack([r.theta for (_, r, _, _) in rollouts])
+    out = s.implicit_dynamics(q, th)    # leaves the sensitivities resident on the device
+    assert out["status"].all()
     lay = onewton.Layout(d, H)
     rng = np.random.default_rng(0)
     r = rng.standard_normal((B, lay.N))
     for beta in (1e-5, 10.0):
         delta = s.kkt_solve(r, beta)
-        for b, (tr, o) in enumerate(ref):
-            R = onewton.jacobian(lay, obj, o, beta, prob["kappa"])
+        for b in range(B):
+            # R from the DEVICE's own sensitivities: isolates the linear solve from the interior-point parity
+            im = {k: out[k][b] for k in ("d", "dq0", "dq1", "du1")}
+            R = onewton.jacobian(lay, obj, im, beta, prob["kappa"])
             x = np.linalg.solve(R, r[b])
             np.testing.assert_allclose(delta[b], x, rtol=0, atol=1e-7 * max(1.0, np.abs(x).max()))
 
