@@ -1,0 +1,51 @@
+"""Real reference problems for the tests: the reference's gait files (tests/golden/gaits/*.jld2 - data files of the
+reference: src/dynamics/quadruped/gaits/gait2.jld2 is the input of test/controller/implicit_dynamics.jl and
+test/controller/mpc_quadruped.jl; examples/centroidal_quadruped/reference/inplace_trot_v7.jld2 of
+examples/centroidal_quadruped/continuous_trot.jl) through the model restatements of
+contactimplicitmpc/jl_amd/lcp_models.py."""
+import functools
+import os
+
+import numpy as np
+
+from oracle import lcp
+from oracle.dims import Dims
+from oracle.newton import Traj
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GAITS = {
+    "quadruped": ("quadruped", os.path.join(HERE, "golden", "gaits", "quadruped_gait2.jld2")),
+    "centroidal": ("centroidal_quadruped", os.path.join(HERE, "golden", "gaits", "centroidal_inplace_trot_v7.jld2")),
+}
+
+
+@functools.lru_cache(maxsize=None)
+def real_problem(which: str, kappa: float):
+    """-> (Dims, ReferenceProblem, prob dict in the layout of oracle.synth.make_problem, LinTables)."""
+    from contactimplicitmpc.jl_amd import gait_io, lcp_models
+    name, path = GAITS[which]
+    model = lcp_models.MODELS[name]()
+    P = lcp_models.reference_problem(model, gait_io.load_gait(path), kappa)
+    d = Dims(nq=model.nq, nu=model.nu, nw=model.nw, nc=model.nc, nb=model.nb)
+    prob = dict(z0=P.z, th0=P.theta, r0=P.r0, rz0=P.rz0, rth0=P.rth0, kappa=kappa, q_ref=P.q, u_ref=P.u, w_ref=P.w,
+                gamma_ref=P.gamma, b_ref=P.b, stride=lcp_models.get_stride(model, P.q))
+    tabs = [lcp.LinTable(d, P.z[t], P.theta[t], P.r0[t], P.rz0[t], P.rth0[t]) for t in range(P.H)]
+    return d, P, prob, tabs
+
+
+def real_rollout(d: Dims, prob, H: int, phase: int, seed: int, perturb: float = 0.0, vel_perturb: float = 0.05):
+    """One rollout on the real gait: window = knots phase .. phase+H+1 (periodic, with the gait's stride added on
+    wrap-around - rot_n_stride!, mpc_utils.jl:48-101), (q0, q1) = reference + a shared U(-perturb, perturb) offset
+    (examples/quadruped/monte_carlo.jl:79-91 perturbs the initial configuration)."""
+    H_ref = prob["u_ref"].shape[0]
+    window = (phase + np.arange(H + 2)) % H_ref
+    q = np.stack([prob["q_ref"][(phase + i) % H_ref] + ((phase + i) // H_ref) * prob["stride"] for i in range(H + 2)])
+    kn = window[:H]
+    ref = Traj(q=q, u=prob["u_ref"][kn].copy(), w=prob["w_ref"][kn].copy(), gamma=prob["gamma_ref"][kn].copy(),
+               b=prob["b_ref"][kn].copy(), theta=prob["th0"][kn].copy())
+    ref.update_theta(d)
+    rng = np.random.default_rng(seed)
+    dq = rng.uniform(-perturb, perturb, d.nq)
+    q0 = q[0] + dq
+    q1 = q[1] + dq + vel_perturb * rng.uniform(-perturb, perturb, d.nq)
+    return window, ref, q0, q1

@@ -1,0 +1,74 @@
+"""GPU parity on the REAL reference problems: the reference's gait files through the model
+restatements (contactimplicitmpc/jl_amd/lcp_models.py) into the C-ABI path, against the oracle on the same inputs."""
+import numpy as np
+import pytest
+
+from common import make_solver, oracle_sweep
+from oracle import ip as oip
+from oracle import newton as onewton, synth
+from real_problems import real_problem, real_rollout
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_implicit_dynamics_test_on_device(gpu_required):
+    """test/controller/implicit_dynamics.jl:7-24 through the device: every knot of quadruped gait2 (60 knots as
+    two windows of 30 + wrap-around ones), |dq2|_inf < 1e-2, and agreement with the oracle."""
+    d, P, prob, tabs = real_problem("quadruped", 1e-4)
+    H = 30
+    rollouts = [real_rollout(d, prob, H, phase, seed=0) for phase in (0, 30, 45, 59)]
+    from contactimplicitmpc.jl_amd import InteriorPointOptions
+    s = make_solver(d, prob, rollouts, H, ip_opts=InteriorPointOptions(kappa_tol=2e-4, r_tol=1e-8))
+    ref = oracle_sweep(d, tabs, rollouts, oip.IPOptions(kappa_tol=2e-4, r_tol=1e-8))
+    q = np.stack([tr.q for tr, _ in ref]); th = np.stack([tr.theta for tr, _ in ref])
+    out = s.implicit_dynamics(q, th, want_z=True)
+    assert out["status"].all()
+    assert np.abs(out["d"]).max() < 1e-2
+    for b, (tr, o) in enumerate(ref):
+        same = out["iters"][b] == o["iters"]
+        assert same.mean() >= 0.9
+        np.testing.assert_allclose(out["d"][b][same], o["d"][same], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(out["z"][b][same], o["z"][same], rtol=0, atol=1e-7)
+        for k in ("dq0", "dq1", "du1"):
+            np.testing.assert_allclose(out[k][b][same], o[k][same], rtol=0, atol=1e-7 * max(1.0, np.abs(o[k]).max()))
+
+
+@pytest.mark.parametrize("which,kappa,H,B,perturb,ip_rtol,n_rtol", [
+    ("quadruped", 2e-4, 40, 8, 0.05, 1e-8, 3e-4),       # BASELINE configs[2/3] on the true problem (mpc_quadruped.jl:19-47)
+    ("centroidal", 1e-3, 50, 4, 0.02, 1e-4, 3e-5),      # continuous_trot.jl:31-73 (H_mpc = 50; tracking part of the objective)
+])
+def test_newton_solve_on_real_problems(gpu_required, which, kappa, H, B, perturb, ip_rtol, n_rtol):
+    from contactimplicitmpc.jl_amd import InteriorPointOptions, NewtonOptions, lcp_models
+    d, P, prob, tabs = real_problem(which, kappa)
+    H_ref = P.H
+    rng = np.random.default_rng(4)
+    rollouts = [real_rollout(d, prob, H, int(rng.integers(0, H_ref)), seed=10 + b, perturb=perturb) for b in range(B)]
+    if which == "quadruped":
+        obj = synth.make_objective(d, H, kind="quadruped")
+    else:
+        obj = synth.make_objective(d, H, kind="quadruped")
+        # the example's body-x weight is 0 (Q singular along a common x shift; its velocity term restores definiteness,
+        # continuous_trot.jl:43-47) - the tracking-only objective of this test weights body x like y and z
+        obj.q = np.tile(lcp_models.relative_state_cost([1.0, 1, 1], 3e-1 * np.ones(3), [0.2, 0.2, 1.0])[None], (H, 1, 1))
+        obj.u = np.tile((3e-3 * np.eye(d.nu))[None], (H, 1, 1))
+        obj.__post_init__()
+    s = make_solver(d, prob, rollouts, H, obj=obj, ip_opts=InteriorPointOptions(kappa_tol=kappa, r_tol=ip_rtol),
+                    newton_opts=NewtonOptions(kappa=kappa, r_tol=n_rtol, max_iter=5))
+    u1, it, rn = s.newton_solve(np.stack([r[2] for r in rollouts]), np.stack([r[3] for r in rollouts]))
+    traj = s.trajectory()
+    cnt = s.rollout_counters()
+    same = 0
+    for b, (window, ref, q0, q1) in enumerate(rollouts):
+        core = onewton.Newton(d, H, obj, onewton.NewtonOptions(r_tol=n_rtol, max_iter=5, solver="condensed"),
+                              oip.IPOptions(kappa_tol=kappa, r_tol=ip_rtol), kappa, ref)
+        st = onewton.newton_solve(core, q0, q1, window, tabs, ref)
+        assert it[b] == st.iters, (b, it[b], st.iters)
+        if cnt["ip_iters"][b] == st.ip_iters and cnt["sweeps"][b] == st.sweeps:
+            same += 1
+            np.testing.assert_allclose(traj["q"][b], core.traj.q, rtol=0, atol=1e-7)
+            np.testing.assert_allclose(traj["u"][b], core.traj.u, rtol=0, atol=1e-5 * max(1.0, np.abs(core.traj.u).max()))
+            np.testing.assert_allclose(traj["nu"][b], core.nu, rtol=0, atol=1e-5 * max(1.0, np.abs(core.nu).max()))
+            # the residual norm amplifies the 1e-7-level trajectory differences by the real sensitivities
+            np.testing.assert_allclose(rn[b], st.r_norm / core.lay.N, rtol=2e-2, atol=1e-12)
+    assert same >= B - 1, (same, B)
+    assert it.max() >= 1

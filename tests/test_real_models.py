@@ -1,0 +1,157 @@
+"""Real-model inputs for the path: the gait-file reader and the model restatements of
+contactimplicitmpc/jl_amd/{gait_io,lcp_models}.py, pinned by the reference's own DATA and TESTS:
+
+  * the shipped gaits satisfy the restated variational dynamics (quadruped gait2: 1e-5; centroidal in-place trot with
+    the undamped model: round-off) - the files were produced by the reference's models, so this pins M, C, B, J, the
+    integrator and the z / θ packing;
+  * test/controller/linearized_solver.jl:23-67 re-stated on the TRUE hopper_2D residual (random z0, θ0 as there);
+  * test/controller/implicit_dynamics.jl:7-24 re-stated: quadruped gait2, ImplicitTrajectory at κ = 1e-4,
+    κ_tol = 2e-4, r_tol = 1e-8  ->  |dq2|_inf < 1e-2 at every knot.  This runs the oracle's interior point on the
+    real linearizations and is the reference's known-answer test for the implicit dynamics.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from contactimplicitmpc.jl_amd import gait_io, lcp_models
+from oracle import ip as oip
+from oracle import lcp, newton as onewton, synth
+from oracle.dims import Dims
+from real_problems import GAITS, real_problem, real_rollout
+
+
+def test_jld2_reader_reads_the_split_traj_alt_fields():
+    g = gait_io.load_gait(GAITS["quadruped"][1])
+    assert (g.H, g.q.shape, g.u.shape, g.gamma.shape, g.b.shape, g.psi.shape, g.eta.shape) == \
+        (60, (62, 11), (60, 8), (60, 4), (60, 8), (60, 4), (60, 8))
+    assert g.h == 0.015625174962268267 and g.mu == 0.5          # values recorded in SURVEY.md section 8c-6
+    c = gait_io.load_gait(GAITS["centroidal"][1])
+    assert (c.H, c.q.shape, c.u.shape, c.b.shape, c.h, c.mu) == (71, (73, 18), (71, 12), (71, 16), 0.01, 0.3)
+    # body height of the in-place trot reference (examples/centroidal_quadruped/reference: body_height = 0.3 -> settles)
+    assert 0.2 < c.q[0, 2] < 0.35 and np.all(np.isfinite(c.q))
+    raw = gait_io.read_jld2(GAITS["quadruped"][1])
+    assert set(raw) >= {"qm", "um", "γm", "bm", "ψm", "ηm", "μm", "hm"}
+
+
+def test_jld2_reader_rejects_other_files(tmp_path):
+    p = tmp_path / "x.jld2"
+    p.write_bytes(b"not a gait file" * 100)
+    with pytest.raises(gait_io.GaitFormatError):
+        gait_io.read_jld2(p)
+
+
+def _dyn_residual(model, g, kappa=1e-4):
+    out = []
+    for t in range(g.H):
+        z = model.pack_z(g.q[t + 2], g.gamma[t], g.b[t], g.psi[t], g.eta[t])
+        th = model.pack_theta(g.q[t], g.q[t + 1], g.u[t], np.zeros(model.nw), g.mu, g.h)
+        out.append(model.residual(torch.as_tensor(z), torch.as_tensor(th), torch.tensor(kappa, dtype=torch.float64)).numpy())
+    return np.array(out)
+
+
+def test_shipped_gaits_satisfy_the_restated_dynamics():
+    g = gait_io.load_gait(GAITS["quadruped"][1])
+    m = lcp_models.Quadruped()
+    r = _dyn_residual(m, g)
+    assert np.abs(r[:, :m.nq]).max() < 2e-5                       # trajectory-optimiser tolerance of the file
+    assert np.abs(r[:, m.nq:m.nq + m.nc]).max() < 1e-12           # s1 = ϕ(q2) by construction of pack_z
+    c = gait_io.load_gait(GAITS["centroidal"][1])
+    mu = lcp_models.CentroidalQuadrupedUndamped()
+    ru = _dyn_residual(mu, c, 1e-3)
+    assert np.abs(ru[:, :mu.nq]).max() < 5e-6                     # optimiser tolerance of the file (feet rows: 1e-10)
+    # the damped model of the example differs by exactly the joint-friction term  -h c (q2 - q1) / h
+    md = lcp_models.CentroidalQuadruped()
+    rd = _dyn_residual(md, c, 1e-3)
+    fr = np.stack([-(md.joint_friction().numpy()) * (c.q[t + 2] - c.q[t + 1]) for t in range(c.H)])
+    np.testing.assert_allclose(rd[:, :md.nq] - ru[:, :mu.nq], fr, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["hopper_2D", "quadruped", "centroidal_quadruped"])
+def test_exact_derivatives_and_block_structure(name):
+    m = lcp_models.MODELS[name]()
+    rng = np.random.default_rng(1)
+    z = rng.uniform(0.1, 1.0, m.nz)
+    th = rng.uniform(0.1, 1.0, m.nth)
+    r0, rz0, rth0 = m.linearize(z, th, 1e-4)
+    f = lambda zz, tt: m.residual(torch.as_tensor(zz), torch.as_tensor(tt), torch.tensor(1e-4, dtype=torch.float64)).numpy()
+    eps = 1e-6
+    Jz = np.stack([(f(z + eps * e, th) - f(z - eps * e, th)) / (2 * eps) for e in np.eye(m.nz)], 1)
+    Jt = np.stack([(f(z, th + eps * e) - f(z, th - eps * e)) / (2 * eps) for e in np.eye(m.nth)], 1)
+    assert np.abs(Jz - rz0).max() < 1e-7 * max(1.0, np.abs(rz0).max())
+    assert np.abs(Jt - rth0).max() < 1e-7 * max(1.0, np.abs(rth0).max())
+    # [Dx Dy1 0; Rx Ry1 diag(Ry2); 0 diag(y2) diag(y1)]  (linearized_solver.jl:167-169), Ry2 = 1, rθ0[ibil, :] = 0
+    d = Dims(nq=m.nq, nu=m.nu, nw=m.nw, nc=m.nc, nb=m.nb)
+    ix, iy1, iy2 = d.ix, d.iy1, d.iy2
+    assert np.abs(rz0[np.ix_(ix, iy2)]).max() == 0.0
+    np.testing.assert_array_equal(rz0[np.ix_(iy1, iy2)], np.eye(d.ny))
+    assert np.abs(rz0[np.ix_(iy2, ix)]).max() == 0.0
+    np.testing.assert_allclose(rz0[np.ix_(iy2, iy1)], np.diag(z[iy2]), rtol=0, atol=1e-15)
+    np.testing.assert_allclose(rz0[np.ix_(iy2, iy2)], np.diag(z[iy1]), rtol=0, atol=1e-15)
+    assert np.abs(rth0[iy2, :]).max() == 0.0
+
+
+def test_reference_linearized_solver_test_on_the_true_hopper():
+    """test/controller/linearized_solver.jl:23-67 with the hopper_2D residual itself (z0, θ0 = rand)."""
+    m = lcp_models.Hopper2D()
+    d = Dims(nq=m.nq, nu=m.nu, nw=m.nw, nc=m.nc, nb=m.nb)
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        z0, th0, kappa = rng.random(m.nz), rng.random(m.nth), 1e-4
+        r0, rz0, rth0 = m.linearize(z0, th0, kappa)
+        tab = lcp.LinTable(d, z0, th0, r0, rz0, rth0)
+        ix, iy1, iy2 = d.ix, d.iy1, d.iy2
+        for blk, ref in ((tab.Dx, rz0[np.ix_(ix, ix)]), (tab.Dy1, rz0[np.ix_(ix, iy1)]), (tab.Rx, rz0[np.ix_(iy1, ix)]),
+                         (tab.Ry1, rz0[np.ix_(iy1, iy1)]), (tab.Ry2, np.diag(rz0[np.ix_(iy1, iy2)])),
+                         (tab.y2, np.diag(rz0[np.ix_(iy2, iy1)])), (tab.y1, np.diag(rz0[np.ix_(iy2, iy2)]))):
+            assert np.abs(blk - ref).max() < 1e-10                       # test :35-41
+        lcp.rzlin(tab, z0)
+        rdyn, rrst, rbil = lcp.rlin(tab, z0, th0, kappa)
+        assert np.abs(r0[ix] - rdyn).max() < 1e-10 and np.abs(r0[iy1] - rrst).max() < 1e-10 \
+            and np.abs(r0[iy2] - rbil).max() < 1e-10                      # test :47-49
+        Delta = lcp.linear_solve_vec(tab, rdyn, rrst, rbil)
+        x = np.linalg.solve(rz0, r0)
+        assert np.abs(Delta - x).max() < 1e-10 * max(1.0, np.abs(x).max())   # test :52-54
+        assert np.abs(rth0[iy2, :]).max() < 1e-10                           # test :58
+        dz = lcp.linear_solve_mat(tab)
+        X = np.linalg.solve(rz0, rth0)
+        assert np.abs(dz - X).max() < 1e-10 * max(1.0, np.abs(X).max())     # test :63-67
+
+
+def test_reference_implicit_dynamics_test_on_gait2():
+    """test/controller/implicit_dynamics.jl:7-24: implicit_dynamics!(im_traj, ref_traj) on quadruped gait2 keeps
+    |dq2|_inf < 1e-2 at every knot (κ = 1e-4 linearization, κ_tol = 2e-4, r_tol = 1e-8)."""
+    d, P, prob, tabs = real_problem("quadruped", 1e-4)
+    opts = oip.IPOptions(kappa_tol=2e-4, r_tol=1e-8)
+    out = oip.implicit_dynamics(d, tabs, np.arange(P.H + 2), P.q, P.theta, opts)
+    assert out["status"].all()
+    worst = np.abs(out["d"]).max(axis=1)
+    assert np.all(worst[:P.H - 1] < 1e-2), worst.max()
+    assert worst.max() > 1e-4           # not trivially zero: κ relaxation + file tolerance move q2 by ~1e-3
+    assert 3 <= out["iters"].min() and out["iters"].max() <= 10
+    # the centroidal example configuration (continuous_trot.jl:40,60-66: κ_mpc = 1e-3, r_tol = 1e-4) behaves the same
+    d2, P2, prob2, tabs2 = real_problem("centroidal", 1e-3)
+    out2 = oip.implicit_dynamics(d2, tabs2, np.arange(P2.H + 2), P2.q, P2.theta, oip.IPOptions(kappa_tol=1e-3, r_tol=1e-4))
+    assert out2["status"].all() and np.abs(out2["d"]).max() < 1e-2
+
+
+def test_newton_solve_on_the_real_quadruped_problem():
+    """The MPC step of test/controller/mpc_quadruped.jl:19-47 (objective :23-27, κ_mpc = 2e-4, r_tol 3e-4, max_iter 5)
+    on the true linearizations: at the reference the first residual is already below tolerance (no Newton step); a
+    perturbed initial configuration takes a few."""
+    d, P, prob, tabs = real_problem("quadruped", 2e-4)
+    H = 40
+    obj = synth.make_objective(d, H, kind="quadruped")
+    N = H * (d.nr + d.nd)
+    its = []
+    for perturb, phase in ((0.0, 0), (0.0, 37), (0.05, 13), (0.05, 30)):
+        window, ref, q0, q1 = real_rollout(d, prob, H, phase, seed=phase, perturb=perturb)
+        core = onewton.Newton(d, H, obj, onewton.NewtonOptions(r_tol=3e-4, max_iter=5, solver="condensed"),
+                              oip.IPOptions(kappa_tol=2e-4), 2e-4, ref)
+        st = onewton.newton_solve(core, q0, q1, window, tabs, ref)
+        assert st.ip_fail == 0
+        its.append(st.iters)
+        if perturb == 0.0:
+            assert st.iters == 0 and st.r_norm / N < 3e-4          # phase 37 wraps around the gait: stride handling
+    assert max(its) >= 1
