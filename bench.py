@@ -134,6 +134,50 @@ def mpc_loop_latency(dims, kind, H, H_ref, device, steps=40):
     return {"ms_per_mpc_step": 1e3 * dt / steps, "mpc_steps_per_s": steps / dt, "newton_iters_per_step": its / steps}
 
 
+def real_problem_leg(B, H, device, steps=5, perturb=0.05):
+    """The same Monte-Carlo batch on the REAL quadruped problem: the reference's gait file (gait2.jld2, a data file
+    of the reference kept under tests/golden/gaits) linearized through the model restatement of
+    contactimplicitmpc/jl_amd/lcp_models.py, objective of test/controller/mpc_quadruped.jl:23-27, kappa_mpc = 2e-4,
+    initial configurations perturbed by U(-perturb, perturb) (examples/quadruped/monte_carlo.jl:79-91)."""
+    import torch
+    from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions, gait_io, lcp_models
+    m = lcp_models.Quadruped()
+    kappa = 2e-4
+    t0 = time.perf_counter()
+    P = lcp_models.reference_problem(m, gait_io.load_gait(os.path.join(ROOT, "tests", "golden", "gaits", "quadruped_gait2.jld2")), kappa)
+    t_lin = time.perf_counter() - t0
+    ro = [lcp_models.make_rollout(P, H, int(np.random.default_rng(7919 + g).integers(0, P.H)), seed=100003 + g, perturb=perturb)
+          for g in range(B)]
+    qd = 1e-2 * np.concatenate([[1.0, 0.02, 0.25], 0.25 * np.ones(m.nq - 3)])
+    s = CIMPCSolver(m.nq, m.nu, m.nw, m.nc, m.nb, P.H, H, B=B, mode=0, ip_opts=InteriorPointOptions(kappa_tol=kappa),
+                    newton_opts=NewtonOptions(kappa=kappa, r_tol=3e-4, max_iter=5), device=device)
+    for t in range(P.H):
+        s.set_linearization(t + 1, P.z[t], P.theta[t], P.r0[t], P.rz0[t], P.rth0[t])
+    s.set_objective(np.tile(np.diag(qd)[None], (H, 1, 1)), np.tile((3e-2 * np.eye(m.nu))[None], (H, 1, 1)))
+    s.set_window(np.stack([r["window"] for r in ro]) + 1)
+    s.set_reference(*(np.stack([r[k] for r in ro]) for k in ("q", "u", "w", "gamma", "b", "theta")))
+    q0 = torch.tensor(np.stack([r["q0"] for r in ro]), dtype=torch.float64, device="cuda")
+    q1 = torch.tensor(np.stack([r["q1"] for r in ro]), dtype=torch.float64, device="cuda")
+    s.newton_solve_dev(q0.data_ptr(), q1.data_ptr(), warm_start=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    acc = dict(newton_iters=0, sweeps=0, ip_solves=0, ip_iters=0, ip_failures=0)
+    for _ in range(steps):
+        s.newton_solve_dev(q0.data_ptr(), q1.data_ptr(), warm_start=False)
+        st = s.stats()
+        for k in acc:
+            acc[k] += st[k]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    s.close()
+    return {"workload": "quadruped gait2.jld2 (reference data file), true model linearization, H=%d, %d rollouts, "
+                        "U(-%.2f, %.2f) initial-configuration offsets, cold start" % (H, B, perturb, perturb),
+            "value": B / dt, "unit": "MPC steps/s", "ms_per_step": 1e3 * dt,
+            "newton_iters_per_step": acc["newton_iters"] / (steps * B), "sweeps_per_step": acc["sweeps"] / (steps * B),
+            "ip_iters_per_solve": acc["ip_iters"] / max(acc["ip_solves"], 1), "ip_failures_per_step": acc["ip_failures"] / steps,
+            "linearization_build_s": t_lin}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +188,7 @@ def main():
     ap.add_argument("--perturb", type=float, default=0.05)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency", action="store_true", help="also time the B = 1 single-rollout loop")
+    ap.add_argument("--no-real-problem", action="store_true", help="skip the leg on the real quadruped gait")
     args = ap.parse_args()
 
     import torch
@@ -281,6 +326,11 @@ def main():
         # plant: q1_next = planned q_3), reference / window advanced on the device (cimpc_mpc_advance)
         out["mpc_loop_b1"] = {"quadruped_h40": mpc_loop_latency(QUADRUPED, "quadruped", 40, 60, local_rank),
                               "hopper_h20 (BASELINE configs[1])": mpc_loop_latency(dict(nq=4, nu=2, nw=2, nc=1, nb=2), "hopper", 20, 30, local_rank)}
+    if not args.no_real_problem and world == 1:      # informative second workload (N = 1 only), outside the timed region
+        try:
+            out["real_problem"] = real_problem_leg(B, H, local_rank)
+        except Exception as e:
+            out["real_problem"] = {"error": repr(e)}
     if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a rank-0, N = 1 measurement
         try:
             cb = cpu_baseline(d, prob, obj, rollouts, H, H_ref)

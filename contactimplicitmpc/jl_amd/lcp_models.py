@@ -341,6 +341,27 @@ def get_stride(model: ContactModel, q_ref: np.ndarray) -> np.ndarray:
     return stride
 
 
+def make_rollout(P: ReferenceProblem, H: int, phase: int, seed: int = 0, perturb: float = 0.0, vel_perturb: float = 0.05):
+    """One MPC problem on the reference gait: window = knots phase .. phase+H+1 (0-based, periodic), the reference
+    restricted to it with the gait's stride added on wrap-around (`rot_n_stride!`, mpc_utils.jl:48-101) and θ
+    rebuilt from the shifted configurations (`update_θ!`, trajectory.jl:67-82); (q0, q1) = reference + one shared
+    U(-perturb, perturb) offset (examples/quadruped/monte_carlo.jl:79-91 perturbs the initial configuration)."""
+    m, Hr = P.model, P.H
+    stride = get_stride(m, P.q)
+    window = (phase + np.arange(H + 2)) % Hr
+    q = np.stack([P.q[(phase + i) % Hr] + ((phase + i) // Hr) * stride for i in range(H + 2)])
+    kn = window[:H]
+    th = P.theta[kn].copy()
+    th[:, :m.nq] = q[:H]
+    th[:, m.nq:2 * m.nq] = q[1:H + 1]
+    rng = np.random.default_rng(seed)
+    dq = rng.uniform(-perturb, perturb, m.nq)
+    q0 = q[0] + dq
+    q1 = q[1] + dq + vel_perturb * rng.uniform(-perturb, perturb, m.nq)
+    return dict(window=window, q=q, u=P.u[kn].copy(), w=P.w[kn].copy(), gamma=P.gamma[kn].copy(), b=P.b[kn].copy(),
+                theta=th, q0=q0, q1=q1)
+
+
 def relative_state_cost(qbody, qorientation, qfoot):
     """Dense 18 x 18 state cost of the centroidal examples (centroidal_quadruped/model.jl:170-185): body, orientation
     and foot-relative-to-body terms."""

@@ -28,24 +28,17 @@ def real_problem(which: str, kappa: float):
     P = lcp_models.reference_problem(model, gait_io.load_gait(path), kappa)
     d = Dims(nq=model.nq, nu=model.nu, nw=model.nw, nc=model.nc, nb=model.nb)
     prob = dict(z0=P.z, th0=P.theta, r0=P.r0, rz0=P.rz0, rth0=P.rth0, kappa=kappa, q_ref=P.q, u_ref=P.u, w_ref=P.w,
-                gamma_ref=P.gamma, b_ref=P.b, stride=lcp_models.get_stride(model, P.q))
+                gamma_ref=P.gamma, b_ref=P.b, stride=lcp_models.get_stride(model, P.q), P=P)
     tabs = [lcp.LinTable(d, P.z[t], P.theta[t], P.r0[t], P.rz0[t], P.rth0[t]) for t in range(P.H)]
     return d, P, prob, tabs
 
 
 def real_rollout(d: Dims, prob, H: int, phase: int, seed: int, perturb: float = 0.0, vel_perturb: float = 0.05):
-    """One rollout on the real gait: window = knots phase .. phase+H+1 (periodic, with the gait's stride added on
-    wrap-around - rot_n_stride!, mpc_utils.jl:48-101), (q0, q1) = reference + a shared U(-perturb, perturb) offset
-    (examples/quadruped/monte_carlo.jl:79-91 perturbs the initial configuration)."""
-    H_ref = prob["u_ref"].shape[0]
-    window = (phase + np.arange(H + 2)) % H_ref
-    q = np.stack([prob["q_ref"][(phase + i) % H_ref] + ((phase + i) // H_ref) * prob["stride"] for i in range(H + 2)])
-    kn = window[:H]
-    ref = Traj(q=q, u=prob["u_ref"][kn].copy(), w=prob["w_ref"][kn].copy(), gamma=prob["gamma_ref"][kn].copy(),
-               b=prob["b_ref"][kn].copy(), theta=prob["th0"][kn].copy())
-    ref.update_theta(d)
-    rng = np.random.default_rng(seed)
-    dq = rng.uniform(-perturb, perturb, d.nq)
-    q0 = q[0] + dq
-    q1 = q[1] + dq + vel_perturb * rng.uniform(-perturb, perturb, d.nq)
-    return window, ref, q0, q1
+    """`lcp_models.make_rollout` in the (window, ref, q0, q1) form of oracle.synth.make_rollout."""
+    from contactimplicitmpc.jl_amd import lcp_models
+    r = lcp_models.make_rollout(prob["P"], H, phase, seed, perturb, vel_perturb)
+    ref = Traj(q=r["q"], u=r["u"], w=r["w"], gamma=r["gamma"], b=r["b"], theta=r["theta"])
+    chk = ref.copy()
+    chk.update_theta(d)
+    assert np.array_equal(chk.theta, ref.theta)
+    return r["window"], ref, r["q0"], r["q1"]
