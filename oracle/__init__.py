@@ -16,6 +16,10 @@ Parity status (see DESIGN.md section "Oracle"):
     NOT present under /root/reference and cannot be executed here (no Julia):
     **IP iterate-level parity: unpinned** - the loop in `ip.py` is
     build-defined, modelled on RoboDojo 0.1.3, pinned only at the level the
-    reference's tests pin it (converged answer to tolerance).
+    reference's tests pin it (converged answer to tolerance).  That level IS
+    exercised on the reference's own data: test/controller/implicit_dynamics.jl
+    (quadruped gait2.jld2, |dq2|_inf < 1e-2 at every knot) is reproduced by
+    tests/test_real_models.py through the true model linearization
+    (contactimplicitmpc/jl_amd/lcp_models.py + gait_io.py).
 """
 from .dims import Dims  # noqa: F401
