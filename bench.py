@@ -134,6 +134,42 @@ def mpc_loop_latency(dims, kind, H, H_ref, device, steps=40):
     return {"ms_per_mpc_step": 1e3 * dt / steps, "mpc_steps_per_s": steps / dt, "newton_iters_per_step": its / steps}
 
 
+def real_mpc_loop_latency(H, device, steps=60, perturb=0.02):
+    """The reference's own use (policy.jl:98-146 cadence, no plant): ONE robot on the real quadruped gait2 problem,
+    warm-started newton_solve! every step, reference / window advanced on the device, next state = planned q_3.
+    Starts from a perturbed configuration, so the first steps need Newton iterations and the loop then settles."""
+    from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions, gait_io, lcp_models
+    m = lcp_models.Quadruped()
+    kappa = 2e-4
+    P = lcp_models.reference_problem(m, gait_io.load_gait(os.path.join(ROOT, "tests", "golden", "gaits", "quadruped_gait2.jld2")), kappa)
+    r = lcp_models.make_rollout(P, H, 0, seed=3, perturb=perturb)
+    qd = 1e-2 * np.concatenate([[1.0, 0.02, 0.25], 0.25 * np.ones(m.nq - 3)])
+    s = CIMPCSolver(m.nq, m.nu, m.nw, m.nc, m.nb, P.H, H, B=1, mode=0, ip_opts=InteriorPointOptions(kappa_tol=kappa),
+                    newton_opts=NewtonOptions(kappa=kappa, r_tol=3e-4, max_iter=5), device=device)
+    for t in range(P.H):
+        s.set_linearization(t + 1, P.z[t], P.theta[t], P.r0[t], P.rz0[t], P.rth0[t])
+    s.set_objective(np.tile(np.diag(qd)[None], (H, 1, 1)), np.tile((3e-2 * np.eye(m.nu))[None], (H, 1, 1)))
+    s.set_window(r["window"][None] + 1)
+    s.set_reference(*(r[k][None] for k in ("q", "u", "w", "gamma", "b", "theta")))
+    stride = lcp_models.get_stride(m, P.q)
+    a, b = r["q0"][None].copy(), r["q1"][None].copy()
+    its, hist = 0, []
+    t0 = None
+    for k in range(steps + 3):
+        if k == 3:
+            t0 = time.perf_counter()
+            its = 0
+        u1, it, rn = s.newton_solve(a, b, warm_start=k > 0)
+        its += int(it[0]); hist.append(int(it[0]))
+        nxt = s.trajectory()["q"][:, 2].copy()
+        s.mpc_advance(stride)
+        a, b = b, nxt
+    dt = time.perf_counter() - t0
+    s.close()
+    return {"ms_per_mpc_step": 1e3 * dt / steps, "mpc_steps_per_s": steps / dt, "newton_iters_per_step": its / steps,
+            "newton_iters_first_steps": hist[:8]}
+
+
 def real_problem_leg(B, H, device, steps=5, perturb=0.05):
     """The same Monte-Carlo batch on the REAL quadruped problem: the reference's gait file (gait2.jld2, a data file
     of the reference kept under tests/golden/gaits) linearized through the model restatement of
@@ -325,7 +361,8 @@ def main():
         # the reference's own use: ONE robot, warm-started MPC steps in a loop (policy.jl:98-146 cadence without the
         # plant: q1_next = planned q_3), reference / window advanced on the device (cimpc_mpc_advance)
         out["mpc_loop_b1"] = {"quadruped_h40": mpc_loop_latency(QUADRUPED, "quadruped", 40, 60, local_rank),
-                              "hopper_h20 (BASELINE configs[1])": mpc_loop_latency(dict(nq=4, nu=2, nw=2, nc=1, nb=2), "hopper", 20, 30, local_rank)}
+                              "hopper_h20 (BASELINE configs[1])": mpc_loop_latency(dict(nq=4, nu=2, nw=2, nc=1, nb=2), "hopper", 20, 30, local_rank),
+                              "quadruped_h40_real_gait2": real_mpc_loop_latency(40, local_rank)}
     if not args.no_real_problem and world == 1:      # informative second workload (N = 1 only), outside the timed region
         try:
             out["real_problem"] = real_problem_leg(B, H, local_rank)

@@ -54,6 +54,10 @@ struct cimpc_ctx {
     double* d_tab = nullptr;
     IpQueues Q{};                // device work queues (par is set per launch)
     int* d_window = nullptr;
+    // cimpc_set_gait: the controller's full reference trajectory + per-rollout step counters
+    double *g_q = nullptr, *g_u = nullptr, *g_w = nullptr, *g_g = nullptr, *g_b = nullptr, *g_th = nullptr, *g_stride = nullptr;
+    int* g_phase = nullptr;
+    bool gait_set = false;
     int wpk = 1;                 // persistent workgroups of a sweep launch
     double* d_alt = nullptr;
     double* d_zout = nullptr;
@@ -670,6 +674,7 @@ int cimpc_set_window(cimpc_handle h, const int* window) {
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpy(h->d_window, w0.data(), w0.size() * sizeof(int), hipMemcpyHostToDevice));
     h->window_set = true;
+    h->gait_set = false;               // an explicit window / reference replaces the gait-generated ones
     return CIMPC_OK;
 }
 
@@ -691,6 +696,7 @@ int cimpc_set_reference(cimpc_handle h, const double* q_ref, const double* u_ref
     if (b_ref) HIP_TRY(h, hipMemcpy(h->S.ref.b, b_ref, B * H * d.nb * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->S.ref.th, theta_ref, B * H * h->nth * sizeof(double), hipMemcpyHostToDevice));
     h->reference_set = true;
+    h->gait_set = false;
     return CIMPC_OK;
 }
 
@@ -1072,10 +1078,52 @@ int cimpc_get_rollout_counters(cimpc_handle h, int* sweeps, int* ip_iters, int* 
     return CIMPC_OK;
 }
 
+static GaitDev gait_dev(cimpc_ctx* h) {
+    return GaitDev{h->g_q, h->g_u, h->g_w, h->g_g, h->g_b, h->g_th, h->g_stride, h->g_phase, h->dm.H_ref};
+}
+
+int cimpc_set_gait(cimpc_handle h, const double* q, const double* u, const double* w, const double* gamma,
+                   const double* b, const double* theta, const double* stride, const int* phase) {
+    if (!h || !q || !u || !theta || !stride) return fail(h, CIMPC_ERR_INVALID, "q, u, theta, stride are required");
+    const cimpc_dims& d = h->dm;
+    const size_t K = d.H_ref, B = d.B;
+    if (d.H > d.H_ref) return fail(h, CIMPC_ERR_INVALID, "H_mpc must not exceed H_ref");
+    if (phase) for (size_t i = 0; i < B; ++i) if (phase[i] < 0) return fail(h, CIMPC_ERR_INVALID, "negative phase");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->g_q) {
+        if (dev_alloc(h, &h->g_q, (K + 2) * d.nq) != CIMPC_OK || dev_alloc(h, &h->g_u, K * d.nu) != CIMPC_OK ||
+            dev_alloc(h, &h->g_w, K * d.nw) != CIMPC_OK || dev_alloc(h, &h->g_g, K * d.nc) != CIMPC_OK ||
+            dev_alloc(h, &h->g_b, K * d.nb) != CIMPC_OK || dev_alloc(h, &h->g_th, K * h->nth) != CIMPC_OK ||
+            dev_alloc(h, &h->g_stride, d.nq) != CIMPC_OK || dev_alloc(h, &h->g_phase, B) != CIMPC_OK)
+            return CIMPC_ERR_HIP;                    // (dev_alloc zero-fills: w, gamma, b default to 0)
+    }
+    HIP_TRY(h, hipMemcpy(h->g_q, q, (K + 2) * d.nq * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->g_u, u, K * d.nu * sizeof(double), hipMemcpyHostToDevice));
+    if (w) HIP_TRY(h, hipMemcpy(h->g_w, w, K * d.nw * sizeof(double), hipMemcpyHostToDevice));
+    if (gamma) HIP_TRY(h, hipMemcpy(h->g_g, gamma, K * d.nc * sizeof(double), hipMemcpyHostToDevice));
+    if (b) HIP_TRY(h, hipMemcpy(h->g_b, b, K * d.nb * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->g_th, theta, K * h->nth * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->g_stride, stride, d.nq * sizeof(double), hipMemcpyHostToDevice));
+    if (phase) HIP_TRY(h, hipMemcpy(h->g_phase, phase, B * sizeof(int), hipMemcpyHostToDevice));
+    else { HIP_TRY(h, hipMemset(h->g_phase, 0, B * sizeof(int))); HIP_TRY(h, hipStreamSynchronize(nullptr)); }
+    int rc = launch_gait_window(h->S, gait_dev(h), h->d_window, 0, h->stream);
+    if (rc != CIMPC_OK) return fail(h, rc, "gait window launch failed");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->gait_set = h->window_set = h->reference_set = true;
+    return CIMPC_OK;
+}
+
 int cimpc_mpc_advance(cimpc_handle h, const double* stride) {
     if (!h || !stride) return fail(h, CIMPC_ERR_INVALID, "null argument");
     if (!h->window_set || !h->reference_set) return fail(h, CIMPC_ERR_STATE, "set_window / set_reference have not been called");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->gait_set) {          // full reference resident: regenerate the horizon from the gait (stride as given now)
+        HIP_TRY(h, hipMemcpyAsync(h->g_stride, stride, (size_t)h->dm.nq * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        int rcg = launch_gait_window(h->S, gait_dev(h), h->d_window, 1, h->stream);
+        if (rcg != CIMPC_OK) return fail(h, rcg, "mpc_advance launch failed");
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return CIMPC_OK;
+    }
     HIP_TRY(h, hipMemcpyAsync(h->d_q0, stride, (size_t)h->dm.nq * sizeof(double), hipMemcpyHostToDevice, h->stream));   // d_q0: staging
     int rc = launch_mpc_advance(h->S, h->d_window, h->d_q0, h->dm.H_ref, h->stream);
     if (rc != CIMPC_OK) return fail(h, rc, "mpc_advance launch failed");

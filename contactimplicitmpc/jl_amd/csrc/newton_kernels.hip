@@ -183,6 +183,50 @@ __global__ __launch_bounds__(64) void mpc_advance_kernel(NewtonDev S, int* windo
         *w = (*w + 1) % H_ref;
     }
 }
+// The same glue when the controller's FULL reference trajectory is resident (cimpc_set_gait): the state after k
+// applications of rot_n_stride! has a closed form.  Entry i holds "absolute" knot a = k + i.  u, w, gamma, b, theta
+// only rotate: row a mod H_ref.  Configurations: mpc_stride! overwrites q_{H+1}, q_{H+2} with q_1 + stride, q_2 + stride
+// after every rotation (1-based), so q(a) = q(a - H_ref) + stride for a > H_ref while q_{H+1} of the file itself
+// survives its lap through the horizon: with a - 1 = lap * H_ref + r,  q(a) = gait_q[r + 1] + lap * stride  (a >= 1),
+// q(0) = gait_q[0]; the only other file value is gait_q[H_ref + 1], visible at k = 0.  theta's q0 / q1 slices equal
+// the configurations of their step (update_theta! after every overwrite).  Rebuilds a rollout's window-length
+// reference and window after adding `advance` to its step counter.
+__global__ __launch_bounds__(128) void gait_window_kernel(NewtonDev S, GaitDev G, int* window, int advance) {
+    const cimpc_dims& m = S.dm;
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x, H = m.H, nq = m.nq, nth = S.nth, Hr = G.H_ref;
+    const int k = G.phase[b] + advance;
+    __syncthreads();
+    if (tid == 0) G.phase[b] = k;
+    double* q = S.ref.q + (size_t)b * (H + 2) * nq;
+    double* th = S.ref.th + (size_t)b * H * nth;
+    for (int e = tid; e < (H + 2) * nq; e += nt) {
+        const int i = e / nq, c = e - i * nq, a = k + i;
+        const int lap = a >= 1 ? (a - 1) / Hr : 0, j = a >= 1 ? (a - 1) - lap * Hr + 1 : 0;
+        q[e] = (k == 0 && a == Hr + 1) ? G.q[(size_t)a * nq + c]
+                                       : (lap ? G.q[(size_t)j * nq + c] + (double)lap * G.stride[c] : G.q[(size_t)j * nq + c]);
+    }
+    auto rows = [&](double* dst, const double* src, int n) {
+        for (int e = tid; e < H * n; e += nt) {
+            const int i = e / n, c = e - i * n;
+            dst[e] = src[(size_t)((k + i) % Hr) * n + c];
+        }
+    };
+    rows(S.ref.u + (size_t)b * H * m.nu, G.u, m.nu);
+    rows(S.ref.w + (size_t)b * H * m.nw, G.w, m.nw);
+    rows(S.ref.g + (size_t)b * H * m.nc, G.g, m.nc);
+    rows(S.ref.b + (size_t)b * H * m.nb, G.b, m.nb);
+    rows(th, G.th, nth);
+    __syncthreads();
+    for (int e = tid; e < H * 2 * nq; e += nt) {           // update_theta!: q0, q1 slices of every step
+        const int i = e / (2 * nq), c = e - i * 2 * nq;
+        th[(size_t)i * nth + c] = q[(size_t)i * nq + c];   // c < nq: q_i, else q_{i+1} (contiguous in q)
+    }
+    for (int i = tid; i < H + 2; i += nt) window[(size_t)b * (H + 2) + i] = (k + i) % Hr;
+}
+int launch_gait_window(const NewtonDev& S, const GaitDev& G, int* window, int advance, hipStream_t s) {
+    hipLaunchKernelGGL(gait_window_kernel, dim3(S.dm.B), dim3(128), 0, s, S, G, window, advance);
+    return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+}
 int launch_mpc_advance(const NewtonDev& S, int* window, const double* stride, int H_ref, hipStream_t s) {
     hipLaunchKernelGGL(mpc_advance_kernel, dim3(S.dm.B), dim3(64), 0, s, S, window, stride, H_ref);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;

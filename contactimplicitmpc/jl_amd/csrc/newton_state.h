@@ -85,6 +85,14 @@ bool newton_async_available(const cimpc_dims* dm);
 int launch_newton_async(const cimpc_dims* dm, const IpParams& p, const NewtonDev& S, int waves, int grid, hipStream_t s);
 int launch_async_handoff(const NewtonDev& S, const IpQueues& lockstep_next, hipStream_t s);
 int launch_mpc_advance(const NewtonDev& S, int* window, const double* stride, int H_ref, hipStream_t s);
+// the controller's full reference trajectory (shared by the rollouts) and the per-rollout step counter
+struct GaitDev {
+    const double *q, *u, *w, *g, *b, *th;   // [H_ref+2][nq], [H_ref][nu | nw | nc | nb | nth]
+    const double* stride;                    // [nq]
+    int* phase;                              // [B] rot_n_stride! steps applied so far
+    int H_ref;
+};
+int launch_gait_window(const NewtonDev& S, const GaitDev& G, int* window, int advance, hipStream_t s);
 int launch_reset(const NewtonDev& nd, const double* q0, const double* q1, int warm, hipStream_t s);
 int launch_resid_decide(const NewtonDev& nd, hipStream_t s);
 int launch_enqueue_all(const NewtonDev& nd, hipStream_t s);   // B3 seam: queue slot 0 of every rollout

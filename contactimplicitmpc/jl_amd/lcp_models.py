@@ -322,10 +322,14 @@ class ReferenceProblem:
     rth0: np.ndarray       # (H, nz, nθ)
 
 
-def reference_problem(model: ContactModel, gait, kappa: float) -> ReferenceProblem:
+def reference_problem(model: ContactModel, gait, kappa: float, update_friction: bool = False) -> ReferenceProblem:
     """`get_trajectory(...; load_type = :split_traj_alt)` (trajectory.jl:169-180) followed by the `LinearizedStep`
-    of every knot at κ (`ImplicitTrajectory`, implicit_dynamics.jl:37-50)."""
+    of every knot at κ (`ImplicitTrajectory`, implicit_dynamics.jl:37-50).  `update_friction`:
+    `update_friction_coefficient!` (trajectory.jl:133-141) - θ carries the model's μ_world instead of the file's μ."""
     H = gait.H
+    if update_friction:
+        import dataclasses
+        gait = dataclasses.replace(gait, mu=float(model.mu_world))
     w = np.zeros((H, model.nw))
     z = np.stack([model.pack_z(gait.q[t + 2], gait.gamma[t], gait.b[t], gait.psi[t], gait.eta[t]) for t in range(H)])
     th = np.stack([model.pack_theta(gait.q[t], gait.q[t + 1], gait.u[t], w[t], gait.mu, gait.h) for t in range(H)])
@@ -349,7 +353,14 @@ def make_rollout(P: ReferenceProblem, H: int, phase: int, seed: int = 0, perturb
     m, Hr = P.model, P.H
     stride = get_stride(m, P.q)
     window = (phase + np.arange(H + 2)) % Hr
-    q = np.stack([P.q[(phase + i) % Hr] + ((phase + i) // Hr) * stride for i in range(H + 2)])
+    # what `phase` applications of rot_n_stride! leave in p.traj.q: mpc_stride! re-derives q_{H+1}, q_{H+2} from
+    # q_1, q_2 (+ stride) after every rotation, the file's own q_{H+1} survives one lap (cimpc_set_gait does the same)
+    def qa(a):
+        if a == 0 or (phase == 0 and a == Hr + 1):
+            return P.q[a]
+        lap, r = divmod(a - 1, Hr)
+        return P.q[r + 1] + lap * stride
+    q = np.stack([qa(phase + i) for i in range(H + 2)])
     kn = window[:H]
     th = P.theta[kn].copy()
     th[:, :m.nq] = q[:H]

@@ -224,6 +224,20 @@ class CIMPCSolver:
         st = _f64(stride, (self.nq,))
         self._check(self.lib.cimpc_mpc_advance(self.h, _dp(st)), "mpc_advance")
 
+    def set_gait(self, q, u, theta, stride, w=None, gamma=None, b=None, phase=None):
+        """The controller's full reference trajectory (p.traj of the CIMPC policy): H_ref knots shared by the
+        rollouts; builds every rollout's window and horizon reference on the device (phase = steps already
+        rotated, per rollout) and switches `mpc_advance` to regenerate them from the gait."""
+        K = self.H_ref
+        opt = lambda a, n: None if a is None else _f64(a, (K, n))
+        qa, ua, tha = _f64(q, (K + 2, self.nq)), _f64(u, (K, self.nu)), _f64(theta, (K, self.nth))
+        wa, ga, ba = opt(w, self.nw), opt(gamma, self.nc), opt(b, self.nb)
+        st = _f64(stride, (self.nq,))
+        ph = None if phase is None else np.ascontiguousarray(np.asarray(phase, dtype=np.int32).reshape(self.B))
+        P = lambda a: None if a is None else _dp(a)
+        self._check(self.lib.cimpc_set_gait(self.h, _dp(qa), _dp(ua), P(wa), P(ga), P(ba), _dp(tha), _dp(st),
+                                            None if ph is None else _ipt(ph)), "set_gait")
+
     def reference(self):
         B, H = self.B, self.H
         q = np.zeros((B, H + 2, self.nq)); u = np.zeros((B, H, self.nu)); w = np.zeros((B, H, self.nw))

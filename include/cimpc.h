@@ -184,6 +184,21 @@ int cimpc_get_rollout_counters(cimpc_handle h, int* sweeps, int* ip_iters, int* 
  * stride: nq doubles (get_stride, mpc_utils.jl:103-107), shared by the rollouts.
  * The Newton iterate (core.traj, nu) stays resident for warm_start = 1, as in the reference. */
 int cimpc_mpc_advance(cimpc_handle h, const double* stride);
+
+/* The controller's FULL reference trajectory (p.traj / p.ref_traj of the CIMPC policy, policy.jl:70-96): H_ref
+ * knots shared by all rollouts, of which a rollout's Newton problem reads the first H_mpc (newton_solve! gets
+ * ref_traj = p.traj and window = p.window).  With H_mpc < H_ref the knots that rotate into the horizon come from
+ * the rest of the gait - the window-length cimpc_set_reference cannot know them - so a policy loop with
+ * H_mpc < H_ref needs this call instead of cimpc_set_window + cimpc_set_reference:
+ *   q (H_ref+2) x nq, u H_ref x nu, w H_ref x nw (NULL = 0), gamma H_ref x nc, b H_ref x nb (NULL = 0),
+ *   theta H_ref x nth, stride nq (get_stride, mpc_utils.jl:103-107),
+ *   phase B ints (NULL = 0): number of rot_n_stride! / update_window! steps already applied per rollout
+ *   (0 = reset_window!: window 1..H_mpc+2; Monte-Carlo rollouts may start anywhere in the gait).
+ * Builds every rollout's window and reference on the device.  Afterwards cimpc_mpc_advance regenerates them from
+ * the gait: entry i of a rollout at step k is knot (k+i) mod H_ref, configurations shifted by floor((k+i)/H_ref)
+ * strides, theta's q0/q1 slices refreshed - exactly what k applications of rot_n_stride! leave in p.traj. */
+int cimpc_set_gait(cimpc_handle h, const double* q, const double* u, const double* w, const double* gamma,
+                   const double* b, const double* theta, const double* stride, const int* phase);
 /* reads the controller's reference trajectory and 1-based window back (any pointer may be NULL) */
 int cimpc_get_reference(cimpc_handle h, double* q_ref, double* u_ref, double* w_ref, double* gamma_ref,
                         double* b_ref, double* theta_ref, int* window);

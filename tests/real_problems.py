@@ -20,12 +20,12 @@ GAITS = {
 
 
 @functools.lru_cache(maxsize=None)
-def real_problem(which: str, kappa: float):
+def real_problem(which: str, kappa: float, update_friction: bool = False):
     """-> (Dims, ReferenceProblem, prob dict in the layout of oracle.synth.make_problem, LinTables)."""
     from contactimplicitmpc.jl_amd import gait_io, lcp_models
     name, path = GAITS[which]
     model = lcp_models.MODELS[name]()
-    P = lcp_models.reference_problem(model, gait_io.load_gait(path), kappa)
+    P = lcp_models.reference_problem(model, gait_io.load_gait(path), kappa, update_friction)
     d = Dims(nq=model.nq, nu=model.nu, nw=model.nw, nc=model.nc, nb=model.nb)
     prob = dict(z0=P.z, th0=P.theta, r0=P.r0, rz0=P.rz0, rth0=P.rth0, kappa=kappa, q_ref=P.q, u_ref=P.u, w_ref=P.w,
                 gamma_ref=P.gamma, b_ref=P.b, stride=lcp_models.get_stride(model, P.q), P=P)

@@ -1,0 +1,125 @@
+"""Closed loop: the reference's own end-to-end test, test/controller/mpc_quadruped.jl:1-64, re-stated.
+
+  quadruped gait2 (update_friction_coefficient!), H_mpc = 10, N_sample = 5, κ_mpc = 2e-4, TrackingObjective :23-27,
+  NewtonOptions(r_tol 3e-4, max_iter 5), IP (undercut 5, γ_reg 0.1, κ_tol = κ_mpc, r_tol 1e-8); simulate 1000 plant
+  steps at h/5 and compare `tracking_error` with the RECORDED nominal values q 0.0201, u 0.0437, γ 0.374, b 0.0789
+  (the reference asserts < 1.5 x nominal).
+
+The plant (RoboDojo's simulate!, external) is oracle/plant.py: the nonlinear time-stepping complementarity problem
+solved to 1e-8 per step.  Measured with the oracle as the controller, H_sim = 1000 (scripts/closed_loop_quadruped.py):
+q 0.02048, u 0.04331, γ 0.3768, b 0.07917 - within 2 %, 1 %, 0.7 %, 0.3 % of the reference's recorded values.
+The suite runs 300 plant steps (one and a half gait cycles): CPU with the oracle, GPU with the product policy
+(contactimplicitmpc/jl_amd/policy.py over the C ABI).
+"""
+import numpy as np
+import pytest
+
+from oracle import ip as oip
+from oracle import newton as onewton, plant as pl, synth
+from real_problems import real_problem
+
+NOMINAL = (0.0201, 0.0437, 0.374, 0.0789)         # test/controller/mpc_quadruped.jl:59-62
+H_MPC, N_SAMPLE, KAPPA = 10, 5, 2e-4
+
+
+def _oracle_loop(H_sim):
+    d, P, prob, tabs = real_problem("quadruped", KAPPA, True)
+    obj = synth.make_objective(d, H_MPC, kind="quadruped")
+    ref = onewton.Traj(q=P.q.copy(), u=P.u.copy(), w=P.w.copy(), gamma=P.gamma.copy(), b=P.b.copy(), theta=P.theta.copy())
+    pol = pl.OraclePolicy(d, tabs, ref, prob["stride"], obj, H_MPC, N_SAMPLE, KAPPA,
+                          onewton.NewtonOptions(r_tol=3e-4, max_iter=5, solver="lu"), oip.IPOptions(kappa_tol=KAPPA, r_tol=1e-8))
+    q1, v1 = P.q[1].copy(), (P.q[1] - P.q[0]) / P.h                     # initial_conditions, trajectory.jl:222-227
+    ok, q, u, g, b = pl.simulate(pl.QuadrupedPlant(), pol, q1, v1, H_sim, P.h / N_SAMPLE)
+    return P, pol, ok, q, u, g, b
+
+
+def test_numpy_plant_equals_the_torch_model():
+    """Two independent derivations of the quadruped dynamics: closed-form sums over the bodies (oracle/plant.py) and
+    the autodiff Lagrangian (lcp_models.py)."""
+    from contactimplicitmpc.jl_amd import lcp_models
+    P, m = pl.QuadrupedPlant(), lcp_models.Quadruped()
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        z, th = rng.uniform(0.1, 1.0, 43), rng.uniform(0.1, 1.0, 34)
+        r_t, rz_t, _ = m.linearize(z, th, 1e-3)
+        np.testing.assert_allclose(P.residual(z, th, 1e-3), r_t, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(P.jacobian_z(z, th), rz_t, rtol=0, atol=1e-11 * np.abs(rz_t).max())
+
+
+def test_plant_step_reproduces_the_gait():
+    """Plant step from two consecutive gait configurations with the gait's control: lands on the next one (the gait
+    file satisfies the dynamics to 1e-5; contact forces differ by the κ the file was optimised at)."""
+    d, P, prob, tabs = real_problem("quadruped", KAPPA, True)
+    plant = pl.QuadrupedPlant()
+    for t in (0, 17, 40):
+        status, it, q2, gam, b = pl.plant_step(plant, P.q[t], P.q[t + 1], P.u[t], np.zeros(2), plant.mu_world, P.h, pl.SIM_OPTS)
+        assert status and it <= 30
+        assert np.abs(q2 - P.q[t + 2]).max() < 5e-3
+
+
+def test_closed_loop_tracking_error_with_the_oracle_controller():
+    P, pol, ok, q, u, g, b = _oracle_loop(300)
+    assert ok                                                            # @test status
+    qe, ue, ge, be = pl.tracking_error(P.q, P.u, P.gamma, P.b, q, u, g, b, N_SAMPLE)
+    assert qe < NOMINAL[0] * 1.5 and ue < NOMINAL[1] * 1.5 and ge < NOMINAL[2] * 1.5 and be < NOMINAL[3] * 1.5   # :59-62
+    # and close to the recorded nominal values themselves (u, γ, b are stationary; q drifts, so shorter runs sit lower)
+    assert abs(ue / NOMINAL[1] - 1) < 0.05 and abs(ge / NOMINAL[2] - 1) < 0.05 and abs(be / NOMINAL[3] - 1) < 0.05
+    assert 0.5 * NOMINAL[0] < qe
+    assert 1.0 <= np.mean(pol.iters) <= 5.0
+
+
+@pytest.mark.gpu
+def test_gait_advance_equals_rot_n_stride_on_the_full_trajectory(gpu_required):
+    """cimpc_set_gait + cimpc_mpc_advance against rot_n_stride! / update_window! applied to the FULL reference
+    trajectory (policy.jl:136-139), H_mpc = 10 < H_ref = 60, rollouts starting at different phases, two laps."""
+    from contactimplicitmpc.jl_amd import CIMPCSolver
+    from oracle import mpc as ompc
+    d, P, prob, tabs = real_problem("quadruped", KAPPA, True)
+    B, H = 3, H_MPC
+    phase = np.array([0, 7, 55], dtype=np.int32)
+    s = CIMPCSolver(d.nq, d.nu, d.nw, d.nc, d.nb, P.H, H, B=B, mode=0)
+    s.set_gait(P.q, P.u, P.theta, prob["stride"], w=P.w, gamma=P.gamma, b=P.b, phase=phase)
+    refs = []
+    for b in range(B):
+        tr = onewton.Traj(q=P.q.copy(), u=P.u.copy(), w=P.w.copy(), gamma=P.gamma.copy(), b=P.b.copy(), theta=P.theta.copy())
+        win = np.arange(H + 2)
+        for _ in range(int(phase[b])):
+            ompc.rot_n_stride(d, tr, prob["stride"]); win = ompc.update_window(win, P.H)
+        refs.append((tr, win))
+    for step in range(130):
+        got = s.reference()
+        for b, (tr, win) in enumerate(refs):
+            np.testing.assert_array_equal(got["window"][b] - 1, win)          # the ABI speaks 1-based knots
+            np.testing.assert_allclose(got["q"][b], tr.q[:H + 2], rtol=0, atol=1e-12)
+            np.testing.assert_allclose(got["u"][b], tr.u[:H], rtol=0, atol=0)
+            np.testing.assert_allclose(got["gamma"][b], tr.gamma[:H], rtol=0, atol=0)
+            np.testing.assert_allclose(got["b"][b], tr.b[:H], rtol=0, atol=0)
+            np.testing.assert_allclose(got["theta"][b], tr.theta[:H], rtol=0, atol=1e-12)
+        s.mpc_advance(prob["stride"])
+        refs = [(ompc.rot_n_stride(d, tr, prob["stride"]) or tr, ompc.update_window(win, P.H)) for tr, win in refs]
+    s.close()
+
+
+@pytest.mark.gpu
+def test_closed_loop_tracking_error_with_the_device_policy(gpu_required):
+    """The same loop with the PRODUCT in it: CIMPCPolicy (device solver + device-side trajectory rotation)."""
+    from contactimplicitmpc.jl_amd import NewtonOptions, InteriorPointOptions
+    from contactimplicitmpc.jl_amd.policy import CIMPCPolicy
+    d, P, prob, tabs = real_problem("quadruped", KAPPA, True)
+    obj = synth.make_objective(d, H_MPC, kind="quadruped")
+    pol = CIMPCPolicy(P, obj.q, obj.u, H_mpc=H_MPC, N_sample=N_SAMPLE, B=1,
+                      n_opts=NewtonOptions(kappa=KAPPA, r_tol=3e-4, max_iter=5), ip_opts=InteriorPointOptions(kappa_tol=KAPPA, r_tol=1e-8))
+    H_sim = 300
+    q1, v1 = P.q[1].copy(), (P.q[1] - P.q[0]) / P.h
+    ok, q, u, g, b = pl.simulate(pl.QuadrupedPlant(), lambda qq, t: pol(qq[t + 1][None])[0], q1, v1, H_sim, P.h / N_SAMPLE)
+    pol.close()
+    assert ok
+    qe, ue, ge, be = pl.tracking_error(P.q, P.u, P.gamma, P.b, q, u, g, b, N_SAMPLE)
+    assert qe < NOMINAL[0] * 1.5 and ue < NOMINAL[1] * 1.5 and ge < NOMINAL[2] * 1.5 and be < NOMINAL[3] * 1.5
+    assert abs(ue / NOMINAL[1] - 1) < 0.05 and abs(ge / NOMINAL[2] - 1) < 0.05 and abs(be / NOMINAL[3] - 1) < 0.05
+    # against the oracle-controlled loop: same plant, same controller algorithm
+    Po, polo, oko, qo, uo, go, bo = _oracle_loop(H_sim)
+    np.testing.assert_allclose(q[:60], qo[:60], rtol=0, atol=1e-5)       # before round-off has time to grow
+    eo = pl.tracking_error(P.q, P.u, P.gamma, P.b, qo, uo, go, bo, N_SAMPLE)
+    for a, c in zip((qe, ue, ge, be), eo):
+        assert abs(a / c - 1) < 0.03
