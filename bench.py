@@ -114,10 +114,10 @@ def mpc_loop_latency(dims, kind, H, H_ref, device, steps=40):
     for t in range(H_ref):
         s.set_linearization(t + 1, prob["z0"][t], prob["th0"][t], prob["r0"][t], prob["rz0"][t], prob["rth0"][t])
     s.set_objective(obj.q, obj.u)
-    s.set_window(window[None] + 1)
-    s.set_reference(ref.q[None], ref.u[None], ref.w[None], ref.gamma[None], ref.b[None], ref.theta[None])
     stride = np.zeros(d.nq)
-    stride[0] = ref.q[-2][0] - ref.q[0][0]          # get_stride, mpc_utils.jl:103-107
+    stride[0] = prob["q_ref"][-2][0] - prob["q_ref"][0][0]          # get_stride, mpc_utils.jl:103-107
+    # the controller's full reference trajectory lives on the device (cimpc_set_gait); mpc_advance rotates it
+    s.set_gait(prob["q_ref"], prob["u_ref"], prob["th0"], stride, w=prob["w_ref"], gamma=prob["gamma_ref"], b=prob["b_ref"])
     a, b = q0[None].copy(), q1[None].copy()
     its = 0
     t0 = None
@@ -149,9 +149,8 @@ def real_mpc_loop_latency(H, device, steps=60, perturb=0.02):
     for t in range(P.H):
         s.set_linearization(t + 1, P.z[t], P.theta[t], P.r0[t], P.rz0[t], P.rth0[t])
     s.set_objective(np.tile(np.diag(qd)[None], (H, 1, 1)), np.tile((3e-2 * np.eye(m.nu))[None], (H, 1, 1)))
-    s.set_window(r["window"][None] + 1)
-    s.set_reference(*(r[k][None] for k in ("q", "u", "w", "gamma", "b", "theta")))
     stride = lcp_models.get_stride(m, P.q)
+    s.set_gait(P.q, P.u, P.theta, stride, w=P.w, gamma=P.gamma, b=P.b)
     a, b = r["q0"][None].copy(), r["q1"][None].copy()
     its, hist = 0, []
     t0 = None
