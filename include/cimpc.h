@@ -182,7 +182,9 @@ int cimpc_get_rollout_counters(cimpc_handle h, int* sweeps, int* ip_iters, int* 
  *   update_window!(p.window, p.ref_traj.H)                     policy.jl:162-171
  * on the reference trajectory / window last given by cimpc_set_reference / cimpc_set_window.
  * stride: nq doubles (get_stride, mpc_utils.jl:103-107), shared by the rollouts.
- * The Newton iterate (core.traj, nu) stays resident for warm_start = 1, as in the reference. */
+ * The Newton iterate (core.traj, nu) stays resident for warm_start = 1, as in the reference.
+ * After cimpc_set_reference the H_mpc-knot arrays are rotated in place - the reference's policy only when
+ * H_mpc = H_ref; after cimpc_set_gait (below) the horizon is regenerated from the full trajectory for any H_mpc. */
 int cimpc_mpc_advance(cimpc_handle h, const double* stride);
 
 /* The controller's FULL reference trajectory (p.traj / p.ref_traj of the CIMPC policy, policy.jl:70-96): H_ref

@@ -20,6 +20,9 @@ Parity status (see DESIGN.md section "Oracle"):
     exercised on the reference's own data: test/controller/implicit_dynamics.jl
     (quadruped gait2.jld2, |dq2|_inf < 1e-2 at every knot) is reproduced by
     tests/test_real_models.py through the true model linearization
-    (contactimplicitmpc/jl_amd/lcp_models.py + gait_io.py).
+    (contactimplicitmpc/jl_amd/lcp_models.py + gait_io.py), and the closed
+    loop of test/controller/mpc_quadruped.jl (plant = oracle/plant.py) lands
+    within 2 % of the tracking errors that test records (tests/test_closed_loop.py,
+    scripts/closed_loop_quadruped.py).
 """
 from .dims import Dims  # noqa: F401
