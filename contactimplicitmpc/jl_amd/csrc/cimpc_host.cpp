@@ -478,7 +478,9 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         const size_t nprob = B * H;
         size_t w = (nprob + 2 * groups_per_wg - 1) / (2 * groups_per_wg);
         w = std::max<size_t>(w, std::min<size_t>(d.H_ref, nprob));
-        const size_t resident = (size_t)256 * (8 / h->waves);
+        // (32-lane models run one wave per SIMD - 512 registers - i.e. 4 waves per CU; the asynchronous launcher
+        //  clamps its grid to the occupancy the runtime reports in any case)
+        const size_t resident = (size_t)256 * ((h->ki.G == 16 ? 8 : 4) / h->waves);
         h->wpk = (int)std::max<size_t>(1, std::min<size_t>(w, resident));
         if (getenv("CIMPC_SWEEP_WGS")) h->wpk = std::max(1, atoi(getenv("CIMPC_SWEEP_WGS")));
         // asynchronous solve: the same resident set plus dedicated residual/KKT workgroups
@@ -1099,9 +1101,13 @@ int cimpc_set_gait(cimpc_handle h, const double* q, const double* u, const doubl
     }
     HIP_TRY(h, hipMemcpy(h->g_q, q, (K + 2) * d.nq * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->g_u, u, K * d.nu * sizeof(double), hipMemcpyHostToDevice));
-    if (w) HIP_TRY(h, hipMemcpy(h->g_w, w, K * d.nw * sizeof(double), hipMemcpyHostToDevice));
-    if (gamma) HIP_TRY(h, hipMemcpy(h->g_g, gamma, K * d.nc * sizeof(double), hipMemcpyHostToDevice));
-    if (b) HIP_TRY(h, hipMemcpy(h->g_b, b, K * d.nb * sizeof(double), hipMemcpyHostToDevice));
+    auto opt = [&](double* dst, const double* src, size_t n) {      // NULL = zeros (also when an earlier call gave values)
+        return src ? hipMemcpy(dst, src, n * sizeof(double), hipMemcpyHostToDevice) : hipMemset(dst, 0, n * sizeof(double));
+    };
+    HIP_TRY(h, opt(h->g_w, w, K * d.nw));
+    HIP_TRY(h, opt(h->g_g, gamma, K * d.nc));
+    HIP_TRY(h, opt(h->g_b, b, K * d.nb));
+    HIP_TRY(h, hipStreamSynchronize(nullptr));
     HIP_TRY(h, hipMemcpy(h->g_th, theta, K * h->nth * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->g_stride, stride, d.nq * sizeof(double), hipMemcpyHostToDevice));
     if (phase) HIP_TRY(h, hipMemcpy(h->g_phase, phase, B * sizeof(int), hipMemcpyHostToDevice));

@@ -84,7 +84,7 @@ __device__ __noinline__ void async_serve_job(unsigned long long ka, double* smem
 }
 
 template <class M>
-__global__ __launch_bounds__(256, 2) void newton_async_kernel(AsyncArgs args) {
+__global__ __launch_bounds__(256, (M::G == 16 ? 2 : 1)) void newton_async_kernel(AsyncArgs args) {
     const IpParams& p = args.p;
     const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
     static_assert(M::MODE == CIMPC_MODE_CONFIGURATION, "the KKT stage implements :configuration");
@@ -184,6 +184,19 @@ int launch_async_model(const IpParams& p, const NewtonDev& S, int waves, int gri
     const size_t lds = lds_ip > lds_kkt ? lds_ip : lds_kkt;
     static LdsOptIn optin;
     if (lds_opt_in(optin, (const void*)newton_async_kernel<M>, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
+    // every workgroup of this kernel must be resident (they wait for each other's jobs): clamp the grid to what the
+    // device really holds for this kernel / block size / LDS footprint
+    static int max_resident[5] = {0, 0, 0, 0, 0};
+    if (max_resident[waves] == 0) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)newton_async_kernel<M>, 64 * waves, lds) != hipSuccess ||
+            hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu < 1)
+            return CIMPC_ERR_HIP;
+        max_resident[waves] = per_cu * prop.multiProcessorCount;
+    }
+    if (grid > max_resident[waves]) grid = max_resident[waves];
+    if (grid <= S.A.n_service) return CIMPC_ERR_INVALID;          // no workgroup left for the interior-point queues
     AsyncArgs args{p, S};
     hipLaunchKernelGGL((newton_async_kernel<M>), dim3(grid), dim3(64 * waves), lds, s, args);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
