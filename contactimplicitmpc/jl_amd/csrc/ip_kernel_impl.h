@@ -113,7 +113,7 @@ struct IpSolver {
 
     // rzlin! + schur_factorize! + MGS factorize!.  Right-looking order: per column exactly
     // the arithmetic of the reference's left-looking loop (qr.jl:113-137); dot products use
-    // four partial sums, 1/|a_k| comes from v_rsq_f64 + two Newton steps.
+    // four partial sums, 1/|a_k| comes from v_rsq_f64 + two Newton steps on the broadcast self-product of column k.
     __device__ __forceinline__ void factorize(double reg) {
         const double* tW = tab + L.oW;
         y1r = fmax(y1, reg);
@@ -131,14 +131,6 @@ struct IpSolver {
         // step cheaper and without a lane-divergent branch.
         static_for<0, NY>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            double n2[4] = {0.0, 0.0, 0.0, 0.0};
-            static_for<0, NY>([&](auto ic) {
-                constexpr int r = decltype(ic)::value;
-                n2[r & 3] = fma(Qc[r], Qc[r], n2[r & 3]);
-            });
-            const double inv = fast_rsqrt((n2[0] + n2[1]) + (n2[2] + n2[3]));
-            rdinv = (l == k) ? inv : rdinv;
-            const double invk = LG::template bcast<k>(inv);
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
             double ak[NY];
             static_for<0, NY>([&](auto ic) {
@@ -146,7 +138,12 @@ struct IpSolver {
                 ak[r] = LG::template bcast<k>(Qc[r]);
                 acc[r & 3] = fma(ak[r], Qc[r], acc[r & 3]);
             });
-            double rk = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * invk;
+            const double dot = (acc[0] + acc[1]) + (acc[2] + acc[3]);     // a_k . a_l
+            // |a_k|^2 is lane k's own dot product (there a_k[r] * a_k[r], the same four partial sums a separate
+            // norm loop would form): one broadcast instead of 16 multiply-adds per step
+            const double invk = fast_rsqrt(LG::template bcast<k>(dot));
+            rdinv = (l == k) ? invk : rdinv;
+            double rk = dot * invk;
             rk = ((l > k) && vy) ? rk : 0.0;
             const double coef = rk * invk;
             static_for<0, NY>([&](auto ic) {
