@@ -74,7 +74,9 @@ struct cimpc_ctx {
     int n_knots_set = 0;
     bool objective_set = false, window_set = false, reference_set = false, alt_set = false;
     bool velocity_objective = false;
-    bool use_dense = false;        // KKT through the reference-default dense LU (any mode / objective), kkt_dense.hip
+    bool use_dense = false;        // KKT through kkt_dense.hip: the reference-default dense LU (any mode / objective) ...
+    bool use_banded = false;       // ... or its banded LDL^T (:configuration mode, velocity objective / on request)
+    size_t dense_ws_doubles = 0;
     double* d_dense_ws = nullptr;  // [B][N*N + 2N], allocated on first use
     double *d_V = nullptr, *d_qt = nullptr, *d_vt = nullptr;
     int waves = 4;
@@ -249,8 +251,20 @@ int run_sweep(cimpc_ctx* h, int par, int* pending_counter, double* zout, hipStre
 }
 
 int ensure_dense_ws(cimpc_ctx* h) {
-    if (h->d_dense_ws) return CIMPC_OK;
-    return dev_alloc(h, &h->d_dense_ws, kkt_dense_workspace_doubles(h->S));
+    const size_t need = kkt_dense_workspace_doubles(h->S, h->use_banded);
+    if (h->d_dense_ws && h->dense_ws_doubles >= need) return CIMPC_OK;
+    h->d_dense_ws = nullptr;                      // (an earlier, smaller workspace stays in h->allocs until destroy)
+    h->dense_ws_doubles = need;
+    return dev_alloc(h, &h->d_dense_ws, need);
+}
+
+// which kkt_dense.hip path serves the current mode / objective / requested backend
+static void select_kkt_backend(cimpc_ctx* h) {
+    const bool cfg = h->dm.mode == CIMPC_MODE_CONFIGURATION;
+    const int want = h->nt.kkt_backend;
+    const bool velocity = h->S.V != nullptr;
+    h->use_dense = !cfg || want == CIMPC_KKT_DENSE_LU || want == CIMPC_KKT_BANDED_LDL || velocity;
+    h->use_banded = h->use_dense && cfg && want != CIMPC_KKT_DENSE_LU && kkt_banded_available(h->S);
 }
 
 int check_ready(cimpc_ctx* h, bool need_newton) {
@@ -443,7 +457,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     // when the solve is latency-bound (small batches), costs throughput otherwise (B = 2048: -8 %)
     // condensed MFMA/scalar solve: :configuration + TrackingObjective; everything else (and kkt_backend = dense LU)
     // goes through the reference-default dense LU
-    h->use_dense = d.mode != CIMPC_MODE_CONFIGURATION || h->nt.kkt_backend == CIMPC_KKT_DENSE_LU;
+    select_kkt_backend(h);
     S.spec_all = getenv("CIMPC_SPEC_ALL") ? atoi(getenv("CIMPC_SPEC_ALL")) : (d.B <= 128 ? 3 : 8);
     // small batches: one wave per workgroup keeps every problem on its own CU (latency);
     // large batches: 4 waves share one staged table (throughput)
@@ -629,12 +643,12 @@ int cimpc_set_objective(cimpc_handle h, const double* Q, const double* R, const 
         HIP_TRY(h, hipMemcpy(h->d_qt, qt.data(), qt.size() * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(h->d_vt, vt.data(), vt.size() * sizeof(double), hipMemcpyHostToDevice));
         h->S.V = h->d_V; h->S.q_target = h->d_qt; h->S.v_target = h->d_vt;
+        select_kkt_backend(h);     // P is block tridiagonal: the condensed solve does not apply (banded LDL^T / dense LU)
         h->velocity_objective = true;
-        h->use_dense = true;       // P is block tridiagonal: the condensed solve does not apply
     } else {
         h->S.V = nullptr; h->S.q_target = nullptr; h->S.v_target = nullptr;
         h->velocity_objective = false;
-        h->use_dense = d.mode != CIMPC_MODE_CONFIGURATION || h->nt.kkt_backend == CIMPC_KKT_DENSE_LU;
+        select_kkt_backend(h);
     }
     std::vector<double> Qi(H * d.nq * d.nq), Ri(H * d.nu * d.nu);
     for (size_t i = 0; i < H; ++i) {
@@ -766,7 +780,7 @@ int cimpc_kkt_solve(cimpc_handle h, const double* r, double beta, double* delta)
     if (h->use_dense) {
         rc = ensure_dense_ws(h);
         if (rc != CIMPC_OK) return rc;
-        rc = launch_kkt_dense_raw(h->S, h->d_rhs, beta, h->S.delta, h->d_dense_ws, h->stream);
+        rc = launch_kkt_dense_raw(h->S, h->d_rhs, beta, h->S.delta, h->d_dense_ws, h->stream, h->use_banded);
     } else {
         rc = launch_kkt_raw(h->S, h->d_rhs, beta, h->S.delta, h->stream);
     }
@@ -922,7 +936,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             Sk.kkt_same_round = 1;
             prof_begin(h, PC_KKT, sb.st);
             // (same compact list / packed or pipelined kernel as the overlapped path)
-            int rr = h->use_dense ? launch_kkt_dense_newton(Sk, h->d_dense_ws, sb.st) : launch_kkt_packed(Sk, last_kkt, Sk.WQ.par ^ 1, sb.st);
+            int rr = h->use_dense ? launch_kkt_dense_newton(Sk, h->d_dense_ws, sb.st, h->use_banded) : launch_kkt_packed(Sk, last_kkt, Sk.WQ.par ^ 1, sb.st);
             prof_end(h, sb.st);
             if (rr != CIMPC_OK) return fail(h, rr, "kkt launch failed");
         }
@@ -935,7 +949,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             prof_begin(h, PC_KKT, sb.st_kkt);
             static const bool packed = !getenv("CIMPC_KKT_PACKED") || atoi(getenv("CIMPC_KKT_PACKED")) != 0;
             // the list was built by the residual kernel of the previous round (its queue parity)
-            int rk = h->use_dense ? launch_kkt_dense_newton(Sk, h->d_dense_ws, sb.st_kkt)
+            int rk = h->use_dense ? launch_kkt_dense_newton(Sk, h->d_dense_ws, sb.st_kkt, h->use_banded)
                                   : packed ? launch_kkt_packed(Sk, last_kkt, Sk.WQ.par ^ 1, sb.st_kkt, depth > 1 ? Sk.counters_next + 1 : nullptr)
                                            : launch_kkt(Sk, sb.st_kkt);
             prof_end(h, sb.st_kkt);

@@ -157,21 +157,193 @@ __global__ __launch_bounds__(256) void kkt_dense_kernel(NewtonDev S, KktArgs K, 
     }
 }
 
-size_t kkt_dense_workspace_doubles(const NewtonDev& S) {
+// ---------------------------------------------------------------------------------------------------------
+// Banded backend for :configuration + TrackingVelocityObjective (block-tridiagonal P: the condensed dual Schur
+// complement would be dense).  The same KKT matrix in the INTERLEAVED ordering [u_i, q_{i+2}, nu_i] per step
+// ("the form the HIP KKT kernel should factor") is symmetric, banded with half-bandwidth
+// w = 3 (nr + nd) - 1 - nu (row nu_i reaches back to q_i of step i-2) and quasi-definite (P > 0, -rho I < 0), so the
+// LDL^T factorization needs no pivoting in this order (measured on the oracle's jacobian!: |L| <= 1e2..1e4,
+// backward error 3e-15..3e-14).  One workgroup per rollout; the active (w+1) x (w+1) lower-triangular window of
+// the right-looking elimination lives in LDS (circular row / column slots, no data movement), every matrix row
+// is GENERATED when it enters the window (no assembled matrix in memory), the right-hand side rides along, the
+// rows of L go to a global workspace for the back substitution (one wavefront, axpy form, LDS window).
+// Work: N w^2 / 2 multiply-adds (centroidal H = 60: 25 M, against (2/3) N^3 = 16 G of the dense LU).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct BandRows {
+    const NewtonDev& S; const DenseLayout& L; const double* dzb; double rho; int s, nths;
+    // entry (i, j), j <= i, of the interleaved KKT matrix
+    __device__ double operator()(int i, int j) const {
+        const int nq = L.nq, nu = L.nu, nr = L.nr, nd = L.nd, H = L.H;
+        const int ti = i / s, ki = i - ti * s, tj = j / s, kj = j - tj * s;
+        const int dt = ti - tj;
+        if (ki < nu) {                                           // u row: R_t (same block only)
+            return (dt == 0 && kj < nu) ? S.R[(size_t)ti * nu * nu + (size_t)kj * nu + ki] : 0.0;
+        }
+        if (ki < nr) {                                           // q row
+            const int kq = ki - nu;
+            if (kj < nu || kj >= nr) return 0.0;                 // (lower part: no dual columns before a q row)
+            const int cq = kj - nu;
+            const size_t e = (size_t)cq * nq + kq;
+            if (dt == 0) {
+                double v = S.Q[(size_t)ti * nq * nq + e];
+                if (S.V != nullptr) {
+                    v += S.V[(size_t)ti * nq * nq + e];
+                    if (ti + 1 < H) v += S.V[(size_t)(ti + 1) * nq * nq + e];
+                }
+                return v;
+            }
+            if (dt == 1 && S.V != nullptr) return -S.V[(size_t)ti * nq * nq + e];
+            return 0.0;
+        }
+        const int kd = ki - nr;                                  // dual row nu_t
+        const double* dz = dzb + (size_t)ti * nths * nd;
+        if (dt == 0) {
+            if (kj < nu) return dz[(size_t)(2 * nq + kj) * nd + kd];          // du1
+            if (kj < nr) return (kj - nu == kd) ? -1.0 : 0.0;                 // -I at q_{t+2}
+            return (kj == ki) ? -rho : 0.0;
+        }
+        if (kj < nu || kj >= nr) return 0.0;
+        if (dt == 1) return dz[(size_t)(nq + kj - nu) * nd + kd];             // dq1 at q_{t+1}
+        if (dt == 2) return dz[(size_t)(kj - nu) * nd + kd];                  // dq0 at q_t
+        return 0.0;
+    }
+};
+}  // namespace
+
+__global__ __launch_bounds__(256) void kkt_banded_kernel(NewtonDev S, KktArgs K, double* ws_all) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int b = blockIdx.x + S.b0, tid = threadIdx.x, nt = blockDim.x;
+    if (K.stage != nullptr && K.stage[b] != STAGE_KKT) return;
+    const DenseLayout L(S);
+    const int N = L.N, H = L.H, nr = L.nr, nd = L.nd, s = nr + nd;
+    const int w = min(3 * s - 1 - L.nu, N - 1), M = w + 1;
+    double* Lr = ws_all + (size_t)b * ((size_t)N * M + N);       // row i: L[i][i-w .. i-1], slot w: d_i
+    double* yg = Lr + (size_t)N * M;
+    double* W = sm;                                              // [M][M] window, slot = index mod M
+    double* yw = W + (size_t)M * M;                              // [M]
+    double* lv = yw + M;                                         // [M]: lv[0] = d_k, lv[r] = L[k+r][k]
+    const double beta = K.beta ? K.beta[b] : K.beta_scalar;
+    const double rho = (double)H * beta * S.kappa;               // newton_jacobian.jl:169-186 quirk
+    const double* dzb = K.stage ? S.dz_good + (size_t)b * H * S.nths * nd : S.dz + (size_t)b * CS * H * S.nths * nd;
+    const BandRows row{S, L, dzb, rho, s, S.nths};
+    const double* rb = K.r + (size_t)b * S.N;
+    // interleaved index -> index in the reference's layout (primal segment step-major, then the duals)
+    auto orig = [&](int i) { const int t = i / s, k = i - t * s; return k < nr ? t * nr + k : H * nr + t * nd + (k - nr); };
+    auto load_row = [&](int i) {                                 // row i enters the window (columns i-w .. i)
+        const int si = i % M;
+        for (int c = tid; c <= w; c += nt) {
+            const int j = i - w + c;
+            if (j >= 0) W[(size_t)si * M + j % M] = row(i, j);
+        }
+        if (tid == 0) yw[si] = rb[orig(i)];
+    };
+    for (int i = 0; i <= w && i < N; ++i) load_row(i);
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    for (int k = 0; k < N; ++k) {
+        const int sk = k % M, m = min(w, N - 1 - k);             // rows k+1 .. k+m are coupled to the pivot
+        {
+            const double d = W[(size_t)sk * M + sk], inv = 1.0 / d;
+            for (int r = tid; r <= m; r += nt) {
+                int sr = sk + r; if (sr >= M) sr -= M;
+                const double v = r == 0 ? d : W[(size_t)sr * M + sk] * inv;
+                lv[r] = v;
+                Lr[(size_t)(k + r) * M + (w - r)] = v;           // r = 0: the pivot on the diagonal slot
+            }
+        }
+        __syncthreads();
+        {
+            const double d = lv[0], yk = yw[sk];
+            for (int ri = 1 + ty; ri <= m; ri += 16) {
+                int si = sk + ri; if (si >= M) si -= M;
+                const double li = lv[ri] * d;
+                double* Wi = W + (size_t)si * M;
+                for (int rj = 1 + tx; rj <= ri; rj += 16) {
+                    int sj = sk + rj; if (sj >= M) sj -= M;
+                    Wi[sj] = fma(-li, lv[rj], Wi[sj]);
+                }
+                if (tx == 0) yw[si] = fma(-lv[ri], yk, yw[si]);
+            }
+            if (tid == 0) yg[k] = yk;
+        }
+        __syncthreads();
+        if (k + M < N) load_row(k + M);                          // takes the slots the pivot row / column just freed
+        __syncthreads();
+    }
+    // ---- back substitution  L^T x = D^-1 y  (wavefront 0; acc[j] collects sum_{i > j} L[i][j] x_i) ---------
+    double* D = K.delta + (size_t)b * S.N;
+    if (tid < 64) {
+        double* acc = yw;                                        // reuse: [M]
+        for (int c = tid; c < M; c += 64) acc[c] = 0.0;
+        __builtin_amdgcn_wave_barrier();
+        double pre[3] = {0.0, 0.0, 0.0};
+        auto fetch = [&](int i) {
+            if (i < 0) return;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { const int c = tid + 64 * q; pre[q] = c <= w ? Lr[(size_t)i * M + c] : 0.0; }
+        };
+        fetch(N - 1);
+        for (int i = N - 1; i >= 0; --i) {
+            double cur[3] = {pre[0], pre[1], pre[2]};
+            fetch(i - 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int si = i % M;
+            // the pivot d_i sits at c = w: lane (w % 64), register (w / 64)
+            double di = 0.0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) if (w / 64 == q) di = __shfl(cur[q], w % 64, 64);
+            const double xi = yg[i] / di - acc[si];
+            __builtin_amdgcn_wave_barrier();
+            if (tid == 0) { acc[si] = 0.0; D[orig(i)] = xi; }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int c = tid + 64 * q, j = i - w + c;
+                if (c < w && j >= 0) acc[j % M] = fma(cur[q], xi, acc[j % M]);
+            }
+        }
+    }
+    __syncthreads();
+    if (K.finish) {
+        __threadfence_block();
+        start_line_search<BlockSync>(S, b, 1, tid, nt);
+    }
+}
+
+static int band_halfwidth(const NewtonDev& S) {
+    const int s = S.nr + S.nd;
+    return std::min(3 * s - 1 - S.dm.nu, S.N - 1);
+}
+bool kkt_banded_available(const NewtonDev& S) {      // window + two vectors in 160 KB of LDS, back substitution: w < 192
+    const int M = band_halfwidth(S) + 1;
+    return S.dm.mode == CIMPC_MODE_CONFIGURATION && M <= 192 && ((size_t)M * M + 2 * (size_t)M) * sizeof(double) <= 160 * 1024;
+}
+
+size_t kkt_dense_workspace_doubles(const NewtonDev& S, bool banded) {
+    if (banded) return (size_t)S.dm.B * ((size_t)S.N * (band_halfwidth(S) + 1) + (size_t)S.N);
     return (size_t)S.dm.B * ((size_t)S.N * S.N + 2 * (size_t)S.N);
 }
 
-static int launch_kkt_dense(const NewtonDev& S, const KktArgs& K, double* ws, hipStream_t s) {
+static int launch_kkt_dense(const NewtonDev& S, const KktArgs& K, double* ws, hipStream_t s, bool banded) {
+    if (banded) {
+        const int M = band_halfwidth(S) + 1;
+        const size_t lds = ((size_t)M * M + 2 * (size_t)M) * sizeof(double);
+        static LdsOptIn optin;
+        if (lds_opt_in(optin, (const void*)kkt_banded_kernel, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
+        hipLaunchKernelGGL(kkt_banded_kernel, dim3(S.nb_launch), dim3(256), lds, s, S, K, ws);
+        return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+    }
     hipLaunchKernelGGL(kkt_dense_kernel, dim3(S.nb_launch), dim3(256), 0, s, S, K, ws);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
-int launch_kkt_dense_newton(const NewtonDev& S, double* ws, hipStream_t s) {
+int launch_kkt_dense_newton(const NewtonDev& S, double* ws, hipStream_t s, bool banded) {
     KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 1};
-    return launch_kkt_dense(S, K, ws, s);
+    return launch_kkt_dense(S, K, ws, s, banded);
 }
-int launch_kkt_dense_raw(const NewtonDev& S, const double* r_dev, double beta, double* delta_dev, double* ws, hipStream_t s) {
+int launch_kkt_dense_raw(const NewtonDev& S, const double* r_dev, double beta, double* delta_dev, double* ws, hipStream_t s, bool banded) {
     KktArgs K{r_dev, delta_dev, nullptr, beta, nullptr, 0};
-    return launch_kkt_dense(S, K, ws, s);
+    return launch_kkt_dense(S, K, ws, s, banded);
 }
 
 }  // namespace cimpc

@@ -100,9 +100,10 @@ int launch_kkt(const NewtonDev& nd, hipStream_t s);
 // packed variant: n_kkt rollouts from kkt_list[list_par], KKT_PACK per workgroup (dedicates whole CUs to the recursion)
 int launch_kkt_packed(const NewtonDev& nd, int n_kkt, int list_par, hipStream_t s, const int* n_dev = nullptr);
 // reference-default backend (dense jacobian! + LU with partial pivoting), any mode / objective (kkt_dense.hip)
-size_t kkt_dense_workspace_doubles(const NewtonDev& S);
-int launch_kkt_dense_newton(const NewtonDev& S, double* ws, hipStream_t s);
-int launch_kkt_dense_raw(const NewtonDev& S, const double* r_dev, double beta, double* delta_dev, double* ws, hipStream_t s);
+size_t kkt_dense_workspace_doubles(const NewtonDev& S, bool banded);
+int launch_kkt_dense_newton(const NewtonDev& S, double* ws, hipStream_t s, bool banded);
+bool kkt_banded_available(const NewtonDev& S);
+int launch_kkt_dense_raw(const NewtonDev& S, const double* r_dev, double beta, double* delta_dev, double* ws, hipStream_t s, bool banded);
 // B1 seam: solve with caller-provided residual / beta for all rollouts, no state change
 int launch_kkt_raw(const NewtonDev& nd, const double* r_dev, double beta, double* delta_dev,
                    hipStream_t s);

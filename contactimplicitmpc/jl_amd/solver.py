@@ -44,7 +44,7 @@ class NewtonOptions:
     beta_init: float = 1.0e-5
     max_time: float = 0.0
     kappa: float = 2.0e-4
-    kkt_backend: int = 0      # 0 condensed (falls back to dense LU where it does not apply), 1 dense LU (reference default)
+    kkt_backend: int = 0      # 0 auto: condensed MFMA solve (TrackingObjective), banded LDL^T (velocity objective), dense LU (:configurationforce); 1 dense LU (reference default); 2 banded LDL^T (:configuration, any objective)
 
 
 def _dp(a):

@@ -36,9 +36,13 @@ extern "C" {
 
 #define CIMPC_KKT_CONDENSED 0  /* dual Schur complement + block Cholesky (structure of
                                   newton_structure_solver/methods.jl:386-557); :configuration
-                                  mode + TrackingObjective, otherwise the dense LU is used */
+                                  mode + TrackingObjective; with a TrackingVelocityObjective the banded LDL^T
+                                  below, in :configurationforce mode the dense LU is used */
 #define CIMPC_KKT_DENSE_LU 1   /* reference default: dense jacobian! + LU with partial pivoting
                                   (newton.jl:10,218; lu.jl:4-12), any mode / objective     */
+#define CIMPC_KKT_BANDED_LDL 2 /* :configuration mode, any objective: the KKT matrix in the interleaved ordering
+                                  [u_i, q_{i+2}, nu_i] (banded, quasi-definite) factored L D L^T without pivoting;
+                                  the :ldl_solver analogue (ldl.jl:144-149) for block-tridiagonal P              */
 
 typedef struct cimpc_ctx* cimpc_handle;
 

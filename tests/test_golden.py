@@ -68,14 +68,18 @@ def test_hip_reproduces_golden(gpu_required, path):
                         q_target=opt("obj_q_target"), v_target=opt("obj_v_target"))
         u1, it, rn = s.newton_solve(g["q0"], g["q1"])
         tr = s.trajectory(); cnt = s.rollout_counters()
-        assert np.array_equal(it, g["newton_iters"])
+        # (velocity objective / :configurationforce: the residual of a converged rollout sits at the noise floor of the
+        #  interior-point solves, a few 1e-6 against r_tol = 1e-5 - the dense-LU and the banded LDL^T backend, whose
+        #  steps agree to 1e-14, already stop one iteration apart on one rollout of the velocity fixture)
+        noisy = d.mode == 1 or "obj_v" in g.files
+        assert np.array_equal(it, g["newton_iters"]) or (noisy and (it == g["newton_iters"]).sum() >= B - 1)
         # A converged interior-point solve is unique only up to kappa_tol, and one roundoff-level flip of an
         # iteration count moves the rollout's path; such a rollout is recognisable by its
         # counters or, when those coincide by chance, by its trajectory.  At most one of the B may differ.
         good = 0
         for b in range(B):
             dense = d.mode == 1 or "obj_v" in g.files      # dense-LU KKT: the final (tiny) residual moves with roundoff
-            ok_b = (cnt["ip_iters"][b] == g["newton_ip_iters"][b]
+            ok_b = (it[b] == g["newton_iters"][b] and cnt["ip_iters"][b] == g["newton_ip_iters"][b]
                     and np.abs(tr["q"][b] - g["newton_q"][b]).max() < 1e-7
                     and np.abs(tr["u"][b] - g["newton_u"][b]).max() < 1e-7
                     and np.abs(rn[b] - g["newton_rnorm"][b]) < (1e-3 if dense else 1e-6) * max(1e-6, g["newton_rnorm"][b]) + 1e-12)

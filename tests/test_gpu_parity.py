@@ -179,7 +179,11 @@ def test_kkt_solve_matches_dense_lu(gpu_required, model, H, H_ref):
     ("quadruped", 0, False, 1),     # :configuration through the reference-default backend
     ("pushbot", 1, False, 0),       # BASELINE configs[0] dimensions, :configurationforce (policy.jl:46 default)
     ("hopper", 1, True, 0),         # :configurationforce + TrackingVelocityObjective
-    ("hopper", 0, True, 0),         # velocity objective in :configuration mode (v_target terms)
+    ("hopper", 0, True, 1),         # velocity objective in :configuration mode (v_target terms), dense LU on request
+    ("hopper", 0, True, 0),         # ... and through the backend the library picks for it: banded LDL^T
+    ("quadruped", 0, True, 0),      # banded LDL^T, w = 81
+    ("quadruped", 0, False, 2),     # banded LDL^T on request for a TrackingObjective
+    ("centroidal", 0, True, 0),     # banded LDL^T, w = 131 (139 KB window in LDS)
 ])
 def test_kkt_dense_lu_backend(gpu_required, model, mode, velocity, backend):
     """B1 seam through kkt_dense.hip: dense jacobian! + LU with partial pivoting (the reference default
@@ -210,8 +214,13 @@ def test_kkt_dense_lu_backend(gpu_required, model, mode, velocity, backend):
             R = onewton.jacobian(lay, obj, im, beta, prob["kappa"])
             x = np.linalg.solve(R, r[b])
             back = np.abs(R @ delta[b] - r[b]).max() / (np.abs(R).sum(axis=1).max() * np.abs(delta[b]).max() + np.abs(r[b]).max())
-            assert back < 1e-13, back             # backward stable (lu.jl's own test pins the residual to 1e-10)
-            np.testing.assert_allclose(delta[b], x, rtol=0, atol=1e-13 * np.linalg.cond(R) * max(1.0, np.abs(x).max()))
+            # dense LU with partial pivoting: backward stable; the banded LDL^T runs WITHOUT pivoting (quasi-definite
+            # matrix, interleaved order): its backward error carries the growth of L (1e2 .. 1e4 here) - both far
+            # inside the 1e-10 residual lu.jl's own test asks for
+            banded = mode == 0 and backend != 1 and (velocity or backend == 2)
+            tol = 1e-11 if banded else 1e-13
+            assert back < tol, back
+            np.testing.assert_allclose(delta[b], x, rtol=0, atol=tol * np.linalg.cond(R) * max(1.0, np.abs(x).max()))
 
 
 @pytest.mark.parametrize("model,mode,velocity", [("hopper", 1, False), ("quadruped", 1, False), ("hopper", 0, True)])
