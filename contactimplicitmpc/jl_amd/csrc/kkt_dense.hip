@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void kkt_dense_kernel(NewtonDev S, KktArgs K, 
 // complement would be dense).  The same KKT matrix in the INTERLEAVED ordering [u_i, q_{i+2}, nu_i] per step
 // ("the form the HIP KKT kernel should factor") is symmetric, banded with half-bandwidth
 // w = 3 (nr + nd) - 1 - nu (row nu_i reaches back to q_i of step i-2) and quasi-definite (P > 0, -rho I < 0), so the
-// LDL^T factorization needs no pivoting in this order (measured on the oracle's jacobian!: |L| <= 1e2..1e4,
+// LDL^T factorization needs no pivoting in this order (measured on assembled jacobian! matrices: |L| <= 1e2..1e4,
 // backward error 3e-15..3e-14).  One workgroup per rollout; the active (w+1) x (w+1) lower-triangular window of
 // the right-looking elimination lives in LDS (circular row / column slots, no data movement), every matrix row
 // is GENERATED when it enters the window (no assembled matrix in memory), the right-hand side rides along, the
