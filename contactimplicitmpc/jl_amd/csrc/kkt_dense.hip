@@ -211,7 +211,18 @@ struct BandRows {
 };
 }  // namespace
 
-__global__ __launch_bounds__(256) void kkt_banded_kernel(NewtonDev S, KktArgs K, double* ws_all) {
+// Workgroup barrier that waits for the wave's LDS traffic only: the pivots hand data over through LDS, while
+// the global stores of the factor rows and the prefetch loads of the next matrix row stay in flight across
+// them (a __syncthreads() waits for vmcnt(0) too - measured 6.4 us per pivot, almost all of it store / load
+// latency at the two barriers).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+#ifndef CIMPC_BANDED_THREADS
+#define CIMPC_BANDED_THREADS 1024
+#endif
+__global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(NewtonDev S, KktArgs K, double* ws_all) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int b = blockIdx.x + S.b0, tid = threadIdx.x, nt = blockDim.x;
     if (K.stage != nullptr && K.stage[b] != STAGE_KKT) return;
@@ -220,8 +231,9 @@ __global__ __launch_bounds__(256) void kkt_banded_kernel(NewtonDev S, KktArgs K,
     const int w = min(3 * s - 1 - L.nu, N - 1), M = w + 1;
     double* Lr = ws_all + (size_t)b * ((size_t)N * M + N);       // row i: L[i][i-w .. i-1], slot w: d_i
     double* yg = Lr + (size_t)N * M;
-    double* W = sm;                                              // [M][M] window, slot = index mod M
-    double* yw = W + (size_t)M * M;                              // [M]
+    const int MS = M + 1;                                        // row stride: slot M is a dummy row / column
+    double* W = sm;                                              // [M+1][M+1] window, slot = index mod M; BOTH triangles kept
+    double* yw = W + (size_t)MS * MS;                            // [M]
     double* lv = yw + M;                                         // [M]: lv[0] = d_k, lv[r] = L[k+r][k]
     const double beta = K.beta ? K.beta[b] : K.beta_scalar;
     const double rho = (double)H * beta * S.kappa;               // newton_jacobian.jl:169-186 quirk
@@ -230,77 +242,121 @@ __global__ __launch_bounds__(256) void kkt_banded_kernel(NewtonDev S, KktArgs K,
     const double* rb = K.r + (size_t)b * S.N;
     // interleaved index -> index in the reference's layout (primal segment step-major, then the duals)
     auto orig = [&](int i) { const int t = i / s, k = i - t * s; return k < nr ? t * nr + k : H * nr + t * nd + (k - nr); };
-    auto load_row = [&](int i) {                                 // row i enters the window (columns i-w .. i)
-        const int si = i % M;
-        for (int c = tid; c <= w; c += nt) {
-            const int j = i - w + c;
-            if (j >= 0) W[(size_t)si * M + j % M] = row(i, j);
-        }
-        if (tid == 0) yw[si] = rb[orig(i)];
+    // row i enters the window (columns i-w .. i): a row has at most w + 1 <= 192 entries - one per thread; the
+    // value is FETCHED one pivot ahead (global loads of the sensitivities / weights stay off the critical path)
+    auto row_value = [&](int i) -> double {
+        if (i >= N) return 0.0;
+        if (tid <= w) { const int j = i - w + tid; return j >= 0 ? row(i, j) : 0.0; }
+        return tid == w + 1 ? rb[orig(i)] : 0.0;                 // thread w + 1 carries the right-hand side entry
     };
-    for (int i = 0; i <= w && i < N; ++i) load_row(i);
+    auto row_commit = [&](int i, double v) {
+        if (i >= N) return;
+        const int si = i % M;
+        if (tid <= w) {
+            const int j = i - w + tid;
+            if (j >= 0) { const int sj = j % M; W[(size_t)si * MS + sj] = v; W[(size_t)sj * MS + si] = v; }   // and its mirror image
+        } else if (tid == w + 1) yw[si] = v;
+    };
+    for (int i = 0; i <= w && i < N; ++i) row_commit(i, row_value(i));
     __syncthreads();
-    const int tx = tid & 15, ty = tid >> 4;
+    const int tx = tid & 63, ty = tid >> 6, nty = nt >> 6;       // update: column 1 + tx + 64 q of row 1 + ty + nty p
+    double nxt = row_value(M);                                   // row entering after pivot 0
     for (int k = 0; k < N; ++k) {
         const int sk = k % M, m = min(w, N - 1 - k);             // rows k+1 .. k+m are coupled to the pivot
         {
-            const double d = W[(size_t)sk * M + sk], inv = 1.0 / d;
+            const double d = W[(size_t)sk * MS + sk], inv = 1.0 / d, yk = yw[sk];
             for (int r = tid; r <= m; r += nt) {
                 int sr = sk + r; if (sr >= M) sr -= M;
-                const double v = r == 0 ? d : W[(size_t)sr * M + sk] * inv;
+                const double v = r == 0 ? d : W[(size_t)sr * MS + sk] * inv;
                 lv[r] = v;
                 Lr[(size_t)(k + r) * M + (w - r)] = v;           // r = 0: the pivot on the diagonal slot
+                if (r == 0) yg[k] = yk;
+                else yw[sr] = fma(-v, yk, yw[sr]);               // forward substitution rides along
             }
         }
-        __syncthreads();
+        lds_barrier();
+        const double nxt2 = row_value(k + M + 1);                // fetch for the NEXT pivot while this one updates
         {
-            const double d = lv[0], yk = yw[sk];
-            for (int ri = 1 + ty; ri <= m; ri += 16) {
-                int si = sk + ri; if (si >= M) si -= M;
-                const double li = lv[ri] * d;
-                double* Wi = W + (size_t)si * M;
-                for (int rj = 1 + tx; rj <= ri; rj += 16) {
-                    int sj = sk + rj; if (sj >= M) sj -= M;
-                    Wi[sj] = fma(-li, lv[rj], Wi[sj]);
-                }
-                if (tx == 0) yw[si] = fma(-lv[ri], yk, yw[si]);
+            // rank-1 update of the whole (symmetric) m x m window, branch-free: a wavefront takes 64 consecutive
+            // columns of a row, lanes beyond the coupled rows / columns work on the dummy slot with a zero multiplier.
+            // The loop is instruction-issue bound (address + load + fma + store per entry and one wavefront's issue
+            // rate), not LDS bound: 256 / 512 / 1024 threads -> 18.6 / 12.4 / 9.3 ms per centroidal H = 50 solve
+            // (N = 2400, w = 131); blocking several pivots per window update is the next step.
+            const double d = lv[0];
+            const int nq = (m + 63) >> 6;                        // uniform: column chunks of 64
+            double lj[3];
+            int sjv[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int r = 1 + tx + 64 * q;
+                const bool on = r <= m;
+                lj[q] = on ? lv[on ? r : 0] : 0.0;
+                int sj = sk + r; if (sj >= M) sj -= M;
+                sjv[q] = on ? sj : M;
             }
-            if (tid == 0) yg[k] = yk;
+            for (int r0 = 1 + ty; r0 <= m; r0 += 4 * nty) {      // four rows per trip: their loads are issued together
+                double li[4], t[4][3];
+                double* Wi[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = r0 + nty * u;
+                    const bool on = r <= m;
+                    li[u] = on ? lv[on ? r : 0] * d : 0.0;
+                    int si = sk + r; if (si >= M) si -= M;
+                    Wi[u] = W + (size_t)(on ? si : M) * MS;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) if (q < nq) t[u][q] = Wi[u][sjv[q]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) if (q < nq) Wi[u][sjv[q]] = fma(-li[u], lj[q], t[u][q]);
+            }
         }
-        __syncthreads();
-        if (k + M < N) load_row(k + M);                          // takes the slots the pivot row / column just freed
-        __syncthreads();
+        lds_barrier();
+        row_commit(k + M, nxt);                                  // takes the slots the pivot row / column just freed
+        nxt = nxt2;
+        lds_barrier();
     }
+    __syncthreads();              // full barrier: the rows of L and y in global memory are read back below
     // ---- back substitution  L^T x = D^-1 y  (wavefront 0; acc[j] collects sum_{i > j} L[i][j] x_i) ---------
     double* D = K.delta + (size_t)b * S.N;
     if (tid < 64) {
         double* acc = yw;                                        // reuse: [M]
         for (int c = tid; c < M; c += 64) acc[c] = 0.0;
         __builtin_amdgcn_wave_barrier();
-        double pre[3] = {0.0, 0.0, 0.0};
-        auto fetch = [&](int i) {
-            if (i < 0) return;
+        // the rows of L come from global memory: a ring of PD rows in flight (one wavefront, nothing else to hide the latency)
+        constexpr int PD = 8;
+        double pre[PD][3], pre_y[PD];
+        auto fetch = [&](int i, int slot) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) { const int c = tid + 64 * q; pre[q] = c <= w ? Lr[(size_t)i * M + c] : 0.0; }
+            for (int q = 0; q < 3; ++q) { const int c = tid + 64 * q; pre[slot][q] = (i >= 0 && c <= w) ? Lr[(size_t)i * M + c] : 0.0; }
+            pre_y[slot] = i >= 0 ? yg[i] : 0.0;
         };
-        fetch(N - 1);
-        for (int i = N - 1; i >= 0; --i) {
-            double cur[3] = {pre[0], pre[1], pre[2]};
-            fetch(i - 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            const int si = i % M;
-            // the pivot d_i sits at c = w: lane (w % 64), register (w / 64)
-            double di = 0.0;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) if (w / 64 == q) di = __shfl(cur[q], w % 64, 64);
-            const double xi = yg[i] / di - acc[si];
-            __builtin_amdgcn_wave_barrier();
-            if (tid == 0) { acc[si] = 0.0; D[orig(i)] = xi; }
+        for (int u = 0; u < PD; ++u) fetch(N - 1 - u, u);
+        for (int i0 = N - 1; i0 >= 0; i0 -= PD) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int c = tid + 64 * q, j = i - w + c;
-                if (c < w && j >= 0) acc[j % M] = fma(cur[q], xi, acc[j % M]);
+            for (int u = 0; u < PD; ++u) {
+                const int i = i0 - u;
+                const double cur[3] = {pre[u][0], pre[u][1], pre[u][2]}, yi = pre_y[u];
+                fetch(i - PD, u);
+                if (i < 0) continue;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const int si = i % M;
+                // the pivot d_i sits at c = w: lane (w % 64), register (w / 64)
+                double di = 0.0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) if (w / 64 == q) di = __shfl(cur[q], w % 64, 64);
+                const double xi = yi / di - acc[si];
+                __builtin_amdgcn_wave_barrier();
+                if (tid == 0) { acc[si] = 0.0; D[orig(i)] = xi; }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int c = tid + 64 * q, j = i - w + c;
+                    if (c < w && j >= 0) acc[j % M] = fma(cur[q], xi, acc[j % M]);
+                }
             }
         }
     }
@@ -317,7 +373,7 @@ static int band_halfwidth(const NewtonDev& S) {
 }
 bool kkt_banded_available(const NewtonDev& S) {      // window + two vectors in 160 KB of LDS, back substitution: w < 192
     const int M = band_halfwidth(S) + 1;
-    return S.dm.mode == CIMPC_MODE_CONFIGURATION && M <= 192 && ((size_t)M * M + 2 * (size_t)M) * sizeof(double) <= 160 * 1024;
+    return S.dm.mode == CIMPC_MODE_CONFIGURATION && M <= 192 && ((size_t)(M + 1) * (M + 1) + 2 * (size_t)M) * sizeof(double) <= 160 * 1024;
 }
 
 size_t kkt_dense_workspace_doubles(const NewtonDev& S, bool banded) {
@@ -328,10 +384,10 @@ size_t kkt_dense_workspace_doubles(const NewtonDev& S, bool banded) {
 static int launch_kkt_dense(const NewtonDev& S, const KktArgs& K, double* ws, hipStream_t s, bool banded) {
     if (banded) {
         const int M = band_halfwidth(S) + 1;
-        const size_t lds = ((size_t)M * M + 2 * (size_t)M) * sizeof(double);
+        const size_t lds = ((size_t)(M + 1) * (M + 1) + 2 * (size_t)M) * sizeof(double);
         static LdsOptIn optin;
         if (lds_opt_in(optin, (const void*)kkt_banded_kernel, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
-        hipLaunchKernelGGL(kkt_banded_kernel, dim3(S.nb_launch), dim3(256), lds, s, S, K, ws);
+        hipLaunchKernelGGL(kkt_banded_kernel, dim3(S.nb_launch), dim3(CIMPC_BANDED_THREADS), lds, s, S, K, ws);
         return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
     }
     hipLaunchKernelGGL(kkt_dense_kernel, dim3(S.nb_launch), dim3(256), 0, s, S, K, ws);

@@ -66,3 +66,29 @@ for B in (1, 64, 512):
     print("REAL centroidal inplace_trot_v7 H=50 B=%d: %.2f ms per batch step, %.0f MPC steps/s, newton iters/step %.2f, ip iters/solve %.2f, ip failures %d"
           % (B, 1e3 * dt, B / dt, it.mean(), st["ip_iters"] / max(st["ip_solves"], 1), st["ip_failures"]))
     s.close()
+
+# ---- ... and with the example's OWN objective (continuous_trot.jl:43-47: TrackingVelocityObjective, Q singular along a
+# common x shift): block-tridiagonal P -> banded LDL^T KKT backend (kkt_dense.hip: kkt_banded_kernel), lock-step rounds
+Qx = np.tile(lcp_models.relative_state_cost([0.0, 1, 1], 3e-1 * np.ones(3), [0.2, 0.2, 1.0])[None], (H, 1, 1))
+Vx = np.tile(np.diag(1e-3 * np.concatenate([np.ones(3), 1e3 * np.ones(3), np.ones(12)]))[None], (H, 1, 1))
+for B in (1, 64, 512):
+    ro = [lcp_models.make_rollout(P, H, int(np.random.default_rng(g).integers(0, P.H)), seed=100 + g, perturb=0.01) for g in range(B)]
+    s = CIMPCSolver(m.nq, m.nu, m.nw, m.nc, m.nb, P.H, H, B=B, mode=0, ip_opts=InteriorPointOptions(kappa_tol=1e-3, r_tol=1e-4),
+                    newton_opts=NewtonOptions(kappa=1e-3, r_tol=3e-5, max_iter=5))
+    for t in range(P.H):
+        s.set_linearization(t + 1, P.z[t], P.theta[t], P.r0[t], P.rz0[t], P.rth0[t])
+    s.set_objective(Qx, R, V=Vx, v_target=np.zeros((H, m.nq)))
+    s.set_window(np.stack([r["window"] for r in ro]) + 1)
+    s.set_reference(*(np.stack([r[k] for r in ro]) for k in ("q", "u", "w", "gamma", "b", "theta")))
+    q0 = np.stack([r["q0"] for r in ro]); q1 = np.stack([r["q1"] for r in ro])
+    s.newton_solve(q0, q1)
+    s.profile_enable(True); s.profile_reset()
+    n = 3 if B > 1 else 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        u1, it, rn = s.newton_solve(q0, q1)
+    dt = (time.perf_counter() - t0) / n
+    st = s.stats(); pr = s.profile_read()
+    print("REAL centroidal, example objective (velocity, banded LDL^T) H=50 B=%d: %.2f ms per batch step, %.0f MPC steps/s, newton iters/step %.2f, "
+          "kkt %.2f ms in %d launches, ip failures %d" % (B, 1e3 * dt, B / dt, it.mean(), pr["kkt_ms"] / n, pr["kkt_launches"] // n, st["ip_failures"]))
+    s.close()

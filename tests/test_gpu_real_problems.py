@@ -36,15 +36,27 @@ def test_reference_implicit_dynamics_test_on_device(gpu_required):
 @pytest.mark.parametrize("which,kappa,H,B,perturb,ip_rtol,n_rtol", [
     ("quadruped", 2e-4, 40, 8, 0.05, 1e-8, 3e-4),       # BASELINE configs[2/3] on the true problem (mpc_quadruped.jl:19-47)
     ("centroidal", 1e-3, 50, 4, 0.02, 1e-4, 3e-5),      # continuous_trot.jl:31-73 (H_mpc = 50; tracking part of the objective)
+    ("centroidal_velocity", 1e-3, 50, 3, 0.01, 1e-4, 3e-5),   # ... with the example's OWN TrackingVelocityObjective (:43-47)
 ])
 def test_newton_solve_on_real_problems(gpu_required, which, kappa, H, B, perturb, ip_rtol, n_rtol):
     from contactimplicitmpc.jl_amd import InteriorPointOptions, NewtonOptions, lcp_models
+    velocity = which.endswith("_velocity")
+    which = which.split("_")[0]
     d, P, prob, tabs = real_problem(which, kappa)
     H_ref = P.H
     rng = np.random.default_rng(4)
     rollouts = [real_rollout(d, prob, H, int(rng.integers(0, H_ref)), seed=10 + b, perturb=perturb) for b in range(B)]
     if which == "quadruped":
         obj = synth.make_objective(d, H, kind="quadruped")
+    elif velocity:
+        # continuous_trot.jl:43-47: Q singular along a common x shift, made definite by the velocity term - the banded
+        # LDL^T backend (block-tridiagonal P); the oracle solves the dense KKT system by LU
+        obj = synth.make_objective(d, H, kind="quadruped", velocity=True)
+        obj.q = np.tile(lcp_models.relative_state_cost([0.0, 1, 1], 3e-1 * np.ones(3), [0.2, 0.2, 1.0])[None], (H, 1, 1))
+        obj.u = np.tile((3e-3 * np.eye(d.nu))[None], (H, 1, 1))
+        obj.v = np.tile(np.diag(1e-3 * np.concatenate([np.ones(3), 1e3 * np.ones(3), np.ones(12)]))[None], (H, 1, 1))
+        obj.v_target = np.zeros((H, d.nq)); obj.q_target = None
+        obj.__post_init__()
     else:
         obj = synth.make_objective(d, H, kind="quadruped")
         # the example's body-x weight is 0 (Q singular along a common x shift; its velocity term restores definiteness,
@@ -65,7 +77,7 @@ def test_newton_solve_on_real_problems(gpu_required, which, kappa, H, B, perturb
     # (1e-6), all of them within the amplification band.
     tight = 0
     for b, (window, ref, q0, q1) in enumerate(rollouts):
-        core = onewton.Newton(d, H, obj, onewton.NewtonOptions(r_tol=n_rtol, max_iter=5, solver="condensed"),
+        core = onewton.Newton(d, H, obj, onewton.NewtonOptions(r_tol=n_rtol, max_iter=5, solver="lu" if velocity else "condensed"),
                               oip.IPOptions(kappa_tol=kappa, r_tol=ip_rtol), kappa, ref)
         st = onewton.newton_solve(core, q0, q1, window, tabs, ref)
         assert it[b] == st.iters, (b, it[b], st.iters)
