@@ -341,7 +341,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         delete h;
         return fail(nullptr, CIMPC_ERR_INVALID,
                     "no kernel instantiation for these model dimensions (pushbot, hopper_2D, "
-                    "quadruped, centroidal_quadruped are built)");
+                    "quadruped, flamingo, centroidal_quadruped are built)");
     }
     h->nx = d.nq;
     h->ny = 2 * d.nc + d.nb;

@@ -8,6 +8,7 @@ namespace cimpc {
     X(pushbot, 2, 2, 2, 2, 4)                \
     X(hopper, 4, 2, 2, 1, 2)                 \
     X(quadruped, 11, 8, 2, 4, 8)             \
+    X(flamingo, 9, 6, 2, 4, 8)               \
     X(centroidal, 18, 12, 3, 4, 16)
 
 #define X(name, q, u, w, c, b)                                                               \
@@ -40,6 +41,7 @@ int launch_ip_sweep(const cimpc_dims* dm, const IpParams& p, int waves, hipStrea
 int async_launch_pushbot(const IpParams& p, const NewtonDev& S, int waves, int grid, hipStream_t s);
 int async_launch_hopper(const IpParams& p, const NewtonDev& S, int waves, int grid, hipStream_t s);
 int async_launch_quadruped(const IpParams& p, const NewtonDev& S, int waves, int grid, hipStream_t s);
+int async_launch_flamingo(const IpParams& p, const NewtonDev& S, int waves, int grid, hipStream_t s);
 int async_launch_centroidal(const IpParams& p, const NewtonDev& S, int waves, int grid, hipStream_t s);
 
 bool newton_async_available(const cimpc_dims* dm) {
@@ -47,6 +49,7 @@ bool newton_async_available(const cimpc_dims* dm) {
     return (dm->nq == 2 && dm->nu == 2 && dm->nw == 2 && dm->nc == 2 && dm->nb == 4) ||
            (dm->nq == 4 && dm->nu == 2 && dm->nw == 2 && dm->nc == 1 && dm->nb == 2) ||
            (dm->nq == 11 && dm->nu == 8 && dm->nw == 2 && dm->nc == 4 && dm->nb == 8) ||
+           (dm->nq == 9 && dm->nu == 6 && dm->nw == 2 && dm->nc == 4 && dm->nb == 8) ||
            (dm->nq == 18 && dm->nu == 12 && dm->nw == 3 && dm->nc == 4 && dm->nb == 16);
 }
 
@@ -55,6 +58,7 @@ int launch_newton_async(const cimpc_dims* dm, const IpParams& p, const NewtonDev
     if (dm->nq == 2) return async_launch_pushbot(p, S, waves, grid, s);
     if (dm->nq == 4) return async_launch_hopper(p, S, waves, grid, s);
     if (dm->nq == 18) return async_launch_centroidal(p, S, waves, grid, s);
+    if (dm->nq == 9) return async_launch_flamingo(p, S, waves, grid, s);
     return async_launch_quadruped(p, S, waves, grid, s);
 }
 

@@ -95,6 +95,7 @@ static int launch_kkt_any(const NewtonDev& S, const KktArgs& K, hipStream_t s) {
     if (nq == 2 && nu == 2) return launch_kkt_t<2, 2>(S, K, s);       // pushbot
     if (nq == 4 && nu == 2) return launch_kkt_t<4, 2>(S, K, s);       // hopper_2D
     if (nq == 11 && nu == 8) return launch_kkt_t<11, 8>(S, K, s);     // quadruped
+    if (nq == 9 && nu == 6) return launch_kkt_t<9, 6>(S, K, s);       // flamingo
     if (nq == 18 && nu == 12) return launch_kkt_t<18, 12>(S, K, s);   // centroidal_quadruped
     return CIMPC_ERR_INVALID;
 }
@@ -248,6 +249,7 @@ int launch_resid_decide(const NewtonDev& S, hipStream_t s) {
     if (nq == 2 && nu == 2) return launch_resid_t<2, 2>(S, s);
     if (nq == 4 && nu == 2) return launch_resid_t<4, 2>(S, s);
     if (nq == 11 && nu == 8) return launch_resid_t<11, 8>(S, s);
+    if (nq == 9 && nu == 6) return launch_resid_t<9, 6>(S, s);
     if (nq == 18 && nu == 12) return launch_resid_t<18, 12>(S, s);
     return CIMPC_ERR_INVALID;
 }
@@ -286,6 +288,7 @@ int launch_kkt_packed(const NewtonDev& S, int n_kkt, int list_par, hipStream_t s
     if (nq == 2 && nu == 2) return launch_kkt_packed_t<2, 2>(S, K, list, n_kkt, n_dev, s, latency);
     if (nq == 4 && nu == 2) return launch_kkt_packed_t<4, 2>(S, K, list, n_kkt, n_dev, s, latency);
     if (nq == 11 && nu == 8) return launch_kkt_packed_t<11, 8>(S, K, list, n_kkt, n_dev, s, latency);
+    if (nq == 9 && nu == 6) return launch_kkt_packed_t<9, 6>(S, K, list, n_kkt, n_dev, s, latency);
     if (nq == 18 && nu == 12) return launch_kkt_packed_t<18, 12>(S, K, list, n_kkt, n_dev, s, latency);
     return launch_kkt(S, s);
 }

@@ -10,6 +10,7 @@ definitions and differentiates it with torch (fp64, CPU, `torch.func` - exact de
   z / θ packing     src/simulation/index.jl:413-415, 437-451; simulation.jl:108-124
   hopper_2D         src/dynamics/hopper_2D/model.jl:31-110
   quadruped         src/dynamics/quadruped/model.jl:75-590  (planar kinematic tree, Lagrangian)
+  flamingo          src/dynamics/flamingo/model.jl:62-503   (planar biped with toe / heel contacts)
   centroidal_quad.  src/dynamics/centroidal_quadruped/model.jl:61-229, src/dynamics/euler.jl:3-11
   reference traj.   src/controller/trajectory.jl:152-184    (`get_trajectory`, :split_traj_alt)
 
@@ -178,30 +179,21 @@ class Hopper2D(ContactModel):
         return torch.stack([torch.stack([z, z, o, z]), torch.stack([-torch.sin(q[2]), torch.cos(q[2]), z, o])])
 
 
-class Quadruped(ContactModel):
-    """Planar quadruped (~Unitree A1): q = (x, z, torso, thigh1, calf1, thigh2, calf2, thigh3, calf3, thigh4, calf4),
-    absolute link angles.  Every body is a chain of (length, angle index) segments from the hip at (x, z)."""
-    name, nq, nu, nw, nc, space = "quadruped", 11, 8, 2, 4, 2
-    mu_world = 1.0
-    mu_joint = 0.1
-    m_torso, m_thigh, m_leg = 4.713 + 4 * 0.696, 1.013, 0.166
-    J_torso, J_thigh, J_leg = 0.01683 + 4 * 0.696 * 0.183 ** 2, 0.00552, 0.00299
-    l_torso, l_thigh, l_leg = 0.183 * 2, 0.2, 0.2
-    d_torso, d_thigh, d_leg = 0.5 * 0.183 * 2 + 0.0127, 0.5 * 0.2 - 0.00323, 0.5 * 0.2 - 0.006435
+class PlanarChain(ContactModel):
+    """Planar articulated model with ABSOLUTE link angles: q = (x, z, angles...).  Every body / contact point is a chain
+    of (signed length, angle index) segments from the hip at (x, z): a segment adds r (sin θ, -cos θ).  The Lagrangian
+    is the sum over bodies of translational + rotational kinetic energy minus m g z (quadruped/model.jl:261-359,
+    flamingo/model.jl:257-325)."""
+    space = 2
 
-    def bodies(self):
-        """(mass, inertia, own angle index, chain to the centre of mass)."""
-        lt, lh = self.l_torso, self.l_thigh
-        out = [(self.m_torso, self.J_torso, 2, [(self.d_torso, 2)])]
-        for thigh, calf, front in ((3, 4, False), (5, 6, False), (7, 8, True), (9, 10, True)):
-            root = [(lt, 2)] if front else []         # legs 3, 4 hang from the far end of the torso
-            out.append((self.m_thigh, self.J_thigh, thigh, root + [(self.d_thigh, thigh)]))
-            out.append((self.m_leg, self.J_leg, calf, root + [(lh, thigh), (self.d_leg, calf)]))
-        return out
+    def bodies(self):       # (mass, inertia, own angle index, chain to the centre of mass)
+        raise NotImplementedError
 
-    def feet(self):
-        lt, lh, ll = self.l_torso, self.l_thigh, self.l_leg
-        return [[(lh, 3), (ll, 4)], [(lh, 5), (ll, 6)], [(lt, 2), (lh, 7), (ll, 8)], [(lt, 2), (lh, 9), (ll, 10)]]
+    def contacts(self):     # chains to the contact points
+        raise NotImplementedError
+
+    def torque_pairs(self):  # (parent angle, child angle) per actuator: the torque acts on the relative angle
+        raise NotImplementedError
 
     @staticmethod
     def _point(q, chain):
@@ -231,18 +223,76 @@ class Quadruped(ContactModel):
 
     def kinematics(self, q):
         pts = []
-        for chain in self.feet():
+        for chain in self.contacts():
             pts.extend(self._point(q, chain))
         return torch.stack(pts)
 
     def B(self, q):
-        Bm = np.zeros((8, 11))
-        for i, (a, b) in enumerate(((2, 3), (3, 4), (2, 5), (5, 6), (2, 7), (7, 8), (2, 9), (9, 10))):
-            Bm[i, a], Bm[i, b] = -1.0, 1.0            # torque between two links acts on their relative angle
+        pairs = self.torque_pairs()
+        Bm = np.zeros((len(pairs), self.nq))
+        for i, (a, b) in enumerate(pairs):
+            Bm[i, a], Bm[i, b] = -1.0, 1.0
         return _t(Bm)
+
+
+class Quadruped(PlanarChain):
+    """Planar quadruped (~Unitree A1): q = (x, z, torso, thigh1, calf1, thigh2, calf2, thigh3, calf3, thigh4, calf4)."""
+    name, nq, nu, nw, nc = "quadruped", 11, 8, 2, 4
+    mu_world = 1.0
+    mu_joint = 0.1
+    m_torso, m_thigh, m_leg = 4.713 + 4 * 0.696, 1.013, 0.166
+    J_torso, J_thigh, J_leg = 0.01683 + 4 * 0.696 * 0.183 ** 2, 0.00552, 0.00299
+    l_torso, l_thigh, l_leg = 0.183 * 2, 0.2, 0.2
+    d_torso, d_thigh, d_leg = 0.5 * 0.183 * 2 + 0.0127, 0.5 * 0.2 - 0.00323, 0.5 * 0.2 - 0.006435
+
+    def bodies(self):
+        lt, lh = self.l_torso, self.l_thigh
+        out = [(self.m_torso, self.J_torso, 2, [(self.d_torso, 2)])]
+        for thigh, calf, front in ((3, 4, False), (5, 6, False), (7, 8, True), (9, 10, True)):
+            root = [(lt, 2)] if front else []         # legs 3, 4 hang from the far end of the torso
+            out.append((self.m_thigh, self.J_thigh, thigh, root + [(self.d_thigh, thigh)]))
+            out.append((self.m_leg, self.J_leg, calf, root + [(lh, thigh), (self.d_leg, calf)]))
+        return out
+
+    def contacts(self):
+        lt, lh, ll = self.l_torso, self.l_thigh, self.l_leg
+        return [[(lh, 3), (ll, 4)], [(lh, 5), (ll, 6)], [(lt, 2), (lh, 7), (ll, 8)], [(lt, 2), (lh, 9), (ll, 10)]]
+
+    def torque_pairs(self):
+        return ((2, 3), (3, 4), (2, 5), (5, 6), (2, 7), (7, 8), (2, 9), (9, 10))
 
     def joint_friction(self):
         return _t([0.0] * 3 + [self.mu_joint] * 8)
+
+
+class Flamingo(PlanarChain):
+    """Planar biped with feet (src/dynamics/flamingo/model.jl): q = (x, z, torso, thigh1, calf1, thigh2, calf2, foot1,
+    foot2); the torso points UP from the hip (negative segment), each foot has a toe and a heel contact."""
+    name, nq, nu, nw, nc = "flamingo", 9, 6, 2, 4
+    mu_world = 0.9
+    m_torso, m_thigh, m_calf, m_foot = 12.0, 0.4598, 0.306, 0.3466
+    J_torso, J_thigh, J_calf, J_foot = 0.10, 0.01256, 0.00952, 0.0015
+    l_torso, l_thigh, l_calf, l_foot = 0.385, 0.42, 0.45, 0.1725
+    d_torso, d_thigh, d_calf, d_foot = 0.20, 0.42 / 2, 0.45 / 2, 0.0525
+
+    def bodies(self):
+        cb = 0.5 * (self.l_foot - self.d_foot)
+        out = [(self.m_torso, self.J_torso, 2, [(-self.d_torso, 2)])]
+        for thigh, calf, foot in ((3, 4, 7), (5, 6, 8)):
+            out.append((self.m_thigh, self.J_thigh, thigh, [(self.d_thigh, thigh)]))
+            out.append((self.m_calf, self.J_calf, calf, [(self.l_thigh, thigh), (self.d_calf, calf)]))
+            out.append((self.m_foot, self.J_foot, foot, [(self.l_thigh, thigh), (self.l_calf, calf), (cb, foot)]))
+        return out
+
+    def contacts(self):     # toe 1, heel 1, toe 2, heel 2 (flamingo/model.jl:343-350)
+        out = []
+        for thigh, calf, foot in ((3, 4, 7), (5, 6, 8)):
+            leg = [(self.l_thigh, thigh), (self.l_calf, calf)]
+            out += [leg + [(self.l_foot, foot)], leg + [(-self.d_foot, foot)]]
+        return out
+
+    def torque_pairs(self):
+        return ((2, 3), (3, 4), (2, 5), (5, 6), (4, 7), (6, 8))
 
 
 def _skew(x):
@@ -299,7 +349,7 @@ class CentroidalQuadrupedUndamped(CentroidalQuadruped):
         return torch.zeros(self.nq, dtype=F64)
 
 
-MODELS = {"hopper_2D": Hopper2D, "quadruped": Quadruped, "centroidal_quadruped": CentroidalQuadruped,
+MODELS = {"hopper_2D": Hopper2D, "quadruped": Quadruped, "flamingo": Flamingo, "centroidal_quadruped": CentroidalQuadruped,
           "centroidal_quadruped_undamped": CentroidalQuadrupedUndamped}
 
 

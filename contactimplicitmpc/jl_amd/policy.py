@@ -20,9 +20,11 @@ from .solver import CIMPCSolver, InteriorPointOptions, NewtonOptions
 class CIMPCPolicy:
     def __init__(self, problem, obj_q, obj_u, H_mpc=None, N_sample=1, kappa_mpc=None, B=1, mode=0,
                  n_opts: NewtonOptions | None = None, ip_opts: InteriorPointOptions | None = None, device=0,
-                 phase=None):
+                 phase=None, obj_gamma=None, obj_b=None, obj_v=None, v_target=None):
         """problem: a `lcp_models.ReferenceProblem` (reference trajectory + per-knot linearization at κ_mpc);
-        obj_q, obj_u: (H_mpc, nq, nq), (H_mpc, nu, nu) TrackingObjective weights."""
+        obj_q, obj_u: (H_mpc, nq, nq), (H_mpc, nu, nu) TrackingObjective weights; obj_gamma / obj_b: contact-force
+        weights of `:configurationforce` mode (mode = 1, the default of ci_mpc_policy); obj_v (+ v_target): the
+        velocity weights of a TrackingVelocityObjective."""
         m = problem.model
         self.problem = problem
         self.H = H_mpc or problem.H
@@ -36,7 +38,7 @@ class CIMPCPolicy:
                                   newton_opts=n_opts or NewtonOptions(kappa=kappa, r_tol=3e-4, max_iter=5), device=device)
         for t in range(problem.H):
             self.solver.set_linearization(t + 1, problem.z[t], problem.theta[t], problem.r0[t], problem.rz0[t], problem.rth0[t])
-        self.solver.set_objective(obj_q, obj_u)
+        self.solver.set_objective(obj_q, obj_u, obj_gamma, obj_b, V=obj_v, v_target=v_target)
         from .lcp_models import get_stride
         self.stride = get_stride(m, problem.q)
         self.phase0 = None if phase is None else np.asarray(phase, dtype=np.int32).reshape(B)

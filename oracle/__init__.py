@@ -23,6 +23,6 @@ Parity status (see DESIGN.md section "Oracle"):
     (contactimplicitmpc/jl_amd/lcp_models.py + gait_io.py), and the closed
     loop of test/controller/mpc_quadruped.jl (plant = oracle/plant.py) lands
     within 2 % of the tracking errors that test records (tests/test_closed_loop.py,
-    scripts/closed_loop_quadruped.py).
+    scripts/closed_loop.py).
 """
 from .dims import Dims  # noqa: F401

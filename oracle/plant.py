@@ -29,32 +29,21 @@ from . import newton as onewton
 from .dims import Dims
 
 
-class QuadrupedPlant:
-    """flat_2D_lc quadruped (src/dynamics/quadruped/model.jl:75-590); parameters :516-540."""
-    nq, nu, nw, nc, nb = 11, 8, 2, 4, 8
+class PlanarChainPlant:
+    """Planar articulated model with absolute link angles, q = (x, z, angles...): every body / contact point is a chain
+    of (signed length, angle index) segments from the hip, a segment adds r (sin θ, -cos θ).  nc = 4 contacts with a
+    two-sided linearized friction cone (flat_2D_lc)."""
+    nw, nc, nb = 2, 4, 8
     g = 9.81
-    mu_world = 1.0
-    mu_joint = 0.1
-    m_torso, m_thigh, m_leg = 4.713 + 4 * 0.696, 1.013, 0.166
-    J_torso, J_thigh, J_leg = 0.01683 + 4 * 0.696 * 0.183 ** 2, 0.00552, 0.00299
-    l_torso, l_thigh, l_leg = 0.183 * 2, 0.2, 0.2
-    d_torso, d_thigh, d_leg = 0.5 * 0.183 * 2 + 0.0127, 0.5 * 0.2 - 0.00323, 0.5 * 0.2 - 0.006435
 
-    def __init__(self):
-        lt, lh = self.l_torso, self.l_thigh
-        self.bodies = [(self.m_torso, self.J_torso, 2, [(self.d_torso, 2)])]
-        for thigh, calf, front in ((3, 4, False), (5, 6, False), (7, 8, True), (9, 10, True)):
-            root = [(lt, 2)] if front else []
-            self.bodies.append((self.m_thigh, self.J_thigh, thigh, root + [(self.d_thigh, thigh)]))
-            self.bodies.append((self.m_leg, self.J_leg, calf, root + [(lh, thigh), (self.d_leg, calf)]))
-        ll = self.l_leg
-        self.feet = [[(lh, 3), (ll, 4)], [(lh, 5), (ll, 6)], [(lt, 2), (lh, 7), (ll, 8)], [(lt, 2), (lh, 9), (ll, 10)]]
-        B = np.zeros((8, 11))
-        for i, (a, b) in enumerate(((2, 3), (3, 4), (2, 5), (5, 6), (2, 7), (7, 8), (2, 9), (9, 10))):
+    def _finish(self, torque_pairs, joint_friction):
+        B = np.zeros((self.nu, self.nq))
+        for i, (a, b) in enumerate(torque_pairs):
             B[i, a], B[i, b] = -1.0, 1.0
         self.B = B
-        self.joint_friction = np.array([0.0] * 3 + [self.mu_joint] * 8)
-        self.dims = Dims(nq=11, nu=8, nw=2, nc=4, nb=8)
+        self.joint_friction = np.asarray(joint_friction, dtype=float)
+        self.dims = Dims(nq=self.nq, nu=self.nu, nw=self.nw, nc=self.nc, nb=self.nb)
+
 
     # D1L = dL/dq - (d/dq dL/dq') q',  D2L = dL/dq'   (dynamics/model.jl:11-15 with C of quadruped/model.jl:479-484)
     def lagrangian_derivatives(self, q, v):
@@ -92,7 +81,7 @@ class QuadrupedPlant:
 
     def foot_jacobian(self, q):
         s, c = np.sin(q), np.cos(q)
-        J = np.zeros(q.shape[:-1] + (8, 11), dtype=q.dtype)
+        J = np.zeros(q.shape[:-1] + (8, self.nq), dtype=q.dtype)
         for i, chain in enumerate(self.feet):
             J[..., 2 * i, 0] = 1.0
             J[..., 2 * i + 1, 1] = 1.0
@@ -102,10 +91,10 @@ class QuadrupedPlant:
         return J
 
     def residual(self, z, th, kappa):
-        """r(z, θ, κ), simulation.jl:133-158 (z, θ: (..., 43), (..., 34); real or complex)."""
-        nq, nc, nb = self.nq, self.nc, self.nb
-        q0, q1, u1, w1 = th[..., 0:11], th[..., 11:22], th[..., 22:30], th[..., 30:32]
-        mu, h = th[..., 32:33], th[..., 33:34]
+        """r(z, θ, κ), simulation.jl:133-158 (z, θ: (..., nz), (..., nθ); real or complex)."""
+        nq, nu, nc, nb = self.nq, self.nu, self.nc, self.nb
+        ot = np.cumsum([0, nq, nq, nu, self.nw, 1, 1])
+        q0, q1, u1, w1, mu, h = (th[..., ot[i]:ot[i + 1]] for i in range(6))
         o = np.cumsum([0, nq, nc, nb, nc, nc, nb, nc])
         q2, gam, b, psi, s1, eta, s2 = (z[..., o[i]:o[i + 1]] for i in range(7))
         qm1, vm1 = 0.5 * (q0 + q1), (q1 - q0) / h
@@ -134,6 +123,51 @@ class QuadrupedPlant:
         Z = np.tile(z.astype(complex), (n, 1)) + 1j * eps * np.eye(n)
         R = self.residual(Z, np.tile(th.astype(complex), (n, 1)), 0.0)
         return (R.imag / eps).T
+
+
+class QuadrupedPlant(PlanarChainPlant):
+    """flat_2D_lc quadruped (src/dynamics/quadruped/model.jl:75-590); parameters :516-540."""
+    nq, nu = 11, 8
+    mu_world = 1.0
+    mu_joint = 0.1
+    m_torso, m_thigh, m_leg = 4.713 + 4 * 0.696, 1.013, 0.166
+    J_torso, J_thigh, J_leg = 0.01683 + 4 * 0.696 * 0.183 ** 2, 0.00552, 0.00299
+    l_torso, l_thigh, l_leg = 0.183 * 2, 0.2, 0.2
+    d_torso, d_thigh, d_leg = 0.5 * 0.183 * 2 + 0.0127, 0.5 * 0.2 - 0.00323, 0.5 * 0.2 - 0.006435
+
+    def __init__(self):
+        lt, lh = self.l_torso, self.l_thigh
+        self.bodies = [(self.m_torso, self.J_torso, 2, [(self.d_torso, 2)])]
+        for thigh, calf, front in ((3, 4, False), (5, 6, False), (7, 8, True), (9, 10, True)):
+            root = [(lt, 2)] if front else []
+            self.bodies.append((self.m_thigh, self.J_thigh, thigh, root + [(self.d_thigh, thigh)]))
+            self.bodies.append((self.m_leg, self.J_leg, calf, root + [(lh, thigh), (self.d_leg, calf)]))
+        ll = self.l_leg
+        self.feet = [[(lh, 3), (ll, 4)], [(lh, 5), (ll, 6)], [(lt, 2), (lh, 7), (ll, 8)], [(lt, 2), (lh, 9), (ll, 10)]]
+        self._finish(((2, 3), (3, 4), (2, 5), (5, 6), (2, 7), (7, 8), (2, 9), (9, 10)), [0.0] * 3 + [self.mu_joint] * 8)
+
+
+class FlamingoPlant(PlanarChainPlant):
+    """flat_2D_lc flamingo (src/dynamics/flamingo/model.jl:62-503; parameters :458-495): torso up from the hip, two legs
+    with feet, toe and heel contacts."""
+    nq, nu = 9, 6
+    mu_world = 0.9
+    m_torso, m_thigh, m_calf, m_foot = 12.0, 0.4598, 0.306, 0.3466
+    J_torso, J_thigh, J_calf, J_foot = 0.10, 0.01256, 0.00952, 0.0015
+    l_torso, l_thigh, l_calf, l_foot = 0.385, 0.42, 0.45, 0.1725
+    d_torso, d_thigh, d_calf, d_foot = 0.20, 0.21, 0.225, 0.0525
+
+    def __init__(self):
+        cb = 0.5 * (self.l_foot - self.d_foot)
+        self.bodies = [(self.m_torso, self.J_torso, 2, [(-self.d_torso, 2)])]
+        self.feet = []
+        for thigh, calf, foot in ((3, 4, 7), (5, 6, 8)):
+            leg = [(self.l_thigh, thigh), (self.l_calf, calf)]
+            self.bodies.append((self.m_thigh, self.J_thigh, thigh, [(self.d_thigh, thigh)]))
+            self.bodies.append((self.m_calf, self.J_calf, calf, [(self.l_thigh, thigh), (self.d_calf, calf)]))
+            self.bodies.append((self.m_foot, self.J_foot, foot, leg + [(cb, foot)]))
+            self.feet += [leg + [(self.l_foot, foot)], leg + [(-self.d_foot, foot)]]
+        self._finish(((2, 3), (3, 4), (2, 5), (5, 6), (4, 7), (6, 8)), np.zeros(9))
 
 
 def plant_step(plant, q0, q1, u, w, mu, h, opts: oip.IPOptions):

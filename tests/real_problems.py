@@ -16,17 +16,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GAITS = {
     "quadruped": ("quadruped", os.path.join(HERE, "golden", "gaits", "quadruped_gait2.jld2")),
     "centroidal": ("centroidal_quadruped", os.path.join(HERE, "golden", "gaits", "centroidal_inplace_trot_v7.jld2")),
+    "flamingo": ("flamingo", os.path.join(HERE, "golden", "gaits", "flamingo_gait_forward_36_4.jld2")),
 }
 
 
 @functools.lru_cache(maxsize=None)
-def real_problem(which: str, kappa: float, update_friction: bool = False):
+def real_problem(which: str, kappa: float, update_friction: bool = False, mode: int = 0):
     """-> (Dims, ReferenceProblem, prob dict in the layout of oracle.synth.make_problem, LinTables)."""
     from contactimplicitmpc.jl_amd import gait_io, lcp_models
     name, path = GAITS[which]
     model = lcp_models.MODELS[name]()
     P = lcp_models.reference_problem(model, gait_io.load_gait(path), kappa, update_friction)
-    d = Dims(nq=model.nq, nu=model.nu, nw=model.nw, nc=model.nc, nb=model.nb)
+    d = Dims(nq=model.nq, nu=model.nu, nw=model.nw, nc=model.nc, nb=model.nb, mode=mode)
     prob = dict(z0=P.z, th0=P.theta, r0=P.r0, rz0=P.rz0, rth0=P.rth0, kappa=kappa, q_ref=P.q, u_ref=P.u, w_ref=P.w,
                 gamma_ref=P.gamma, b_ref=P.b, stride=lcp_models.get_stride(model, P.q), P=P)
     tabs = [lcp.LinTable(d, P.z[t], P.theta[t], P.r0[t], P.rz0[t], P.rth0[t]) for t in range(P.H)]

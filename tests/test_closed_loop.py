@@ -6,7 +6,7 @@
   (the reference asserts < 1.5 x nominal).
 
 The plant (RoboDojo's simulate!, external) is oracle/plant.py: the nonlinear time-stepping complementarity problem
-solved to 1e-8 per step.  Measured with the oracle as the controller, H_sim = 1000 (scripts/closed_loop_quadruped.py):
+solved to 1e-8 per step.  Measured with the oracle as the controller, H_sim = 1000 (scripts/closed_loop.py):
 q 0.02048, u 0.04331, γ 0.3768, b 0.07917 - within 2 %, 1 %, 0.7 %, 0.3 % of the reference's recorded values.
 The suite runs 300 plant steps (one and a half gait cycles): CPU with the oracle, GPU with the product policy
 (contactimplicitmpc/jl_amd/policy.py over the C ABI).
@@ -123,3 +123,73 @@ def test_closed_loop_tracking_error_with_the_device_policy(gpu_required):
     eo = pl.tracking_error(P.q, P.u, P.gamma, P.b, qo, uo, go, bo, N_SAMPLE)
     for a, c in zip((qe, ue, ge, be), eo):
         assert abs(a / c - 1) < 0.03
+
+
+# ---- second closed-loop test of the reference: test/controller/mpc_flamingo.jl:1-80 --------------------------------------
+#   flamingo gait_forward_36_4, H_mpc = 15, N_sample = 5, κ_mpc = 2e-4, TrackingVelocityObjective (:23-28), the policy's
+#   DEFAULT mode :configurationforce (policy.jl:46), simulator options :53-60; recorded nominal tracking errors
+#   q 0.0154, u 0.0829, γ 0.444, b 0.0169.  Oracle-controlled, 1000 plant steps (98 s of CPU): q 0.01268, u 0.08252,
+#   γ 0.4406, b 0.01591.
+NOMINAL_F = (0.0154, 0.0829, 0.444, 0.0169)
+SIM_OPTS_F = oip.IPOptions(r_tol=1e-8, kappa_tol=1e-8, undercut=np.inf, gamma_reg=0.0, eps_min=0.05, max_iter=100, max_ls=25)
+
+
+def _flamingo_objective(H):
+    t = lambda a: np.tile(np.diag(np.asarray(a, dtype=float))[None], (H, 1, 1))
+    return onewton.Objective(q=t(1e-1 * np.array([3e2, 1e-6, 3e2, 1, 1, 1, 1, 0.1, 0.1])), u=t(3e-1 * np.array([0.1, 0.1, 0.3, 0.3, 2, 2])),
+                             gamma=t(1e-100 * np.ones(4)), b=t(1e-100 * np.ones(8)), v=t(1e-3 * np.array([1, 1, 1e4, 1, 1, 1, 1, 1e4, 1e4])))
+
+
+def _flamingo_oracle_loop(H_sim, H_mpc=15):
+    d, P, prob, tabs = real_problem("flamingo", KAPPA, False, 1)
+    ref = onewton.Traj(q=P.q.copy(), u=P.u.copy(), w=P.w.copy(), gamma=P.gamma.copy(), b=P.b.copy(), theta=P.theta.copy())
+    pol = pl.OraclePolicy(d, tabs, ref, prob["stride"], _flamingo_objective(H_mpc), H_mpc, N_SAMPLE, KAPPA,
+                          onewton.NewtonOptions(r_tol=3e-4, max_iter=5, solver="lu"), oip.IPOptions(kappa_tol=KAPPA, r_tol=1e-8))
+    q1, v1 = P.q[1].copy(), (P.q[1] - P.q[0]) / P.h
+    ok, q, u, g, b = pl.simulate(pl.FlamingoPlant(), pol, q1, v1, H_sim, P.h / N_SAMPLE, opts=SIM_OPTS_F)
+    return P, pol, ok, q, u, g, b
+
+
+def test_flamingo_plant_equals_the_torch_model_and_gait_is_periodic():
+    from contactimplicitmpc.jl_amd import lcp_models
+    P, m = pl.FlamingoPlant(), lcp_models.Flamingo()
+    rng = np.random.default_rng(1)
+    z, th = rng.uniform(0.1, 1.0, m.nz), rng.uniform(0.1, 1.0, m.nth)
+    r_t, rz_t, _ = m.linearize(z, th, 1e-3)
+    np.testing.assert_allclose(P.residual(z, th, 1e-3), r_t, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(P.jacobian_z(z, th), rz_t, rtol=0, atol=1e-11 * np.abs(rz_t).max())
+    d, Pr, prob, tabs = real_problem("flamingo", KAPPA, False, 1)
+    assert np.abs(Pr.r0[:, :m.nq]).max() < 2e-6                       # the shipped gait satisfies the restated dynamics
+    assert np.abs(Pr.q[0][1:] - Pr.q[-2][1:]).max() < 1e-8 and np.abs(Pr.q[1][1:] - Pr.q[-1][1:]).max() < 1e-8   # mpc_flamingo.jl:67-68
+
+
+def test_flamingo_closed_loop_with_the_oracle_controller():
+    P, pol, ok, q, u, g, b = _flamingo_oracle_loop(150)
+    assert ok
+    assert np.abs(q[0] - (P.q[1] * (1 - 1 / N_SAMPLE) + P.q[0] / N_SAMPLE)).max() < 1e-8 and np.abs(q[1] - P.q[1]).max() < 1e-8   # :65-66
+    e = pl.tracking_error(P.q, P.u, P.gamma, P.b, q, u, g, b, N_SAMPLE)
+    assert all(a < 1.5 * n for a, n in zip(e, NOMINAL_F))               # mpc_flamingo.jl:71-74
+    assert abs(e[1] / NOMINAL_F[1] - 1) < 0.10 and abs(e[2] / NOMINAL_F[2] - 1) < 0.10      # (150 steps; 1000 steps: 0.5 %, 0.8 %)
+
+
+@pytest.mark.gpu
+def test_flamingo_closed_loop_with_the_device_policy(gpu_required):
+    """:configurationforce mode + TrackingVelocityObjective (dense-LU KKT backend) + policy glue, third model."""
+    from contactimplicitmpc.jl_amd import NewtonOptions, InteriorPointOptions
+    from contactimplicitmpc.jl_amd.policy import CIMPCPolicy
+    d, P, prob, tabs = real_problem("flamingo", KAPPA, False, 1)
+    H_mpc, H_sim = 15, 150
+    obj = _flamingo_objective(H_mpc)
+    pol = CIMPCPolicy(P, obj.q, obj.u, H_mpc=H_mpc, N_sample=N_SAMPLE, B=1, mode=1, obj_gamma=obj.gamma, obj_b=obj.b, obj_v=obj.v,
+                      n_opts=NewtonOptions(kappa=KAPPA, r_tol=3e-4, max_iter=5), ip_opts=InteriorPointOptions(kappa_tol=KAPPA, r_tol=1e-8))
+    q1, v1 = P.q[1].copy(), (P.q[1] - P.q[0]) / P.h
+    ok, q, u, g, b = pl.simulate(pl.FlamingoPlant(), lambda qq, t: pol(qq[t + 1][None])[0], q1, v1, H_sim, P.h / N_SAMPLE, opts=SIM_OPTS_F)
+    pol.close()
+    assert ok
+    e = pl.tracking_error(P.q, P.u, P.gamma, P.b, q, u, g, b, N_SAMPLE)
+    assert all(a < 1.5 * n for a, n in zip(e, NOMINAL_F))
+    Po, polo, oko, qo, uo, go, bo = _flamingo_oracle_loop(H_sim)
+    np.testing.assert_allclose(q[:40], qo[:40], rtol=0, atol=1e-5)
+    eo = pl.tracking_error(P.q, P.u, P.gamma, P.b, qo, uo, go, bo, N_SAMPLE)
+    for a, c in zip(e, eo):
+        assert abs(a / c - 1) < 0.05
