@@ -77,6 +77,9 @@ struct cimpc_ctx {
     bool use_dense = false;        // KKT through kkt_dense.hip: the reference-default dense LU (any mode / objective) ...
     bool use_banded = false;       // ... or its banded LDL^T (:configuration mode, velocity objective / on request)
     size_t dense_ws_doubles = 0;
+    // :configurationforce with negligible gamma / b weights: eliminated onto the :configuration solvers (newton_kernels.hip)
+    bool cf_reduce = false, cf_tiny = true;
+    double* d_cf_ws = nullptr;
     double* d_dense_ws = nullptr;  // [B][N*N + 2N], allocated on first use
     double *d_V = nullptr, *d_qt = nullptr, *d_vt = nullptr;
     int waves = 4;
@@ -251,7 +254,9 @@ int run_sweep(cimpc_ctx* h, int par, int* pending_counter, double* zout, hipStre
 }
 
 int ensure_dense_ws(cimpc_ctx* h) {
-    const size_t need = kkt_dense_workspace_doubles(h->S, h->use_banded);
+    if (h->cf_reduce && !h->d_cf_ws && dev_alloc(h, &h->d_cf_ws, cf_reduce_doubles(h->S)) != CIMPC_OK) return CIMPC_ERR_HIP;
+    if (h->cf_reduce && h->S.V == nullptr) return CIMPC_OK;            // reduced problem goes to the condensed MFMA solve
+    const size_t need = h->cf_reduce ? kkt_dense_workspace_doubles(cf_shadow(h->S), true) : kkt_dense_workspace_doubles(h->S, h->use_banded);
     if (h->d_dense_ws && h->dense_ws_doubles >= need) return CIMPC_OK;
     h->d_dense_ws = nullptr;                      // (an earlier, smaller workspace stays in h->allocs until destroy)
     h->dense_ws_doubles = need;
@@ -265,6 +270,13 @@ static void select_kkt_backend(cimpc_ctx* h) {
     const bool velocity = h->S.V != nullptr;
     h->use_dense = !cfg || want == CIMPC_KKT_DENSE_LU || want == CIMPC_KKT_BANDED_LDL || velocity;
     h->use_banded = h->use_dense && cfg && want != CIMPC_KKT_DENSE_LU && kkt_banded_available(h->S);
+    h->cf_reduce = !cfg && want != CIMPC_KKT_DENSE_LU && h->cf_tiny && kkt_cf_reduce_available(h->S);
+}
+
+// KKT stage of the Newton loop for everything that is not the plain condensed solve
+static int launch_kkt_general(cimpc_ctx* h, const NewtonDev& Sk, hipStream_t st) {
+    if (h->cf_reduce) return launch_kkt_cf_reduced_newton(Sk, h->d_cf_ws, h->d_dense_ws, st);
+    return launch_kkt_dense_newton(Sk, h->d_dense_ws, st, h->use_banded);
 }
 
 int check_ready(cimpc_ctx* h, bool need_newton) {
@@ -630,6 +642,13 @@ int cimpc_set_objective(cimpc_handle h, const double* Q, const double* R, const 
     const cimpc_dims& d = h->dm;
     const size_t H = d.H;
     HIP_TRY(h, hipSetDevice(h->device));
+    {   // contact-impulse weights below fp64 resolution (1e-100 in every example of the reference): the cf-mode KKT
+        // system reduces exactly onto the :configuration solvers (newton_kernels.hip: cf_reduce_*)
+        double gmax = 0.0;
+        if (Cg) for (size_t k = 0; k < H * d.nc * d.nc; ++k) gmax = std::max(gmax, std::fabs(Cg[k]));
+        if (Cb) for (size_t k = 0; k < H * d.nb * d.nb; ++k) gmax = std::max(gmax, std::fabs(Cb[k]));
+        h->cf_tiny = gmax <= 1e-30;
+    }
     if (V != nullptr) {      // TrackingVelocityObjective (objective.jl:18-47): q_target integrates v_target when not given
         std::vector<double> vt(H * d.nq, 0.0), qt(H * d.nq, 0.0);
         if (v_target) std::copy(v_target, v_target + H * d.nq, vt.begin());
@@ -652,10 +671,11 @@ int cimpc_set_objective(cimpc_handle h, const double* Q, const double* R, const 
     }
     std::vector<double> Qi(H * d.nq * d.nq), Ri(H * d.nu * d.nu);
     for (size_t i = 0; i < H; ++i) {
-        // (the inverses feed the condensed solve only)
-        if (!invert(Q + i * d.nq * d.nq, Qi.data() + i * d.nq * d.nq, d.nq) && !h->use_dense)
+        // (the inverses feed the condensed solve only - also behind the cf-mode reduction)
+        const bool need_inv = !h->use_dense || (h->cf_reduce && V == nullptr);
+        if (!invert(Q + i * d.nq * d.nq, Qi.data() + i * d.nq * d.nq, d.nq) && need_inv)
             return fail(h, CIMPC_ERR_INVALID, "objective block Q[i] is singular");
-        if (d.nu > 0 && !invert(R + i * d.nu * d.nu, Ri.data() + i * d.nu * d.nu, d.nu) && !h->use_dense)
+        if (d.nu > 0 && !invert(R + i * d.nu * d.nu, Ri.data() + i * d.nu * d.nu, d.nu) && need_inv)
             return fail(h, CIMPC_ERR_INVALID, "objective block R[i] is singular");
     }
     HIP_TRY(h, hipMemcpy(h->d_Q, Q, H * d.nq * d.nq * sizeof(double), hipMemcpyHostToDevice));
@@ -780,7 +800,8 @@ int cimpc_kkt_solve(cimpc_handle h, const double* r, double beta, double* delta)
     if (h->use_dense) {
         rc = ensure_dense_ws(h);
         if (rc != CIMPC_OK) return rc;
-        rc = launch_kkt_dense_raw(h->S, h->d_rhs, beta, h->S.delta, h->d_dense_ws, h->stream, h->use_banded);
+        rc = h->cf_reduce ? launch_kkt_cf_reduced_raw(h->S, h->d_rhs, beta, h->S.delta, h->d_cf_ws, h->d_dense_ws, h->stream)
+                          : launch_kkt_dense_raw(h->S, h->d_rhs, beta, h->S.delta, h->d_dense_ws, h->stream, h->use_banded);
     } else {
         rc = launch_kkt_raw(h->S, h->d_rhs, beta, h->S.delta, h->stream);
     }
@@ -936,7 +957,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             Sk.kkt_same_round = 1;
             prof_begin(h, PC_KKT, sb.st);
             // (same compact list / packed or pipelined kernel as the overlapped path)
-            int rr = h->use_dense ? launch_kkt_dense_newton(Sk, h->d_dense_ws, sb.st, h->use_banded) : launch_kkt_packed(Sk, last_kkt, Sk.WQ.par ^ 1, sb.st);
+            int rr = h->use_dense ? launch_kkt_general(h, Sk, sb.st) : launch_kkt_packed(Sk, last_kkt, Sk.WQ.par ^ 1, sb.st);
             prof_end(h, sb.st);
             if (rr != CIMPC_OK) return fail(h, rr, "kkt launch failed");
         }
@@ -949,7 +970,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             prof_begin(h, PC_KKT, sb.st_kkt);
             static const bool packed = !getenv("CIMPC_KKT_PACKED") || atoi(getenv("CIMPC_KKT_PACKED")) != 0;
             // the list was built by the residual kernel of the previous round (its queue parity)
-            int rk = h->use_dense ? launch_kkt_dense_newton(Sk, h->d_dense_ws, sb.st_kkt, h->use_banded)
+            int rk = h->use_dense ? launch_kkt_general(h, Sk, sb.st_kkt)
                                   : packed ? launch_kkt_packed(Sk, last_kkt, Sk.WQ.par ^ 1, sb.st_kkt, depth > 1 ? Sk.counters_next + 1 : nullptr)
                                            : launch_kkt(Sk, sb.st_kkt);
             prof_end(h, sb.st_kkt);

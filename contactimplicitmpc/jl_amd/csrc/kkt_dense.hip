@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void kkt_dense_kernel(NewtonDev S, KktArgs K, 
     int* piv = reinterpret_cast<int*>(x + N);
     const double beta = K.beta ? K.beta[b] : K.beta_scalar;
     const double rho = (double)H * beta * S.kappa;  // newton_jacobian.jl:169-186 quirk
-    const double* dzb = K.stage ? S.dz_good + (size_t)b * H * nths * nd : S.dz + (size_t)b * CS * H * nths * nd;
+    const double* dzb = kkt_dz(S, K, b, H, nths, nd);
     __shared__ double s_val[256];
     __shared__ int s_idx[256];
 
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     double* lv = yw + M;                                         // [M]: lv[0] = d_k, lv[r] = L[k+r][k]
     const double beta = K.beta ? K.beta[b] : K.beta_scalar;
     const double rho = (double)H * beta * S.kappa;               // newton_jacobian.jl:169-186 quirk
-    const double* dzb = K.stage ? S.dz_good + (size_t)b * H * S.nths * nd : S.dz + (size_t)b * CS * H * S.nths * nd;
+    const double* dzb = kkt_dz(S, K, b, H, S.nths, nd);
     const BandRows row{S, L, dzb, rho, s, S.nths};
     const double* rb = K.r + (size_t)b * S.N;
     // interleaved index -> index in the reference's layout (primal segment step-major, then the duals)
@@ -392,6 +392,9 @@ static int launch_kkt_dense(const NewtonDev& S, const KktArgs& K, double* ws, hi
     }
     hipLaunchKernelGGL(kkt_dense_kernel, dim3(S.nb_launch), dim3(256), 0, s, S, K, ws);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+}
+int launch_kkt_dense_args(const NewtonDev& S, const KktArgs& K, double* ws, hipStream_t s, bool banded) {
+    return launch_kkt_dense(S, K, ws, s, banded);
 }
 int launch_kkt_dense_newton(const NewtonDev& S, double* ws, hipStream_t s, bool banded) {
     KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 1};

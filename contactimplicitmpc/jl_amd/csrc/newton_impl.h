@@ -530,7 +530,14 @@ struct KktArgs {
     double beta_scalar;
     const int* stage;    // only rollouts with stage == STAGE_KKT (null = all)
     int finish;          // 1: set alpha/ls_iter/cand/stage after the solve (newton loop)
+    const double* dz_override;   // [B][H][nths][nd] sensitivities to use instead of S.dz_good / S.dz (cf-mode reduction)
 };
+// sensitivities a KKT solve reads: the accepted evaluation's (Newton loop), slot 0 of the last implicit_dynamics! (B1
+// seam, no stage array), or an explicit buffer
+__device__ __forceinline__ const double* kkt_dz(const NewtonDev& S, const KktArgs& K, int b, int H, int nths, int nd) {
+    if (K.dz_override) return K.dz_override + (size_t)b * H * nths * nd;
+    return K.stage ? S.dz_good + (size_t)b * H * nths * nd : S.dz + (size_t)b * CS * H * nths * nd;
+}
 
 __device__ __forceinline__ void lds_sync() { __syncthreads(); }
 
@@ -573,7 +580,7 @@ __global__ __launch_bounds__(64) void kkt_kernel_scalar(NewtonDev S, KktArgs K) 
     const double beta = K.beta ? K.beta[b] : K.beta_scalar;
     const double rho = (double)H * beta * S.kappa;     // newton_jacobian.jl:169-186 quirk
     // Newton loop: the accepted evaluation's sensitivities; B1 seam (no stage): slot 0 of the last implicit_dynamics!
-    const double* dzb = K.stage ? S.dz_good + (size_t)b * H * nths * nd : S.dz + (size_t)b * CS * H * nths * nd;
+    const double* dzb = kkt_dz(S, K, b, H, nths, nd);
     constexpr int n2 = nd * nd;
     double* ws = S.kkt_ws + (size_t)b * H * (3 * n2 + nd);
     const int oq = nu;   // offset of q2 inside a primal block (:configuration)
@@ -1107,7 +1114,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     const double beta = K.beta ? K.beta[b] : K.beta_scalar;
     const double rho = (double)H * beta * S.kappa;         // newton_jacobian.jl:169-186 quirk
     // Newton loop: the accepted evaluation's sensitivities; B1 seam (no stage): slot 0 of the last implicit_dynamics!
-    const double* dzb = K.stage ? S.dz_good + (size_t)b * H * nths * nd : S.dz + (size_t)b * CS * H * nths * nd;
+    const double* dzb = kkt_dz(S, K, b, H, nths, nd);
     double* ws = S.kkt_ws + (size_t)b * H * (3 * n2 + nd);
     constexpr int WSR = 3 * n2 + nd;
 

@@ -292,6 +292,139 @@ int launch_kkt_packed(const NewtonDev& S, int n_kkt, int list_par, hipStream_t s
     if (nq == 18 && nu == 12) return launch_kkt_packed_t<18, 12>(S, K, list, n_kkt, n_dev, s, latency);
     return launch_kkt(S, s);
 }
+// ---------------------------------------------------------------------------------------------------------
+// :configurationforce mode through the :configuration solvers.  In cf mode the contact impulses (gamma_i, b_i) are extra
+// primal variables (newton_residual.jl:18-54) that appear in exactly two places: their own rows of the dynamics
+// constraint, d_i^y = y*(theta_i) - y_i with C = [S_i  -I]  (S_i = dy/d(q0, q1, u1): the y rows of the sensitivities),
+// and the objective with the weights G = blkdiag(Cg, Cb) - 1e-100 in every example of the reference.  Eliminating them
+// is exact:      G Dy - Dnu_y = r_y ,   S_i Dtheta_i - Dy - rho Dnu_y = r_nuy
+//   =>  Dnu_y = G Dy - r_y ,  (I + rho G) Dy = S_i Dtheta_i + rho r_y - r_nuy ,
+// and the rows of (u_i, q_i, q_{i+1}) see  S_i^T Dnu_y = -S_i^T r_y + O(G).  For G below fp64 resolution (the host
+// takes this path only for max |G| <= 1e-30) the system for (Du, Dq, Dnu_q) is the :configuration-mode KKT system with
+// the right-hand side  r_x + S^T r_y  - solved by the condensed MFMA kernel or, with a velocity objective, the banded
+// LDL^T - followed by the two formulas above.  (General weights keep the dense LU of the reference.)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cf_reduce_pre_kernel(NewtonDev S, KktArgs K, CfReduce W) {
+    const int b = blockIdx.x + S.b0, tid = threadIdx.x, nt = blockDim.x;
+    if (K.stage != nullptr && K.stage[b] != STAGE_KKT) return;
+    const int nq = S.dm.nq, nu = S.dm.nu, ny = S.dm.nc + S.dm.nb, H = S.dm.H, nr = S.nr, nd = S.nd, nths = S.nths;
+    const int nr2 = nu + nq, N2 = H * (nr2 + nq);
+    const double* dz = kkt_dz(S, K, b, H, nths, nd);
+    const double* r = K.r + (size_t)b * S.N;
+    double* dzq = W.dzq + (size_t)b * H * nths * nq;
+    double* r2 = W.r2 + (size_t)b * N2;
+    for (int e = tid; e < H * nths * nq; e += nt) {            // q rows of the sensitivities, packed
+        const int ic = e / nq, rr = e - ic * nq;
+        dzq[e] = dz[(size_t)ic * nd + rr];
+    }
+    auto dot_y = [&](int i, int c) {                            // (column c of S_i) . r_y,i
+        const double* col = dz + ((size_t)i * nths + c) * nd + nq;
+        const double* ry = r + (size_t)i * nr + nu;
+        double acc = 0.0;
+        for (int k = 0; k < ny; ++k) acc = fma(col[k], ry[k], acc);
+        return acc;
+    };
+    for (int e = tid; e < H * nr2; e += nt) {                  // primal rows: r_x + S^T r_y
+        const int j = e / nr2, k = e - j * nr2;
+        double v;
+        if (k < nu) v = r[(size_t)j * nr + k] + dot_y(j, 2 * nq + k);
+        else {
+            const int cq = k - nu;
+            v = r[(size_t)j * nr + nu + ny + cq];
+            if (j + 1 < H) v += dot_y(j + 1, nq + cq);          // q_{j+2} is q1 of step j+1 ...
+            if (j + 2 < H) v += dot_y(j + 2, cq);               // ... and q0 of step j+2
+        }
+        r2[e] = v;
+    }
+    for (int e = tid; e < H * nq; e += nt) {                   // dual rows of q
+        const int i = e / nq, k = e - i * nq;
+        r2[(size_t)H * nr2 + e] = r[(size_t)H * nr + (size_t)i * nd + k];
+    }
+}
+
+__global__ __launch_bounds__(256) void cf_reduce_post_kernel(NewtonDev S, KktArgs K, CfReduce W) {
+    const int b = blockIdx.x + S.b0, tid = threadIdx.x, nt = blockDim.x;
+    if (K.stage != nullptr && K.stage[b] != STAGE_KKT) return;
+    const int nq = S.dm.nq, nu = S.dm.nu, nc = S.dm.nc, nbb = S.dm.nb, ny = nc + nbb, H = S.dm.H, nr = S.nr, nd = S.nd, nths = S.nths;
+    const int nr2 = nu + nq, N2 = H * (nr2 + nq);
+    const double* dz = kkt_dz(S, K, b, H, nths, nd);
+    const double* r = K.r + (size_t)b * S.N;
+    const double* d2 = W.d2 + (size_t)b * N2;
+    double* D = K.delta + (size_t)b * S.N;
+    const double beta = K.beta ? K.beta[b] : K.beta_scalar;
+    const double rho = (double)H * beta * S.kappa;
+    for (int e = tid; e < H * nr2; e += nt) {
+        const int j = e / nr2, k = e - j * nr2;
+        D[(size_t)j * nr + (k < nu ? k : ny + k)] = d2[e];
+    }
+    for (int e = tid; e < H * nq; e += nt) {
+        const int i = e / nq, k = e - i * nq;
+        D[(size_t)H * nr + (size_t)i * nd + k] = d2[(size_t)H * nr2 + e];
+    }
+    for (int e = tid; e < H * ny; e += nt) {                   // Dy_i = S_i Dtheta_i + rho r_y - r_nuy   ((I + rho G)^-1 = I here)
+        const int i = e / ny, k = e - i * ny;
+        double s = 0.0;
+        for (int c = 0; c < nths; ++c) {
+            double x;
+            if (c < nq) x = i >= 2 ? d2[(size_t)(i - 2) * nr2 + nu + c] : 0.0;
+            else if (c < 2 * nq) x = i >= 1 ? d2[(size_t)(i - 1) * nr2 + nu + (c - nq)] : 0.0;
+            else x = d2[(size_t)i * nr2 + (c - 2 * nq)];
+            s = fma(dz[((size_t)i * nths + c) * nd + nq + k], x, s);
+        }
+        D[(size_t)i * nr + nu + k] = s + rho * r[(size_t)i * nr + nu + k] - r[(size_t)H * nr + (size_t)i * nd + nq + k];
+    }
+    __syncthreads();
+    for (int e = tid; e < H * ny; e += nt) {                   // Dnu_y = G Dy - r_y
+        const int i = e / ny, k = e - i * ny;
+        double g = 0.0;
+        if (k < nc) { for (int c = 0; c < nc; ++c) g = fma(S.Cg[(size_t)i * nc * nc + (size_t)c * nc + k], D[(size_t)i * nr + nu + c], g); }
+        else { const int kb = k - nc; for (int c = 0; c < nbb; ++c) g = fma(S.Cb[(size_t)i * nbb * nbb + (size_t)c * nbb + kb], D[(size_t)i * nr + nu + nc + c], g); }
+        D[(size_t)H * nr + (size_t)i * nd + nq + k] = g - r[(size_t)i * nr + nu + k];
+    }
+    __syncthreads();
+    if (K.finish) {
+        __threadfence_block();
+        start_line_search<BlockSync>(S, b, 1, tid, nt);
+    }
+}
+
+NewtonDev cf_shadow(const NewtonDev& S) {          // the :configuration-mode problem the reduction solves
+    NewtonDev S2 = S;
+    S2.dm.mode = CIMPC_MODE_CONFIGURATION;
+    S2.nd = S.dm.nq; S2.nr = S.dm.nu + S.dm.nq; S2.N = S.dm.H * (S.dm.nu + 2 * S.dm.nq);
+    S2.Cg = nullptr; S2.Cb = nullptr;
+    return S2;
+}
+size_t cf_reduce_doubles(const NewtonDev& S) {
+    return (size_t)S.dm.B * ((size_t)S.dm.H * S.nths * S.dm.nq + 2 * (size_t)S.dm.H * (S.dm.nu + 2 * S.dm.nq));
+}
+int launch_kkt_cf_reduced(const NewtonDev& S, const KktArgs& K, double* ws, double* dense_ws, hipStream_t s) {
+    const size_t B = S.dm.B, n_dz = (size_t)S.dm.H * S.nths * S.dm.nq, N2 = (size_t)S.dm.H * (S.dm.nu + 2 * S.dm.nq);
+    CfReduce W{ws, ws + B * n_dz, ws + B * n_dz + B * N2};
+    hipLaunchKernelGGL(cf_reduce_pre_kernel, dim3(S.nb_launch), dim3(256), 0, s, S, K, W);
+    const NewtonDev S2 = cf_shadow(S);
+    const KktArgs K2{W.r2, W.d2, K.beta, K.beta_scalar, K.stage, 0, W.dzq};
+    const int rc = S.V != nullptr ? launch_kkt_dense_args(S2, K2, dense_ws, s, true) : launch_kkt_any(S2, K2, s);
+    if (rc != CIMPC_OK) return rc;
+    hipLaunchKernelGGL(cf_reduce_post_kernel, dim3(S.nb_launch), dim3(256), 0, s, S, K, W);
+    return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+}
+int launch_kkt_cf_reduced_newton(const NewtonDev& S, double* ws, double* dense_ws, hipStream_t s) {
+    const KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 1};
+    return launch_kkt_cf_reduced(S, K, ws, dense_ws, s);
+}
+int launch_kkt_cf_reduced_raw(const NewtonDev& S, const double* r_dev, double beta, double* delta_dev, double* ws, double* dense_ws, hipStream_t s) {
+    const KktArgs K{r_dev, delta_dev, nullptr, beta, nullptr, 0};
+    return launch_kkt_cf_reduced(S, K, ws, dense_ws, s);
+}
+bool kkt_cf_reduce_available(const NewtonDev& S) {   // the reduced problem must have a :configuration-mode solver
+    if (S.dm.mode != CIMPC_MODE_CONFIGURATIONFORCE) return false;
+    const NewtonDev S2 = cf_shadow(S);
+    if (S.V != nullptr) return kkt_banded_available(S2);
+    const int nq = S.dm.nq, nu = S.dm.nu;
+    return (nq == 2 && nu == 2) || (nq == 4 && nu == 2) || (nq == 11 && nu == 8) || (nq == 9 && nu == 6) || (nq == 18 && nu == 12);
+}
+
 int launch_kkt(const NewtonDev& S, hipStream_t s) {
     KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 1};
     return launch_kkt_any(S, K, s);

@@ -102,6 +102,15 @@ int launch_kkt_packed(const NewtonDev& nd, int n_kkt, int list_par, hipStream_t 
 // reference-default backend (dense jacobian! + LU with partial pivoting), any mode / objective (kkt_dense.hip)
 size_t kkt_dense_workspace_doubles(const NewtonDev& S, bool banded);
 int launch_kkt_dense_newton(const NewtonDev& S, double* ws, hipStream_t s, bool banded);
+struct KktArgs;
+int launch_kkt_dense_args(const NewtonDev& S, const KktArgs& K, double* ws, hipStream_t s, bool banded);
+// :configurationforce mode reduced to the :configuration solvers (newton_kernels.hip)
+struct CfReduce { double* dzq; double* r2; double* d2; };   // packed q rows of the sensitivities, reduced rhs, reduced solution
+NewtonDev cf_shadow(const NewtonDev& S);
+size_t cf_reduce_doubles(const NewtonDev& S);
+bool kkt_cf_reduce_available(const NewtonDev& S);
+int launch_kkt_cf_reduced_newton(const NewtonDev& S, double* ws, double* dense_ws, hipStream_t s);
+int launch_kkt_cf_reduced_raw(const NewtonDev& S, const double* r_dev, double beta, double* delta_dev, double* ws, double* dense_ws, hipStream_t s);
 bool kkt_banded_available(const NewtonDev& S);
 int launch_kkt_dense_raw(const NewtonDev& S, const double* r_dev, double beta, double* delta_dev, double* ws, hipStream_t s, bool banded);
 // B1 seam: solve with caller-provided residual / beta for all rollouts, no state change

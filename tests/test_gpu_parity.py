@@ -177,8 +177,11 @@ def test_kkt_solve_matches_dense_lu(gpu_required, model, H, H_ref):
 
 @pytest.mark.parametrize("model,mode,velocity,backend", [
     ("quadruped", 0, False, 1),     # :configuration through the reference-default backend
-    ("pushbot", 1, False, 0),       # BASELINE configs[0] dimensions, :configurationforce (policy.jl:46 default)
-    ("hopper", 1, True, 0),         # :configurationforce + TrackingVelocityObjective
+    ("pushbot", 1, False, 1),       # BASELINE configs[0] dimensions, :configurationforce (policy.jl:46 default), dense LU
+    ("hopper", 1, True, 1),         # :configurationforce + TrackingVelocityObjective, dense LU
+    ("pushbot", 1, False, 0),       # ... and as the library solves them by default: gamma / b eliminated (weights 1e-100),
+    ("hopper", 1, True, 0),         #     the rest through the condensed MFMA solve / the banded LDL^T
+    ("quadruped", 1, False, 0),
     ("hopper", 0, True, 1),         # velocity objective in :configuration mode (v_target terms), dense LU on request
     ("hopper", 0, True, 0),         # ... and through the backend the library picks for it: banded LDL^T
     ("quadruped", 0, True, 0),      # banded LDL^T, w = 81
@@ -218,9 +221,13 @@ def test_kkt_dense_lu_backend(gpu_required, model, mode, velocity, backend):
             # matrix, interleaved order): its backward error carries the growth of L (1e2 .. 1e4 here) - both far
             # inside the 1e-10 residual lu.jl's own test asks for
             banded = mode == 0 and backend != 1 and (velocity or backend == 2)
-            tol = 1e-11 if banded else 1e-13
+            reduced = mode == 1 and backend != 1        # cf mode eliminated onto the :configuration solvers
+            tol = 1e-9 if reduced else 1e-11 if banded else 1e-13
             assert back < tol, back
-            np.testing.assert_allclose(delta[b], x, rtol=0, atol=tol * np.linalg.cond(R) * max(1.0, np.abs(x).max()))
+            atol = tol * np.linalg.cond(R) * max(1.0, np.abs(x).max())
+            if reduced:     # condensed MFMA solve behind the reduction: its own bar (test_kkt_solve_matches_dense_lu)
+                atol = 1e-7 * max(1.0, np.abs(x).max())
+            np.testing.assert_allclose(delta[b], x, rtol=0, atol=atol)
 
 
 @pytest.mark.parametrize("model,mode,velocity", [("hopper", 1, False), ("quadruped", 1, False), ("hopper", 0, True)])
