@@ -230,6 +230,30 @@ def test_kkt_dense_lu_backend(gpu_required, model, mode, velocity, backend):
             np.testing.assert_allclose(delta[b], x, rtol=0, atol=atol)
 
 
+def test_cf_mode_with_real_contact_weights_keeps_the_dense_lu(gpu_required):
+    """The elimination of (gamma, b) is only taken for weights below fp64 resolution; a :configurationforce problem that
+    really penalises contact impulses goes through the dense LU and still matches numpy."""
+    from contactimplicitmpc.jl_amd import NewtonOptions
+    H, H_ref, B = 5, 7, 2
+    d, prob, tabs, rollouts = make_case("pushbot", 1, H_ref=H_ref, H=H, B=B, seed=4)
+    obj = synth.make_objective(d, H, kind="pushbot")
+    obj.gamma = np.tile((3e-2 * np.eye(d.nc))[None], (H, 1, 1))
+    obj.b = np.tile((2e-2 * np.eye(d.nb))[None], (H, 1, 1))
+    s = make_solver(d, prob, rollouts, H, obj=obj, newton_opts=NewtonOptions(kappa=prob["kappa"]))
+    ref = oracle_sweep(d, tabs, rollouts, oip.IPOptions(kappa_tol=prob["kappa"]))
+    q = np.stack([tr.q for tr, _ in ref]); th = np.stack([tr.theta for tr, _ in ref])
+    g = np.stack([tr.gamma for tr, _ in ref]); bb = np.stack([tr.b for tr, _ in ref])
+    out = s.implicit_dynamics(q, th, g, bb)
+    lay = onewton.Layout(d, H)
+    r = np.random.default_rng(0).standard_normal((B, lay.N))
+    delta = s.kkt_solve(r, 1e-3)
+    for b in range(B):
+        im = {k: out[k][b] for k in ("d", "dq0", "dq1", "du1")}
+        R = onewton.jacobian(lay, obj, im, 1e-3, prob["kappa"])
+        x = np.linalg.solve(R, r[b])
+        np.testing.assert_allclose(delta[b], x, rtol=0, atol=1e-12 * np.linalg.cond(R) * max(1.0, np.abs(x).max()))
+
+
 @pytest.mark.parametrize("model,mode,velocity", [("hopper", 1, False), ("quadruped", 1, False), ("hopper", 0, True)])
 def test_newton_solve_configurationforce_and_velocity(gpu_required, model, mode, velocity):
     """newton_solve! in :configurationforce mode / with a TrackingVelocityObjective (dense LU KKT) against
