@@ -17,6 +17,24 @@ import numpy as np
 from .solver import CIMPCSolver, InteriorPointOptions, NewtonOptions
 
 
+def update_altitude(model, alt, gamma_hist, q_hist, threshold=1.0):
+    """`update_altitude!(alt, ϕ, s, traj, t, nc, N_sample; threshold)` (mpc_utils.jl:109-136) on the window of simulator
+    steps the caller hands over (the reference looks at steps max(0, t-1-N_sample)+1 .. t-1): per contact point, the step
+    with the largest normal impulse decides - if it exceeds `threshold`, the altitude becomes ϕ_i at the configuration
+    that step ended in.  gamma_hist: (n, nc); q_hist: (n, nq) with q_hist[j] = traj.q[j+2]; alt: (nc,) updated in place."""
+    import torch
+    gamma_hist = np.asarray(gamma_hist, dtype=np.float64).reshape(-1, model.nc)
+    q_hist = np.asarray(q_hist, dtype=np.float64).reshape(gamma_hist.shape[0], model.nq)
+    for i in range(model.nc):
+        g_max, idx = 0.0, -1
+        for j in range(gamma_hist.shape[0]):
+            if gamma_hist[j, i] > g_max:
+                g_max, idx = gamma_hist[j, i], j
+        if g_max > threshold:
+            alt[i] = float(model.phi(torch.as_tensor(q_hist[idx]))[i])
+    return alt
+
+
 class CIMPCPolicy:
     def __init__(self, problem, obj_q, obj_u, H_mpc=None, N_sample=1, kappa_mpc=None, B=1, mode=0,
                  n_opts: NewtonOptions | None = None, ip_opts: InteriorPointOptions | None = None, device=0,
@@ -68,6 +86,11 @@ class CIMPCPolicy:
             self.u = u1 / self.N_sample                      # policy.jl:142-144 (:direct)
         self.cnt += 1
         return self.u
+
+    def set_altitude(self, alt):
+        """`set_altitude!(p.im_traj, p.altitude)` (policy.jl:116, implicit_dynamics.jl:141-154): (B, nc) or (nc,)."""
+        alt = np.broadcast_to(np.asarray(alt, dtype=np.float64), (self.B, self.problem.model.nc))
+        self.solver.set_altitude(np.ascontiguousarray(alt))
 
     def close(self):
         self.solver.close()

@@ -155,3 +155,21 @@ def test_newton_solve_on_the_real_quadruped_problem():
         if perturb == 0.0:
             assert st.iters == 0 and st.r_norm / N < 3e-4          # phase 37 wraps around the gait: stride handling
     assert max(its) >= 1
+
+
+def test_update_altitude_restated():
+    """mpc_utils.jl:109-136: the step with the largest normal impulse inside the window decides, per contact point."""
+    from contactimplicitmpc.jl_amd.policy import update_altitude
+    m = lcp_models.Quadruped()
+    g = gait_io.load_gait(GAITS["quadruped"][1])
+    q_hist = g.q[2:8].copy()
+    q_hist[:, 1] += np.linspace(0.0, 0.05, 6)            # lift the body a little more every step
+    gamma = np.zeros((6, 4))
+    gamma[2, 0], gamma[4, 0] = 3.0, 2.0                   # contact 1: largest impulse at step 2
+    gamma[5, 1] = 0.5                                     # contact 2: below the threshold
+    gamma[1, 3] = 1.5                                     # contact 4: step 1
+    alt = np.array([9.0, 9.0, 9.0, 9.0])
+    update_altitude(m, alt, gamma, q_hist, threshold=1.0)
+    phi = lambda q: m.phi(torch.as_tensor(q)).numpy()
+    assert alt[0] == phi(q_hist[2])[0] and alt[3] == phi(q_hist[1])[3]
+    assert alt[1] == 9.0 and alt[2] == 9.0
