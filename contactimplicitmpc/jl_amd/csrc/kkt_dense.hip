@@ -267,15 +267,19 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
             const double d = W[(size_t)sk * MS + sk], inv = 1.0 / d, yk = yw[sk];
             for (int r = tid; r <= m; r += nt) {
                 int sr = sk + r; if (sr >= M) sr -= M;
-                const double v = r == 0 ? d : W[(size_t)sr * MS + sk] * inv;
-                lv[r] = v;
-                Lr[(size_t)(k + r) * M + (w - r)] = v;           // r = 0: the pivot on the diagonal slot
+                const double v = r == 0 ? inv : W[(size_t)sr * MS + sk] * inv;    // (slot w of a row of L keeps 1 / d)
+                lv[r] = r == 0 ? d : v;
+                Lr[(size_t)(k + r) * M + (w - r)] = v;           // r = 0: the diagonal slot
                 if (r == 0) yg[k] = yk;
                 else yw[sr] = fma(-v, yk, yw[sr]);               // forward substitution rides along
             }
         }
         lds_barrier();
         const double nxt2 = row_value(k + M + 1);                // fetch for the NEXT pivot while this one updates
+        // the entering row takes the slots the pivot row / column just freed: nothing below touches slot sk (the
+        // multipliers were copied to lv), so it is committed next to the update and one barrier per pivot is saved
+        row_commit(k + M, nxt);
+        nxt = nxt2;
         {
             // rank-1 update of the whole (symmetric) m x m window, branch-free: a wavefront takes 64 consecutive
             // columns of a row, lanes beyond the coupled rows / columns work on the dummy slot with a zero multiplier.
@@ -314,9 +318,6 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
             }
         }
         lds_barrier();
-        row_commit(k + M, nxt);                                  // takes the slots the pivot row / column just freed
-        nxt = nxt2;
-        lds_barrier();
     }
     __syncthreads();              // full barrier: the rows of L and y in global memory are read back below
     // ---- back substitution  L^T x = D^-1 y  (wavefront 0; acc[j] collects sum_{i > j} L[i][j] x_i) ---------
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         for (int c = tid; c < M; c += 64) acc[c] = 0.0;
         __builtin_amdgcn_wave_barrier();
         // the rows of L come from global memory: a ring of PD rows in flight (one wavefront, nothing else to hide the latency)
-        constexpr int PD = 8;
+        constexpr int PD = 16;
         double pre[PD][3], pre_y[PD];
         auto fetch = [&](int i, int slot) {
 #pragma unroll
@@ -345,11 +346,11 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
                 const int si = i % M;
-                // the pivot d_i sits at c = w: lane (w % 64), register (w / 64)
+                // 1 / d_i sits at c = w: lane (w % 64), register (w / 64)
                 double di = 0.0;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) if (w / 64 == q) di = __shfl(cur[q], w % 64, 64);
-                const double xi = yi / di - acc[si];
+                const double xi = yi * di - acc[si];               // di = 1 / d_i
                 __builtin_amdgcn_wave_barrier();
                 if (tid == 0) { acc[si] = 0.0; D[orig(i)] = xi; }
 #pragma unroll
