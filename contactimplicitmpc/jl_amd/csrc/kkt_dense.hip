@@ -289,34 +289,44 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
             // of which 46 % move useful entries (131 of 192 column lanes, 8.2 of 12 row slots).  Blocking several
             // pivots per window update (LDS traffic / block size, MFMA-shaped) is the next step.
             const double d = lv[0];
-            const int nq = (m + 63) >> 6;                        // uniform: column chunks of 64
-            double lj[3];
-            int sjv[3];
+            const int nqf = m >> 6, tail = m - (nqf << 6);       // uniform: full column chunks of 64 + a tail of < 64 columns
+            double lj[2];
+            int sjv[2];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < 2; ++q) {
                 const int r = 1 + tx + 64 * q;
-                const bool on = r <= m;
-                lj[q] = on ? lv[on ? r : 0] : 0.0;
+                lj[q] = q < nqf ? lv[r] : 0.0;
                 int sj = sk + r; if (sj >= M) sj -= M;
-                sjv[q] = on ? sj : M;
+                sjv[q] = q < nqf ? sj : M;
             }
-            for (int r0 = 1 + ty; r0 <= m; r0 += 4 * nty) {      // four rows per trip: their loads are issued together
-                double li[4], t[4][3];
-                double* Wi[4];
+            if (nqf > 0) {
+                for (int r0 = 1 + ty; r0 <= m; r0 += 3 * nty) {  // three rows per trip: their loads are issued together
+                    double li[3], t[3][2];
+                    double* Wi[3];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int r = r0 + nty * u;
-                    const bool on = r <= m;
-                    li[u] = on ? lv[on ? r : 0] * d : 0.0;
-                    int si = sk + r; if (si >= M) si -= M;
-                    Wi[u] = W + (size_t)(on ? si : M) * MS;
+                    for (int u = 0; u < 3; ++u) {
+                        const int r = r0 + nty * u;
+                        const bool on = r <= m;
+                        li[u] = on ? lv[on ? r : 0] * d : 0.0;
+                        int si = sk + r; if (si >= M) si -= M;
+                        Wi[u] = W + (size_t)(on ? si : M) * MS;
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) if (q < nq) t[u][q] = Wi[u][sjv[q]];
+                        for (int q = 0; q < 2; ++q) if (q < nqf) t[u][q] = Wi[u][sjv[q]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 3; ++u)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) if (q < nqf) Wi[u][sjv[q]] = fma(-li[u], lj[q], t[u][q]);
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) if (q < nq) Wi[u][sjv[q]] = fma(-li[u], lj[q], t[u][q]);
+            }
+            // the tail columns (131 = 2 x 64 + 3 for the centroidal sizes) as one entry per thread over all rows:
+            // a third 64-lane chunk would spend a third of the LDS bandwidth on three useful lanes
+            for (int e = tid; e < m * tail; e += nt) {
+                const int rr = e / tail, r = 1 + rr, c = 1 + (nqf << 6) + (e - rr * tail);
+                int si = sk + r; if (si >= M) si -= M;
+                int sj = sk + c; if (sj >= M) sj -= M;
+                double* cell = W + (size_t)si * MS + sj;
+                *cell = fma(-lv[r] * d, lv[c], *cell);
             }
         }
         lds_barrier();
