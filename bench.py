@@ -100,20 +100,23 @@ def cpu_baseline(d, prob, obj, rollouts, H, H_ref, budget_s=12.0):
     return out
 
 
-def mpc_loop_latency(dims, kind, H, H_ref, device, steps=40):
+def mpc_loop_latency(dims, kind, H, H_ref, device, steps=40, mode=0):
     """Warm-started single-rollout MPC loop: newton_solve! -> rot_n_stride! / update_window! -> q0 <- q1."""
     from oracle import synth
     from oracle.dims import Dims
     from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions
-    d = Dims(**dims)
+    d = Dims(**dims, mode=mode)
     prob = synth.make_problem(d, H_ref, seed=1)
     obj = synth.make_objective(d, H, kind=kind)
     window, ref, q0, q1 = synth.make_rollout(d, prob, H, phase=0, seed=7, perturb=0.01)
-    s = CIMPCSolver(d.nq, d.nu, d.nw, d.nc, d.nb, H_ref, H, B=1, mode=0, ip_opts=InteriorPointOptions(kappa_tol=prob["kappa"]),
+    s = CIMPCSolver(d.nq, d.nu, d.nw, d.nc, d.nb, H_ref, H, B=1, mode=mode, ip_opts=InteriorPointOptions(kappa_tol=prob["kappa"]),
                     newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=3e-4, max_iter=5), device=device)
     for t in range(H_ref):
         s.set_linearization(t + 1, prob["z0"][t], prob["th0"][t], prob["r0"][t], prob["rz0"][t], prob["rth0"][t])
-    s.set_objective(obj.q, obj.u)
+    if mode == 1:
+        s.set_objective(obj.q, obj.u, obj.gamma, obj.b)      # :configurationforce: contact-impulse weights 1e-100
+    else:
+        s.set_objective(obj.q, obj.u)
     stride = np.zeros(d.nq)
     stride[0] = prob["q_ref"][-2][0] - prob["q_ref"][0][0]          # get_stride, mpc_utils.jl:103-107
     # the controller's full reference trajectory lives on the device (cimpc_set_gait); mpc_advance rotates it
@@ -361,6 +364,7 @@ def main():
         # plant: q1_next = planned q_3), reference / window advanced on the device (cimpc_mpc_advance)
         out["mpc_loop_b1"] = {"quadruped_h40": mpc_loop_latency(QUADRUPED, "quadruped", 40, 60, local_rank),
                               "hopper_h20 (BASELINE configs[1])": mpc_loop_latency(dict(nq=4, nu=2, nw=2, nc=1, nb=2), "hopper", 20, 30, local_rank),
+                              "pushbot_h10_configurationforce (BASELINE configs[0])": mpc_loop_latency(dict(nq=2, nu=2, nw=2, nc=2, nb=4), "pushbot", 10, 16, local_rank, mode=1),
                               "quadruped_h40_real_gait2": real_mpc_loop_latency(40, local_rank)}
     if not args.no_real_problem and world == 1:      # informative second workload (N = 1 only), outside the timed region
         try:
