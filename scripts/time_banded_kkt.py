@@ -1,3 +1,4 @@
+"""Times the banded LDL^T KKT backend on the real centroidal problem (H = 50, the example objective)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
