@@ -228,13 +228,15 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     if (K.stage != nullptr && K.stage[b] != STAGE_KKT) return;
     const DenseLayout L(S);
     const int N = L.N, H = L.H, nr = L.nr, nd = L.nd, s = nr + nd;
-    const int w = min(3 * s - 1 - L.nu, N - 1), M = w + 1;
-    double* Lr = ws_all + (size_t)b * ((size_t)N * M + N);       // row i: L[i][i-w .. i-1], slot w: d_i
-    double* yg = Lr + (size_t)N * M;
+    constexpr int RB = 4;                                        // pivots per window update
+    const int w = min(3 * s - 1 - L.nu, N - 1), LW = w + 1, M = w + RB;   // window slots: pivot k+RB-1 reaches row k+RB-1+w
+    double* Lr = ws_all + (size_t)b * ((size_t)N * LW + N);      // row i: L[i][i-w .. i-1], slot w: 1 / d_i
+    double* yg = Lr + (size_t)N * LW;
     const int MS = M + 1;                                        // row stride: slot M is a dummy row / column
     double* W = sm;                                              // [M+1][M+1] window, slot = index mod M; BOTH triangles kept
-    double* yw = W + (size_t)MS * MS;                            // [M]
-    double* lv = yw + M;                                         // [M]: lv[0] = d_k, lv[r] = L[k+r][k]
+    double* yw = W + (size_t)MS * MS;                            // [M]   right-hand side of the rows in the window
+    double* PL = yw + MS;                                        // [RB][M+1] multipliers of the block's pivots, by row SLOT
+    double* dv = PL + (size_t)RB * MS;                           // [RB]  the block's pivots d
     const double beta = K.beta ? K.beta[b] : K.beta_scalar;
     const double rho = (double)H * beta * S.kappa;               // newton_jacobian.jl:169-186 quirk
     const double* dzb = kkt_dz(S, K, b, H, S.nths, nd);
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     // interleaved index -> index in the reference's layout (primal segment step-major, then the duals)
     auto orig = [&](int i) { const int t = i / s, k = i - t * s; return k < nr ? t * nr + k : H * nr + t * nd + (k - nr); };
     // row i enters the window (columns i-w .. i): a row has at most w + 1 <= 192 entries - one per thread; the
-    // value is FETCHED one pivot ahead (global loads of the sensitivities / weights stay off the critical path)
+    // values are FETCHED one block ahead (global loads of the sensitivities / weights stay off the critical path)
     auto row_value = [&](int i) -> double {
         if (i >= N) return 0.0;
         if (tid <= w) { const int j = i - w + tid; return j >= 0 ? row(i, j) : 0.0; }
@@ -257,76 +259,102 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
             if (j >= 0) { const int sj = j % M; W[(size_t)si * MS + sj] = v; W[(size_t)sj * MS + si] = v; }   // and its mirror image
         } else if (tid == w + 1) yw[si] = v;
     };
-    for (int i = 0; i <= w && i < N; ++i) row_commit(i, row_value(i));
+    for (int i = 0; i < M && i < N; ++i) row_commit(i, row_value(i));
+    for (int e = tid; e < RB * MS; e += nt) PL[e] = 0.0;
     __syncthreads();
-    const int tx = tid & 63, ty = tid >> 6, nty = nt >> 6;       // update: column 1 + tx + 64 q of row 1 + ty + nty p
-    double nxt = row_value(M);                                   // row entering after pivot 0
-    for (int k = 0; k < N; ++k) {
-        const int sk = k % M, m = min(w, N - 1 - k);             // rows k+1 .. k+m are coupled to the pivot
-        {
-            const double d = W[(size_t)sk * MS + sk], inv = 1.0 / d, yk = yw[sk];
-            for (int r = tid; r <= m; r += nt) {
-                int sr = sk + r; if (sr >= M) sr -= M;
-                const double v = r == 0 ? inv : W[(size_t)sr * MS + sk] * inv;    // (slot w of a row of L keeps 1 / d)
-                lv[r] = r == 0 ? d : v;
-                Lr[(size_t)(k + r) * M + (w - r)] = v;           // r = 0: the diagonal slot
-                if (r == 0) yg[k] = yk;
-                else yw[sr] = fma(-v, yk, yw[sr]);               // forward substitution rides along
-            }
-        }
-        lds_barrier();
-        const double nxt2 = row_value(k + M + 1);                // fetch for the NEXT pivot while this one updates
-        // the entering row takes the slots the pivot row / column just freed: nothing below touches slot sk (the
-        // multipliers were copied to lv), so it is committed next to the update and one barrier per pivot is saved
-        row_commit(k + M, nxt);
-        nxt = nxt2;
-        {
-            // rank-1 update of the whole (symmetric) m x m window, branch-free: a wavefront takes 64 consecutive
-            // columns of a row, lanes beyond the coupled rows / columns work on the dummy slot with a zero multiplier.
-            // Measured with clock64 per phase (centroidal H = 50: N = 2400, w = 131, 1024 threads, 7.9 k cycles per pivot):
-            // this update 5.3 k, pivot column 0.85 k, row generation 0.8 k, commit 0.4 k, barriers 0.6 k.  The update
-            // is LDS-bandwidth bound: 16 wavefronts x 36 load + store pairs of 512 bytes at 128 B / clk = 4.6 k cycles,
-            // of which 46 % move useful entries (131 of 192 column lanes, 8.2 of 12 row slots).  Blocking several
-            // pivots per window update (LDS traffic / block size, MFMA-shaped) is the next step.
-            const double d = lv[0];
-            const int nqf = m >> 6, tail = m - (nqf << 6);       // uniform: full column chunks of 64 + a tail of < 64 columns
-            double lj[2];
-            int sjv[2];
+    const int tx = tid & 63, ty = tid >> 6, nty = nt >> 6;       // update: column tx + 64 q of row ty + nty p (relative to k + RB)
+    double nxt[RB];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int r = 1 + tx + 64 * q;
-                lj[q] = q < nqf ? lv[r] : 0.0;
-                int sj = sk + r; if (sj >= M) sj -= M;
-                sjv[q] = q < nqf ? sj : M;
-            }
-            if (nqf > 0) {
-                for (int r0 = 1 + ty; r0 <= m; r0 += 3 * nty) {  // three rows per trip: their loads are issued together
-                    double li[3], t[3][2];
-                    double* Wi[3];
-#pragma unroll
-                    for (int u = 0; u < 3; ++u) {
-                        const int r = r0 + nty * u;
-                        const bool on = r <= m;
-                        li[u] = on ? lv[on ? r : 0] * d : 0.0;
-                        int si = sk + r; if (si >= M) si -= M;
-                        Wi[u] = W + (size_t)(on ? si : M) * MS;
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) if (q < nqf) t[u][q] = Wi[u][sjv[q]];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 3; ++u)
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) if (q < nqf) Wi[u][sjv[q]] = fma(-li[u], lj[q], t[u][q]);
+    for (int t = 0; t < RB; ++t) nxt[t] = row_value(M + t);      // rows entering after the first block
+    for (int k = 0; k < N; k += RB) {
+        const int nb_ = min(RB, N - k);                          // pivots of this block
+        // ---- panel: the block's pivots one after the other, each column first brought up to date with the
+        //      earlier pivots of the block (left-looking inside the panel) ------------------------------------
+        for (int t = 0; t < nb_; ++t) {
+            const int p = k + t, sp = p % M, m = min(w, N - 1 - p);
+            if (tid < M) {
+                int sr = sp + tid; if (sr >= M) sr -= M;         // slot of row p + tid
+                double v = 0.0;
+                if (tid <= m) {
+                    v = W[(size_t)sr * MS + sp];
+                    for (int u = 0; u < t; ++u) v = fma(-PL[(size_t)u * MS + sr] * dv[u], PL[(size_t)u * MS + sp], v);
                 }
+                // every thread needs the updated pivot: recompute it (row p itself: sr = sp)
+                double d = W[(size_t)sp * MS + sp];
+                for (int u = 0; u < t; ++u) d = fma(-PL[(size_t)u * MS + sp] * dv[u], PL[(size_t)u * MS + sp], d);
+                const double inv = 1.0 / d, yp = yw[sp];
+                const double l = (tid >= 1 && tid <= m) ? v * inv : 0.0;
+                // (this phase only writes PL[t], dv[t], yw of the coupled rows: nothing another thread reads here)
+                if (tid >= 1 && tid <= m) {
+                    Lr[(size_t)(p + tid) * LW + (w - tid)] = l;
+                    yw[sr] = fma(-l, yp, yw[sr]);                // forward substitution rides along
+                }
+                if (tid == 0) { dv[t] = d; yg[p] = yp; Lr[(size_t)p * LW + w] = inv; }
+                PL[(size_t)t * MS + sr] = l;                     // all M slots: zero where the pivot does not couple
             }
-            // the tail columns (131 = 2 x 64 + 3 for the centroidal sizes) as one entry per thread over all rows:
-            // a third 64-lane chunk would spend a third of the LDS bandwidth on three useful lanes
-            for (int e = tid; e < m * tail; e += nt) {
-                const int rr = e / tail, r = 1 + rr, c = 1 + (nqf << 6) + (e - rr * tail);
-                int si = sk + r; if (si >= M) si -= M;
-                int sj = sk + c; if (sj >= M) sj -= M;
-                double* cell = W + (size_t)si * MS + sj;
-                *cell = fma(-lv[r] * d, lv[c], *cell);
+            lds_barrier();
+        }
+        // ---- rows entering the window: fetch for the NEXT block, commit this block's (their slots - the
+        //      pivots' - are not touched by the update below) -------------------------------------------------
+        double nxt2[RB];
+#pragma unroll
+        for (int t = 0; t < RB; ++t) nxt2[t] = row_value(k + M + RB + t);
+#pragma unroll
+        for (int t = 0; t < RB; ++t) { if (t < nb_) row_commit(k + M + t, nxt[t]); nxt[t] = nxt2[t]; }
+        // ---- rank-nb_ update of the trailing window, rows / columns k+RB .. k+RB-1+w --------------------------
+        {
+            const int base = k + nb_, mt = min(w, N - base);     // mt rows / columns present
+            if (mt > 0) {
+                int sb = base % M;
+                double dd[RB];
+#pragma unroll
+                for (int t = 0; t < RB; ++t) dd[t] = t < nb_ ? dv[t] : 0.0;
+                const int nqf = mt >> 6, tail = mt - (nqf << 6);
+                double lj[2][RB];
+                int sjv[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    int sj = sb + tx + 64 * q; if (sj >= M) sj -= M; if (sj >= M) sj -= M;
+                    sjv[q] = q < nqf ? sj : M;
+#pragma unroll
+                    for (int t = 0; t < RB; ++t) lj[q][t] = (q < nqf && t < nb_) ? PL[(size_t)t * MS + sj] : 0.0;
+                }
+                if (nqf > 0) {
+                    for (int r0 = ty; r0 < mt; r0 += 3 * nty) {
+                        double t_[3][2], li[3][RB];
+                        double* Wi[3];
+#pragma unroll
+                        for (int u = 0; u < 3; ++u) {
+                            const int r = r0 + nty * u;
+                            const bool on = r < mt;
+                            int si = sb + (on ? r : 0); if (si >= M) si -= M; if (si >= M) si -= M;
+#pragma unroll
+                            for (int t = 0; t < RB; ++t) li[u][t] = on ? PL[(size_t)t * MS + si] * dd[t] : 0.0;
+                            Wi[u] = W + (size_t)(on ? si : M) * MS;
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) if (q < nqf) t_[u][q] = Wi[u][sjv[q]];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 3; ++u)
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) if (q < nqf) {
+                                double acc = t_[u][q];
+#pragma unroll
+                                for (int t = 0; t < RB; ++t) acc = fma(-li[u][t], lj[q][t], acc);
+                                Wi[u][sjv[q]] = acc;
+                            }
+                    }
+                }
+                for (int e = tid; e < mt * tail; e += nt) {      // tail columns: one entry per thread over all rows
+                    const int rr = e / tail, c = (nqf << 6) + (e - rr * tail);
+                    int si = sb + rr; if (si >= M) si -= M; if (si >= M) si -= M;
+                    int sj = sb + c; if (sj >= M) sj -= M; if (sj >= M) sj -= M;
+                    double* cell = W + (size_t)si * MS + sj;
+                    double acc = *cell;
+#pragma unroll
+                    for (int t = 0; t < RB; ++t) acc = fma(-PL[(size_t)t * MS + si] * dd[t], PL[(size_t)t * MS + sj], acc);
+                    *cell = acc;
+                }
             }
         }
         lds_barrier();
@@ -343,7 +371,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         double pre[PD][3], pre_y[PD];
         auto fetch = [&](int i, int slot) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) { const int c = tid + 64 * q; pre[slot][q] = (i >= 0 && c <= w) ? Lr[(size_t)i * M + c] : 0.0; }
+            for (int q = 0; q < 3; ++q) { const int c = tid + 64 * q; pre[slot][q] = (i >= 0 && c <= w) ? Lr[(size_t)i * LW + c] : 0.0; }
             pre_y[slot] = i >= 0 ? yg[i] : 0.0;
         };
 #pragma unroll
@@ -380,13 +408,17 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     }
 }
 
+static size_t banded_lds_bytes(int w) {      // window (w + 4 slots + dummy)^2, right-hand side, 4 multiplier rows, pivots
+    const size_t MS = (size_t)w + 4 + 1;
+    return (MS * MS + MS + 4 * MS + 8) * sizeof(double);
+}
 static int band_halfwidth(const NewtonDev& S) {
     const int s = S.nr + S.nd;
     return std::min(3 * s - 1 - S.dm.nu, S.N - 1);
 }
 bool kkt_banded_available(const NewtonDev& S) {      // window + two vectors in 160 KB of LDS, back substitution: w < 192
-    const int M = band_halfwidth(S) + 1;
-    return S.dm.mode == CIMPC_MODE_CONFIGURATION && M <= 192 && ((size_t)(M + 1) * (M + 1) + 2 * (size_t)M) * sizeof(double) <= 160 * 1024;
+    const int w = band_halfwidth(S);
+    return S.dm.mode == CIMPC_MODE_CONFIGURATION && w <= 190 && banded_lds_bytes(w) <= 160 * 1024;
 }
 
 size_t kkt_dense_workspace_doubles(const NewtonDev& S, bool banded) {
@@ -396,8 +428,7 @@ size_t kkt_dense_workspace_doubles(const NewtonDev& S, bool banded) {
 
 static int launch_kkt_dense(const NewtonDev& S, const KktArgs& K, double* ws, hipStream_t s, bool banded) {
     if (banded) {
-        const int M = band_halfwidth(S) + 1;
-        const size_t lds = ((size_t)(M + 1) * (M + 1) + 2 * (size_t)M) * sizeof(double);
+        const size_t lds = banded_lds_bytes(band_halfwidth(S));
         static LdsOptIn optin;
         if (lds_opt_in(optin, (const void*)kkt_banded_kernel, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
         hipLaunchKernelGGL(kkt_banded_kernel, dim3(S.nb_launch), dim3(CIMPC_BANDED_THREADS), lds, s, S, K, ws);
