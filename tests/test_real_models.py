@@ -173,3 +173,33 @@ def test_update_altitude_restated():
     phi = lambda q: m.phi(torch.as_tensor(q)).numpy()
     assert alt[0] == phi(q_hist[2])[0] and alt[3] == phi(q_hist[1])[3]
     assert alt[1] == 9.0 and alt[2] == 9.0
+
+
+def test_reference_trajectory_test_tracking_error_of_the_repeated_gait_is_zero():
+    """test/controller/trajectory.jl:1-12: flamingo gait repeated five times (repeat_ref_traj, idx_shift = [1]) against
+    itself, N_sample = 1  ->  tracking_error == 0 in all four components."""
+    from oracle import plant as pl
+    g = gait_io.load_gait(GAITS["flamingo"][1])
+    n_rep, H = 5, g.H
+    shift = np.zeros(g.q.shape[1]); shift[0] = g.q[-1][0] - g.q[1][0]          # trajectory.jl:87
+    q = [g.q[t] for t in range(H + 2)]
+    for i in range(1, n_rep):
+        q += [g.q[t + 2] + i * shift for t in range(H)]
+    rep = lambda a: np.concatenate([a] * n_rep)
+    e = pl.tracking_error(g.q, g.u, g.gamma, g.b, np.array(q), rep(g.u), rep(g.gamma), rep(g.b), 1)
+    assert e == (0.0, 0.0, 0.0, 0.0)
+
+
+def test_reference_linearized_step_test_on_the_true_quadruped():
+    """test/controller/linearized_step.jl:1-30 (quadruped case): a LinearizedStep at random (z, θ) holds them and the
+    residual / Jacobian evaluated there - here: LinTable built from `linearize` reproduces r0 exactly at the point."""
+    m = lcp_models.Quadruped()
+    d = Dims(nq=m.nq, nu=m.nu, nw=m.nw, nc=m.nc, nb=m.nb)
+    rng = np.random.default_rng(5)
+    z, th, kappa = rng.random(m.nz), rng.random(m.nth), 1e-5
+    r0, rz0, rth0 = m.linearize(z, th, kappa)
+    tab = lcp.LinTable(d, z, th, r0, rz0, rth0)
+    assert np.abs(tab.x0 - z[d.ix]).max() == 0.0 and np.abs(tab.th0 - th).max() == 0.0
+    rdyn, rrst, rbil = lcp.rlin(tab, z, th, kappa)          # "the linearization is exact at the linearization point"
+    assert np.abs(np.concatenate([rdyn, rrst, rbil]) - r0).max() < 1e-8
+    assert np.abs(lcp.dense_rz(tab, z) - rz0).max() < 1e-8
