@@ -169,6 +169,16 @@ class _Reader:
         return a.reshape(d.shape[::-1]).T if len(d.shape) > 1 else a     # HDF5 stores Julia's dims reversed
 
 
+    def struct_slots(self, rel: int) -> bytes:
+        """Raw bytes of a scalar dataset stored with a compact layout, whatever its (committed) datatype - a Julia
+        struct saved by JLD2: 8-byte slots, plain fields inline, array fields as relative object addresses."""
+        for mtype, m in self.messages(rel):
+            if mtype == 0x08 and m[0] in (3, 4) and m[1] == 0:
+                n = struct.unpack_from("<H", m, 2)[0]
+                return m[4:4 + n]
+        raise GaitFormatError(f"object at {rel} has no compact data")
+
+
 def read_jld2(path) -> dict:
     """All root-level datasets of a gait file: name -> float / ndarray / list of ndarrays."""
     with open(path, "rb") as f:
@@ -209,3 +219,45 @@ def load_gait(path) -> Gait:
     mu = float(np.asarray(mu).reshape(-1)[0])
     return Gait(q=np.stack(d["qm"]), u=np.stack(d["um"]), gamma=np.stack(d["γm"]), b=np.stack(d["bm"]),
                 psi=np.stack(d["ψm"]), eta=np.stack(d["ηm"]), mu=mu, h=float(d["hm"]))
+
+
+@dataclass
+class JointTraj:
+    """A serialized `ContactTraj` (`load_type = :joint_traj`, trajectory.jl:181-182; fields trajectory.jl:1-19)."""
+    H: int
+    h: float
+    kappa: float
+    q: np.ndarray          # (H + 2, nq)
+    u: np.ndarray          # (H, nu)
+    w: np.ndarray          # (H, nw)
+    gamma: np.ndarray      # (H, nc)
+    b: np.ndarray          # (H, nb)
+    z: np.ndarray          # (H, nz)
+    theta: np.ndarray      # (H, nθ)
+
+
+def load_joint_traj(path) -> JointTraj:
+    """Reads the `traj` struct of a :joint_traj gait file (e.g. src/dynamics/hopper_2D/gaits/gait_forward.jld2): 17
+    eight-byte slots in the field order of `ContactTraj` - H, h inline, then the addresses of κ, q, u, w, γ, b, z, θ and of
+    the seven index vectors.  The shapes are cross-checked against each other; anything unexpected raises."""
+    with open(path, "rb") as f:
+        r = _Reader(f.read())
+    links = r.links(r.root)
+    if "traj" not in links:
+        raise GaitFormatError(f"{path}: no `traj` object (not a :joint_traj gait file)")
+    raw = r.struct_slots(links["traj"])
+    if len(raw) != 17 * 8:
+        raise GaitFormatError(f"{path}: ContactTraj struct of {len(raw)} bytes, expected 136")
+    H = struct.unpack_from("<q", raw, 0)[0]
+    h = struct.unpack_from("<d", raw, 8)[0]
+    fields = [r.value(struct.unpack_from("<Q", raw, 8 * k)[0]) for k in range(2, 17)]
+    kappa, q, u, w, g, b, z, th = fields[:8]
+    arr = lambda v: np.stack(v) if isinstance(v, list) else np.asarray(v)
+    q, u, w, g, b, z, th = map(arr, (q, u, w, g, b, z, th))
+    nq, nu, nw, nc, nb = q.shape[1], u.shape[1], w.shape[1], g.shape[1], b.shape[1]
+    ok = (q.shape[0] == H + 2 and all(a.shape[0] == H for a in (u, w, g, b, z, th)) and 0.0 < h < 1.0
+          and z.shape[1] == nq + 4 * nc + 2 * nb and th.shape[1] == 2 * nq + nu + nw + 2
+          and [len(np.atleast_1d(f)) for f in fields[8:]] == [nq, nq, nu, nw, nq, nc, nb])
+    if not ok:
+        raise GaitFormatError(f"{path}: the struct does not have the ContactTraj field layout")
+    return JointTraj(int(H), float(h), float(np.atleast_1d(kappa)[0]), q, u, w, g, b, z, th)

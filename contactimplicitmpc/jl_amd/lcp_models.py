@@ -388,6 +388,13 @@ def reference_problem(model: ContactModel, gait, kappa: float, update_friction: 
                             r0, rz0, rth0)
 
 
+def reference_problem_from_traj(model: ContactModel, traj, kappa: float) -> ReferenceProblem:
+    """The same from a serialized ContactTraj (`load_type = :joint_traj`: z and θ come from the file as they are)."""
+    r0, rz0, rth0 = model.linearize_batch(traj.z, traj.theta, kappa)
+    return ReferenceProblem(model, traj.H, traj.h, kappa, traj.q.copy(), traj.u.copy(), traj.w.copy(), traj.gamma.copy(),
+                            traj.b.copy(), traj.z.copy(), traj.theta.copy(), r0, rz0, rth0)
+
+
 def get_stride(model: ContactModel, q_ref: np.ndarray) -> np.ndarray:
     """`get_stride` (mpc_utils.jl:103-107): forward progress of one gait period, first coordinate only."""
     stride = np.zeros(model.nq)

@@ -203,3 +203,27 @@ def test_reference_linearized_step_test_on_the_true_quadruped():
     rdyn, rrst, rbil = lcp.rlin(tab, z, th, kappa)          # "the linearization is exact at the linearization point"
     assert np.abs(np.concatenate([rdyn, rrst, rbil]) - r0).max() < 1e-8
     assert np.abs(lcp.dense_rz(tab, z) - rz0).max() < 1e-8
+
+
+def test_joint_traj_reader_on_the_hopper_gait():
+    """`load_type = :joint_traj` (trajectory.jl:181-182): the serialized ContactTraj of src/dynamics/hopper_2D/gaits/
+    gait_forward.jld2.  The file predates the shipped hopper model (its z still has an older ordering and the leg-length
+    equation is off by 4e-3), so it pins the READER - field order, shapes, h, κ - and the hopper dynamics only in the three
+    body coordinates."""
+    t = gait_io.load_joint_traj(os.path.join(os.path.dirname(GAITS["quadruped"][1]), "hopper_gait_forward.jld2"))
+    assert (t.H, t.h, t.kappa) == (92, 0.01, 2e-8)
+    assert (t.q.shape, t.u.shape, t.w.shape, t.gamma.shape, t.b.shape, t.z.shape, t.theta.shape) == \
+        ((94, 4), (92, 2), (92, 2), (92, 1), (92, 2), (92, 12), (92, 14))
+    # θ = [q0; q1; u1; w1; μ; h] of the same step (index.jl:413-415)
+    k = 17
+    np.testing.assert_array_equal(t.theta[k], np.concatenate([t.q[k], t.q[k + 1], t.u[k], t.w[k], [0.8], [0.01]]))
+    np.testing.assert_array_equal(t.z[k][:7], np.concatenate([t.q[k + 2], t.gamma[k], t.b[k]]))
+    m = lcp_models.Hopper2D()
+    res = []
+    for k in range(t.H):
+        z = m.pack_z(t.q[k + 2], t.gamma[k], t.b[k], np.ones(1), np.ones(2))
+        res.append(m.residual(torch.as_tensor(z), torch.as_tensor(t.theta[k]), torch.tensor(0.0, dtype=torch.float64)).numpy()[:4])
+    res = np.abs(np.array(res)).max(axis=0)
+    assert res[:3].max() < 1e-4 and res[3] < 1e-2
+    with pytest.raises(gait_io.GaitFormatError):
+        gait_io.load_joint_traj(GAITS["quadruped"][1])          # a :split_traj_alt file has no `traj` object
