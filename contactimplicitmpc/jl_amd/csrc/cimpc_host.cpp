@@ -66,7 +66,7 @@ struct cimpc_ctx {
     double *d_q0 = nullptr, *d_q1 = nullptr;
     double* d_rhs = nullptr;   // B1 seam staging
     double* d_pstate = nullptr;   // parked interior-point iterates
-    int iter_cap = 16;
+    int iter_cap = 24;            // measured B = 512: 16 / 20 / 24 / 32 / 48 -> 13.57 / 12.73 / 12.85 / 12.97 / 14.41 ms per batch step
     NewtonDev S{};
     int* h_counters = nullptr;   // pinned
     // bookkeeping
