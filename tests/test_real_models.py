@@ -227,3 +227,22 @@ def test_joint_traj_reader_on_the_hopper_gait():
     assert res[:3].max() < 1e-4 and res[3] < 1e-2
     with pytest.raises(gait_io.GaitFormatError):
         gait_io.load_joint_traj(GAITS["quadruped"][1])          # a :split_traj_alt file has no `traj` object
+
+
+def test_make_rollout_equals_rot_n_stride_on_the_full_trajectory():
+    """The closed form `lcp_models.make_rollout` / `cimpc_set_gait` use for "k applications of rot_n_stride!" (mpc_utils.jl:
+    1-101) against the oracle applying it k times to the full reference trajectory: two laps of the quadruped gait."""
+    from oracle import mpc as ompc
+    d, P, prob, tabs = real_problem("quadruped", 2e-4)
+    H = 10
+    tr = onewton.Traj(q=P.q.copy(), u=P.u.copy(), w=P.w.copy(), gamma=P.gamma.copy(), b=P.b.copy(), theta=P.theta.copy())
+    win = np.arange(H + 2)
+    for k in range(2 * P.H + 5):
+        r = lcp_models.make_rollout(P, H, k)
+        np.testing.assert_array_equal(r["window"], win)
+        np.testing.assert_allclose(r["q"], tr.q[:H + 2], rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(r["u"], tr.u[:H])
+        np.testing.assert_array_equal(r["gamma"], tr.gamma[:H])
+        np.testing.assert_allclose(r["theta"], tr.theta[:H], rtol=0, atol=1e-12)
+        ompc.rot_n_stride(d, tr, prob["stride"])
+        win = ompc.update_window(win, P.H)
