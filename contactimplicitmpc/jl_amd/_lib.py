@@ -77,6 +77,8 @@ SIGNATURES = {
     "cimpc_get_newton_info": (C.c_int, [_h, _ip, _dp, _dp]),
     "cimpc_mpc_advance": (C.c_int, [_h, _dp]),
     "cimpc_set_gait": (C.c_int, [_h, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "cimpc_plant_step": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_double, C.c_double, C.POINTER(IpOpts),
+                                   _dp, _dp, _dp, _ip, _ip]),
     "cimpc_get_reference": (C.c_int, [_h, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
     "cimpc_get_stats": (C.c_int, [_h, C.POINTER(Stats)]),
     "cimpc_get_rollout_counters": (C.c_int, [_h, _ip, _ip, _ip]),

@@ -1,0 +1,201 @@
+// Plant-side residual of the reference's planar-chain models (quadruped, flamingo) for the batched simulator step
+// (SURVEY.md section 8f-4).  Host- and device-compilable.
+//
+//   residual            src/simulation/simulation.jl:133-158     (LinearizedCone, flat ground: surface rotation = identity)
+//   dynamics            src/dynamics/model.jl:11-36              (variational midpoint integrator)
+//   quadruped           src/dynamics/quadruped/model.jl:75-590   flamingo  src/dynamics/flamingo/model.jl:62-503
+//
+// A model is a table: bodies and contact points are chains of (signed length, angle index) segments from the hip at
+// (x, z) - a segment adds r (sin θ, -cos θ).  For such a chain with absolute angles the Lagrangian derivatives the
+// integrator needs are explicit sums over the bodies,
+//   D2L = dL/dq' ,   D1L = dL/dq - (d/dq dL/dq') q'      (dynamics/model.jl:11-15 with C of quadruped/model.jl:479-484),
+// so no code generation is involved.  The Jacobian dr/dz comes from evaluating the same code on first-order dual
+// numbers (one tangent direction per lane in the kernel): exact derivatives.
+#pragma once
+#include <cmath>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define PLANT_HD __host__ __device__ __forceinline__
+#else
+#define PLANT_HD inline
+#endif
+
+namespace cimpc {
+
+struct Dual {            // value + one tangent, eps^2 = 0
+    double v, d;
+};
+PLANT_HD Dual operator+(Dual a, Dual b) { return {a.v + b.v, a.d + b.d}; }
+PLANT_HD Dual operator-(Dual a, Dual b) { return {a.v - b.v, a.d - b.d}; }
+PLANT_HD Dual operator-(Dual a) { return {-a.v, -a.d}; }
+PLANT_HD Dual operator*(Dual a, Dual b) { return {a.v * b.v, a.d * b.v + a.v * b.d}; }
+PLANT_HD Dual operator*(double a, Dual b) { return {a * b.v, a * b.d}; }
+PLANT_HD Dual operator*(Dual a, double b) { return {a.v * b, a.d * b}; }
+PLANT_HD Dual operator+(Dual a, double b) { return {a.v + b, a.d}; }
+PLANT_HD Dual operator-(Dual a, double b) { return {a.v - b, a.d}; }
+PLANT_HD Dual operator/(Dual a, double b) { return {a.v / b, a.d / b}; }
+PLANT_HD Dual psin(Dual a) { return {sin(a.v), a.d * cos(a.v)}; }
+PLANT_HD Dual pcos(Dual a) { return {cos(a.v), -a.d * sin(a.v)}; }
+PLANT_HD double psin(double a) { return sin(a); }
+PLANT_HD double pcos(double a) { return cos(a); }
+PLANT_HD double pval(double a) { return a; }
+PLANT_HD double pval(Dual a) { return a.v; }
+template <class T> PLANT_HD T pconst(double a);
+template <> PLANT_HD double pconst<double>(double a) { return a; }
+template <> PLANT_HD Dual pconst<Dual>(double a) { return {a, 0.0}; }
+
+constexpr int PLANT_MAX_Q = 11, PLANT_MAX_U = 8, PLANT_MAX_BODIES = 9, PLANT_MAX_SEG = 3;
+constexpr int PLANT_NC = 4, PLANT_NB = 8, PLANT_NW = 2;      // four contacts, two-sided friction cone, flat_2D_lc
+
+struct PlantChain { int n; double r[PLANT_MAX_SEG]; int k[PLANT_MAX_SEG]; };
+struct PlantModel {
+    int nq, nu, n_bodies;
+    double g, mu_world;
+    double mass[PLANT_MAX_BODIES], inertia[PLANT_MAX_BODIES];
+    int own[PLANT_MAX_BODIES];
+    PlantChain body[PLANT_MAX_BODIES];
+    PlantChain foot[PLANT_NC];
+    int tq_a[PLANT_MAX_U], tq_b[PLANT_MAX_U];     // actuator i: torque between links a and b (B = -e_a + e_b)
+    double joint_friction[PLANT_MAX_Q];
+    PLANT_HD int nz() const { return nq + 4 * PLANT_NC + 2 * PLANT_NB; }
+    PLANT_HD int nth() const { return 2 * nq + nu + PLANT_NW + 2; }
+};
+
+// D1L, D2L at (q, v), accumulated into d1, d2 (nq entries each, zeroed here)
+template <class T>
+PLANT_HD void plant_lagrangian_derivatives(const PlantModel& M, const T* q, const T* v, T* d1, T* d2) {
+    T s[PLANT_MAX_Q], c[PLANT_MAX_Q];
+    for (int i = 0; i < M.nq; ++i) { d1[i] = pconst<T>(0.0); d2[i] = pconst<T>(0.0); s[i] = psin(q[i]); c[i] = pcos(q[i]); }
+    for (int b = 0; b < M.n_bodies; ++b) {
+        const double m = M.mass[b];
+        const PlantChain& ch = M.body[b];
+        T vx = v[0], vz = v[1], ax = pconst<T>(0.0), az = pconst<T>(0.0);
+        for (int e = 0; e < ch.n; ++e) {
+            const int k = ch.k[e]; const double r = ch.r[e];
+            vx = vx + r * (c[k] * v[k]);
+            vz = vz + r * (s[k] * v[k]);
+            ax = ax - r * (s[k] * (v[k] * v[k]));      // derivative of the body velocity along q' in q
+            az = az + r * (c[k] * (v[k] * v[k]));
+        }
+        d2[0] = d2[0] + m * vx;
+        d2[1] = d2[1] + m * vz;
+        d1[0] = d1[0] - m * ax;
+        d1[1] = d1[1] - (m * az + m * M.g);
+        for (int e = 0; e < ch.n; ++e) {
+            const int k = ch.k[e]; const double r = ch.r[e];
+            d2[k] = d2[k] + (r * m) * (c[k] * vx + s[k] * vz);
+            // dL/dθ_k - d(dL/dθ'_k)/dq q': the velocity-product terms cancel, gravity and the centripetal part stay
+            d1[k] = d1[k] - ((m * M.g * r) * s[k] + (r * m) * (c[k] * ax + s[k] * az));
+        }
+        d2[M.own[b]] = d2[M.own[b]] + M.inertia[b] * v[M.own[b]];
+    }
+}
+
+// r(z, θ, κ): z = [q2; γ; b; ψ; s1; η; s2], θ = [q0; q1; u1; w1; μ; h] (θ real: only dr/dz is needed)
+template <class T>
+PLANT_HD void plant_residual(const PlantModel& M, const T* z, const double* th, double kappa, T* r) {
+    const int nq = M.nq, nu = M.nu, nc = PLANT_NC, nb = PLANT_NB;
+    const double* q0 = th; const double* q1 = th + nq; const double* u1 = th + 2 * nq; const double* w1 = u1 + nu;
+    const double mu = w1[PLANT_NW], h = w1[PLANT_NW + 1];
+    const T* q2 = z; const T* gam = z + nq; const T* b = gam + nc; const T* psi = b + nb; const T* s1 = psi + nc;
+    const T* eta = s1 + nc; const T* s2 = eta + nb;
+    T qm1[PLANT_MAX_Q], vm1[PLANT_MAX_Q], qm2[PLANT_MAX_Q], vm2[PLANT_MAX_Q];
+    for (int i = 0; i < nq; ++i) {
+        qm1[i] = pconst<T>(0.5 * (q0[i] + q1[i])); vm1[i] = pconst<T>((q1[i] - q0[i]) / h);
+        qm2[i] = (q2[i] + q1[i]) * 0.5; vm2[i] = (q2[i] - q1[i]) / h;
+    }
+    T a1[PLANT_MAX_Q], b1[PLANT_MAX_Q], a2[PLANT_MAX_Q], b2[PLANT_MAX_Q];
+    plant_lagrangian_derivatives(M, qm1, vm1, a1, b1);
+    plant_lagrangian_derivatives(M, qm2, vm2, a2, b2);
+    T dyn[PLANT_MAX_Q];
+    for (int i = 0; i < nq; ++i)
+        dyn[i] = (0.5 * h) * a1[i] + b1[i] + (0.5 * h) * a2[i] - b2[i] - (h * M.joint_friction[i]) * vm2[i];
+    for (int i = 0; i < nu; ++i) { dyn[M.tq_a[i]] = dyn[M.tq_a[i]] - u1[i]; dyn[M.tq_b[i]] = dyn[M.tq_b[i]] + u1[i]; }
+    dyn[0] = dyn[0] + w1[0]; dyn[1] = dyn[1] + w1[1];
+    // contacts: position, Jacobian rows (x and z) of every foot at q2
+    T s[PLANT_MAX_Q], c[PLANT_MAX_Q];
+    for (int i = 0; i < nq; ++i) { s[i] = psin(q2[i]); c[i] = pcos(q2[i]); }
+    for (int f = 0; f < nc; ++f) {
+        const PlantChain& ch = M.foot[f];
+        T pz = q2[1];
+        T lx = b[2 * f] - b[2 * f + 1], lz = gam[f];                 // contact force [m b; γ]
+        T vx = (q2[0] - q1[0]) / h;                                  // tangential foot velocity J_x (q2 - q1) / h
+        dyn[0] = dyn[0] + lx; dyn[1] = dyn[1] + lz;                  // J^T λ: base columns
+        for (int e = 0; e < ch.n; ++e) {
+            const int k = ch.k[e]; const double rr = ch.r[e];
+            pz = pz - rr * c[k];
+            dyn[k] = dyn[k] + rr * (c[k] * lx + s[k] * lz);
+            vx = vx + rr * (c[k] * ((q2[k] - q1[k]) / h));
+        }
+        r[nq + f] = s1[f] - pz;                                      // s1 - ϕ(q2)
+        r[nq + nc + 2 * f] = eta[2 * f] - vx - psi[f];               // η - v_T stack - Eᵀψ
+        r[nq + nc + 2 * f + 1] = eta[2 * f + 1] + vx - psi[f];
+        r[nq + nc + nb + f] = s2[f] - (mu * gam[f] - (b[2 * f] + b[2 * f + 1]));
+        r[nq + 2 * nc + nb + f] = gam[f] * s1[f] - kappa;
+        r[nq + 3 * nc + nb + 2 * f] = b[2 * f] * eta[2 * f] - kappa;
+        r[nq + 3 * nc + nb + 2 * f + 1] = b[2 * f + 1] * eta[2 * f + 1] - kappa;
+        r[nq + 3 * nc + 2 * nb + f] = psi[f] * s2[f] - kappa;
+    }
+    for (int i = 0; i < nq; ++i) r[i] = dyn[i];
+}
+
+// ---- the two models the reference tests in closed loop ---------------------------------------------------------------
+inline PlantChain plant_chain(int n, double r0, int k0, double r1 = 0, int k1 = 0, double r2 = 0, int k2 = 0) {
+    PlantChain c{}; c.n = n; c.r[0] = r0; c.k[0] = k0; c.r[1] = r1; c.k[1] = k1; c.r[2] = r2; c.k[2] = k2; return c;
+}
+inline PlantModel plant_quadruped() {          // quadruped/model.jl:516-575
+    PlantModel M{};
+    M.nq = 11; M.nu = 8; M.g = 9.81; M.mu_world = 1.0;
+    const double m_torso = 4.713 + 4 * 0.696, m_thigh = 1.013, m_leg = 0.166;
+    const double J_torso = 0.01683 + 4 * 0.696 * 0.183 * 0.183, J_thigh = 0.00552, J_leg = 0.00299;
+    const double l_torso = 0.183 * 2, l_thigh = 0.2, l_leg = 0.2;
+    const double d_torso = 0.5 * l_torso + 0.0127, d_thigh = 0.5 * l_thigh - 0.00323, d_leg = 0.5 * l_leg - 0.006435;
+    int nb = 0;
+    auto add = [&](double m, double J, int own, PlantChain c) { M.mass[nb] = m; M.inertia[nb] = J; M.own[nb] = own; M.body[nb] = c; ++nb; };
+    add(m_torso, J_torso, 2, plant_chain(1, d_torso, 2));
+    const int legs[4][2] = {{3, 4}, {5, 6}, {7, 8}, {9, 10}};
+    for (int l = 0; l < 4; ++l) {
+        const int th = legs[l][0], ca = legs[l][1];
+        if (l < 2) {
+            add(m_thigh, J_thigh, th, plant_chain(1, d_thigh, th));
+            add(m_leg, J_leg, ca, plant_chain(2, l_thigh, th, d_leg, ca));
+            M.foot[l] = plant_chain(2, l_thigh, th, l_leg, ca);
+        } else {                                   // legs 3, 4 hang from the far end of the torso
+            add(m_thigh, J_thigh, th, plant_chain(2, l_torso, 2, d_thigh, th));
+            add(m_leg, J_leg, ca, plant_chain(3, l_torso, 2, l_thigh, th, d_leg, ca));
+            M.foot[l] = plant_chain(3, l_torso, 2, l_thigh, th, l_leg, ca);
+        }
+    }
+    M.n_bodies = nb;
+    const int pairs[8][2] = {{2, 3}, {3, 4}, {2, 5}, {5, 6}, {2, 7}, {7, 8}, {2, 9}, {9, 10}};
+    for (int i = 0; i < 8; ++i) { M.tq_a[i] = pairs[i][0]; M.tq_b[i] = pairs[i][1]; }
+    for (int i = 0; i < 11; ++i) M.joint_friction[i] = i < 3 ? 0.0 : 0.1;
+    return M;
+}
+inline PlantModel plant_flamingo() {           // flamingo/model.jl:458-495
+    PlantModel M{};
+    M.nq = 9; M.nu = 6; M.g = 9.81; M.mu_world = 0.9;
+    const double m_torso = 12.0, m_thigh = 0.4598, m_calf = 0.306, m_foot = 0.3466;
+    const double J_torso = 0.10, J_thigh = 0.01256, J_calf = 0.00952, J_foot = 0.0015;
+    const double l_thigh = 0.42, l_calf = 0.45, l_foot = 0.1725;
+    const double d_torso = 0.20, d_thigh = 0.21, d_calf = 0.225, d_foot = 0.0525, cb = 0.5 * (l_foot - d_foot);
+    int nb = 0;
+    auto add = [&](double m, double J, int own, PlantChain c) { M.mass[nb] = m; M.inertia[nb] = J; M.own[nb] = own; M.body[nb] = c; ++nb; };
+    add(m_torso, J_torso, 2, plant_chain(1, -d_torso, 2));           // the torso points up from the hip
+    const int legs[2][3] = {{3, 4, 7}, {5, 6, 8}};
+    for (int l = 0; l < 2; ++l) {
+        const int th = legs[l][0], ca = legs[l][1], ft = legs[l][2];
+        add(m_thigh, J_thigh, th, plant_chain(1, d_thigh, th));
+        add(m_calf, J_calf, ca, plant_chain(2, l_thigh, th, d_calf, ca));
+        add(m_foot, J_foot, ft, plant_chain(3, l_thigh, th, l_calf, ca, cb, ft));
+        M.foot[2 * l] = plant_chain(3, l_thigh, th, l_calf, ca, l_foot, ft);          // toe
+        M.foot[2 * l + 1] = plant_chain(3, l_thigh, th, l_calf, ca, -d_foot, ft);     // heel
+    }
+    M.n_bodies = nb;
+    const int pairs[6][2] = {{2, 3}, {3, 4}, {2, 5}, {5, 6}, {4, 7}, {6, 8}};
+    for (int i = 0; i < 6; ++i) { M.tq_a[i] = pairs[i][0]; M.tq_b[i] = pairs[i][1]; }
+    for (int i = 0; i < 9; ++i) M.joint_friction[i] = 0.0;
+    return M;
+}
+
+}  // namespace cimpc

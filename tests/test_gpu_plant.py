@@ -1,0 +1,55 @@
+"""Device plant step (`cimpc_plant_step`) against the CPU restatement of the same step
+(oracle/plant.py), and the reference's closed loop with BOTH sides on the device: policy and plant."""
+import numpy as np
+import pytest
+
+from oracle import ip as oip
+from oracle import plant as pl, synth
+from real_problems import real_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("model,which,mu,eps_min", [("quadruped", "quadruped", 1.0, 0.25), ("flamingo", "flamingo", 0.9, 0.05)])
+def test_plant_step_matches_the_cpu_restatement(gpu_required, model, which, mu, eps_min):
+    from contactimplicitmpc.jl_amd import InteriorPointOptions, plant
+    d, P, prob, tabs = real_problem(which, 2e-4, False, 0)
+    cpu = pl.QuadrupedPlant() if model == "quadruped" else pl.FlamingoPlant()
+    knots = [0, 7, 19, 33, 48, 57]
+    rng = np.random.default_rng(2)
+    q0 = np.stack([P.q[t] for t in knots]); q1 = np.stack([P.q[t + 1] for t in knots]) + 1e-3 * rng.standard_normal((len(knots), d.nq))
+    u = np.stack([P.u[t] for t in knots]) * np.array([1.0, 0.2, 1.0, 0.2, 1.0, 0.2])[:, None]      # full and N_sample-scaled controls
+    for h in (P.h, P.h / 5):
+        o_cpu = oip.IPOptions(r_tol=1e-8, kappa_tol=1e-8, undercut=np.inf, gamma_reg=0.1, eps_min=eps_min, max_iter=100, max_ls=25)
+        o_dev = InteriorPointOptions(r_tol=1e-8, kappa_tol=1e-8, undercut=float("inf"), eps_min=eps_min, max_iter=100, max_ls=25)
+        q2, g, b, st, it = plant.plant_step(model, q0, q1, u, mu, h, opts=o_dev)
+        assert st.all()
+        for k in range(len(knots)):
+            s_, i_, q2c, gc, bc = pl.plant_step(cpu, q0[k], q1[k], u[k], np.zeros(2), mu, h, o_cpu)
+            assert s_ and abs(int(it[k]) - i_) <= 1
+            np.testing.assert_allclose(q2[k], q2c, rtol=0, atol=1e-7)
+            np.testing.assert_allclose(g[k], gc, rtol=0, atol=1e-5 * max(1.0, np.abs(gc).max()))
+            np.testing.assert_allclose(b[k], bc, rtol=0, atol=1e-5 * max(1.0, np.abs(bc).max()))
+
+
+def test_closed_loop_with_policy_and_plant_on_the_device(gpu_required):
+    """test/controller/mpc_quadruped.jl with the device policy AND the device plant; two robots side by side (the second one
+    starts from a perturbed state) - nothing but q1 / u crosses the host per step."""
+    from contactimplicitmpc.jl_amd import InteriorPointOptions, NewtonOptions, plant
+    from contactimplicitmpc.jl_amd.policy import CIMPCPolicy
+    KAPPA, H_MPC, N_SAMPLE, H_sim = 2e-4, 10, 5, 300
+    d, P, prob, tabs = real_problem("quadruped", KAPPA, True)
+    obj = synth.make_objective(d, H_MPC, kind="quadruped")
+    B = 2
+    pol = CIMPCPolicy(P, obj.q, obj.u, H_mpc=H_MPC, N_sample=N_SAMPLE, B=B, n_opts=NewtonOptions(kappa=KAPPA, r_tol=3e-4, max_iter=5),
+                      ip_opts=InteriorPointOptions(kappa_tol=KAPPA, r_tol=1e-8))
+    q1 = np.stack([P.q[1], P.q[1]]); v1 = np.stack([(P.q[1] - P.q[0]) / P.h] * 2)
+    q1[1, 1] += 0.01; q1[1, 3:] += 0.02                                     # robot 2: 1 cm higher, joints 0.02 rad off
+    ok, q, u, g, b = plant.simulate("quadruped", pol, q1, v1, H_sim, P.h / N_SAMPLE, mu=1.0)
+    pol.close()
+    assert ok
+    e0 = pl.tracking_error(P.q, P.u, P.gamma, P.b, q[:, 0], u[:, 0], g[:, 0], b[:, 0], N_SAMPLE)
+    e1 = pl.tracking_error(P.q, P.u, P.gamma, P.b, q[:, 1], u[:, 1], g[:, 1], b[:, 1], N_SAMPLE)
+    nominal = (0.0201, 0.0437, 0.374, 0.0789)
+    assert all(a < 1.5 * n for a, n in zip(e0, nominal)) and all(a < 2.0 * n for a, n in zip(e1, nominal))
+    assert abs(e0[1] / nominal[1] - 1) < 0.05 and abs(e0[2] / nominal[2] - 1) < 0.05 and abs(e0[3] / nominal[3] - 1) < 0.05
