@@ -153,3 +153,55 @@ def test_ip_converges_like_reference_boundary_tests():
         assert np.abs(dz).sum() != 0.0
         assert np.abs(z[:d.nq] - prob["q_ref"][t + 2]).max() < 1e-2
         assert np.all(z[d.nq:] > 0.0)
+
+
+def test_configurationforce_elimination_identity():
+    """The identity the device uses to solve :configurationforce KKT systems with the :configuration solvers
+    (newton_kernels.hip: cf_reduce_*): with contact-impulse weights G,
+        Dnu_y = G Dy - r_y ,   (I + rho G) Dy = S Dtheta + rho r_y - r_nuy ,
+    and the system for (Du, Dq, Dnu_q) is the :configuration system with right-hand side r_x + S^T r_y (+ O(G)).
+    Checked in numpy on the oracle's jacobian! for G = 1e-100 (the reference's value): elimination == dense solve."""
+    from oracle.dims import Dims as D_
+    d = D_(**QUADRUPED, mode=1)
+    H = 6
+    prob = synth.make_problem(d, 8, seed=2)
+    tabs = [lcp.LinTable(d, prob["z0"][t], prob["th0"][t], prob["r0"][t], prob["rz0"][t], prob["rth0"][t]) for t in range(8)]
+    window, ref, q0, q1 = synth.make_rollout(d, prob, H, phase=1, seed=3, perturb=1e-2)
+    tr = ref.copy(); tr.q[0], tr.q[1] = q0, q1; tr.update_theta(d, 0); tr.update_theta(d, 1)
+    im = oip.implicit_dynamics(d, tabs, window, tr.q, tr.theta, oip.IPOptions(), gamma=tr.gamma, b=tr.b)
+    obj = synth.make_objective(d, H, kind="quadruped")
+    lay = onewton.Layout(d, H)
+    beta, kappa = 1e-5, prob["kappa"]
+    R = onewton.jacobian(lay, obj, im, beta, kappa)
+    r = np.random.default_rng(0).standard_normal(lay.N)
+    x = np.linalg.solve(R, r)
+    # the reduced (:configuration) problem: same sensitivities restricted to the q rows
+    d0 = D_(**QUADRUPED, mode=0)
+    lay0 = onewton.Layout(d0, H)
+    nq, nu, ny, nr, nd = d.nq, d.nu, d.nc + d.nb, d.nr, d.nd
+    im0 = dict(d=im["d"][:, :nq], dq0=im["dq0"][:, :nq], dq1=im["dq1"][:, :nq], du1=im["du1"][:, :nq])
+    obj0 = onewton.Objective(q=obj.q, u=obj.u)
+    R0 = onewton.jacobian(lay0, obj0, im0, beta, kappa)
+    nr0 = nu + nq
+    r0 = np.zeros(lay0.N)
+    Sy = lambda i, key: im[key][i][nq:]                          # y rows of the sensitivities of step i
+    for j in range(H):
+        ry = lambda i: r[i * nr + nu:i * nr + nu + ny]
+        r0[j * nr0:j * nr0 + nu] = r[j * nr:j * nr + nu] + Sy(j, "du1").T @ ry(j)
+        v = r[j * nr + nu + ny:j * nr + nr].copy()
+        if j + 1 < H: v += Sy(j + 1, "dq1").T @ ry(j + 1)
+        if j + 2 < H: v += Sy(j + 2, "dq0").T @ ry(j + 2)
+        r0[j * nr0 + nu:(j + 1) * nr0] = v
+        r0[H * nr0 + j * nq:H * nr0 + (j + 1) * nq] = r[H * nr + j * nd:H * nr + j * nd + nq]
+    x0 = np.linalg.solve(R0, r0)
+    rho = H * beta * kappa
+    for j in range(H):
+        np.testing.assert_allclose(x[j * nr:j * nr + nu], x0[j * nr0:j * nr0 + nu], rtol=0, atol=1e-9 * max(1, np.abs(x).max()))
+        np.testing.assert_allclose(x[j * nr + nu + ny:(j + 1) * nr], x0[j * nr0 + nu:(j + 1) * nr0], rtol=0, atol=1e-9 * max(1, np.abs(x).max()))
+        dq0 = x0[(j - 2) * nr0 + nu:(j - 1) * nr0] if j >= 2 else np.zeros(nq)
+        dq1 = x0[(j - 1) * nr0 + nu:j * nr0] if j >= 1 else np.zeros(nq)
+        du = x0[j * nr0:j * nr0 + nu]
+        dy = Sy(j, "dq0") @ dq0 + Sy(j, "dq1") @ dq1 + Sy(j, "du1") @ du + rho * r[j * nr + nu:j * nr + nu + ny] \
+            - r[H * nr + j * nd + nq:H * nr + (j + 1) * nd]
+        np.testing.assert_allclose(x[j * nr + nu:j * nr + nu + ny], dy, rtol=0, atol=1e-9 * max(1, np.abs(x).max()))
+        np.testing.assert_allclose(x[H * nr + j * nd + nq:H * nr + (j + 1) * nd], -r[j * nr + nu:j * nr + nu + ny], rtol=0, atol=1e-9 * max(1, np.abs(x).max()))
