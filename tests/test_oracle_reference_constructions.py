@@ -205,3 +205,36 @@ def test_configurationforce_elimination_identity():
             - r[H * nr + j * nd + nq:H * nr + (j + 1) * nd]
         np.testing.assert_allclose(x[j * nr + nu:j * nr + nu + ny], dy, rtol=0, atol=1e-9 * max(1, np.abs(x).max()))
         np.testing.assert_allclose(x[H * nr + j * nd + nq:H * nr + (j + 1) * nd], -r[j * nr + nu:j * nr + nu + ny], rtol=0, atol=1e-9 * max(1, np.abs(x).max()))
+
+
+@pytest.mark.parametrize("model,velocity", [("hopper", True), ("quadruped", True), ("quadruped", False)])
+def test_interleaved_banded_ldl(model, velocity):
+    """Structure behind the banded KKT backend (kkt_dense.hip: kkt_banded_kernel), on the oracle's jacobian!: in the
+    interleaved ordering the matrix has half-bandwidth 3 (nr + nd) - 1 - nu, D has exactly H nd negative pivots
+    (quasi-definite), and the blocked sliding-window L D L^T WITHOUT pivoting (oracle/banded.py, the kernel's algorithm)
+    reproduces the dense solve."""
+    from oracle import banded
+    from oracle.dims import HOPPER_2D as HP
+    d = Dims(**(HP if model == "hopper" else QUADRUPED))
+    H = 5
+    prob = synth.make_problem(d, 7, seed=4)
+    tabs = [lcp.LinTable(d, prob["z0"][t], prob["th0"][t], prob["r0"][t], prob["rz0"][t], prob["rth0"][t]) for t in range(7)]
+    window, ref, q0, q1 = synth.make_rollout(d, prob, H, phase=1, seed=3, perturb=1e-2)
+    tr = ref.copy(); tr.q[0], tr.q[1] = q0, q1; tr.update_theta(d, 0); tr.update_theta(d, 1)
+    im = oip.implicit_dynamics(d, tabs, window, tr.q, tr.theta, oip.IPOptions())
+    obj = synth.make_objective(d, H, kind=model, velocity=velocity)
+    if velocity:
+        obj.v = obj.v * 1e3; obj.__post_init__()
+    lay = onewton.Layout(d, H)
+    R = onewton.jacobian(lay, obj, im, 1e-5, prob["kappa"])
+    p = banded.interleave_perm(lay, d)
+    A = R[np.ix_(p, p)]
+    w = banded.half_bandwidth(d)
+    i, j = np.nonzero(A)
+    assert np.abs(i - j).max() == min(w, lay.N - 1)
+    r = np.random.default_rng(0).standard_normal(lay.N)
+    x, lmax = banded.blocked_ldl_solve(A, r[p], min(w, lay.N - 1))
+    xs = np.linalg.solve(A, r[p])
+    back = np.abs(A @ x - r[p]).max() / (np.abs(A).sum(axis=1).max() * np.abs(x).max() + np.abs(r).max())
+    assert back < 1e-12 and lmax < 1e5
+    np.testing.assert_allclose(x, xs, rtol=0, atol=1e-11 * np.linalg.cond(A) * max(1.0, np.abs(xs).max()))
