@@ -3,8 +3,13 @@
 TEST INFRASTRUCTURE ONLY.  Nothing in the product path
 (`contactimplicitmpc/jl_amd`, `include/`, the HIP library) may import, link or
 execute anything under `oracle/`.  Allowed importers: `tests/`,
-`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg - and there only
-as the checker / the timed CPU baseline, never as the thing shipped.
+`__graft_entry__.smoke()`, `bench.py`'s `cpu_baseline` leg and the validation
+scripts under `scripts/` (closed-loop runs: CPU plant, tracking_error) - and
+there only as the checker / the timed CPU baseline, never as the thing shipped.
+
+Modules: lcp.py, ip.py, newton.py, mpc.py (the path), cimpc_ref.c / cref.py (C port,
+CPU baseline), synth.py (synthetic inputs), plant.py (simulator step + closed
+loop, CPU), banded.py (the banded KKT kernel's algorithm in numpy).
 
 Parity status (see DESIGN.md section "Oracle"):
   * reference-side callbacks (rlin!, rzlin!, Schur/MGS-QR, linear_solve!,
