@@ -246,3 +246,15 @@ def test_make_rollout_equals_rot_n_stride_on_the_full_trajectory():
         np.testing.assert_allclose(r["theta"], tr.theta[:H], rtol=0, atol=1e-12)
         ompc.rot_n_stride(d, tr, prob["stride"])
         win = ompc.update_window(win, P.H)
+
+
+def test_implicit_dynamics_on_the_flamingo_gait():
+    """The check of test/controller/implicit_dynamics.jl:7-24 on the third planar model: flamingo gait_forward_36_4 (the gait of
+    test/controller/mpc_flamingo.jl), linearization at κ = 2e-4: every knot converges in 4-6 iterations and stays within 2e-2 of the gait (1.1e-2 at the worst knot;
+    the 1e-2 of the reference's test is recorded for the quadruped only)."""
+    d, P, prob, tabs = real_problem("flamingo", 2e-4)
+    assert np.abs(P.r0[:, :d.nq]).max() < 2e-6                   # the gait satisfies the restated flamingo dynamics
+    out = oip.implicit_dynamics(d, tabs, np.arange(P.H + 2), P.q, P.theta, oip.IPOptions(kappa_tol=2e-4, r_tol=1e-8))
+    assert out["status"].all()
+    assert np.abs(out["d"]).max() < 2e-2
+    assert out["iters"].max() <= 12
