@@ -42,8 +42,8 @@ def algorithmic_sizes(nq, nu, nw, nc, nb, mode=0):
 
 
 def build_inputs(B, H, H_ref, seed, perturb, first=0):
-    from oracle import synth
-    from oracle.dims import Dims
+    from contactimplicitmpc.jl_amd import synthetic as synth
+    from contactimplicitmpc.jl_amd.trajectory import Dims
     d = Dims(**QUADRUPED)
     prob = synth.make_problem(d, H_ref, seed=1)            # shared linearization table (all ranks)
     obj = synth.make_objective(d, H)
@@ -102,8 +102,8 @@ def cpu_baseline(d, prob, obj, rollouts, H, H_ref, budget_s=12.0):
 
 def mpc_loop_latency(dims, kind, H, H_ref, device, steps=40, mode=0):
     """Warm-started single-rollout MPC loop: newton_solve! -> rot_n_stride! / update_window! -> q0 <- q1."""
-    from oracle import synth
-    from oracle.dims import Dims
+    from contactimplicitmpc.jl_amd import synthetic as synth
+    from contactimplicitmpc.jl_amd.trajectory import Dims
     from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions
     d = Dims(**dims, mode=mode)
     prob = synth.make_problem(d, H_ref, seed=1)

@@ -7,3 +7,4 @@ the thin Python host that mirrors the reference's interface for the path.
 from ._lib import CimpcError, LIB_PATH, load  # noqa: F401
 from .solver import (CIMPCSolver, InteriorPointOptions, NewtonOptions,  # noqa: F401
                      MODE_CONFIGURATION, MODE_CONFIGURATIONFORCE)
+from .trajectory import Dims, Traj, Objective  # noqa: F401  (host-side mirrors of the reference's data types)

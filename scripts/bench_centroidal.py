@@ -4,8 +4,8 @@ not a practical configuration yet - DESIGN.md).  Lock-step rounds, 32-lane inter
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from oracle import synth
-from oracle.dims import Dims
+from contactimplicitmpc.jl_amd import synthetic as synth
+from contactimplicitmpc.jl_amd.trajectory import Dims
 from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions
 d = Dims(nq=18, nu=12, nw=3, nc=4, nb=16)
 H, H_ref = 60, 71

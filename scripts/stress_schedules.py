@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from common import make_case, make_solver
-from oracle import synth
+from contactimplicitmpc.jl_amd import synthetic as synth
 from contactimplicitmpc.jl_amd import NewtonOptions
 bad = 0
 for (model, H, H_ref, B, pert, seed) in [("quadruped", 20, 30, 200, 0.05, 1), ("quadruped", 12, 16, 300, 0.1, 2), ("hopper", 20, 24, 256, 0.05, 3),
