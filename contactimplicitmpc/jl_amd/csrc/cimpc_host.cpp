@@ -39,8 +39,60 @@ struct RoundStreams {
     hipEvent_t ev_join = nullptr, ev_round = nullptr;   // ev_round: end of a round (rounds enqueued ahead of the host)
 };
 
+// Schedule knobs.  Every environment override is read ONCE, in cimpc_create (a handle's configuration never
+// changes afterwards and no solve-path call touches the environment).  The defaults are the measured optima
+// (DESIGN.md section 5); the overrides exist for the A/B scripts under scripts/.
+struct Knobs {
+    int async_mode = 2;          // CIMPC_ASYNC: 0 lock-step rounds only, 1 always the single launch, 2 auto
+    int async_tail = -1;         // CIMPC_ASYNC_TAIL: hybrid hand-over threshold (-1: by batch size)
+    int async_mem = 0;           // CIMPC_ASYNC_MEM: 1 uncached, 2 fine-grained exchange buffers (experiment)
+    int spec_all = -1;           // CIMPC_SPEC_ALL
+    int spec_tail = 3;           // CIMPC_SPEC_TAIL
+    int iter_cap = 24;           // CIMPC_ITER_CAP
+    int waves = 0;               // CIMPC_WAVES (0: by batch size)
+    int kkt_overlap = -1;        // CIMPC_KKT_OVERLAP (-1: by batch size)
+    int sweep_wgs = 0;           // CIMPC_SWEEP_WGS (0: computed)
+    int async_service = 0;       // CIMPC_ASYNC_SERVICE (0: computed)
+    bool async_debug = false;    // CIMPC_ASYNC_DEBUG
+    int async_flags = 0;         // CIMPC_ASYNC_FLAGS
+    int async_sleep = 2;         // CIMPC_ASYNC_SLEEP
+    int async_spins = 48;        // CIMPC_ASYNC_SPINS
+    int async_fan = 1;           // CIMPC_ASYNC_FAN
+    double watchdog_s = 30.0;    // CIMPC_ASYNC_WATCHDOG_S
+    int depth = 1;               // CIMPC_DEPTH
+    bool debug_rounds = false;   // CIMPC_DEBUG_ROUNDS
+    bool kkt_packed = true;      // CIMPC_KKT_PACKED
+    int tail_div = 8;            // CIMPC_TAIL_DIV
+
+    static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+    void read_environment() {
+        async_mode = env_int("CIMPC_ASYNC", async_mode);
+        async_tail = env_int("CIMPC_ASYNC_TAIL", async_tail);
+        async_mem = env_int("CIMPC_ASYNC_MEM", async_mem);
+        spec_all = env_int("CIMPC_SPEC_ALL", spec_all);
+        spec_tail = env_int("CIMPC_SPEC_TAIL", spec_tail);
+        iter_cap = std::max(1, env_int("CIMPC_ITER_CAP", iter_cap));
+        waves = env_int("CIMPC_WAVES", waves);
+        kkt_overlap = env_int("CIMPC_KKT_OVERLAP", kkt_overlap);
+        sweep_wgs = env_int("CIMPC_SWEEP_WGS", sweep_wgs);
+        async_service = env_int("CIMPC_ASYNC_SERVICE", async_service);
+        async_debug = getenv("CIMPC_ASYNC_DEBUG") != nullptr;
+        async_flags = env_int("CIMPC_ASYNC_FLAGS", async_flags);
+        async_sleep = env_int("CIMPC_ASYNC_SLEEP", async_sleep);
+        async_spins = std::max(1, env_int("CIMPC_ASYNC_SPINS", async_spins));
+        async_fan = env_int("CIMPC_ASYNC_FAN", async_fan);
+        if (async_fan != 1 && async_fan != 2 && async_fan != 4 && async_fan != 8 && async_fan != 16) async_fan = 1;
+        if (const char* v = getenv("CIMPC_ASYNC_WATCHDOG_S")) watchdog_s = atof(v);
+        depth = std::min(2, std::max(1, env_int("CIMPC_DEPTH", depth)));
+        debug_rounds = getenv("CIMPC_DEBUG_ROUNDS") != nullptr;
+        kkt_packed = env_int("CIMPC_KKT_PACKED", 1) != 0;
+        tail_div = env_int("CIMPC_TAIL_DIV", tail_div);
+    }
+};
+
 struct cimpc_ctx {
     cimpc_dims dm{};
+    Knobs kn{};
     cimpc_ip_opts ip{};
     cimpc_newton_opts nt{};
     int device = 0;
@@ -66,7 +118,7 @@ struct cimpc_ctx {
     double *d_q0 = nullptr, *d_q1 = nullptr;
     double* d_rhs = nullptr;   // B1 seam staging
     double* d_pstate = nullptr;   // parked interior-point iterates
-    int iter_cap = 24;            // measured B = 512: 16 / 20 / 24 / 32 / 48 -> 13.57 / 12.73 / 12.85 / 12.97 / 14.41 ms per batch step
+    int iter_cap = 24;            // (Knobs::iter_cap) measured B = 512: 16 / 20 / 24 / 32 / 48 -> 13.57 / 12.73 / 12.85 / 12.97 / 14.41 ms per batch step
     NewtonDev S{};
     int* h_counters = nullptr;   // pinned
     // bookkeeping
@@ -349,6 +401,8 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     if (ip) h->ip = *ip; else cimpc_default_ip_opts(&h->ip);
     if (nt) h->nt = *nt; else cimpc_default_newton_opts(&h->nt);
     h->device = device;
+    h->kn.read_environment();       // the only place the environment is consulted
+    h->iter_cap = h->kn.iter_cap;
     if (ip_kernel_info(&h->dm, &h->ki) != CIMPC_OK) {
         delete h;
         return fail(nullptr, CIMPC_ERR_INVALID,
@@ -378,10 +432,9 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         // MI355X (quadruped, H = 40): the single launch wins for 4 <= B <= 128 rollouts
         // (B = 64: 8.1 vs 11.2 ms), the rounds win for large batches (B = 512: 16.5 vs 21.7 ms) - except for
         // their sparse tail, which auto mode hands over to the asynchronous kernel.
-        const char* ev = getenv("CIMPC_ASYNC");
-        h->async_mode = ev ? atoi(ev) : 2;
+        h->async_mode = h->kn.async_mode;
         h->async_tail = std::min(256, std::max(64, d.B / 4));     // measured: B = 512 -> 128, B = 2048 -> 256
-        if (getenv("CIMPC_ASYNC_TAIL")) h->async_tail = atoi(getenv("CIMPC_ASYNC_TAIL"));
+        if (h->kn.async_tail >= 0) h->async_tail = h->kn.async_tail;
         const bool want = h->async_mode != 0;
         const size_t K = d.H_ref;
         const size_t evals = 1 + 7 * (size_t)std::max(1, h->nt.max_iter);       // per rollout and solve
@@ -391,7 +444,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         const size_t bytes = (K * h->a_cap + h->a_rq_cap + h->a_kq_cap) * sizeof(int);
         h->async_on = want && newton_async_available(&d) && K <= 256 && bytes <= ((size_t)1 << 30);
     }
-    const int xm = (h->async_on && getenv("CIMPC_ASYNC_MEM")) ? atoi(getenv("CIMPC_ASYNC_MEM")) : 0;   // experiments: 1 uncached, 2 fine-grained
+    const int xm = h->async_on ? h->kn.async_mem : 0;   // experiments: 1 uncached, 2 fine-grained
     auto A = [&](auto** p, size_t n) { if (rc == CIMPC_OK) rc = dev_alloc(h, p, n); };
     auto AX = [&](auto** p, size_t n) { if (rc == CIMPC_OK) rc = dev_alloc(h, p, n, xm); };   // exchanged state
     A(&h->d_tab, (size_t)d.H_ref * h->ki.tab_size);
@@ -470,17 +523,16 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     // condensed MFMA/scalar solve: :configuration + TrackingObjective; everything else (and kkt_backend = dense LU)
     // goes through the reference-default dense LU
     select_kkt_backend(h);
-    S.spec_all = getenv("CIMPC_SPEC_ALL") ? atoi(getenv("CIMPC_SPEC_ALL")) : (d.B <= 128 ? 3 : 8);
+    S.spec_all = h->kn.spec_all >= 0 ? h->kn.spec_all : (d.B <= 128 ? 3 : 8);
     // small batches: one wave per workgroup keeps every problem on its own CU (latency);
     // large batches: 4 waves share one staged table (throughput)
-    if (getenv("CIMPC_ITER_CAP")) h->iter_cap = std::max(1, atoi(getenv("CIMPC_ITER_CAP")));
     h->waves = (B * H >= 4096) ? 4 : 1;
     // the single-launch solve runs its residual jobs on the whole workgroup: 4 waves also for small batches
     // (measured B = 8: 5.2 -> 4.4 ms, B = 64: 8.5 -> 7.5 ms)
     if (h->async_on && (h->async_mode == 1 || (h->async_mode == 2 && B >= 4 && B <= 128))) h->waves = 4;
-    if (getenv("CIMPC_WAVES")) { const int w = atoi(getenv("CIMPC_WAVES")); if (w == 1 || w == 2 || w == 4) h->waves = w; }
+    if (h->kn.waves == 1 || h->kn.waves == 2 || h->kn.waves == 4) h->waves = h->kn.waves;
     h->kkt_overlap = B >= 64;
-    if (getenv("CIMPC_KKT_OVERLAP")) h->kkt_overlap = atoi(getenv("CIMPC_KKT_OVERLAP")) != 0;
+    if (h->kn.kkt_overlap >= 0) h->kkt_overlap = h->kn.kkt_overlap != 0;
     if (dev_alloc(h, &h->d_ring, 32) != CIMPC_OK ||
         hipHostMalloc((void**)&h->h_ring, 32 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&h->h_ring_dev, h->h_ring, 0) != hipSuccess) {
@@ -493,7 +545,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
                 dev_alloc(h, &h->a_ctrl, 2 * K * QPAD + 64 + 33 * 16, xm) != CIMPC_OK || dev_alloc(h, &h->a_evals, B, xm) != CIMPC_OK) {
                 g_create_error = h->err; cimpc_destroy(h); return CIMPC_ERR_HIP;
             }
-            if (getenv("CIMPC_ASYNC_DEBUG") && dev_alloc(h, &h->a_dbg, 16) != CIMPC_OK) { g_create_error = h->err; cimpc_destroy(h); return CIMPC_ERR_HIP; }
+            if (h->kn.async_debug && dev_alloc(h, &h->a_dbg, 16) != CIMPC_OK) { g_create_error = h->err; cimpc_destroy(h); return CIMPC_ERR_HIP; }
             h->async_dirty = true;
         }
     }
@@ -508,13 +560,13 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         //  clamps its grid to the occupancy the runtime reports in any case)
         const size_t resident = (size_t)256 * ((h->ki.G == 16 ? 8 : 4) / h->waves);
         h->wpk = (int)std::max<size_t>(1, std::min<size_t>(w, resident));
-        if (getenv("CIMPC_SWEEP_WGS")) h->wpk = std::max(1, atoi(getenv("CIMPC_SWEEP_WGS")));
+        if (h->kn.sweep_wgs > 0) h->wpk = h->kn.sweep_wgs;
         // asynchronous solve: the same resident set plus dedicated residual/KKT workgroups
         // (a line-search burst is up to 7 evaluations x H knots per rollout and every knot needs a workgroup of
         //  its own: small batches get at least 240 - measured B = 8: 6.4 -> 5.1 ms, B = 128: 11.1 -> 10.3 ms)
-        const int a_wgs = getenv("CIMPC_SWEEP_WGS") ? h->wpk : std::max(h->wpk, 240);
+        const int a_wgs = h->kn.sweep_wgs > 0 ? h->wpk : std::max(h->wpk, 240);
         h->a_service = std::max(1, a_wgs / 8);
-        if (getenv("CIMPC_ASYNC_SERVICE")) h->a_service = std::max(1, atoi(getenv("CIMPC_ASYNC_SERVICE")));
+        if (h->kn.async_service > 0) h->a_service = h->kn.async_service;
         h->a_grid = (int)std::min<size_t>(resident, (size_t)a_wgs + h->a_service);
         if (h->a_grid <= h->a_service) h->a_grid = h->a_service + 1;
     }
@@ -845,7 +897,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         Sk.host_flag = h->h_ring_dev;
         // the tail is latency-bound: its stragglers (rollouts that exhaust the line search in every iteration)
         // evaluate all seven step lengths at once there, whatever the throughput-oriented setting of the rounds
-        if (!from_reset) Sk.spec_all = getenv("CIMPC_SPEC_TAIL") ? atoi(getenv("CIMPC_SPEC_TAIL")) : 3;
+        if (!from_reset) Sk.spec_all = h->kn.spec_tail;
         Sk.WQ = h->Q; Sk.WQ.par = 0;
         Sk.WQ.items = h->a_items; Sk.WQ.cap = (int)h->a_cap;
         Sk.WQ.count = h->a_ctrl; Sk.WQ.head = h->a_ctrl + K * QPAD;
@@ -859,11 +911,10 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         A.evals_left = h->a_evals;
         A.abort_flag = (volatile int*)(h->h_ring_dev + 3);
         A.n_service = h->a_service;
-        A.flags = getenv("CIMPC_ASYNC_FLAGS") ? atoi(getenv("CIMPC_ASYNC_FLAGS")) : 0;
-        A.idle_sleep = getenv("CIMPC_ASYNC_SLEEP") ? atoi(getenv("CIMPC_ASYNC_SLEEP")) : 2;
-        A.idle_spins = getenv("CIMPC_ASYNC_SPINS") ? std::max(1, atoi(getenv("CIMPC_ASYNC_SPINS"))) : 48;
-        A.wake_fan = getenv("CIMPC_ASYNC_FAN") ? atoi(getenv("CIMPC_ASYNC_FAN")) : 1;
-        if (A.wake_fan != 1 && A.wake_fan != 2 && A.wake_fan != 4 && A.wake_fan != 8 && A.wake_fan != 16) A.wake_fan = 1;
+        A.flags = h->kn.async_flags;
+        A.idle_sleep = h->kn.async_sleep;
+        A.idle_spins = h->kn.async_spins;
+        A.wake_fan = h->kn.async_fan;
         A.dbg = h->a_dbg;
         if (h->a_dbg) HIP_TRY(h, hipMemsetAsync(h->a_dbg, 0, 16 * sizeof(long long), st));
         A.B = h->dm.B;
@@ -884,7 +935,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         // The host watches the persistent kernel: the reference's wall-clock budget ends the loop silently
         // (newton.jl:187-277), and a watchdog turns a kernel that stopped making progress into an error
         // instead of a hang (the kernel polls the host-mapped abort flag).
-        static const double watchdog_s = getenv("CIMPC_ASYNC_WATCHDOG_S") ? atof(getenv("CIMPC_ASYNC_WATCHDOG_S")) : 30.0;
+        const double watchdog_s = h->kn.watchdog_s;
         const bool budget = h->nt.max_time > 0.0 && h->nt.max_time < 1.0e6;
         bool timed_out = false;
         const auto tw = std::chrono::steady_clock::now();
@@ -935,11 +986,10 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     // ahead of the host's knowledge was measured: slower, the KKT kernel then has to be launched every round.)
     // CIMPC_DEPTH = 2: rounds enqueued one ahead of the host's knowledge.  Measured (B = 512): 15.9 vs 13.7 ms -
     // the KKT kernel must then be launched blind at full grid every round; kept as an experiment switch.
-    static const int depth_env = getenv("CIMPC_DEPTH") ? std::min(2, std::max(1, atoi(getenv("CIMPC_DEPTH")))) : 1;
-    const int depth = h->kkt_overlap ? depth_env : 1;
+    const int depth = h->kkt_overlap ? h->kn.depth : 1;
     bool draining = false;
     long long launched = 0, completed = 0, rounds = 0;
-    static const bool dbg_rounds = getenv("CIMPC_DEBUG_ROUNDS") != nullptr;
+    const bool dbg_rounds = h->kn.debug_rounds;
     int last_kkt = 0, last_sweep = h->dm.B;
     auto launch_round = [&](long long r) -> int {
         // [KKT for rollouts that start an iteration] || sweep -> residual + line-search decision
@@ -968,7 +1018,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             // of most rounds.)
             if (depth > 1 && hipStreamWaitEvent(sb.st_kkt, sb.ev_round, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "fork failed");
             prof_begin(h, PC_KKT, sb.st_kkt);
-            static const bool packed = !getenv("CIMPC_KKT_PACKED") || atoi(getenv("CIMPC_KKT_PACKED")) != 0;
+            const bool packed = h->kn.kkt_packed;
             // the list was built by the residual kernel of the previous round (its queue parity)
             int rk = h->use_dense ? launch_kkt_general(h, Sk, sb.st_kkt)
                                   : packed ? launch_kkt_packed(Sk, last_kkt, Sk.WQ.par ^ 1, sb.st_kkt, depth > 1 ? Sk.counters_next + 1 : nullptr)
@@ -979,7 +1029,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         }
         // parking (iter_cap) protects a busy round from one long solve; in the sparse tail of a solve
         // it only adds rounds, so a round that serves few rollouts lets every solve run to the end
-        static const int tail_div = getenv("CIMPC_TAIL_DIV") ? atoi(getenv("CIMPC_TAIL_DIV")) : 8;
+        const int tail_div = h->kn.tail_div;
         const int cap = (tail_div > 0 && last_sweep * tail_div <= h->dm.B) ? h->ip.max_iter : h->iter_cap;
         int rr = run_sweep(h, Sk.WQ.par, d_cnt + 2, nullptr, sb.st, cap);
         if (rr != CIMPC_OK) return rr;

@@ -8,6 +8,8 @@
 // is defined by its converged answer (the time-stepping complementarity problem to 1e-8); the CPU restatement used by the
 // tests states the same step.  Robots are independent: B wavefronts, no communication.
 #include <hip/hip_runtime.h>
+#include <cstring>
+#include <mutex>
 
 #include <cmath>
 
@@ -188,40 +190,77 @@ __global__ __launch_bounds__(64) void plant_step_kernel(PlantModel M, PlantOpts 
 }  // namespace cimpc
 
 // ---- C ABI -------------------------------------------------------------------------------------------------------------
+namespace {
+// Per-device workspace of the plant entry point: buffers and a private stream live across calls (a simulator step is called
+// thousands of times in a closed loop; allocating and a device-wide synchronize per call stalled everything else on the GPU).
+struct PlantWs {
+    int device = -1;
+    hipStream_t st = nullptr;
+    double *d_in = nullptr, *d_out = nullptr;
+    int* d_st = nullptr;
+    size_t cap_in = 0, cap_out = 0, cap_st = 0;
+};
+constexpr int PLANT_MAX_DEVICES = 16;
+PlantWs g_plant_ws[PLANT_MAX_DEVICES];
+std::mutex g_plant_mu;
+
+template <class T>
+bool plant_grow(T** p, size_t* cap, size_t need) {
+    if (*cap >= need) return true;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    if (hipMalloc((void**)p, need * sizeof(T)) != hipSuccess) return false;
+    *cap = need;
+    return true;
+}
+}  // namespace
+
 extern "C" int cimpc_plant_step(int model, int B, const double* q0, const double* q1, const double* u, const double* w,
                                 double mu, double h, const cimpc_ip_opts* opts, double* q2, double* gamma, double* b,
                                 int* status, int* iters) {
     using namespace cimpc;
     if (B <= 0 || !q0 || !q1 || !u || !opts || !q2 || !gamma || !b || !status || !iters || h <= 0.0) return CIMPC_ERR_INVALID;
     if (model != CIMPC_PLANT_QUADRUPED && model != CIMPC_PLANT_FLAMINGO) return CIMPC_ERR_INVALID;
+    if (opts->max_iter <= 0 || opts->max_ls < 0 || !(opts->r_tol > 0.0) || !(opts->kappa_tol > 0.0) || !(opts->ls_scale > 0.0 && opts->ls_scale < 1.0))
+        return CIMPC_ERR_INVALID;
+    // runs on the calling thread's CURRENT device (the caller selects it, e.g. hipSetDevice(rank) / torch.cuda.set_device)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PLANT_MAX_DEVICES) return CIMPC_ERR_NO_DEVICE;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return CIMPC_ERR_NO_DEVICE;
+    }
     const PlantModel M = model == CIMPC_PLANT_QUADRUPED ? plant_quadruped() : plant_flamingo();
     PlantOpts o{opts->r_tol, opts->kappa_tol, std::isinf(opts->undercut) ? 0.0 : opts->kappa_tol / opts->undercut, opts->eps_min,
                 opts->ls_scale, opts->stall_alpha, opts->max_iter, opts->max_ls};
     const size_t nq = M.nq, nu = M.nu;
-    double *d_in = nullptr, *d_out = nullptr;
-    int* d_st = nullptr;
     const size_t n_in = (size_t)B * (2 * nq + nu + PLANT_NW), n_out = (size_t)B * (nq + PLANT_NC + PLANT_NB);
-    if (hipMalloc(&d_in, n_in * sizeof(double)) != hipSuccess || hipMalloc(&d_out, n_out * sizeof(double)) != hipSuccess ||
-        hipMalloc(&d_st, 2 * (size_t)B * sizeof(int)) != hipSuccess) {
-        (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_st);
+    std::lock_guard<std::mutex> lock(g_plant_mu);
+    PlantWs& W = g_plant_ws[dev];
+    if (!W.st) {
+        if (hipStreamCreateWithFlags(&W.st, hipStreamNonBlocking) != hipSuccess) return CIMPC_ERR_HIP;
+        W.device = dev;
+    }
+    if (!plant_grow(&W.d_in, &W.cap_in, n_in) || !plant_grow(&W.d_out, &W.cap_out, n_out) || !plant_grow(&W.d_st, &W.cap_st, 2 * (size_t)B))
         return CIMPC_ERR_HIP;
-    }
-    double* dq0 = d_in; double* dq1 = dq0 + B * nq; double* du = dq1 + B * nq; double* dw = du + B * nu;
-    double* dq2 = d_out; double* dg = dq2 + B * nq; double* db = dg + (size_t)B * PLANT_NC;
-    bool ok = hipMemcpy(dq0, q0, B * nq * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(dq1, q1, B * nq * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(du, u, B * nu * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
-    if (ok && w) ok = hipMemcpy(dw, w, (size_t)B * PLANT_NW * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+    double* dq0 = W.d_in; double* dq1 = dq0 + B * nq; double* du = dq1 + B * nq; double* dw = du + B * nu;
+    double* dq2 = W.d_out; double* dg = dq2 + B * nq; double* db = dg + (size_t)B * PLANT_NC;
+    int* d_st = W.d_st;
+    hipStream_t st = W.st;
+    bool ok = hipMemcpyAsync(dq0, q0, B * nq * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess &&
+              hipMemcpyAsync(dq1, q1, B * nq * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess &&
+              hipMemcpyAsync(du, u, B * nu * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess;
+    if (ok && w) ok = hipMemcpyAsync(dw, w, (size_t)B * PLANT_NW * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess;
     if (ok) {
-        hipLaunchKernelGGL(plant_step_kernel, dim3(B), dim3(64), 0, nullptr, M, o, B, dq0, dq1, du, w ? dw : nullptr, mu, h, dq2, dg, db,
+        hipLaunchKernelGGL(plant_step_kernel, dim3(B), dim3(64), 0, st, M, o, B, dq0, dq1, du, w ? dw : nullptr, mu, h, dq2, dg, db,
                            d_st, d_st + B);
-        ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+        ok = hipGetLastError() == hipSuccess;
     }
-    if (ok) ok = hipMemcpy(q2, dq2, B * nq * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess &&
-                 hipMemcpy(gamma, dg, (size_t)B * PLANT_NC * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess &&
-                 hipMemcpy(b, db, (size_t)B * PLANT_NB * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess &&
-                 hipMemcpy(status, d_st, (size_t)B * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess &&
-                 hipMemcpy(iters, d_st + B, (size_t)B * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
-    (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_st);
+    if (ok) ok = hipMemcpyAsync(q2, dq2, B * nq * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                 hipMemcpyAsync(gamma, dg, (size_t)B * PLANT_NC * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                 hipMemcpyAsync(b, db, (size_t)B * PLANT_NB * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                 hipMemcpyAsync(status, d_st, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                 hipMemcpyAsync(iters, d_st + B, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok = (hipStreamSynchronize(st) == hipSuccess) && ok;      // this stream only
     return ok ? CIMPC_OK : CIMPC_ERR_HIP;
 }

@@ -139,7 +139,14 @@ class CIMPCSolver:
                 raise ValueError(f"objective block shape {a.shape} != {(self.H, n, n)}")
             return np.ascontiguousarray(np.transpose(a, (0, 2, 1)))
         Qc, Rc, Gc, Bc, Vc = blk(Q, self.nq), blk(R, self.nu), blk(Cg, self.nc), blk(Cb, self.nb), blk(V, self.nq)
-        qt = _f64(q_target); vt = _f64(v_target)
+        def tgt(a):      # (H, nq) per-step targets; a single (nq,) vector is broadcast over the horizon
+            if a is None:
+                return None
+            a = np.asarray(a, dtype=np.float64)
+            if a.shape == (self.nq,):
+                a = np.tile(a[None], (self.H, 1))
+            return _f64(a, (self.H, self.nq))
+        qt = tgt(q_target); vt = tgt(v_target)
         self._check(self.lib.cimpc_set_objective(self.h, _dp(Qc), _dp(Rc), _dp(Gc), _dp(Bc), _dp(Vc),
                                                  _dp(qt), _dp(vt)), "set_objective")
 

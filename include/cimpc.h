@@ -108,7 +108,16 @@ int cimpc_version(void);
 int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_newton_opts* nt,
                  int device, cimpc_handle* out);
 int cimpc_destroy(cimpc_handle h);
-/* Use an externally owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
+/* Use an externally owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream): every solve of the handle is
+ * then enqueued on that stream, after whatever the caller enqueued there before.
+ * STREAM-ORDERING CONTRACT.  Without cimpc_set_stream the library runs on PRIVATE non-blocking streams, which do not
+ * wait for the NULL stream or for any stream of the caller.  A caller that produces device-resident inputs
+ * (cimpc_newton_solve_dev: q0_dev / q1_dev) on a stream of its own must therefore either
+ *   (a) call cimpc_set_stream(h, that_stream) once, or
+ *   (b) complete the producer before the call (hipStreamSynchronize / hipDeviceSynchronize / torch.cuda.synchronize()).
+ * All entry points are synchronous on return EXCEPT that results stay device-resident: cimpc_newton_solve_dev returns
+ * when the solve has completed on the library's streams (or, with an external stream, when it has been drained -
+ * the hybrid schedule polls device counters), so device buffers read afterwards on the caller's stream are ordered. */
 int cimpc_set_stream(cimpc_handle h, void* hip_stream);
 int cimpc_synchronize(cimpc_handle h);
 
@@ -222,7 +231,10 @@ int cimpc_query_sizes(cimpc_handle h, int* table_doubles, int* N_kkt);
  * time-stepping complementarity problem r(z, theta, kappa -> kappa_tol) = 0 from z = initialize_z!(q1), theta = (q0, q1, u, w,
  * mu, h), solved by the interior point with `opts` (the simulator's: undercut = Inf, r_tol = kappa_tol = 1e-8, max_ls = 25,
  * eps_min 0.25 / 0.05 - simulator.jl:24-32, test/controller/mpc_flamingo.jl:53-60).  Models: the planar chains of
- * plant_model.h.  q0, q1: B x nq; u: B x nu; w: B x 2 or NULL; outputs q2 B x nq, gamma B x 4, b B x 8, status, iters: B. */
+ * plant_model.h.  q0, q1: B x nq; u: B x nu; w: B x 2 or NULL; outputs q2 B x nq, gamma B x 4, b B x 8, status, iters: B.
+ * Runs on the calling thread's CURRENT HIP device (select it with hipSetDevice before the call; a handle's device is
+ * not implied) on a private per-device stream with persistent buffers; only that stream is synchronized.
+ * opts->max_iter >= 1, max_ls >= 0, 0 < ls_scale < 1 are validated (CIMPC_ERR_INVALID). */
 #define CIMPC_PLANT_QUADRUPED 0   /* src/dynamics/quadruped/model.jl, flat_2D_lc */
 #define CIMPC_PLANT_FLAMINGO 1    /* src/dynamics/flamingo/model.jl, flat_2D_lc  */
 int cimpc_plant_step(int model, int B, const double* q0, const double* q1, const double* u, const double* w,

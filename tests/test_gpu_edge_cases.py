@@ -103,3 +103,26 @@ def test_repeated_solves_are_deterministic(gpu_required):
         np.testing.assert_array_equal(o[1], outs[0][1])
         np.testing.assert_array_equal(o[0], outs[0][0])
         np.testing.assert_array_equal(o[2], outs[0][2])
+
+
+def test_objective_target_shapes_are_validated(gpu_required):
+    """cimpc_set_objective copies H * nq doubles from q_target / v_target: the host wrapper must refuse anything else
+    (a (nq,) vector is broadcast over the horizon explicitly) instead of letting the C side read past the buffer."""
+    d, prob, tabs, rollouts = make_case("hopper", 0, H_ref=8, H=6, B=2, seed=2)
+    obj = synth.make_objective(d, 6, kind="hopper", velocity=True)
+    s = make_solver(d, prob, rollouts, 6)
+    vt = 0.01 * np.arange(d.nq)
+    s.set_objective(obj.q, obj.u, V=obj.v, v_target=vt)                       # (nq,) -> broadcast
+    s.set_objective(obj.q, obj.u, V=obj.v, v_target=np.tile(vt[None], (6, 1)))
+    with pytest.raises(ValueError):
+        s.set_objective(obj.q, obj.u, V=obj.v, v_target=np.zeros((5, d.nq)))    # wrong horizon
+    with pytest.raises(ValueError):
+        s.set_objective(obj.q, obj.u, V=obj.v, q_target=np.zeros(d.nq + 1))
+    s.close()
+
+
+def test_plant_step_validates_options(gpu_required):
+    from contactimplicitmpc.jl_amd import InteriorPointOptions, plant
+    q = np.zeros((1, 11)); u = np.zeros((1, 8))
+    with pytest.raises(Exception):
+        plant.plant_step("quadruped", q, q, u, mu=0.5, h=0.01, opts=InteriorPointOptions(max_iter=0))
