@@ -6,15 +6,24 @@ dimensions (nq 11, nu 8, nw 2, nc 4, nb 8), mode :configuration, H = 40, H_ref =
 fp64, B Monte-Carlo rollouts per GPU (synthetic horizons, seeded - SURVEY.md section 8d).
 `value` = rollouts * steps / wall time, inputs resident in HBM before the timed region.
 
-    python bench.py --gpus N --steps K --warmup W [--rollouts B]
-For N > 1 the driver launches one rank per GPU with torch.distributed.run; rollouts are
-independent, so ranks never exchange data inside the solve (weak scaling: B per GPU fixed).
+    python bench.py --gpus N --steps K --warmup W [--rollouts B] [--scaling weak|strong]
+For N > 1 the driver launches one rank per GPU with torch.distributed.run.  Rank 0 builds the shared problem and
+BROADCASTS the packed linearization tables / gait / objective over RCCL, every rank solves its contiguous shard of
+the global rollout indices (no collective inside a solve), and ONE all-gather per reporting interval returns
+[u1 | newton_iters | r_norm | sweeps] of every rollout (contactimplicitmpc/jl_amd/monte_carlo.py; the reference's
+workload: examples/quadruped/monte_carlo.jl:76-92).  --scaling weak (default): B rollouts PER GPU;
+--scaling strong: B rollouts in total, split over the ranks (BASELINE configs[3]: 512 over 8 GPUs).
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -41,17 +50,73 @@ def algorithmic_sizes(nq, nu, nw, nc, nb, mode=0):
                 flop_iter=flop_iter, flop_tail=flop_tail)
 
 
-def build_inputs(B, H, H_ref, seed, perturb, first=0):
+def build_problem(H, H_ref):
+    """The shared part of the batch: per-knot linearization tables + reference gait + objective (rank 0 only for N > 1)."""
     from contactimplicitmpc.jl_amd import synthetic as synth
     from contactimplicitmpc.jl_amd.trajectory import Dims
     d = Dims(**QUADRUPED)
-    prob = synth.make_problem(d, H_ref, seed=1)            # shared linearization table (all ranks)
-    obj = synth.make_objective(d, H)
+    return d, synth.make_problem(d, H_ref, seed=1), synth.make_objective(d, H)
+
+
+def build_rollouts(d, prob, B, H, H_ref, seed, perturb, first=0):
+    from contactimplicitmpc.jl_amd import synthetic as synth
     rollouts = []
     for g in range(first, first + B):     # g = GLOBAL rollout index: the batch does not depend on the sharding
         phase = int(np.random.default_rng(seed * 7919 + g).integers(0, H_ref))
         rollouts.append(synth.make_rollout(d, prob, H, phase=phase, seed=seed * 100003 + g, perturb=perturb))
-    return d, prob, obj, rollouts
+    return rollouts
+
+
+def build_inputs(B, H, H_ref, seed, perturb, first=0):
+    d, prob, obj = build_problem(H, H_ref)
+    return d, prob, obj, build_rollouts(d, prob, B, H, H_ref, seed, perturb, first)
+
+
+def csrc_hash():
+    """Identity of the kernels a measurement belongs to: sha256 over the library sources."""
+    hsh = hashlib.sha256()
+    base = os.path.join(ROOT, "contactimplicitmpc", "jl_amd", "csrc")
+    for f in sorted(os.listdir(base)):
+        if f.endswith((".h", ".hip", ".cpp")):
+            hsh.update(f.encode())
+            hsh.update(open(os.path.join(base, f), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
+def measure_sweep_traffic(B, H, timeout_s=150):
+    """HBM bytes per `ip_queue_kernel` launch from the PMC counters, measured IN THIS RUN: two `rocprofv3 --pmc` passes
+    (FETCH_SIZE and WRITE_SIZE do not fit one pass; PMC passes carry no trace domain - MI355X_MICROARCH.md, HBM section)
+    over a short child run of this same script; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts
+    128-byte requests as 64 bytes).  Returns (bytes_per_launch or None, source string)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--rollouts", str(B), "--horizon", str(H),
+             "--no-cpu-baseline", "--no-real-problem", "--no-latency", "--no-traffic"]
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="cimpc_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "p", "--"] + child, cwd="/tmp", env=env,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            import csv
+            tot = n = 0
+            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(path)):
+                    if "ip_queue_kernel" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                        tot += float(r["Counter_Value"]); n += 1
+            if n == 0:
+                return None, "no ip_queue_kernel dispatches in the %s pass" % ctr
+            vals[ctr] = tot / n
+        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "rocprofv3 --pmc, measured in this run (2 passes, child run of 2 steps)"
+    except Exception as e:      # the counters never block the bench line
+        return None, "rocprofv3 pass failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def cpu_baseline(d, prob, obj, rollouts, H, H_ref, budget_s=12.0):
@@ -221,12 +286,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rollouts", type=int, default=512, help="Monte-Carlo rollouts per GPU")
+    ap.add_argument("--rollouts", type=int, default=512, help="Monte-Carlo rollouts per GPU (weak) / in total (strong)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--horizon", type=int, default=40)
     ap.add_argument("--perturb", type=float, default=0.05)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--latency", action="store_true", help="also time the B = 1 single-rollout loop")
+    ap.add_argument("--latency", action="store_true", help="(default on) the B = 1 legs: BASELINE configs[0..2]")
+    ap.add_argument("--no-latency", action="store_true", help="skip the B = 1 single-rollout legs")
     ap.add_argument("--no-real-problem", action="store_true", help="skip the leg on the real quadruped gait")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 --pmc passes (roofline.traffic)")
     args = ap.parse_args()
 
     import torch
@@ -235,18 +303,39 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    # (CIMPC_BENCH_BACKEND=gloo: validation of the N > 1 control flow on a ONE-GPU box - every rank solves on the one
+    #  device, collectives on CPU tensors; the driver's runs use the default: one rank per GPU, RCCL)
+    backend = os.environ.get("CIMPC_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions
-    H, H_ref, B = args.horizon, 60, args.rollouts
+    from contactimplicitmpc.jl_amd import monte_carlo as mc
     from contactimplicitmpc.jl_amd.sharding import rollout_shard
-    first, count = rollout_shard(world * B, rank, world)      # weak scaling: B rollouts per GPU
-    d, prob, obj, rollouts = build_inputs(count, H, H_ref, seed=1234, perturb=args.perturb, first=first)
+    from contactimplicitmpc.jl_amd.trajectory import Dims
+    H, H_ref = args.horizon, 60
+    n_global = world * args.rollouts if args.scaling == "weak" else args.rollouts
+    d = Dims(**QUADRUPED)
+    t_setup = time.perf_counter()
+    if world > 1:       # rank 0 builds the shared problem, RCCL broadcast to the other GPUs (1.4 MB)
+        shapes = mc.problem_shapes(H_ref, H, d.nq, d.nu, d.nw, d.nc, d.nb)
+        built = build_problem(H, H_ref) if rank == 0 else None
+        prob, obj_q, obj_u = mc.broadcast_problem(*((built[1], built[2].q, built[2].u) if rank == 0 else (None, None, None)), shapes, dev)
+    else:
+        _, prob, obj = build_problem(H, H_ref)
+        obj_q, obj_u = obj.q, obj.u
+    first, B = rollout_shard(n_global, rank, world)
+    rollouts = build_rollouts(d, prob, B, H, H_ref, 1234, args.perturb, first=first)
+    t_setup = time.perf_counter() - t_setup
 
     def make(Bn, ro):
         s = CIMPCSolver(d.nq, d.nu, d.nw, d.nc, d.nb, H_ref, H, B=Bn, mode=0,
@@ -254,7 +343,7 @@ def main():
                         newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=3e-4, max_iter=5), device=local_rank)
         for t in range(H_ref):
             s.set_linearization(t + 1, prob["z0"][t], prob["th0"][t], prob["r0"][t], prob["rz0"][t], prob["rth0"][t])
-        s.set_objective(obj.q, obj.u)
+        s.set_objective(obj_q, obj_u)
         s.set_window(np.stack([w for (w, _, _, _) in ro]) + 1)
         s.set_reference(np.stack([r.q for (_, r, _, _) in ro]), np.stack([r.u for (_, r, _, _) in ro]),
                         np.stack([r.w for (_, r, _, _) in ro]), np.stack([r.gamma for (_, r, _, _) in ro]),
@@ -264,13 +353,20 @@ def main():
         return s, q0, q1
 
     s, q0, q1 = make(B, rollouts)
-    torch.cuda.synchronize()
+    torch.cuda.synchronize()      # stream-ordering contract of cimpc_newton_solve_dev (include/cimpc.h): producers complete
 
     def step():
         s.newton_solve_dev(q0.data_ptr(), q1.data_ptr(), warm_start=False)
 
+    def report():
+        """Once per reporting interval: controls / iteration counts of every rollout of the job in global order
+        (N > 1: one RCCL all-gather of B x (nu + 3) doubles per rank)."""
+        u1, it, rn = s.newton_info()
+        return mc.gather_results(u1, it, rn, s.rollout_counters()["sweeps"], n_global, dev)
+
     for _ in range(args.warmup):
         step()
+    report()
     s.profile_enable(not os.environ.get("CIMPC_BENCH_NOPROF"))
     s.profile_reset()
     torch.cuda.synchronize()
@@ -283,13 +379,20 @@ def main():
         st = s.stats()
         sweeps += st["sweeps"]; ip_solves += st["ip_solves"]; ip_iters += st["ip_iters"]
         newton_iters += st["newton_iters"]; rounds += st["rounds"]
+    gathered = report()               # inside the timed region: the job's results reach every rank
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        cnt = torch.tensor([sweeps, ip_solves, ip_iters, newton_iters], dtype=torch.float64, device=dev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)          # step counters of the whole job
+        job_sweeps, job_ip_solves, job_ip_iters, job_newton = (float(x) for x in cnt.tolist())
+    else:
+        job_sweeps, job_ip_solves, job_ip_iters, job_newton = sweeps, ip_solves, ip_iters, newton_iters
     prof = s.profile_read()
     s.profile_enable(False)
 
@@ -299,48 +402,58 @@ def main():
         return
 
     alg = algorithmic_sizes(**QUADRUPED)
-    K = ip_iters / max(ip_solves, 1)
-    L = newton_iters / (B * args.steps)
-    S = sweeps / max(newton_iters + B * args.steps, 1)
+    K = job_ip_iters / max(job_ip_solves, 1)
+    L = job_newton / (n_global * args.steps)
+    S = job_sweeps / max(job_newton + n_global * args.steps, 1)
     ip_ms = prof["ip_sweep_ms"]
     launches = max(prof["ip_sweep_launches"], 1)
     solves_per_launch = prof["ip_sweep_problems"] / launches
     avg_launch_ms = ip_ms / launches
     bytes_per_launch = solves_per_launch * alg["bytes_per_solve"]
-    achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if ip_ms > 0 else 0.0
+    hbm_gbs = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if ip_ms > 0 else 0.0
     flops_per_solve = K * alg["flop_iter"] + alg["flop_tail"]
     tflops = solves_per_launch * flops_per_solve / (avg_launch_ms * 1e-3) / 1e12 if ip_ms > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "ip_sweep_traffic.json")
-    if os.path.exists(tpath):
+    # roofline.traffic: measured in this run (N = 1), else the committed measurement IF it belongs to these kernels
+    traffic, traffic_src = None, "skipped (--no-traffic)"
+    if not args.no_traffic and world == 1:
+        traffic, traffic_src = measure_sweep_traffic(B, H)
+    if traffic is None:
+        tpath = os.path.join(ROOT, "profiles", "ip_sweep_traffic.json")
         try:
             tj = json.load(open(tpath))
-            if tj.get("rollouts") == B and tj.get("horizon") == H:
-                traffic = tj.get("hbm_bytes_per_launch")
+            if tj.get("rollouts") == B and tj.get("horizon") == H and tj.get("csrc_sha16") == csrc_hash():
+                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), traffic_src + "; profiles/ip_sweep_traffic.json (same kernel sources)"
+            else:
+                traffic_src += "; profiles/ip_sweep_traffic.json is STALE for these kernel sources / sizes - not used"
         except Exception:
-            traffic = None
+            pass
     out = {
         "metric": "MPC steps/s (quadruped, H=40, fp64)",
-        "value": world * B * args.steps / dt,
+        "value": n_global * args.steps / dt,
         "unit": "MPC steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "quadruped flat_2D_lc dims, :configuration, H=%d, H_ref=%d, fp64, "
-                               "%d Monte-Carlo rollouts per GPU batch-sharded (BASELINE configs[3]; "
-                               "configs[2] = same problem at B=1, see latency_b1)" % (H, H_ref, B),
-                   "rollouts_per_gpu": B, "horizon": H, "perturb": args.perturb,
-                   "newton": "r_tol 3e-4, max_iter 5, cold start", "ip": "r_tol 1e-8, kappa_tol 2e-4, undercut 5"},
+        "config": {"workload": "quadruped flat_2D_lc dims, :configuration, H=%d, H_ref=%d, fp64, %d Monte-Carlo rollouts in the job "
+                               "(%d per GPU), batch-sharded over %d GPU(s) (BASELINE configs[3]; configs[0..2] = the B=1 legs under latency_b1 / mpc_loop_b1)"
+                               % (H, H_ref, n_global, B, world),
+                   "rollouts_total": n_global, "rollouts_per_gpu": B, "horizon": H, "perturb": args.perturb,
+                   "newton": "r_tol 3e-4, max_iter 5, cold start", "ip": "r_tol 1e-8, kappa_tol 2e-4, undercut 5",
+                   "multi_gpu": "rank-0 problem broadcast + one all-gather of [u1|iters|r_norm|sweeps] per reporting interval over RCCL; no collective inside a solve" if world > 1 else "single GPU"},
         "solver_iters": {"newton_iters_per_step": L, "ip_iters_per_solve": K, "sweeps_per_eval": S,
-                         "sweeps_per_step": sweeps / (B * args.steps), "lockstep_rounds_per_step": rounds / args.steps},
-        "roofline": {"bound": "hbm", "kernel": "ip_queue_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "bytes_per_unit": alg["bytes_per_solve"], "units_per_launch": solves_per_launch,
+                         "sweeps_per_step": job_sweeps / (n_global * args.steps), "lockstep_rounds_per_step": rounds / args.steps,
+                         "converged_rollouts": int((gathered["r_norm"] < 3e-4).sum()), "rollouts_reported": int(gathered["u1"].shape[0])},
+        # the sweep kernel runs out of LDS-resident tables: its binding roof is fp64 issue (vector FMA and MFMA share the
+        # 78.6 TFLOP/s fp64 peak on gfx950), not HBM - both fractions are reported, the binding one as `frac`
+        "roofline": {"bound": "mfma", "bound_detail": "fp64 issue roof (fp64 vector = fp64 MFMA dense peak = 78.6 TFLOP/s); HBM contract fraction under `hbm`",
+                     "kernel": "ip_queue_kernel", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                     "flops_per_unit": flops_per_solve, "bytes_per_unit": alg["bytes_per_solve"], "units_per_launch": solves_per_launch,
                      "avg_launch_ms": avg_launch_ms,
-                     "achieved_shared_table": solves_per_launch * alg["bytes_per_solve_shared_table"] / (avg_launch_ms * 1e-3) / 1e9 if ip_ms > 0 else 0.0,
-                     "fp64_tflops": tflops, "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
-                     "fp64_frac": tflops / FP64_VECTOR_PEAK_TFLOPS},
+                     "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
+                             "achieved_shared_table": solves_per_launch * alg["bytes_per_solve_shared_table"] / (avg_launch_ms * 1e-3) / 1e9 if ip_ms > 0 else 0.0,
+                             "traffic_over_algorithmic": (traffic / bytes_per_launch) if traffic and bytes_per_launch else None}},
         "kernel_time_ms_per_step": {"ip_sweep": prof["ip_sweep_ms"] / args.steps, "kkt": prof["kkt_ms"] / args.steps,
                                     "resid": prof["resid_ms"] / args.steps, "other": prof["other_ms"] / args.steps,
                                     "async_tail": prof["async_ms"] / args.steps},
@@ -348,8 +461,10 @@ def main():
                      "async_tail_launches_per_step": prof["async_launches"] / args.steps,
                      "ip_problems_in_rounds": prof["ip_sweep_problems"] / args.steps,
                      "ip_problems_in_async_tail": prof["async_problems"] / args.steps},
+        "setup_s": t_setup,
     }
-    if args.latency:
+    if not args.no_latency and world == 1:
+        # BASELINE configs[2]: the same quadruped problem for ONE robot, cold start
         s1, a0, a1 = make(1, rollouts[:1])
         for _ in range(3):
             s1.newton_solve_dev(a0.data_ptr(), a1.data_ptr(), False)
@@ -359,10 +474,13 @@ def main():
         for _ in range(n1):
             s1.newton_solve_dev(a0.data_ptr(), a1.data_ptr(), False)
         torch.cuda.synchronize()
-        out["latency_b1"] = {"ms_per_step": 1e3 * (time.perf_counter() - t1) / n1, "stats": s1.stats()}
+        ms1 = 1e3 * (time.perf_counter() - t1) / n1
+        out["latency_b1"] = {"workload": "quadruped H=40, ONE rollout, cold-start newton_solve! (BASELINE configs[2])",
+                             "ms_per_step": ms1, "mpc_steps_per_s": 1e3 / ms1, "stats": s1.stats()}
+        s1.close()
         # the reference's own use: ONE robot, warm-started MPC steps in a loop (policy.jl:98-146 cadence without the
         # plant: q1_next = planned q_3), reference / window advanced on the device (cimpc_mpc_advance)
-        out["mpc_loop_b1"] = {"quadruped_h40": mpc_loop_latency(QUADRUPED, "quadruped", 40, 60, local_rank),
+        out["mpc_loop_b1"] = {"quadruped_h40 (BASELINE configs[2])": mpc_loop_latency(QUADRUPED, "quadruped", 40, 60, local_rank),
                               "hopper_h20 (BASELINE configs[1])": mpc_loop_latency(dict(nq=4, nu=2, nw=2, nc=1, nb=2), "hopper", 20, 30, local_rank),
                               "pushbot_h10_configurationforce (BASELINE configs[0])": mpc_loop_latency(dict(nq=2, nu=2, nw=2, nc=2, nb=4), "pushbot", 10, 16, local_rank, mode=1),
                               "quadruped_h40_real_gait2": real_mpc_loop_latency(40, local_rank)}
@@ -373,7 +491,8 @@ def main():
             out["real_problem"] = {"error": repr(e)}
     if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a rank-0, N = 1 measurement
         try:
-            cb = cpu_baseline(d, prob, obj, rollouts, H, H_ref)
+            from contactimplicitmpc.jl_amd.trajectory import Objective
+            cb = cpu_baseline(d, prob, Objective(q=obj_q, u=obj_u), rollouts, H, H_ref)
             out["cpu_baseline"] = {
                 "value": cb["condensed"][0], "unit": "MPC steps/s", "cores": 1, "kind": "port",
                 "sample": "%d rollouts (condensed block-Cholesky KKT, the :ldl_solver analogue) and %d rollouts "
@@ -382,8 +501,11 @@ def main():
                 "value_dense_lu": cb["dense_lu"][0],
                 "value_all_cores": cb["all_cores"][0], "all_cores_threads": cb["all_cores"][2],
                 "all_cores_sample": "%d rollouts, condensed KKT, one solver instance per thread" % cb["all_cores"][1],
-                "host_cores_available": os.cpu_count()}
+                "host_cores_available": os.cpu_count(),
+                "note": "C restatement of the reference algorithm (not the Julia package: no Julia in this image)"}
             out["speedup_vs_cpu_1thread"] = out["value"] / cb["condensed"][0]
+            if "latency_b1" in out:     # the north-star ratio on the reference's own configuration: ONE robot, H = 40
+                out["latency_b1"]["speedup_vs_cpu_1thread"] = out["latency_b1"]["mpc_steps_per_s"] / cb["condensed"][0]
         except Exception as e:  # the baseline never blocks the GPU number
             out["cpu_baseline"] = {"error": repr(e)}
     print(json.dumps(out))
