@@ -66,7 +66,7 @@ struct IpSolver {
     double tthdyn, tthrst, altl;
     // iterate, residual, direction
     double x, y1, y2, rdyn, rrst, rbil, Dx_, Dy1_, Dy2_;
-    // factorization: column l of Q, row l of R, 1/R[l,l], regularised y, 1/y1r
+    // factorization: column l of Q, row l of -R (strict upper part), 1/R[l,l], regularised y, 1/y1r
     double Qc[NY], Rr[NY], rdinv, y1r, y2r, iy1r;
 
     __device__ __forceinline__ void bind(const double* tab_, double* Rst_, int l_) {
@@ -90,20 +90,24 @@ struct IpSolver {
         const double* tDx = tab + L.oDx; const double* tRx = tab + L.oRx;
         const double* tDy1 = tab + L.oDy1; const double* tRy1 = tab + L.oRy1;
         const double dx = x - x0, dy1 = y1 - y10, dy2 = y2 - y20;
-        double a = 0.0, c = 0.0;
-        static_for<0, NX>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            const double v = LG::template bcast<k>(dx);
-            a = fma(tDx[k * G + l], v, a);
-            c = fma(tRx[k * G + l], v, c);
-        });
-        double bb = 0.0, e = 0.0;
-        static_for<0, NY>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            const double v = LG::template bcast<k>(dy1);
-            bb = fma(tDy1[k * G + l], v, bb);
-            e = fma(tRy1[k * G + l], v, e);
-        });
+        double a = 0.0, c = 0.0, bb = 0.0, e = 0.0;
+        if constexpr (G == 16) {       // broadcast fused into the multiply-add (lane_group.h: Dpp16), same summation order
+            Dpp16::pair<NX>(a, c, dx, [&](auto kc) { return tDx[decltype(kc)::value * G + l]; }, [&](auto kc) { return tRx[decltype(kc)::value * G + l]; });
+            Dpp16::pair<NY>(bb, e, dy1, [&](auto kc) { return tDy1[decltype(kc)::value * G + l]; }, [&](auto kc) { return tRy1[decltype(kc)::value * G + l]; });
+        } else {
+            static_for<0, NX>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const double v = LG::template bcast<k>(dx);
+                a = fma(tDx[k * G + l], v, a);
+                c = fma(tRx[k * G + l], v, c);
+            });
+            static_for<0, NY>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const double v = LG::template bcast<k>(dy1);
+                bb = fma(tDy1[k * G + l], v, bb);
+                e = fma(tRy1[k * G + l], v, e);
+            });
+        }
         rdyn = ((rdyn0 + a) + bb) + tthdyn;
         rrst = ((((rrst0 + c) + e) + ry2 * dy2) + tthrst) + altl;
         rbil = vy ? (y1 * y2 - kappa) : 0.0;
@@ -132,12 +136,17 @@ struct IpSolver {
         static_for<0, NY>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
-            double ak[NY];
-            static_for<0, NY>([&](auto ic) {
-                constexpr int r = decltype(ic)::value;
-                ak[r] = LG::template bcast<k>(Qc[r]);
-                acc[r & 3] = fma(ak[r], Qc[r], acc[r & 3]);
-            });
+            [[maybe_unused]] double ak[G == 16 ? 1 : NY];     // 32-lane groups: column k broadcast once (ds_bpermute), used twice
+            if constexpr (G == 16) {
+                // a_k . a_l: column k rides on the DPP source of the multiply-add (no broadcast registers)
+                Dpp16::dot<k, NY>(acc, Qc);
+            } else {
+                static_for<0, NY>([&](auto ic) {
+                    constexpr int r = decltype(ic)::value;
+                    ak[r] = LG::template bcast<k>(Qc[r]);
+                    acc[r & 3] = fma(ak[r], Qc[r], acc[r & 3]);
+                });
+            }
             const double dot = (acc[0] + acc[1]) + (acc[2] + acc[3]);     // a_k . a_l
             // |a_k|^2 is lane k's own dot product (there a_k[r] * a_k[r], the same four partial sums a separate
             // norm loop would form): one broadcast instead of 16 multiply-adds per step
@@ -145,17 +154,21 @@ struct IpSolver {
             rdinv = (l == k) ? invk : rdinv;
             double rk = dot * invk;
             rk = ((l > k) && vy) ? rk : 0.0;
-            const double coef = rk * invk;
-            static_for<0, NY>([&](auto ic) {
-                constexpr int r = decltype(ic)::value;
-                Qc[r] = fma(-coef, ak[r], Qc[r]);
-            });
+            const double ncoef = -(rk * invk);          // zero in lanes <= k: column k itself stays as it is during the update
+            if constexpr (G == 16) {
+                Dpp16::self<k, NY>(Qc, ncoef);       // a_l -= (r_kl / |a_k|) a_k
+            } else {
+                static_for<0, NY>([&](auto ic) {
+                    constexpr int r = decltype(ic)::value;
+                    Qc[r] = fma(ncoef, ak[r], Qc[r]);
+                });
+            }
             Rst[k * M::RST_LD + l] = rk;   // R[k,l], l > k (zeros elsewhere)
         });
         wave_lds_fence();
         static_for<0, NY>([&](auto kc) {   // row l of R (transpose through the LDS tile)
             constexpr int k = decltype(kc)::value;
-            Rr[k] = vy ? Rst[l * M::RST_LD + k] : 0.0;
+            Rr[k] = vy ? -Rst[l * M::RST_LD + k] : 0.0;      // kept negated: the back-substitution adds
         });
         wave_lds_fence();
     }
@@ -163,37 +176,53 @@ struct IpSolver {
     // t = R^-1 Q^T rhs  (qr_solve!, qr.jl:142-158); rhs lane-indexed
     __device__ __forceinline__ double qr_solve(double rhs) const {
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        static_for<0, NY>([&](auto ic) {
-            constexpr int r = decltype(ic)::value;
-            acc[r & 3] = fma(Qc[r], LG::template bcast<r>(rhs), acc[r & 3]);
-        });
+        if constexpr (G == 16) {
+            Dpp16::matvec<NY, 4>(acc, rhs, [&](auto rc) { return Qc[decltype(rc)::value]; });
+        } else {
+            static_for<0, NY>([&](auto ic) {
+                constexpr int r = decltype(ic)::value;
+                acc[r & 3] = fma(Qc[r], LG::template bcast<r>(rhs), acc[r & 3]);
+            });
+        }
         double c = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * rdinv;   // (Q^T rhs)_l, Q = Qc * rdinv
-        double t = 0.0;
-        static_rfor<NY - 1>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            const double xk = LG::template bcast<k>(c * rdinv);
-            t = (l == k) ? xk : t;
-            c = fma(-Rr[k], xk, c);   // R[l,k] (zero for k <= l)
-        });
-        return t;
+        // back-substitution, row l of R in this lane: x_k = c_k / R[k,k] broadcast, c_l -= R[l,k] x_k (k > l).  Lane l's c is
+        // final once step k = l + 1 is done (R[l,k] = 0 for k <= l), so x_l = c * rdinv after the loop - the same product
+        // the reference forms at step l (qr.jl:150-157).
+        if constexpr (G == 16) {
+            static_rfor<NY - 1>([&](auto kc) { Dpp16::backsub<decltype(kc)::value>(c, rdinv, Rr[decltype(kc)::value]); });
+        } else {
+            static_rfor<NY - 1>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const double xk = LG::template bcast<k>(c * rdinv);
+                c = fma(Rr[k], xk, c);
+            });
+        }
+        return c * rdinv;
     }
 
     // schur_solve! (schur.jl:93-110): returns temp; x = Ai*(u + B*temp), y = -temp
     __device__ __forceinline__ double schur_solve(double u, double v, double& xs) const {
         const double* tCAi = tab + L.oCAi; const double* tAi = tab + L.oAi; const double* tDy1 = tab + L.oDy1;
-        double bq[2] = {0.0, 0.0};
+        double bq[2] = {0.0, 0.0}, w[2] = {0.0, 0.0}, xx[2] = {0.0, 0.0};
+        if constexpr (G == 16) {
+            Dpp16::matvec<NX, 2>(bq, u, [&](auto kc) { return tCAi[decltype(kc)::value * G + l]; });
+            const double t = qr_solve((bq[0] + bq[1]) - v);
+            Dpp16::matvec<NY, 2>(w, t, [&](auto kc) { return tDy1[decltype(kc)::value * G + l]; });
+            const double ww = u + (w[0] + w[1]);
+            Dpp16::matvec<NX, 2>(xx, ww, [&](auto kc) { return tAi[decltype(kc)::value * G + l]; });
+            xs = xx[0] + xx[1];
+            return t;
+        }
         static_for<0, NX>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             bq[k & 1] = fma(tCAi[k * G + l], LG::template bcast<k>(u), bq[k & 1]);
         });
         const double t = qr_solve((bq[0] + bq[1]) - v);
-        double w[2] = {0.0, 0.0};
         static_for<0, NY>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             w[k & 1] = fma(tDy1[k * G + l], LG::template bcast<k>(t), w[k & 1]);
         });
         const double ww = u + (w[0] + w[1]);
-        double xx[2] = {0.0, 0.0};
         static_for<0, NX>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             xx[k & 1] = fma(tAi[k * G + l], LG::template bcast<k>(ww), xx[k & 1]);

@@ -93,6 +93,123 @@ struct LaneGroup {
     }
 };
 
+// ------------------------------------------------------------------------------------------------------------------
+// Fused broadcast-FMA for 16-lane groups:  acc += bcast<K>(s) * t  in ONE instruction.
+// gfx90a+ DP-ALU instructions accept a DPP source with the row_newbcast control (and only that one): the broadcast of
+// lane K of every 16-lane row rides on src0 of `v_fmac_f64_dpp`.  hipcc does not form it from `update_dpp` + `fma`
+// (it emits v_mov_b64_dpp + v_fmac_f64: two DP-ALU issue slots per multiply-add), hence the inline assembly.
+//   * DPP hazard: a VGPR written by a VALU instruction may be read through DPP only two wait states later.  The
+//     hazard recogniser does not look inside inline assembly (and register allocation may place a copy right in
+//     front of a statement), so every statement opens with `s_nop 1`; statements carry 2..4 multiply-adds.
+//   * EXEC: every lane of the row must be active (same rule as for the broadcasts above).
+//   * Arithmetic: fmac(acc, a, b) = fma(a, b, acc) - the same roundings as the unfused form.
+#define CIMPC_FMAC_DPP(acc, src, t, k) "v_fmac_f64_dpp %[" #acc "], %[" #src "], %[" #t "] row_newbcast:%[" #k "] row_mask:0xf bank_mask:0xf\n\t"
+
+}  // namespace cimpc
+#include "dpp16_gen.h"     // Dpp16Gen: statements of 1, 2, 3, 4, 8, 16 fused multiply-adds (scripts/gen_dpp16.py)
+namespace cimpc {
+
+// largest generated statement size that fits into N remaining multiply-adds (earlier chunks are multiples of four,
+// so accumulator rotation k & 1 / k & 3 stays aligned)
+template <int N, int MAX = 16>
+constexpr int dpp_chunk() { return (N >= 16 && MAX >= 16) ? 16 : (N >= 8 && MAX >= 8) ? 8 : N >= 4 ? 4 : N; }
+
+struct Dpp16 {
+    // ---- acc[r & 3] += bcast<K>(Q[r]) * Q[r], r = R0 .. R0+N-1: dot products of column K with every column -------------
+    template <int K, int R0, int NQ, int... I>
+    static __device__ __forceinline__ void dot_c(double (&a)[4], const double (&Q)[NQ], std::integer_sequence<int, I...>) {
+        constexpr int C = sizeof...(I);
+        if constexpr (C == 16) Dpp16Gen::dot16<K>(a[0], a[1], a[2], a[3], Q[R0 + I]...);
+        else if constexpr (C == 8) Dpp16Gen::dot8<K>(a[0], a[1], a[2], a[3], Q[R0 + I]...);
+        else if constexpr (C == 4) Dpp16Gen::dot4<K>(a[0], a[1], a[2], a[3], Q[R0 + I]...);
+        else if constexpr (C == 3) Dpp16Gen::dot3<K>(a[0], a[1], a[2], Q[R0 + I]...);
+        else if constexpr (C == 2) Dpp16Gen::dot2<K>(a[0], a[1], Q[R0 + I]...);
+        else Dpp16Gen::dot1<K>(a[0], Q[R0 + I]...);
+    }
+    template <int K, int N, int R0 = 0, int NQ>
+    static __device__ __forceinline__ void dot(double (&a)[4], const double (&Q)[NQ]) {
+        if constexpr (N > 0) {
+            constexpr int C = dpp_chunk<N>();
+            dot_c<K, R0>(a, Q, std::make_integer_sequence<int, C>{});
+            dot<K, N - C, R0 + C>(a, Q);
+        }
+    }
+    // ---- Q[r] += bcast<K>(Q[r]) * c: rank-1 update of the columns by column K --------------------------------------------
+    template <int K, int R0, int NQ, int... I>
+    static __device__ __forceinline__ void self_c(double (&Q)[NQ], double c, std::integer_sequence<int, I...>) {
+        constexpr int C = sizeof...(I);
+        if constexpr (C == 16) Dpp16Gen::self16<K>(Q[R0 + I]..., c);
+        else if constexpr (C == 8) Dpp16Gen::self8<K>(Q[R0 + I]..., c);
+        else if constexpr (C == 4) Dpp16Gen::self4<K>(Q[R0 + I]..., c);
+        else if constexpr (C == 3) Dpp16Gen::self3<K>(Q[R0 + I]..., c);
+        else if constexpr (C == 2) Dpp16Gen::self2<K>(Q[R0 + I]..., c);
+        else Dpp16Gen::self1<K>(Q[R0 + I]..., c);
+    }
+    template <int K, int N, int R0 = 0, int NQ>
+    static __device__ __forceinline__ void self(double (&Q)[NQ], double c) {
+        if constexpr (N > 0) {
+            constexpr int C = dpp_chunk<N>();
+            self_c<K, R0>(Q, c, std::make_integer_sequence<int, C>{});
+            self<K, N - C, R0 + C>(Q, c);
+        }
+    }
+    // ---- acc[k & (NACC-1)] += bcast<k>(v) * T(k), k = 0..N-1  (T: callable on std::integral_constant<int,k>) ------------------
+    template <int K0, int NACC, class TF, int... I>
+    static __device__ __forceinline__ void matvec_c(double (&a)[NACC], double v, TF& T, std::integer_sequence<int, I...>) {
+        constexpr int C = sizeof...(I);
+        if constexpr (NACC == 2) {
+            if constexpr (C == 16) Dpp16Gen::lanes16_acc2<K0>(a[0], a[1], v, T(std::integral_constant<int, K0 + I>{})...);
+            else if constexpr (C == 8) Dpp16Gen::lanes8_acc2<K0>(a[0], a[1], v, T(std::integral_constant<int, K0 + I>{})...);
+            else if constexpr (C == 4) Dpp16Gen::lanes4_acc2<K0>(a[0], a[1], v, T(std::integral_constant<int, K0 + I>{})...);
+            else if constexpr (C == 3) Dpp16Gen::lanes3_acc2<K0>(a[0], a[1], v, T(std::integral_constant<int, K0 + I>{})...);
+            else if constexpr (C == 2) Dpp16Gen::lanes2_acc2<K0>(a[0], a[1], v, T(std::integral_constant<int, K0 + I>{})...);
+            else Dpp16Gen::lanes1_acc2<K0>(a[0], v, T(std::integral_constant<int, K0 + I>{})...);
+        } else {
+            static_assert(NACC == 4, "two or four accumulators");
+            if constexpr (C == 16) Dpp16Gen::lanes16_acc4<K0>(a[0], a[1], a[2], a[3], v, T(std::integral_constant<int, K0 + I>{})...);
+            else if constexpr (C == 8) Dpp16Gen::lanes8_acc4<K0>(a[0], a[1], a[2], a[3], v, T(std::integral_constant<int, K0 + I>{})...);
+            else if constexpr (C == 4) Dpp16Gen::lanes4_acc4<K0>(a[0], a[1], a[2], a[3], v, T(std::integral_constant<int, K0 + I>{})...);
+            else if constexpr (C == 3) Dpp16Gen::lanes3_acc4<K0>(a[0], a[1], a[2], v, T(std::integral_constant<int, K0 + I>{})...);
+            else if constexpr (C == 2) Dpp16Gen::lanes2_acc4<K0>(a[0], a[1], v, T(std::integral_constant<int, K0 + I>{})...);
+            else Dpp16Gen::lanes1_acc4<K0>(a[0], v, T(std::integral_constant<int, K0 + I>{})...);
+        }
+    }
+    template <int N, int NACC, int K0 = 0, class TF>
+    static __device__ __forceinline__ void matvec(double (&a)[NACC], double v, TF&& T) {
+        if constexpr (N > 0) {
+            constexpr int C = dpp_chunk<N>();
+            matvec_c<K0>(a, v, T, std::make_integer_sequence<int, C>{});
+            matvec<N - C, NACC, K0 + C>(a, v, T);
+        }
+    }
+    // ---- a += bcast<k>(v) * TA(k), c += bcast<k>(v) * TC(k), k = 0..N-1: two operators on one vector, sequential chains ---
+    template <int K0, class TA, class TC, int... I>
+    static __device__ __forceinline__ void pair_c(double& a, double& c, double v, TA& ta, TC& tc, std::integer_sequence<int, I...>) {
+        constexpr int C = sizeof...(I);
+        // (argument order of the generated statements: ta0, tc0, ta1, tc1, ...)
+        if constexpr (C == 8) Dpp16Gen::pair8<K0>(a, c, v, ta(std::integral_constant<int, K0 + 0>{}), tc(std::integral_constant<int, K0 + 0>{}), ta(std::integral_constant<int, K0 + 1>{}), tc(std::integral_constant<int, K0 + 1>{}), ta(std::integral_constant<int, K0 + 2>{}), tc(std::integral_constant<int, K0 + 2>{}), ta(std::integral_constant<int, K0 + 3>{}), tc(std::integral_constant<int, K0 + 3>{}), ta(std::integral_constant<int, K0 + 4>{}), tc(std::integral_constant<int, K0 + 4>{}), ta(std::integral_constant<int, K0 + 5>{}), tc(std::integral_constant<int, K0 + 5>{}), ta(std::integral_constant<int, K0 + 6>{}), tc(std::integral_constant<int, K0 + 6>{}), ta(std::integral_constant<int, K0 + 7>{}), tc(std::integral_constant<int, K0 + 7>{}));
+        else if constexpr (C == 4) Dpp16Gen::pair4<K0>(a, c, v, ta(std::integral_constant<int, K0 + 0>{}), tc(std::integral_constant<int, K0 + 0>{}), ta(std::integral_constant<int, K0 + 1>{}), tc(std::integral_constant<int, K0 + 1>{}), ta(std::integral_constant<int, K0 + 2>{}), tc(std::integral_constant<int, K0 + 2>{}), ta(std::integral_constant<int, K0 + 3>{}), tc(std::integral_constant<int, K0 + 3>{}));
+        else if constexpr (C == 3) Dpp16Gen::pair3<K0>(a, c, v, ta(std::integral_constant<int, K0 + 0>{}), tc(std::integral_constant<int, K0 + 0>{}), ta(std::integral_constant<int, K0 + 1>{}), tc(std::integral_constant<int, K0 + 1>{}), ta(std::integral_constant<int, K0 + 2>{}), tc(std::integral_constant<int, K0 + 2>{}));
+        else if constexpr (C == 2) Dpp16Gen::pair2<K0>(a, c, v, ta(std::integral_constant<int, K0 + 0>{}), tc(std::integral_constant<int, K0 + 0>{}), ta(std::integral_constant<int, K0 + 1>{}), tc(std::integral_constant<int, K0 + 1>{}));
+        else Dpp16Gen::pair1<K0>(a, c, v, ta(std::integral_constant<int, K0>{}), tc(std::integral_constant<int, K0>{}));
+    }
+    template <int N, int K0 = 0, class TA, class TC>
+    static __device__ __forceinline__ void pair(double& a, double& c, double v, TA&& ta, TC&& tc) {
+        if constexpr (N > 0) {
+            constexpr int C = dpp_chunk<N, 8>();
+            pair_c<K0>(a, c, v, ta, tc, std::make_integer_sequence<int, C>{});
+            pair<N - C, K0 + C>(a, c, v, ta, tc);
+        }
+    }
+    // back-substitution step K of an upper-triangular solve kept one ROW per lane (nr = -R[l,K], zero for K <= l):
+    //   x_K = c_K * rdinv_K  (formed in every lane, lane K's value is the solution component);  c += bcast<K>(x) * nr
+    template <int K>
+    static __device__ __forceinline__ void backsub(double& c, double rdinv, double nr) {
+        double x;
+        asm("v_mul_f64 %[x], %[c], %[ri]\n\ts_nop 1\n\t" CIMPC_FMAC_DPP(c, x, nr, k) : [c] "+v"(c), [x] "=&v"(x) : [ri] "v"(rdinv), [nr] "v"(nr), [k] "n"(K));
+    }
+};
+
 // 1/sqrt(x) and 1/x to ~1 ulp from the hardware seeds (v_rsq_f64 / v_rcp_f64) and two
 // Newton steps - an order of magnitude fewer instructions than the IEEE sqrt + divide
 // sequences hipcc emits (v_div_scale / v_div_fmas / v_div_fixup).

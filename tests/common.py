@@ -52,3 +52,25 @@ def oracle_sweep(d, tabs, rollouts, opts, traj_of=None):
         tr.update_theta(d, 1)
         outs.append((tr, oip.implicit_dynamics(d, tabs, window, tr.q, tr.theta, opts, gamma=tr.gamma, b=tr.b)))
     return outs
+
+
+def oracle_scatter(d, tabs, rollout, opts, K=4, seed=0):
+    """How far the ORACLE's own converged answers move when theta is perturbed in the last place (theta * (1 +- 2^-52),
+    K draws): per solve the largest deviation of z, d and the sensitivities among the draws that keep (status, iters).
+    A converged interior-point iterate is unique only up to the termination tolerances; ill-conditioned solves amplify
+    round-off well above the nominal 1e-7.  Device-vs-oracle tolerances are max(nominal, 50 x this scatter), so a tight
+    bound applies wherever the oracle itself is stable.  Returns (base_out, dict of (H,) arrays, sensitive (H,) bool)."""
+    (tr, o), = oracle_sweep(d, tabs, [rollout], opts)
+    H = o["iters"].shape[0]
+    sc = {k: np.zeros(H) for k in ("z", "d", "dq0", "dq1", "du1")}
+    sens = np.zeros(H, dtype=bool)
+    rng = np.random.default_rng(seed)
+    for _ in range(K):
+        th = tr.theta * (1.0 + (rng.integers(0, 2, tr.theta.shape) * 2 - 1) * 2.0 ** -52)
+        p = oip.implicit_dynamics(d, tabs, rollout[0], tr.q, th, opts, gamma=tr.gamma, b=tr.b)
+        same = (p["status"] == o["status"]) & (p["iters"] == o["iters"])
+        sens |= ~same
+        for k in sc:
+            dev = np.abs(p[k] - o[k]).reshape(H, -1).max(axis=1)
+            sc[k] = np.maximum(sc[k], np.where(same, dev, 0.0))
+    return (tr, o), sc, sens

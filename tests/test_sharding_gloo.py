@@ -53,9 +53,8 @@ def _solve(prob, obj_q, obj_u, rollouts):
     cr = CRef(d, H_REF, H, prob, Objective(q=obj_q, u=obj_u), oip.IPOptions(kappa_tol=prob["kappa"]),
               onewton.NewtonOptions(r_tol=1e-5, max_iter=4), prob["kappa"])
     res = [cr.newton_solve(w, ref, q0, q1, solver=1) for (w, ref, q0, q1) in rollouts]
-    N = H * (d.nr + d.nd)
     return (np.stack([r["u"][0] for r in res]), np.array([r["iters"] for r in res]),
-            np.array([r["r_norm"] / N for r in res]), np.array([r["sweeps"] for r in res]))
+            np.array([r["r_norm"] for r in res]), np.array([r["sweeps"] for r in res]))
 
 
 def _shapes():
