@@ -63,7 +63,6 @@ struct Knobs {
     bool debug_rounds = false;   // CIMPC_DEBUG_ROUNDS
     bool kkt_packed = true;      // CIMPC_KKT_PACKED
     int tail_div = 8;            // CIMPC_TAIL_DIV
-    int ahead_margin = 64;       // CIMPC_AHEAD_MARGIN: pull-ahead of the sweep's queue (negative: off)
 
     static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
     void read_environment() {
@@ -88,7 +87,6 @@ struct Knobs {
         debug_rounds = getenv("CIMPC_DEBUG_ROUNDS") != nullptr;
         kkt_packed = env_int("CIMPC_KKT_PACKED", 1) != 0;
         tail_div = env_int("CIMPC_TAIL_DIV", tail_div);
-        ahead_margin = env_int("CIMPC_AHEAD_MARGIN", ahead_margin);
     }
 };
 
@@ -290,7 +288,6 @@ IpParams make_ip_params(cimpc_ctx* h, const TrajDev& T, int par, int* pending_co
     p.pstate = h->d_pstate;
     p.pending_count = pending_counter;
     p.iter_cap = h->iter_cap;
-    p.ahead_margin = h->kn.ahead_margin >= 0 ? h->kn.ahead_margin : (1 << 30);
     p.slots = CS;
     p.H = h->dm.H;
     p.o = h->ip;

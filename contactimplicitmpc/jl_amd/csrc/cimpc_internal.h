@@ -141,8 +141,6 @@ struct IpParams {
     double* pstate;        // [B*slots][H][2nx + 4ny + 4]  parked iterate / converged z for the sens pass
     int* pending_count;    // device counter, incremented once per parked problem
     int iter_cap;
-    int ahead_margin;      // pull-ahead (ip_kernel_impl.h: serve_knot): the next queue index is requested early only while
-                           // at least this many items lie beyond the current one; INT_MAX / 2 switches it off
     int slots;             // evaluation slots per rollout: rollout = slot index / slots
     int H;
     cimpc_ip_opts o;

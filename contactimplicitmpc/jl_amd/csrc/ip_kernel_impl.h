@@ -440,35 +440,8 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
     [[maybe_unused]] long long dbg_pop[4] = {0, 0, 0, 0};
     [[maybe_unused]] const bool dbg_on = ASYNC && p.A.dbg != nullptr;      // diagnostics only with CIMPC_ASYNC_DEBUG
     double reg = 0.0, r_vio = 0.0, k_vio = 0.0, qinit = 0.0;
-    // Pull-ahead (lock-step rounds): a pull is three DEPENDENT global round trips - queue head (returning atomic), problem
-    // id, problem inputs - about 2-4 us during which all four groups of the wave stand still.  While a group solves a
-    // problem it therefore walks the NEXT one through the same three steps, one step per trip, so that every wait falls
-    // on a load issued a whole interior-point iteration earlier.  Only while the knot's queue is long (`ahead_margin`
-    // items beyond the current one): the last items stay unclaimed for whichever group runs dry first.
-    constexpr int NTHR = (NTH + G - 1) / G;
-    [[maybe_unused]] int pre_state = 0;      // 0 nothing, 1 index requested, 2 problem id known, 3 inputs loaded, 4 queue exhausted
-    [[maybe_unused]] int pre_raw = 0, pre_prob = 0, pre_flag = 0, pre_idx = 0, cur_idx = 0;
-    [[maybe_unused]] double pre_th[NTHR], pre_q = 0.0;
 
     while (true) {
-        if constexpr (!ASYNC) {
-            if (pre_state == 2) {
-                const size_t pi = (size_t)pre_prob;
-                const int sb = pre_prob / p.H, i = pre_prob - sb * p.H;
-                const double* th = p.theta + pi * NTH;
-                static_for<0, NTHR>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    pre_th[j] = (l + j * G < NTH) ? th[l + j * G] : 0.0;
-                });
-                pre_q = vx ? p.q[((size_t)sb * (p.H + 2) + (i + 2)) * M::NQ + l] : 0.0;
-                pre_flag = p.pflag[pi];
-                pre_state = 3;
-            } else if (pre_state == 1) {
-                pre_idx = group_bcast0<G>(pre_raw);
-                if (pre_idx < n) { pre_prob = items[pre_idx]; pre_state = 2; }
-                else pre_state = 4;
-            }
-        }
         // ---- 1. end of a solve? ---------------------------------------------------------------
         if (have) {
             int code = -1;
@@ -532,31 +505,15 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
                 if (item >= 0) xfence(p.A.flags);      // acquire the candidate trajectory of the producer
                 if (dbg_on) { dbg_tpop += tq1 - tq0; dbg_tfence += wall_clock64() - tq1; }
             } else {
-                if (pre_state == 0) {
-                    if (l == 0) idx = atomicAdd(head, 1);
-                    idx = group_bcast0<G>(idx);
-                } else if (pre_state == 1) {
-                    idx = group_bcast0<G>(pre_raw);
-                } else {
-                    idx = pre_state == 4 ? n : pre_idx;
-                }
+                if (l == 0) idx = atomicAdd(head, 1);
+                idx = group_bcast0<G>(idx);
             }
             if (idx < n) {
-                if constexpr (ASYNC) prob = item;
-                else prob = (pre_state == 2 || pre_state == 3) ? pre_prob : items[idx];
-                cur_idx = idx;
+                prob = ASYNC ? item : items[idx];
                 const int sb = prob / p.H, i = prob - sb * p.H;
                 const size_t pi = (size_t)prob;
                 const double* th = p.theta + pi * NTH;
-                const bool pre_in = !ASYNC && pre_state == 3;
-                if (pre_in) {
-                    static_for<0, NTHR>([&](auto jc) {
-                        constexpr int j = decltype(jc)::value;
-                        if (l + j * G < NTH) dth[l + j * G] = pre_th[j] - tab[L.oTh0 + l + j * G];
-                    });
-                } else {
-                    for (int k = l; k < NTH; k += G) dth[k] = xld<ASYNC>(th + k) - tab[L.oTh0 + k];
-                }
+                for (int k = l; k < NTH; k += G) dth[k] = xld<ASYNC>(th + k) - tab[L.oTh0 + k];
                 wave_lds_fence();
                 {   // rthdyn*(th-th0), rthrst*(th-th0): constant per solve
                     double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
@@ -578,17 +535,9 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
                 }
                 S.altl = (p.alt != nullptr && l < NC) ? p.alt[(size_t)(sb / p.slots) * NC + l] : 0.0;
                 const double* qrow = p.q + ((size_t)sb * (p.H + 2) + (i + 2)) * M::NQ;
-                qinit = pre_in ? pre_q : (vx ? xld<ASYNC>(qrow + l) : 0.0);
+                qinit = vx ? xld<ASYNC>(qrow + l) : 0.0;
                 const double* ps = p.pstate + pi * PS;
-                const int parked = pre_in ? pre_flag : p.pflag[pi];
-                if constexpr (!ASYNC) {       // request the index of the problem after this one
-                    pre_state = 0;
-                    if (cur_idx + p.ahead_margin < n) {
-                        if (l == 0) pre_raw = atomicAdd(head, 1);
-                        pre_state = 1;
-                    }
-                }
-                if (parked == 1) {      // resume a parked solve
+                if (p.pflag[pi] == 1) {      // resume a parked solve
                     S.x = vx ? ps[l] : 0.0;
                     S.y1 = vy ? ps[NX + l] : 1.0;
                     S.y2 = vy ? ps[NX + NY + l] : 1.0;
