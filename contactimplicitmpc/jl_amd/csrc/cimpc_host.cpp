@@ -48,7 +48,7 @@ struct Knobs {
     int async_mem = 0;           // CIMPC_ASYNC_MEM: 1 uncached, 2 fine-grained exchange buffers (experiment)
     int spec_all = -1;           // CIMPC_SPEC_ALL
     int spec_tail = 3;           // CIMPC_SPEC_TAIL
-    int iter_cap = 24;           // CIMPC_ITER_CAP
+    int iter_cap = 28;           // CIMPC_ITER_CAP (B = 512: 24 / 28 / 32 / 36 -> 11.8 / 11.5 / 11.8 / 11.75 ms with the fused-broadcast sweep)
     int waves = 0;               // CIMPC_WAVES (0: by batch size)
     int kkt_overlap = -1;        // CIMPC_KKT_OVERLAP (-1: by batch size)
     int sweep_wgs = 0;           // CIMPC_SWEEP_WGS (0: computed)
@@ -118,7 +118,7 @@ struct cimpc_ctx {
     double *d_q0 = nullptr, *d_q1 = nullptr;
     double* d_rhs = nullptr;   // B1 seam staging
     double* d_pstate = nullptr;   // parked interior-point iterates
-    int iter_cap = 24;            // (Knobs::iter_cap) measured B = 512: 16 / 20 / 24 / 32 / 48 -> 13.57 / 12.73 / 12.85 / 12.97 / 14.41 ms per batch step
+    int iter_cap = 28;            // (Knobs::iter_cap) measured B = 512: 16 / 20 / 24 / 32 / 48 -> 13.57 / 12.73 / 12.85 / 12.97 / 14.41 ms per batch step
     NewtonDev S{};
     int* h_counters = nullptr;   // pinned
     // bookkeeping
@@ -433,7 +433,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         // (B = 64: 8.1 vs 11.2 ms), the rounds win for large batches (B = 512: 16.5 vs 21.7 ms) - except for
         // their sparse tail, which auto mode hands over to the asynchronous kernel.
         h->async_mode = h->kn.async_mode;
-        h->async_tail = std::min(256, std::max(64, d.B / 4));     // measured: B = 512 -> 128, B = 2048 -> 256
+        h->async_tail = std::min(256, std::max(64, d.B / 6));     // measured: B = 512 -> 80 .. 96, B = 2048 -> 256
         if (h->kn.async_tail >= 0) h->async_tail = h->kn.async_tail;
         const bool want = h->async_mode != 0;
         const size_t K = d.H_ref;

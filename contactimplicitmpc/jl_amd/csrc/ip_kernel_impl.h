@@ -23,6 +23,12 @@
 #include "lane_group.h"
 #include "lin_table.h"
 
+// wave priorities: the KKT recursion that runs next to the sweep (second stream, one wave per rollout) is the longer leg of
+// most rounds since the sweep lost a third of its instructions: it gets the issue slots first (KKT 2 / sweep 0: 11.9 -> 11.6 ms)
+#ifndef CIMPC_SWEEP_PRIO
+#define CIMPC_SWEEP_PRIO 0
+#endif
+
 namespace cimpc {
 
 template <int NQ_, int NU_, int NW_, int NC_, int NB_, int MODE_>
@@ -35,6 +41,7 @@ struct Model {
     static_assert(NX <= 32 && NY <= 32, "lane group holds at most 32 rows");
     static constexpr int RST_LD = G + 1;                       // padded row stride of the R tile
     static constexpr int SENS_MAX = 16;                         // converged problems a group may defer
+// (measured dead end: C A^-1, A^-1, Dy1 rows register-resident per knot - the 76 extra VGPRs spill, sweep launch 0.30 -> 0.47 ms)
 #ifndef CIMPC_SENS_ILP
 #define CIMPC_SENS_ILP 5
 #endif
@@ -613,9 +620,7 @@ __global__ __launch_bounds__(256, M::G == 16 ? 2 : 1) void ip_queue_kernel(IpPar
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int s_knot, s_total, s_rem[PICK_MAXK];
     const int tid = (int)threadIdx.x;
-    // The sweep heads the critical path of a round; the KKT recursion that runs next to it on the same SIMDs
-    // (one wave per rollout, second stream) does not: the sweep's waves get the issue slots first.
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(CIMPC_SWEEP_PRIO);
     while (true) {
         __syncthreads();            // every wave is done with the staged table
         const int knot = pick_knot(p, s_rem, &s_total, &s_knot, tid, (int)blockIdx.x, (int)gridDim.x);

@@ -481,6 +481,9 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
     }
 }
 
+#ifndef CIMPC_KKT_PRIO
+#define CIMPC_KKT_PRIO 2
+#endif
 #ifndef CIMPC_RESID_THREADS
 #define CIMPC_RESID_THREADS 256
 #endif
@@ -1497,6 +1500,7 @@ __global__ __launch_bounds__((64 * kkt_pack<NQ, NU>()), (kkt_tld<NQ, NU>() <= 16
     if (n_dev != nullptr) n = *n_dev;        // rounds enqueued ahead of the host: the count is only known on the device
     const int wave = (int)threadIdx.x >> 6, slot = (int)blockIdx.x * kkt_pack<NQ, NU>() + wave;
     if (slot >= n) return;
+    __builtin_amdgcn_s_setprio(CIMPC_KKT_PRIO);      // (see ip_kernel_impl.h: CIMPC_SWEEP_PRIO)
     kkt_body<NQ, NU, WaveSync>(S, K, list[slot], sm + (size_t)wave * kkt_lds_doubles<NQ, NU, 1>(), (int)threadIdx.x & 63);
 }
 
