@@ -128,6 +128,9 @@ struct cimpc_ctx {
     bool velocity_objective = false;
     bool use_dense = false;        // KKT through kkt_dense.hip: the reference-default dense LU (any mode / objective) ...
     bool use_banded = false;       // ... or its banded LDL^T (:configuration mode, velocity objective / on request)
+    bool use_mixed = false;        // condensed solve in mixed precision (CIMPC_KKT_CONDENSED_MIXED)
+    double* d_mix_ws = nullptr;
+    int* d_mix_nfb = nullptr;
     size_t dense_ws_doubles = 0;
     // :configurationforce with negligible gamma / b weights: eliminated onto the :configuration solvers (newton_kernels.hip)
     bool cf_reduce = false, cf_tiny = true;
@@ -323,10 +326,18 @@ static void select_kkt_backend(cimpc_ctx* h) {
     h->use_dense = !cfg || want == CIMPC_KKT_DENSE_LU || want == CIMPC_KKT_BANDED_LDL || velocity;
     h->use_banded = h->use_dense && cfg && want != CIMPC_KKT_DENSE_LU && kkt_banded_available(h->S);
     h->cf_reduce = !cfg && want != CIMPC_KKT_DENSE_LU && h->cf_tiny && kkt_cf_reduce_available(h->S);
+    h->use_mixed = want == CIMPC_KKT_CONDENSED_MIXED && !h->use_dense && kkt_mixed_available(h->S);
+}
+
+int ensure_mixed_ws(cimpc_ctx* h) {
+    if (!h->use_mixed || h->d_mix_ws) return CIMPC_OK;
+    if (dev_alloc(h, &h->d_mix_ws, kkt_mixed_workspace_doubles(h->S)) != CIMPC_OK) return CIMPC_ERR_HIP;
+    return dev_alloc(h, &h->d_mix_nfb, 1);
 }
 
 // KKT stage of the Newton loop for everything that is not the plain condensed solve
 static int launch_kkt_general(cimpc_ctx* h, const NewtonDev& Sk, hipStream_t st) {
+    if (h->use_mixed) return launch_kkt_mixed_newton(Sk, h->d_mix_ws, h->d_mix_nfb, st);
     if (h->cf_reduce) return launch_kkt_cf_reduced_newton(Sk, h->d_cf_ws, h->d_dense_ws, st);
     return launch_kkt_dense_newton(Sk, h->d_dense_ws, st, h->use_banded);
 }
@@ -406,7 +417,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     if (ip_kernel_info(&h->dm, &h->ki) != CIMPC_OK) {
         delete h;
         return fail(nullptr, CIMPC_ERR_INVALID,
-                    "no kernel instantiation for these model dimensions (pushbot, hopper_2D, "
+                    "no kernel instantiation for these model dimensions (built: pushbot, hopper_2D, hopper_3D, walledcartpole, particle, particle_2D, "
                     "quadruped, flamingo, centroidal_quadruped are built)");
     }
     h->nx = d.nq;
@@ -849,7 +860,11 @@ int cimpc_kkt_solve(cimpc_handle h, const double* r, double beta, double* delta)
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpyAsync(h->d_rhs, r, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     prof_begin(h, PC_KKT);
-    if (h->use_dense) {
+    if (h->use_mixed) {
+        rc = ensure_mixed_ws(h);
+        if (rc != CIMPC_OK) return rc;
+        rc = launch_kkt_mixed_raw(h->S, h->d_rhs, beta, h->S.delta, h->d_mix_ws, h->d_mix_nfb, h->stream);
+    } else if (h->use_dense) {
         rc = ensure_dense_ws(h);
         if (rc != CIMPC_OK) return rc;
         rc = h->cf_reduce ? launch_kkt_cf_reduced_raw(h->S, h->d_rhs, beta, h->S.delta, h->d_cf_ws, h->d_dense_ws, h->stream)
@@ -972,8 +987,9 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         return CIMPC_OK;
     };
     if (h->use_dense) { rc = ensure_dense_ws(h); if (rc != CIMPC_OK) return rc; }
-    const bool full_async = h->async_on && !h->use_dense && (h->async_mode == 1 || (h->async_mode == 2 && h->dm.B >= 4 && h->dm.B <= 128));
-    const bool hybrid = h->async_on && !h->use_dense && h->async_mode == 2 && !full_async && h->dm.B > 128;
+    if (h->use_mixed) { rc = ensure_mixed_ws(h); if (rc != CIMPC_OK) return rc; }
+    const bool full_async = h->async_on && !h->use_dense && !h->use_mixed && (h->async_mode == 1 || (h->async_mode == 2 && h->dm.B >= 4 && h->dm.B <= 128));
+    const bool hybrid = h->async_on && !h->use_dense && !h->use_mixed && h->async_mode == 2 && !full_async && h->dm.B > 128;
     if (full_async) return run_async(true, 0);
     // safety net only: every Newton iteration needs at most 3 (speculative) rounds, each evaluation at
     // most ceil(max_iter / iter_cap) launches of the resumable interior-point sweep
@@ -1007,7 +1023,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             Sk.kkt_same_round = 1;
             prof_begin(h, PC_KKT, sb.st);
             // (same compact list / packed or pipelined kernel as the overlapped path)
-            int rr = h->use_dense ? launch_kkt_general(h, Sk, sb.st) : launch_kkt_packed(Sk, last_kkt, Sk.WQ.par ^ 1, sb.st);
+            int rr = (h->use_dense || h->use_mixed) ? launch_kkt_general(h, Sk, sb.st) : launch_kkt_packed(Sk, last_kkt, Sk.WQ.par ^ 1, sb.st);
             prof_end(h, sb.st);
             if (rr != CIMPC_OK) return fail(h, rr, "kkt launch failed");
         }
@@ -1020,7 +1036,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             prof_begin(h, PC_KKT, sb.st_kkt);
             const bool packed = h->kn.kkt_packed;
             // the list was built by the residual kernel of the previous round (its queue parity)
-            int rk = h->use_dense ? launch_kkt_general(h, Sk, sb.st_kkt)
+            int rk = (h->use_dense || h->use_mixed) ? launch_kkt_general(h, Sk, sb.st_kkt)
                                   : packed ? launch_kkt_packed(Sk, last_kkt, Sk.WQ.par ^ 1, sb.st_kkt, depth > 1 ? Sk.counters_next + 1 : nullptr)
                                            : launch_kkt(Sk, sb.st_kkt);
             prof_end(h, sb.st_kkt);
@@ -1239,6 +1255,18 @@ int cimpc_get_reference(cimpc_handle h, double* q_ref, double* u_ref, double* w_
         HIP_TRY(h, hipMemcpy(window, h->d_window, B * (H + 2) * sizeof(int), hipMemcpyDeviceToHost));
         for (size_t k = 0; k < B * (H + 2); ++k) window[k] += 1;     // 1-based at the boundary
     }
+    return CIMPC_OK;
+}
+
+int cimpc_get_kkt_fallbacks(cimpc_handle h, long long* n) {
+    if (!h || !n) return CIMPC_ERR_INVALID;
+    *n = 0;
+    if (!h->d_mix_nfb) return CIMPC_OK;
+    int v = 0;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(&v, h->d_mix_nfb, sizeof(int), hipMemcpyDeviceToHost));
+    *n = v;
     return CIMPC_OK;
 }
 

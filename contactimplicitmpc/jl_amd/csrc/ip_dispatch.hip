@@ -1,5 +1,7 @@
-// Dimension dispatch of the interior-point sweep kernel (one instantiation per model the
-// reference ships dimensions for; SURVEY.md section 2 "Problem dimensions").
+// Dimension dispatch of the interior-point sweep kernel: one instantiation per model of the reference
+// (src/dynamics/*/model.jl; point_foot_quadruped and centroidal_quadruped_box share the centroidal dimensions).
+// A further model is ONE line here + a five-line ip_model_<name>.hip + its (nq, nu) pair in newton_kernels.hip
+// (CIMPC_NQNU).  Not covered: centroidal_quadruped_wall (ny = 48 exceeds the 32-lane group).
 #include "newton_state.h"
 
 namespace cimpc {
@@ -9,7 +11,11 @@ namespace cimpc {
     X(hopper, 4, 2, 2, 1, 2)                 \
     X(quadruped, 11, 8, 2, 4, 8)             \
     X(flamingo, 9, 6, 2, 4, 8)               \
-    X(centroidal, 18, 12, 3, 4, 16)
+    X(centroidal, 18, 12, 3, 4, 16)          \
+    X(hopper3d, 7, 3, 3, 1, 4)               \
+    X(walledcartpole, 4, 1, 4, 2, 4)         \
+    X(particle, 3, 3, 3, 1, 4)               \
+    X(particle2d, 2, 2, 2, 1, 2)
 
 #define X(name, q, u, w, c, b)                                                               \
     int ip_launch_##name(int mode, const IpParams& p, int waves, hipStream_t s);   \

@@ -534,6 +534,7 @@ struct KktArgs {
     const int* stage;    // only rollouts with stage == STAGE_KKT (null = all)
     int finish;          // 1: set alpha/ls_iter/cand/stage after the solve (newton loop)
     const double* dz_override;   // [B][H][nths][nd] sensitivities to use instead of S.dz_good / S.dz (cf-mode reduction)
+    const int* only_flag;        // [B] or null: run only the rollouts whose flag is non-zero (mixed-precision refinement / fallback)
 };
 // sensitivities a KKT solve reads: the accepted evaluation's (Newton loop), slot 0 of the last implicit_dynamics! (B1
 // seam, no stage array), or an explicit buffer
@@ -934,21 +935,32 @@ constexpr int KKT_MFMA_TILES = 22;
 
 // Tiles are TLD x TLD column-major (TLD = 16, or 24 for the larger models); a product C (+)= X * Y^T runs as
 // NB x NB sub-blocks of the 16x16x4 MFMA (NB = ceil(TLD / 16)), rows / columns beyond TLD masked to zero.
-template <int NB>
+// F32 = true: the SAME block products on v_mfma_f32_16x16x4_f32 (BASELINE configs[4]: "fp32 mixed-precision Schur GEMM on
+// MFMA"): operands are rounded to fp32 when they leave the fp64 LDS tiles, the accumulator is fp32, results are widened
+// when stored back; Cholesky, triangular inverses, substitutions and the right-hand side stay fp64.  The fp32 MFMA keeps
+// four CONSECUTIVE rows of D per lane (D[4 (l>>4) + reg][l & 15]) where the fp64 one interleaves them
+// (D[(l>>4) + 4 reg][l & 15]): only the column map of ld / st / add_diag differs.  The caller refines in fp64
+// (newton_kernels.hip: launch_kkt_mixed).
+using f4 = __attribute__((ext_vector_type(4))) float;
+template <int NB, bool F32 = false>
 struct TAcc {
-    d4 v[NB][NB];
+    std::conditional_t<F32, f4, d4> v[NB][NB];
 };
-template <int NB>
-__device__ __forceinline__ TAcc<NB> tile_zero() {
-    TAcc<NB> z;
+template <bool F32>
+__device__ __forceinline__ constexpr int tile_col(int J, int lk, int r) { return 16 * J + (F32 ? 4 * lk + r : lk + 4 * r); }
+template <int NB, bool F32 = false>
+__device__ __forceinline__ TAcc<NB, F32> tile_zero() {
+    TAcc<NB, F32> z;
 #pragma unroll
     for (int I = 0; I < NB; ++I)
 #pragma unroll
-        for (int J = 0; J < NB; ++J) z.v[I][J] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int J = 0; J < NB; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z.v[I][J][r] = 0;
     return z;
 }
-template <int KB, bool NEG, int TLD>
-__device__ __forceinline__ TAcc<(TLD + 15) / 16> tile_mma(const double* X, const double* Y, TAcc<(TLD + 15) / 16> acc, int li, int lk) {
+template <int KB, bool NEG, int TLD, bool F32 = false>
+__device__ __forceinline__ TAcc<(TLD + 15) / 16, F32> tile_mma(const double* X, const double* Y, TAcc<(TLD + 15) / 16, F32> acc, int li, int lk) {
     constexpr int NB = (TLD + 15) / 16;
     constexpr bool MASK = (TLD % 16) != 0;
 #pragma unroll
@@ -965,29 +977,31 @@ __device__ __forceinline__ TAcc<(TLD + 15) / 16> tile_mma(const double* X, const
 #pragma unroll
         for (int I = 0; I < NB; ++I)
 #pragma unroll
-            for (int J = 0; J < NB; ++J)
-                acc.v[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[J], xa[I], acc.v[I][J], 0, 0, 0);
+            for (int J = 0; J < NB; ++J) {
+                if constexpr (F32) acc.v[I][J] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)ya[J], (float)xa[I], acc.v[I][J], 0, 0, 0);
+                else acc.v[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[J], xa[I], acc.v[I][J], 0, 0, 0);
+            }
     }
     return acc;
 }
-template <int TLD>
-__device__ __forceinline__ TAcc<(TLD + 15) / 16> tile_ld(const double* C, int li, int lk) {
+template <int TLD, bool F32 = false>
+__device__ __forceinline__ TAcc<(TLD + 15) / 16, F32> tile_ld(const double* C, int li, int lk) {
     constexpr int NB = (TLD + 15) / 16;
     constexpr bool MASK = (TLD % 16) != 0;
-    TAcc<NB> a;
+    TAcc<NB, F32> a;
 #pragma unroll
     for (int I = 0; I < NB; ++I)
 #pragma unroll
         for (int J = 0; J < NB; ++J)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 16 * I + li, col = 16 * J + lk + 4 * r;
+                const int row = 16 * I + li, col = tile_col<F32>(J, lk, r);
                 a.v[I][J][r] = (!MASK || (row < TLD && col < TLD)) ? C[row + col * TLD] : 0.0;
             }
     return a;
 }
-template <int TLD>
-__device__ __forceinline__ void tile_st(double* C, const TAcc<(TLD + 15) / 16>& a, int li, int lk) {
+template <int TLD, bool F32 = false>
+__device__ __forceinline__ void tile_st(double* C, const TAcc<(TLD + 15) / 16, F32>& a, int li, int lk) {
     constexpr int NB = (TLD + 15) / 16;
     constexpr bool MASK = (TLD % 16) != 0;
 #pragma unroll
@@ -996,12 +1010,12 @@ __device__ __forceinline__ void tile_st(double* C, const TAcc<(TLD + 15) / 16>& 
         for (int J = 0; J < NB; ++J)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 16 * I + li, col = 16 * J + lk + 4 * r;
-                if (!MASK || (row < TLD && col < TLD)) C[row + col * TLD] = a.v[I][J][r];
+                const int row = 16 * I + li, col = tile_col<F32>(J, lk, r);
+                if (!MASK || (row < TLD && col < TLD)) C[row + col * TLD] = (double)a.v[I][J][r];
             }
 }
-template <int NB>
-__device__ __forceinline__ TAcc<NB> tile_neg(TAcc<NB> a) {
+template <int NB, bool F32 = false>
+__device__ __forceinline__ TAcc<NB, F32> tile_neg(TAcc<NB, F32> a) {
 #pragma unroll
     for (int I = 0; I < NB; ++I)
 #pragma unroll
@@ -1009,13 +1023,13 @@ __device__ __forceinline__ TAcc<NB> tile_neg(TAcc<NB> a) {
     return a;
 }
 // adds rho to the diagonal entries (row == col < n) this lane holds
-template <int NB>
-__device__ __forceinline__ void tile_add_diag(TAcc<NB>& a, double rho, int n, int li, int lk) {
+template <int NB, bool F32 = false>
+__device__ __forceinline__ void tile_add_diag(TAcc<NB, F32>& a, double rho, int n, int li, int lk) {
 #pragma unroll
     for (int I = 0; I < NB; ++I)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = 16 * I + li, col = 16 * I + lk + 4 * r;
+            const int row = 16 * I + li, col = tile_col<F32>(I, lk, r);
             if (row == col && row < n) a.v[I][I][r] += rho;
         }
 }
@@ -1075,14 +1089,14 @@ constexpr int kkt_max_h() {
 template <int NQ, int NU>
 constexpr int kkt_pack();
 
-template <int NQ, int NU, class Sync, int PIPE = 1>
+template <int NQ, int NU, class Sync, int PIPE = 1, bool F32 = false>
 __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, int b, double* sm, int lane, int wave = 0) {
     static_assert(NQ <= 24 && NU <= 24, "MFMA KKT kernel: tiles of at most 24 x 24");
     constexpr int TL = kkt_tld<NQ, NU>();            // (shadow the 16-wide defaults of the file scope)
     constexpr int TSZ = TL * TL;
     constexpr int NB = (TL + 15) / 16;
     constexpr int VS = TL <= 16 ? 16 : 32;           // stride of the small vectors behind the tiles
-    using Acc = TAcc<NB>;
+    using Acc = TAcc<NB, F32>;
     constexpr int NTILES = PIPE == 2 ? KKT_PIPE_TILES : KKT_MFMA_TILES;
     // The body runs on ONE wavefront; its phases hand data over through LDS only.  The hand-off needs the
     // wave's LDS operations complete (lgkmcnt(0)) - NOT its global ones: a full barrier (vmcnt(0)) would
@@ -1209,7 +1223,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         t.p0 = p0; t.m0 = m0;
         return t;
     };
-    const Acc z4 = tile_zero<NB>();
+    const Acc z4 = tile_zero<NB, F32>();
     Acc y0 = z4, y1a = z4;                 // PIPE = 1: Y_ii / Y_i,i-1 accumulators stay in registers between the stages
     // ---- stage A of step i: needs factors of steps <= i-2 only --------------------------------------------
     auto stageA = [&](int i) {
@@ -1226,24 +1240,24 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         prefetch(i + 1);
         KPROF(1)
         // ---- P2: T0 = du1 Rinv, T1 = dq1 Qinv_{i-1}, T2 = dq0 Qinv_{i-2}  (Qinv, Rinv symmetric)
-        tile_st<TL>(T0, tile_mma<KBU, false, TL>(A0, Ri, z4, li, lk), li, lk);
-        if (i >= 1) tile_st<TL>(T1, tile_mma<KBQ, false, TL>(A1, Qi1, z4, li, lk), li, lk);
-        if (i >= 2) tile_st<TL>(T2, tile_mma<KBQ, false, TL>(A2, Qi2, z4, li, lk), li, lk);
+        tile_st<TL, F32>(T0, tile_mma<KBU, false, TL, F32>(A0, Ri, z4, li, lk), li, lk);
+        if (i >= 1) tile_st<TL, F32>(T1, tile_mma<KBQ, false, TL, F32>(A1, Qi1, z4, li, lk), li, lk);
+        if (i >= 2) tile_st<TL, F32>(T2, tile_mma<KBQ, false, TL, F32>(A2, Qi2, z4, li, lk), li, lk);
         lds_sync();
         KPROF(2)
         // ---- P3: Y_ii, Y_i,i-1, L2_i = -T2 L0_{i-2}^-T, beta_i -------------------------------
-        y0 = tile_ld<TL>(Qi0, li, lk);
-        tile_add_diag<NB>(y0, rho, nd, li, lk);
-        y0 = tile_mma<KBU, false, TL>(T0, A0, y0, li, lk);
+        y0 = tile_ld<TL, F32>(Qi0, li, lk);
+        tile_add_diag<NB, F32>(y0, rho, nd, li, lk);
+        y0 = tile_mma<KBU, false, TL, F32>(T0, A0, y0, li, lk);
         y1a = z4;
         if (i >= 1) {
-            y0 = tile_mma<KBQ, false, TL>(T1, A1, y0, li, lk);
-            y1a = tile_neg<NB>(tile_ld<TL>(T1, li, lk));
+            y0 = tile_mma<KBQ, false, TL, F32>(T1, A1, y0, li, lk);
+            y1a = tile_neg<NB, F32>(tile_ld<TL, F32>(T1, li, lk));
         }
         if (i >= 2) {
-            y0 = tile_mma<KBQ, false, TL>(T2, A2, y0, li, lk);
-            y1a = tile_mma<KBQ, false, TL>(T2, A1p, y1a, li, lk);
-            tile_st<TL>(L2c, tile_mma<KBD, true, TL>(T2, Li2, z4, li, lk), li, lk);
+            y0 = tile_mma<KBQ, false, TL, F32>(T2, A2, y0, li, lk);
+            y1a = tile_mma<KBQ, false, TL, F32>(T2, A1p, y1a, li, lk);
+            tile_st<TL, F32>(L2c, tile_mma<KBD, true, TL, F32>(T2, Li2, z4, li, lk), li, lk);
         }
         if (lane < nd) {   // beta_i = T0 rpu - Qinv_i rq_i + T1 rq_{i-1} + T2 rq_{i-2} - rd_i
             double s = tile_mv<nu, false, TL>(T0, rpu, lane) - tile_mv<nq, false, TL>(Qi0, q0r, lane);
@@ -1251,7 +1265,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
             if (i >= 2) s += tile_mv<nq, false, TL>(T2, q2r, lane);
             bet[lane] = s - rd_i;
         }
-        if constexpr (PIPE == 2) { tile_st<TL>(t.Y0h, y0, li, lk); tile_st<TL>(t.Y1h, y1a, li, lk); }
+        if constexpr (PIPE == 2) { tile_st<TL, F32>(t.Y0h, y0, li, lk); tile_st<TL, F32>(t.Y1h, y1a, li, lk); }
     };
     // ---- stage B of step i: L1_i, the Cholesky factor L0_i and its inverse, y_i, spill --------------------
     auto stageB = [&](int i) {
@@ -1259,21 +1273,21 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         double* const Li = t.Li; double* const Li1 = t.Li1; double* const L1c = t.L1c; double* const L1p = t.L1p;
         double* const yc = t.yc; double* const y1 = t.y1; double* const y2 = t.y2;
         double* const L2c = t.L2c; double* const bet = t.bet;
-        if constexpr (PIPE == 2) { y0 = tile_ld<TL>(t.Y0h, li, lk); y1a = tile_ld<TL>(t.Y1h, li, lk); }
+        if constexpr (PIPE == 2) { y0 = tile_ld<TL, F32>(t.Y0h, li, lk); y1a = tile_ld<TL, F32>(t.Y1h, li, lk); }
         // ---- P4: Y1 -= L2 L1_{i-1}^T ; stage Y1 as an operand ------------------------------
         if (i >= 1) {
-            if (i >= 2) y1a = tile_mma<KBD, true, TL>(L2c, L1p, y1a, li, lk);
-            tile_st<TL>(Y1, y1a, li, lk);
+            if (i >= 2) y1a = tile_mma<KBD, true, TL, F32>(L2c, L1p, y1a, li, lk);
+            tile_st<TL, F32>(Y1, y1a, li, lk);
             lds_sync();
             // ---- P5: L1_i = Y1 L0_{i-1}^-T -----------------------------------------------------
-            tile_st<TL>(L1c, tile_mma<KBD, false, TL>(Y1, Li1, z4, li, lk), li, lk);
+            tile_st<TL, F32>(L1c, tile_mma<KBD, false, TL, F32>(Y1, Li1, z4, li, lk), li, lk);
             lds_sync();
         }
         KPROF(4)
         // ---- P6: Lc = Y0 - L1 L1^T - L2 L2^T ; rhs of the forward substitution ---------------
-        if (i >= 1) y0 = tile_mma<KBD, true, TL>(L1c, L1c, y0, li, lk);
-        if (i >= 2) y0 = tile_mma<KBD, true, TL>(L2c, L2c, y0, li, lk);
-        tile_st<TL>(Lc, y0, li, lk);
+        if (i >= 1) y0 = tile_mma<KBD, true, TL, F32>(L1c, L1c, y0, li, lk);
+        if (i >= 2) y0 = tile_mma<KBD, true, TL, F32>(L2c, L2c, y0, li, lk);
+        tile_st<TL, F32>(Lc, y0, li, lk);
         if (lane < nd) {
             double s = bet[lane];
             if (i >= 1) s -= tile_mv<nd, false, TL>(L1c, y1, lane);
@@ -1514,12 +1528,13 @@ __global__ __launch_bounds__(128, (kkt_tld<NQ, NU>() <= 16 ? 2 : 1)) void kkt_ke
 }
 
 // (wide tiles: 105 KB of LDS allow one workgroup per CU anyway - let it use the 512-register budget)
-template <int NQ, int NU>
+template <int NQ, int NU, bool F32 = false>
 __global__ __launch_bounds__(64, (kkt_tld<NQ, NU>() <= 16 ? 2 : 1)) void kkt_kernel(NewtonDev S, KktArgs K) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int b = blockIdx.x + S.b0;
     if (K.stage != nullptr && K.stage[b] != STAGE_KKT) return;
-    kkt_body<NQ, NU, BlockSync>(S, K, b, sm, (int)threadIdx.x);
+    if (K.only_flag != nullptr && K.only_flag[b] == 0) return;
+    kkt_body<NQ, NU, BlockSync, 1, F32>(S, K, b, sm, (int)threadIdx.x);
 }
 
 }  // namespace cimpc

@@ -72,14 +72,21 @@ __global__ __launch_bounds__(256) void reset_kernel(NewtonDev S, const double* q
 }
 
 template <int NQ, int NU>
-static int launch_kkt_t(const NewtonDev& S, const KktArgs& K, hipStream_t s) {
+static int launch_kkt_t(const NewtonDev& S, const KktArgs& K, hipStream_t s, bool f32 = false) {
     static const bool force_scalar = getenv("CIMPC_KKT_SCALAR") && atoi(getenv("CIMPC_KKT_SCALAR")) != 0;
     if (NQ <= 24 && NU <= 24 && S.dm.H <= kkt_max_h<NQ, NU>() && !force_scalar) {   // dnu / recovery staging bounds H
         const size_t lds = (size_t)kkt_lds_doubles<NQ, NU, 1>() * sizeof(double);
+        if (f32) {      // block products on the fp32 MFMA (launch_kkt_mixed refines the result in fp64)
+            static LdsOptIn optin32;
+            if (lds_opt_in(optin32, (const void*)kkt_kernel<NQ, NU, true>, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
+            hipLaunchKernelGGL((kkt_kernel<NQ, NU, true>), dim3(S.nb_launch), dim3(64), lds, s, S, K);
+            return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+        }
         static LdsOptIn optin;
         if (lds_opt_in(optin, (const void*)kkt_kernel<NQ, NU>, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
         hipLaunchKernelGGL((kkt_kernel<NQ, NU>), dim3(S.nb_launch), dim3(64), lds, s, S, K);
     } else {
+        if (f32) return CIMPC_ERR_INVALID;
         constexpr int LD = ((NQ > NU ? NQ : NU) + 3) & ~3;
         const size_t lds = (size_t)(KKT_TILES * LD * LD + 10 * LD) * sizeof(double);
         static LdsOptIn optin;
@@ -89,15 +96,148 @@ static int launch_kkt_t(const NewtonDev& S, const KktArgs& K, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
 
-static int launch_kkt_any(const NewtonDev& S, const KktArgs& K, hipStream_t s) {
+// (nq, nu) pairs of the built models (the horizon-level kernels depend on these two sizes only): pushbot / particle_2D,
+// hopper_2D, quadruped, flamingo, centroidal_quadruped (= point_foot_quadruped, centroidal_quadruped_box), hopper_3D,
+// walledcartpole, particle
+#define CIMPC_NQNU(X) X(2, 2) X(4, 2) X(11, 8) X(9, 6) X(18, 12) X(7, 3) X(4, 1) X(3, 3)
+
+static int launch_kkt_any(const NewtonDev& S, const KktArgs& K, hipStream_t s, bool f32 = false) {
     if (S.dm.mode != CIMPC_MODE_CONFIGURATION) return CIMPC_ERR_INVALID;
     const int nq = S.dm.nq, nu = S.dm.nu;
-    if (nq == 2 && nu == 2) return launch_kkt_t<2, 2>(S, K, s);       // pushbot
-    if (nq == 4 && nu == 2) return launch_kkt_t<4, 2>(S, K, s);       // hopper_2D
-    if (nq == 11 && nu == 8) return launch_kkt_t<11, 8>(S, K, s);     // quadruped
-    if (nq == 9 && nu == 6) return launch_kkt_t<9, 6>(S, K, s);       // flamingo
-    if (nq == 18 && nu == 12) return launch_kkt_t<18, 12>(S, K, s);   // centroidal_quadruped
+#define X(q, u) if (nq == q && nu == u) return launch_kkt_t<q, u>(S, K, s, f32);
+    CIMPC_NQNU(X)
+#undef X
     return CIMPC_ERR_INVALID;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Mixed-precision condensed KKT solve (BASELINE configs[4]: "fp32 mixed-precision Schur GEMM on MFMA" + fp64 refinement).
+//   P0:  D   = solve32(r)                       block products of the recursion on v_mfma_f32_16x16x4_f32 (kkt_body<.., F32>)
+//   Ck:  res = r - R D  in fp64, matrix-free    R = [P C^T; C -rho I] applied from the objective blocks and the accepted
+//                                               sensitivities (the same data the solve condenses - newton_jacobian.jl:148-198)
+//        |res|_inf <= tol max(1, |r|_inf) ?  done (Newton loop: the line search starts) : stays flagged
+//   Pk:  D  += solve32(res)                     at most two corrections
+//   F:   D   = solve64(r)                       fp64 fallback for whatever is still flagged (ill-conditioned Schur blocks,
+//                                               a non-positive fp32 pivot -> NaN -> fails the check: test/solver/schur.jl:19-62)
+// Every kernel covers all rollouts and leaves at once where it has nothing to do (flag array), so the host enqueues the
+// whole sequence without reading anything back.
+// ---------------------------------------------------------------------------------------------------------------------
+// (R x)[e] for rollout data at dzb / x; :configuration mode, TrackingObjective (dense Q_i, R_i allowed)
+__device__ __forceinline__ double kkt_apply_row(const NewtonDev& S, const double* dzb, const double* x, double rho, int e) {
+    const int H = S.dm.H, nq = S.dm.nq, nu = S.dm.nu, nr = nq + nu, nd = nq, blk = (2 * nq + nu) * nd;
+    const double* nuv = x + (size_t)H * nr;
+    if (e >= H * nr) {                                   // dual row (i, k):  C x - rho nu
+        const int i = (e - H * nr) / nd, k = (e - H * nr) - i * nd;
+        const double* dz = dzb + (size_t)i * blk;
+        double s = -x[(size_t)i * nr + nu + k] - rho * nuv[(size_t)i * nd + k];
+        for (int c = 0; c < nu; ++c) s = fma(dz[(size_t)(2 * nq + c) * nd + k], x[(size_t)i * nr + c], s);
+        if (i >= 1) for (int c = 0; c < nq; ++c) s = fma(dz[(size_t)(nq + c) * nd + k], x[(size_t)(i - 1) * nr + nu + c], s);
+        if (i >= 2) for (int c = 0; c < nq; ++c) s = fma(dz[(size_t)c * nd + k], x[(size_t)(i - 2) * nr + nu + c], s);
+        return s;
+    }
+    const int i = e / nr, c = e - i * nr;
+    double s = 0.0;
+    if (c < nu) {                                        // u row: R_i u + du1_i^T nu_i
+        const double* Rm = S.R + (size_t)i * nu * nu;
+        for (int k = 0; k < nu; ++k) s = fma(Rm[c + k * nu], x[(size_t)i * nr + k], s);
+        const double* A0 = dzb + (size_t)i * blk + (size_t)(2 * nq + c) * nd;
+        for (int k = 0; k < nd; ++k) s = fma(A0[k], nuv[(size_t)i * nd + k], s);
+        return s;
+    }
+    const int cq = c - nu;                               // q row: Q_i q - nu_i + dq1_{i+1}^T nu_{i+1} + dq0_{i+2}^T nu_{i+2}
+    const double* Qm = S.Q + (size_t)i * nq * nq;
+    for (int k = 0; k < nq; ++k) s = fma(Qm[cq + k * nq], x[(size_t)i * nr + nu + k], s);
+    s -= nuv[(size_t)i * nd + cq];
+    if (i + 1 < H) {
+        const double* A1 = dzb + (size_t)(i + 1) * blk + (size_t)(nq + cq) * nd;
+        for (int k = 0; k < nd; ++k) s = fma(A1[k], nuv[(size_t)(i + 1) * nd + k], s);
+    }
+    if (i + 2 < H) {
+        const double* A2 = dzb + (size_t)(i + 2) * blk + (size_t)cq * nd;
+        for (int k = 0; k < nd; ++k) s = fma(A2[k], nuv[(size_t)(i + 2) * nd + k], s);
+    }
+    return s;
+}
+struct MixArgs {
+    int* flag;          // [B] 1 = still to be solved
+    double* corr;       // [B][N] correction of the running pass (null in the first check)
+    double* res;        // [B][N] residual out
+    double tol;
+    int last;           // 1: a rollout that fails this check keeps its flag for the fp64 fallback (else for another correction)
+    int* n_fallback;    // device counter: rollouts handed to the fp64 solve (statistics)
+};
+__global__ __launch_bounds__(256) void kkt_mixed_init_kernel(NewtonDev S, KktArgs K, int* flag) {
+    const int b = blockIdx.x * 256 + threadIdx.x + S.b0;
+    if (b < S.b0 + S.nb_launch) flag[b] = (K.stage == nullptr || K.stage[b] == STAGE_KKT) ? 1 : 0;
+}
+// D += corr ; res = r - R D ; verdict.  One workgroup per rollout.
+__global__ __launch_bounds__(256) void kkt_mixed_check_kernel(NewtonDev S, KktArgs K, MixArgs M) {
+    const int b = blockIdx.x + S.b0, tid = threadIdx.x, nt = blockDim.x;
+    if (M.flag[b] == 0) return;
+    __shared__ double red[2 * 256];
+    const int N = S.N, H = S.dm.H;
+    double* D = K.delta + (size_t)b * N;
+    const double* r = K.r + (size_t)b * N;
+    if (M.corr != nullptr) {
+        const double* c = M.corr + (size_t)b * N;
+        for (int e = tid; e < N; e += nt) D[e] += c[e];
+        __syncthreads();
+    }
+    const double beta = K.beta ? K.beta[b] : K.beta_scalar;
+    const double rho = (double)H * beta * S.kappa;
+    const double* dzb = kkt_dz(S, K, b, H, S.nths, S.nd);
+    double* res = M.res + (size_t)b * N;
+    double mr = 0.0, mres = 0.0;
+    for (int e = tid; e < N; e += nt) {
+        const double v = r[e] - kkt_apply_row(S, dzb, D, rho, e);
+        res[e] = v;
+        mr = fmax(mr, fabs(r[e]));
+        mres = (v == v) ? fmax(mres, fabs(v)) : HUGE_VAL;       // NaN (failed fp32 pivot) never passes
+    }
+    red[tid] = mr; red[256 + tid] = mres;
+    __syncthreads();
+    for (int st = nt / 2; st > 0; st >>= 1) {
+        if (tid < st) { red[tid] = fmax(red[tid], red[tid + st]); red[256 + tid] = fmax(red[256 + tid], red[256 + tid + st]); }
+        __syncthreads();
+    }
+    const bool ok = red[256] <= M.tol * fmax(1.0, red[0]);
+    __syncthreads();
+    if (ok) {
+        if (tid == 0) M.flag[b] = 0;
+        if (K.finish) {
+            __threadfence_block();
+            start_line_search<BlockSync>(S, b, 1, tid, nt);
+        }
+    } else if (M.last && tid == 0 && M.n_fallback != nullptr) {
+        atomicAdd(M.n_fallback, 1);
+    }
+}
+size_t kkt_mixed_workspace_doubles(const NewtonDev& S) { return 2 * (size_t)S.dm.B * S.N + (size_t)S.dm.B; }
+bool kkt_mixed_available(const NewtonDev& S) {
+    return S.dm.mode == CIMPC_MODE_CONFIGURATION && S.V == nullptr && S.dm.nq <= 24 && S.dm.nu <= 24 && S.dm.H <= 96;
+}
+int launch_kkt_mixed(const NewtonDev& S, const KktArgs& K0, double* ws, int* n_fallback, hipStream_t s) {
+    if (!kkt_mixed_available(S)) return CIMPC_ERR_INVALID;
+    const size_t BN = (size_t)S.dm.B * S.N;
+    double* corr = ws; double* res = ws + BN;
+    int* flag = reinterpret_cast<int*>(ws + 2 * BN);
+    hipLaunchKernelGGL(kkt_mixed_init_kernel, dim3((S.nb_launch + 255) / 256), dim3(256), 0, s, S, K0, flag);
+    KktArgs P = K0; P.finish = 0; P.only_flag = flag;
+    int rc = launch_kkt_any(S, P, s, true);                                   // P0
+    if (rc != CIMPC_OK) return rc;
+    constexpr int CORRECTIONS = 2;
+    for (int k = 0; k <= CORRECTIONS; ++k) {
+        MixArgs M{flag, k == 0 ? nullptr : corr, res, 1.0e-10, k == CORRECTIONS ? 1 : 0, n_fallback};
+        hipLaunchKernelGGL(kkt_mixed_check_kernel, dim3(S.nb_launch), dim3(256), 0, s, S, K0, M);       // Ck
+        if (k == CORRECTIONS) break;
+        KktArgs Pk = P; Pk.r = res; Pk.delta = corr;
+        rc = launch_kkt_any(S, Pk, s, true);                                  // P(k+1)
+        if (rc != CIMPC_OK) return rc;
+    }
+    KktArgs F = K0; F.only_flag = flag;                                        // fp64 fallback (keeps K0.finish)
+    rc = launch_kkt_any(S, F, s, false);
+    if (rc != CIMPC_OK) return rc;
+    return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
 
 __global__ __launch_bounds__(64) void enqueue_all_kernel(NewtonDev S) {
@@ -246,11 +386,9 @@ static int launch_resid_t(const NewtonDev& S, hipStream_t s) {
 }
 int launch_resid_decide(const NewtonDev& S, hipStream_t s) {
     const int nq = S.dm.nq, nu = S.dm.nu;
-    if (nq == 2 && nu == 2) return launch_resid_t<2, 2>(S, s);
-    if (nq == 4 && nu == 2) return launch_resid_t<4, 2>(S, s);
-    if (nq == 11 && nu == 8) return launch_resid_t<11, 8>(S, s);
-    if (nq == 9 && nu == 6) return launch_resid_t<9, 6>(S, s);
-    if (nq == 18 && nu == 12) return launch_resid_t<18, 12>(S, s);
+#define X(q, u) if (nq == q && nu == u) return launch_resid_t<q, u>(S, s);
+    CIMPC_NQNU(X)
+#undef X
     return CIMPC_ERR_INVALID;
 }
 template <int NQ, int NU>
@@ -285,11 +423,9 @@ int launch_kkt_packed(const NewtonDev& S, int n_kkt, int list_par, hipStream_t s
     if (S.kkt_list == nullptr || S.dm.mode != CIMPC_MODE_CONFIGURATION || nq > 24 || nu > 24 || S.dm.H > 96 || force_scalar) return launch_kkt(S, s);
     const KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 1};
     const int* list = S.kkt_list + (size_t)list_par * S.dm.B;
-    if (nq == 2 && nu == 2) return launch_kkt_packed_t<2, 2>(S, K, list, n_kkt, n_dev, s, latency);
-    if (nq == 4 && nu == 2) return launch_kkt_packed_t<4, 2>(S, K, list, n_kkt, n_dev, s, latency);
-    if (nq == 11 && nu == 8) return launch_kkt_packed_t<11, 8>(S, K, list, n_kkt, n_dev, s, latency);
-    if (nq == 9 && nu == 6) return launch_kkt_packed_t<9, 6>(S, K, list, n_kkt, n_dev, s, latency);
-    if (nq == 18 && nu == 12) return launch_kkt_packed_t<18, 12>(S, K, list, n_kkt, n_dev, s, latency);
+#define X(q, u) if (nq == q && nu == u) return launch_kkt_packed_t<q, u>(S, K, list, n_kkt, n_dev, s, latency);
+    CIMPC_NQNU(X)
+#undef X
     return launch_kkt(S, s);
 }
 // ---------------------------------------------------------------------------------------------------------
@@ -422,12 +558,23 @@ bool kkt_cf_reduce_available(const NewtonDev& S) {   // the reduced problem must
     const NewtonDev S2 = cf_shadow(S);
     if (S.V != nullptr) return kkt_banded_available(S2);
     const int nq = S.dm.nq, nu = S.dm.nu;
-    return (nq == 2 && nu == 2) || (nq == 4 && nu == 2) || (nq == 11 && nu == 8) || (nq == 9 && nu == 6) || (nq == 18 && nu == 12);
+#define X(q, u) if (nq == q && nu == u) return true;
+    CIMPC_NQNU(X)
+#undef X
+    return false;
 }
 
 int launch_kkt(const NewtonDev& S, hipStream_t s) {
     KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 1};
     return launch_kkt_any(S, K, s);
+}
+int launch_kkt_mixed_newton(const NewtonDev& S, double* ws, int* n_fallback, hipStream_t s) {
+    const KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 1};
+    return launch_kkt_mixed(S, K, ws, n_fallback, s);
+}
+int launch_kkt_mixed_raw(const NewtonDev& S, const double* r_dev, double beta, double* delta_dev, double* ws, int* n_fallback, hipStream_t s) {
+    const KktArgs K{r_dev, delta_dev, nullptr, beta, nullptr, 0};
+    return launch_kkt_mixed(S, K, ws, n_fallback, s);
 }
 int launch_kkt_raw(const NewtonDev& S, const double* r_dev, double beta, double* delta_dev,
                    hipStream_t s) {

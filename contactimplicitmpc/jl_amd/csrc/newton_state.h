@@ -97,6 +97,11 @@ int launch_reset(const NewtonDev& nd, const double* q0, const double* q1, int wa
 int launch_resid_decide(const NewtonDev& nd, hipStream_t s);
 int launch_enqueue_all(const NewtonDev& nd, hipStream_t s);   // B3 seam: queue slot 0 of every rollout
 int launch_kkt(const NewtonDev& nd, hipStream_t s);
+// mixed precision: block products on the fp32 MFMA, fp64 matrix-free refinement, fp64 fallback (newton_kernels.hip)
+bool kkt_mixed_available(const NewtonDev& nd);
+size_t kkt_mixed_workspace_doubles(const NewtonDev& nd);
+int launch_kkt_mixed_newton(const NewtonDev& nd, double* ws, int* n_fallback, hipStream_t s);
+int launch_kkt_mixed_raw(const NewtonDev& nd, const double* r_dev, double beta, double* delta_dev, double* ws, int* n_fallback, hipStream_t s);
 // packed variant: n_kkt rollouts from kkt_list[list_par], KKT_PACK per workgroup (dedicates whole CUs to the recursion)
 int launch_kkt_packed(const NewtonDev& nd, int n_kkt, int list_par, hipStream_t s, const int* n_dev = nullptr);
 // reference-default backend (dense jacobian! + LU with partial pivoting), any mode / objective (kkt_dense.hip)

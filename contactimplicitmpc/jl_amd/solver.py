@@ -44,7 +44,7 @@ class NewtonOptions:
     beta_init: float = 1.0e-5
     max_time: float = 0.0
     kappa: float = 2.0e-4
-    kkt_backend: int = 0      # 0 auto: condensed MFMA solve (TrackingObjective), banded LDL^T (velocity objective), dense LU (:configurationforce); 1 dense LU (reference default); 2 banded LDL^T (:configuration, any objective)
+    kkt_backend: int = 0      # 3 = the condensed solve in mixed precision (fp32-MFMA Schur products + fp64 refinement + fp64 fallback); 0 auto: condensed MFMA solve (TrackingObjective), banded LDL^T (velocity objective), dense LU (:configurationforce); 1 dense LU (reference default); 2 banded LDL^T (:configuration, any objective)
 
 
 def _dp(a):
@@ -260,6 +260,12 @@ class CIMPCSolver:
         self._check(self.lib.cimpc_get_rollout_counters(self.h, _ipt(sw), _ipt(it), _ipt(fl)),
                     "get_rollout_counters")
         return dict(sweeps=sw, ip_iters=it, ip_failures=fl)
+
+    def kkt_fallbacks(self):
+        """kkt_backend = 3 (mixed precision): KKT systems that went to the fp64 fallback since the handle was created."""
+        n = C.c_longlong()
+        self._check(self.lib.cimpc_get_kkt_fallbacks(self.h, C.byref(n)), "get_kkt_fallbacks")
+        return n.value
 
     def stats(self):
         s = _lib.Stats()

@@ -105,7 +105,12 @@ class Dims:
 PUSHBOT = dict(nq=2, nu=2, nw=2, nc=2, nb=4)        # pushbot/model.jl:126-130
 HOPPER_2D = dict(nq=4, nu=2, nw=2, nc=1, nb=2)      # hopper_2D/model.jl:100-104
 QUADRUPED = dict(nq=11, nu=8, nw=2, nc=4, nb=8)     # quadruped/model.jl:500-504
-CENTROIDAL = dict(nq=18, nu=12, nw=3, nc=4, nb=16)  # centroidal_quadruped/model.jl:187-190
+CENTROIDAL = dict(nq=18, nu=12, nw=3, nc=4, nb=16)  # centroidal_quadruped/model.jl:187-190 (= point_foot_quadruped, centroidal_quadruped_box)
+FLAMINGO = dict(nq=9, nu=6, nw=2, nc=4, nb=8)       # flamingo/model.jl
+HOPPER_3D = dict(nq=7, nu=3, nw=3, nc=1, nb=4)      # hopper_3D/model.jl:96-99
+WALLEDCARTPOLE = dict(nq=4, nu=1, nw=4, nc=2, nb=4)  # walledcartpole/model.jl:143-147
+PARTICLE = dict(nq=3, nu=3, nw=3, nc=1, nb=4)       # particle/model.jl:114-117
+PARTICLE_2D = dict(nq=2, nu=2, nw=2, nc=1, nb=2)    # particle_2D/model.jl
 
 
 @dataclass

@@ -43,6 +43,11 @@ extern "C" {
 #define CIMPC_KKT_BANDED_LDL 2 /* :configuration mode, any objective: the KKT matrix in the interleaved ordering
                                   [u_i, q_{i+2}, nu_i] (banded, quasi-definite) factored L D L^T without pivoting;
                                   the :ldl_solver analogue (ldl.jl:144-149) for block-tridiagonal P              */
+#define CIMPC_KKT_CONDENSED_MIXED 3 /* the condensed solve with its Schur-block products on the fp32 MFMA
+                                    * (v_mfma_f32_16x16x4_f32), refined in fp64 against the matrix-free KKT operator (at most two
+                                    * corrections, |r - R x|_inf <= 1e-10 max(1, |r|_inf)), fp64 solve for whatever does not get
+                                    * there (ill-conditioned Schur blocks).  :configuration mode + TrackingObjective; anything
+                                    * else falls back to the backend `0` would pick.  BASELINE configs[4]. */
 
 typedef struct cimpc_ctx* cimpc_handle;
 
@@ -185,6 +190,9 @@ int cimpc_get_trajectory(cimpc_handle h, double* q, double* u, double* gamma, do
                          double* nu_dual);
 int cimpc_get_newton_info(cimpc_handle h, int* newton_iters, double* r_norm, double* u1);
 int cimpc_get_stats(cimpc_handle h, cimpc_stats* s);
+/* CIMPC_KKT_CONDENSED_MIXED: KKT systems handed to the fp64 fallback since cimpc_create (0 = every system met the
+ * refinement tolerance in mixed precision). */
+int cimpc_get_kkt_fallbacks(cimpc_handle h, long long* n);
 /* per rollout, last newton solve: implicit_dynamics! evaluations, sum of IP iterations
  * ("solver iterations to tolerance"), failed IP solves.  Each B ints; any may be NULL. */
 int cimpc_get_rollout_counters(cimpc_handle h, int* sweeps, int* ip_iters, int* ip_failures);

@@ -23,6 +23,11 @@ pytestmark = pytest.mark.gpu
     ("pushbot", 1, 3, 5, 8),
     ("quadruped", 1, 3, 4, 8),
     ("centroidal", 0, 3, 4, 6),
+    ("flamingo", 1, 3, 5, 8),
+    ("hopper3d", 0, 4, 6, 8),            # the reference's remaining models (src/dynamics/*/model.jl): dimension sets without
+    ("walledcartpole", 1, 3, 5, 8),      # a single-launch kernel - lock-step rounds only
+    ("particle", 0, 3, 5, 8),
+    ("particle2d", 1, 3, 4, 6),
 ])
 def test_implicit_dynamics_matches_oracle(gpu_required, model, mode, B, H, H_ref):
     d, prob, tabs, rollouts = make_case(model, mode, H_ref=H_ref, H=H, B=B, seed=3)
@@ -84,6 +89,9 @@ def test_newton_solve_matches_oracle(gpu_required):
 @pytest.mark.parametrize("model,H,H_ref,dense_q", [
     ("hopper", 20, 24, False),       # BASELINE configs[1]: hopper flat, H = 20
     ("centroidal", 6, 8, True),      # nq = 18 > 16: 24 x 24 KKT tiles, dense Q (relative_state_cost)
+    ("hopper3d", 10, 12, False),     # (nq, nu) = (7, 3): hopper_3D
+    ("walledcartpole", 8, 10, False),    # (4, 1)
+    ("particle", 8, 10, True),       # (3, 3)
 ])
 def test_newton_solve_other_models(gpu_required, model, H, H_ref, dense_q):
     u1, it, rn, traj, cnt, res = _newton_case(perturb=5e-3, r_tol=1e-5, max_iter=4, seed=23, B=4, H=H, H_ref=H_ref,
