@@ -115,8 +115,10 @@ static int launch_kkt_any(const NewtonDev& S, const KktArgs& K, hipStream_t s, b
 //   P0:  D   = solve32(r)                       block products of the recursion on v_mfma_f32_16x16x4_f32 (kkt_body<.., F32>)
 //   Ck:  res = r - R D  in fp64, matrix-free    R = [P C^T; C -rho I] applied from the objective blocks and the accepted
 //                                               sensitivities (the same data the solve condenses - newton_jacobian.jl:148-198)
-//        |res|_inf <= tol max(1, |r|_inf) ?  done (Newton loop: the line search starts) : stays flagged
-//   Pk:  D  += solve32(res)                     at most two corrections
+//        |res|_inf <= 1e-9 max(1, |r|_inf) ?  done (Newton loop: the line search starts) : stays flagged
+//   Pk:  D  += solve32(res)                     at most four corrections (contraction ~ cond(Y) 2^-24 per pass: dual Schur
+//                                               complements up to cond ~ 1e5 reach 1e-9; the cold start's beta = 1e-5 - rho = 1e-7,
+//                                               cond > 1e8 - does not and takes the fp64 solve)
 //   F:   D   = solve64(r)                       fp64 fallback for whatever is still flagged (ill-conditioned Schur blocks,
 //                                               a non-positive fp32 pivot -> NaN -> fails the check: test/solver/schur.jl:19-62)
 // Every kernel covers all rollouts and leaves at once where it has nothing to do (flag array), so the host enqueues the
@@ -225,9 +227,9 @@ int launch_kkt_mixed(const NewtonDev& S, const KktArgs& K0, double* ws, int* n_f
     KktArgs P = K0; P.finish = 0; P.only_flag = flag;
     int rc = launch_kkt_any(S, P, s, true);                                   // P0
     if (rc != CIMPC_OK) return rc;
-    constexpr int CORRECTIONS = 2;
+    constexpr int CORRECTIONS = 4;
     for (int k = 0; k <= CORRECTIONS; ++k) {
-        MixArgs M{flag, k == 0 ? nullptr : corr, res, 1.0e-10, k == CORRECTIONS ? 1 : 0, n_fallback};
+        MixArgs M{flag, k == 0 ? nullptr : corr, res, 1.0e-9, k == CORRECTIONS ? 1 : 0, n_fallback};
         hipLaunchKernelGGL(kkt_mixed_check_kernel, dim3(S.nb_launch), dim3(256), 0, s, S, K0, M);       // Ck
         if (k == CORRECTIONS) break;
         KktArgs Pk = P; Pk.r = res; Pk.delta = corr;

@@ -44,8 +44,8 @@ extern "C" {
                                   [u_i, q_{i+2}, nu_i] (banded, quasi-definite) factored L D L^T without pivoting;
                                   the :ldl_solver analogue (ldl.jl:144-149) for block-tridiagonal P              */
 #define CIMPC_KKT_CONDENSED_MIXED 3 /* the condensed solve with its Schur-block products on the fp32 MFMA
-                                    * (v_mfma_f32_16x16x4_f32), refined in fp64 against the matrix-free KKT operator (at most two
-                                    * corrections, |r - R x|_inf <= 1e-10 max(1, |r|_inf)), fp64 solve for whatever does not get
+                                    * (v_mfma_f32_16x16x4_f32), refined in fp64 against the matrix-free KKT operator (at most four
+                                    * corrections, |r - R x|_inf <= 1e-9 max(1, |r|_inf)), fp64 solve for whatever does not get
                                     * there (ill-conditioned Schur blocks).  :configuration mode + TrackingObjective; anything
                                     * else falls back to the backend `0` would pick.  BASELINE configs[4]. */
 
