@@ -92,7 +92,7 @@ def measure_sweep_traffic(B, H, timeout_s=150):
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--rollouts", str(B), "--horizon", str(H),
-             "--no-cpu-baseline", "--no-real-problem", "--no-latency", "--no-traffic"]
+             "--no-cpu-baseline", "--no-real-problem", "--no-latency", "--no-traffic", "--no-centroidal"]
     vals = {}
     tmp = tempfile.mkdtemp(prefix="cimpc_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
@@ -281,6 +281,59 @@ def real_problem_leg(B, H, device, steps=5, perturb=0.05):
             "linearization_build_s": t_lin}
 
 
+def centroidal_payload_leg(B, H, device, steps=3):
+    """BASELINE configs[4]: centroidal_quadruped with a payload (body-force disturbance w in theta:
+    src/dynamics/centroidal_quadruped/model.jl:121-125, continuous_trot.jl:80-81), H = 60, on the REAL problem
+    (examples/centroidal_quadruped/reference/inplace_trot_v7.jld2 through the model restatement, continuous_trot.jl:37-73
+    settings: kappa = 1e-3, IP r_tol 1e-4, Newton r_tol 3e-5; tracking part of its objective).  Timed twice: KKT in mixed
+    precision (Schur-block products on the fp32 MFMA + fp64 refinement + fp64 fallback) and in fp64.  B = the per-GPU
+    share of 512 rollouts on 8 GPUs."""
+    import torch
+    from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions, gait_io, lcp_models
+    m = lcp_models.CentroidalQuadruped()
+    kappa = 1e-3
+    P = lcp_models.reference_problem(m, gait_io.load_gait(os.path.join(ROOT, "tests", "golden", "gaits", "centroidal_inplace_trot_v7.jld2")), kappa)
+    rng = np.random.default_rng(5)
+    ro = []
+    for g in range(B):
+        r = lcp_models.make_rollout(P, H, int(np.random.default_rng(g).integers(0, P.H)), seed=100 + g, perturb=0.02)
+        r["w"][:] = np.array([0.0, 0.0, -rng.uniform(5.0, 30.0)])            # payload: constant downward body force
+        r["theta"][:, 2 * m.nq + m.nu:2 * m.nq + m.nu + m.nw] = r["w"]
+        ro.append(r)
+    Q = np.tile(lcp_models.relative_state_cost([1.0, 1, 1], 3e-1 * np.ones(3), [0.2, 0.2, 1.0])[None], (H, 1, 1))
+    R = np.tile((3e-3 * np.eye(m.nu))[None], (H, 1, 1))
+    out = {"workload": "centroidal_quadruped inplace_trot_v7.jld2 (reference data file), payload w_z = -5..-30 N per rollout, "
+                       "H=%d, %d rollouts (512 / 8 GPUs), kappa 1e-3, cold start" % (H, B)}
+    q0 = torch.tensor(np.stack([r["q0"] for r in ro]), dtype=torch.float64, device="cuda")
+    q1 = torch.tensor(np.stack([r["q1"] for r in ro]), dtype=torch.float64, device="cuda")
+    for name, backend in (("mixed_fp32_mfma_kkt", 3), ("fp64_kkt", 0)):
+        s = CIMPCSolver(m.nq, m.nu, m.nw, m.nc, m.nb, P.H, H, B=B, mode=0, ip_opts=InteriorPointOptions(kappa_tol=kappa, r_tol=1e-4),
+                        newton_opts=NewtonOptions(kappa=kappa, r_tol=3e-5, max_iter=5, kkt_backend=backend), device=device)
+        for t in range(P.H):
+            s.set_linearization(t + 1, P.z[t], P.theta[t], P.r0[t], P.rz0[t], P.rth0[t])
+        s.set_objective(Q, R)
+        s.set_window(np.stack([r["window"] for r in ro]) + 1)
+        s.set_reference(*(np.stack([r[k] for r in ro]) for k in ("q", "u", "w", "gamma", "b", "theta")))
+        torch.cuda.synchronize()
+        s.newton_solve_dev(q0.data_ptr(), q1.data_ptr(), False)
+        s.profile_enable(True); s.profile_reset()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            s.newton_solve_dev(q0.data_ptr(), q1.data_ptr(), False)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        pr = s.profile_read(); st = s.stats()
+        u1, it, rn = s.newton_info()
+        out[name] = {"value": B / dt, "unit": "MPC steps/s", "ms_per_step": 1e3 * dt, "newton_iters_per_step": float(it.mean()),
+                     "kkt_ms_per_step": pr["kkt_ms"] / steps, "ip_sweep_ms_per_step": pr["ip_sweep_ms"] / steps,
+                     "ip_failures": st["ip_failures"], "kkt_fp64_fallbacks_since_create": s.kkt_fallbacks() if backend == 3 else 0,
+                     "kkt_systems_since_create": int(it.sum()) * (steps + 1), "u1_checksum": float(np.abs(u1).sum())}
+        s.close()
+    a, b = out["mixed_fp32_mfma_kkt"], out["fp64_kkt"]
+    out["u1_rel_diff_mixed_vs_fp64"] = abs(a["u1_checksum"] - b["u1_checksum"]) / max(b["u1_checksum"], 1e-300)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -295,6 +348,7 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the B = 1 single-rollout legs")
     ap.add_argument("--no-real-problem", action="store_true", help="skip the leg on the real quadruped gait")
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 --pmc passes (roofline.traffic)")
+    ap.add_argument("--no-centroidal", action="store_true", help="skip the centroidal payload leg (BASELINE configs[4])")
     args = ap.parse_args()
 
     import torch
@@ -489,6 +543,11 @@ def main():
             out["real_problem"] = real_problem_leg(B, H, local_rank)
         except Exception as e:
             out["real_problem"] = {"error": repr(e)}
+    if not args.no_centroidal and world == 1:        # BASELINE configs[4]: per-GPU share of 512 rollouts, mixed-precision KKT next to fp64
+        try:
+            out["centroidal_payload_h60"] = centroidal_payload_leg(64, 60, local_rank)
+        except Exception as e:
+            out["centroidal_payload_h60"] = {"error": repr(e)}
     if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a rank-0, N = 1 measurement
         try:
             from contactimplicitmpc.jl_amd.trajectory import Objective

@@ -32,6 +32,59 @@ struct DenseLayout {      // newton_residual.jl:18-54 / 69-98 (0-based offsets i
 
 }  // namespace
 
+// LU with partial pivoting of the N x N column-major matrix A (in place) and solve of A x = b with b given in x
+// (getrf-style, right-looking; the right-hand side is permuted and forward-substituted on the fly), one workgroup.
+__device__ void dense_lu_solve(double* A, double* x, int* piv, int N, int tid, int nt, double* s_val, int* s_idx) {
+    for (int k = 0; k < N; ++k) {
+        double best = -1.0; int bi = k;
+        for (int i = k + tid; i < N; i += nt) {
+            const double v = fabs(A[(size_t)k * N + i]);
+            if (v > best) { best = v; bi = i; }
+        }
+        s_val[tid] = best; s_idx[tid] = bi;
+        __syncthreads();
+        for (int s = nt / 2; s > 0; s >>= 1) {
+            if (tid < s) {
+                const double o = s_val[tid + s];
+                if (o > s_val[tid] || (o == s_val[tid] && s_idx[tid + s] < s_idx[tid])) { s_val[tid] = o; s_idx[tid] = s_idx[tid + s]; }
+            }
+            __syncthreads();
+        }
+        const int p = s_idx[0];
+        __syncthreads();
+        if (p != k) {
+            for (int j = tid; j < N; j += nt) {
+                const double t0 = A[(size_t)j * N + k];
+                A[(size_t)j * N + k] = A[(size_t)j * N + p];
+                A[(size_t)j * N + p] = t0;
+            }
+            if (tid == 0) { const double t0 = x[k]; x[k] = x[p]; x[p] = t0; }
+        }
+        if (tid == 0) piv[k] = p;
+        __syncthreads();
+        const double inv = 1.0 / A[(size_t)k * N + k];
+        for (int i = k + 1 + tid; i < N; i += nt) A[(size_t)k * N + i] *= inv;
+        __syncthreads();
+        const int m = N - k - 1;
+        // trailing update, columns j > k: A[i,j] -= l[i] * u[j]; rows are the fast (coalesced) index
+        for (size_t e = tid; e < (size_t)m * m; e += nt) {
+            const int i = k + 1 + (int)(e % m), j = k + 1 + (int)(e / m);
+            A[(size_t)j * N + i] = fma(-A[(size_t)k * N + i], A[(size_t)j * N + k], A[(size_t)j * N + i]);
+        }
+        // forward substitution of the right-hand side rides along: x[i] -= l[i] * x[k]
+        for (int i = k + 1 + tid; i < N; i += nt) x[i] = fma(-A[(size_t)k * N + i], x[k], x[i]);
+        __syncthreads();
+    }
+    // ---- back substitution with U ------------------------------------------------------------------
+    for (int k = N - 1; k >= 0; --k) {
+        if (tid == 0) x[k] /= A[(size_t)k * N + k];
+        __syncthreads();
+        const double xk = x[k];
+        for (int i = tid; i < k; i += nt) x[i] = fma(-A[(size_t)k * N + i], xk, x[i]);
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void kkt_dense_kernel(NewtonDev S, KktArgs K, double* ws_all) {
     const int b = blockIdx.x + S.b0, tid = threadIdx.x, nt = blockDim.x;
     if (K.stage != nullptr && K.stage[b] != STAGE_KKT) return;
@@ -99,55 +152,7 @@ __global__ __launch_bounds__(256) void kkt_dense_kernel(NewtonDev S, KktArgs K, 
     for (int e = tid; e < N; e += nt) x[e] = K.r[(size_t)b * S.N + e];
     __syncthreads();
 
-    // ---- LU with partial pivoting (getrf-style, right-looking), rhs permuted on the fly -----------
-    for (int k = 0; k < N; ++k) {
-        double best = -1.0; int bi = k;
-        for (int i = k + tid; i < N; i += nt) {
-            const double v = fabs(A[(size_t)k * N + i]);
-            if (v > best) { best = v; bi = i; }
-        }
-        s_val[tid] = best; s_idx[tid] = bi;
-        __syncthreads();
-        for (int s = nt / 2; s > 0; s >>= 1) {
-            if (tid < s) {
-                const double o = s_val[tid + s];
-                if (o > s_val[tid] || (o == s_val[tid] && s_idx[tid + s] < s_idx[tid])) { s_val[tid] = o; s_idx[tid] = s_idx[tid + s]; }
-            }
-            __syncthreads();
-        }
-        const int p = s_idx[0];
-        __syncthreads();
-        if (p != k) {
-            for (int j = tid; j < N; j += nt) {
-                const double t0 = A[(size_t)j * N + k];
-                A[(size_t)j * N + k] = A[(size_t)j * N + p];
-                A[(size_t)j * N + p] = t0;
-            }
-            if (tid == 0) { const double t0 = x[k]; x[k] = x[p]; x[p] = t0; }
-        }
-        if (tid == 0) piv[k] = p;
-        __syncthreads();
-        const double inv = 1.0 / A[(size_t)k * N + k];
-        for (int i = k + 1 + tid; i < N; i += nt) A[(size_t)k * N + i] *= inv;
-        __syncthreads();
-        const int m = N - k - 1;
-        // trailing update, columns j > k: A[i,j] -= l[i] * u[j]; rows are the fast (coalesced) index
-        for (size_t e = tid; e < (size_t)m * m; e += nt) {
-            const int i = k + 1 + (int)(e % m), j = k + 1 + (int)(e / m);
-            A[(size_t)j * N + i] = fma(-A[(size_t)k * N + i], A[(size_t)j * N + k], A[(size_t)j * N + i]);
-        }
-        // forward substitution of the right-hand side rides along: x[i] -= l[i] * x[k]
-        for (int i = k + 1 + tid; i < N; i += nt) x[i] = fma(-A[(size_t)k * N + i], x[k], x[i]);
-        __syncthreads();
-    }
-    // ---- back substitution with U ------------------------------------------------------------------
-    for (int k = N - 1; k >= 0; --k) {
-        if (tid == 0) x[k] /= A[(size_t)k * N + k];
-        __syncthreads();
-        const double xk = x[k];
-        for (int i = tid; i < k; i += nt) x[i] = fma(-A[(size_t)k * N + i], xk, x[i]);
-        __syncthreads();
-    }
+    dense_lu_solve(A, x, piv, N, tid, nt, s_val, s_idx);
     double* D = K.delta + (size_t)b * S.N;
     for (int e = tid; e < N; e += nt) D[e] = x[e];
     __syncthreads();
@@ -449,4 +454,67 @@ int launch_kkt_dense_raw(const NewtonDev& S, const double* r_dev, double beta, d
     return launch_kkt_dense(S, K, ws, s, banded);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Stand-alone B1 seam: `linear_solve!(solver, x, A::SparseMatrixCSC, b)` with the matrix PASSED IN
+// (/root/reference/src/controller/newton.jl:86,218; contract src/solver/lu.jl:4-12, src/solver/ldl.jl:144-149: the
+// solver factorizes the CSC matrix it is handed and overwrites x).  The reference default `lu_solver` densifies
+// (`Array(A)`) and runs LU with partial pivoting; so does this: scatter on the device, the LU of the dense backend
+// above, one workgroup.  It exists so that the Julia host can swap `opts.solver` alone; it is not a fast path - the
+// fast path is cimpc_kkt_solve on a handle whose sensitivities are device-resident (no matrix crosses the boundary).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void csc_dense_solve_kernel(int n, const long long* colptr, const long long* rowval, const double* nzval,
+                                                              const double* bvec, double* A, double* x, int* piv, int* bad) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    __shared__ double s_val[256];
+    __shared__ int s_idx[256];
+    for (size_t e = tid; e < (size_t)n * n; e += nt) A[e] = 0.0;
+    for (int i = tid; i < n; i += nt) x[i] = bvec[i];
+    __syncthreads();
+    for (int c = tid; c < n; c += nt)                       // 1-based CSC as Julia stores it (duplicate entries add up)
+        for (long long p = colptr[c] - 1; p < colptr[c + 1] - 1; ++p) {
+            const long long r = rowval[p] - 1;
+            if (r < 0 || r >= n) { *bad = 1; continue; }
+            A[(size_t)c * n + r] += nzval[p];
+        }
+    __syncthreads();
+    dense_lu_solve(A, x, piv, n, tid, nt, s_val, s_idx);
+}
+
 }  // namespace cimpc
+
+extern "C" int cimpc_linear_solve_csc(int device, int n, const long long* colptr, const long long* rowval, const double* nzval,
+                                      const double* b, double* x) {
+    using namespace cimpc;
+    if (n <= 0 || !colptr || !rowval || !nzval || !b || !x) return CIMPC_ERR_INVALID;
+    if (colptr[0] != 1) return CIMPC_ERR_INVALID;           // 1-based column pointers (SparseMatrixCSC)
+    const long long nnz = colptr[n] - 1;
+    if (nnz < 0 || (size_t)n * n > ((size_t)1 << 31)) return CIMPC_ERR_INVALID;
+    for (int c = 0; c < n; ++c) if (colptr[c + 1] < colptr[c]) return CIMPC_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return CIMPC_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return CIMPC_ERR_NO_DEVICE;
+    long long *d_cp = nullptr, *d_rv = nullptr;
+    double *d_nz = nullptr, *d_b = nullptr, *d_A = nullptr, *d_x = nullptr;
+    int* d_i = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_cp); (void)hipFree(d_rv); (void)hipFree(d_nz); (void)hipFree(d_b); (void)hipFree(d_A); (void)hipFree(d_x); (void)hipFree(d_i); };
+    const size_t nz = (size_t)(nnz > 0 ? nnz : 1);
+    bool ok = hipMalloc(&d_cp, (n + 1) * sizeof(long long)) == hipSuccess && hipMalloc(&d_rv, nz * sizeof(long long)) == hipSuccess &&
+              hipMalloc(&d_nz, nz * sizeof(double)) == hipSuccess && hipMalloc(&d_b, n * sizeof(double)) == hipSuccess &&
+              hipMalloc(&d_A, (size_t)n * n * sizeof(double)) == hipSuccess && hipMalloc(&d_x, n * sizeof(double)) == hipSuccess &&
+              hipMalloc(&d_i, (n + 1) * sizeof(int)) == hipSuccess;
+    ok = ok && hipMemcpy(d_cp, colptr, (n + 1) * sizeof(long long), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(d_rv, rowval, (size_t)nnz * sizeof(long long), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(d_nz, nzval, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(d_b, b, n * sizeof(double), hipMemcpyHostToDevice) == hipSuccess && hipMemset(d_i + n, 0, sizeof(int)) == hipSuccess;
+    int bad = 0;
+    if (ok) {
+        hipLaunchKernelGGL(csc_dense_solve_kernel, dim3(1), dim3(256), 0, nullptr, n, d_cp, d_rv, d_nz, d_b, d_A, d_x, d_i, d_i + n);
+        ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+             hipMemcpy(x, d_x, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(&bad, d_i + n, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    cleanup();
+    if (!ok) return CIMPC_ERR_HIP;
+    return bad ? CIMPC_ERR_INVALID : CIMPC_OK;
+}
+

@@ -64,6 +64,27 @@ def _f64(a, shape=None):
     return a
 
 
+def linear_solve_csc(A, b, device=0):
+    """`linear_solve!(solver, x, A, b)` with the sparse matrix passed in (B1 stand-alone, lu.jl:4-12): A is a
+    scipy.sparse matrix (converted to CSC with Julia's 1-based Int64 index arrays), returns x."""
+    import scipy.sparse as sp
+    A = sp.csc_matrix(A)
+    A.sum_duplicates()
+    n = A.shape[0]
+    if A.shape != (n, n):
+        raise ValueError("square matrix expected")
+    cp = np.ascontiguousarray(A.indptr.astype(np.int64) + 1)
+    rv = np.ascontiguousarray(A.indices.astype(np.int64) + 1)
+    nz = np.ascontiguousarray(A.data, dtype=np.float64)
+    bb = _f64(b, (n,))
+    x = np.zeros(n)
+    pll = lambda a: a.ctypes.data_as(C.POINTER(C.c_longlong))
+    rc = _lib.load().cimpc_linear_solve_csc(int(device), n, pll(cp), pll(rv), _dp(nz), _dp(bb), _dp(x))
+    if rc != 0:
+        raise CimpcError(f"cimpc_linear_solve_csc failed ({rc})")
+    return x
+
+
 class CIMPCSolver:
     """One handle = one GPU.  Wraps the C ABI; raises CimpcError on any non-zero status."""
 

@@ -1,0 +1,195 @@
+# CIMPCHip.jl - Julia-side binding of libcimpc_hip.so (include/cimpc.h) for ContactImplicitMPC.jl.
+#
+# Drop-in at the reference's own seams (file:line relative to dojo-sim/ContactImplicitMPC.jl v0.2.0):
+#   B4  newton_solve!(core, s, q0, q1, window, im_traj, ref_traj; warm_start)   src/controller/newton.jl:169-177
+#   B3  implicit_dynamics!(im_traj, traj; window)                               src/controller/implicit_dynamics.jl:156-158
+#   B1  linear_solve!(solver, x, A, b)   (opts.solver = :hip_kkt_solver / :hip_csc_solver)   src/controller/newton.jl:86,218
+#   A1  LinearizedStep per knot -> cimpc_set_linearization                      src/controller/linearized_step.jl:10-31
+#   glue rot_n_stride! / update_window!                                         src/controller/policy.jl:133-141
+#
+# Usage inside the package (after `include("CIMPCHip.jl")` in src/ContactImplicitMPC.jl, library path in ENV["CIMPC_LIB"]):
+#   p   = ci_mpc_policy(ref_traj, s, obj; H_mpc, N_sample, κ_mpc, mode, n_opts, ip_opts)
+#   hip = CIMPCHip.Solver(s, ref_traj, obj; H_mpc, κ = κ_mpc, mode, n_opts, ip_opts)      # once
+#   CIMPCHip.newton_solve!(hip, p.newton, p.q0, q1, p.window, p.traj; warm_start = t > 1)   # instead of newton.jl:169
+#
+# There is no Julia toolchain in the build image of this repository: the file is written against the C header and the
+# reference's types, every call it makes is exercised through the identical C ABI by the Python host
+# (contactimplicitmpc/jl_amd/_lib.py, solver.py) in tests/.  Struct layouts below are checked against the header by
+# tests/test_abi_and_host.py (field order / sizes of the C structs).
+module CIMPCHip
+
+using SparseArrays
+
+const LIB = get(ENV, "CIMPC_LIB", "libcimpc_hip.so")
+
+# ---- include/cimpc.h structs (field order = C order; all Cint / Cdouble: no padding surprises) -------------------------
+struct Dims
+    nq::Cint; nu::Cint; nw::Cint; nc::Cint; nb::Cint
+    mode::Cint                  # 0 = :configuration, 1 = :configurationforce
+    H_ref::Cint; H::Cint; B::Cint
+end
+struct IpOpts                   # <- InteriorPointOptions (policy.jl:54-61, implicit_dynamics.jl:25-32)
+    r_tol::Cdouble; kappa_tol::Cdouble; undercut::Cdouble; gamma_reg::Cdouble
+    kappa_reg::Cdouble; eps_min::Cdouble; ls_scale::Cdouble
+    max_iter::Cint; max_ls::Cint; stall_alpha::Cdouble
+end
+struct NewtonOpts               # <- NewtonOptions (newton.jl:2-11)
+    r_tol::Cdouble; beta_init::Cdouble; max_time::Cdouble; kappa::Cdouble
+    max_iter::Cint; kkt_backend::Cint
+end
+const KKT_CONDENSED, KKT_DENSE_LU, KKT_BANDED_LDL, KKT_CONDENSED_MIXED = Cint(0), Cint(1), Cint(2), Cint(3)
+
+lasterror(h) = unsafe_string(ccall((:cimpc_last_error, LIB), Cstring, (Ptr{Cvoid},), h))
+check(rc, h = C_NULL) = rc == 0 ? nothing : error("libcimpc_hip: ($rc) " * lasterror(h))
+
+pack(v::AbstractVector{<:AbstractVector}, n = length(v)) = reduce(hcat, v[1:n])     # Vector{Vector} -> column-major matrix
+
+# ---- handle = ImplicitTrajectory + Newton state on one GPU ----------------------------------------------------------------
+mutable struct Solver
+    h::Ptr{Cvoid}
+    dims::Dims
+    β::Float64                  # mirror of core.β for the B1 seam
+    function Solver(h, dims)
+        s = new(h, dims, 1e-5)
+        finalizer(x -> (x.h == C_NULL || ccall((:cimpc_destroy, LIB), Cint, (Ptr{Cvoid},), x.h); x.h = C_NULL), s)
+        return s
+    end
+end
+
+"""
+    Solver(s, ref_traj, obj; H_mpc, κ, mode, n_opts, ip_opts, B = 1, device = 0, kkt_backend = KKT_CONDENSED)
+
+Replaces `ImplicitTrajectory(ref_traj, s; κ, mode, opts)` (implicit_dynamics.jl:21-90) and `Newton(s, H, h, traj, im_traj; obj,
+opts)` (newton.jl:37-91): uploads one `LinearizedStep` per knot and the objective blocks.
+"""
+function Solver(s, ref_traj, obj; H_mpc::Int, κ::Float64, mode::Symbol = :configurationforce, n_opts, ip_opts,
+                B::Int = 1, device::Int = 0, kkt_backend = KKT_CONDENSED)
+    m = s.model
+    nb = m.nc * Main.ContactImplicitMPC.friction_dim(s.env)
+    dims = Dims(m.nq, m.nu, m.nw, m.nc, nb, mode == :configuration ? 0 : 1, ref_traj.H, H_mpc, B)
+    ip = Ref(IpOpts(ip_opts.r_tol, ip_opts.κ_tol, ip_opts.undercut, ip_opts.γ_reg, ip_opts.κ_reg, ip_opts.ϵ_min,
+                    ip_opts.ls_scale, ip_opts.max_iter, ip_opts.max_ls, 1e-13))
+    nt = Ref(NewtonOpts(n_opts.r_tol, n_opts.β_init, n_opts.max_time, κ, n_opts.max_iter, kkt_backend))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:cimpc_create, LIB), Cint, (Ref{Dims}, Ref{IpOpts}, Ref{NewtonOpts}, Cint, Ref{Ptr{Cvoid}}),
+                Ref(dims), ip, nt, device, h))
+    hs = Solver(h[], dims)
+    for t = 1:ref_traj.H                                             # A1
+        lin = Main.ContactImplicitMPC.LinearizedStep(s, ref_traj.z[t], ref_traj.θ[t], κ)
+        check(ccall((:cimpc_set_linearization, LIB), Cint,
+                    (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                    hs.h, t, lin.z, lin.θ, lin.r, Matrix(lin.rz), Matrix(lin.rθ)), hs.h)
+    end
+    set_objective!(hs, obj, H_mpc)
+    return hs
+end
+
+"TrackingObjective / TrackingVelocityObjective (objective.jl:3-47) -> cimpc_set_objective (column-major blocks per step)."
+function set_objective!(hs::Solver, obj, H::Int)
+    blk(v) = cat((Matrix(v[t]) for t = 1:H)...; dims = 3)
+    Q, R = blk(obj.q), blk(obj.u)
+    Cg = hs.dims.mode == 1 ? blk(obj.γ) : C_NULL
+    Cb = hs.dims.mode == 1 ? blk(obj.b) : C_NULL
+    hasv = hasproperty(obj, :v)
+    V = hasv ? blk(obj.v) : C_NULL
+    qt = hasv ? pack(obj.q_target, H) : C_NULL
+    vt = hasv ? pack(obj.v_target, H) : C_NULL
+    check(ccall((:cimpc_set_objective, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                hs.h, Q, R, Cg, Cb, V, qt, vt), hs.h)
+end
+
+"RLin.alt of every knot (set_altitude!, implicit_dynamics.jl:141-154); alt: nc (one robot) or nc x B."
+set_altitude!(hs::Solver, alt) =
+    check(ccall((:cimpc_set_altitude, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), hs.h, Matrix{Float64}(reshape(alt, :, Int(hs.dims.B)))), hs.h)
+
+# ---- B4: newton_solve! ---------------------------------------------------------------------------------------------------------
+"""
+    newton_solve!(hs, core, q0, q1, window, ref_traj; warm_start = false)
+
+`newton_solve!(core, s, q0, q1, window, im_traj, ref_traj; warm_start)` (newton.jl:169-177) on the GPU: uploads window and
+reference, solves, writes `core.traj.u[1]` (read by policy.jl:142) and, with `full = true`, the whole `core.traj`, `core.ν`.
+Returns nothing and never throws for a solve that merely ran out of iterations / time (the reference returns silently too).
+"""
+function newton_solve!(hs::Solver, core, q0, q1, window::Vector{Int}, ref_traj; warm_start::Bool = false, full::Bool = false)
+    H = core.traj.H
+    check(ccall((:cimpc_set_window, LIB), Cint, (Ptr{Cvoid}, Ptr{Cint}), hs.h, Cint.(window)), hs.h)      # 1-based knots
+    check(ccall((:cimpc_set_reference, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                hs.h, pack(ref_traj.q, H + 2), pack(ref_traj.u, H), pack(ref_traj.w, H), pack(ref_traj.γ, H),
+                pack(ref_traj.b, H), pack(ref_traj.θ, H)), hs.h)
+    u1 = zeros(length(core.traj.u[1])); iters = Ref{Cint}(0); rn = Ref{Cdouble}(0.0)
+    check(ccall((:cimpc_newton_solve, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ref{Cint}, Ref{Cdouble}),
+                hs.h, q0, q1, warm_start, u1, iters, rn), hs.h)
+    core.traj.u[1] .= u1
+    if full
+        nq, nu = length(core.traj.q[1]), length(core.traj.u[1]); nd = length(core.ν[1])
+        q = zeros(nq, H + 2); u = zeros(nu, H); ν = zeros(nd, H)
+        check(ccall((:cimpc_get_trajectory, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                    hs.h, q, u, C_NULL, C_NULL, ν), hs.h)
+        for t = 1:H + 2; core.traj.q[t] .= @view q[:, t]; end
+        for t = 1:H; core.traj.u[t] .= @view u[:, t]; core.ν[t] .= @view ν[:, t]; end
+    end
+    return nothing
+end
+
+"Policy glue after a solve: rot_n_stride!(p.traj, ...) + update_window! (policy.jl:136-139) on the device-resident copy."
+mpc_advance!(hs::Solver, stride) = check(ccall((:cimpc_mpc_advance, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), hs.h, stride), hs.h)
+
+# ---- B3: implicit_dynamics! ------------------------------------------------------------------------------------------------------
+function implicit_dynamics!(hs::Solver, im_traj, traj; window = collect(1:traj.H + 2))
+    H = length(window) - 2; nd = length(im_traj.d[1]); nq = length(traj.q[1]); nu = length(traj.u[1])
+    check(ccall((:cimpc_set_window, LIB), Cint, (Ptr{Cvoid}, Ptr{Cint}), hs.h, Cint.(window)), hs.h)
+    d = zeros(nd, H); dz = zeros(nd, 2nq + nu, H); status = zeros(Cint, H); iters = zeros(Cint, H)
+    cf = hs.dims.mode == 1
+    check(ccall((:cimpc_implicit_dynamics, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cint}, Ptr{Cdouble}),
+                hs.h, pack(traj.q, H + 2), pack(traj.θ, H), cf ? pack(traj.γ, H) : C_NULL, cf ? pack(traj.b, H) : C_NULL,
+                d, dz, status, iters, C_NULL), hs.h)
+    for (i, t) in enumerate(window[1:end-2])                     # write through the reference's views (implicit_dynamics.jl:84-86)
+        im_traj.d[t] .= @view d[:, i]
+        if status[i] == 1
+            im_traj.δq0[t] .= @view dz[:, 1:nq, i]
+            im_traj.δq1[t] .= @view dz[:, nq+1:2nq, i]
+            im_traj.δu1[t] .= @view dz[:, 2nq+1:2nq+nu, i]
+        else
+            @warn "implicit dynamics failure (t = $t)"             # implicit_dynamics.jl:169-176: δz keeps its last value
+        end
+    end
+    return nothing
+end
+
+# ---- B1: LinearSolver seam ---------------------------------------------------------------------------------------------------------
+# (a) on a handle: the KKT system of the handle's device-resident sensitivities - A is NOT read; requires B3 / a Newton
+#     evaluation on the same handle before the call (include/cimpc.h).  Select with opts.solver = :hip_kkt_solver.
+const CURRENT = Ref{Union{Nothing,Solver}}(nothing)
+struct HipKKTSolver; hs::Solver; end            # <: LinearSolver inside the package
+hip_kkt_solver(A) = HipKKTSolver(CURRENT[])
+function linear_solve!(s::HipKKTSolver, x::Vector{Float64}, A, b::Vector{Float64}; reg = 0.0, fact::Bool = true)
+    check(ccall((:cimpc_kkt_solve, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}), s.hs.h, b, s.hs.β, x), s.hs.h)
+    return nothing
+end
+# (b) stand-alone: solves with the SparseMatrixCSC passed in, exactly the contract of lu.jl:4-12 / ldl.jl:144-149.
+#     Select with opts.solver = :hip_csc_solver.
+struct HipCSCSolver; device::Int; end
+hip_csc_solver(A) = HipCSCSolver(0)
+function linear_solve!(s::HipCSCSolver, x::Vector{Float64}, A::SparseMatrixCSC{Float64,Int}, b::Vector{Float64}; reg = 0.0, fact::Bool = true)
+    check(ccall((:cimpc_linear_solve_csc, LIB), Cint,
+                (Cint, Cint, Ptr{Int64}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                s.device, size(A, 1), A.colptr, A.rowval, A.nzval, b, x))
+    return nothing
+end
+
+# ---- plant side: one simulator step for B robots (RoboDojo step! inside simulate!, simulator.jl:15-63) ---------------------------
+function plant_step(model::Symbol, q0::Matrix{Float64}, q1::Matrix{Float64}, u::Matrix{Float64}, μ, h_sim, opts::IpOpts)
+    B = size(q0, 2); nq = size(q0, 1)
+    q2 = zeros(nq, B); γ = zeros(4, B); b = zeros(8, B); status = zeros(Cint, B); iters = zeros(Cint, B)
+    check(ccall((:cimpc_plant_step, LIB), Cint,
+                (Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Ref{IpOpts},
+                 Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cint}),
+                model == :quadruped ? 0 : 1, B, q0, q1, u, C_NULL, μ, h_sim, Ref(opts), q2, γ, b, status, iters))
+    return q2, γ, b, status, iters
+end
+
+end # module

@@ -7,7 +7,7 @@ shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-real-problem --no-latency $*"
+CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-real-problem --no-latency --no-centroidal $*"
 rocprofv3 -L > $OUT/counters_available.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/bench_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $CMD > $OUT/bench_fetch.log 2>&1

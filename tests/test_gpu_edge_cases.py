@@ -126,3 +126,30 @@ def test_plant_step_validates_options(gpu_required):
     q = np.zeros((1, 11)); u = np.zeros((1, 8))
     with pytest.raises(Exception):
         plant.plant_step("quadruped", q, q, u, mu=0.5, h=0.01, opts=InteriorPointOptions(max_iter=0))
+
+
+def test_linear_solve_csc_standalone_seam(gpu_required):
+    """B1 stand-alone (`linear_solve!(solver, x, A::SparseMatrixCSC, b)`, lu.jl:4-12): the matrix that is passed in is the
+    matrix that is solved - the oracle's jacobian! as a sparse matrix, and the construction of test/solver/lu.jl (random
+    sparse + identity), against scipy / numpy."""
+    import scipy.sparse as sp
+    from contactimplicitmpc.jl_amd.solver import linear_solve_csc
+    from oracle import newton as onewton
+    from common import oracle_sweep
+    from oracle import ip as oip
+    d, prob, tabs, rollouts = make_case("hopper", 0, H_ref=10, H=8, B=1, seed=3)
+    obj = synth.make_objective(d, 8, kind="hopper")
+    (tr, o), = oracle_sweep(d, tabs, rollouts, oip.IPOptions(kappa_tol=prob["kappa"]))
+    lay = onewton.Layout(d, 8)
+    R = onewton.jacobian(lay, obj, o, 1e-5, prob["kappa"])
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal(lay.N)
+    x = linear_solve_csc(sp.csc_matrix(R), b)
+    np.testing.assert_allclose(R @ x, b, rtol=0, atol=1e-10 * max(1.0, np.abs(b).max()))
+    n = 120
+    A = sp.random(n, n, density=0.05, random_state=1, format="csc") + sp.identity(n, format="csc") * 4.0     # test/solver/lu.jl
+    b = rng.standard_normal(n)
+    x = linear_solve_csc(A, b)
+    assert np.abs(A @ x - b).max() < 1e-10
+    with pytest.raises(ValueError):
+        linear_solve_csc(sp.random(4, 5, density=0.5, format="csc"), np.zeros(4))
