@@ -518,6 +518,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     AX(&S.counters, 8);
     AX(&S.stats, 4);
     AX(&S.ro_sweeps, B); AX(&S.ro_ip_iters, B); AX(&S.ro_ip_fail, B);
+    AX(&S.nlog, B * NLOG * 4);
     A(&S.kkt_ws, B * H * (3 * (size_t)h->nd * h->nd + h->nd));
     (void)ppw;
     if (rc == CIMPC_OK && hipHostMalloc((void**)&h->h_counters, 8 * sizeof(int)) != hipSuccess)
@@ -1255,6 +1256,17 @@ int cimpc_get_reference(cimpc_handle h, double* q_ref, double* u_ref, double* w_
         HIP_TRY(h, hipMemcpy(window, h->d_window, B * (H + 2) * sizeof(int), hipMemcpyDeviceToHost));
         for (size_t k = 0; k < B * (H + 2); ++k) window[k] += 1;     // 1-based at the boundary
     }
+    return CIMPC_OK;
+}
+
+int cimpc_get_newton_log(cimpc_handle h, double* log, int max_entries) {
+    if (!h || !log || max_entries <= 0) return CIMPC_ERR_INVALID;
+    const size_t B = h->dm.B;
+    const int n = std::min(max_entries, NLOG);
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy2D(log, (size_t)max_entries * 4 * sizeof(double), h->S.nlog, (size_t)NLOG * 4 * sizeof(double),
+                           (size_t)n * 4 * sizeof(double), B, hipMemcpyDeviceToHost));
     return CIMPC_OK;
 }
 

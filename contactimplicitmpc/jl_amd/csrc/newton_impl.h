@@ -442,6 +442,10 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
     }
     if (tid == 0) {
         const double rn = rc[slot];
+        if (act == 1 && S.nlog != nullptr && S.newton_l[b] < NLOG) {      // status line of this iteration (print_status, newton.jl:290-301)
+            double* e = S.nlog + ((size_t)b * NLOG + S.newton_l[b]) * 4;
+            e[0] = alpha; e[1] = S.r_norm[b] / (double)S.N; e[2] = rn / (double)S.N; e[3] = (double)iter;
+        }
         S.r_norm[b] = rn;
         S.cur_slot[b] = it0 + slot;
         S.alpha[b] = alpha;

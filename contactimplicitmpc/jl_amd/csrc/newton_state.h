@@ -6,6 +6,7 @@
 #include "cimpc_internal.h"
 
 namespace cimpc {
+constexpr int NLOG = 16;       // Newton iterations kept per rollout in the status log
 
 enum Stage : int { STAGE_DONE = 0, STAGE_INIT = 1, STAGE_LS0 = 2, STAGE_KKT = 3, STAGE_LS1 = 4, STAGE_LS2 = 5, STAGE_LS7 = 6 };
 constexpr int CS = 7;   // evaluation slots per rollout (speculative line search, newton_impl.h)
@@ -77,6 +78,7 @@ struct NewtonDev {
     // options
     double r_tol, beta_init, kappa;
     int max_iter;
+    double* nlog;      // [B][NLOG][4] per accepted Newton iteration: alpha, |r|_1/N before, after, line-search iter (print_status, newton.jl:290-301)
     int spec_all;      // a rollout whose previous line search ended at iter >= spec_all evaluates all 7 step lengths at once
 };
 

@@ -282,6 +282,13 @@ class CIMPCSolver:
                     "get_rollout_counters")
         return dict(sweeps=sw, ip_iters=it, ip_failures=fl)
 
+    def newton_log(self, max_entries=16):
+        """Status lines of the last newton_solve! (print_status, newton.jl:290-301): (B, max_entries, 4) =
+        alpha, |r|_1/N before, after, line-search iterate per accepted Newton iteration."""
+        log = np.zeros((self.B, max_entries, 4))
+        self._check(self.lib.cimpc_get_newton_log(self.h, _dp(log), int(max_entries)), "get_newton_log")
+        return log
+
     def kkt_fallbacks(self):
         """kkt_backend = 3 (mixed precision): KKT systems that went to the fp64 fallback since the handle was created."""
         n = C.c_longlong()

@@ -190,6 +190,11 @@ int cimpc_get_trajectory(cimpc_handle h, double* q, double* u, double* gamma, do
                          double* nu_dual);
 int cimpc_get_newton_info(cimpc_handle h, int* newton_iters, double* r_norm, double* u1);
 int cimpc_get_stats(cimpc_handle h, cimpc_stats* s);
+/* Per-rollout status log of the last newton_solve!: one entry per ACCEPTED Newton iteration l = 1.. (what print_status prints,
+ * src/controller/newton.jl:290-301): log[b][l-1] = {alpha, |r|_1 / N before the step, after the step, line-search iterate
+ * (7 = search exhausted)}; entries beyond the rollout's iteration count keep older content (read newton_iters first).
+ * log: B x max_entries x 4 doubles (at most 16 iterations are kept). */
+int cimpc_get_newton_log(cimpc_handle h, double* log, int max_entries);
 /* CIMPC_KKT_CONDENSED_MIXED: KKT systems handed to the fp64 fallback since cimpc_create (0 = every system met the
  * refinement tolerance in mixed precision). */
 int cimpc_get_kkt_fallbacks(cimpc_handle h, long long* n);

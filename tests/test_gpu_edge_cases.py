@@ -153,3 +153,27 @@ def test_linear_solve_csc_standalone_seam(gpu_required):
     assert np.abs(A @ x - b).max() < 1e-10
     with pytest.raises(ValueError):
         linear_solve_csc(sp.random(4, 5, density=0.5, format="csc"), np.zeros(4))
+
+
+def test_newton_status_log_matches_oracle(gpu_required):
+    """cimpc_get_newton_log: the per-iteration status print_status shows (newton.jl:290-301) - step length, residual before /
+    after - per rollout, against the oracle's record of the same solve."""
+    from contactimplicitmpc.jl_amd import NewtonOptions
+    from oracle import ip as oip, newton as onewton
+    H, B = 10, 6
+    d, prob, tabs, rollouts = make_case("quadruped", 0, H_ref=16, H=H, B=B, seed=11, perturb=1e-2)
+    obj = synth.make_objective(d, H, kind="quadruped")
+    s = make_solver(d, prob, rollouts, H, obj=obj, newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=1e-5, max_iter=5))
+    u1, it, rn = s.newton_solve(np.stack([r[2] for r in rollouts]), np.stack([r[3] for r in rollouts]))
+    log = s.newton_log()
+    s.close()
+    assert log.shape == (B, 16, 4) and it.max() >= 1
+    for b, (window, ref, q0, q1) in enumerate(rollouts):
+        core = onewton.Newton(d, H, obj, onewton.NewtonOptions(r_tol=1e-5, max_iter=5, solver="lu"), oip.IPOptions(kappa_tol=prob["kappa"]), prob["kappa"], ref)
+        st = onewton.newton_solve(core, q0, q1, window, tabs, ref)
+        assert it[b] == st.iters
+        n = int(it[b])
+        np.testing.assert_allclose(log[b, :n, 0], st.alphas[:n], rtol=0, atol=0)            # accepted step lengths
+        if n:
+            np.testing.assert_allclose(log[b, n - 1, 2], rn[b], rtol=1e-12)                   # residual after the last step
+            assert (log[b, 1:n, 1] == log[b, :n - 1, 2]).all()                               # before(l+1) == after(l)
