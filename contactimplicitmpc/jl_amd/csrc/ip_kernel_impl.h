@@ -31,6 +31,16 @@
 
 namespace cimpc {
 
+// -DCIMPC_SWEEP_PROF: per-wave shader-clock accounting of the lock-step sweep (diagnostic builds only; the timers cost ~10 %):
+//   [0] wave lifetime  [1] barriers + knot pick  [2] table staging  [3] end-of-solve section  [4] pull section
+//   [5] interior-point trips  [6] sensitivity trips  [7] waves  [8] pulls  [9] ip trips  [10] sens trips
+#ifdef CIMPC_SWEEP_PROF
+static __device__ unsigned long long g_sweep_prof[16];
+#define SPROF_T() ((long long)__builtin_amdgcn_s_memtime())
+#else
+#define SPROF_T() 0ll
+#endif
+
 template <int NQ_, int NU_, int NW_, int NC_, int NB_, int MODE_>
 struct Model {
     static constexpr int NQ = NQ_, NU = NU_, NW = NW_, NC = NC_, NB = NB_, MODE = MODE_;
@@ -416,7 +426,7 @@ __device__ __forceinline__ int pick_knot(const IpParams& p, int* s_rem, int* s_t
 // neighbours keep iterating.  Converged problems wait in a per-group backlog for a wave-uniform
 // sensitivity trip.  Must be entered by the whole workgroup; ends with every wave drained.
 template <class M, bool ASYNC>
-__device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int knot, int tid) {
+__device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int knot, int tid, [[maybe_unused]] long long* sp = nullptr) {
     constexpr int NX = M::NX, NY = M::NY, NTH = M::NTH, ND = M::ND, G = M::G;
     constexpr int NC = M::NC, NB = M::NB;
     constexpr LinLayout L(NX, NY, NTH, G);
@@ -432,9 +442,13 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
     const bool vx = l < NX, vy = l < NY;
     const cimpc_ip_opts o = p.o;
 
+    [[maybe_unused]] const long long sp_t0 = SPROF_T();
     const int n = ASYNC ? 1 : *qcount(p.Q, par, knot);
     stage_table<M>(tab, p.tab, knot, tid);
     __syncthreads();
+#ifdef CIMPC_SWEEP_PROF
+    if (sp) sp[2] += SPROF_T() - sp_t0;
+#endif
     const int* items = p.Q.items + ((size_t)par * K + knot) * cap;
     int* head = qhead(p.Q, knot);
     [[maybe_unused]] const int* tailp = qcount(p.Q, par, knot);
@@ -449,6 +463,7 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
     double reg = 0.0, r_vio = 0.0, k_vio = 0.0, qinit = 0.0;
 
     while (true) {
+        [[maybe_unused]] const long long sp_a = SPROF_T();
         // ---- 1. end of a solve? ---------------------------------------------------------------
         if (have) {
             int code = -1;
@@ -499,6 +514,7 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
                 have = false;
             }
         }
+        [[maybe_unused]] const long long sp_b = SPROF_T();
         // ---- 2. pull the next problem of this knot -----------------------------------------
         // (ASYNC: the queue is live - an idle group looks again every few trips while its wave is busy)
         if (!have && (!exhausted || (ASYNC && !(p.A.flags & 2) && (++idle_trips & 7) == 0))) {
@@ -566,6 +582,9 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
                 done_here = 0;
                 stalled = false;
                 have = true;
+#ifdef CIMPC_SWEEP_PROF
+                if (sp) sp[8] += 1;
+#endif
             } else {
                 exhausted = true;
             }
@@ -575,6 +594,10 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
         //         every group of the wave has something in its backlog (all four groups then run
         //         the same code on their own problem - no SIMT divergence), when the wave has no
         //         interior-point work left, or when a backlog is full.
+        [[maybe_unused]] const long long sp_c = SPROF_T();
+#ifdef CIMPC_SWEEP_PROF
+        if (sp) { sp[3] += sp_b - sp_a; sp[4] += sp_c - sp_b; }
+#endif
         if (dbg_on) { dbg_trips += 1; dbg_act += have ? 1 : 0; }
         const bool any_ip = __any(have ? 1 : 0);
         if (!any_ip && !__any(nback > 0 ? 1 : 0)) break;
@@ -597,6 +620,9 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
             sensitivities<M, ASYNC>(p, S, tab, pr, l);
             S.x = sx; S.y1 = sy1; S.y2 = sy2; S.rdyn = sd; S.rrst = sr; S.rbil = sb_; S.tthdyn = st; S.tthrst = su; S.altl = sa;
         }
+#ifdef CIMPC_SWEEP_PROF
+        if (sp) { const long long sp_d = SPROF_T(); if (sens_trip) { sp[6] += sp_d - sp_c; sp[10] += 1; } else { sp[5] += sp_d - sp_c; sp[9] += 1; } }
+#endif
     }
     if constexpr (ASYNC) {      // diagnostics: group-trips with / without a problem
         if (p.A.dbg != nullptr && l == 0) {
@@ -621,12 +647,24 @@ __global__ __launch_bounds__(256, M::G == 16 ? 2 : 1) void ip_queue_kernel(IpPar
     __shared__ int s_knot, s_total, s_rem[PICK_MAXK];
     const int tid = (int)threadIdx.x;
     __builtin_amdgcn_s_setprio(CIMPC_SWEEP_PRIO);
+    [[maybe_unused]] long long sp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    [[maybe_unused]] const long long sp_life = SPROF_T();
     while (true) {
+        [[maybe_unused]] const long long sp_t = SPROF_T();
         __syncthreads();            // every wave is done with the staged table
         const int knot = pick_knot(p, s_rem, &s_total, &s_knot, tid, (int)blockIdx.x, (int)gridDim.x);
+#ifdef CIMPC_SWEEP_PROF
+        sp[1] += SPROF_T() - sp_t;
+#endif
         if (knot < 0) break;
-        serve_knot<M, false>(p, smem, knot, tid);
+        serve_knot<M, false>(p, smem, knot, tid, sp);
     }
+#ifdef CIMPC_SWEEP_PROF
+    if ((tid & 63) == 0) {
+        sp[0] = SPROF_T() - sp_life; sp[7] = 1;
+        for (int k = 0; k < 11; ++k) atomicAdd(&g_sweep_prof[k], (unsigned long long)sp[k]);
+    }
+#endif
 }
 
 // ----------------------------------------------------------------------------------------
