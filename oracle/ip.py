@@ -61,7 +61,7 @@ def centering(y1, y2, dy1, dy2, a_aff):
     return mu, sigma
 
 
-def interior_point_solve(tab: lcp.LinTable, z, th, opts: IPOptions, trace=None):
+def interior_point_solve(tab: lcp.LinTable, z, th, opts: IPOptions, trace=None, counters=None):
     """One `interior_point_solve!(ip[t])`.  z is updated in place.
 
     Returns (status, iterations, dz) with dz = dz/dth = -rz^-1 rth (nz x nth) on
@@ -110,6 +110,12 @@ def interior_point_solve(tab: lcp.LinTable, z, th, opts: IPOptions, trace=None):
             if r_c <= r_vio or k_c <= k_vio:
                 break
             z += alpha * opts.ls_scale ** i * D   # [spec] back off
+        else:
+            # [spec] max_ls evaluations without a decrease: z has moved once more and is NOT re-evaluated - the violations
+            # carried into the next iteration belong to the last evaluated point.  Kept because the upstream loop this spec
+            # models is written that way; counted for tests/test_oracle_line_search.py.
+            if counters is not None:
+                counters["ls_exhausted"] = counters.get("ls_exhausted", 0) + 1
         k_vio, r_vio = k_c, r_c
         if trace is not None:
             trace.append((z.copy(), r_vio, k_vio, alpha, reg))
