@@ -48,6 +48,8 @@ struct Knobs {
     int async_mem = 0;           // CIMPC_ASYNC_MEM: 1 uncached, 2 fine-grained exchange buffers (experiment)
     int spec_all = -1;           // CIMPC_SPEC_ALL
     int spec_tail = 3;           // CIMPC_SPEC_TAIL
+    int spec_first = 1;          // CIMPC_SPEC_FIRST: step lengths of the first line-search round of a solve's first Newton iteration
+    int spec_mid = -1;           // CIMPC_SPEC_MID: previous search depth from which a rollout starts with three candidates (-1: by batch size)
     int iter_cap = 28;           // CIMPC_ITER_CAP (B = 512: 24 / 28 / 32 / 36 -> 11.8 / 11.5 / 11.8 / 11.75 ms with the fused-broadcast sweep)
     int waves = 0;               // CIMPC_WAVES (0: by batch size)
     int kkt_overlap = -1;        // CIMPC_KKT_OVERLAP (-1: by batch size)
@@ -71,6 +73,8 @@ struct Knobs {
         async_mem = env_int("CIMPC_ASYNC_MEM", async_mem);
         spec_all = env_int("CIMPC_SPEC_ALL", spec_all);
         spec_tail = env_int("CIMPC_SPEC_TAIL", spec_tail);
+        spec_first = env_int("CIMPC_SPEC_FIRST", spec_first);
+        spec_mid = env_int("CIMPC_SPEC_MID", spec_mid);
         iter_cap = std::max(1, env_int("CIMPC_ITER_CAP", iter_cap));
         waves = env_int("CIMPC_WAVES", waves);
         kkt_overlap = env_int("CIMPC_KKT_OVERLAP", kkt_overlap);
@@ -536,6 +540,11 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     // goes through the reference-default dense LU
     select_kkt_backend(h);
     S.spec_all = h->kn.spec_all >= 0 ? h->kn.spec_all : (d.B <= 128 ? 3 : 8);
+    S.spec_first = h->kn.spec_first;
+    // large batches: a rollout whose previous search needed a back-off starts the next one with 1, 1/2, 1/4 together (one
+    // round less per Newton iteration for 0.9 more evaluated sweeps per step: B = 512 11.4 -> 10.9 ms); small batches already
+    // evaluate all seven step lengths from depth 3 on
+    S.spec_mid = h->kn.spec_mid >= 0 ? h->kn.spec_mid : (d.B > 128 ? 1 : 8);
     // small batches: one wave per workgroup keeps every problem on its own CU (latency);
     // large batches: 4 waves share one staged table (throughput)
     h->waves = (B * H >= 4096) ? 4 : 1;

@@ -153,10 +153,20 @@ __device__ __forceinline__ void apply_step(const NewtonDev& S, const TrajDev& ds
 template <class Sync>
 __device__ __forceinline__ void start_line_search(const NewtonDev& S, int b, int mode, int lane, int nt) {
     const size_t sb0 = (size_t)b * CS;
-    const int n = (S.newton_l[b] > 0 && S.ls_iter[b] >= S.spec_all) ? 7 : 1;
+    // How many step lengths the first round evaluates: the reference accepts the FIRST alpha = 2^-it that passes, so a
+    // batch always starts at it = 0; a rollout whose previous search went to it >= spec_mid / spec_all starts with three /
+    // all seven candidates (one round instead of two / three), the first iteration of a solve with spec_first.
+    int n = 1;
+    {
+        const int prev = S.ls_iter[b];
+        if (S.newton_l[b] == 0) n = S.spec_first;
+        else if (prev >= S.spec_all) n = 7;
+        else if (prev >= S.spec_mid) n = 3;
+        n = (n >= 7) ? 7 : (n >= 3) ? 3 : 1;
+    }
     Sync::sync();
     for (int c = 0; c < n; ++c) apply_step<Sync>(S, S.cand, S.nu_cand, sb0 + c, b, ls_alpha(c), lane, nt);
-    if (lane == 0) { S.alpha[b] = 1.0; S.ls_iter[b] = 0; S.stage[b] = (n == 7) ? STAGE_LS7 : STAGE_LS0; }
+    if (lane == 0) { S.alpha[b] = 1.0; S.ls_iter[b] = 0; S.stage[b] = (n == 7) ? STAGE_LS7 : (n == 3) ? STAGE_LS3 : STAGE_LS0; }
     if (mode == 2) {
         enqueue_eval_async<Sync>(S, sb0, 0, n, b, lane, nt);
     } else {
@@ -300,7 +310,7 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
     }
     const int stage = S.stage[b];
     if (stage == STAGE_DONE || stage == STAGE_KKT) return;
-    const int ncand = (stage == STAGE_LS1) ? 2 : (stage == STAGE_LS2) ? 4 : (stage == STAGE_LS7) ? 7 : 1;
+    const int ncand = (stage == STAGE_LS1) ? 2 : (stage == STAGE_LS2) ? 4 : (stage == STAGE_LS7) ? 7 : (stage == STAGE_LS3) ? 3 : 1;
     const int it0 = (stage == STAGE_LS1) ? 1 : (stage == STAGE_LS2) ? 3 : 0;      // first iterate (= slot) of the batch
     if (S.need_sweep[sb0 + it0] == 0) return;    // nothing was evaluated for this rollout
     if constexpr (!ASYNC) {   // an interior-point solve of this evaluation is still parked: wait for the next round

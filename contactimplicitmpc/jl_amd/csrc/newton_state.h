@@ -8,7 +8,7 @@
 namespace cimpc {
 constexpr int NLOG = 16;       // Newton iterations kept per rollout in the status log
 
-enum Stage : int { STAGE_DONE = 0, STAGE_INIT = 1, STAGE_LS0 = 2, STAGE_KKT = 3, STAGE_LS1 = 4, STAGE_LS2 = 5, STAGE_LS7 = 6 };
+enum Stage : int { STAGE_DONE = 0, STAGE_INIT = 1, STAGE_LS0 = 2, STAGE_KKT = 3, STAGE_LS1 = 4, STAGE_LS2 = 5, STAGE_LS7 = 6, STAGE_LS3 = 7 };
 constexpr int CS = 7;   // evaluation slots per rollout (speculative line search, newton_impl.h)
 
 struct TrajDev {
@@ -79,6 +79,8 @@ struct NewtonDev {
     double r_tol, beta_init, kappa;
     int max_iter;
     double* nlog;      // [B][NLOG][4] per accepted Newton iteration: alpha, |r|_1/N before, after, line-search iter (print_status, newton.jl:290-301)
+    int spec_first;    // candidates of the FIRST line-search round of a solve's first Newton iteration (1, 3 or 7): no history yet
+    int spec_mid;      // previous search ended at iter >= spec_mid: the first round evaluates 1, 1/2, 1/4 together (STAGE_LS3)
     int spec_all;      // a rollout whose previous line search ended at iter >= spec_all evaluates all 7 step lengths at once
 };
 
