@@ -327,7 +327,8 @@ static void select_kkt_backend(cimpc_ctx* h) {
     const bool cfg = h->dm.mode == CIMPC_MODE_CONFIGURATION;
     const int want = h->nt.kkt_backend;
     const bool velocity = h->S.V != nullptr;
-    h->use_dense = !cfg || want == CIMPC_KKT_DENSE_LU || want == CIMPC_KKT_BANDED_LDL || velocity;
+    // (dimension sets without a compiled condensed solve - the runtime-dimension path - take the banded LDL^T / dense LU)
+    h->use_dense = !cfg || want == CIMPC_KKT_DENSE_LU || want == CIMPC_KKT_BANDED_LDL || velocity || !kkt_condensed_available(h->S);
     h->use_banded = h->use_dense && cfg && want != CIMPC_KKT_DENSE_LU && kkt_banded_available(h->S);
     h->cf_reduce = !cfg && want != CIMPC_KKT_DENSE_LU && h->cf_tiny && kkt_cf_reduce_available(h->S);
     h->use_mixed = want == CIMPC_KKT_CONDENSED_MIXED && !h->use_dense && kkt_mixed_available(h->S);
@@ -421,7 +422,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     if (ip_kernel_info(&h->dm, &h->ki) != CIMPC_OK) {
         delete h;
         return fail(nullptr, CIMPC_ERR_INVALID,
-                    "no kernel instantiation for these model dimensions (built: pushbot, hopper_2D, hopper_3D, walledcartpole, particle, particle_2D, "
+                    "model dimensions outside the runtime-dimension kernel (nx, ny <= 64) and without a compiled set (built: pushbot, hopper_2D, hopper_3D, walledcartpole, particle, particle_2D, "
                     "quadruped, flamingo, centroidal_quadruped are built)");
     }
     h->nx = d.nq;

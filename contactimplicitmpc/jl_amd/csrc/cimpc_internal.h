@@ -152,6 +152,7 @@ struct KernelInfo {
     int lds_table;    // doubles
     int lds_group;    // doubles of per-problem scratch
     int tab_size;     // doubles per knot
+    int generic;      // 1: no compiled lane-group kernel for these dimensions - the runtime-dimension kernel (ip_generic.hip) serves them
 };
 
 // Opt a kernel in to more than 64 KiB of dynamic LDS (gfx950: 160 KiB per CU).  The attribute call is not free,
@@ -172,5 +173,9 @@ inline int lds_opt_in(LdsOptIn& cache, const void* kernel, size_t lds) {
 int ip_kernel_info(const cimpc_dims* dm, KernelInfo* info);
 // launches the queue kernel followed by the sensitivity kernel
 int launch_ip_sweep(const cimpc_dims* dm, const IpParams& p, int waves, hipStream_t s);
+// runtime-dimension fallback (ip_generic.hip): nx, ny <= 64, one problem per wavefront
+bool ip_generic_available(const cimpc_dims* dm);
+void ip_generic_info(const cimpc_dims* dm, KernelInfo* info);
+int launch_ip_generic(const cimpc_dims* dm, const IpParams& p, hipStream_t s);
 
 }  // namespace cimpc

@@ -27,10 +27,16 @@ int ip_kernel_info(const cimpc_dims* dm, KernelInfo* info) {
 #define X(name, q, u, w, c, b)                                                          \
     if (dm->nq == q && dm->nu == u && dm->nw == w && dm->nc == c && dm->nb == b) {      \
         ip_info_##name(dm->mode, info);                                                 \
+        info->generic = 0;                                                              \
         return CIMPC_OK;                                                                \
     }
     CIMPC_MODELS(X)
 #undef X
+    if (ip_generic_available(dm)) {      // any other model with nx, ny <= 64: runtime-dimension kernel
+        ip_generic_info(dm, info);
+        info->generic = 1;
+        return CIMPC_OK;
+    }
     return CIMPC_ERR_INVALID;
 }
 
@@ -40,7 +46,7 @@ int launch_ip_sweep(const cimpc_dims* dm, const IpParams& p, int waves, hipStrea
         return ip_launch_##name(dm->mode, p, waves, s);
     CIMPC_MODELS(X)
 #undef X
-    return CIMPC_ERR_INVALID;
+    return launch_ip_generic(dm, p, s);
 }
 
 // asynchronous single-launch Newton solve (newton_async_impl.h): :configuration mode, nq, nu <= 16

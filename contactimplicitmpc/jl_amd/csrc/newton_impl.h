@@ -202,7 +202,7 @@ __device__ __forceinline__ const double* dz_eff(const NewtonDev& S, int b, int i
 template <int NQ, int NU, bool CF>
 __device__ double slot_residual(const NewtonDev& S, size_t sb, int b, const int* eff, int tid, int nt) {
     const cimpc_dims& m = S.dm;
-    constexpr int nq = NQ, nu = NU;
+    const int nq = NQ > 0 ? NQ : m.nq, nu = NQ > 0 ? NU : m.nu;      // NQ = 0: runtime dimensions (models without a compiled set)
     constexpr bool cf = CF;
     const int H = m.H, nc = m.nc, nb = m.nb, nr = S.nr;
     const int nd = cf ? nq + nc + nb : nq;       // compile-time in :configuration mode

@@ -391,7 +391,7 @@ int launch_resid_decide(const NewtonDev& S, hipStream_t s) {
 #define X(q, u) if (nq == q && nu == u) return launch_resid_t<q, u>(S, s);
     CIMPC_NQNU(X)
 #undef X
-    return CIMPC_ERR_INVALID;
+    return launch_resid_t<0, 0>(S, s);        // runtime dimensions (models without a compiled set)
 }
 template <int NQ, int NU>
 static int launch_kkt_packed_t(const NewtonDev& S, const KktArgs& K, const int* list, int n, const int* n_dev, hipStream_t s, bool latency) {
@@ -566,6 +566,13 @@ bool kkt_cf_reduce_available(const NewtonDev& S) {   // the reduced problem must
     return false;
 }
 
+bool kkt_condensed_available(const NewtonDev& S) {      // a compiled condensed solve exists for these (nq, nu)
+    const int nq = S.dm.nq, nu = S.dm.nu;
+#define X(q, u) if (nq == q && nu == u) return true;
+    CIMPC_NQNU(X)
+#undef X
+    return false;
+}
 int launch_kkt(const NewtonDev& S, hipStream_t s) {
     KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 1};
     return launch_kkt_any(S, K, s);

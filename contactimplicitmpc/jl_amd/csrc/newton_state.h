@@ -101,6 +101,7 @@ int launch_reset(const NewtonDev& nd, const double* q0, const double* q1, int wa
 int launch_resid_decide(const NewtonDev& nd, hipStream_t s);
 int launch_enqueue_all(const NewtonDev& nd, hipStream_t s);   // B3 seam: queue slot 0 of every rollout
 int launch_kkt(const NewtonDev& nd, hipStream_t s);
+bool kkt_condensed_available(const NewtonDev& nd);
 // mixed precision: block products on the fp32 MFMA, fp64 matrix-free refinement, fp64 fallback (newton_kernels.hip)
 bool kkt_mixed_available(const NewtonDev& nd);
 size_t kkt_mixed_workspace_doubles(const NewtonDev& nd);

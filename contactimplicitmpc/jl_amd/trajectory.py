@@ -111,6 +111,7 @@ HOPPER_3D = dict(nq=7, nu=3, nw=3, nc=1, nb=4)      # hopper_3D/model.jl:96-99
 WALLEDCARTPOLE = dict(nq=4, nu=1, nw=4, nc=2, nb=4)  # walledcartpole/model.jl:143-147
 PARTICLE = dict(nq=3, nu=3, nw=3, nc=1, nb=4)       # particle/model.jl:114-117
 PARTICLE_2D = dict(nq=2, nu=2, nw=2, nc=1, nb=2)    # particle_2D/model.jl
+CENTROIDAL_WALL = dict(nq=18, nu=12, nw=3, nc=8, nb=32)   # centroidal_quadruped_wall (nz = 114, ny = 48: runtime-dimension kernel)
 
 
 @dataclass

@@ -3,4 +3,4 @@
 and the device path are fed from the same layouts."""
 from contactimplicitmpc.jl_amd.trajectory import (Dims, MODE_CONFIGURATION, MODE_CONFIGURATIONFORCE,  # noqa: F401
                                                   PUSHBOT, HOPPER_2D, QUADRUPED, CENTROIDAL, FLAMINGO, HOPPER_3D,
-                                                  WALLEDCARTPOLE, PARTICLE, PARTICLE_2D)
+                                                  WALLEDCARTPOLE, PARTICLE, PARTICLE_2D, CENTROIDAL_WALL)

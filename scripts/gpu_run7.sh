@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-bash scripts/sweep_knobs.sh CIMPC_SPEC_MID=1 "CIMPC_SPEC_MID=1 CIMPC_DEPTH=2" "CIMPC_SPEC_MID=1 CIMPC_ASYNC_TAIL=64" "CIMPC_SPEC_MID=1 CIMPC_ASYNC_TAIL=110" "CIMPC_SPEC_MID=1 CIMPC_ITER_CAP=24" "CIMPC_SPEC_MID=1 CIMPC_ITER_CAP=32" "CIMPC_SPEC_MID=1 CIMPC_SPEC_TAIL=2" "CIMPC_SPEC_MID=1 CIMPC_KKT_PIPE=1" 2>&1 | tee gpurun_out/sweep_r02l.log
+L=$GRAFT_REPO_ROOT/contactimplicitmpc/jl_amd
+bash scripts/sweep_knobs.sh CIMPC_LIB=$L/libcimpc_v1.so CIMPC_LIB=$L/libcimpc_v2.so 2>&1 | tee gpurun_out/sweep_r02m.log

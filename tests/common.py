@@ -5,10 +5,11 @@ import numpy as np
 from oracle import ip as oip
 from oracle import lcp, newton as onewton, synth
 from oracle.dims import (Dims, QUADRUPED, HOPPER_2D, PUSHBOT, CENTROIDAL, FLAMINGO, HOPPER_3D, WALLEDCARTPOLE, PARTICLE,  # noqa: F401
-                         PARTICLE_2D)
+                         PARTICLE_2D, CENTROIDAL_WALL)
 
 MODELS = dict(quadruped=QUADRUPED, hopper=HOPPER_2D, pushbot=PUSHBOT, centroidal=CENTROIDAL, flamingo=FLAMINGO, hopper3d=HOPPER_3D,
-              walledcartpole=WALLEDCARTPOLE, particle=PARTICLE, particle2d=PARTICLE_2D)
+              walledcartpole=WALLEDCARTPOLE, particle=PARTICLE, particle2d=PARTICLE_2D, centroidal_wall=CENTROIDAL_WALL,
+              anydims=dict(nq=5, nu=3, nw=2, nc=3, nb=6))       # a dimension set no kernel was compiled for
 
 
 def make_case(model="quadruped", mode=0, H_ref=12, H=6, B=3, seed=0, perturb=2e-2, kappa=2e-4):

@@ -28,6 +28,9 @@ pytestmark = pytest.mark.gpu
     ("walledcartpole", 1, 3, 5, 8),      # a single-launch kernel - lock-step rounds only
     ("particle", 0, 3, 5, 8),
     ("particle2d", 1, 3, 4, 6),
+    ("anydims", 0, 3, 5, 8),             # no compiled set: the runtime-dimension kernel (ip_generic.hip)
+    ("anydims", 1, 3, 5, 8),
+    ("centroidal_wall", 0, 2, 4, 6),     # ny = 48 > 32 lanes: runtime-dimension kernel only
 ])
 def test_implicit_dynamics_matches_oracle(gpu_required, model, mode, B, H, H_ref):
     d, prob, tabs, rollouts = make_case(model, mode, H_ref=H_ref, H=H, B=B, seed=3)
@@ -92,6 +95,8 @@ def test_newton_solve_matches_oracle(gpu_required):
     ("hopper3d", 10, 12, False),     # (nq, nu) = (7, 3): hopper_3D
     ("walledcartpole", 8, 10, False),    # (4, 1)
     ("particle", 8, 10, True),       # (3, 3)
+    ("anydims", 8, 10, False),       # runtime dimensions end to end: generic sweep + runtime residual kernel + banded LDL^T / dense LU
+    ("centroidal_wall", 5, 6, True),
 ])
 def test_newton_solve_other_models(gpu_required, model, H, H_ref, dense_q):
     u1, it, rn, traj, cnt, res = _newton_case(perturb=5e-3, r_tol=1e-5, max_iter=4, seed=23, B=4, H=H, H_ref=H_ref,

@@ -36,7 +36,8 @@ def test_every_reference_model_is_covered_by_the_generic_dimension_rule():
     others = {"hopper_3D": dict(nq=7, nu=3, nw=3, nc=1, nb=4), "point_foot_quadruped": dict(nq=18, nu=12, nw=3, nc=4, nb=16),
               "centroidal_quadruped_box": dict(nq=18, nu=12, nw=3, nc=4, nb=16), "walledcartpole": dict(nq=4, nu=1, nw=4, nc=2, nb=4),
               "particle": dict(nq=3, nu=3, nw=3, nc=1, nb=4),
-              "particle_2D": dict(nq=2, nu=2, nw=2, nc=1, nb=2)}
+              "particle_2D": dict(nq=2, nu=2, nw=2, nc=1, nb=2),
+              "centroidal_quadruped_wall": dict(nq=18, nu=12, nw=3, nc=8, nb=32)}
     for name, dm in others.items():
         d = Dims(**dm)
         assert SHAPES[name]["rz_shape"] == [d.nz, d.nz], name
