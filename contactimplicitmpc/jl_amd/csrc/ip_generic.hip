@@ -11,6 +11,7 @@
 // It consumes the lock-step queues exactly like ip_queue_kernel (items bucketed by reference knot, done_count per slot), so
 // the Newton rounds above it do not know which sweep kernel ran.
 #include <algorithm>
+#include <cstdio>
 
 #include "cimpc_internal.h"
 #include "lin_table.h"
@@ -26,20 +27,28 @@ __device__ __forceinline__ void wfence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+// Wave-uniform values are handed to the compiler AS uniform (v_readfirstlane -> SGPR): every loop / branch of this kernel
+// that depends on a reduction result is then a scalar branch.  (The whole wavefront is always active here, so lane 0 is the
+// first active lane.)  The queue is partitioned statically for the same reason - see the knot loop below.
+__device__ __forceinline__ double uniform(double v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane(__double2loint(v));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double((int)hi, (int)lo);
+}
 __device__ __forceinline__ double wmax(double v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
-    return v;
+    return uniform(v);
 }
 __device__ __forceinline__ double wmin(double v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m, 64));
-    return v;
+    return uniform(v);
 }
 __device__ __forceinline__ double wsum(double v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return __shfl(v, 0, 64);      // every lane holds lane 0's bits
+    return uniform(v);            // every lane holds lane 0's bits
 }
 
 struct Gen {
@@ -220,17 +229,16 @@ __global__ __launch_bounds__(64) void ip_generic_kernel(IpParams p, GenDims gd) 
         const int n = *qcount(p.Q, par, knot);
         if (n == 0) continue;
         const int* items = p.Q.items + ((size_t)par * K + knot) * cap;
-        int* head = qhead(p.Q, knot);
         S.tab = p.tab + (size_t)knot * L.size;
         const double* tVec = S.tab + L.oVec;
         S.ry2 = tVec[LinLayout::V_RY2 * GW + l]; S.ry1d = tVec[LinLayout::V_RY1D * GW + l]; S.caibd = tVec[LinLayout::V_CAIBD * GW + l];
         S.rdyn0 = tVec[LinLayout::V_RDYN0 * GW + l]; S.rrst0 = tVec[LinLayout::V_RRST0 * GW + l];
         S.x0 = tVec[LinLayout::V_X0 * GW + l]; S.y10 = tVec[LinLayout::V_Y10 * GW + l]; S.y20 = tVec[LinLayout::V_Y20 * GW + l];
-        while (true) {
-            int idx = 0;
-            if (l == 0) idx = atomicAdd(head, 1);
-            idx = __shfl(idx, 0, 64);
-            if (idx >= n) break;
+        // static partition of the knot's queue over the workgroups.  (A dynamic pull - lane 0 takes an index with atomicAdd and
+        // broadcasts it - hung on the GPU: hipcc structurised that loop of a single-wave workgroup as a divergent loop whose
+        // latch never repeats the atomic, so lanes 1..63 re-read a stale index for ever.  The loop below has scalar control only.)
+        const int G0 = (int)gridDim.x;
+        for (int idx = (int)blockIdx.x; idx < n; idx += G0) {
             const int prob = items[idx];
             const int sb = prob / p.H, i = prob - sb * p.H;
             const size_t pi = (size_t)prob;

@@ -59,11 +59,17 @@ def make_problem(dims: Dims, H_ref: int, seed: int = 0, h: float = 0.015625, mu:
                h=h, mu=mu, kappa=kappa)
     # contact Jacobians drift slowly along the gait; like a legged robot each contact
     # point depends on the floating base (first 3 coordinates) and on its own leg joints
+    # Models with more contact rows than coordinates (centroidal_quadruped_wall: 8 contacts = 4 feet x {floor, wall}) pair the
+    # contacts up per foot: the two contacts of a foot share its leg columns and are in stance on opposite halves of the gait,
+    # so that the active set never over-constrains q (all contacts of such a model active at once has no solution).
+    paired = nc * (1 + nt) > nq
+    nfeet = (nc + 1) // 2 if paired else max(nc, 1)
     def _sparsify(J, rows_per_contact):
         mask = np.zeros_like(J)
-        nleg = max((nq - 3) // max(nc, 1), 1)
+        nleg = max((nq - 3) // nfeet, 1)
         for c in range(nc):
-            cols = list(range(min(3, nq))) + [min(3 + c * nleg + k, nq - 1) for k in range(nleg)]
+            f = c % nfeet
+            cols = list(range(min(3, nq))) + [min(3 + f * nleg + k, nq - 1) for k in range(nleg)]
             mask[c * rows_per_contact:(c + 1) * rows_per_contact, cols] = 1.0
         return J * mask
     Jn0 = _sparsify(rng.standard_normal((nc, nq)) * 0.6, 1)
@@ -72,6 +78,8 @@ def make_problem(dims: Dims, H_ref: int, seed: int = 0, h: float = 0.015625, mu:
     Jt1 = _sparsify(rng.standard_normal((nc * nt, nq)) * 0.2, nt)
     # stance pattern: each contact is active on a contiguous half of the gait
     stance_phase = rng.uniform(0, 1, nc)
+    if paired:
+        stance_phase = np.array([stance_phase[c % nfeet] + 0.5 * (c // nfeet) for c in range(nc)])
     for t in range(H_ref):
         s = np.sin(2 * np.pi * t / H_ref)
         Jn = Jn0 + s * Jn1

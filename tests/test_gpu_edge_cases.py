@@ -48,8 +48,10 @@ def test_bad_arguments_are_rejected(gpu_required):
         s.set_window(bad)
     with pytest.raises(CimpcError):
         s.set_linearization(0, prob["z0"][0], prob["th0"][0], prob["r0"][0], prob["rz0"][0], prob["rth0"][0])
-    with pytest.raises(CimpcError):                     # dimensions no kernel is instantiated for
-        CIMPCSolver(5, 3, 2, 1, 2, 8, 6, B=1, mode=0)
+    with pytest.raises(CimpcError):                     # beyond the runtime-dimension kernel (nq, ny <= 64)
+        CIMPCSolver(70, 3, 2, 1, 2, 8, 6, B=1, mode=0)
+    with pytest.raises(CimpcError):
+        CIMPCSolver(5, 3, 2, 12, 48, 8, 6, B=1, mode=0)      # ny = 72
 
 
 def test_single_rollout_minimum_horizon_and_wrapping_window(gpu_required):
