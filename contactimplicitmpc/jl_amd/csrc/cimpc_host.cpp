@@ -65,6 +65,10 @@ struct Knobs {
     bool debug_rounds = false;   // CIMPC_DEBUG_ROUNDS
     bool kkt_packed = true;      // CIMPC_KKT_PACKED
     int tail_div = 8;            // CIMPC_TAIL_DIV
+    int kkt_chain = -1;          // CIMPC_KKT_CHAIN: chained rounds ({sweep || KKT} -> sweep of the new candidates -> residual) when at least this
+                                 // percentage of the round's rollouts start a Newton iteration; -1 = never
+    int kkt_pipe = -1;           // CIMPC_KKT_PIPE: two-wave pipelined KKT kernel 0 never, 1 always, -1 where the solve is on the critical path
+    int kkt_pipe_max = 128;      // CIMPC_KKT_PIPE_MAX: ... and at most this many rollouts start an iteration (it takes twice the CUs)
 
     static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
     void read_environment() {
@@ -91,6 +95,9 @@ struct Knobs {
         debug_rounds = getenv("CIMPC_DEBUG_ROUNDS") != nullptr;
         kkt_packed = env_int("CIMPC_KKT_PACKED", 1) != 0;
         tail_div = env_int("CIMPC_TAIL_DIV", tail_div);
+        kkt_chain = env_int("CIMPC_KKT_CHAIN", kkt_chain);
+        kkt_pipe = env_int("CIMPC_KKT_PIPE", kkt_pipe);
+        kkt_pipe_max = env_int("CIMPC_KKT_PIPE_MAX", kkt_pipe_max);
     }
 };
 
@@ -552,7 +559,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     // the single-launch solve runs its residual jobs on the whole workgroup: 4 waves also for small batches
     // (measured B = 8: 5.2 -> 4.4 ms, B = 64: 8.5 -> 7.5 ms)
     if (h->async_on && (h->async_mode == 1 || (h->async_mode == 2 && B >= 4 && B <= 128))) h->waves = 4;
-    if (h->kn.waves == 1 || h->kn.waves == 2 || h->kn.waves == 4) h->waves = h->kn.waves;
+    if (h->kn.waves == 1 || h->kn.waves == 2 || (h->kn.waves >= 4 && h->kn.waves <= 8)) h->waves = h->kn.waves;   // (5..8: builds with CIMPC_SWEEP_THREADS > 256)
     h->kkt_overlap = B >= 64;
     if (h->kn.kkt_overlap >= 0) h->kkt_overlap = h->kn.kkt_overlap != 0;
     if (dev_alloc(h, &h->d_ring, 32) != CIMPC_OK ||
@@ -580,7 +587,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         w = std::max<size_t>(w, std::min<size_t>(d.H_ref, nprob));
         // (32-lane models run one wave per SIMD - 512 registers - i.e. 4 waves per CU; the asynchronous launcher
         //  clamps its grid to the occupancy the runtime reports in any case)
-        const size_t resident = (size_t)256 * ((h->ki.G == 16 ? 8 : 4) / h->waves);
+        const size_t resident = (size_t)256 * std::max(1, (h->ki.G == 16 ? (h->waves > 4 ? 2 * h->waves : 8) : 4) / h->waves);
         h->wpk = (int)std::max<size_t>(1, std::min<size_t>(w, resident));
         if (h->kn.sweep_wgs > 0) h->wpk = h->kn.sweep_wgs;
         // asynchronous solve: the same resident set plus dedicated residual/KKT workgroups
@@ -906,8 +913,8 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     // ---- one persistent launch: every rollout advances on its own chain (newton_async_impl.h).  Entered
     //      from the start (from_reset) or with the rollouts the lock-step rounds left active (hybrid). ----
-    auto run_async = [&](bool from_reset, long long rounds_before) -> int {
-        IpQueues LQ = h->Q; LQ.par = (int)(rounds_before & 1);      // lock-step queue of the round that would come next
+    auto run_async = [&](bool from_reset, long long rounds_before, int next_par = -1) -> int {
+        IpQueues LQ = h->Q; LQ.par = next_par >= 0 ? next_par : (int)(rounds_before & 1);      // lock-step queue of the round that would come next
         hipStream_t st = h->external_stream ? h->stream : h->rs.st;
         const size_t K = h->Q.K;
         if (h->async_dirty) {     // entries are reset by their consumers; only an aborted solve leaves some behind
@@ -955,7 +962,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         long long solved_before = 0;      // interior-point problems the lock-step rounds had solved (profiling only)
         if (h->prof_on && !from_reset) HIP_TRY(h, hipMemcpy(&solved_before, S.stats + 1, sizeof(long long), hipMemcpyDeviceToHost));
         prof_begin(h, PC_ASYNC, st);
-        rc2 = launch_newton_async(&h->dm, p, Sk, h->waves, h->a_grid, st);
+        rc2 = launch_newton_async(&h->dm, p, Sk, std::min(h->waves, 4), h->a_grid, st);
         prof_end(h, st);
         if (rc2 != CIMPC_OK) return fail(h, rc2, "asynchronous newton launch failed");
         // The host watches the persistent kernel: the reference's wall-clock budget ends the loop silently
@@ -1018,6 +1025,12 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     long long launched = 0, completed = 0, rounds = 0;
     const bool dbg_rounds = h->kn.debug_rounds;
     int last_kkt = 0, last_sweep = h->dm.B;
+    // Queue parity is tracked explicitly: a plain round consumes Q[par] and leaves the next round's requests in Q[par ^ 1]; a
+    // CHAINED round - {sweep of Q[par] || KKT} -> sweep of Q[par ^ 1] (the candidates the KKT stage just requested, and what
+    // the first sweep parked) -> residual - ends with the next round's requests in Q[par] again.  Chaining takes a rollout
+    // through a whole Newton iteration (KKT, evaluation of the first step lengths, decision) in ONE round; it pays where the
+    // rounds are latency bound (the KKT recursion and the slowest interior-point solve, not the amount of work, set their length).
+    int cur_par = 0, list_par = 0;
     auto launch_round = [&](long long r) -> int {
         // [KKT for rollouts that start an iteration] || sweep -> residual + line-search decision
         const int slot = (int)(r & 1);
@@ -1028,13 +1041,17 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         Sk.host_flag = h->h_ring_dev + 8 * slot;
         Sk.A.n_done = hybrid ? h->a_ctrl + 2 * (size_t)h->Q.K * QPAD + 8 : nullptr;
         Sk.round_stamp = (int)(r + 1);
-        Sk.WQ = h->Q; Sk.WQ.par = (int)(r & 1);       // round parity selects the queue being consumed
+        const int par = depth > 1 ? (int)(r & 1) : cur_par;
+        Sk.WQ = h->Q; Sk.WQ.par = par;       // the queue being consumed
         const bool kkt = (r > 0) && (depth > 1 || last_kkt > 0);
+        const bool chain = kkt && h->kkt_overlap && depth == 1 && h->kn.kkt_chain >= 0 &&
+                           (long long)last_kkt * 100 >= (long long)h->kn.kkt_chain * (last_kkt + last_sweep);
+        const int pipe = h->kn.kkt_pipe >= 0 ? h->kn.kkt_pipe : ((chain || !h->kkt_overlap) && last_kkt <= h->kn.kkt_pipe_max) ? 1 : 0;
         if (kkt && !h->kkt_overlap) {   // small batches: latency matters, keep the KKT result in this round
             Sk.kkt_same_round = 1;
             prof_begin(h, PC_KKT, sb.st);
             // (same compact list / packed or pipelined kernel as the overlapped path)
-            int rr = (h->use_dense || h->use_mixed) ? launch_kkt_general(h, Sk, sb.st) : launch_kkt_packed(Sk, last_kkt, Sk.WQ.par ^ 1, sb.st);
+            int rr = (h->use_dense || h->use_mixed) ? launch_kkt_general(h, Sk, sb.st) : launch_kkt_packed(Sk, last_kkt, depth > 1 ? par ^ 1 : list_par, sb.st, nullptr, pipe);
             prof_end(h, sb.st);
             if (rr != CIMPC_OK) return fail(h, rr, "kkt launch failed");
         }
@@ -1044,11 +1061,12 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             // BEFORE the sweep: the other order was measured 10 % slower - the KKT recursion is the longer leg
             // of most rounds.)
             if (depth > 1 && hipStreamWaitEvent(sb.st_kkt, sb.ev_round, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "fork failed");
+            if (chain) Sk.kkt_same_round = 2;      // its candidates are evaluated in this round: not a request for the next one
             prof_begin(h, PC_KKT, sb.st_kkt);
             const bool packed = h->kn.kkt_packed;
             // the list was built by the residual kernel of the previous round (its queue parity)
             int rk = (h->use_dense || h->use_mixed) ? launch_kkt_general(h, Sk, sb.st_kkt)
-                                  : packed ? launch_kkt_packed(Sk, last_kkt, Sk.WQ.par ^ 1, sb.st_kkt, depth > 1 ? Sk.counters_next + 1 : nullptr)
+                                  : packed ? launch_kkt_packed(Sk, last_kkt, depth > 1 ? par ^ 1 : list_par, sb.st_kkt, depth > 1 ? Sk.counters_next + 1 : nullptr, pipe)
                                            : launch_kkt(Sk, sb.st_kkt);
             prof_end(h, sb.st_kkt);
             if (rk != CIMPC_OK) return fail(h, rk, "kkt launch failed");
@@ -1058,14 +1076,27 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         // it only adds rounds, so a round that serves few rollouts lets every solve run to the end
         const int tail_div = h->kn.tail_div;
         const int cap = (tail_div > 0 && last_sweep * tail_div <= h->dm.B) ? h->ip.max_iter : h->iter_cap;
-        int rr = run_sweep(h, Sk.WQ.par, d_cnt + 2, nullptr, sb.st, cap);
+        int rr = CIMPC_OK;
+        if (!chain || last_sweep > 0) rr = run_sweep(h, par, d_cnt + 2, nullptr, sb.st, cap);
         if (rr != CIMPC_OK) return rr;
         if (kkt && h->kkt_overlap && hipStreamWaitEvent(sb.st, sb.ev_join, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join failed");
+        if (chain) {
+            // Q[par] is consumed: recycle it (the second sweep parks into it), then evaluate what the KKT stage requested
+            rr = launch_queue_recycle(h->Q, par, sb.st);
+            if (rr != CIMPC_OK) return fail(h, rr, "queue recycle failed");
+            const int cap2 = (tail_div > 0 && (last_kkt + last_sweep) * tail_div <= h->dm.B) ? h->ip.max_iter : h->iter_cap;
+            rr = run_sweep(h, par ^ 1, d_cnt + 2, nullptr, sb.st, cap2);
+            if (rr != CIMPC_OK) return rr;
+            Sk.WQ.par = par ^ 1;         // the residual stage recycles that queue; its requests go to Q[par]
+            Sk.kkt_same_round = 0;
+        }
         prof_begin(h, PC_RESID, sb.st);
         rr = launch_resid_decide(Sk, sb.st);
         prof_end(h, sb.st);
         if (rr != CIMPC_OK) return fail(h, rr, "residual launch failed");
         if (depth > 1 && hipEventRecord(sb.ev_round, sb.st) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "round event failed");
+        list_par = Sk.WQ.par;
+        cur_par = Sk.WQ.par ^ 1;
         return CIMPC_OK;
     };
     HIP_TRY(h, hipMemsetAsync(h->Q.count, 0, 2 * h->Q.K * QPAD * sizeof(int), sb.st));
@@ -1117,7 +1148,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             if (draining && launched == completed) {
                 HIP_TRY(h, hipStreamSynchronize(sb.st));
                 HIP_TRY(h, hipStreamSynchronize(sb.st_kkt));
-                return run_async(false, rounds);
+                return run_async(false, rounds, depth > 1 ? -1 : cur_par);
             }
         }
     }

@@ -50,8 +50,14 @@ struct Model {
     static constexpr int G = (NX <= 16 && NY <= 16) ? 16 : 32;
     static_assert(NX <= 32 && NY <= 32, "lane group holds at most 32 rows");
     static constexpr int RST_LD = G + 1;                       // padded row stride of the R tile
-    static constexpr int SENS_MAX = 16;                         // converged problems a group may defer
+#ifndef CIMPC_SENS_MAX
+#define CIMPC_SENS_MAX 16
+#endif
+    static constexpr int SENS_MAX = CIMPC_SENS_MAX;             // converged problems a group may defer
 // (measured dead end: C A^-1, A^-1, Dy1 rows register-resident per knot - the 76 extra VGPRs spill, sweep launch 0.30 -> 0.47 ms)
+#ifndef CIMPC_RR_LDS
+#define CIMPC_RR_LDS 0
+#endif
 #ifndef CIMPC_SENS_ILP
 #define CIMPC_SENS_ILP 5
 #endif
@@ -84,7 +90,10 @@ struct IpSolver {
     // iterate, residual, direction
     double x, y1, y2, rdyn, rrst, rbil, Dx_, Dy1_, Dy2_;
     // factorization: column l of Q, row l of -R (strict upper part), 1/R[l,l], regularised y, 1/y1r
-    double Qc[NY], Rr[NY], rdinv, y1r, y2r, iy1r;
+    // (CIMPC_RR_LDS: row l of -R stays in the LDS tile and is read where the back-substitution uses it - 2 NY registers
+    //  fewer per lane, the price of NY LDS reads per triangular solve)
+    static constexpr bool RR_LDS = CIMPC_RR_LDS != 0 && G == 16;
+    double Qc[NY], Rr[RR_LDS ? 1 : NY], rdinv, y1r, y2r, iy1r;
 
     __device__ __forceinline__ void bind(const double* tab_, double* Rst_, int l_) {
         tab = tab_; Rst = Rst_; l = l_;
@@ -180,14 +189,16 @@ struct IpSolver {
                     Qc[r] = fma(ncoef, ak[r], Qc[r]);
                 });
             }
-            Rst[k * M::RST_LD + l] = rk;   // R[k,l], l > k (zeros elsewhere)
+            Rst[k * M::RST_LD + l] = RR_LDS ? -rk : rk;   // R[k,l], l > k (zeros elsewhere)
         });
         wave_lds_fence();
-        static_for<0, NY>([&](auto kc) {   // row l of R (transpose through the LDS tile)
-            constexpr int k = decltype(kc)::value;
-            Rr[k] = vy ? -Rst[l * M::RST_LD + k] : 0.0;      // kept negated: the back-substitution adds
-        });
-        wave_lds_fence();
+        if constexpr (!RR_LDS) {
+            static_for<0, NY>([&](auto kc) {   // row l of R (transpose through the LDS tile)
+                constexpr int k = decltype(kc)::value;
+                Rr[k] = vy ? -Rst[l * M::RST_LD + k] : 0.0;      // kept negated: the back-substitution adds
+            });
+            wave_lds_fence();
+        }
     }
 
     // t = R^-1 Q^T rhs  (qr_solve!, qr.jl:142-158); rhs lane-indexed
@@ -206,7 +217,16 @@ struct IpSolver {
         // final once step k = l + 1 is done (R[l,k] = 0 for k <= l), so x_l = c * rdinv after the loop - the same product
         // the reference forms at step l (qr.jl:150-157).
         if constexpr (G == 16) {
-            static_rfor<NY - 1>([&](auto kc) { Dpp16::backsub<decltype(kc)::value>(c, rdinv, Rr[decltype(kc)::value]); });
+            if constexpr (RR_LDS) {
+                const double* row = Rst + (vy ? l : 0) * M::RST_LD;      // (lanes beyond NY: any valid row, masked below)
+                static_rfor<NY - 1>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    const double nr = row[k];
+                    Dpp16::backsub<k>(c, rdinv, vy ? nr : 0.0);
+                });
+            } else {
+                static_rfor<NY - 1>([&](auto kc) { Dpp16::backsub<decltype(kc)::value>(c, rdinv, Rr[decltype(kc)::value]); });
+            }
         } else {
             static_rfor<NY - 1>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
@@ -387,7 +407,10 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
 // Remaining-work proportional knot pick (WG-uniform result in *s_knot, -1 = no work anywhere):
 // workgroup b takes the knot holding quantile b/gridDim of the problems not yet pulled, so the
 // workgroups spread over the knots like the work does - initially and after every hop.
-constexpr int PICK_MAXK = 256;
+#ifndef CIMPC_PICK_MAXK
+#define CIMPC_PICK_MAXK 256
+#endif
+constexpr int PICK_MAXK = CIMPC_PICK_MAXK;
 __device__ __forceinline__ int pick_knot(const IpParams& p, int* s_rem, int* s_total, int* s_knot, int tid, int wg, int nwg) {
     const int K = p.Q.K, par = p.Q.par;
     if (tid == 0) *s_total = 0;
@@ -641,8 +664,16 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
 // ----------------------------------------------------------------------------------------
 // (32-lane models: the table + group scratch fill most of a CU's LDS, one workgroup per CU is resident anyway -
 //  the kernel may then use the full 512-VGPR budget instead of spilling: centroidal 341 spilled VGPRs -> 0)
+// Occupancy of the 16-lane sweep: CIMPC_SWEEP_THREADS (largest workgroup launched) x CIMPC_SWEEP_OCC workgroups per CU.
+// Default 256 x 2 = 8 waves per CU (2 per SIMD, 256 VGPRs).
+#ifndef CIMPC_SWEEP_OCC
+#define CIMPC_SWEEP_OCC 2
+#endif
+#ifndef CIMPC_SWEEP_THREADS
+#define CIMPC_SWEEP_THREADS 256
+#endif
 template <class M>
-__global__ __launch_bounds__(256, M::G == 16 ? 2 : 1) void ip_queue_kernel(IpParams p) {
+__global__ __launch_bounds__(M::G == 16 ? CIMPC_SWEEP_THREADS : 256, M::G == 16 ? CIMPC_SWEEP_OCC : 1) void ip_queue_kernel(IpParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int s_knot, s_total, s_rem[PICK_MAXK];
     const int tid = (int)threadIdx.x;
@@ -674,7 +705,7 @@ __global__ __launch_bounds__(256, M::G == 16 ? 2 : 1) void ip_queue_kernel(IpPar
 template <class M>
 int launch_model(const IpParams& p, int waves, hipStream_t s) {
     constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G);
-    if (waves != 1 && waves != 2 && waves != 4) return CIMPC_ERR_INVALID;
+    if (waves < 1 || waves > (M::G == 16 ? CIMPC_SWEEP_THREADS : 256) / 64 || waves == 3) return CIMPC_ERR_INVALID;
     const int ppw = 64 / M::G;
     const size_t lds = (size_t)(L.size + waves * ppw * M::LDS_GROUP) * sizeof(double);
     static LdsOptIn optin;

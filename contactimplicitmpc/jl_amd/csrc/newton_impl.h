@@ -172,11 +172,12 @@ __device__ __forceinline__ void start_line_search(const NewtonDev& S, int b, int
     } else {
         // the KKT kernel runs on its own stream NEXT TO the sweep of the running round: its
         // candidates join the queue of the next round
-        const int par = S.kkt_same_round ? S.WQ.par : (S.WQ.par ^ 1);
+        // (chained round, kkt_same_round = 2: the round's second sweep consumes par ^ 1 - nothing is requested of the next round)
+        const int par = (S.kkt_same_round == 1) ? S.WQ.par : (S.WQ.par ^ 1);
         for (int c = 0; c < n; ++c) enqueue_eval(S, sb0 + c, b, par, lane, nt);
         if (lane == 0) {
             for (int c = n; c < CS; ++c) S.need_sweep[sb0 + c] = 0;
-            atomicAdd(&S.counters[0], 1);
+            if (S.kkt_same_round != 2) atomicAdd(&S.counters[0], 1);
         }
     }
 }

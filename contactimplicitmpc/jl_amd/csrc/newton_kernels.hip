@@ -386,6 +386,14 @@ static int launch_resid_t(const NewtonDev& S, hipStream_t s) {
         hipLaunchKernelGGL((resid_decide_kernel<NQ, NU, false>), dim3(S.nb_launch), dim3(CIMPC_RESID_THREADS), 0, s, S);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
+__global__ void queue_recycle_kernel(IpQueues Q, int par) {
+    const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (k < Q.K) { *qcount(Q, par, k) = 0; *qhead(Q, k) = 0; }
+}
+int launch_queue_recycle(const IpQueues& Q, int par, hipStream_t s) {
+    hipLaunchKernelGGL(queue_recycle_kernel, dim3((Q.K + 255) / 256), dim3(256), 0, s, Q, par);
+    return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+}
 int launch_resid_decide(const NewtonDev& S, hipStream_t s) {
     const int nq = S.dm.nq, nu = S.dm.nu;
 #define X(q, u) if (nq == q && nu == u) return launch_resid_t<q, u>(S, s);
@@ -394,17 +402,16 @@ int launch_resid_decide(const NewtonDev& S, hipStream_t s) {
     return launch_resid_t<0, 0>(S, s);        // runtime dimensions (models without a compiled set)
 }
 template <int NQ, int NU>
-static int launch_kkt_packed_t(const NewtonDev& S, const KktArgs& K, const int* list, int n, const int* n_dev, hipStream_t s, bool latency) {
+static int launch_kkt_packed_t(const NewtonDev& S, const KktArgs& K, const int* list, int n, const int* n_dev, hipStream_t s, bool pipe) {
     if constexpr (NQ <= 24 && NU <= 24) {
         constexpr int PACK = kkt_pack<NQ, NU>();
         const size_t lds = (size_t)PACK * kkt_lds_doubles<NQ, NU, 1>() * sizeof(double);
         static LdsOptIn optin;
         if (lds_opt_in(optin, (const void*)kkt_kernel_packed<NQ, NU>, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
-        // CIMPC_KKT_PIPE: 0 never, 1 always, unset = where the KKT solve is on the critical path (`latency`: small
-        // batches run it in the round itself).  Next to a busy sweep the pipelined kernel takes twice the CUs
-        // for half the time - measured neutral - so the packed one-wave kernel stays there.
-        static const int pipe_env = getenv("CIMPC_KKT_PIPE") ? atoi(getenv("CIMPC_KKT_PIPE")) : 2;
-        if (pipe_env == 1 || (pipe_env == 2 && latency)) {      // two wavefronts per rollout, software-pipelined forward recursion
+        // `pipe` (host schedule, CIMPC_KKT_PIPE): where the KKT solve is on the critical path (small batches, chained rounds).
+        // Next to a busy sweep the pipelined kernel takes twice the CUs for half the time - measured neutral - so the
+        // packed one-wave kernel stays there.
+        if (pipe) {      // two wavefronts per rollout, software-pipelined forward recursion
             const size_t lds2 = (size_t)kkt_lds_doubles<NQ, NU, 2>() * sizeof(double);
             static LdsOptIn optin2;
             if (lds_opt_in(optin2, (const void*)kkt_kernel_pipe<NQ, NU>, lds2) != CIMPC_OK) return CIMPC_ERR_HIP;
@@ -416,8 +423,8 @@ static int launch_kkt_packed_t(const NewtonDev& S, const KktArgs& K, const int* 
     }
     return CIMPC_ERR_INVALID;
 }
-int launch_kkt_packed(const NewtonDev& S, int n_kkt, int list_par, hipStream_t s, const int* n_dev) {
-    const bool latency = S.kkt_same_round != 0;
+int launch_kkt_packed(const NewtonDev& S, int n_kkt, int list_par, hipStream_t s, const int* n_dev, int pipe) {
+    const bool latency = pipe >= 0 ? pipe != 0 : S.kkt_same_round == 1;
     const int nq = S.dm.nq, nu = S.dm.nu;
     if (n_dev != nullptr) n_kkt = S.dm.B;      // upper bound of the grid; surplus workgroups leave at once
     if (n_kkt <= 0) return CIMPC_OK;

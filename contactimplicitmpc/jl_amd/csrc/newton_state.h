@@ -24,7 +24,8 @@ struct NewtonDev {
     cimpc_dims dm;
     int b0;            // first rollout served by this launch (sub-batch offset)
     int nb_launch;     // rollouts served by this launch
-    int kkt_same_round; // 1: KKT runs before the sweep on the same stream (small batches)
+    int kkt_same_round; // 1: KKT runs before the sweep on the same stream (small batches); 2: chained round - KKT next to the first sweep,
+                        //    its candidates are evaluated by the round's second sweep (queue par ^ 1)
     int nd, nr, nth, nths, N;
     TrajDev traj, cand, ref;   // cand: [B*CS] evaluation slots; traj, ref: [B]
     double* nu;        // [B][H][nd]
@@ -108,7 +109,8 @@ size_t kkt_mixed_workspace_doubles(const NewtonDev& nd);
 int launch_kkt_mixed_newton(const NewtonDev& nd, double* ws, int* n_fallback, hipStream_t s);
 int launch_kkt_mixed_raw(const NewtonDev& nd, const double* r_dev, double beta, double* delta_dev, double* ws, int* n_fallback, hipStream_t s);
 // packed variant: n_kkt rollouts from kkt_list[list_par], KKT_PACK per workgroup (dedicates whole CUs to the recursion)
-int launch_kkt_packed(const NewtonDev& nd, int n_kkt, int list_par, hipStream_t s, const int* n_dev = nullptr);
+int launch_kkt_packed(const NewtonDev& nd, int n_kkt, int list_par, hipStream_t s, const int* n_dev = nullptr, int pipe = -1);
+int launch_queue_recycle(const IpQueues& Q, int par, hipStream_t s);
 // reference-default backend (dense jacobian! + LU with partial pivoting), any mode / objective (kkt_dense.hip)
 size_t kkt_dense_workspace_doubles(const NewtonDev& S, bool banded);
 int launch_kkt_dense_newton(const NewtonDev& S, double* ws, hipStream_t s, bool banded);
