@@ -121,6 +121,8 @@ struct cimpc_ctx {
     double *g_q = nullptr, *g_u = nullptr, *g_w = nullptr, *g_g = nullptr, *g_b = nullptr, *g_th = nullptr, *g_stride = nullptr;
     int* g_phase = nullptr;
     bool gait_set = false;
+    int dz_producer = 0;            // who wrote the per-step sensitivity memory last: 0 nobody, 1 newton_solve (dz_good), 2 implicit_dynamics (slot 0)
+    double* d_dz_knot = nullptr;    // [B][H_ref][nths*nd] per-knot archive, allocated at the first window change that needs it
     int wpk = 1;                 // persistent workgroups of a sweep launch
     double* d_alt = nullptr;
     double* d_zout = nullptr;
@@ -778,6 +780,23 @@ int cimpc_set_altitude(cimpc_handle h, const double* alt) {
     return CIMPC_OK;
 }
 
+// The sensitivity memory of failed solves belongs to the reference KNOTS (newton_kernels.hip: dz_rekey_kernel).  Called around
+// every change of the window: rekey_out with the window still in force, rekey_in with the new one.
+static int rekey_out(cimpc_ctx* h) {
+    if (h->dz_producer == 0 || !h->window_set) return CIMPC_OK;
+    if (!h->d_dz_knot && dev_alloc(h, &h->d_dz_knot, (size_t)h->dm.B * h->dm.H_ref * h->nths * h->nd) != CIMPC_OK) return CIMPC_ERR_HIP;
+    int rc = launch_dz_rekey(h->S, h->d_dz_knot, h->d_window, h->dz_producer == 1 ? 0 : 1, 0, h->stream);
+    return rc == CIMPC_OK ? CIMPC_OK : fail(h, rc, "sensitivity archive launch failed");
+}
+static int rekey_in(cimpc_ctx* h) {
+    if (h->dz_producer == 0 || !h->d_dz_knot) return CIMPC_OK;
+    for (int which = 0; which < 2; ++which) {      // both consumers see the knots' blocks
+        int rc = launch_dz_rekey(h->S, h->d_dz_knot, h->d_window, which, 1, h->stream);
+        if (rc != CIMPC_OK) return fail(h, rc, "sensitivity restore launch failed");
+    }
+    return CIMPC_OK;
+}
+
 int cimpc_set_window(cimpc_handle h, const int* window) {
     if (!h || !window) return fail(h, CIMPC_ERR_INVALID, "null argument");
     const cimpc_dims& d = h->dm;
@@ -789,7 +808,11 @@ int cimpc_set_window(cimpc_handle h, const int* window) {
         w0[k] = t - 1;                 // the device buckets problems by 0-based knot (newton_kernels.hip: enqueue_eval)
     }
     HIP_TRY(h, hipSetDevice(h->device));
+    if (int rk = rekey_out(h); rk != CIMPC_OK) return rk;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(h->d_window, w0.data(), w0.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (int rk = rekey_in(h); rk != CIMPC_OK) return rk;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->window_set = true;
     h->gait_set = false;               // an explicit window / reference replaces the gait-generated ones
     return CIMPC_OK;
@@ -828,6 +851,7 @@ int cimpc_implicit_dynamics(cimpc_handle h, const double* q, const double* theta
     if (d.mode == CIMPC_MODE_CONFIGURATIONFORCE && (!gamma || !b))
         return fail(h, CIMPC_ERR_INVALID, "gamma and b are required in configurationforce mode");
     HIP_TRY(h, hipSetDevice(h->device));
+    h->dz_producer = 2;
     TrajDev& T = h->S.cand;
     // evaluation slot 0 of every rollout (slot stride = CS rows)
     auto up = [&](double* dst, const double* src, size_t row_doubles) {
@@ -902,6 +926,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     if (rc != CIMPC_OK) return rc;
     if (!q0_dev || !q1_dev) return fail(h, CIMPC_ERR_INVALID, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
+    h->dz_producer = 1;
     NewtonDev& S = h->S;
     const auto t0 = std::chrono::steady_clock::now();
     auto over_budget = [&]() {
@@ -1255,8 +1280,10 @@ int cimpc_set_gait(cimpc_handle h, const double* q, const double* u, const doubl
     HIP_TRY(h, hipMemcpy(h->g_stride, stride, d.nq * sizeof(double), hipMemcpyHostToDevice));
     if (phase) HIP_TRY(h, hipMemcpy(h->g_phase, phase, B * sizeof(int), hipMemcpyHostToDevice));
     else { HIP_TRY(h, hipMemset(h->g_phase, 0, B * sizeof(int))); HIP_TRY(h, hipStreamSynchronize(nullptr)); }
+    if (int rk = rekey_out(h); rk != CIMPC_OK) return rk;
     int rc = launch_gait_window(h->S, gait_dev(h), h->d_window, 0, h->stream);
     if (rc != CIMPC_OK) return fail(h, rc, "gait window launch failed");
+    if (int rk = rekey_in(h); rk != CIMPC_OK) return rk;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->gait_set = h->window_set = h->reference_set = true;
     return CIMPC_OK;
@@ -1268,14 +1295,18 @@ int cimpc_mpc_advance(cimpc_handle h, const double* stride) {
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->gait_set) {          // full reference resident: regenerate the horizon from the gait (stride as given now)
         HIP_TRY(h, hipMemcpyAsync(h->g_stride, stride, (size_t)h->dm.nq * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (int rk = rekey_out(h); rk != CIMPC_OK) return rk;
         int rcg = launch_gait_window(h->S, gait_dev(h), h->d_window, 1, h->stream);
         if (rcg != CIMPC_OK) return fail(h, rcg, "mpc_advance launch failed");
+        if (int rk = rekey_in(h); rk != CIMPC_OK) return rk;
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         return CIMPC_OK;
     }
     HIP_TRY(h, hipMemcpyAsync(h->d_q0, stride, (size_t)h->dm.nq * sizeof(double), hipMemcpyHostToDevice, h->stream));   // d_q0: staging
+    if (int rk = rekey_out(h); rk != CIMPC_OK) return rk;
     int rc = launch_mpc_advance(h->S, h->d_window, h->d_q0, h->dm.H_ref, h->stream);
     if (rc != CIMPC_OK) return fail(h, rc, "mpc_advance launch failed");
+    if (int rk = rekey_in(h); rk != CIMPC_OK) return rk;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return CIMPC_OK;
 }

@@ -374,6 +374,37 @@ int launch_mpc_advance(const NewtonDev& S, int* window, const double* stride, in
     hipLaunchKernelGGL(mpc_advance_kernel, dim3(S.dm.B), dim3(64), 0, s, S, window, stride, H_ref);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
+// ---------------------------------------------------------------------------------------------------------
+// Sensitivity memory follows the KNOTS.  The reference owns one interior-point solver per reference knot (im_traj.ip[t],
+// implicit_dynamics.jl:71-86, 169-176): ip[t].dz is overwritten by every successful solve of knot t and left alone by failed
+// ones - across candidate evaluations, Newton solves and the window shifts of the MPC loop.  On the device that memory is
+// kept per horizon STEP (dz_good: the accepted evaluation of the Newton loop; slot 0 of S.dz: the B3 seam), which is the
+// same thing as long as the window stands still.  When the window changes the blocks are re-keyed through a per-knot
+// archive: dir 0  knot[b][window[b][i]] <- step(b, i)   (with the window in force),
+//          dir 1  step(b, i) <- knot[b][window[b][i]]   (with the new window).
+// One workgroup per (rollout, step).  A knot that occurs twice among the H steps (H > H_ref) keeps its LAST step's block,
+// the order in which the reference's loop over the steps would have written it.
+__global__ __launch_bounds__(128) void dz_rekey_kernel(double* step_base, size_t stride_b, size_t stride_i, double* knot,
+                                                       const int* window, int H, int K, int blk, int dir) {
+    const int b = (int)blockIdx.x / H, i = (int)blockIdx.x - b * H;
+    const int* w = window + (size_t)b * (H + 2);
+    const int t = w[i];
+    if (dir == 0)
+        for (int j = i + 1; j < H; ++j) if (w[j] == t) return;
+    double* st = step_base + (size_t)b * stride_b + (size_t)i * stride_i;
+    double* kn = knot + ((size_t)b * K + t) * (size_t)blk;
+    const double* src = dir == 0 ? st : kn;
+    double* dst = dir == 0 ? kn : st;
+    for (int e = (int)threadIdx.x; e < blk; e += (int)blockDim.x) dst[e] = src[e];
+}
+// which: 0 = dz_good (Newton loop), 1 = evaluation slot 0 of S.dz (implicit_dynamics seam)
+int launch_dz_rekey(const NewtonDev& S, double* knot, const int* window, int which, int dir, hipStream_t s) {
+    const size_t blk = (size_t)S.nths * S.nd, H = S.dm.H;
+    double* base = which == 0 ? S.dz_good : S.dz;
+    const size_t stride_b = which == 0 ? H * blk : (size_t)CS * H * blk;
+    hipLaunchKernelGGL(dz_rekey_kernel, dim3(S.dm.B * S.dm.H), dim3(128), 0, s, base, stride_b, blk, knot, window, S.dm.H, S.dm.H_ref, (int)blk, dir);
+    return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+}
 int launch_reset(const NewtonDev& S, const double* q0, const double* q1, int warm, hipStream_t s) {
     hipLaunchKernelGGL(reset_kernel, dim3(S.nb_launch), dim3(256), 0, s, S, q0, q1, warm);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;

@@ -146,7 +146,10 @@ int cimpc_set_objective(cimpc_handle h, const double* Q, const double* R, const 
 /* RLin.alt (set_altitude!, implicit_dynamics.jl:141-154): B x nc, NULL = zeros. */
 int cimpc_set_altitude(cimpc_handle h, const double* alt);
 
-/* window: B x (H+2) 1-based reference-knot indices (policy.jl:154-171). */
+/* window: B x (H+2) 1-based reference-knot indices (policy.jl:154-171).
+ * The sensitivity block a FAILED interior-point solve falls back to belongs to the reference knot (im_traj.ip[t].dz,
+ * implicit_dynamics.jl:71-86, 169-176), not to the horizon step: every call that moves the window (this one,
+ * cimpc_set_gait, cimpc_mpc_advance) carries the blocks along with their knots. */
 int cimpc_set_window(cimpc_handle h, const int* window);
 
 /* The `ref_traj` argument of newton_solve! (policy.jl:119-120 passes p.traj, already

@@ -137,14 +137,24 @@ def z_initialize(dims: Dims, q):
     return z
 
 
+def knot_store(dims: Dims, n_knots: int):
+    """The reference keeps ONE interior-point solver per reference knot (im_traj.ip[t], implicit_dynamics.jl:71-86): its
+    sensitivity block ip[t].dz is overwritten by every successful solve of knot t and survives failed ones, candidate
+    evaluations, Newton solves and window shifts of the MPC loop.  This is that per-knot memory (zeros before the first
+    success, like the freshly constructed solver)."""
+    nd, nq, nu = dims.nd, dims.nq, dims.nu
+    return dict(dq0=np.zeros((n_knots, nd, nq)), dq1=np.zeros((n_knots, nd, nq)), du1=np.zeros((n_knots, nd, nu)))
+
+
 def implicit_dynamics(dims: Dims, tables, window, q, theta, opts: IPOptions,
-                      gamma=None, b=None, prev=None):
+                      gamma=None, b=None, prev=None, store=None):
     """`implicit_dynamics!` (implicit_dynamics.jl:156-192) for one rollout.
 
     tables : list of LinTable over reference knots (0-based knot index)
     window : int array, length H+2, 0-based knot indices (policy.jl:154-171)
     q      : (H+2, nq) trajectory configurations   theta : (H, nth)
-    prev   : previous output dict (source of stale sensitivities for failed solves)
+    store  : knot_store(): per-knot sensitivity memory - updated by successful solves, read by failed ones
+    prev   : (without a store) previous output dict of the same window: source of stale sensitivities, per step
     Returns dict(d (H,nd), dq0 (H,nd,nq), dq1 (H,nd,nq), du1 (H,nd,nu),
                  status (H,), iters (H,), z (H,nz))."""
     H = len(window) - 2
@@ -164,6 +174,13 @@ def implicit_dynamics(dims: Dims, tables, window, q, theta, opts: IPOptions,
             out["dq0"][i] = dz[:nd, 0:nq]
             out["dq1"][i] = dz[:nd, nq:2 * nq]
             out["du1"][i] = dz[:nd, 2 * nq:2 * nq + nu]
+            if store is not None:
+                for k in ("dq0", "dq1", "du1"):
+                    store[k][t] = out[k][i]
+        elif store is not None:
+            # failed solve: ip[t].dz is untouched - the last successful solve of knot t, whenever that was
+            for k in ("dq0", "dq1", "du1"):
+                out[k][i] = store[k][t]
         elif prev is not None:
             # failed solve: the reference leaves ip[t].dz untouched (stale values of the
             # last successful solve of that knot); this build keeps the slot (rollout, i).

@@ -299,6 +299,7 @@ class Newton:
         self.nu_cand = z(H, dims.nd)
         self.beta = opts.beta_init
         self.im = None
+        self.store = None          # per-knot sensitivity memory (ip[t].dz), created at the first sweep, kept across solves
         self.Delta = z(self.lay.N)
         self.res = z(self.lay.N)
 
@@ -316,8 +317,10 @@ class Newton:
         copy_traj(self.traj_cand, self.traj, self.H)
 
     def _sweep(self, tables, window, traj: Traj, stats: NewtonStats):
+        if self.store is None:
+            self.store = ipm.knot_store(self.dims, len(tables))
         im = ipm.implicit_dynamics(self.dims, tables, window, traj.q, traj.theta, self.ip_opts,
-                                   gamma=traj.gamma, b=traj.b, prev=self.im)
+                                   gamma=traj.gamma, b=traj.b, store=self.store)
         stats.sweeps += 1
         stats.ip_iters += int(im["iters"].sum())
         stats.ip_fail += int((im["status"] == 0).sum())

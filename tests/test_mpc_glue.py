@@ -87,3 +87,71 @@ def test_mpc_loop_three_steps_warm_start(gpu_required):
         s.mpc_advance(stride)
         q0, q1 = q1, tr["q"][:, 2].copy()
     assert agree.sum() >= B - 1
+
+
+# ---- stale sensitivities follow the KNOTS across the MPC loop (implicit_dynamics.jl:71-86, 169-176: one ip[t] per reference knot) ----
+_FAIL_IP = dict(max_iter=5)        # most solves of the synthetic quadruped need 5-7 iterations: a good share fails
+
+
+def _oracle_loop(per_knot, steps=3, H=8, H_ref=12, B=3, seed=21):
+    """Three warm-started MPC steps of the oracle with an interior-point budget that makes solves fail.  per_knot=False
+    restates the OLD rule (stale blocks stay with the horizon step when the window moves) for comparison."""
+    d, prob, tabs, rollouts = make_case("quadruped", 0, H_ref=H_ref, H=H, B=B, seed=seed, perturb=5e-3)
+    obj = synth.make_objective(d, H)
+    stride = np.zeros(d.nq); stride[0] = 0.05
+    out = []
+    for (window, ref, a, b_) in rollouts:
+        ref = ref.copy(); win = np.array(window); q0, q1 = a.copy(), b_.copy()
+        core = onewton.Newton(d, H, obj, onewton.NewtonOptions(r_tol=1e-5, max_iter=4, solver="lu"),
+                              oip.IPOptions(kappa_tol=prob["kappa"], **_FAIL_IP), prob["kappa"], ref)
+        if not per_knot:
+            def sweep(tables, window_, traj, stats, core=core):
+                im = oip.implicit_dynamics(core.dims, tables, window_, traj.q, traj.theta, core.ip_opts,
+                                           gamma=traj.gamma, b=traj.b, prev=core.im)
+                stats.sweeps += 1; stats.ip_iters += int(im["iters"].sum()); stats.ip_fail += int((im["status"] == 0).sum())
+                return im
+            core._sweep = sweep
+        hist = []
+        for step in range(steps):
+            st = onewton.newton_solve(core, q0, q1, win, tabs, ref, warm_start=step > 0)
+            hist.append((st.iters, st.ip_iters, st.ip_fail, core.traj.u[0].copy(), core.traj.q.copy()))
+            ompc.rot_n_stride(d, ref, stride)
+            win = ompc.update_window(win, H_ref)
+            q0, q1 = q1, core.traj.q[2].copy()
+        out.append(hist)
+    return d, prob, tabs, rollouts, obj, stride, out
+
+
+def test_oracle_knot_store_matters_after_an_advance():
+    """The per-knot rule and the per-step rule agree within the first solve and part ways once the window has moved."""
+    *_, knot = _oracle_loop(True)
+    *_, step = _oracle_loop(False)
+    assert sum(h[0][2] for h in knot) > 0                                  # solves do fail
+    for hk, hs in zip(knot, step):
+        np.testing.assert_array_equal(hk[0][3], hs[0][3])                  # first solve: one window, same thing
+    assert any(not np.array_equal(hk[s][3], hs[s][3]) for hk, hs in zip(knot, step) for s in (1, 2))
+
+
+@pytest.mark.gpu
+def test_mpc_loop_failed_solves_follow_the_knots(gpu_required):
+    """Same loop on the device (cimpc_mpc_advance re-keys the sensitivity memory through the per-knot archive)."""
+    from contactimplicitmpc.jl_amd import InteriorPointOptions, NewtonOptions
+    H, H_ref, B = 8, 12, 3
+    d, prob, tabs, rollouts, obj, stride, want = _oracle_loop(True, H=H, H_ref=H_ref, B=B)
+    s = make_solver(d, prob, rollouts, H, obj=obj, ip_opts=InteriorPointOptions(kappa_tol=prob["kappa"], **_FAIL_IP),
+                    newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=1e-5, max_iter=4))
+    q0 = np.stack([r[2] for r in rollouts]); q1 = np.stack([r[3] for r in rollouts])
+    agree = np.ones(B, dtype=bool)
+    for step in range(3):
+        u1, it, rn = s.newton_solve(q0, q1, warm_start=step > 0)
+        tr = s.trajectory(); cnt = s.rollout_counters()
+        for b in range(B):
+            iters, ip_iters, ip_fail, u_want, q_want = want[b][step]
+            agree[b] &= (it[b] == iters and cnt["ip_iters"][b] == ip_iters and cnt["ip_failures"][b] == ip_fail)
+            if agree[b]:
+                np.testing.assert_allclose(u1[b], u_want, rtol=0, atol=1e-7)
+                np.testing.assert_allclose(tr["q"][b], q_want, rtol=0, atol=1e-7)
+        s.mpc_advance(stride)
+        # the oracle continues from ITS planned configuration; the device loop from its own (identical while they agree)
+        q0, q1 = q1, tr["q"][:, 2].copy()
+    assert agree.sum() >= B - 1
