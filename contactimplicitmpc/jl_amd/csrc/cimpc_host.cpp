@@ -65,6 +65,8 @@ struct Knobs {
     bool debug_rounds = false;   // CIMPC_DEBUG_ROUNDS
     bool kkt_packed = true;      // CIMPC_KKT_PACKED
     int tail_div = 8;            // CIMPC_TAIL_DIV
+    int drain_pct = 95;          // CIMPC_DRAIN_PCT: drain parking once this percentage of the sweep's workgroups has left (0 = off; B = 512: 0 / 75 / 90 / 95 / 97 -> 10.68 / 10.97 / 10.48 / 10.45 / 10.47 ms)
+    int drain_min = 4;           // CIMPC_DRAIN_MIN: ... for solves that have had at least this many iterations in the launch
     int kkt_chain = -1;          // CIMPC_KKT_CHAIN: chained rounds ({sweep || KKT} -> sweep of the new candidates -> residual) when at least this
                                  // percentage of the round's rollouts start a Newton iteration; -1 = never
     int kkt_pipe = -1;           // CIMPC_KKT_PIPE: two-wave pipelined KKT kernel 0 never, 1 always, -1 where the solve is on the critical path
@@ -96,6 +98,8 @@ struct Knobs {
         kkt_packed = env_int("CIMPC_KKT_PACKED", 1) != 0;
         tail_div = env_int("CIMPC_TAIL_DIV", tail_div);
         kkt_chain = env_int("CIMPC_KKT_CHAIN", kkt_chain);
+        drain_pct = env_int("CIMPC_DRAIN_PCT", drain_pct);
+        drain_min = std::max(1, env_int("CIMPC_DRAIN_MIN", drain_min));
         kkt_pipe = env_int("CIMPC_KKT_PIPE", kkt_pipe);
         kkt_pipe_max = env_int("CIMPC_KKT_PIPE_MAX", kkt_pipe_max);
     }
@@ -311,9 +315,14 @@ IpParams make_ip_params(cimpc_ctx* h, const TrajDev& T, int par, int* pending_co
 }
 
 // queue kernel + sensitivity kernel of one round
-int run_sweep(cimpc_ctx* h, int par, int* pending_counter, double* zout, hipStream_t st, int iter_cap = 0) {
+int run_sweep(cimpc_ctx* h, int par, int* pending_counter, double* zout, hipStream_t st, int iter_cap = 0, int* drain_counter = nullptr) {
     IpParams p = make_ip_params(h, h->S.cand, par, pending_counter, zout);
     if (iter_cap > 0) p.iter_cap = iter_cap;
+    if (drain_counter != nullptr && h->kn.drain_pct > 0 && p.iter_cap < h->ip.max_iter) {
+        p.drain_count = drain_counter;
+        p.drain_thresh = std::max(1, (int)((long long)h->wpk * h->kn.drain_pct / 100));
+        p.drain_min = h->kn.drain_min;
+    }
     prof_begin(h, PC_IP, st);
     int rc = launch_ip_sweep(&h->dm, p, h->waves, st);
     prof_end(h, st);
@@ -1102,7 +1111,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         const int tail_div = h->kn.tail_div;
         const int cap = (tail_div > 0 && last_sweep * tail_div <= h->dm.B) ? h->ip.max_iter : h->iter_cap;
         int rr = CIMPC_OK;
-        if (!chain || last_sweep > 0) rr = run_sweep(h, par, d_cnt + 2, nullptr, sb.st, cap);
+        if (!chain || last_sweep > 0) rr = run_sweep(h, par, d_cnt + 2, nullptr, sb.st, cap, chain ? nullptr : d_cnt + 3);
         if (rr != CIMPC_OK) return rr;
         if (kkt && h->kkt_overlap && hipStreamWaitEvent(sb.st, sb.ev_join, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join failed");
         if (chain) {

@@ -141,6 +141,10 @@ struct IpParams {
     double* pstate;        // [B*slots][H][2nx + 4ny + 4]  parked iterate / converged z for the sens pass
     int* pending_count;    // device counter, incremented once per parked problem
     int iter_cap;
+    // drain parking (experiment, CIMPC_DRAIN_PCT): once `drain_thresh` workgroups of the launch have run out of work, a solve
+    // that has had at least `drain_min` iterations in this launch is parked instead of holding the launch (and the round)
+    int* drain_count;      // workgroups of this launch that found no work any more (null = off); zeroed with the round's counters
+    int drain_thresh, drain_min;
     int slots;             // evaluation slots per rollout: rollout = slot index / slots
     int H;
     cimpc_ip_opts o;

@@ -484,16 +484,24 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
     [[maybe_unused]] long long dbg_pop[4] = {0, 0, 0, 0};
     [[maybe_unused]] const bool dbg_on = ASYNC && p.A.dbg != nullptr;      // diagnostics only with CIMPC_ASYNC_DEBUG
     double reg = 0.0, r_vio = 0.0, k_vio = 0.0, qinit = 0.0;
+    [[maybe_unused]] int drain_seen = 0;      // (lock-step launches) workgroups that have left, sampled one trip ago
 
     while (true) {
         [[maybe_unused]] const long long sp_a = SPROF_T();
+        [[maybe_unused]] bool draining = false;
+        if constexpr (!ASYNC) {
+            if (p.drain_count != nullptr) {
+                draining = drain_seen >= p.drain_thresh;
+                drain_seen = __builtin_amdgcn_readfirstlane(aload(p.drain_count));      // consumed at the top of the next trip
+            }
+        }
         // ---- 1. end of a solve? ---------------------------------------------------------------
         if (have) {
             int code = -1;
             if (stalled) code = 0;
             else if (r_vio < o.r_tol && k_vio < o.kappa_tol) code = 1;
             else if (iters >= o.max_iter) code = 0;
-            else if (done_here >= p.iter_cap) code = 2;
+            else if (done_here >= p.iter_cap || (!ASYNC && draining && done_here >= p.drain_min)) code = 2;
             if (code >= 0) {
                 const size_t pi = (size_t)prob;
                 const int sb = prob / p.H;
@@ -687,7 +695,10 @@ __global__ __launch_bounds__(M::G == 16 ? CIMPC_SWEEP_THREADS : 256, M::G == 16 
 #ifdef CIMPC_SWEEP_PROF
         sp[1] += SPROF_T() - sp_t;
 #endif
-        if (knot < 0) break;
+        if (knot < 0) {
+            if (tid == 0 && p.drain_count != nullptr) atomicAdd(p.drain_count, 1);
+            break;
+        }
         serve_knot<M, false>(p, smem, knot, tid, sp);
     }
 #ifdef CIMPC_SWEEP_PROF
