@@ -1045,7 +1045,9 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     if (full_async) return run_async(true, 0);
     // safety net only: every Newton iteration needs at most 3 (speculative) rounds, each evaluation at
     // most ceil(max_iter / iter_cap) launches of the resumable interior-point sweep
-    const int max_rounds = (h->nt.max_iter * 8 + 2) * ((h->ip.max_iter + h->iter_cap - 1) / h->iter_cap + 1);
+    // (drain parking guarantees drain_min iterations of progress per launch, iter_cap parking iter_cap)
+    const int min_progress = h->kn.drain_pct > 0 ? std::min(h->iter_cap, h->kn.drain_min) : h->iter_cap;
+    const int max_rounds = (h->nt.max_iter * 8 + 2) * ((h->ip.max_iter + min_progress - 1) / min_progress + 1);
     // the rounds run on the library's private streams, or on the caller's stream when one was given
     RoundStreams sb = h->rs;
     if (h->external_stream) sb.st = h->stream;
