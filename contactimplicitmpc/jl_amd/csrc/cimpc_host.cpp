@@ -1156,7 +1156,10 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             if (rc != CIMPC_OK) return rc;
             ++launched;
         }
-        if (completed >= launched) break;     // max_rounds reached
+        if (completed >= launched) {          // max_rounds reached with work left: a scheduling bug, never a silent partial solve
+            (void)hipStreamSynchronize(sb.st); (void)hipStreamSynchronize(sb.st_kkt);
+            return fail(h, CIMPC_ERR_STATE, "newton_solve: round limit reached with unfinished rollouts");
+        }
         {   // the residual kernel's last block stamps the mapped flag when round `completed` is done
             volatile int* hm = (volatile int*)h->h_ring + 8 * (completed & 1);
             const int want = (int)(completed + 1);
