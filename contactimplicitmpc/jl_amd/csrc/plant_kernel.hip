@@ -53,7 +53,7 @@ __global__ __launch_bounds__(64) void plant_step_kernel(PlantModel M, PlantOpts 
     __shared__ int piv[NZM];
     const int rb = blockIdx.x, lane = threadIdx.x;
     if (rb >= B) return;
-    const int nq = M.nq, nu = M.nu, nz = M.nz(), ny = 2 * PLANT_NC + PLANT_NB, nxy = nq + ny;
+    const int nq = M.nq, nu = M.nu, nz = M.nz(), ny = 2 * M.nc + M.nb(), nxy = nq + ny;
     // θ = [q0; q1; u1; w1; μ; h], z = (q1, 1, ..., 1)
     for (int i = lane; i < M.nth(); i += 64) {
         double v;
@@ -182,8 +182,8 @@ __global__ __launch_bounds__(64) void plant_step_kernel(PlantModel M, PlantOpts 
         r_vio = r_c; k_vio = k_c;
     }
     for (int i = lane; i < nq; i += 64) q2[(size_t)rb * nq + i] = zs[i];
-    for (int i = lane; i < PLANT_NC; i += 64) gamma[(size_t)rb * PLANT_NC + i] = zs[nq + i];
-    for (int i = lane; i < PLANT_NB; i += 64) bb[(size_t)rb * PLANT_NB + i] = zs[nq + PLANT_NC + i];
+    for (int i = lane; i < M.nc; i += 64) gamma[(size_t)rb * M.nc + i] = zs[nq + i];
+    for (int i = lane; i < M.nb(); i += 64) bb[(size_t)rb * M.nb() + i] = zs[nq + M.nc + i];
     if (lane == 0) { status[rb] = (r_vio < o.r_tol && k_vio < o.kappa_tol) ? 1 : 0; iters[rb] = it; }
 }
 
@@ -220,7 +220,7 @@ extern "C" int cimpc_plant_step(int model, int B, const double* q0, const double
                                 int* status, int* iters) {
     using namespace cimpc;
     if (B <= 0 || !q0 || !q1 || !u || !opts || !q2 || !gamma || !b || !status || !iters || h <= 0.0) return CIMPC_ERR_INVALID;
-    if (model != CIMPC_PLANT_QUADRUPED && model != CIMPC_PLANT_FLAMINGO) return CIMPC_ERR_INVALID;
+    if (model != CIMPC_PLANT_QUADRUPED && model != CIMPC_PLANT_FLAMINGO && model != CIMPC_PLANT_HOPPER_2D) return CIMPC_ERR_INVALID;
     if (opts->max_iter <= 0 || opts->max_ls < 0 || !(opts->r_tol > 0.0) || !(opts->kappa_tol > 0.0) || !(opts->ls_scale > 0.0 && opts->ls_scale < 1.0))
         return CIMPC_ERR_INVALID;
     // runs on the calling thread's CURRENT device (the caller selects it, e.g. hipSetDevice(rank) / torch.cuda.set_device)
@@ -230,11 +230,12 @@ extern "C" int cimpc_plant_step(int model, int B, const double* q0, const double
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return CIMPC_ERR_NO_DEVICE;
     }
-    const PlantModel M = model == CIMPC_PLANT_QUADRUPED ? plant_quadruped() : plant_flamingo();
+    const PlantModel M = model == CIMPC_PLANT_QUADRUPED ? plant_quadruped() : model == CIMPC_PLANT_FLAMINGO ? plant_flamingo() : plant_hopper_2d();
+    const size_t pnc = (size_t)M.nc, pnb = (size_t)M.nb();
     PlantOpts o{opts->r_tol, opts->kappa_tol, std::isinf(opts->undercut) ? 0.0 : opts->kappa_tol / opts->undercut, opts->eps_min,
                 opts->ls_scale, opts->stall_alpha, opts->max_iter, opts->max_ls};
     const size_t nq = M.nq, nu = M.nu;
-    const size_t n_in = (size_t)B * (2 * nq + nu + PLANT_NW), n_out = (size_t)B * (nq + PLANT_NC + PLANT_NB);
+    const size_t n_in = (size_t)B * (2 * nq + nu + PLANT_NW), n_out = (size_t)B * (nq + pnc + pnb);
     std::lock_guard<std::mutex> lock(g_plant_mu);
     PlantWs& W = g_plant_ws[dev];
     if (!W.st) {
@@ -244,7 +245,7 @@ extern "C" int cimpc_plant_step(int model, int B, const double* q0, const double
     if (!plant_grow(&W.d_in, &W.cap_in, n_in) || !plant_grow(&W.d_out, &W.cap_out, n_out) || !plant_grow(&W.d_st, &W.cap_st, 2 * (size_t)B))
         return CIMPC_ERR_HIP;
     double* dq0 = W.d_in; double* dq1 = dq0 + B * nq; double* du = dq1 + B * nq; double* dw = du + B * nu;
-    double* dq2 = W.d_out; double* dg = dq2 + B * nq; double* db = dg + (size_t)B * PLANT_NC;
+    double* dq2 = W.d_out; double* dg = dq2 + B * nq; double* db = dg + (size_t)B * pnc;
     int* d_st = W.d_st;
     hipStream_t st = W.st;
     bool ok = hipMemcpyAsync(dq0, q0, B * nq * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess &&
@@ -257,8 +258,8 @@ extern "C" int cimpc_plant_step(int model, int B, const double* q0, const double
         ok = hipGetLastError() == hipSuccess;
     }
     if (ok) ok = hipMemcpyAsync(q2, dq2, B * nq * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess &&
-                 hipMemcpyAsync(gamma, dg, (size_t)B * PLANT_NC * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess &&
-                 hipMemcpyAsync(b, db, (size_t)B * PLANT_NB * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                 hipMemcpyAsync(gamma, dg, (size_t)B * pnc * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                 hipMemcpyAsync(b, db, (size_t)B * pnb * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess &&
                  hipMemcpyAsync(status, d_st, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
                  hipMemcpyAsync(iters, d_st + B, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess;
     ok = (hipStreamSynchronize(st) == hipSuccess) && ok;      // this stream only

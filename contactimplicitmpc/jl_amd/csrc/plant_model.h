@@ -45,10 +45,13 @@ template <> PLANT_HD double pconst<double>(double a) { return a; }
 template <> PLANT_HD Dual pconst<Dual>(double a) { return {a, 0.0}; }
 
 constexpr int PLANT_MAX_Q = 11, PLANT_MAX_U = 8, PLANT_MAX_BODIES = 9, PLANT_MAX_SEG = 3;
-constexpr int PLANT_NC = 4, PLANT_NB = 8, PLANT_NW = 2;      // four contacts, two-sided friction cone, flat_2D_lc
+constexpr int PLANT_NC = 4, PLANT_NB = 8, PLANT_NW = 2;      // at most four contacts, two-sided friction cone (flat_2D_lc)
+constexpr int PLANT_KIND_CHAIN = 0, PLANT_KIND_HOPPER_2D = 1;
 
 struct PlantChain { int n; double r[PLANT_MAX_SEG]; int k[PLANT_MAX_SEG]; };
 struct PlantModel {
+    int kind = PLANT_KIND_CHAIN;      // planar chain with absolute angles | hopper_2D (constant mass matrix, prismatic leg)
+    int nc = PLANT_NC;                // contacts (nb = 2 nc friction directions)
     int nq, nu, n_bodies;
     double g, mu_world;
     double mass[PLANT_MAX_BODIES], inertia[PLANT_MAX_BODIES];
@@ -57,7 +60,8 @@ struct PlantModel {
     PlantChain foot[PLANT_NC];
     int tq_a[PLANT_MAX_U], tq_b[PLANT_MAX_U];     // actuator i: torque between links a and b (B = -e_a + e_b)
     double joint_friction[PLANT_MAX_Q];
-    PLANT_HD int nz() const { return nq + 4 * PLANT_NC + 2 * PLANT_NB; }
+    PLANT_HD int nb() const { return 2 * nc; }
+    PLANT_HD int nz() const { return nq + 4 * nc + 2 * nb(); }
     PLANT_HD int nth() const { return 2 * nq + nu + PLANT_NW + 2; }
 };
 
@@ -65,6 +69,13 @@ struct PlantModel {
 template <class T>
 PLANT_HD void plant_lagrangian_derivatives(const PlantModel& M, const T* q, const T* v, T* d1, T* d2) {
     T s[PLANT_MAX_Q], c[PLANT_MAX_Q];
+    if (M.kind == PLANT_KIND_HOPPER_2D) {
+        // hopper_2D/model.jl:41-55: M = diag(mb + ml, mb + ml, Jb + Jl, ml) (kept in mass[0..3]), C = (0, (mb + ml) g, 0, 0);
+        // lagrangian = 0, so D1L = -C and D2L = M v (dynamics/model.jl:11-15)
+        for (int i = 0; i < 4; ++i) { d1[i] = pconst<T>(0.0); d2[i] = M.mass[i] * v[i]; }
+        d1[1] = pconst<T>(-(M.mass[1] * M.g));
+        return;
+    }
     for (int i = 0; i < M.nq; ++i) { d1[i] = pconst<T>(0.0); d2[i] = pconst<T>(0.0); s[i] = psin(q[i]); c[i] = pcos(q[i]); }
     for (int b = 0; b < M.n_bodies; ++b) {
         const double m = M.mass[b];
@@ -94,7 +105,7 @@ PLANT_HD void plant_lagrangian_derivatives(const PlantModel& M, const T* q, cons
 // r(z, θ, κ): z = [q2; γ; b; ψ; s1; η; s2], θ = [q0; q1; u1; w1; μ; h] (θ real: only dr/dz is needed)
 template <class T>
 PLANT_HD void plant_residual(const PlantModel& M, const T* z, const double* th, double kappa, T* r) {
-    const int nq = M.nq, nu = M.nu, nc = PLANT_NC, nb = PLANT_NB;
+    const int nq = M.nq, nu = M.nu, nc = M.nc, nb = M.nb();
     const double* q0 = th; const double* q1 = th + nq; const double* u1 = th + 2 * nq; const double* w1 = u1 + nu;
     const double mu = w1[PLANT_NW], h = w1[PLANT_NW + 1];
     const T* q2 = z; const T* gam = z + nq; const T* b = gam + nc; const T* psi = b + nb; const T* s1 = psi + nc;
@@ -110,7 +121,14 @@ PLANT_HD void plant_residual(const PlantModel& M, const T* z, const double* th, 
     T dyn[PLANT_MAX_Q];
     for (int i = 0; i < nq; ++i)
         dyn[i] = (0.5 * h) * a1[i] + b1[i] + (0.5 * h) * a2[i] - b2[i] - (h * M.joint_friction[i]) * vm2[i];
-    for (int i = 0; i < nu; ++i) { dyn[M.tq_a[i]] = dyn[M.tq_a[i]] - u1[i]; dyn[M.tq_b[i]] = dyn[M.tq_b[i]] + u1[i]; }
+    if (M.kind == PLANT_KIND_HOPPER_2D) {
+        // B(qm2)^T u, hopper_2D/model.jl:68-71: body torque on t; leg force along the leg axis (-sin t, cos t) and on r
+        const T st = psin(qm2[2]), ct = pcos(qm2[2]);
+        dyn[2] = dyn[2] + u1[0];
+        dyn[0] = dyn[0] - u1[1] * st; dyn[1] = dyn[1] + u1[1] * ct; dyn[3] = dyn[3] + u1[1];
+    } else {
+        for (int i = 0; i < nu; ++i) { dyn[M.tq_a[i]] = dyn[M.tq_a[i]] - u1[i]; dyn[M.tq_b[i]] = dyn[M.tq_b[i]] + u1[i]; }
+    }
     dyn[0] = dyn[0] + w1[0]; dyn[1] = dyn[1] + w1[1];
     // contacts: position, Jacobian rows (x and z) of every foot at q2
     T s[PLANT_MAX_Q], c[PLANT_MAX_Q];
@@ -121,7 +139,15 @@ PLANT_HD void plant_residual(const PlantModel& M, const T* z, const double* th, 
         T lx = b[2 * f] - b[2 * f + 1], lz = gam[f];                 // contact force [m b; γ]
         T vx = (q2[0] - q1[0]) / h;                                  // tangential foot velocity J_x (q2 - q1) / h
         dyn[0] = dyn[0] + lx; dyn[1] = dyn[1] + lz;                  // J^T λ: base columns
-        for (int e = 0; e < ch.n; ++e) {
+        if (M.kind == PLANT_KIND_HOPPER_2D) {
+            // foot = (x + r sin t, z - r cos t), J = [1 0 r cos t sin t; 0 1 r sin t -cos t] at q2 (hopper_2D/model.jl:35-66)
+            const T rl = q2[3];
+            pz = pz - rl * c[2];
+            dyn[2] = dyn[2] + rl * (c[2] * lx + s[2] * lz);
+            dyn[3] = dyn[3] + (s[2] * lx - c[2] * lz);
+            vx = vx + rl * (c[2] * ((q2[2] - q1[2]) / h)) + s[2] * ((q2[3] - q1[3]) / h);
+        }
+        for (int e = 0; e < (M.kind == PLANT_KIND_HOPPER_2D ? 0 : ch.n); ++e) {
             const int k = ch.k[e]; const double rr = ch.r[e];
             pz = pz - rr * c[k];
             dyn[k] = dyn[k] + rr * (c[k] * lx + s[k] * lz);
@@ -170,6 +196,15 @@ inline PlantModel plant_quadruped() {          // quadruped/model.jl:516-575
     const int pairs[8][2] = {{2, 3}, {3, 4}, {2, 5}, {5, 6}, {2, 7}, {7, 8}, {2, 9}, {9, 10}};
     for (int i = 0; i < 8; ++i) { M.tq_a[i] = pairs[i][0]; M.tq_b[i] = pairs[i][1]; }
     for (int i = 0; i < 11; ++i) M.joint_friction[i] = i < 3 ? 0.0 : 0.1;
+    return M;
+}
+inline PlantModel plant_hopper_2d() {          // hopper_2D/model.jl:95-121
+    PlantModel M{};
+    M.kind = PLANT_KIND_HOPPER_2D; M.nc = 1;
+    M.nq = 4; M.nu = 2; M.g = 9.81; M.mu_world = 0.8; M.n_bodies = 0;
+    const double mb = 3.0, ml = 0.3, Jb = 0.75, Jl = 0.075;
+    M.mass[0] = mb + ml; M.mass[1] = mb + ml; M.mass[2] = Jb + Jl; M.mass[3] = ml;      // diagonal of the mass matrix
+    for (int i = 0; i < 4; ++i) M.joint_friction[i] = 0.0;
     return M;
 }
 inline PlantModel plant_flamingo() {           // flamingo/model.jl:458-495

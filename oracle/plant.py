@@ -170,6 +170,52 @@ class FlamingoPlant(PlanarChainPlant):
         self._finish(((2, 3), (3, 4), (2, 5), (5, 6), (4, 7), (6, 8)), np.zeros(9))
 
 
+class HopperPlant:
+    """hopper_2D (src/dynamics/hopper_2D/model.jl): q = (x, z, t, r), constant mass matrix diag(mb+ml, mb+ml, Jb+Jl, ml),
+    C = (0, (mb+ml) g, 0, 0), one contact at the foot (x + r sin t, z - r cos t), u = (body torque, leg force).  Same residual
+    layout as the chains (simulation.jl:133-158), complex-step Jacobian."""
+    nq, nu, nw, nc, nb = 4, 2, 2, 1, 2
+    g = 9.81
+    mu_world = 0.8
+    mb, ml, Jb, Jl = 3.0, 0.3, 0.75, 0.075
+
+    def __init__(self):
+        self.Md = np.array([self.mb + self.ml, self.mb + self.ml, self.Jb + self.Jl, self.ml])
+        self.dims = Dims(nq=self.nq, nu=self.nu, nw=self.nw, nc=self.nc, nb=self.nb)
+
+    def lagrangian_derivatives(self, q, v):          # lagrangian = 0: D1L = -C, D2L = M v   (model.jl:30, 41-55)
+        d1 = np.zeros_like(q)
+        d1[..., 1] = -self.Md[1] * self.g
+        return d1, self.Md * v
+
+    def residual(self, z, th, kappa):
+        nq, nu = self.nq, self.nu
+        ot = np.cumsum([0, nq, nq, nu, self.nw, 1, 1])
+        q0, q1, u1, w1, mu, h = (th[..., ot[i]:ot[i + 1]] for i in range(6))
+        o = np.cumsum([0, nq, 1, 2, 1, 1, 2, 1])
+        q2, gam, b, psi, s1, eta, s2 = (z[..., o[i]:o[i + 1]] for i in range(7))
+        qm1, vm1 = 0.5 * (q0 + q1), (q1 - q0) / h
+        qm2, vm2 = 0.5 * (q1 + q2), (q2 - q1) / h
+        a1, b1 = self.lagrangian_derivatives(qm1, vm1)
+        a2, b2 = self.lagrangian_derivatives(qm2, vm2)
+        sm, cm = np.sin(qm2[..., 2]), np.cos(qm2[..., 2])
+        Bu = np.stack([-sm * u1[..., 1], cm * u1[..., 1], u1[..., 0], u1[..., 1]], axis=-1)      # B(qm2)^T u, model.jl:68-71
+        Aw = np.concatenate([w1, np.zeros_like(w1)], axis=-1)                                    # A^T w,      model.jl:73-76
+        st, ct, r = np.sin(q2[..., 2]), np.cos(q2[..., 2]), q2[..., 3]
+        lx, lz = b[..., 0] - b[..., 1], gam[..., 0]
+        one, zero = np.ones_like(st), np.zeros_like(st)
+        Jx = np.stack([one, zero, r * ct, st], axis=-1)                                          # J_func, model.jl:62-66
+        Jz = np.stack([zero, one, r * st, -ct], axis=-1)
+        dyn = 0.5 * h * a1 + b1 + 0.5 * h * a2 - b2 + Bu + Aw + Jx * lx[..., None] + Jz * lz[..., None]
+        pz = q2[..., 1] - r * ct
+        vt = np.sum(Jx * (q2 - q1) / h, axis=-1)
+        return np.concatenate([dyn, s1 - pz[..., None], eta - np.stack([vt, -vt], axis=-1) - np.repeat(psi, 2, axis=-1),
+                               s2 - (mu * gam - (b[..., 0:1] + b[..., 1:2])),
+                               gam * s1 - kappa, b * eta - kappa, psi * s2 - kappa], axis=-1)
+
+    jacobian_z = PlanarChainPlant.jacobian_z
+
+
 def plant_step(plant, q0, q1, u, w, mu, h, opts: oip.IPOptions):
     """One simulator step: solve r(z, θ, κ -> κ_tol) = 0 from z = (q1, 1, ..., 1) (`initialize_z!`,
     quadruped/model.jl:586-590).  Returns (status, iterations, q2, γ, b)."""

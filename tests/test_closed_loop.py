@@ -193,3 +193,40 @@ def test_flamingo_closed_loop_with_the_device_policy(gpu_required):
     eo = pl.tracking_error(P.q, P.u, P.gamma, P.b, qo, uo, go, bo, N_SAMPLE)
     for a, c in zip(e, eo):
         assert abs(a / c - 1) < 0.05
+
+
+def test_hopper_plant_equals_the_torch_model_and_steps_along_the_gait():
+    """hopper_2D (BASELINE configs[1]'s model): the numpy plant against the torch model of lcp_models.py, and one simulator
+    step from two consecutive configurations of the reference's hopper gait lands on the next one."""
+    from contactimplicitmpc.jl_amd import lcp_models
+    P, m = pl.HopperPlant(), lcp_models.Hopper2D()
+    rng = np.random.default_rng(4)
+    for _ in range(3):
+        z, th = rng.uniform(0.1, 1.0, m.nz), rng.uniform(0.1, 1.0, m.nth)
+        r_t, rz_t, _ = m.linearize(z, th, 1e-3)
+        np.testing.assert_allclose(P.residual(z, th, 1e-3), r_t, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(P.jacobian_z(z, th), rz_t, rtol=0, atol=1e-11 * np.abs(rz_t).max())
+    import os
+    from contactimplicitmpc.jl_amd import gait_io
+    from real_problems import GAITS
+    # (the shipped hopper gait predates the shipped model - tests/test_real_models.py: its leg-length equation is off by 4e-3)
+    tr = gait_io.load_joint_traj(os.path.join(os.path.dirname(GAITS["quadruped"][1]), "hopper_gait_forward.jld2"))
+    for t in (0, 9, 20, 60):
+        status, it, q2, gam, b = pl.plant_step(P, tr.q[t], tr.q[t + 1], tr.u[t], np.zeros(2), P.mu_world, tr.h, pl.SIM_OPTS)
+        assert status and it <= 40
+        assert np.abs(q2 - tr.q[t + 2])[:3].max() < 2e-3 and abs(q2[3] - tr.q[t + 2][3]) < 2e-2
+
+
+def test_disturbance_schedules():
+    """open_loop_disturbances / impulse_disturbances, src/simulator/disturbances.jl:4-58 (index pattern of the comment at :17-20)."""
+    from contactimplicitmpc.jl_amd.plant import ImpulseDisturbance, OpenLoopDisturbance
+    w = [np.array([1.0, 0.0]), np.array([0.0, 2.0]), np.array([3.0, 3.0]), np.array([4.0, 0.0])]
+    d = OpenLoopDisturbance(w, 3)
+    got = [d(t) for t in range(1, 11)]
+    idx = [1, 1, 1, 2, 2, 2, 3, 3, 3, 4]
+    for g, i in zip(got, idx):
+        np.testing.assert_array_equal(g, w[i - 1] / 3)
+    np.testing.assert_array_equal(d(1), w[0] / 3)                          # t == 1 resets
+    imp = ImpulseDisturbance([np.array([5.0, 0.0]), np.array([0.0, -7.0])], [4, 9])
+    out = np.array([imp(t) for t in range(1, 11)])
+    assert np.count_nonzero(out.any(axis=1)) == 2 and out[3, 0] == 5.0 and out[8, 1] == -7.0

@@ -53,3 +53,40 @@ def test_closed_loop_with_policy_and_plant_on_the_device(gpu_required):
     nominal = (0.0201, 0.0437, 0.374, 0.0789)
     assert all(a < 1.5 * n for a, n in zip(e0, nominal)) and all(a < 2.0 * n for a, n in zip(e1, nominal))
     assert abs(e0[1] / nominal[1] - 1) < 0.05 and abs(e0[2] / nominal[2] - 1) < 0.05 and abs(e0[3] / nominal[3] - 1) < 0.05
+
+
+def test_hopper_plant_step_and_disturbances_match_the_cpu_restatement(gpu_required):
+    """hopper_2D plant (nc = 1) and the disturbance input w (src/simulator/disturbances.jl: an impulse on one robot, an
+    open-loop push on another) against the CPU restatement."""
+    import os
+    from contactimplicitmpc.jl_amd import InteriorPointOptions, gait_io, plant
+    from real_problems import GAITS
+    tr = gait_io.load_joint_traj(os.path.join(os.path.dirname(GAITS["quadruped"][1]), "hopper_gait_forward.jld2"))
+    cpu = pl.HopperPlant()
+    knots = [0, 9, 20, 37, 60, 81]
+    rng = np.random.default_rng(5)
+    q0 = np.stack([tr.q[t] for t in knots]); q1 = np.stack([tr.q[t + 1] for t in knots]) + 1e-3 * rng.standard_normal((len(knots), 4))
+    u = np.stack([tr.u[t] for t in knots])
+    w = np.zeros((len(knots), 2)); w[1] = [2.0, 0.0]; w[4] = [-1.0, 0.5]
+    o_cpu = oip.IPOptions(r_tol=1e-8, kappa_tol=1e-8, undercut=np.inf, gamma_reg=0.1, eps_min=0.25, max_iter=100, max_ls=25)
+    o_dev = InteriorPointOptions(r_tol=1e-8, kappa_tol=1e-8, undercut=float("inf"), eps_min=0.25, max_iter=100, max_ls=25)
+    q2, g, b, st, it = plant.plant_step("hopper_2D", q0, q1, u, cpu.mu_world, tr.h, w=w, opts=o_dev)
+    assert st.all() and g.shape == (len(knots), 1) and b.shape == (len(knots), 2)
+    for k in range(len(knots)):
+        s_, i_, q2c, gc, bc = pl.plant_step(cpu, q0[k], q1[k], u[k], w[k], cpu.mu_world, tr.h, o_cpu)
+        assert s_ and abs(int(it[k]) - i_) <= 1
+        np.testing.assert_allclose(q2[k], q2c, rtol=0, atol=1e-7)
+        np.testing.assert_allclose(g[k], gc, rtol=0, atol=1e-5 * max(1.0, np.abs(gc).max()))
+        np.testing.assert_allclose(b[k], bc, rtol=0, atol=1e-5 * max(1.0, np.abs(bc).max()))
+    # the disturbance is felt: the pushed robots land elsewhere than the same robots without it
+    q2n, *_ = plant.plant_step("hopper_2D", q0, q1, u, cpu.mu_world, tr.h, opts=o_dev)
+    assert np.abs(q2[1] - q2n[1]).max() > 1e-5 and np.abs(q2[4] - q2n[4]).max() > 1e-5 and np.abs(q2[0] - q2n[0]).max() == 0.0
+    # simulate() with a schedule: an impulse at step 3 changes the trajectory from q[4] on
+    pol = lambda q: np.tile(tr.u[0], (q.shape[0], 1))
+    v1 = (tr.q[1] - tr.q[0])[None] / tr.h
+    ok0, qa, *_ = plant.simulate("hopper_2D", pol, tr.q[1][None], v1, 6, tr.h, cpu.mu_world)
+    ok1, qb, *_ = plant.simulate("hopper_2D", pol, tr.q[1][None], v1, 6, tr.h, cpu.mu_world,
+                                 disturbances=plant.ImpulseDisturbance([np.array([3.0, 0.0])], [3]))
+    assert ok0 and ok1
+    np.testing.assert_array_equal(qa[:4], qb[:4])
+    assert np.abs(qa[4] - qb[4]).max() > 1e-6

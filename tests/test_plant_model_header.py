@@ -1,6 +1,6 @@
 """`contactimplicitmpc/jl_amd/csrc/plant_model.h` is host- and device-compilable: built here with g++ (tests/native/
 plant_model_check.cpp) and compared with the numpy plant of oracle/plant.py - residual and dual-number Jacobian of both
-planar-chain models."""
+planar-chain models and of hopper_2D."""
 import os
 import shutil
 import subprocess
@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def test_plant_model_header_matches_the_numpy_plant(tmp_path):
     exe = str(tmp_path / "plant_check")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(HERE, "native", "plant_model_check.cpp")])
-    for mid, P in ((0, pl.QuadrupedPlant()), (1, pl.FlamingoPlant())):
+    for mid, P in ((0, pl.QuadrupedPlant()), (1, pl.FlamingoPlant()), (2, pl.HopperPlant())):
         d = P.dims
         rng = np.random.default_rng(mid)
         z, th, kappa = rng.uniform(0.1, 1.0, d.nz), rng.uniform(0.1, 1.0, d.nth), 1e-3
