@@ -62,7 +62,10 @@ struct Model {
 #define CIMPC_SENS_ILP 5
 #endif
     static constexpr int SENS_ILP = (NX <= 16 && NY <= 16) ? CIMPC_SENS_ILP : 2;   // sensitivity columns solved side by side
-    static constexpr int LDS_GROUP = ((NY * RST_LD + NTH + SENS_MAX / 2) + 1) & ~1;  // doubles / problem
+    // per-problem LDS: the R tile and theta - theta0 SHARE their space (theta - theta0 lives from the pull of a problem to the two
+    // dot products a few lines below it; the tile is scratch inside factorize), then the backlog of deferred sensitivities
+    static constexpr int TILE = NY * RST_LD > NTH ? NY * RST_LD : NTH;
+    static constexpr int LDS_GROUP = ((TILE + SENS_MAX / 2) + 1) & ~1;  // doubles / problem
 };
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -459,8 +462,8 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
     const int grp = tid / G;
     const int l = tid % G;
     double* Rst = smem + L.size + (size_t)grp * M::LDS_GROUP;   // [NY][G+1]
-    double* dth = Rst + NY * M::RST_LD;                          // [NTH]
-    int* backlog = reinterpret_cast<int*>(dth + NTH);            // [SENS_MAX] converged, sensitivities pending
+    double* dth = Rst;                                           // [NTH]  (aliases the tile, see Model::LDS_GROUP)
+    int* backlog = reinterpret_cast<int*>(Rst + M::TILE);        // [SENS_MAX] converged, sensitivities pending
     int nback = 0;
     const bool vx = l < NX, vy = l < NY;
     const cimpc_ip_opts o = p.o;
