@@ -67,6 +67,7 @@ struct Knobs {
     int tail_div = 8;            // CIMPC_TAIL_DIV
     int drain_pct = 95;          // CIMPC_DRAIN_PCT: drain parking once this percentage of the sweep's workgroups has left (0 = off; B = 512: 0 / 75 / 90 / 95 / 97 -> 10.68 / 10.97 / 10.48 / 10.45 / 10.47 ms)
     int drain_min = 4;           // CIMPC_DRAIN_MIN: ... for solves that have had at least this many iterations in the launch
+    bool kkt_scalar = false;     // CIMPC_KKT_SCALAR
     int kkt_chain = -1;          // CIMPC_KKT_CHAIN: chained rounds ({sweep || KKT} -> sweep of the new candidates -> residual) when at least this
                                  // percentage of the round's rollouts start a Newton iteration; -1 = never
     int kkt_pipe = -1;           // CIMPC_KKT_PIPE: two-wave pipelined KKT kernel 0 never, 1 always, -1 where the solve is on the critical path
@@ -98,6 +99,7 @@ struct Knobs {
         kkt_packed = env_int("CIMPC_KKT_PACKED", 1) != 0;
         tail_div = env_int("CIMPC_TAIL_DIV", tail_div);
         kkt_chain = env_int("CIMPC_KKT_CHAIN", kkt_chain);
+        kkt_scalar = env_int("CIMPC_KKT_SCALAR", 0) != 0;
         drain_pct = env_int("CIMPC_DRAIN_PCT", drain_pct);
         drain_min = std::max(1, env_int("CIMPC_DRAIN_MIN", drain_min));
         kkt_pipe = env_int("CIMPC_KKT_PIPE", kkt_pipe);
@@ -560,6 +562,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     select_kkt_backend(h);
     S.spec_all = h->kn.spec_all >= 0 ? h->kn.spec_all : (d.B <= 128 ? 3 : 8);
     S.spec_first = h->kn.spec_first;
+    S.kkt_scalar = h->kn.kkt_scalar ? 1 : 0;
     // large batches: a rollout whose previous search needed a back-off starts the next one with 1, 1/2, 1/4 together (one
     // round less per Newton iteration for 0.9 more evaluated sweeps per step: B = 512 11.4 -> 10.9 ms); small batches already
     // evaluate all seven step lengths from depth 3 on

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void reset_kernel(NewtonDev S, const double* q
 
 template <int NQ, int NU>
 static int launch_kkt_t(const NewtonDev& S, const KktArgs& K, hipStream_t s, bool f32 = false) {
-    static const bool force_scalar = getenv("CIMPC_KKT_SCALAR") && atoi(getenv("CIMPC_KKT_SCALAR")) != 0;
+    const bool force_scalar = S.kkt_scalar != 0;      // (CIMPC_KKT_SCALAR, read at cimpc_create)
     if (NQ <= 24 && NU <= 24 && S.dm.H <= kkt_max_h<NQ, NU>() && !force_scalar) {   // dnu / recovery staging bounds H
         const size_t lds = (size_t)kkt_lds_doubles<NQ, NU, 1>() * sizeof(double);
         if (f32) {      // block products on the fp32 MFMA (launch_kkt_mixed refines the result in fp64)
@@ -459,7 +459,7 @@ int launch_kkt_packed(const NewtonDev& S, int n_kkt, int list_par, hipStream_t s
     const int nq = S.dm.nq, nu = S.dm.nu;
     if (n_dev != nullptr) n_kkt = S.dm.B;      // upper bound of the grid; surplus workgroups leave at once
     if (n_kkt <= 0) return CIMPC_OK;
-    static const bool force_scalar = getenv("CIMPC_KKT_SCALAR") && atoi(getenv("CIMPC_KKT_SCALAR")) != 0;
+    const bool force_scalar = S.kkt_scalar != 0;
     if (S.kkt_list == nullptr || S.dm.mode != CIMPC_MODE_CONFIGURATION || nq > 24 || nu > 24 || S.dm.H > 96 || force_scalar) return launch_kkt(S, s);
     const KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 1};
     const int* list = S.kkt_list + (size_t)list_par * S.dm.B;

@@ -26,6 +26,7 @@ struct NewtonDev {
     int nb_launch;     // rollouts served by this launch
     int kkt_same_round; // 1: KKT runs before the sweep on the same stream (small batches); 2: chained round - KKT next to the first sweep,
                         //    its candidates are evaluated by the round's second sweep (queue par ^ 1)
+    int kkt_scalar;     // 1: the non-MFMA condensed kernel everywhere (CIMPC_KKT_SCALAR, diagnostic)
     int nd, nr, nth, nths, N;
     TrajDev traj, cand, ref;   // cand: [B*CS] evaluation slots; traj, ref: [B]
     double* nu;        // [B][H][nd]
