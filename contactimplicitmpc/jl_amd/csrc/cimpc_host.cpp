@@ -68,6 +68,8 @@ struct Knobs {
     int drain_pct = 95;          // CIMPC_DRAIN_PCT: drain parking once this percentage of the sweep's workgroups has left (0 = off; B = 512: 0 / 75 / 90 / 95 / 97 -> 10.68 / 10.97 / 10.48 / 10.45 / 10.47 ms)
     int drain_min = 4;           // CIMPC_DRAIN_MIN: ... for solves that have had at least this many iterations in the launch
     bool kkt_scalar = false;     // CIMPC_KKT_SCALAR
+    int async_tail_grid = -1;    // CIMPC_ASYNC_TAIL_GRID: workgroups of the hybrid tail's persistent kernel (0 = the full resident set, -1 = 3 per
+                                 // rollout handed over; B = 512: 512 / 320 / 256 / 192 / 96 workgroups -> 10.85 / 10.42 / 10.35 / 10.38 / 10.6 ms)
     int kkt_chain = -1;          // CIMPC_KKT_CHAIN: chained rounds ({sweep || KKT} -> sweep of the new candidates -> residual) when at least this
                                  // percentage of the round's rollouts start a Newton iteration; -1 = never
     int kkt_pipe = -1;           // CIMPC_KKT_PIPE: two-wave pipelined KKT kernel 0 never, 1 always, -1 where the solve is on the critical path
@@ -99,6 +101,7 @@ struct Knobs {
         kkt_packed = env_int("CIMPC_KKT_PACKED", 1) != 0;
         tail_div = env_int("CIMPC_TAIL_DIV", tail_div);
         kkt_chain = env_int("CIMPC_KKT_CHAIN", kkt_chain);
+        async_tail_grid = env_int("CIMPC_ASYNC_TAIL_GRID", async_tail_grid);
         kkt_scalar = env_int("CIMPC_KKT_SCALAR", 0) != 0;
         drain_pct = env_int("CIMPC_DRAIN_PCT", drain_pct);
         drain_min = std::max(1, env_int("CIMPC_DRAIN_MIN", drain_min));
@@ -980,7 +983,14 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         A.epoch = c + 64;
         A.evals_left = h->a_evals;
         A.abort_flag = (volatile int*)(h->h_ring_dev + 3);
-        A.n_service = h->a_service;
+        // (hybrid tail: few rollouts left - a smaller resident set means fewer idle workgroups polling next to the working ones)
+        int a_grid = h->a_grid, a_service = h->a_service;
+        const int tail_grid = h->kn.async_tail_grid >= 0 ? h->kn.async_tail_grid : std::max(128, 3 * h->async_tail);
+        if (!from_reset && tail_grid > 0 && tail_grid < a_grid) {
+            a_grid = tail_grid;
+            a_service = std::max(1, a_grid / 8);
+        }
+        A.n_service = a_service;
         A.flags = h->kn.async_flags;
         A.idle_sleep = h->kn.async_sleep;
         A.idle_spins = h->kn.async_spins;
@@ -999,7 +1009,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         long long solved_before = 0;      // interior-point problems the lock-step rounds had solved (profiling only)
         if (h->prof_on && !from_reset) HIP_TRY(h, hipMemcpy(&solved_before, S.stats + 1, sizeof(long long), hipMemcpyDeviceToHost));
         prof_begin(h, PC_ASYNC, st);
-        rc2 = launch_newton_async(&h->dm, p, Sk, std::min(h->waves, 4), h->a_grid, st);
+        rc2 = launch_newton_async(&h->dm, p, Sk, std::min(h->waves, 4), a_grid, st);
         prof_end(h, st);
         if (rc2 != CIMPC_OK) return fail(h, rc2, "asynchronous newton launch failed");
         // The host watches the persistent kernel: the reference's wall-clock budget ends the loop silently
