@@ -985,7 +985,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         A.abort_flag = (volatile int*)(h->h_ring_dev + 3);
         // (hybrid tail: few rollouts left - a smaller resident set means fewer idle workgroups polling next to the working ones)
         int a_grid = h->a_grid, a_service = h->a_service;
-        const int tail_grid = h->kn.async_tail_grid >= 0 ? h->kn.async_tail_grid : std::max(128, 3 * h->async_tail);
+        const int tail_grid = h->kn.async_tail_grid >= 0 ? h->kn.async_tail_grid : std::max(256, 3 * h->async_tail);      // (256 = one workgroup per CU: the tail is latency bound, co-resident workgroups slow each other)
         if (!from_reset && tail_grid > 0 && tail_grid < a_grid) {
             a_grid = tail_grid;
             a_service = std::max(1, a_grid / 8);
