@@ -20,7 +20,7 @@ namespace cimpc {
 
 namespace {
 
-constexpr int NZM = PLANT_MAX_Q + 4 * PLANT_NC + 2 * PLANT_NB;      // 43
+constexpr int NZM = PLANT_MAX_Q + 4 * PLANT_NC + 2 * PLANT_NB;      // 66 (centroidal); the planar models have 43, hopper_2D 12
 constexpr int LDA = NZM + 1;
 
 struct PlantOpts {
@@ -60,8 +60,8 @@ __global__ __launch_bounds__(64) void plant_step_kernel(PlantModel M, PlantOpts 
         if (i < nq) v = q0[(size_t)rb * nq + i];
         else if (i < 2 * nq) v = q1[(size_t)rb * nq + i - nq];
         else if (i < 2 * nq + nu) v = u[(size_t)rb * nu + i - 2 * nq];
-        else if (i < 2 * nq + nu + PLANT_NW) v = w ? w[(size_t)rb * PLANT_NW + i - 2 * nq - nu] : 0.0;
-        else v = (i == 2 * nq + nu + PLANT_NW) ? mu : h;
+        else if (i < 2 * nq + nu + M.nw) v = w ? w[(size_t)rb * M.nw + i - 2 * nq - nu] : 0.0;
+        else v = (i == 2 * nq + nu + M.nw) ? mu : h;
         ths[i] = v;
     }
     for (int i = lane; i < nz; i += 64) zs[i] = i < nq ? q1[(size_t)rb * nq + i] : 1.0;
@@ -86,19 +86,21 @@ __global__ __launch_bounds__(64) void plant_step_kernel(PlantModel M, PlantOpts 
         for (int i = nq + lane; i < nz; i += 64) { const double dy = D[i]; if (dy > 0.0) a = fmin(a, tau * zs[i] / dy); }
         return wave_min(a);
     };
-    // A = dr/dz at zs (lane j: column j), then LU with partial pivoting (lane = row)
+    // A = dr/dz at zs (a lane evaluates columns lane, lane + 64: nz <= 66), then LU with partial pivoting (rows lane, lane + 64)
     auto factorize = [&]() {
-        if (lane < nz) {
+        for (int col = lane; col < nz; col += 64) {
             Dual zl[NZM], rl[NZM];
-            for (int i = 0; i < nz; ++i) zl[i] = {zs[i], i == lane ? 1.0 : 0.0};
+            for (int i = 0; i < nz; ++i) zl[i] = {zs[i], i == col ? 1.0 : 0.0};
             plant_residual<Dual>(M, zl, ths, 0.0, rl);
-            for (int i = 0; i < nz; ++i) A[i * LDA + lane] = rl[i].d;
+            for (int i = 0; i < nz; ++i) A[i * LDA + col] = rl[i].d;
         }
         wsync();
         for (int k = 0; k < nz; ++k) {
             // pivot: largest |A[i][k]|, i >= k (ties: smallest row)
-            double best = (lane >= k && lane < nz) ? fabs(A[lane * LDA + k]) : -1.0;
+            double best = -1.0;
             int bi = lane;
+            for (int row = lane; row < nz; row += 64)
+                if (row >= k) { const double v = fabs(A[row * LDA + k]); if (v > best) { best = v; bi = row; } }
             for (int off = 32; off > 0; off >>= 1) {
                 const double ob = __shfl_xor(best, off, 64);
                 const int oi = __shfl_xor(bi, off, 64);
@@ -106,17 +108,19 @@ __global__ __launch_bounds__(64) void plant_step_kernel(PlantModel M, PlantOpts 
             }
             const int p = bi;
             if (lane == 0) piv[k] = p;
-            if (p != k && lane < nz) {                                 // swap rows k and p (lane = column)
-                const double t0 = A[k * LDA + lane];
-                A[k * LDA + lane] = A[p * LDA + lane];
-                A[p * LDA + lane] = t0;
-            }
+            if (p != k)                                                // swap rows k and p (a lane takes columns lane, lane + 64)
+                for (int col = lane; col < nz; col += 64) {
+                    const double t0 = A[k * LDA + col];
+                    A[k * LDA + col] = A[p * LDA + col];
+                    A[p * LDA + col] = t0;
+                }
             wsync();
-            if (lane > k && lane < nz) {
-                const double l = A[lane * LDA + k] / A[k * LDA + k];
-                A[lane * LDA + k] = l;
-                for (int j = k + 1; j < nz; ++j) A[lane * LDA + j] = fma(-l, A[k * LDA + j], A[lane * LDA + j]);
-            }
+            for (int row = lane; row < nz; row += 64)
+                if (row > k) {
+                    const double l = A[row * LDA + k] / A[k * LDA + k];
+                    A[row * LDA + k] = l;
+                    for (int j = k + 1; j < nz; ++j) A[row * LDA + j] = fma(-l, A[k * LDA + j], A[row * LDA + j]);
+                }
             wsync();
         }
     };
@@ -126,14 +130,14 @@ __global__ __launch_bounds__(64) void plant_step_kernel(PlantModel M, PlantOpts 
         wsync();
         for (int k = 0; k < nz; ++k) {                                 // L y = P x
             const double xk = x[k];
-            if (lane > k && lane < nz) x[lane] = fma(-A[lane * LDA + k], xk, x[lane]);
+            for (int row = lane; row < nz; row += 64) if (row > k) x[row] = fma(-A[row * LDA + k], xk, x[row]);
             wsync();
         }
         for (int k = nz - 1; k >= 0; --k) {                            // U x = y
-            if (lane == k) x[k] = x[k] / A[k * LDA + k];
+            if (lane == (k & 63)) x[k] = x[k] / A[k * LDA + k];
             wsync();
             const double xk = x[k];
-            if (lane < k) x[lane] = fma(-A[lane * LDA + k], xk, x[lane]);
+            for (int row = lane; row < k; row += 64) x[row] = fma(-A[row * LDA + k], xk, x[row]);
             wsync();
         }
     };
@@ -220,7 +224,7 @@ extern "C" int cimpc_plant_step(int model, int B, const double* q0, const double
                                 int* status, int* iters) {
     using namespace cimpc;
     if (B <= 0 || !q0 || !q1 || !u || !opts || !q2 || !gamma || !b || !status || !iters || h <= 0.0) return CIMPC_ERR_INVALID;
-    if (model != CIMPC_PLANT_QUADRUPED && model != CIMPC_PLANT_FLAMINGO && model != CIMPC_PLANT_HOPPER_2D) return CIMPC_ERR_INVALID;
+    if (model < CIMPC_PLANT_QUADRUPED || model > CIMPC_PLANT_CENTROIDAL_UNDAMPED) return CIMPC_ERR_INVALID;
     if (opts->max_iter <= 0 || opts->max_ls < 0 || !(opts->r_tol > 0.0) || !(opts->kappa_tol > 0.0) || !(opts->ls_scale > 0.0 && opts->ls_scale < 1.0))
         return CIMPC_ERR_INVALID;
     // runs on the calling thread's CURRENT device (the caller selects it, e.g. hipSetDevice(rank) / torch.cuda.set_device)
@@ -230,12 +234,13 @@ extern "C" int cimpc_plant_step(int model, int B, const double* q0, const double
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return CIMPC_ERR_NO_DEVICE;
     }
-    const PlantModel M = model == CIMPC_PLANT_QUADRUPED ? plant_quadruped() : model == CIMPC_PLANT_FLAMINGO ? plant_flamingo() : plant_hopper_2d();
+    const PlantModel M = model == CIMPC_PLANT_QUADRUPED ? plant_quadruped() : model == CIMPC_PLANT_FLAMINGO ? plant_flamingo()
+                         : model == CIMPC_PLANT_HOPPER_2D ? plant_hopper_2d() : plant_centroidal(model == CIMPC_PLANT_CENTROIDAL);
     const size_t pnc = (size_t)M.nc, pnb = (size_t)M.nb();
     PlantOpts o{opts->r_tol, opts->kappa_tol, std::isinf(opts->undercut) ? 0.0 : opts->kappa_tol / opts->undercut, opts->eps_min,
                 opts->ls_scale, opts->stall_alpha, opts->max_iter, opts->max_ls};
     const size_t nq = M.nq, nu = M.nu;
-    const size_t n_in = (size_t)B * (2 * nq + nu + PLANT_NW), n_out = (size_t)B * (nq + pnc + pnb);
+    const size_t n_in = (size_t)B * (2 * nq + nu + M.nw), n_out = (size_t)B * (nq + pnc + pnb);
     std::lock_guard<std::mutex> lock(g_plant_mu);
     PlantWs& W = g_plant_ws[dev];
     if (!W.st) {
@@ -251,7 +256,7 @@ extern "C" int cimpc_plant_step(int model, int B, const double* q0, const double
     bool ok = hipMemcpyAsync(dq0, q0, B * nq * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess &&
               hipMemcpyAsync(dq1, q1, B * nq * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess &&
               hipMemcpyAsync(du, u, B * nu * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess;
-    if (ok && w) ok = hipMemcpyAsync(dw, w, (size_t)B * PLANT_NW * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess;
+    if (ok && w) ok = hipMemcpyAsync(dw, w, (size_t)B * M.nw * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess;
     if (ok) {
         hipLaunchKernelGGL(plant_step_kernel, dim3(B), dim3(64), 0, st, M, o, B, dq0, dq1, du, w ? dw : nullptr, mu, h, dq2, dg, db,
                            d_st, d_st + B);

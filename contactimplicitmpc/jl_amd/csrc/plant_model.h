@@ -44,14 +44,16 @@ template <class T> PLANT_HD T pconst(double a);
 template <> PLANT_HD double pconst<double>(double a) { return a; }
 template <> PLANT_HD Dual pconst<Dual>(double a) { return {a, 0.0}; }
 
-constexpr int PLANT_MAX_Q = 11, PLANT_MAX_U = 8, PLANT_MAX_BODIES = 9, PLANT_MAX_SEG = 3;
-constexpr int PLANT_NC = 4, PLANT_NB = 8, PLANT_NW = 2;      // at most four contacts, two-sided friction cone (flat_2D_lc)
-constexpr int PLANT_KIND_CHAIN = 0, PLANT_KIND_HOPPER_2D = 1;
+constexpr int PLANT_MAX_Q = 18, PLANT_MAX_U = 12, PLANT_MAX_BODIES = 9, PLANT_MAX_SEG = 3;
+constexpr int PLANT_NC = 4, PLANT_NB = 16, PLANT_NW = 3;     // maxima: four contacts, two (flat_2D_lc) or four (flat_3D_lc) friction directions each
+constexpr int PLANT_KIND_CHAIN = 0, PLANT_KIND_HOPPER_2D = 1, PLANT_KIND_CENTROIDAL = 2;
 
 struct PlantChain { int n; double r[PLANT_MAX_SEG]; int k[PLANT_MAX_SEG]; };
 struct PlantModel {
     int kind = PLANT_KIND_CHAIN;      // planar chain with absolute angles | hopper_2D (constant mass matrix, prismatic leg)
-    int nc = PLANT_NC;                // contacts (nb = 2 nc friction directions)
+    int nc = PLANT_NC;                // contacts
+    int fd = 2;                       // friction directions per contact: 2 (planar) or 4 (spatial)
+    int nw = 2;                       // disturbance dimension (A = eye(nw, nq))
     int nq, nu, n_bodies;
     double g, mu_world;
     double mass[PLANT_MAX_BODIES], inertia[PLANT_MAX_BODIES];
@@ -60,9 +62,9 @@ struct PlantModel {
     PlantChain foot[PLANT_NC];
     int tq_a[PLANT_MAX_U], tq_b[PLANT_MAX_U];     // actuator i: torque between links a and b (B = -e_a + e_b)
     double joint_friction[PLANT_MAX_Q];
-    PLANT_HD int nb() const { return 2 * nc; }
+    PLANT_HD int nb() const { return fd * nc; }
     PLANT_HD int nz() const { return nq + 4 * nc + 2 * nb(); }
-    PLANT_HD int nth() const { return 2 * nq + nu + PLANT_NW + 2; }
+    PLANT_HD int nth() const { return 2 * nq + nu + nw + 2; }
 };
 
 // D1L, D2L at (q, v), accumulated into d1, d2 (nq entries each, zeroed here)
@@ -102,12 +104,83 @@ PLANT_HD void plant_lagrangian_derivatives(const PlantModel& M, const T* q, cons
     }
 }
 
+// ---- centroidal_quadruped (src/dynamics/centroidal_quadruped/model.jl): q = (body position, body orientation, four foot
+// positions), one rigid body + point feet.  M = blkdiag(m_b I, I_b, m_f I_12) (:67-74), C = (m_b g e_z, w x I_b w, m_f g e_z ...)
+// (:76-85) with lagrangian = 0, so D1L = -C, D2L = M v; B(q)^T u = (sum u_i, sum R^T skew(r_i) u_i, -u_1 .. -u_4) with the
+// Euler rotation R of euler.jl:3-11 and r_i = foot_i - body (:98-121); contacts are the feet themselves (J = selection, :129-138),
+// four friction directions per contact (flat_3D_lc: m = [1 0 -1 0; 0 1 0 -1]).  mass[0] = m_b, mass[1] = m_f, inertia[0..2] = I_b.
+template <class T>
+PLANT_HD void plant_centroidal_derivatives(const PlantModel& M, const T* v, T* d1, T* d2) {
+    const double mb = M.mass[0], mf = M.mass[1];
+    const double I0 = M.inertia[0], I1 = M.inertia[1], I2 = M.inertia[2];
+    for (int i = 0; i < 3; ++i) { d2[i] = mb * v[i]; d1[i] = pconst<T>(i == 2 ? -mb * M.g : 0.0); }
+    const T wx = v[3], wy = v[4], wz = v[5];
+    d2[3] = I0 * wx; d2[4] = I1 * wy; d2[5] = I2 * wz;
+    // -(w x I w)
+    d1[3] = -(wy * (I2 * wz) - wz * (I1 * wy));
+    d1[4] = -(wz * (I0 * wx) - wx * (I2 * wz));
+    d1[5] = -(wx * (I1 * wy) - wy * (I0 * wx));
+    for (int i = 6; i < 18; ++i) { d2[i] = mf * v[i]; d1[i] = pconst<T>((i % 3) == 2 ? -mf * M.g : 0.0); }
+}
+template <class T>
+PLANT_HD void plant_residual_centroidal(const PlantModel& M, const T* z, const double* th, double kappa, T* r) {
+    constexpr int nq = 18, nu = 12, nc = 4, nb = 16;
+    const double* q0 = th; const double* q1 = th + nq; const double* u1 = th + 2 * nq; const double* w1 = u1 + nu;
+    const double mu = w1[3], h = w1[4];
+    const T* q2 = z; const T* gam = z + nq; const T* b = gam + nc; const T* psi = b + nb; const T* s1 = psi + nc;
+    const T* eta = s1 + nc; const T* s2 = eta + nb;
+    T qm2[nq], vm1[nq], vm2[nq];
+    for (int i = 0; i < nq; ++i) { vm1[i] = pconst<T>((q1[i] - q0[i]) / h); qm2[i] = (q2[i] + q1[i]) * 0.5; vm2[i] = (q2[i] - q1[i]) / h; }
+    T a1[nq], b1[nq], a2[nq], b2[nq];
+    plant_centroidal_derivatives(M, vm1, a1, b1);
+    plant_centroidal_derivatives(M, vm2, a2, b2);
+    T dyn[nq];
+    for (int i = 0; i < nq; ++i)
+        dyn[i] = (0.5 * h) * a1[i] + b1[i] + (0.5 * h) * a2[i] - b2[i] - (h * M.joint_friction[i]) * vm2[i];
+    {   // B(qm2)^T u
+        const T sa = psin(qm2[3]), ca = pcos(qm2[3]), sb = psin(qm2[4]), cb = pcos(qm2[4]), sc = psin(qm2[5]), cc = pcos(qm2[5]);
+        T R[3][3];
+        R[0][0] = ca * cb; R[0][1] = ca * sb * sc - sa * cc; R[0][2] = ca * sb * cc + sa * sc;
+        R[1][0] = sa * cb; R[1][1] = sa * sb * sc + ca * cc; R[1][2] = sa * sb * cc - ca * sc;
+        R[2][0] = -sb;     R[2][1] = cb * sc;                R[2][2] = cb * cc;
+        for (int f = 0; f < 4; ++f) {
+            const double ux = u1[3 * f], uy = u1[3 * f + 1], uz = u1[3 * f + 2];
+            const T rx = qm2[6 + 3 * f] - qm2[0], ry = qm2[7 + 3 * f] - qm2[1], rz = qm2[8 + 3 * f] - qm2[2];
+            // skew(r) u = r x u
+            const T cx = ry * uz - rz * uy, cy = rz * ux - rx * uz, cz = rx * uy - ry * ux;
+            dyn[0] = dyn[0] + ux; dyn[1] = dyn[1] + uy; dyn[2] = dyn[2] + uz;
+            for (int k = 0; k < 3; ++k) dyn[3 + k] = dyn[3 + k] + (R[0][k] * cx + R[1][k] * cy + R[2][k] * cz);      // R^T (r x u)
+            dyn[6 + 3 * f] = dyn[6 + 3 * f] - ux; dyn[7 + 3 * f] = dyn[7 + 3 * f] - uy; dyn[8 + 3 * f] = dyn[8 + 3 * f] - uz;
+        }
+    }
+    for (int i = 0; i < 3; ++i) dyn[i] = dyn[i] + w1[i];
+    for (int f = 0; f < nc; ++f) {
+        const T* bf = b + 4 * f; const T* ef = eta + 4 * f;
+        // J^T lambda: the foot's own coordinates, lambda = [m b; gamma]
+        dyn[6 + 3 * f] = dyn[6 + 3 * f] + (bf[0] - bf[2]);
+        dyn[7 + 3 * f] = dyn[7 + 3 * f] + (bf[1] - bf[3]);
+        dyn[8 + 3 * f] = dyn[8 + 3 * f] + gam[f];
+        const T vx = (q2[6 + 3 * f] - q1[6 + 3 * f]) / h, vy = (q2[7 + 3 * f] - q1[7 + 3 * f]) / h;
+        r[nq + f] = s1[f] - q2[8 + 3 * f];                           // s1 - phi(q2)
+        r[nq + nc + 4 * f + 0] = ef[0] - vx - psi[f];                // eta - m^T v_T - E^T psi
+        r[nq + nc + 4 * f + 1] = ef[1] - vy - psi[f];
+        r[nq + nc + 4 * f + 2] = ef[2] + vx - psi[f];
+        r[nq + nc + 4 * f + 3] = ef[3] + vy - psi[f];
+        r[nq + nc + nb + f] = s2[f] - (mu * gam[f] - (bf[0] + bf[1] + bf[2] + bf[3]));
+        r[nq + 2 * nc + nb + f] = gam[f] * s1[f] - kappa;
+        for (int k = 0; k < 4; ++k) r[nq + 3 * nc + nb + 4 * f + k] = bf[k] * ef[k] - kappa;
+        r[nq + 3 * nc + 2 * nb + f] = psi[f] * s2[f] - kappa;
+    }
+    for (int i = 0; i < nq; ++i) r[i] = dyn[i];
+}
+
 // r(z, θ, κ): z = [q2; γ; b; ψ; s1; η; s2], θ = [q0; q1; u1; w1; μ; h] (θ real: only dr/dz is needed)
 template <class T>
 PLANT_HD void plant_residual(const PlantModel& M, const T* z, const double* th, double kappa, T* r) {
+    if (M.kind == PLANT_KIND_CENTROIDAL) { plant_residual_centroidal<T>(M, z, th, kappa, r); return; }
     const int nq = M.nq, nu = M.nu, nc = M.nc, nb = M.nb();
     const double* q0 = th; const double* q1 = th + nq; const double* u1 = th + 2 * nq; const double* w1 = u1 + nu;
-    const double mu = w1[PLANT_NW], h = w1[PLANT_NW + 1];
+    const double mu = w1[M.nw], h = w1[M.nw + 1];
     const T* q2 = z; const T* gam = z + nq; const T* b = gam + nc; const T* psi = b + nb; const T* s1 = psi + nc;
     const T* eta = s1 + nc; const T* s2 = eta + nb;
     T qm1[PLANT_MAX_Q], vm1[PLANT_MAX_Q], qm2[PLANT_MAX_Q], vm2[PLANT_MAX_Q];
@@ -129,7 +202,7 @@ PLANT_HD void plant_residual(const PlantModel& M, const T* z, const double* th, 
     } else {
         for (int i = 0; i < nu; ++i) { dyn[M.tq_a[i]] = dyn[M.tq_a[i]] - u1[i]; dyn[M.tq_b[i]] = dyn[M.tq_b[i]] + u1[i]; }
     }
-    dyn[0] = dyn[0] + w1[0]; dyn[1] = dyn[1] + w1[1];
+    for (int i = 0; i < M.nw; ++i) dyn[i] = dyn[i] + w1[i];
     // contacts: position, Jacobian rows (x and z) of every foot at q2
     T s[PLANT_MAX_Q], c[PLANT_MAX_Q];
     for (int i = 0; i < nq; ++i) { s[i] = psin(q2[i]); c[i] = pcos(q2[i]); }
@@ -205,6 +278,15 @@ inline PlantModel plant_hopper_2d() {          // hopper_2D/model.jl:95-121
     const double mb = 3.0, ml = 0.3, Jb = 0.75, Jl = 0.075;
     M.mass[0] = mb + ml; M.mass[1] = mb + ml; M.mass[2] = Jb + Jl; M.mass[3] = ml;      // diagonal of the mass matrix
     for (int i = 0; i < 4; ++i) M.joint_friction[i] = 0.0;
+    return M;
+}
+inline PlantModel plant_centroidal(bool damped) {          // centroidal_quadruped/model.jl:187-228
+    PlantModel M{};
+    M.kind = PLANT_KIND_CENTROIDAL; M.nc = 4; M.fd = 4; M.nw = 3;
+    M.nq = 18; M.nu = 12; M.g = 9.81; M.mu_world = 0.3; M.n_bodies = 0;
+    M.mass[0] = 13.5; M.mass[1] = 0.2;
+    M.inertia[0] = 0.0178533 * 10.0; M.inertia[1] = 0.0377999 * 10.0; M.inertia[2] = 0.0456542 * 10.0;
+    for (int i = 0; i < 18; ++i) M.joint_friction[i] = damped ? ((i >= 3 && i < 6) ? 30.0 : 10.0) : 0.0;      // mu_joint = 1
     return M;
 }
 inline PlantModel plant_flamingo() {           // flamingo/model.jl:458-495

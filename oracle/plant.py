@@ -216,6 +216,74 @@ class HopperPlant:
     jacobian_z = PlanarChainPlant.jacobian_z
 
 
+class CentroidalPlant:
+    """centroidal_quadruped (src/dynamics/centroidal_quadruped/model.jl; flat_3D_lc): q = (body position, Euler orientation,
+    four foot positions), M = blkdiag(m_b I, I_b, m_f I_12), C = (m_b g e_z, w x I_b w, m_f g e_z ...), u = four foot forces
+    (B of :98-121 with the rotation of dynamics/euler.jl), contacts = the feet, four friction directions each.
+    damped=False is `centroidal_quadruped_undamped` (:218-228)."""
+    nq, nu, nw, nc, nb = 18, 12, 3, 4, 16
+    g = 9.81
+    mu_world = 0.3
+    mass_body, mass_foot = 13.5, 0.2
+    inertia = np.array([0.0178533, 0.0377999, 0.0456542]) * 10.0
+
+    def __init__(self, damped=True):
+        self.joint_friction = (np.array([10.0] * 3 + [30.0] * 3 + [10.0] * 12) if damped else np.zeros(18))
+        self.dims = Dims(nq=self.nq, nu=self.nu, nw=self.nw, nc=self.nc, nb=self.nb)
+
+    def lagrangian_derivatives(self, v):
+        d1 = np.zeros_like(v); d2 = np.zeros_like(v)
+        d2[..., 0:3] = self.mass_body * v[..., 0:3]
+        d2[..., 3:6] = self.inertia * v[..., 3:6]
+        d2[..., 6:18] = self.mass_foot * v[..., 6:18]
+        d1[..., 2] = -self.mass_body * self.g
+        w = v[..., 3:6]; Iw = self.inertia * w
+        d1[..., 3:6] = -np.cross(w, Iw)
+        d1[..., 8::3] = -self.mass_foot * self.g
+        return d1, d2
+
+    @staticmethod
+    def rotation(e):                                    # dynamics/euler.jl:3-11
+        a, b, c = e[..., 0], e[..., 1], e[..., 2]
+        sa, ca, sb, cb, sc, cc = np.sin(a), np.cos(a), np.sin(b), np.cos(b), np.sin(c), np.cos(c)
+        R = np.stack([np.stack([ca * cb, ca * sb * sc - sa * cc, ca * sb * cc + sa * sc], axis=-1),
+                      np.stack([sa * cb, sa * sb * sc + ca * cc, sa * sb * cc - ca * sc], axis=-1),
+                      np.stack([-sb, cb * sc, cb * cc], axis=-1)], axis=-2)
+        return R
+
+    def residual(self, z, th, kappa):
+        nq, nu = self.nq, self.nu
+        ot = np.cumsum([0, nq, nq, nu, self.nw, 1, 1])
+        q0, q1, u1, w1, mu, h = (th[..., ot[i]:ot[i + 1]] for i in range(6))
+        o = np.cumsum([0, nq, 4, 16, 4, 4, 16, 4])
+        q2, gam, b, psi, s1, eta, s2 = (z[..., o[i]:o[i + 1]] for i in range(7))
+        vm1, qm2, vm2 = (q1 - q0) / h, 0.5 * (q1 + q2), (q2 - q1) / h
+        a1, b1 = self.lagrangian_derivatives(vm1)
+        a2, b2 = self.lagrangian_derivatives(vm2)
+        dyn = 0.5 * h * a1 + b1 + 0.5 * h * a2 - b2 - h * self.joint_friction * vm2
+        R = self.rotation(qm2[..., 3:6])
+        add = np.zeros_like(dyn)
+        for f in range(4):
+            uf = u1[..., 3 * f:3 * f + 3]
+            rf = qm2[..., 6 + 3 * f:9 + 3 * f] - qm2[..., 0:3]
+            add[..., 0:3] += uf
+            add[..., 3:6] += np.einsum("...ji,...j->...i", R, np.cross(rf, uf))          # R^T skew(r) u
+            add[..., 6 + 3 * f:9 + 3 * f] -= uf
+            bf = b[..., 4 * f:4 * f + 4]
+            add[..., 6 + 3 * f] += bf[..., 0] - bf[..., 2]
+            add[..., 7 + 3 * f] += bf[..., 1] - bf[..., 3]
+            add[..., 8 + 3 * f] += gam[..., f]
+        add[..., 0:3] += w1
+        dyn = dyn + add
+        vt = (q2 - q1)[..., 6:18] / h
+        vstack = np.concatenate([np.stack([vt[..., 3 * f], vt[..., 3 * f + 1], -vt[..., 3 * f], -vt[..., 3 * f + 1]], axis=-1) for f in range(4)], axis=-1)
+        Eb = np.stack([b[..., 4 * f:4 * f + 4].sum(axis=-1) for f in range(4)], axis=-1)
+        return np.concatenate([dyn, s1 - q2[..., 8::3], eta - vstack - np.repeat(psi, 4, axis=-1), s2 - (mu * gam - Eb),
+                               gam * s1 - kappa, b * eta - kappa, psi * s2 - kappa], axis=-1)
+
+    jacobian_z = PlanarChainPlant.jacobian_z
+
+
 def plant_step(plant, q0, q1, u, w, mu, h, opts: oip.IPOptions):
     """One simulator step: solve r(z, θ, κ -> κ_tol) = 0 from z = (q1, 1, ..., 1) (`initialize_z!`,
     quadruped/model.jl:586-590).  Returns (status, iterations, q2, γ, b)."""

@@ -230,3 +230,23 @@ def test_disturbance_schedules():
     imp = ImpulseDisturbance([np.array([5.0, 0.0]), np.array([0.0, -7.0])], [4, 9])
     out = np.array([imp(t) for t in range(1, 11)])
     assert np.count_nonzero(out.any(axis=1)) == 2 and out[3, 0] == 5.0 and out[8, 1] == -7.0
+
+
+def test_centroidal_plant_equals_the_torch_model_and_steps_along_the_trot():
+    """centroidal_quadruped (BASELINE configs[4]'s model), damped and undamped: numpy plant against the torch model, and the
+    undamped plant stepped from two consecutive configurations of the reference's in-place trot lands on the next one (the
+    shipped reference satisfies the undamped dynamics to round-off, tests/test_real_models.py)."""
+    from contactimplicitmpc.jl_amd import lcp_models
+    rng = np.random.default_rng(8)
+    for damped, m in ((True, lcp_models.CentroidalQuadruped()), (False, lcp_models.CentroidalQuadrupedUndamped())):
+        P = pl.CentroidalPlant(damped)
+        z, th = rng.uniform(0.1, 1.0, m.nz), rng.uniform(0.1, 1.0, m.nth)
+        r_t, rz_t, _ = m.linearize(z, th, 1e-3)
+        np.testing.assert_allclose(P.residual(z, th, 1e-3), r_t, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(P.jacobian_z(z, th), rz_t, rtol=0, atol=1e-11 * np.abs(rz_t).max())
+    d, Pr, prob, tabs = real_problem("centroidal", 1e-3, False, 0)
+    P = pl.CentroidalPlant(False)
+    for t in (0, 13, 40):
+        status, it, q2, gam, b = pl.plant_step(P, Pr.q[t], Pr.q[t + 1], Pr.u[t], np.zeros(3), P.mu_world, Pr.h, pl.SIM_OPTS)
+        assert status and it <= 40
+        assert np.abs(q2 - Pr.q[t + 2]).max() < 2e-3

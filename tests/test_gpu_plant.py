@@ -90,3 +90,29 @@ def test_hopper_plant_step_and_disturbances_match_the_cpu_restatement(gpu_requir
     assert ok0 and ok1
     np.testing.assert_array_equal(qa[:4], qb[:4])
     assert np.abs(qa[4] - qb[4]).max() > 1e-6
+
+
+@pytest.mark.parametrize("model,damped", [("centroidal_quadruped", True), ("centroidal_quadruped_undamped", False)])
+def test_centroidal_plant_step_with_payload_matches_the_cpu_restatement(gpu_required, model, damped):
+    """The 3-D centroidal plant (nz = 66: two Jacobian columns / LU rows per lane) against the CPU restatement, with the payload
+    of BASELINE configs[4] as the disturbance w (a body force, centroidal_quadruped/model.jl:123-127)."""
+    from contactimplicitmpc.jl_amd import InteriorPointOptions, plant
+    d, P, prob, tabs = real_problem("centroidal", 1e-3, False, 0)
+    cpu = pl.CentroidalPlant(damped)
+    knots = [0, 13, 27, 40, 55]
+    rng = np.random.default_rng(6)
+    q0 = np.stack([P.q[t] for t in knots]); q1 = np.stack([P.q[t + 1] for t in knots]) + 1e-3 * rng.standard_normal((len(knots), 18))
+    u = np.stack([P.u[t] for t in knots])
+    w = np.zeros((len(knots), 3)); w[1] = [0.0, 0.0, -0.3]; w[3] = [0.1, -0.05, -0.2]          # h * (force): payload on two robots
+    o_cpu = oip.IPOptions(r_tol=1e-8, kappa_tol=1e-8, undercut=np.inf, gamma_reg=0.1, eps_min=0.25, max_iter=100, max_ls=25)
+    o_dev = InteriorPointOptions(r_tol=1e-8, kappa_tol=1e-8, undercut=float("inf"), eps_min=0.25, max_iter=100, max_ls=25)
+    q2, g, b, st, it = plant.plant_step(model, q0, q1, u, cpu.mu_world, P.h, w=w, opts=o_dev)
+    assert st.all() and g.shape == (len(knots), 4) and b.shape == (len(knots), 16)
+    for k in range(len(knots)):
+        s_, i_, q2c, gc, bc = pl.plant_step(cpu, q0[k], q1[k], u[k], w[k], cpu.mu_world, P.h, o_cpu)
+        assert s_ and abs(int(it[k]) - i_) <= 1
+        np.testing.assert_allclose(q2[k], q2c, rtol=0, atol=1e-7)
+        np.testing.assert_allclose(g[k], gc, rtol=0, atol=1e-5 * max(1.0, np.abs(gc).max()))
+        np.testing.assert_allclose(b[k], bc, rtol=0, atol=1e-5 * max(1.0, np.abs(bc).max()))
+    q2n, *_ = plant.plant_step(model, q0, q1, u, cpu.mu_world, P.h, opts=o_dev)
+    assert np.abs(q2[1] - q2n[1]).max() > 1e-6 and np.abs(q2[0] - q2n[0]).max() == 0.0
