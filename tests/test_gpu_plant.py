@@ -116,3 +116,21 @@ def test_centroidal_plant_step_with_payload_matches_the_cpu_restatement(gpu_requ
         np.testing.assert_allclose(b[k], bc, rtol=0, atol=1e-5 * max(1.0, np.abs(bc).max()))
     q2n, *_ = plant.plant_step(model, q0, q1, u, cpu.mu_world, P.h, opts=o_dev)
     assert np.abs(q2[1] - q2n[1]).max() > 1e-6 and np.abs(q2[0] - q2n[0]).max() == 0.0
+
+
+def test_centroidal_closed_loop_with_payload_on_the_device(gpu_required):
+    """examples/centroidal_quadruped/continuous_trot.jl's configuration (H_mpc = 50, velocity objective, kappa 1e-3) with policy
+    AND 3-D plant on the device; two robots, one carrying a 30 N payload the controller does not know about (BASELINE
+    configs[4]); the example's vertical push at MPC step 10 included.  Both keep trotting in place."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("closed_loop_centroidal", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                         "scripts", "closed_loop_centroidal.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    ok, out = mod.run(steps=250, payload=(0.0, -30.0), verbose=False)
+    assert ok                                                            # every plant step converged
+    free, loaded = out
+    assert free["height_drift_max"] < 0.01 and loaded["height_drift_max"] < 0.03
+    assert loaded["height_end"] < free["height_end"] - 0.003            # the payload is felt (≈ 8 mm lower) ...
+    assert free["orientation_max"] < 0.05 and loaded["orientation_max"] < 0.05      # ... and both stay level
+    assert free["newton_iters"] <= 5.0 and loaded["newton_iters"] <= 5.0
