@@ -68,6 +68,8 @@ struct Knobs {
     int drain_pct = 95;          // CIMPC_DRAIN_PCT: drain parking once this percentage of the sweep's workgroups has left (0 = off; B = 512: 0 / 75 / 90 / 95 / 97 -> 10.68 / 10.97 / 10.48 / 10.45 / 10.47 ms)
     int drain_min = 4;           // CIMPC_DRAIN_MIN: ... for solves that have had at least this many iterations in the launch
     bool kkt_scalar = false;     // CIMPC_KKT_SCALAR
+    int async_full_max = 64;     // CIMPC_ASYNC_FULL_MAX: largest batch solved by the single persistent launch alone (larger: hybrid).
+                                 // Measured 128 -> 64: B = 96 8.88 -> 8.11 ms, B = 128 9.72 -> 9.48 ms, B = 64 unchanged (6.9 ms)
     int async_tail_grid = -1;    // CIMPC_ASYNC_TAIL_GRID: workgroups of the hybrid tail's persistent kernel (0 = the full resident set, -1 = 3 per
                                  // rollout handed over; B = 512: 512 / 320 / 256 / 192 / 96 workgroups -> 10.85 / 10.42 / 10.35 / 10.38 / 10.6 ms)
     int kkt_chain = -1;          // CIMPC_KKT_CHAIN: chained rounds ({sweep || KKT} -> sweep of the new candidates -> residual) when at least this
@@ -102,6 +104,7 @@ struct Knobs {
         tail_div = env_int("CIMPC_TAIL_DIV", tail_div);
         kkt_chain = env_int("CIMPC_KKT_CHAIN", kkt_chain);
         async_tail_grid = env_int("CIMPC_ASYNC_TAIL_GRID", async_tail_grid);
+        async_full_max = env_int("CIMPC_ASYNC_FULL_MAX", async_full_max);
         kkt_scalar = env_int("CIMPC_KKT_SCALAR", 0) != 0;
         drain_pct = env_int("CIMPC_DRAIN_PCT", drain_pct);
         drain_min = std::max(1, env_int("CIMPC_DRAIN_MIN", drain_min));
@@ -575,7 +578,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     h->waves = 4;
     // the single-launch solve runs its residual jobs on the whole workgroup: 4 waves also for small batches
     // (measured B = 8: 5.2 -> 4.4 ms, B = 64: 8.5 -> 7.5 ms)
-    if (h->async_on && (h->async_mode == 1 || (h->async_mode == 2 && B >= 4 && B <= 128))) h->waves = 4;
+    if (h->async_on && (h->async_mode == 1 || (h->async_mode == 2 && B >= 4 && B <= h->kn.async_full_max))) h->waves = 4;
     if (h->kn.waves == 1 || h->kn.waves == 2 || (h->kn.waves >= 4 && h->kn.waves <= 8)) h->waves = h->kn.waves;   // (5..8: builds with CIMPC_SWEEP_THREADS > 256)
     h->kkt_overlap = B >= 64;
     if (h->kn.kkt_overlap >= 0) h->kkt_overlap = h->kn.kkt_overlap != 0;
@@ -1053,8 +1056,8 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     };
     if (h->use_dense) { rc = ensure_dense_ws(h); if (rc != CIMPC_OK) return rc; }
     if (h->use_mixed) { rc = ensure_mixed_ws(h); if (rc != CIMPC_OK) return rc; }
-    const bool full_async = h->async_on && !h->use_dense && !h->use_mixed && (h->async_mode == 1 || (h->async_mode == 2 && h->dm.B >= 4 && h->dm.B <= 128));
-    const bool hybrid = h->async_on && !h->use_dense && !h->use_mixed && h->async_mode == 2 && !full_async && h->dm.B > 128;
+    const bool full_async = h->async_on && !h->use_dense && !h->use_mixed && (h->async_mode == 1 || (h->async_mode == 2 && h->dm.B >= 4 && h->dm.B <= h->kn.async_full_max));
+    const bool hybrid = h->async_on && !h->use_dense && !h->use_mixed && h->async_mode == 2 && !full_async && h->dm.B > h->kn.async_full_max;
     if (full_async) return run_async(true, 0);
     // safety net only: every Newton iteration needs at most 3 (speculative) rounds, each evaluation at
     // most ceil(max_iter / iter_cap) launches of the resumable interior-point sweep
