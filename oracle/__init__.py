@@ -7,9 +7,12 @@ execute anything under `oracle/`.  Allowed importers: `tests/`,
 scripts under `scripts/` (closed-loop runs: CPU plant, tracking_error) - and
 there only as the checker / the timed CPU baseline, never as the thing shipped.
 
-Modules: lcp.py, ip.py, newton.py, mpc.py (the path), cimpc_ref.c / cref.py (C port,
-CPU baseline), synth.py (synthetic inputs), plant.py (simulator step + closed
-loop, CPU), banded.py (the banded KKT kernel's algorithm in numpy).
+Modules: lcp.py, ip.py (incl. knot_store: the per-knot sensitivity memory of
+im_traj.ip[t]), newton.py, mpc.py (the path), cimpc_ref.c / cref.py (C port,
+CPU baseline), synth.py / dims.py (re-exports of the product's synthetic-input
+generator and data types), plant.py (simulator step + closed loop, CPU: planar
+chains, hopper_2D, 3-D centroidal_quadruped), banded.py (the banded KKT kernel's
+algorithm in numpy).
 
 Parity status (see DESIGN.md section "Oracle"):
   * reference-side callbacks (rlin!, rzlin!, Schur/MGS-QR, linear_solve!,
