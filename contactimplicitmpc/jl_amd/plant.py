@@ -66,6 +66,24 @@ class OpenLoopDisturbance:
         return self.w[self.idx - 1] / self.N_sample
 
 
+class OpenLoopPolicy:
+    """open_loop_policy(u; N_sample), src/simulator/policy.jl:4-34: nominal control u[k] held for N_sample simulator steps, each
+    step applying u[k] / N_sample.  Usable as the `policy` of `simulate` through `lambda q: pol(t)` or called with the 1-based step."""
+
+    def __init__(self, u, N_sample: int = 1):
+        self.u, self.N_sample = [np.asarray(x, dtype=np.float64) for x in u], int(N_sample)
+        self.idx, self.cnt = 0, self.N_sample
+
+    def __call__(self, t: int):
+        if t == 1:
+            self.idx, self.cnt = 0, self.N_sample
+        if self.cnt == self.N_sample:
+            self.idx += 1
+            self.cnt = 0
+        self.cnt += 1
+        return self.u[self.idx - 1] / self.N_sample
+
+
 class ImpulseDisturbance:
     """impulse_disturbances(w, idx), src/simulator/disturbances.jl:38-58: w[i] at simulator step idx[i] (1-based), zero otherwise."""
 

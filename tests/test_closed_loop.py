@@ -217,6 +217,24 @@ def test_hopper_plant_equals_the_torch_model_and_steps_along_the_gait():
         assert np.abs(q2 - tr.q[t + 2])[:3].max() < 2e-3 and abs(q2[3] - tr.q[t + 2][3]) < 2e-2
 
 
+def test_reference_open_loop_tests():
+    """test/simulator/open_loop.jl:1-43 restated: index / counter sequences and values of open_loop_disturbances and
+    open_loop_policy (H = 4, N_sample = 3)."""
+    from contactimplicitmpc.jl_amd.plant import OpenLoopDisturbance, OpenLoopPolicy
+    rng = np.random.default_rng(0)
+    H, N_sample = 4, 3
+    idx = [1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4]
+    cnt = [1, 2, 3, 1, 2, 3, 1, 2, 3, 1, 2, 3]
+    w = [rng.random(4) for _ in range(H)]
+    d = OpenLoopDisturbance(w, N_sample)
+    u = [rng.random(4) for _ in range(H)]
+    p = OpenLoopPolicy(u, N_sample)
+    for t in range(1, H * N_sample + 1):
+        wt, ut = d(t), p(t)
+        assert (d.idx, d.cnt) == (idx[t - 1], cnt[t - 1]) and (p.idx, p.cnt) == (idx[t - 1], cnt[t - 1])
+        assert np.linalg.norm(wt - w[d.idx - 1] / N_sample) < 1e-10 and np.linalg.norm(ut - u[p.idx - 1] / N_sample) < 1e-10
+
+
 def test_disturbance_schedules():
     """open_loop_disturbances / impulse_disturbances, src/simulator/disturbances.jl:4-58 (index pattern of the comment at :17-20)."""
     from contactimplicitmpc.jl_amd.plant import ImpulseDisturbance, OpenLoopDisturbance
