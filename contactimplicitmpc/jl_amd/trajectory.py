@@ -164,6 +164,12 @@ class Objective:
     v_target: np.ndarray = None        # (H, nq)
     q_target: np.ndarray = None        # (H, nq)
 
+    @classmethod
+    def tracking(cls, dims, H, q=None, u=None, gamma=None, b=None):
+        """TrackingObjective(model, env, H; q, u, γ, b) (objective.jl:9-22): per-step weight matrices, zeros where not given."""
+        z = lambda n, M: np.zeros((H, n, n)) if M is None else np.asarray(M, dtype=np.float64).reshape(H, n, n)
+        return cls(q=z(dims.nq, q), u=z(dims.nu, u), gamma=z(dims.nc, gamma), b=z(dims.nb, b))
+
     def __post_init__(self):
         if self.v is not None:
             H, nq = self.q.shape[0], self.q.shape[1]

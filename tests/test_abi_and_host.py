@@ -82,3 +82,12 @@ def test_struct_layouts_match_the_header(tmp_path):
         assert int(got[cname]) == C.sizeof(py), cname
         for fname, _ in py._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(py, fname).offset, f"{cname}.{fname}"
+
+
+def test_reference_objective_test():
+    """test/controller/objective.jl:1-12: a TrackingObjective over H steps holds H weight matrices of every kind."""
+    from contactimplicitmpc.jl_amd.trajectory import Dims, Objective, QUADRUPED
+    H = 10
+    obj = Objective.tracking(Dims(**QUADRUPED), H)
+    assert len(obj.q) == H and len(obj.u) == H and len(obj.gamma) == H and len(obj.b) == H
+    assert obj.q.shape == (H, 11, 11) and obj.u.shape == (H, 8, 8) and obj.gamma.shape == (H, 4, 4) and obj.b.shape == (H, 8, 8)
