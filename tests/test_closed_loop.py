@@ -268,3 +268,23 @@ def test_centroidal_plant_equals_the_torch_model_and_steps_along_the_trot():
         status, it, q2, gam, b = pl.plant_step(P, Pr.q[t], Pr.q[t + 1], Pr.u[t], np.zeros(3), P.mu_world, Pr.h, pl.SIM_OPTS)
         assert status and it <= 40
         assert np.abs(q2 - Pr.q[t + 2]).max() < 2e-3
+
+
+def test_reference_simulator_test_quadruped_open_loop():
+    """test/simulator/quadruped.jl:1-36 restated on the CPU plant: gait2 with mu_world = 0.5 satisfies the residual (norm < 1e-4
+    at every knot), and the open-loop simulation of the gait's own controls over T = H steps ends within 0.025 of the reference's
+    final base configuration."""
+    from contactimplicitmpc.jl_amd.plant import OpenLoopPolicy
+    d, P, prob, tabs = real_problem("quadruped", KAPPA, True)          # update_friction_coefficient!: mu_world of the model
+    plant = pl.QuadrupedPlant()
+    mu = 0.5                                                            # model.mu_world = 0.5 (:6)
+    th = P.theta.copy(); th[:, -2] = mu
+    s2 = mu * P.gamma - P.b.reshape(P.H, 4, 2).sum(axis=2)              # z packs s2 = mu gamma - E b (index.jl:437-441)
+    z = P.z.copy(); z[:, -4:] = s2
+    for t in range(P.H):
+        assert np.linalg.norm(plant.residual(z[t], th[t], 0.0)) < 1e-4              # :17-20
+    pol = OpenLoopPolicy(list(P.u))
+    q1, v1 = P.q[1].copy(), (P.q[1] - P.q[0]) / P.h
+    ok, q, u, g, b = pl.simulate(plant, lambda qq, t: pol(t + 1), q1, v1, P.H, P.h, mu=mu)
+    assert ok                                                                         # @test status
+    assert np.abs(P.q[-1][:3] - q[-1][:3]).max() < 0.025                              # :35
