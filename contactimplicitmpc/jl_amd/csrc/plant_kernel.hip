@@ -224,7 +224,7 @@ extern "C" int cimpc_plant_step(int model, int B, const double* q0, const double
                                 int* status, int* iters) {
     using namespace cimpc;
     if (B <= 0 || !q0 || !q1 || !u || !opts || !q2 || !gamma || !b || !status || !iters || h <= 0.0) return CIMPC_ERR_INVALID;
-    if (model < CIMPC_PLANT_QUADRUPED || model > CIMPC_PLANT_CENTROIDAL_UNDAMPED) return CIMPC_ERR_INVALID;
+    if (model < CIMPC_PLANT_QUADRUPED || model > CIMPC_PLANT_PARTICLE) return CIMPC_ERR_INVALID;
     if (opts->max_iter <= 0 || opts->max_ls < 0 || !(opts->r_tol > 0.0) || !(opts->kappa_tol > 0.0) || !(opts->ls_scale > 0.0 && opts->ls_scale < 1.0))
         return CIMPC_ERR_INVALID;
     // runs on the calling thread's CURRENT device (the caller selects it, e.g. hipSetDevice(rank) / torch.cuda.set_device)
@@ -235,7 +235,8 @@ extern "C" int cimpc_plant_step(int model, int B, const double* q0, const double
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return CIMPC_ERR_NO_DEVICE;
     }
     const PlantModel M = model == CIMPC_PLANT_QUADRUPED ? plant_quadruped() : model == CIMPC_PLANT_FLAMINGO ? plant_flamingo()
-                         : model == CIMPC_PLANT_HOPPER_2D ? plant_hopper_2d() : plant_centroidal(model == CIMPC_PLANT_CENTROIDAL);
+                         : model == CIMPC_PLANT_HOPPER_2D ? plant_hopper_2d() : model == CIMPC_PLANT_PARTICLE ? plant_particle()
+                         : plant_centroidal(model == CIMPC_PLANT_CENTROIDAL);
     const size_t pnc = (size_t)M.nc, pnb = (size_t)M.nb();
     PlantOpts o{opts->r_tol, opts->kappa_tol, std::isinf(opts->undercut) ? 0.0 : opts->kappa_tol / opts->undercut, opts->eps_min,
                 opts->ls_scale, opts->stall_alpha, opts->max_iter, opts->max_ls};

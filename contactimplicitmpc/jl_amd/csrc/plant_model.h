@@ -46,7 +46,7 @@ template <> PLANT_HD Dual pconst<Dual>(double a) { return {a, 0.0}; }
 
 constexpr int PLANT_MAX_Q = 18, PLANT_MAX_U = 12, PLANT_MAX_BODIES = 9, PLANT_MAX_SEG = 3;
 constexpr int PLANT_NC = 4, PLANT_NB = 16, PLANT_NW = 3;     // maxima: four contacts, two (flat_2D_lc) or four (flat_3D_lc) friction directions each
-constexpr int PLANT_KIND_CHAIN = 0, PLANT_KIND_HOPPER_2D = 1, PLANT_KIND_CENTROIDAL = 2;
+constexpr int PLANT_KIND_CHAIN = 0, PLANT_KIND_HOPPER_2D = 1, PLANT_KIND_CENTROIDAL = 2, PLANT_KIND_PARTICLE = 3;
 
 struct PlantChain { int n; double r[PLANT_MAX_SEG]; int k[PLANT_MAX_SEG]; };
 struct PlantModel {
@@ -174,10 +174,34 @@ PLANT_HD void plant_residual_centroidal(const PlantModel& M, const T* z, const d
     for (int i = 0; i < nq; ++i) r[i] = dyn[i];
 }
 
+// ---- particle (src/dynamics/particle/model.jl): a point mass that is its own contact point; M = m I, C = (0, 0, m g),
+// B = A = J = I, four friction directions (flat_3D_lc).  mass[0] = m.
+template <class T>
+PLANT_HD void plant_residual_particle(const PlantModel& M, const T* z, const double* th, double kappa, T* r) {
+    const double* q0 = th; const double* q1 = th + 3; const double* u1 = th + 6; const double* w1 = th + 9;
+    const double mu = th[12], h = th[13], m = M.mass[0];
+    const T* q2 = z; const T* gam = z + 3; const T* b = z + 4; const T* psi = z + 8; const T* s1 = z + 9; const T* eta = z + 10; const T* s2 = z + 14;
+    T vm2[3];
+    for (int i = 0; i < 3; ++i) vm2[i] = (q2[i] - q1[i]) / h;
+    const T lam[3] = {b[0] - b[2], b[1] - b[3], gam[0]};
+    for (int i = 0; i < 3; ++i) {
+        const double grav = i == 2 ? -m * M.g : 0.0;
+        r[i] = pconst<T>(0.5 * h * grav + m * ((q1[i] - q0[i]) / h) + 0.5 * h * grav + u1[i] + w1[i]) - m * vm2[i] + lam[i];
+    }
+    r[3] = s1[0] - q2[2];
+    r[4] = eta[0] - vm2[0] - psi[0]; r[5] = eta[1] - vm2[1] - psi[0];
+    r[6] = eta[2] + vm2[0] - psi[0]; r[7] = eta[3] + vm2[1] - psi[0];
+    r[8] = s2[0] - (mu * gam[0] - (b[0] + b[1] + b[2] + b[3]));
+    r[9] = gam[0] * s1[0] - kappa;
+    for (int k = 0; k < 4; ++k) r[10 + k] = b[k] * eta[k] - kappa;
+    r[14] = psi[0] * s2[0] - kappa;
+}
+
 // r(z, θ, κ): z = [q2; γ; b; ψ; s1; η; s2], θ = [q0; q1; u1; w1; μ; h] (θ real: only dr/dz is needed)
 template <class T>
 PLANT_HD void plant_residual(const PlantModel& M, const T* z, const double* th, double kappa, T* r) {
     if (M.kind == PLANT_KIND_CENTROIDAL) { plant_residual_centroidal<T>(M, z, th, kappa, r); return; }
+    if (M.kind == PLANT_KIND_PARTICLE) { plant_residual_particle<T>(M, z, th, kappa, r); return; }
     const int nq = M.nq, nu = M.nu, nc = M.nc, nb = M.nb();
     const double* q0 = th; const double* q1 = th + nq; const double* u1 = th + 2 * nq; const double* w1 = u1 + nu;
     const double mu = w1[M.nw], h = w1[M.nw + 1];
@@ -287,6 +311,14 @@ inline PlantModel plant_centroidal(bool damped) {          // centroidal_quadrup
     M.mass[0] = 13.5; M.mass[1] = 0.2;
     M.inertia[0] = 0.0178533 * 10.0; M.inertia[1] = 0.0377999 * 10.0; M.inertia[2] = 0.0456542 * 10.0;
     for (int i = 0; i < 18; ++i) M.joint_friction[i] = damped ? ((i >= 3 && i < 6) ? 30.0 : 10.0) : 0.0;      // mu_joint = 1
+    return M;
+}
+inline PlantModel plant_particle() {           // particle/model.jl:113-121
+    PlantModel M{};
+    M.kind = PLANT_KIND_PARTICLE; M.nc = 1; M.fd = 4; M.nw = 3;
+    M.nq = 3; M.nu = 3; M.g = 9.81; M.mu_world = 1.0; M.n_bodies = 0;
+    M.mass[0] = 1.0;
+    for (int i = 0; i < 3; ++i) M.joint_friction[i] = 0.0;
     return M;
 }
 inline PlantModel plant_flamingo() {           // flamingo/model.jl:458-495

@@ -179,6 +179,25 @@ class Hopper2D(ContactModel):
         return torch.stack([torch.stack([z, z, o, z]), torch.stack([-torch.sin(q[2]), torch.cos(q[2]), z, o])])
 
 
+class Particle(ContactModel):
+    """src/dynamics/particle/model.jl: 3-D unit point mass, its own contact point (flat_3D_lc: four friction directions)."""
+    name, nq, nu, nw, nc, space = "particle", 3, 3, 3, 1, 3
+    mu_world = 1.0
+    m = 1.0
+
+    def M(self, q):
+        return self.m * torch.eye(3, dtype=F64)
+
+    def C(self, q, v):
+        return _t([0.0, 0.0, self.m * self.g])
+
+    def kinematics(self, q):
+        return q
+
+    def B(self, q):
+        return torch.eye(3, dtype=F64)
+
+
 class PlanarChain(ContactModel):
     """Planar articulated model with ABSOLUTE link angles: q = (x, z, angles...).  Every body / contact point is a chain
     of (signed length, angle index) segments from the hip at (x, z): a segment adds r (sin θ, -cos θ).  The Lagrangian
@@ -349,7 +368,7 @@ class CentroidalQuadrupedUndamped(CentroidalQuadruped):
         return torch.zeros(self.nq, dtype=F64)
 
 
-MODELS = {"hopper_2D": Hopper2D, "quadruped": Quadruped, "flamingo": Flamingo, "centroidal_quadruped": CentroidalQuadruped,
+MODELS = {"hopper_2D": Hopper2D, "particle": Particle, "quadruped": Quadruped, "flamingo": Flamingo, "centroidal_quadruped": CentroidalQuadruped,
           "centroidal_quadruped_undamped": CentroidalQuadrupedUndamped}
 
 

@@ -267,6 +267,7 @@ int cimpc_linear_solve_csc(int device, int n, const long long* colptr, const lon
 #define CIMPC_PLANT_HOPPER_2D 2   /* src/dynamics/hopper_2D/model.jl, flat_2D_lc */
 #define CIMPC_PLANT_CENTROIDAL 3            /* src/dynamics/centroidal_quadruped/model.jl:204-215, flat_3D_lc (joint damping) */
 #define CIMPC_PLANT_CENTROIDAL_UNDAMPED 4   /* centroidal_quadruped_undamped, :218-228 */
+#define CIMPC_PLANT_PARTICLE 5              /* src/dynamics/particle/model.jl, flat_3D_lc (nq 3, nu 3, nc 1, nw 3) */
 int cimpc_plant_step(int model, int B, const double* q0, const double* q1, const double* u, const double* w,
                      double mu, double h, const cimpc_ip_opts* opts, double* q2, double* gamma, double* b,
                      int* status, int* iters);

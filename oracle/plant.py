@@ -284,6 +284,31 @@ class CentroidalPlant:
     jacobian_z = PlanarChainPlant.jacobian_z
 
 
+class ParticlePlant:
+    """particle (src/dynamics/particle/model.jl; flat_3D_lc): a unit point mass, q = (x, y, z), M = m I, C = (0, 0, m g),
+    B = A = J = I, the particle is its own contact point, four friction directions.  The reference's simulator tests drop it
+    and let it slide (test/simulator/particle.jl)."""
+    nq, nu, nw, nc, nb = 3, 3, 3, 1, 4
+    m, g, mu_world = 1.0, 9.81, 1.0
+
+    def __init__(self):
+        self.dims = Dims(nq=3, nu=3, nw=3, nc=1, nb=4)
+
+    def residual(self, z, th, kappa):
+        q0, q1, u1, w1, mu, h = th[..., 0:3], th[..., 3:6], th[..., 6:9], th[..., 9:12], th[..., 12:13], th[..., 13:14]
+        q2, gam, b, psi, s1, eta, s2 = z[..., 0:3], z[..., 3:4], z[..., 4:8], z[..., 8:9], z[..., 9:10], z[..., 10:14], z[..., 14:15]
+        vm1, vm2 = (q1 - q0) / h, (q2 - q1) / h
+        grav = np.zeros_like(q2); grav[..., 2] = -self.m * self.g
+        lam = np.stack([b[..., 0] - b[..., 2], b[..., 1] - b[..., 3], gam[..., 0]], axis=-1)
+        dyn = 0.5 * h * grav + self.m * vm1 + 0.5 * h * grav - self.m * vm2 + u1 + w1 + lam
+        vstack = np.stack([vm2[..., 0], vm2[..., 1], -vm2[..., 0], -vm2[..., 1]], axis=-1)
+        return np.concatenate([dyn, s1 - q2[..., 2:3], eta - vstack - np.repeat(psi, 4, axis=-1),
+                               s2 - (mu * gam - b.sum(axis=-1, keepdims=True)),
+                               gam * s1 - kappa, b * eta - kappa, psi * s2 - kappa], axis=-1)
+
+    jacobian_z = PlanarChainPlant.jacobian_z
+
+
 def plant_step(plant, q0, q1, u, w, mu, h, opts: oip.IPOptions):
     """One simulator step: solve r(z, θ, κ -> κ_tol) = 0 from z = (q1, 1, ..., 1) (`initialize_z!`,
     quadruped/model.jl:586-590).  Returns (status, iterations, q2, γ, b)."""

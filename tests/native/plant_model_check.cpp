@@ -7,7 +7,7 @@ int main() {
     int model; double kappa;
     if (scanf("%d %lf", &model, &kappa) != 2) return 1;
     const cimpc::PlantModel M = model == 0 ? cimpc::plant_quadruped() : model == 1 ? cimpc::plant_flamingo() : model == 2 ? cimpc::plant_hopper_2d()
-                                : cimpc::plant_centroidal(model == 3);
+                                : model == 5 ? cimpc::plant_particle() : cimpc::plant_centroidal(model == 3);
     const int nz = M.nz(), nth = M.nth();
     std::vector<double> z(nz), th(nth), r(nz);
     for (auto& v : z) if (scanf("%lf", &v) != 1) return 1;

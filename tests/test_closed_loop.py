@@ -288,3 +288,22 @@ def test_reference_simulator_test_quadruped_open_loop():
     ok, q, u, g, b = pl.simulate(plant, lambda qq, t: pol(t + 1), q1, v1, P.H, P.h, mu=mu)
     assert ok                                                                         # @test status
     assert np.abs(P.q[-1][:3] - q[-1][:3]).max() < 0.025                              # :35
+
+
+def test_reference_simulator_test_particle_drop_and_slide():
+    """test/simulator/particle.jl:1-30 restated on the CPU plant: a particle dropped from 1 m is at rest at the origin after 100
+    steps of 0.01 s (1e-6); thrown with v = (1, 2, 0) it ends on the ground (1e-6) with zero velocity (1e-6).  Known answers the
+    reference holds for the simulator's interior-point loop - here they pin the build-defined spec of DESIGN.md section 3 run
+    with the simulator's options.  Also: numpy plant = torch model."""
+    from contactimplicitmpc.jl_amd import lcp_models
+    P, m = pl.ParticlePlant(), lcp_models.Particle()
+    rng = np.random.default_rng(9)
+    z, th = rng.uniform(0.1, 1.0, m.nz), rng.uniform(0.1, 1.0, m.nth)
+    r_t, rz_t, _ = m.linearize(z, th, 1e-3)
+    np.testing.assert_allclose(P.residual(z, th, 1e-3), r_t, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(P.jacobian_z(z, th), rz_t, rtol=0, atol=1e-12 * np.abs(rz_t).max())
+    h, T = 0.01, 100
+    ok, q, *_ = pl.simulate(P, lambda qq, t: np.zeros(3), np.array([0.0, 0.0, 1.0]), np.zeros(3), T, h)          # DROP
+    assert ok and np.all(np.abs(q[-1]) < 1e-6)
+    ok, q, *_ = pl.simulate(P, lambda qq, t: np.zeros(3), np.array([0.0, 0.0, 1.0]), np.array([1.0, 2.0, 0.0]), T, h)   # SLIDE
+    assert ok and abs(q[-1][2]) < 1e-6 and np.all(np.abs((q[-1] - q[-2]) / h) < 1e-6)

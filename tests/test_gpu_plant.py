@@ -153,3 +153,17 @@ def test_reference_simulator_test_quadruped_open_loop_on_the_device(gpu_required
     assert ok
     assert np.abs(P.q[-1][:3] - q[-1, 0, :3]).max() < 0.025
     np.testing.assert_array_equal(q[:, 0], q[:, 1])
+
+
+def test_reference_simulator_test_particle_on_the_device(gpu_required):
+    """test/simulator/particle.jl:1-30 on the device plant: DROP and SLIDE side by side (two robots of one batch)."""
+    from contactimplicitmpc.jl_amd import plant
+    h, T = 0.01, 100
+    q1 = np.array([[0.0, 0.0, 1.0], [0.0, 0.0, 1.0]]); v1 = np.array([[0.0, 0.0, 0.0], [1.0, 2.0, 0.0]])
+    ok, q, u, g, b = plant.simulate("particle", lambda qq: np.zeros((2, 3)), q1, v1, T, h, mu=1.0)
+    assert ok
+    assert np.all(np.abs(q[-1, 0]) < 1e-6)                                               # dropped: at rest at the origin
+    assert abs(q[-1, 1, 2]) < 1e-6 and np.all(np.abs((q[-1, 1] - q[-2, 1]) / h) < 1e-6)   # slid: on the ground, stopped
+    cpu = pl.ParticlePlant()
+    okc, qc, *_ = pl.simulate(cpu, lambda qq, t: np.zeros(3), q1[1], v1[1], T, h)
+    np.testing.assert_allclose(q[:, 1], qc, rtol=0, atol=1e-7)                          # and the same path as the CPU restatement

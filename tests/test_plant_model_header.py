@@ -18,7 +18,7 @@ def test_plant_model_header_matches_the_numpy_plant(tmp_path):
     exe = str(tmp_path / "plant_check")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(HERE, "native", "plant_model_check.cpp")])
     for mid, P in ((0, pl.QuadrupedPlant()), (1, pl.FlamingoPlant()), (2, pl.HopperPlant()), (3, pl.CentroidalPlant(True)),
-                   (4, pl.CentroidalPlant(False))):
+                   (4, pl.CentroidalPlant(False)), (5, pl.ParticlePlant())):
         d = P.dims
         rng = np.random.default_rng(mid)
         z, th, kappa = rng.uniform(0.1, 1.0, d.nz), rng.uniform(0.1, 1.0, d.nth), 1e-3
