@@ -256,8 +256,8 @@ int cimpc_linear_solve_csc(int device, int n, const long long* colptr, const lon
  * time-stepping complementarity problem r(z, theta, kappa -> kappa_tol) = 0 from z = initialize_z!(q1), theta = (q0, q1, u, w,
  * mu, h), solved by the interior point with `opts` (the simulator's: undercut = Inf, r_tol = kappa_tol = 1e-8, max_ls = 25,
  * eps_min 0.25 / 0.05 - simulator.jl:24-32, test/controller/mpc_flamingo.jl:53-60).  Models: the planar chains of
- * plant_model.h (nc = 4 contacts, 2 friction directions), hopper_2D (nc = 1) and the 3-D centroidal_quadruped (nq 18, nu 12, nc 4,
- * 4 friction directions, nw = 3).  q0, q1: B x nq; u: B x nu; w: B x nw (2 planar, 3 centroidal) or NULL (the disturbance of
+ * plant_model.h (nc = 4 contacts, 2 friction directions), hopper_2D (nc = 1), the 3-D centroidal_quadruped (nq 18, nu 12, nc 4,
+ * 4 friction directions, nw = 3) and the 3-D particle (nq 3, nc 1).  q0, q1: B x nq; u: B x nu; w: B x nw (2 planar, 3 centroidal) or NULL (the disturbance of
  * src/simulator/disturbances.jl - the host decides its schedule); outputs q2 B x nq, gamma B x nc, b B x nb, status, iters: B.
  * Runs on the calling thread's CURRENT HIP device (select it with hipSetDevice before the call; a handle's device is
  * not implied) on a private per-device stream with persistent buffers; only that stream is synchronized.
