@@ -237,13 +237,11 @@ def real_mpc_loop_latency(H, device, steps=60, perturb=0.02):
             "newton_iters_first_steps": hist[:8]}
 
 
-def real_problem_leg(B, H, device, steps=5, perturb=0.05):
-    """The same Monte-Carlo batch on the REAL quadruped problem: the reference's gait file (gait2.jld2, a data file
-    of the reference kept under tests/golden/gaits) linearized through the model restatement of
-    contactimplicitmpc/jl_amd/lcp_models.py, objective of test/controller/mpc_quadruped.jl:23-27, kappa_mpc = 2e-4,
-    initial configurations perturbed by U(-perturb, perturb) (examples/quadruped/monte_carlo.jl:79-91)."""
-    import torch
-    from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions, gait_io, lcp_models
+def real_problem_inputs(B, H, perturb=0.05):
+    """Inputs of `real_problem_leg` (also the full-size parity test's, tests/test_gpu_round3_parity.py): the reference's
+    quadruped gait2.jld2 linearized through the model restatement, objective of test/controller/mpc_quadruped.jl:23-27,
+    kappa_mpc = 2e-4, initial configurations perturbed by U(-perturb, perturb) (examples/quadruped/monte_carlo.jl:79-91)."""
+    from contactimplicitmpc.jl_amd import gait_io, lcp_models
     m = lcp_models.Quadruped()
     kappa = 2e-4
     t0 = time.perf_counter()
@@ -252,11 +250,24 @@ def real_problem_leg(B, H, device, steps=5, perturb=0.05):
     ro = [lcp_models.make_rollout(P, H, int(np.random.default_rng(7919 + g).integers(0, P.H)), seed=100003 + g, perturb=perturb)
           for g in range(B)]
     qd = 1e-2 * np.concatenate([[1.0, 0.02, 0.25], 0.25 * np.ones(m.nq - 3)])
+    return dict(m=m, P=P, kappa=kappa, rollouts=ro, Q=np.tile(np.diag(qd)[None], (H, 1, 1)),
+                R=np.tile((3e-2 * np.eye(m.nu))[None], (H, 1, 1)), linearization_build_s=t_lin)
+
+
+def real_problem_leg(B, H, device, steps=5, perturb=0.05):
+    """The same Monte-Carlo batch on the REAL quadruped problem: the reference's gait file (gait2.jld2, a data file
+    of the reference kept under tests/golden/gaits) linearized through the model restatement of
+    contactimplicitmpc/jl_amd/lcp_models.py, objective of test/controller/mpc_quadruped.jl:23-27, kappa_mpc = 2e-4,
+    initial configurations perturbed by U(-perturb, perturb) (examples/quadruped/monte_carlo.jl:79-91)."""
+    import torch
+    from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions
+    I = real_problem_inputs(B, H, perturb)
+    m, P, kappa, ro, t_lin = I["m"], I["P"], I["kappa"], I["rollouts"], I["linearization_build_s"]
     s = CIMPCSolver(m.nq, m.nu, m.nw, m.nc, m.nb, P.H, H, B=B, mode=0, ip_opts=InteriorPointOptions(kappa_tol=kappa),
                     newton_opts=NewtonOptions(kappa=kappa, r_tol=3e-4, max_iter=5), device=device)
     for t in range(P.H):
         s.set_linearization(t + 1, P.z[t], P.theta[t], P.r0[t], P.rz0[t], P.rth0[t])
-    s.set_objective(np.tile(np.diag(qd)[None], (H, 1, 1)), np.tile((3e-2 * np.eye(m.nu))[None], (H, 1, 1)))
+    s.set_objective(I["Q"], I["R"])
     s.set_window(np.stack([r["window"] for r in ro]) + 1)
     s.set_reference(*(np.stack([r[k] for r in ro]) for k in ("q", "u", "w", "gamma", "b", "theta")))
     q0 = torch.tensor(np.stack([r["q0"] for r in ro]), dtype=torch.float64, device="cuda")
@@ -281,15 +292,12 @@ def real_problem_leg(B, H, device, steps=5, perturb=0.05):
             "linearization_build_s": t_lin}
 
 
-def centroidal_payload_leg(B, H, device, steps=3):
-    """BASELINE configs[4]: centroidal_quadruped with a payload (body-force disturbance w in theta:
-    src/dynamics/centroidal_quadruped/model.jl:121-125, continuous_trot.jl:80-81), H = 60, on the REAL problem
-    (examples/centroidal_quadruped/reference/inplace_trot_v7.jld2 through the model restatement, continuous_trot.jl:37-73
-    settings: kappa = 1e-3, IP r_tol 1e-4, Newton r_tol 3e-5; tracking part of its objective).  Timed twice: KKT in mixed
-    precision (Schur-block products on the fp32 MFMA + fp64 refinement + fp64 fallback) and in fp64.  B = the per-GPU
-    share of 512 rollouts on 8 GPUs."""
-    import torch
-    from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions, gait_io, lcp_models
+def centroidal_payload_inputs(B, H):
+    """Inputs of `centroidal_payload_leg` = BASELINE configs[4] (also the parity test's, tests/test_gpu_round3_parity.py):
+    examples/centroidal_quadruped/reference/inplace_trot_v7.jld2 through the model restatement, continuous_trot.jl:37-73 settings
+    (kappa = 1e-3, IP r_tol 1e-4, Newton r_tol 3e-5; tracking part of its objective), a constant downward body force
+    w_z = -5 .. -30 N per rollout (the payload: src/dynamics/centroidal_quadruped/model.jl:121-125, continuous_trot.jl:80-81)."""
+    from contactimplicitmpc.jl_amd import gait_io, lcp_models
     m = lcp_models.CentroidalQuadruped()
     kappa = 1e-3
     P = lcp_models.reference_problem(m, gait_io.load_gait(os.path.join(ROOT, "tests", "golden", "gaits", "centroidal_inplace_trot_v7.jld2")), kappa)
@@ -302,6 +310,20 @@ def centroidal_payload_leg(B, H, device, steps=3):
         ro.append(r)
     Q = np.tile(lcp_models.relative_state_cost([1.0, 1, 1], 3e-1 * np.ones(3), [0.2, 0.2, 1.0])[None], (H, 1, 1))
     R = np.tile((3e-3 * np.eye(m.nu))[None], (H, 1, 1))
+    return dict(m=m, P=P, kappa=kappa, rollouts=ro, Q=Q, R=R, ip_r_tol=1e-4, newton_r_tol=3e-5)
+
+
+def centroidal_payload_leg(B, H, device, steps=3):
+    """BASELINE configs[4]: centroidal_quadruped with a payload (body-force disturbance w in theta:
+    src/dynamics/centroidal_quadruped/model.jl:121-125, continuous_trot.jl:80-81), H = 60, on the REAL problem
+    (examples/centroidal_quadruped/reference/inplace_trot_v7.jld2 through the model restatement, continuous_trot.jl:37-73
+    settings: kappa = 1e-3, IP r_tol 1e-4, Newton r_tol 3e-5; tracking part of its objective).  Timed twice: KKT in mixed
+    precision (Schur-block products on the fp32 MFMA + fp64 refinement + fp64 fallback) and in fp64.  B = the per-GPU
+    share of 512 rollouts on 8 GPUs."""
+    import torch
+    from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions
+    I = centroidal_payload_inputs(B, H)
+    m, P, kappa, ro, Q, R = I["m"], I["P"], I["kappa"], I["rollouts"], I["Q"], I["R"]
     out = {"workload": "centroidal_quadruped inplace_trot_v7.jld2 (reference data file), payload w_z = -5..-30 N per rollout, "
                        "H=%d, %d rollouts (512 / 8 GPUs), kappa 1e-3, cold start" % (H, B)}
     q0 = torch.tensor(np.stack([r["q0"] for r in ro]), dtype=torch.float64, device="cuda")

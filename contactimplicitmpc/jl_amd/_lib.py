@@ -70,7 +70,10 @@ SIGNATURES = {
     "cimpc_set_window": (C.c_int, [_h, _ip]),
     "cimpc_set_reference": (C.c_int, [_h, _dp, _dp, _dp, _dp, _dp, _dp]),
     "cimpc_implicit_dynamics": (C.c_int, [_h, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp]),
+    "cimpc_ip_residual": (C.c_int, [_h, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, _dp]),
+    "cimpc_ip_linear_solve": (C.c_int, [_h, C.c_int, C.c_int, _dp, _dp, C.c_double, _dp]),
     "cimpc_kkt_solve": (C.c_int, [_h, _dp, C.c_double, _dp]),
+    "cimpc_kkt_solve_rho": (C.c_int, [_h, _dp, C.c_double, _dp]),
     "cimpc_newton_solve": (C.c_int, [_h, _dp, _dp, C.c_int, _dp, _ip, _dp]),
     "cimpc_newton_solve_dev": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_int]),
     "cimpc_get_trajectory": (C.c_int, [_h, _dp, _dp, _dp, _dp, _dp]),

@@ -800,6 +800,21 @@ int cimpc_set_altitude(cimpc_handle h, const double* alt) {
 
 // The sensitivity memory of failed solves belongs to the reference KNOTS (newton_kernels.hip: dz_rekey_kernel).  Called around
 // every change of the window: rekey_out with the window still in force, rekey_in with the new one.
+// One logical store for both seams.  The reference keeps ONE ip[t].dz per knot that implicit_dynamics! (B3) and the
+// evaluations inside newton_solve! (B4) both write; on the device B4 keeps the accepted evaluation in dz_good and B3 writes
+// slot 0 of S.dz.  When the producer changes between two calls on one handle, the blocks of the previous producer are copied
+// into the store the next call reads / falls back to, so a solve that fails there keeps what the reference would keep.
+static int sync_dz_stores(cimpc_ctx* h, int next_producer) {
+    if (h->dz_producer == 0 || h->dz_producer == next_producer) return CIMPC_OK;
+    const size_t row = (size_t)h->dm.H * h->nths * h->nd * sizeof(double), B = h->dm.B;
+    if (next_producer == 2)      // newton_solve ran last: dz_good -> slot 0 of every rollout
+        HIP_TRY(h, hipMemcpy2DAsync(h->S.dz, CS * row, h->S.dz_good, row, row, B, hipMemcpyDeviceToDevice, h->stream));
+    else                         // implicit_dynamics ran last: slot 0 -> dz_good
+        HIP_TRY(h, hipMemcpy2DAsync(h->S.dz_good, row, h->S.dz, CS * row, row, B, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CIMPC_OK;
+}
+
 static int rekey_out(cimpc_ctx* h) {
     if (h->dz_producer == 0 || !h->window_set) return CIMPC_OK;
     if (!h->d_dz_knot && dev_alloc(h, &h->d_dz_knot, (size_t)h->dm.B * h->dm.H_ref * h->nths * h->nd) != CIMPC_OK) return CIMPC_ERR_HIP;
@@ -869,6 +884,7 @@ int cimpc_implicit_dynamics(cimpc_handle h, const double* q, const double* theta
     if (d.mode == CIMPC_MODE_CONFIGURATIONFORCE && (!gamma || !b))
         return fail(h, CIMPC_ERR_INVALID, "gamma and b are required in configurationforce mode");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (int sy = sync_dz_stores(h, 2); sy != CIMPC_OK) return sy;
     h->dz_producer = 2;
     TrajDev& T = h->S.cand;
     // evaluation slot 0 of every rollout (slot stride = CS rows)
@@ -912,6 +928,46 @@ int cimpc_implicit_dynamics(cimpc_handle h, const double* q, const double* theta
     return CIMPC_OK;
 }
 
+// B2 seam: one reference-side callback on n points of knot t (ip_kernel_impl.h: ip_callback_kernel)
+static int run_ip_callback(cimpc_handle h, int t, int n, int op, const double* z, const double* theta, const double* alt,
+                           const double* r, double kappa, double reg, double* out) {
+    if (!h || !z || !out || n <= 0) return fail(h, CIMPC_ERR_INVALID, "null argument");
+    if (t < 1 || t > h->dm.H_ref) return fail(h, CIMPC_ERR_INVALID, "knot index out of range (1-based)");
+    if (!h->knot_set[t - 1]) return fail(h, CIMPC_ERR_STATE, "set_linearization has not been called for this knot");
+    if (h->ki.generic) return fail(h, CIMPC_ERR_INVALID, "B2 callbacks exist for the compiled lane-group models only");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t nz = h->nz, nth = h->nth, nc = h->dm.nc;
+    const size_t naux = std::max(nz, nth);               // theta (op 0) or r (op 1)
+    const size_t tot = (size_t)n * (2 * nz + naux + nc);
+    double* buf = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&buf, tot * sizeof(double)));
+    double* d_z = buf; double* d_out = buf + (size_t)n * nz; double* d_aux = d_out + (size_t)n * nz; double* d_alt = d_aux + (size_t)n * naux;
+    auto done = [&](int rc) { (void)hipFree(buf); return rc; };
+    if (hipMemcpy(d_z, z, (size_t)n * nz * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return done(fail(h, CIMPC_ERR_HIP, "upload failed"));
+    const double* aux = op == 0 ? theta : r;
+    if (!aux) return done(fail(h, CIMPC_ERR_INVALID, "null argument"));
+    if (hipMemcpy(d_aux, aux, (size_t)n * (op == 0 ? nth : nz) * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return done(fail(h, CIMPC_ERR_HIP, "upload failed"));
+    if (alt && hipMemcpy(d_alt, alt, (size_t)n * nc * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return done(fail(h, CIMPC_ERR_HIP, "upload failed"));
+    IpCallbackArgs a{};
+    a.tab = h->d_tab; a.knot = t - 1; a.n = n; a.op = op; a.z = d_z;
+    a.theta = op == 0 ? d_aux : nullptr; a.alt = (op == 0 && alt) ? d_alt : nullptr; a.r = op == 1 ? d_aux : nullptr;
+    a.kappa = kappa; a.reg = reg; a.out = d_out;
+    (void)hipGetLastError();                             // (a stale error of an earlier call must not be read as this launch's)
+    const int rc = launch_ip_callback(&h->dm, a, h->stream);
+    if (rc != CIMPC_OK) return done(fail(h, rc, "callback launch failed"));
+    if (hipStreamSynchronize(h->stream) != hipSuccess ||
+        hipMemcpy(out, d_out, (size_t)n * nz * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return done(fail(h, CIMPC_ERR_HIP, "callback kernel failed"));
+    return done(CIMPC_OK);
+}
+
+int cimpc_ip_residual(cimpc_handle h, int t, int n, const double* z, const double* theta, const double* alt, double kappa, double* r) {
+    return run_ip_callback(h, t, n, 0, z, theta, alt, nullptr, kappa, 0.0, r);
+}
+
+int cimpc_ip_linear_solve(cimpc_handle h, int t, int n, const double* z, const double* r, double reg, double* delta) {
+    return run_ip_callback(h, t, n, 1, z, nullptr, nullptr, r, 0.0, reg, delta);
+}
+
 int cimpc_kkt_solve(cimpc_handle h, const double* r, double beta, double* delta) {
     int rc = check_ready(h, true);
     if (rc != CIMPC_OK) return rc;
@@ -939,11 +995,26 @@ int cimpc_kkt_solve(cimpc_handle h, const double* r, double beta, double* delta)
     return CIMPC_OK;
 }
 
+int cimpc_kkt_solve_rho(cimpc_handle h, const double* r, double rho, double* delta) {
+    if (!h) return CIMPC_ERR_INVALID;
+    if (!(rho >= 0.0) || !(h->nt.kappa > 0.0)) return fail(h, CIMPC_ERR_INVALID, "rho must be >= 0 (and kappa > 0)");
+    // the kernels form rho = H * beta * kappa (newton_jacobian.jl:169-186): hand them the beta that reproduces rho
+    const double Hk = (double)h->dm.H, kap = h->nt.kappa;
+    auto f = [&](double b) { return Hk * b * kap; };
+    double beta = rho / (Hk * kap), err = std::fabs(f(beta) - rho), lo = beta, hi = beta;
+    for (int k = 0; k < 4 && err != 0.0; ++k) {
+        lo = std::nextafter(lo, -HUGE_VAL); hi = std::nextafter(hi, HUGE_VAL);
+        for (double c : {lo, hi}) { const double e = std::fabs(f(c) - rho); if (e < err) { err = e; beta = c; } }
+    }
+    return cimpc_kkt_solve(h, r, beta, delta);
+}
+
 int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q1_dev, int warm_start) {
     int rc = check_ready(h, true);
     if (rc != CIMPC_OK) return rc;
     if (!q0_dev || !q1_dev) return fail(h, CIMPC_ERR_INVALID, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (int sy = sync_dz_stores(h, 1); sy != CIMPC_OK) return sy;
     h->dz_producer = 1;
     NewtonDev& S = h->S;
     const auto t0 = std::chrono::steady_clock::now();

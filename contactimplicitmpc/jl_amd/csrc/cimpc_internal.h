@@ -151,6 +151,18 @@ struct IpParams {
     AsyncQ A;
 };
 
+// B2 seam (cimpc_ip_residual / cimpc_ip_linear_solve): one reference-side callback on n caller-supplied points of knot `knot`
+struct IpCallbackArgs {
+    const double* tab;     // packed linearization tables (device)
+    int knot, n, op;       // op 0: rlin!   op 1: rzlin! + linear_solve!
+    const double* z;       // [n][nz]
+    const double* theta;   // [n][nth]  (op 0)
+    const double* alt;     // [n][nc] or null (op 0)
+    const double* r;       // [n][nz]   (op 1)
+    double kappa, reg;
+    double* out;           // [n][nz]
+};
+
 struct KernelInfo {
     int G;            // lanes per problem
     int lds_table;    // doubles
@@ -177,6 +189,8 @@ inline int lds_opt_in(LdsOptIn& cache, const void* kernel, size_t lds) {
 int ip_kernel_info(const cimpc_dims* dm, KernelInfo* info);
 // launches the queue kernel followed by the sensitivity kernel
 int launch_ip_sweep(const cimpc_dims* dm, const IpParams& p, int waves, hipStream_t s);
+// B2 seam: compiled lane-group models only (CIMPC_ERR_INVALID otherwise)
+int launch_ip_callback(const cimpc_dims* dm, const IpCallbackArgs& a, hipStream_t s);
 // runtime-dimension fallback (ip_generic.hip): nx, ny <= 64, one problem per wavefront
 bool ip_generic_available(const cimpc_dims* dm);
 void ip_generic_info(const cimpc_dims* dm, KernelInfo* info);

@@ -19,6 +19,7 @@ namespace cimpc {
 
 #define X(name, q, u, w, c, b)                                                               \
     int ip_launch_##name(int mode, const IpParams& p, int waves, hipStream_t s);   \
+    int ip_callback_##name(int mode, const IpCallbackArgs& a, hipStream_t s);      \
     void ip_info_##name(int mode, KernelInfo* info);
 CIMPC_MODELS(X)
 #undef X
@@ -47,6 +48,15 @@ int launch_ip_sweep(const cimpc_dims* dm, const IpParams& p, int waves, hipStrea
     CIMPC_MODELS(X)
 #undef X
     return launch_ip_generic(dm, p, s);
+}
+
+int launch_ip_callback(const cimpc_dims* dm, const IpCallbackArgs& a, hipStream_t s) {
+#define X(name, q, u, w, c, b)                                                          \
+    if (dm->nq == q && dm->nu == u && dm->nw == w && dm->nc == c && dm->nb == b)        \
+        return ip_callback_##name(dm->mode, a, s);
+    CIMPC_MODELS(X)
+#undef X
+    return CIMPC_ERR_INVALID;
 }
 
 // asynchronous single-launch Newton solve (newton_async_impl.h): :configuration mode, nq, nu <= 16

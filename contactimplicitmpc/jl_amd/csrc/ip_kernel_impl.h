@@ -713,6 +713,71 @@ __global__ __launch_bounds__(M::G == 16 ? CIMPC_SWEEP_THREADS : 256, M::G == 16 
 }
 
 // ----------------------------------------------------------------------------------------
+// B2 seam: the reference-side callbacks RoboDojo's interior point calls on a knot's linearized problem, exposed one by
+// one (cimpc_ip_residual / cimpc_ip_linear_solve).  The SAME IpSolver members the sweep runs - rlin!
+// (linearized_solver.jl:364-373), rzlin! + schur_factorize! (:378-399, schur.jl:80-88), linear_solve!(D, rz, r)
+// (:424-444) - on caller-supplied points, so that the reference's own known-answer tests of these operators
+// (test/controller/linearized_solver.jl:55-57, test/solver/schur.jl:19-62) run against the device arithmetic.
+// One wavefront per workgroup, 64 / G problems per wavefront.
+// ----------------------------------------------------------------------------------------
+template <class M>
+__global__ __launch_bounds__(64) void ip_callback_kernel(IpCallbackArgs a) {
+    constexpr int NX = M::NX, NY = M::NY, NTH = M::NTH, G = M::G;
+    constexpr LinLayout L(NX, NY, NTH, G);
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = (int)threadIdx.x, grp = tid / G, l = tid % G;
+    double* tab = smem;
+    double* Rst = smem + L.size + (size_t)grp * M::LDS_GROUP;
+    stage_table<M>(tab, a.tab, a.knot, tid);
+    __syncthreads();
+    const int prob = (int)blockIdx.x * (64 / G) + grp;
+    const bool live = prob < a.n;
+    const size_t pi = (size_t)(live ? prob : 0);
+    IpSolver<M> S;
+    S.bind(tab, Rst, l);
+    const bool vx = S.vx, vy = S.vy;
+    const double* z = a.z + pi * M::NZ;
+    S.x = vx ? z[l] : 0.0;
+    S.y1 = vy ? z[NX + l] : 1.0;
+    S.y2 = vy ? z[NX + NY + l] : 1.0;
+    double* out = a.out + pi * M::NZ;
+    if (a.op == 0) {         // rlin!(r, z, theta, kappa)
+        const double* th = a.theta + pi * NTH;
+        double td[2] = {0.0, 0.0}, tr[2] = {0.0, 0.0};      // (even / odd partial sums: the association serve_knot uses)
+        for (int k = 0; k < NTH; ++k) {
+            const double dk = th[k] - tab[L.oTh0 + k];
+            td[k & 1] = fma(tab[L.oRthDyn + k * G + l], dk, td[k & 1]);
+            tr[k & 1] = fma(tab[L.oRthRst + k * G + l], dk, tr[k & 1]);
+        }
+        S.tthdyn = td[0] + td[1]; S.tthrst = tr[0] + tr[1];
+        S.altl = (a.alt != nullptr && l < M::NC) ? a.alt[pi * M::NC + l] : 0.0;
+        S.residual(a.kappa);
+        if (live && vx) out[l] = S.rdyn;
+        if (live && vy) { out[NX + l] = S.rrst; out[NX + NY + l] = S.rbil; }
+    } else {                 // rzlin!(rz, z; reg) ; linear_solve!(Delta, rz, r; reg)
+        const double* r = a.r + pi * M::NZ;
+        S.rdyn = vx ? r[l] : 0.0;
+        S.rrst = vy ? r[NX + l] : 0.0;
+        S.rbil = vy ? r[NX + NY + l] : 0.0;
+        S.factorize(a.reg);
+        S.linear_solve();
+        if (live && vx) out[l] = S.Dx_;
+        if (live && vy) { out[NX + l] = S.Dy1_; out[NX + NY + l] = S.Dy2_; }
+    }
+}
+
+template <class M>
+int launch_callback(const IpCallbackArgs& a, hipStream_t s) {
+    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G);
+    const int ppw = 64 / M::G;
+    const size_t lds = (size_t)(L.size + ppw * M::LDS_GROUP) * sizeof(double);
+    static LdsOptIn optin;
+    if (lds_opt_in(optin, (const void*)ip_callback_kernel<M>, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
+    hipLaunchKernelGGL((ip_callback_kernel<M>), dim3((a.n + ppw - 1) / ppw), dim3(64), lds, s, a);
+    return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+}
+
+// ----------------------------------------------------------------------------------------
 // per-model launch / info (instantiated in ip_model_*.hip, one translation unit per model
 // so that the models build in parallel)
 // ----------------------------------------------------------------------------------------
@@ -742,6 +807,10 @@ void info_model(KernelInfo* info) {
     int ip_launch_##name(int mode, const IpParams& p, int waves, hipStream_t s) {            \
         if (mode == 0) return launch_model<Model<q, u, w, c, b, 0>>(p, waves, s);            \
         return launch_model<Model<q, u, w, c, b, 1>>(p, waves, s);                           \
+    }                                                                                        \
+    int ip_callback_##name(int mode, const IpCallbackArgs& a, hipStream_t s) {               \
+        if (mode == 0) return launch_callback<Model<q, u, w, c, b, 0>>(a, s);                \
+        return launch_callback<Model<q, u, w, c, b, 1>>(a, s);                               \
     }                                                                                        \
     void ip_info_##name(int mode, KernelInfo* info) {                                        \
         if (mode == 0) info_model<Model<q, u, w, c, b, 0>>(info);                            \

@@ -34,7 +34,9 @@ struct DenseLayout {      // newton_residual.jl:18-54 / 69-98 (0-based offsets i
 
 // LU with partial pivoting of the N x N column-major matrix A (in place) and solve of A x = b with b given in x
 // (getrf-style, right-looking; the right-hand side is permuted and forward-substituted on the fly), one workgroup.
-__device__ void dense_lu_solve(double* A, double* x, int* piv, int N, int tid, int nt, double* s_val, int* s_idx) {
+// `singular` (optional): set to 1 when a pivot column is exactly zero or not finite - the situation in which the reference's
+// lu_solver throws SingularException at this seam (lu.jl:4-12 -> LinearAlgebra.lu!)
+__device__ void dense_lu_solve(double* A, double* x, int* piv, int N, int tid, int nt, double* s_val, int* s_idx, int* singular = nullptr) {
     for (int k = 0; k < N; ++k) {
         double best = -1.0; int bi = k;
         for (int i = k + tid; i < N; i += nt) {
@@ -51,7 +53,9 @@ __device__ void dense_lu_solve(double* A, double* x, int* piv, int N, int tid, i
             __syncthreads();
         }
         const int p = s_idx[0];
+        const double pmag = s_val[0];
         __syncthreads();
+        if (tid == 0 && singular != nullptr && !(pmag > 0.0 && pmag < HUGE_VAL)) *singular = 1;
         if (p != k) {
             for (int j = tid; j < N; j += nt) {
                 const double t0 = A[(size_t)j * N + k];
@@ -473,11 +477,11 @@ __global__ __launch_bounds__(256) void csc_dense_solve_kernel(int n, const long 
     for (int c = tid; c < n; c += nt)                       // 1-based CSC as Julia stores it (duplicate entries add up)
         for (long long p = colptr[c] - 1; p < colptr[c + 1] - 1; ++p) {
             const long long r = rowval[p] - 1;
-            if (r < 0 || r >= n) { *bad = 1; continue; }
+            if (r < 0 || r >= n) { bad[0] = 1; continue; }
             A[(size_t)c * n + r] += nzval[p];
         }
     __syncthreads();
-    dense_lu_solve(A, x, piv, n, tid, nt, s_val, s_idx);
+    dense_lu_solve(A, x, piv, n, tid, nt, s_val, s_idx, bad + 1);
 }
 
 }  // namespace cimpc
@@ -501,20 +505,21 @@ extern "C" int cimpc_linear_solve_csc(int device, int n, const long long* colptr
     bool ok = hipMalloc(&d_cp, (n + 1) * sizeof(long long)) == hipSuccess && hipMalloc(&d_rv, nz * sizeof(long long)) == hipSuccess &&
               hipMalloc(&d_nz, nz * sizeof(double)) == hipSuccess && hipMalloc(&d_b, n * sizeof(double)) == hipSuccess &&
               hipMalloc(&d_A, (size_t)n * n * sizeof(double)) == hipSuccess && hipMalloc(&d_x, n * sizeof(double)) == hipSuccess &&
-              hipMalloc(&d_i, (n + 1) * sizeof(int)) == hipSuccess;
+              hipMalloc(&d_i, (n + 2) * sizeof(int)) == hipSuccess;
     ok = ok && hipMemcpy(d_cp, colptr, (n + 1) * sizeof(long long), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(d_rv, rowval, (size_t)nnz * sizeof(long long), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(d_nz, nzval, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(d_b, b, n * sizeof(double), hipMemcpyHostToDevice) == hipSuccess && hipMemset(d_i + n, 0, sizeof(int)) == hipSuccess;
-    int bad = 0;
+         hipMemcpy(d_b, b, n * sizeof(double), hipMemcpyHostToDevice) == hipSuccess && hipMemset(d_i + n, 0, 2 * sizeof(int)) == hipSuccess;
+    int bad[2] = {0, 0};      // [0] row index out of range, [1] singular matrix
     if (ok) {
         hipLaunchKernelGGL(csc_dense_solve_kernel, dim3(1), dim3(256), 0, nullptr, n, d_cp, d_rv, d_nz, d_b, d_A, d_x, d_i, d_i + n);
         ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
              hipMemcpy(x, d_x, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess &&
-             hipMemcpy(&bad, d_i + n, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+             hipMemcpy(bad, d_i + n, 2 * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
     }
     cleanup();
     if (!ok) return CIMPC_ERR_HIP;
-    return bad ? CIMPC_ERR_INVALID : CIMPC_OK;
+    if (bad[0]) return CIMPC_ERR_INVALID;
+    return bad[1] ? CIMPC_ERR_SINGULAR : CIMPC_OK;      // x then holds Inf / NaN, as after a failed factorization
 }
 

@@ -80,6 +80,8 @@ def linear_solve_csc(A, b, device=0):
     x = np.zeros(n)
     pll = lambda a: a.ctypes.data_as(C.POINTER(C.c_longlong))
     rc = _lib.load().cimpc_linear_solve_csc(int(device), n, pll(cp), pll(rv), _dp(nz), _dp(bb), _dp(x))
+    if rc == -5:      # CIMPC_ERR_SINGULAR: the reference's lu_solver throws SingularException here (lu.jl:4-12)
+        raise np.linalg.LinAlgError("cimpc_linear_solve_csc: singular matrix (zero or non-finite pivot)")
     if rc != 0:
         raise CimpcError(f"cimpc_linear_solve_csc failed ({rc})")
     return x
@@ -212,11 +214,38 @@ class CIMPCSolver:
             out["z"] = z
         return out
 
+    # -- B2: the per-knot interior-point callbacks (linearized_solver.jl:364-444) on caller-supplied points --------
+    def ip_residual(self, t, z, theta, kappa, alt=None):
+        """rlin!(r, z, theta, kappa) for n points of knot t (1-based): z (n, nz), theta (n, nth) -> r (n, nz)."""
+        z = np.ascontiguousarray(np.atleast_2d(z), dtype=np.float64)
+        n = z.shape[0]
+        z = _f64(z, (n, self.nz)); theta = _f64(np.atleast_2d(theta), (n, self.nth))
+        alt = _f64(np.atleast_2d(alt), (n, self.nc)) if alt is not None else None
+        r = np.zeros((n, self.nz))
+        self._check(self.lib.cimpc_ip_residual(self.h, int(t), n, _dp(z), _dp(theta), _dp(alt), float(kappa), _dp(r)), "ip_residual")
+        return r
+
+    def ip_linear_solve(self, t, z, r, reg=0.0):
+        """rzlin!(rz, z; reg) + linear_solve!(Delta, rz, r; reg) for n points of knot t (1-based) -> Delta (n, nz)."""
+        z = np.ascontiguousarray(np.atleast_2d(z), dtype=np.float64)
+        n = z.shape[0]
+        z = _f64(z, (n, self.nz)); r = _f64(np.atleast_2d(r), (n, self.nz))
+        delta = np.zeros((n, self.nz))
+        self._check(self.lib.cimpc_ip_linear_solve(self.h, int(t), n, _dp(z), _dp(r), float(reg), _dp(delta)), "ip_linear_solve")
+        return delta
+
     # -- B1: linear_solve!(solver, Delta, R, r) -----------------------------------------------
     def kkt_solve(self, r, beta):
         r = _f64(r, (self.B, self.N))
         delta = np.zeros_like(r)
         self._check(self.lib.cimpc_kkt_solve(self.h, _dp(r), float(beta), _dp(delta)), "kkt_solve")
+        return delta
+
+    def kkt_solve_rho(self, r, rho):
+        """The same with the dual regularisation rho = -R[N, N] given directly (what a LinearSolver sees at newton.jl:218)."""
+        r = _f64(r, (self.B, self.N))
+        delta = np.zeros_like(r)
+        self._check(self.lib.cimpc_kkt_solve_rho(self.h, _dp(r), float(rho), _dp(delta)), "kkt_solve_rho")
         return delta
 
     # -- B4: newton_solve! ----------------------------------------------------------------------

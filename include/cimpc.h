@@ -30,6 +30,8 @@ extern "C" {
 #define CIMPC_ERR_NO_DEVICE (-2)   /* no HIP device / not gfx950 / HIP runtime failure */
 #define CIMPC_ERR_STATE (-3)       /* call order violated (e.g. tables not set)        */
 #define CIMPC_ERR_HIP (-4)         /* a HIP call failed; see cimpc_last_error          */
+#define CIMPC_ERR_SINGULAR (-5)    /* cimpc_linear_solve_csc: zero / non-finite pivot (the reference's lu_solver throws
+                                      SingularException at this seam, lu.jl:4-12); x holds Inf / NaN                  */
 
 #define CIMPC_MODE_CONFIGURATION 0       /* mode = :configuration      (nd = nq)        */
 #define CIMPC_MODE_CONFIGURATIONFORCE 1  /* mode = :configurationforce (nd = nq+nc+nb)  */
@@ -168,12 +170,30 @@ int cimpc_implicit_dynamics(cimpc_handle h, const double* q, const double* theta
                             const double* gamma, const double* b, double* d, double* dz,
                             int* status, int* iters, double* z);
 
+/* ---- B2: the per-knot callbacks the reference hands to RoboDojo's interior_point (implicit_dynamics.jl:58-68) ---------
+ * on n caller-supplied points of reference knot t (1-based), with the arithmetic of the sweep kernel (same lane-group code):
+ *   cimpc_ip_residual      rlin!(r, z, theta, kappa)   linearized_solver.jl:364-373       r = [rdyn; rrst; rbil]
+ *   cimpc_ip_linear_solve  rzlin!(rz, z, theta; reg)   linearized_solver.jl:378-399 (+ schur_factorize!, schur.jl:80-88)
+ *                          linear_solve!(Delta, rz, r; reg)   linearized_solver.jl:424-444 (schur_solve!, qr_solve!)
+ * z, r, delta: n x nz in the order [x (nq); y1 (ny); y2 (ny)] = (linearization_var_index, index.jl:289-327); theta: n x nth;
+ * alt: n x nc (RLin.alt) or NULL.  The reference runs these inside interior_point_solve!; here they are plumbing / test seams
+ * (the reference's known answers test/controller/linearized_solver.jl:55-57 and test/solver/schur.jl:19-62 run through them) -
+ * a whole solve is cimpc_implicit_dynamics.  Compiled lane-group models only (CIMPC_ERR_INVALID for runtime dimensions). */
+int cimpc_ip_residual(cimpc_handle h, int t, int n, const double* z, const double* theta, const double* alt, double kappa,
+                      double* r);
+int cimpc_ip_linear_solve(cimpc_handle h, int t, int n, const double* z, const double* r, double reg, double* delta);
+
 /* ---- B1: linear_solve!(core.solver, Delta.r, jac.R, res.r) (newton.jl:218) ---------- */
 /* Solves R*Delta = r for every rollout, R assembled on the device from the sensitivities of
  * the LAST sweep exactly as jacobian! does (newton_jacobian.jl:148-198) with dual
  * regularisation rho = H*beta*kappa.  r, delta: B x N, N = H*(nr+nd), reference layout
  * (newton_residual.jl:69-98). */
 int cimpc_kkt_solve(cimpc_handle h, const double* r, double beta, double* delta);
+/* The same with the dual regularisation given directly: rho = -R[N, N], the value jacobian! leaves on the dual diagonal
+ * (jac.reg_du, newton_jacobian.jl:185: decremented by beta kappa once per window step).  This is what a LinearSolver at the B1
+ * seam can see - linear_solve!(solver, x, A, b) gets the matrix, not core.beta (newton.jl:218, 280) - so the Julia binding
+ * reads rho from the CSC matrix it is handed (julia/CIMPCHip.jl: HipKKTSolver). */
+int cimpc_kkt_solve_rho(cimpc_handle h, const double* r, double rho, double* delta);
 
 /* ---- B4: newton_solve!(core, s, q0, q1, window, im_traj, ref_traj; warm_start) ------- */
 /* q0, q1: B x nq.  Requires set_linearization (all knots), set_objective, set_window,

@@ -7,10 +7,16 @@
 #   A1  LinearizedStep per knot -> cimpc_set_linearization                      src/controller/linearized_step.jl:10-31
 #   glue rot_n_stride! / update_window!                                         src/controller/policy.jl:133-141
 #
-# Usage inside the package (after `include("CIMPCHip.jl")` in src/ContactImplicitMPC.jl, library path in ENV["CIMPC_LIB"]):
+# Usage: `include("CIMPCHip.jl")` INSIDE `module ContactImplicitMPC` (src/ContactImplicitMPC.jl, after the solver includes of
+# lines 38-42; library path in ENV["CIMPC_LIB"]).  The file defines the submodule `CIMPCHip`, which imports the package's own
+# `linear_solve!` / `LinearSolver` (so that newton.jl:218 dispatches to the GPU solvers) and, with its last line, makes the
+# constructors `hip_kkt_solver` / `hip_csc_solver` visible to `eval(opts.solver)` in the package module (newton.jl:86).
 #   p   = ci_mpc_policy(ref_traj, s, obj; H_mpc, N_sample, κ_mpc, mode, n_opts, ip_opts)
 #   hip = CIMPCHip.Solver(s, ref_traj, obj; H_mpc, κ = κ_mpc, mode, n_opts, ip_opts)      # once
 #   CIMPCHip.newton_solve!(hip, p.newton, p.q0, q1, p.window, p.traj; warm_start = t > 1)   # instead of newton.jl:169
+# B1 alone (the reference's Newton loop with the GPU KKT solve):
+#   CIMPCHip.CURRENT[] = hip                               # the handle whose device-resident sensitivities are solved with
+#   n_opts = NewtonOptions(solver = :hip_kkt_solver, ...)  # -> Newton(...) calls eval(:hip_kkt_solver)(jac.R)
 #
 # There is no Julia toolchain in the build image of this repository: the file is written against the C header and the
 # reference's types, every call it makes is exercised through the identical C ABI by the Python host
@@ -19,6 +25,10 @@
 module CIMPCHip
 
 using SparseArrays
+using LinearAlgebra: SingularException
+# the package's own generic function and abstract type (both imported from RoboDojo at src/ContactImplicitMPC.jl:32): methods
+# added here are the ones newton.jl:218 `linear_solve!(core.solver, core.Δ.r, core.jac.R, core.res.r)` dispatches to
+import ..ContactImplicitMPC: linear_solve!, LinearSolver, LinearizedStep, friction_dim
 
 const LIB = get(ENV, "CIMPC_LIB", "libcimpc_hip.so")
 
@@ -48,9 +58,8 @@ pack(v::AbstractVector{<:AbstractVector}, n = length(v)) = reduce(hcat, v[1:n]) 
 mutable struct Solver
     h::Ptr{Cvoid}
     dims::Dims
-    β::Float64                  # mirror of core.β for the B1 seam
     function Solver(h, dims)
-        s = new(h, dims, 1e-5)
+        s = new(h, dims)
         finalizer(x -> (x.h == C_NULL || ccall((:cimpc_destroy, LIB), Cint, (Ptr{Cvoid},), x.h); x.h = C_NULL), s)
         return s
     end
@@ -65,7 +74,7 @@ opts)` (newton.jl:37-91): uploads one `LinearizedStep` per knot and the objectiv
 function Solver(s, ref_traj, obj; H_mpc::Int, κ::Float64, mode::Symbol = :configurationforce, n_opts, ip_opts,
                 B::Int = 1, device::Int = 0, kkt_backend = KKT_CONDENSED)
     m = s.model
-    nb = m.nc * Main.ContactImplicitMPC.friction_dim(s.env)
+    nb = m.nc * friction_dim(s.env)
     dims = Dims(m.nq, m.nu, m.nw, m.nc, nb, mode == :configuration ? 0 : 1, ref_traj.H, H_mpc, B)
     ip = Ref(IpOpts(ip_opts.r_tol, ip_opts.κ_tol, ip_opts.undercut, ip_opts.γ_reg, ip_opts.κ_reg, ip_opts.ϵ_min,
                     ip_opts.ls_scale, ip_opts.max_iter, ip_opts.max_ls, 1e-13))
@@ -75,7 +84,7 @@ function Solver(s, ref_traj, obj; H_mpc::Int, κ::Float64, mode::Symbol = :confi
                 Ref(dims), ip, nt, device, h))
     hs = Solver(h[], dims)
     for t = 1:ref_traj.H                                             # A1
-        lin = Main.ContactImplicitMPC.LinearizedStep(s, ref_traj.z[t], ref_traj.θ[t], κ)
+        lin = LinearizedStep(s, ref_traj.z[t], ref_traj.θ[t], κ)
         check(ccall((:cimpc_set_linearization, LIB), Cint,
                     (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
                     hs.h, t, lin.z, lin.θ, lin.r, Matrix(lin.rz), Matrix(lin.rθ)), hs.h)
@@ -161,35 +170,71 @@ function implicit_dynamics!(hs::Solver, im_traj, traj; window = collect(1:traj.H
 end
 
 # ---- B1: LinearSolver seam ---------------------------------------------------------------------------------------------------------
-# (a) on a handle: the KKT system of the handle's device-resident sensitivities - A is NOT read; requires B3 / a Newton
-#     evaluation on the same handle before the call (include/cimpc.h).  Select with opts.solver = :hip_kkt_solver.
+# (a) on a handle: the KKT system of the handle's device-resident sensitivities - the ENTRIES of A are not read; requires B3 / a
+#     Newton evaluation on the same handle before the call (include/cimpc.h).  Select with opts.solver = :hip_kkt_solver.
+#     What IS read from A is the dual regularisation: core.β changes after every accepted step (newton.jl:280) and enters the
+#     matrix as jac.reg_du .-= β κ once per window step (newton_jacobian.jl:185), i.e. A[N, N] = -ρ with ρ = H β κ.  A LinearSolver
+#     is handed the matrix, not core.β (newton.jl:218) - so ρ is taken from the matrix of THIS call, every call.
 const CURRENT = Ref{Union{Nothing,Solver}}(nothing)
-struct HipKKTSolver; hs::Solver; end            # <: LinearSolver inside the package
-hip_kkt_solver(A) = HipKKTSolver(CURRENT[])
-function linear_solve!(s::HipKKTSolver, x::Vector{Float64}, A, b::Vector{Float64}; reg = 0.0, fact::Bool = true)
-    check(ccall((:cimpc_kkt_solve, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}), s.hs.h, b, s.hs.β, x), s.hs.h)
+struct HipKKTSolver <: LinearSolver
+    hs::Solver
+end
+"`eval(opts.solver)(jac.R)` (newton.jl:86): the solver works on the handle registered in `CIMPCHip.CURRENT[]`."
+function hip_kkt_solver(A)
+    CURRENT[] === nothing && error("CIMPCHip.CURRENT[] = Solver(...) must be set before Newton(...; opts.solver = :hip_kkt_solver)")
+    return HipKKTSolver(CURRENT[])
+end
+function linear_solve!(s::HipKKTSolver, x::Vector{Float64}, A::SparseMatrixCSC{Float64,Int}, b::Vector{Float64};
+                       reg::Float64 = 0.0, fact::Bool = true)
+    N = size(A, 1)
+    ρ = -A[N, N]                                                   # dual regularisation of this Newton iteration
+    check(ccall((:cimpc_kkt_solve_rho, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}), s.hs.h, b, ρ, x), s.hs.h)
     return nothing
 end
 # (b) stand-alone: solves with the SparseMatrixCSC passed in, exactly the contract of lu.jl:4-12 / ldl.jl:144-149.
-#     Select with opts.solver = :hip_csc_solver.
-struct HipCSCSolver; device::Int; end
+#     Select with opts.solver = :hip_csc_solver.  A singular matrix raises like the reference's LU (SingularException).
+struct HipCSCSolver <: LinearSolver
+    device::Int
+end
 hip_csc_solver(A) = HipCSCSolver(0)
-function linear_solve!(s::HipCSCSolver, x::Vector{Float64}, A::SparseMatrixCSC{Float64,Int}, b::Vector{Float64}; reg = 0.0, fact::Bool = true)
-    check(ccall((:cimpc_linear_solve_csc, LIB), Cint,
-                (Cint, Cint, Ptr{Int64}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
-                s.device, size(A, 1), A.colptr, A.rowval, A.nzval, b, x))
+function linear_solve!(s::HipCSCSolver, x::Vector{Float64}, A::SparseMatrixCSC{Float64,Int}, b::Vector{Float64};
+                       reg::Float64 = 0.0, fact::Bool = true)
+    rc = ccall((:cimpc_linear_solve_csc, LIB), Cint,
+               (Cint, Cint, Ptr{Int64}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+               s.device, size(A, 1), A.colptr, A.rowval, A.nzval, b, x)
+    rc == -5 && throw(SingularException(0))                       # CIMPC_ERR_SINGULAR
+    check(rc)
     return nothing
 end
 
 # ---- plant side: one simulator step for B robots (RoboDojo step! inside simulate!, simulator.jl:15-63) ---------------------------
-function plant_step(model::Symbol, q0::Matrix{Float64}, q1::Matrix{Float64}, u::Matrix{Float64}, μ, h_sim, opts::IpOpts)
-    B = size(q0, 2); nq = size(q0, 1)
-    q2 = zeros(nq, B); γ = zeros(4, B); b = zeros(8, B); status = zeros(Cint, B); iters = zeros(Cint, B)
+# model symbol -> (CIMPC_PLANT_* id, nq, nu, nc, friction directions per contact, nw); mirrors include/cimpc.h and
+# contactimplicitmpc/jl_amd/plant.py: MODELS (checked by tests/test_julia_binding.py)
+const PLANT_MODELS = Dict{Symbol,NTuple{6,Int}}(
+    :quadruped => (0, 11, 8, 4, 2, 2), :flamingo => (1, 9, 6, 4, 2, 2), :hopper_2D => (2, 4, 2, 1, 2, 2),
+    :centroidal_quadruped => (3, 18, 12, 4, 4, 3), :centroidal_quadruped_undamped => (4, 18, 12, 4, 4, 3),
+    :particle => (5, 3, 3, 1, 4, 3))
+"""
+    plant_step(model, q0, q1, u, μ, h_sim, opts; w = nothing) -> (q2, γ, b, status, iters)
+
+q0, q1: nq x B; u: nu x B; w: nw x B or nothing.  Sizes are checked against the model's table; unknown models are an error.
+"""
+function plant_step(model::Symbol, q0::Matrix{Float64}, q1::Matrix{Float64}, u::Matrix{Float64}, μ, h_sim, opts::IpOpts;
+                    w::Union{Nothing,Matrix{Float64}} = nothing)
+    haskey(PLANT_MODELS, model) || error("cimpc_plant_step has no model $model (available: $(collect(keys(PLANT_MODELS))))")
+    id, nq, nu, nc, nf, nw = PLANT_MODELS[model]
+    B = size(q0, 2)
+    (size(q0, 1) == nq && size(q1) == (nq, B) && size(u) == (nu, B)) || error("plant_step($model): q0, q1 must be $nq x B and u $nu x B")
+    (w === nothing || size(w) == (nw, B)) || error("plant_step($model): w must be $nw x B")
+    q2 = zeros(nq, B); γ = zeros(nc, B); b = zeros(nf * nc, B); status = zeros(Cint, B); iters = zeros(Cint, B)
     check(ccall((:cimpc_plant_step, LIB), Cint,
                 (Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Ref{IpOpts},
                  Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cint}),
-                model == :quadruped ? 0 : 1, B, q0, q1, u, C_NULL, μ, h_sim, Ref(opts), q2, γ, b, status, iters))
+                id, B, q0, q1, u, w === nothing ? C_NULL : w, μ, h_sim, Ref(opts), q2, γ, b, status, iters))
     return q2, γ, b, status, iters
 end
 
 end # module
+
+# executed in the INCLUDING module (ContactImplicitMPC): `eval(opts.solver)` of newton.jl:86 looks the constructor up there
+using .CIMPCHip: hip_kkt_solver, hip_csc_solver

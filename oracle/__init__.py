@@ -9,8 +9,10 @@ there only as the checker / the timed CPU baseline, never as the thing shipped.
 
 Modules: lcp.py, ip.py (incl. knot_store: the per-knot sensitivity memory of
 im_traj.ip[t]), newton.py, mpc.py (the path), cimpc_ref.c / cref.py (C port,
-CPU baseline), synth.py / dims.py (re-exports of the product's synthetic-input
-generator and data types), plant.py (simulator step + closed loop, CPU: planar
+CPU baseline), dims.py (the checker's OWN index layouts; newton.py holds its own
+trajectory / objective containers), synth.py (re-export of the seeded synthetic
+INPUT generator - it produces the inputs both sides of a parity test are fed
+with and holds no solver arithmetic), plant.py (simulator step + closed loop, CPU: planar
 chains, hopper_2D, 3-D centroidal_quadruped), banded.py (the banded KKT kernel's
 algorithm in numpy).
 

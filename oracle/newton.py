@@ -21,7 +21,81 @@ import numpy as np
 
 from . import ip as ipm
 from .dims import Dims, MODE_CONFIGURATION, MODE_CONFIGURATIONFORCE
-from contactimplicitmpc.jl_amd.trajectory import Traj, Objective, copy_traj  # noqa: F401  (host-side containers)
+
+
+# ----------------------------------------------------------------------------
+# containers: the checker's own ContactTraj / copy_traj! / objective holders (trajectory.jl:1-82, newton.jl:105-128,
+# objective.jl:3-47).  Not imported from the product package - see oracle/dims.py.
+# ----------------------------------------------------------------------------
+@dataclass
+class Traj:
+    """ContactTraj (trajectory.jl:1-49) restricted to what the path reads."""
+    q: np.ndarray       # (H+2, nq)
+    u: np.ndarray       # (H, nu)
+    w: np.ndarray       # (H, nw)
+    gamma: np.ndarray   # (H, nc)
+    b: np.ndarray       # (H, nb)
+    theta: np.ndarray   # (H, nth)
+
+    @property
+    def H(self):
+        return self.u.shape[0]
+
+    def copy(self):
+        return Traj(*(a.copy() for a in (self.q, self.u, self.w, self.gamma, self.b, self.theta)))
+
+    def update_theta(self, dims: Dims, t=None):
+        """update_theta!, trajectory.jl:67-82 (0-based t; None = all)."""
+        ts = range(self.H) if t is None else [t]
+        for k in ts:
+            if 0 <= k < self.H:
+                self.theta[k, dims.iq0] = self.q[k]
+                self.theta[k, dims.iq1] = self.q[k + 1]
+                self.theta[k, dims.iu1] = self.u[k]
+                self.theta[k, dims.iw1] = self.w[k]
+
+
+def copy_traj(dst: Traj, src: Traj, H):
+    """copy_traj!, newton.jl:105-128 (first H steps)."""
+    dst.q[:H + 2] = src.q[:H + 2]
+    dst.u[:H] = src.u[:H]
+    dst.w[:H] = src.w[:H]
+    dst.gamma[:H] = src.gamma[:H]
+    dst.b[:H] = src.b[:H]
+    dst.theta[:H] = src.theta[:H]
+
+
+@dataclass
+class Objective:
+    """objective.jl:3-47.  q/u/gamma/b: per-step square matrices (dense allowed).
+    velocity objective iff v is not None."""
+    q: np.ndarray                      # (H, nq, nq)
+    u: np.ndarray                      # (H, nu, nu)
+    gamma: np.ndarray = None           # (H, nc, nc)
+    b: np.ndarray = None               # (H, nb, nb)
+    v: np.ndarray = None               # (H, nq, nq) or None
+    v_target: np.ndarray = None        # (H, nq)
+    q_target: np.ndarray = None        # (H, nq)
+
+    @classmethod
+    def tracking(cls, dims, H, q=None, u=None, gamma=None, b=None):
+        """TrackingObjective(model, env, H; q, u, γ, b) (objective.jl:9-22): per-step weight matrices, zeros where not given."""
+        z = lambda n, M: np.zeros((H, n, n)) if M is None else np.asarray(M, dtype=np.float64).reshape(H, n, n)
+        return cls(q=z(dims.nq, q), u=z(dims.nu, u), gamma=z(dims.nc, gamma), b=z(dims.nb, b))
+
+    def __post_init__(self):
+        if self.v is not None:
+            H, nq = self.q.shape[0], self.q.shape[1]
+            if self.v_target is None:
+                self.v_target = np.zeros((H, nq))
+            if self.q_target is None:     # objective.jl:36-45
+                if np.any(self.v_target != 0.0):
+                    qt = np.zeros((H, nq))
+                    for t in range(1, H):
+                        qt[t] = qt[t - 1] + self.v_target[t - 1]
+                    self.q_target = qt
+                else:
+                    self.q_target = np.zeros((H, nq))
 
 
 # ----------------------------------------------------------------------------

@@ -91,3 +91,52 @@ def test_reference_objective_test():
     obj = Objective.tracking(Dims(**QUADRUPED), H)
     assert len(obj.q) == H and len(obj.u) == H and len(obj.gamma) == H and len(obj.b) == H
     assert obj.q.shape == (H, 11, 11) and obj.u.shape == (H, 8, 8) and obj.gamma.shape == (H, 4, 4) and obj.b.shape == (H, 8, 8)
+
+
+def test_oracle_containers_are_its_own():
+    """the checker must not share its small containers with the product (a bug in a shared update_theta / copy_traj /
+    layout would be common-mode and invisible to the parity tests).  oracle/ imports nothing from the product except the seeded
+    INPUT generator; the two copies of the index layouts agree with each other AND with numbers derived from the reference
+    (src/simulation/index.jl:289-327, 371-384; quadruped: nz = 43, ntheta = 34, test/controller/newton.jl sizes)."""
+    import numpy as np
+    import oracle.dims as od
+    import oracle.newton as on
+    from contactimplicitmpc.jl_amd import trajectory as pt
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in os.listdir(os.path.join(root, "oracle")):
+        if f.endswith(".py") and f != "synth.py":
+            src = open(os.path.join(root, "oracle", f)).read()
+            assert not re.search(r"^\s*(from|import)\s+contactimplicitmpc", src, flags=re.M), f
+    assert od.Dims is not pt.Dims and on.Traj is not pt.Traj and on.copy_traj is not pt.copy_traj and on.Objective is not pt.Objective
+    names = ("PUSHBOT", "HOPPER_2D", "QUADRUPED", "CENTROIDAL", "FLAMINGO", "HOPPER_3D", "WALLEDCARTPOLE", "PARTICLE", "PARTICLE_2D", "CENTROIDAL_WALL")
+    for nm in names:
+        assert getattr(od, nm) == getattr(pt, nm), nm
+        for mode in (0, 1):
+            a, b = od.Dims(**getattr(od, nm), mode=mode), pt.Dims(**getattr(pt, nm), mode=mode)
+            for k in ("nx", "ny", "nz", "nth", "nd", "nr"):
+                assert getattr(a, k) == getattr(b, k), (nm, k)
+            for k in ("ix", "iy1", "iy2", "ig1", "ib1", "iq0", "iq1", "iu1", "iw1"):
+                np.testing.assert_array_equal(getattr(a, k), getattr(b, k))
+    # reference-derived numbers (quadruped, flat_2D_lc): nz = nq + 4 nc + 2 nb = 43, ntheta = 2 nq + nu + nw + 2 = 34;
+    # z = [q2 (11); gamma1 (4); b1 (8); psi1 (4); s1 (4); eta1 (8); s2 (4)], theta = [q0; q1; u1 (8); w1 (2); mu; h]
+    q = od.Dims(**od.QUADRUPED)
+    assert (q.nz, q.nth, q.ny, q.nd, q.nr) == (43, 34, 16, 11, 19)
+    np.testing.assert_array_equal(q.iy1, np.arange(11, 27)); np.testing.assert_array_equal(q.iy2, np.arange(27, 43))
+    np.testing.assert_array_equal(q.ig1, np.arange(11, 15)); np.testing.assert_array_equal(q.ib1, np.arange(15, 23))
+    np.testing.assert_array_equal(q.iu1, np.arange(22, 30)); np.testing.assert_array_equal(q.iw1, np.arange(30, 32))
+    qf = od.Dims(**od.QUADRUPED, mode=1)
+    assert (qf.nd, qf.nr) == (23, 31)                                  # :configurationforce, newton_residual.jl:18-54
+    # update_theta! (trajectory.jl:67-82) and copy_traj! (newton.jl:105-128): same result from both copies, on known values
+    H = 3
+    rng = np.random.default_rng(0)
+    mk = lambda T: T(q=np.arange((H + 2) * 11, dtype=float).reshape(H + 2, 11), u=100 + np.arange(H * 8, dtype=float).reshape(H, 8),
+                     w=200 + np.arange(H * 2, dtype=float).reshape(H, 2), gamma=np.zeros((H, 4)), b=np.zeros((H, 8)), theta=-np.ones((H, 34)))
+    A, B = mk(on.Traj), mk(pt.Traj)
+    A.update_theta(q); B.update_theta(pt.Dims(**pt.QUADRUPED))
+    np.testing.assert_array_equal(A.theta, B.theta)
+    np.testing.assert_array_equal(A.theta[1, :11], A.q[1]); np.testing.assert_array_equal(A.theta[1, 11:22], A.q[2])
+    np.testing.assert_array_equal(A.theta[1, 22:30], A.u[1]); np.testing.assert_array_equal(A.theta[1, 30:32], A.w[1])
+    assert (A.theta[:, 32:] == -1).all()                                # mu, h untouched
+    C = mk(on.Traj); C.q[:] = 0; C.theta[:] = 0
+    on.copy_traj(C, A, H)
+    np.testing.assert_array_equal(C.q, A.q); np.testing.assert_array_equal(C.theta, A.theta)

@@ -179,3 +179,75 @@ def test_newton_status_log_matches_oracle(gpu_required):
         if n:
             np.testing.assert_allclose(log[b, n - 1, 2], rn[b], rtol=1e-12)                   # residual after the last step
             assert (log[b, 1:n, 1] == log[b, :n - 1, 2]).all()                               # before(l+1) == after(l)
+
+
+def test_linear_solve_csc_reports_a_singular_matrix(gpu_required):
+    """lu.jl:4-12 contract at the stand-alone B1 seam: the reference's lu_solver throws SingularException for a singular
+    matrix; the device solve reports CIMPC_ERR_SINGULAR (numpy.linalg.LinAlgError here) instead of returning Inf / NaN as OK."""
+    import scipy.sparse as sp
+    from contactimplicitmpc.jl_amd.solver import linear_solve_csc
+    n = 12
+    A = np.eye(n); A[5, 5] = 0.0                                  # an empty pivot column after elimination
+    with pytest.raises(np.linalg.LinAlgError):
+        linear_solve_csc(sp.csc_matrix(A), np.ones(n))
+    A = np.ones((n, n))                                           # rank one
+    with pytest.raises(np.linalg.LinAlgError):
+        linear_solve_csc(sp.csc_matrix(A), np.ones(n))
+    A = np.eye(n) * 2.0
+    np.testing.assert_allclose(linear_solve_csc(sp.csc_matrix(A), np.ones(n)), 0.5 * np.ones(n))       # (the handle-less seam still works afterwards)
+
+
+def test_kkt_solve_rho_reads_the_regularisation_a_linear_solver_sees(gpu_required):
+    """B1 as the Julia LinearSolver uses it (julia/CIMPCHip.jl: HipKKTSolver): linear_solve!(solver, x, A, b) sees the matrix, not
+    core.beta - rho = -A[N, N] (jac.reg_du, newton_jacobian.jl:185).  cimpc_kkt_solve_rho(rho) == cimpc_kkt_solve(beta) with
+    rho = H beta kappa, and solves the oracle's assembled jacobian! for that beta."""
+    from oracle import ip as oip, newton as onewton
+    from common import oracle_sweep
+    H = 8
+    d, prob, tabs, rollouts = make_case("quadruped", 0, H_ref=10, H=H, B=2, seed=11)
+    obj = synth.make_objective(d, H, kind="quadruped")
+    s = make_solver(d, prob, rollouts, H, obj=obj)
+    q = np.stack([r.q for (_, r, _, _) in rollouts]); th = np.stack([r.theta for (_, r, _, _) in rollouts])
+    out = s.implicit_dynamics(q, th)
+    lay = onewton.Layout(d, H)
+    r = np.random.default_rng(2).standard_normal((2, lay.N))
+    for beta in (1e-5, 10.0, 7.6923076923076925):
+        R0 = onewton.jacobian(lay, obj, {k: out[k][0] for k in ("d", "dq0", "dq1", "du1")}, beta, prob["kappa"])
+        rho = -R0[-1, -1]                                         # what the solver reads off the matrix it is handed
+        assert rho > 0
+        a = s.kkt_solve_rho(r, rho); c = s.kkt_solve(r, beta)
+        np.testing.assert_allclose(a, c, rtol=0, atol=1e-12 * max(1.0, np.abs(c).max()))
+        np.testing.assert_allclose(R0 @ a[0], r[0], rtol=0, atol=1e-8 * max(1.0, np.abs(r[0]).max()))
+    s.close()
+
+
+def test_b3_and_b4_seams_share_one_sensitivity_store(gpu_required):
+    """The reference keeps ONE ip[t].dz per knot, written by implicit_dynamics! (B3) and by every evaluation inside
+    newton_solve! (B4) alike (implicit_dynamics.jl:71-86, 169-176).  Mixed use of the two seams on one handle: a B3
+    call whose solves all FAIL right after a Newton solve returns the Newton solve's accepted sensitivities - not the blocks of
+    the older B3 call -, and a Newton solve after a B3 call falls back to that call's blocks."""
+    from contactimplicitmpc.jl_amd import NewtonOptions
+    H, B = 6, 2
+    d, prob, tabs, rollouts = make_case("quadruped", 0, H_ref=8, H=H, B=B, seed=4, perturb=1e-2)
+    obj = synth.make_objective(d, H, kind="quadruped")
+    q = np.stack([r.q for (_, r, _, _) in rollouts]); th = np.stack([r.theta for (_, r, _, _) in rollouts])
+    q0 = np.stack([r[2] for r in rollouts]); q1 = np.stack([r[3] for r in rollouts])
+    s = make_solver(d, prob, rollouts, H, obj=obj, newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=1e-9, max_iter=2))
+    first = s.implicit_dynamics(q, th)
+    assert first["status"].all()
+    u1, it, rn = s.newton_solve(q0, q1)
+    assert it.min() >= 1 and s.rollout_counters()["ip_failures"].sum() == 0
+    tr = s.trajectory()
+    # what the accepted evaluation of that Newton solve left in the store: B3 at the accepted trajectory, on a second handle
+    th_acc = th.copy()
+    th_acc[:, :, :d.nq] = tr["q"][:, :H]; th_acc[:, :, d.nq:2 * d.nq] = tr["q"][:, 1:H + 1]; th_acc[:, :, 2 * d.nq:2 * d.nq + d.nu] = tr["u"]
+    s2 = make_solver(d, prob, rollouts, H, obj=obj)
+    acc = s2.implicit_dynamics(tr["q"], th_acc)
+    s2.close()
+    assert acc["status"].all() and np.abs(acc["dq1"] - first["dq1"]).max() > 1e-9      # the Newton solve really moved the blocks
+    bad = np.full_like(th, np.nan)                     # no solve of this call can converge: every block keeps the store's content
+    fail = s.implicit_dynamics(q, bad)
+    assert not fail["status"].any()
+    for k in ("dq0", "dq1", "du1"):
+        np.testing.assert_allclose(fail[k], acc[k], rtol=0, atol=1e-9 * max(1.0, np.abs(acc[k]).max()))
+    s.close()

@@ -85,10 +85,12 @@ def test_implicit_dynamics_full_size_vs_oracle(gpu_required, case):
     same = (out["status"] == st) & (out["iters"] == it)
     conv = same & (st == 1)
     dd = np.abs(out["d"] - np.stack([r["d"] for r in ref])).max(axis=2)
-    dz_err = 0.0
-    for k in ("dq0", "dq1", "du1"):
-        o = np.stack([r[k] for r in ref])
-        dz_err = max(dz_err, float((np.abs(out[k] - o).max(axis=(2, 3)) / np.maximum(np.abs(o).max(axis=(2, 3)), 1.0))[conv].max()))
+    # sensitivities, per solve: largest absolute deviation of the consumed block [dq0 | dq1 | du1] and its scale
+    dev_raw = np.transpose(np.concatenate([out["dq0"], out["dq1"], out["du1"]], axis=3), (0, 1, 3, 2))      # (B, H, nths, nd) like dz_raw
+    ora_raw = np.stack([r["dz_raw"] for r in ref])
+    dz_abs = np.abs(dev_raw - ora_raw).max(axis=(2, 3))
+    dz_scale = np.maximum(np.abs(ora_raw).max(axis=(2, 3)), 1.0)
+    dz_err = float((dz_abs / dz_scale)[conv].max())
     zz = np.abs(out["z"] - np.stack([r["z"] for r in ref])).max(axis=2)
     # ---- arbiter: last-place input perturbations of the oracle itself -------------------------------------------
     K = 8
@@ -115,7 +117,9 @@ def test_implicit_dynamics_full_size_vs_oracle(gpu_required, case):
     qs = lambda a: {"median": float(np.quantile(a, 0.5)), "q90": float(np.quantile(a, 0.9)), "q95": float(np.quantile(a, 0.95)), "q99": float(np.quantile(a, 0.99)), "max": float(a.max())}
     # value agreement: nominal tolerance wherever the oracle itself is stable, 50 x its own last-place scatter elsewhere
     tol_d = np.maximum(1e-7, 50 * sc_d); tol_z = np.maximum(1e-6, 50 * sc_z)
+    tol_dz = np.maximum(1e-6 * dz_scale, 50 * sc_dz)
     out_d = conv & (dd > 1e-7)
+    out_dz = conv & (dz_abs > 1e-6 * dz_scale)
     _record("implicit_dynamics", {
         "solves": int(n), "identical_status_and_iters": int(same.sum()), "agreement_rate": float(same.mean()),
         "iters_diff_histogram": {str(k): int(v) for k, v in zip(*np.unique((out["iters"] - it)[flip], return_counts=True))},
@@ -124,6 +128,11 @@ def test_implicit_dynamics_full_size_vs_oracle(gpu_required, case):
         "oracle_own_d_scatter_under_1ulp": qs(sc_d[conv]), "oracle_own_z_scatter_under_1ulp": qs(sc_z[conv]),
         "solves_with_d_diff_above_1e-7": int(out_d.sum()), "of_those_within_50x_oracle_scatter": int((out_d & (dd <= tol_d)).sum()),
         "max_rel_dz_diff_on_agreeing_converged": dz_err,
+        "rel_dz_diff_on_agreeing_converged": qs((dz_abs / dz_scale)[conv]), "oracle_own_rel_dz_scatter_under_1ulp": qs((sc_dz / dz_scale)[conv]),
+        "solves_with_rel_dz_diff_above_1e-6": int(out_dz.sum()), "of_those_within_50x_oracle_dz_scatter": int((out_dz & (dz_abs <= tol_dz)).sum()),
+        "worst_dz_solves": [{"b": int(b_), "i": int(i_), "rel_dz": float((dz_abs / dz_scale)[b_, i_]), "oracle_scatter_rel": float((sc_dz / dz_scale)[b_, i_]),
+                             "iters": int(it[b_, i_]), "d_diff": float(dd[b_, i_])}
+                            for b_, i_ in zip(*np.unravel_index(np.argsort(np.where(conv, dz_abs / dz_scale, 0.0), axis=None)[-5:], dz_abs.shape))],
         "max_abs_d_diff_on_flipped": float(dd[flip & (st == 1) & (out["status"] == 1)].max()) if flip.any() else 0.0,
         "oracle_seconds": t_oracle, "ulp_arbiter": dict(table, draws=K, sensitive_share_of_flipped=rate_in, sensitive_share_overall=base_rate)})
     assert same.mean() >= 0.999, same.mean()
@@ -131,6 +140,10 @@ def test_implicit_dynamics_full_size_vs_oracle(gpu_required, case):
     # by 1e-7 .. 2e-5 in d under last-place input noise - recorded above as oracle_own_d_scatter_under_1ulp)
     assert (dd[conv] < 1e-7).mean() >= 0.95 and np.median(dd[conv]) < 1e-11 and (zz[conv] < 1e-6).mean() >= 0.9
     assert (dd[conv] <= tol_d[conv]).all(), int((dd[conv] > tol_d[conv]).sum())                # the rest: explained by the oracle's own scatter
+    # sensitivities (they are the Jacobian data of the KKT stage): 1e-6 relative wherever the oracle itself is stable under
+    # last-place input noise, inside 50 x its own scatter elsewhere - the same rule as d and z
+    assert ((dz_abs / dz_scale)[conv] < 1e-6).mean() >= 0.9 and np.median((dz_abs / dz_scale)[conv]) < 1e-10
+    assert (dz_abs[conv] <= tol_dz[conv]).all(), (int((dz_abs[conv] > tol_dz[conv]).sum()), RECORD["implicit_dynamics"]["worst_dz_solves"])
     assert (zz[conv] <= tol_z[conv]).mean() > 0.999
     # every flip is a one-iteration (or status-at-the-boundary) move of a solve that ALSO converged to the same point
     both = flip & (st == 1) & (out["status"] == 1)

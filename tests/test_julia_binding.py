@@ -112,3 +112,41 @@ def test_option_structs_mirror_the_header_field_by_field():
         cf, jf = _c_struct_fields(cname), _jl_struct_fields(jname)
         assert [n for _, n in cf] == [n for _, n in jf], (cname, cf, jf)
         assert [t for t, _ in cf] == [ctype[t] for t, _ in jf], (cname, cf, jf)
+
+
+def test_b1_seam_is_a_real_drop_in():
+    """VERDICT r02 (missing 3): the B1 solvers must be what newton.jl:86 / :218 can actually reach -
+    subtypes of the package's LinearSolver, methods of the package's own linear_solve!, constructors visible to
+    `eval(opts.solver)` in the package module, and the dual regularisation of EVERY call (core.beta changes per iteration,
+    newton.jl:280) taken from the matrix the solver is handed - not from a mirror that nobody updates."""
+    body = JL.split("\nend # module")[0]
+    assert re.search(r"import \.\.ContactImplicitMPC:[^\n]*\blinear_solve!", body) and re.search(r"import \.\.ContactImplicitMPC:[^\n]*\bLinearSolver\b", body)
+    for name in ("HipKKTSolver", "HipCSCSolver"):
+        assert re.search(r"struct " + name + r" <: LinearSolver", body), name
+        assert re.search(r"function linear_solve!\(s::" + name + r", x::Vector\{Float64\}, A::SparseMatrixCSC\{Float64,Int\}, b::Vector\{Float64\};", body), name
+    tail = JL.split("\nend # module")[1]
+    assert re.search(r"using \.CIMPCHip: hip_kkt_solver, hip_csc_solver", tail)       # in the including module's scope
+    assert "Main." not in JL                                                            # no dependence on where the package is loaded
+    assert not re.search(r"\bhs\.β", body) and not re.search(r"^\s*β::", body, flags=re.M)     # no stale mirror of core.β
+    kkt = body[body.index("function linear_solve!(s::HipKKTSolver"):]
+    kkt = kkt[:kkt.index("\nend") + 4]
+    assert re.search(r"ρ\s*=\s*-A\[N, N\]", kkt) and "cimpc_kkt_solve_rho" in kkt and "s.hs.β" not in kkt
+    assert "cimpc_kkt_solve_rho" in c_declarations()
+
+
+def test_plant_step_is_sized_from_the_model_table():
+    """plant_step must size its buffers from the model and refuse unknown models - the table equals the Python
+    host's (plant.py: MODELS) and the ids of include/cimpc.h."""
+    from contactimplicitmpc.jl_amd import plant
+    m = re.search(r"const PLANT_MODELS = Dict\{Symbol,NTuple\{6,Int\}\}\((.*?)\)\n", JL, flags=re.S).group(1)
+    table = {k: tuple(int(x) for x in v.split(",")) for k, v in re.findall(r":(\w+) => \(([^)]*)\)", m)}
+    assert table == {k: tuple(v) for k, v in plant.MODELS.items()}
+    ids = {name.lower(): int(v) for name, v in re.findall(r"#define CIMPC_PLANT_(\w+) (\d+)", HDR)}
+    alias = {"quadruped": "quadruped", "flamingo": "flamingo", "hopper_2D": "hopper_2d", "centroidal_quadruped": "centroidal",
+             "centroidal_quadruped_undamped": "centroidal_undamped", "particle": "particle"}
+    for k, v in table.items():
+        assert ids[alias[k]] == v[0], k
+    fn = JL[JL.index("function plant_step("):]
+    fn = fn[:fn.index("\nend\n") + 5]
+    assert not re.search(r"zeros\(\s*\d", fn), "literal array size in plant_step"
+    assert "haskey(PLANT_MODELS, model) || error" in fn and "model == :quadruped ? 0 : 1" not in fn

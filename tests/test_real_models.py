@@ -258,3 +258,32 @@ def test_implicit_dynamics_on_the_flamingo_gait():
     assert out["status"].all()
     assert np.abs(out["d"]).max() < 2e-2
     assert out["iters"].max() <= 12
+
+
+def test_reference_schur_ill_conditioning_test_on_the_oracle():
+    """test/solver/schur.jl:19-62 restated: flamingo `gait_forward_36_4`, knot 10, z0 = max(1e-6, z), kappa0 = 0,
+    M = [A B; C D] with D = rz0[irst, iy1] - rz0[irst, iy2] Diagonal(z0[iy2] ./ z0[iy1]), u = r0[idyn],
+    v = r0[irst] - r0[ibil] ./ z0[iy1]; `schur_factorize!` + `schur_solve!`: |M [x; y] - [u; v]|_inf < 1e-7 - the one reference-held
+    known answer for the ill-conditioned regime the interior point ends in (cond M ~ 1e11).  The device runs the same statement
+    through the B2 seam (tests/test_gpu_round3_parity.py)."""
+    d, P, prob, tabs = real_problem("flamingo", 0.0)
+    m = P.model
+    z0 = np.maximum(1e-6, P.z[9]); th0 = P.theta[9].copy()
+    r0, rz0, rth0 = m.linearize(z0, th0, 0.0)
+    nx, ny = d.nx, d.ny
+    iy1 = np.arange(nx, nx + ny); iy2 = np.arange(nx + ny, nx + 2 * ny)
+    A = rz0[:nx, :nx]; B = rz0[:nx, iy1]; C = rz0[iy1, :nx]
+    D = rz0[np.ix_(iy1, iy1)] - rz0[np.ix_(iy1, iy2)] @ np.diag(z0[iy2] / z0[iy1])
+    M = np.block([[A, B], [C, D]])
+    u = r0[:nx]; v = r0[iy1] - r0[iy2] / z0[iy1]
+    assert np.linalg.cond(M) > 1e8
+    S = lcp.Schur.from_matrix(M, nx)           # Schur(M, n = nx, m = ny)
+    S.factorize(D)                             # schur_factorize!(S, D)
+    x, y = S.solve(u, v)                       # schur_solve!(S, u, v)
+    assert np.abs(M @ np.concatenate([x, y]) - np.concatenate([u, v])).max() < 1e-7
+    # the same through the callbacks the interior point uses (rzlin! + linear_solve!, linearized_solver.jl:378-444)
+    tab = lcp.LinTable(d, z0, th0, r0, rz0, rth0)
+    lcp.rzlin(tab, z0, 0.0)
+    delta = lcp.linear_solve_vec(tab, r0[:nx], r0[iy1], r0[iy2], 0.0)
+    np.testing.assert_allclose(delta[:nx], x, rtol=0, atol=1e-9 * np.abs(x).max())
+    np.testing.assert_allclose(delta[iy1], y, rtol=0, atol=1e-9 * np.abs(y).max())
