@@ -472,6 +472,41 @@ def main():
     prof = s.profile_read()
     s.profile_enable(False)
 
+    multi = None
+    if dist is not None:
+        # (1) self-check of the collective path: the rows of this rank's shard in the all-gathered result must be the rank's own
+        #     local result, bit for bit (the gather only moves data); the verdict of all ranks is combined with a MIN all-reduce
+        u1_loc, it_loc, rn_loc = s.newton_info()
+        mine = gathered["u1"][first:first + B]
+        ok_local = bool(np.array_equal(mine, u1_loc) and np.array_equal(gathered["newton_iters"][first:first + B], it_loc.astype(np.int64))
+                        and np.array_equal(gathered["r_norm"][first:first + B], rn_loc))
+        okt = torch.tensor([1.0 if ok_local else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        # (2) the OTHER scaling mode in the same run (the headline line keeps --scaling; the driver computes efficiencies itself):
+        #     weak = --rollouts per GPU, strong = --rollouts in total split over the ranks (BASELINE configs[3]: 512 over 8)
+        other = "strong" if args.scaling == "weak" else "weak"
+        n2 = args.rollouts if other == "strong" else world * args.rollouts
+        first2, B2 = rollout_shard(n2, rank, world)
+        res2 = {"scaling": other, "rollouts_total": n2, "rollouts_per_gpu": B2}
+        if B2 >= 1:
+            ro2 = build_rollouts(d, prob, B2, H, H_ref, 1234, args.perturb, first=first2)
+            s2, a2, b2 = make(B2, ro2)
+            torch.cuda.synchronize()
+            s2.newton_solve_dev(a2.data_ptr(), b2.data_ptr(), warm_start=False)
+            k2 = max(1, min(args.steps, 5))
+            torch.cuda.synchronize(); dist.barrier()
+            t2 = time.perf_counter()
+            for _ in range(k2):
+                s2.newton_solve_dev(a2.data_ptr(), b2.data_ptr(), warm_start=False)
+            u1b, itb, rnb = s2.newton_info()
+            mc.gather_results(u1b, itb, rnb, s2.rollout_counters()["sweeps"], n2, dev)
+            torch.cuda.synchronize(); dist.barrier()
+            tt = torch.tensor([time.perf_counter() - t2], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            res2.update({"value": n2 * k2 / float(tt.item()), "unit": "MPC steps/s", "steps": k2, "ms_per_step": 1e3 * float(tt.item()) / k2})
+            s2.close()
+        multi = {"gather_selfcheck_all_ranks": bool(okt.item() == 1.0), "other_scaling": res2}
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -539,6 +574,8 @@ def main():
                      "ip_problems_in_async_tail": prof["async_problems"] / args.steps},
         "setup_s": t_setup,
     }
+    if multi is not None:
+        out["multi_gpu"] = multi
     if not args.no_latency and world == 1:
         # BASELINE configs[2]: the same quadruped problem for ONE robot, cold start
         s1, a0, a1 = make(1, rollouts[:1])

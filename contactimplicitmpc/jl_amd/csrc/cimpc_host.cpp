@@ -61,7 +61,6 @@ struct Knobs {
     int async_spins = 48;        // CIMPC_ASYNC_SPINS
     int async_fan = 1;           // CIMPC_ASYNC_FAN
     double watchdog_s = 30.0;    // CIMPC_ASYNC_WATCHDOG_S
-    int depth = 1;               // CIMPC_DEPTH
     bool debug_rounds = false;   // CIMPC_DEBUG_ROUNDS
     bool kkt_packed = true;      // CIMPC_KKT_PACKED
     int tail_div = 8;            // CIMPC_TAIL_DIV
@@ -72,8 +71,6 @@ struct Knobs {
                                  // Measured 128 -> 64: B = 96 8.88 -> 8.11 ms, B = 128 9.72 -> 9.48 ms, B = 64 unchanged (6.9 ms)
     int async_tail_grid = -1;    // CIMPC_ASYNC_TAIL_GRID: workgroups of the hybrid tail's persistent kernel (0 = the full resident set, -1 = 3 per
                                  // rollout handed over; B = 512: 512 / 320 / 256 / 192 / 96 workgroups -> 10.85 / 10.42 / 10.35 / 10.38 / 10.6 ms)
-    int kkt_chain = -1;          // CIMPC_KKT_CHAIN: chained rounds ({sweep || KKT} -> sweep of the new candidates -> residual) when at least this
-                                 // percentage of the round's rollouts start a Newton iteration; -1 = never
     int kkt_pipe = -1;           // CIMPC_KKT_PIPE: two-wave pipelined KKT kernel 0 never, 1 always, -1 where the solve is on the critical path
     int kkt_pipe_max = 128;      // CIMPC_KKT_PIPE_MAX: ... and at most this many rollouts start an iteration (it takes twice the CUs)
 
@@ -98,11 +95,9 @@ struct Knobs {
         async_fan = env_int("CIMPC_ASYNC_FAN", async_fan);
         if (async_fan != 1 && async_fan != 2 && async_fan != 4 && async_fan != 8 && async_fan != 16) async_fan = 1;
         if (const char* v = getenv("CIMPC_ASYNC_WATCHDOG_S")) watchdog_s = atof(v);
-        depth = std::min(2, std::max(1, env_int("CIMPC_DEPTH", depth)));
         debug_rounds = getenv("CIMPC_DEBUG_ROUNDS") != nullptr;
         kkt_packed = env_int("CIMPC_KKT_PACKED", 1) != 0;
         tail_div = env_int("CIMPC_TAIL_DIV", tail_div);
-        kkt_chain = env_int("CIMPC_KKT_CHAIN", kkt_chain);
         async_tail_grid = env_int("CIMPC_ASYNC_TAIL_GRID", async_tail_grid);
         async_full_max = env_int("CIMPC_ASYNC_FULL_MAX", async_full_max);
         kkt_scalar = env_int("CIMPC_KKT_SCALAR", 0) != 0;
@@ -373,6 +368,16 @@ static int launch_kkt_general(cimpc_ctx* h, const NewtonDev& Sk, hipStream_t st)
     return launch_kkt_dense_newton(Sk, h->d_dense_ws, st, h->use_banded);
 }
 
+// statistics of the running / last solve: the per-rollout records of the decision stage, summed (NewtonDev::stats)
+int read_stats(cimpc_ctx* h, long long out[4]) {
+    std::vector<long long> v((size_t)h->dm.B * 4);
+    HIP_TRY(h, hipMemcpy(v.data(), h->S.stats, v.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    out[0] = out[1] = out[2] = out[3] = 0;
+    for (size_t b = 0; b < (size_t)h->dm.B; ++b)
+        for (int k = 0; k < 4; ++k) out[k] += v[b * 4 + k];
+    return CIMPC_OK;
+}
+
 int check_ready(cimpc_ctx* h, bool need_newton) {
     if (!h) return CIMPC_ERR_INVALID;
     if (h->n_knots_set != h->dm.H_ref)
@@ -546,13 +551,14 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     AX(&S.r_norm, B); AX(&S.r_cand, BS); AX(&S.alpha, B); AX(&S.beta, B);
     AX(&S.ls_iter, B); AX(&S.newton_l, B); AX(&S.stage, B); AX(&S.need_sweep, BS);
     A(&S.kkt_list, 2 * B);
-    AX(&S.counters, 8);
-    AX(&S.stats, 4);
+    A(&S.slot_list, 2 * BS);
+    AX(&S.counters, 8 * CPAD);
+    AX(&S.stats, B * 4);
     AX(&S.ro_sweeps, B); AX(&S.ro_ip_iters, B); AX(&S.ro_ip_fail, B);
     AX(&S.nlog, B * NLOG * 4);
     A(&S.kkt_ws, B * H * (3 * (size_t)h->nd * h->nd + h->nd));
     (void)ppw;
-    if (rc == CIMPC_OK && hipHostMalloc((void**)&h->h_counters, 8 * sizeof(int)) != hipSuccess)
+    if (rc == CIMPC_OK && hipHostMalloc((void**)&h->h_counters, 8 * CPAD * sizeof(int)) != hipSuccess)
         rc = fail(h, CIMPC_ERR_HIP, "hipHostMalloc failed");
     if (rc != CIMPC_OK) {
         g_create_error = h->err;
@@ -582,7 +588,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     if (h->kn.waves == 1 || h->kn.waves == 2 || (h->kn.waves >= 4 && h->kn.waves <= 8)) h->waves = h->kn.waves;   // (5..8: builds with CIMPC_SWEEP_THREADS > 256)
     h->kkt_overlap = B >= 64;
     if (h->kn.kkt_overlap >= 0) h->kkt_overlap = h->kn.kkt_overlap != 0;
-    if (dev_alloc(h, &h->d_ring, 32) != CIMPC_OK ||
+    if (dev_alloc(h, &h->d_ring, 2 * 8 * CPAD) != CIMPC_OK ||
         hipHostMalloc((void**)&h->h_ring, 32 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&h->h_ring_dev, h->h_ring, 0) != hipSuccess) {
         g_create_error = "ring allocation failed"; cimpc_destroy(h); return CIMPC_ERR_HIP;
@@ -907,14 +913,14 @@ int cimpc_implicit_dynamics(cimpc_handle h, const double* q, const double* theta
     }
     for (int pass = 0; pass < 64; ++pass) {
         const int par = pass & 1;
-        HIP_TRY(h, hipMemsetAsync(h->S.counters, 0, 8 * sizeof(int), h->stream));
-        rc = run_sweep(h, par, h->S.counters + 2, z ? h->d_zout : nullptr, h->stream);
+        HIP_TRY(h, hipMemsetAsync(h->S.counters, 0, 8 * CPAD * sizeof(int), h->stream));
+        rc = run_sweep(h, par, h->S.counters + 2 * CPAD, z ? h->d_zout : nullptr, h->stream);
         if (rc != CIMPC_OK) return rc;
         HIP_TRY(h, hipMemsetAsync(h->Q.count + (size_t)par * h->Q.K * QPAD, 0, h->Q.K * QPAD * sizeof(int), h->stream));
         HIP_TRY(h, hipMemsetAsync(h->Q.head, 0, h->Q.K * QPAD * sizeof(int), h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->h_counters, h->S.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->h_counters, h->S.counters + 2 * CPAD, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        if (h->h_counters[2] == 0) break;
+        if (h->h_counters[0] == 0) break;      // no solve was parked
     }
     auto down = [&](void* dst, const void* src, size_t row_bytes) {
         return hipMemcpy2DAsync(dst, row_bytes, src, CS * row_bytes, row_bytes, B, hipMemcpyDeviceToHost, h->stream);
@@ -1023,7 +1029,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return el >= h->nt.max_time;
     };
-    HIP_TRY(h, hipMemsetAsync(S.stats, 0, 4 * sizeof(long long), h->stream));
+    HIP_TRY(h, hipMemsetAsync(S.stats, 0, (size_t)h->dm.B * 4 * sizeof(long long), h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     // ---- one persistent launch: every rollout advances on its own chain (newton_async_impl.h).  Entered
     //      from the start (from_reset) or with the rollouts the lock-step rounds left active (hybrid). ----
@@ -1040,7 +1046,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         volatile int* hm = (volatile int*)h->h_ring;
         hm[3] = 0;
         NewtonDev Sk = S;
-        Sk.b0 = 0; Sk.nb_launch = h->dm.B; Sk.counters = h->d_ring; Sk.counters_next = h->d_ring + 8;
+        Sk.b0 = 0; Sk.nb_launch = h->dm.B; Sk.counters = h->d_ring; Sk.counters_next = h->d_ring + 8 * CPAD;
         Sk.host_flag = h->h_ring_dev;
         // the tail is latency-bound: its stragglers (rollouts that exhaust the line search in every iteration)
         // evaluate all seven step lengths at once there, whatever the throughput-oriented setting of the rounds
@@ -1076,12 +1082,12 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         int rc2 = from_reset ? launch_reset(Sk, q0_dev, q1_dev, warm_start, st) : launch_async_handoff(Sk, LQ, st);
         prof_end(h, st);
         if (rc2 != CIMPC_OK) return fail(h, rc2, "reset / hand-off launch failed");
-        IpParams p = make_ip_params(h, S.cand, 0, h->d_ring + 2, nullptr);
+        IpParams p = make_ip_params(h, S.cand, 0, h->d_ring + 2 * CPAD, nullptr);
         p.Q = Sk.WQ;
         p.iter_cap = h->ip.max_iter + 1;      // no solve is parked (solves parked by the lock-step rounds resume and finish)
         p.A = A;
         long long solved_before = 0;      // interior-point problems the lock-step rounds had solved (profiling only)
-        if (h->prof_on && !from_reset) HIP_TRY(h, hipMemcpy(&solved_before, S.stats + 1, sizeof(long long), hipMemcpyDeviceToHost));
+        if (h->prof_on && !from_reset) { long long sv[4]; if (int rs = read_stats(h, sv); rs != CIMPC_OK) return rs; solved_before = sv[1]; }
         prof_begin(h, PC_ASYNC, st);
         rc2 = launch_newton_async(&h->dm, p, Sk, std::min(h->waves, 4), a_grid, st);
         prof_end(h, st);
@@ -1110,7 +1116,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
                     dv[0] * 1e-5, dv[1] * 1e-5, dv[2] * 1e-5, dv[3] * 1e-5, dv[9], dv[10], dv[11], h->a_grid, h->a_service, dv[5] * 1e-6, dv[5] ? 100.0 * dv[4] / dv[5] : 0.0, dv[6] * 1e-5, dv[7] * 1e-5, dv[12], dv[13], dv[14] * 1e-5, dv[15] * 1e-5);
         }
         long long stv[4];
-        HIP_TRY(h, hipMemcpy(stv, S.stats, sizeof(stv), hipMemcpyDeviceToHost));
+        if (int rs = read_stats(h, stv); rs != CIMPC_OK) return rs;
         std::vector<int> l(h->dm.B);
         HIP_TRY(h, hipMemcpy(l.data(), S.newton_l, l.size() * sizeof(int), hipMemcpyDeviceToHost));
         h->last_stats.sweeps = stv[0];
@@ -1138,43 +1144,32 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     // the rounds run on the library's private streams, or on the caller's stream when one was given
     RoundStreams sb = h->rs;
     if (h->external_stream) sb.st = h->stream;
-    // Lock-step rounds.  Every kernel of a round is driven by device-side state (work queues, per-rollout
-    // stage); the host only looks at the counters the last residual block publishes.  (Enqueueing rounds
-    // ahead of the host's knowledge was measured: slower, the KKT kernel then has to be launched every round.)
-    // CIMPC_DEPTH = 2: rounds enqueued one ahead of the host's knowledge.  Measured (B = 512): 15.9 vs 13.7 ms -
-    // the KKT kernel must then be launched blind at full grid every round; kept as an experiment switch.
-    const int depth = h->kkt_overlap ? h->kn.depth : 1;
-    bool draining = false;
+    // Lock-step rounds.  Every kernel of a round is driven by device-side state (work queues, per-rollout stage); the host only
+    // looks at the counters the last decision block publishes, one round at a time.  (Measured and removed again: rounds enqueued
+    // one ahead of the host's knowledge - the KKT kernel must then be launched blind at full grid, 15.9 vs 13.7 ms at B = 512 - and
+    // chained rounds {sweep || KKT} -> sweep of the new candidates -> residual: every extra sweep launch pays the slowest-solve
+    // tail again, 10.7 -> 11.0-11.3 ms.)
     long long launched = 0, completed = 0, rounds = 0;
     const bool dbg_rounds = h->kn.debug_rounds;
-    int last_kkt = 0, last_sweep = h->dm.B;
-    // Queue parity is tracked explicitly: a plain round consumes Q[par] and leaves the next round's requests in Q[par ^ 1]; a
-    // CHAINED round - {sweep of Q[par] || KKT} -> sweep of Q[par ^ 1] (the candidates the KKT stage just requested, and what
-    // the first sweep parked) -> residual - ends with the next round's requests in Q[par] again.  Chaining takes a rollout
-    // through a whole Newton iteration (KKT, evaluation of the first step lengths, decision) in ONE round; it pays where the
-    // rounds are latency bound (the KKT recursion and the slowest interior-point solve, not the amount of work, set their length).
-    int cur_par = 0, list_par = 0;
+    int last_kkt = 0, last_sweep = h->dm.B, last_slots = h->dm.B;
     auto launch_round = [&](long long r) -> int {
-        // [KKT for rollouts that start an iteration] || sweep -> residual + line-search decision
-        const int slot = (int)(r & 1);
-        int* d_cnt = h->d_ring + 8 * slot;
+        // [KKT for rollouts that start an iteration] || sweep -> residual of every evaluated slot -> line-search decision
+        const int slot = (int)(r & 1), par = (int)(r & 1);      // round r consumes Q[par] and leaves the next round's requests in Q[par ^ 1]
+        int* d_cnt = h->d_ring + 8 * CPAD * slot;
         NewtonDev Sk = S;
         Sk.b0 = 0; Sk.nb_launch = h->dm.B; Sk.counters = d_cnt;
-        Sk.counters_next = h->d_ring + 8 * (slot ^ 1);
+        Sk.counters_next = h->d_ring + 8 * CPAD * (slot ^ 1);
         Sk.host_flag = h->h_ring_dev + 8 * slot;
         Sk.A.n_done = hybrid ? h->a_ctrl + 2 * (size_t)h->Q.K * QPAD + 8 : nullptr;
         Sk.round_stamp = (int)(r + 1);
-        const int par = depth > 1 ? (int)(r & 1) : cur_par;
         Sk.WQ = h->Q; Sk.WQ.par = par;       // the queue being consumed
-        const bool kkt = (r > 0) && (depth > 1 || last_kkt > 0);
-        const bool chain = kkt && h->kkt_overlap && depth == 1 && h->kn.kkt_chain >= 0 &&
-                           (long long)last_kkt * 100 >= (long long)h->kn.kkt_chain * (last_kkt + last_sweep);
-        const int pipe = h->kn.kkt_pipe >= 0 ? h->kn.kkt_pipe : ((chain || !h->kkt_overlap) && last_kkt <= h->kn.kkt_pipe_max) ? 1 : 0;
+        const bool kkt = (r > 0) && last_kkt > 0;
+        const int pipe = h->kn.kkt_pipe >= 0 ? h->kn.kkt_pipe : (!h->kkt_overlap && last_kkt <= h->kn.kkt_pipe_max) ? 1 : 0;
         if (kkt && !h->kkt_overlap) {   // small batches: latency matters, keep the KKT result in this round
             Sk.kkt_same_round = 1;
             prof_begin(h, PC_KKT, sb.st);
             // (same compact list / packed or pipelined kernel as the overlapped path)
-            int rr = (h->use_dense || h->use_mixed) ? launch_kkt_general(h, Sk, sb.st) : launch_kkt_packed(Sk, last_kkt, depth > 1 ? par ^ 1 : list_par, sb.st, nullptr, pipe);
+            int rr = (h->use_dense || h->use_mixed) ? launch_kkt_general(h, Sk, sb.st) : launch_kkt_packed(Sk, last_kkt, par ^ 1, sb.st, nullptr, pipe);
             prof_end(h, sb.st);
             if (rr != CIMPC_OK) return fail(h, rr, "kkt launch failed");
         }
@@ -1183,14 +1178,11 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             // event: the host has seen the previous round's stamp, so everything before is complete.  (Launched
             // BEFORE the sweep: the other order was measured 10 % slower - the KKT recursion is the longer leg
             // of most rounds.)
-            if (depth > 1 && hipStreamWaitEvent(sb.st_kkt, sb.ev_round, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "fork failed");
-            if (chain) Sk.kkt_same_round = 2;      // its candidates are evaluated in this round: not a request for the next one
             prof_begin(h, PC_KKT, sb.st_kkt);
-            const bool packed = h->kn.kkt_packed;
-            // the list was built by the residual kernel of the previous round (its queue parity)
+            // the list was built by the decision kernel of the previous round (its queue parity)
             int rk = (h->use_dense || h->use_mixed) ? launch_kkt_general(h, Sk, sb.st_kkt)
-                                  : packed ? launch_kkt_packed(Sk, last_kkt, depth > 1 ? par ^ 1 : list_par, sb.st_kkt, depth > 1 ? Sk.counters_next + 1 : nullptr, pipe)
-                                           : launch_kkt(Sk, sb.st_kkt);
+                                  : h->kn.kkt_packed ? launch_kkt_packed(Sk, last_kkt, par ^ 1, sb.st_kkt, nullptr, pipe)
+                                                     : launch_kkt(Sk, sb.st_kkt);
             prof_end(h, sb.st_kkt);
             if (rk != CIMPC_OK) return fail(h, rk, "kkt launch failed");
             if (hipEventRecord(sb.ev_join, sb.st_kkt) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join record failed");
@@ -1199,32 +1191,20 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         // it only adds rounds, so a round that serves few rollouts lets every solve run to the end
         const int tail_div = h->kn.tail_div;
         const int cap = (tail_div > 0 && last_sweep * tail_div <= h->dm.B) ? h->ip.max_iter : h->iter_cap;
-        int rr = CIMPC_OK;
-        if (!chain || last_sweep > 0) rr = run_sweep(h, par, d_cnt + 2, nullptr, sb.st, cap, chain ? nullptr : d_cnt + 3);
+        int rr = run_sweep(h, par, d_cnt + 2 * CPAD, nullptr, sb.st, cap, d_cnt + 3 * CPAD);
         if (rr != CIMPC_OK) return rr;
         if (kkt && h->kkt_overlap && hipStreamWaitEvent(sb.st, sb.ev_join, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join failed");
-        if (chain) {
-            // Q[par] is consumed: recycle it (the second sweep parks into it), then evaluate what the KKT stage requested
-            rr = launch_queue_recycle(h->Q, par, sb.st);
-            if (rr != CIMPC_OK) return fail(h, rr, "queue recycle failed");
-            const int cap2 = (tail_div > 0 && (last_kkt + last_sweep) * tail_div <= h->dm.B) ? h->ip.max_iter : h->iter_cap;
-            rr = run_sweep(h, par ^ 1, d_cnt + 2, nullptr, sb.st, cap2);
-            if (rr != CIMPC_OK) return rr;
-            Sk.WQ.par = par ^ 1;         // the residual stage recycles that queue; its requests go to Q[par]
-            Sk.kkt_same_round = 0;
-        }
         prof_begin(h, PC_RESID, sb.st);
-        rr = launch_resid_decide(Sk, sb.st);
+        // the evaluation slots of this round: the compact list its requesters built (small batches run the KKT stage in the same
+        // round as the evaluation of its candidates - not known to the host at launch: every (rollout, slot) pair gets a block there)
+        rr = launch_resid_decide(Sk, sb.st, h->kkt_overlap ? last_slots : -1);
         prof_end(h, sb.st);
         if (rr != CIMPC_OK) return fail(h, rr, "residual launch failed");
-        if (depth > 1 && hipEventRecord(sb.ev_round, sb.st) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "round event failed");
-        list_par = Sk.WQ.par;
-        cur_par = Sk.WQ.par ^ 1;
         return CIMPC_OK;
     };
     HIP_TRY(h, hipMemsetAsync(h->Q.count, 0, 2 * h->Q.K * QPAD * sizeof(int), sb.st));
     HIP_TRY(h, hipMemsetAsync(h->Q.head, 0, h->Q.K * QPAD * sizeof(int), sb.st));
-    HIP_TRY(h, hipMemsetAsync(h->d_ring, 0, 16 * sizeof(int), sb.st));
+    HIP_TRY(h, hipMemsetAsync(h->d_ring, 0, 2 * 8 * CPAD * sizeof(int), sb.st));
     if (hybrid) HIP_TRY(h, hipMemsetAsync(h->a_ctrl + 2 * (size_t)h->Q.K * QPAD, 0, 64 * sizeof(int), sb.st));
     ((volatile int*)h->h_ring)[2] = 0;
     ((volatile int*)h->h_ring)[10] = 0;
@@ -1238,16 +1218,14 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         if (rc != CIMPC_OK) return fail(h, rc, "reset launch failed");
     }
     while (true) {
-        while (!draining && launched - completed < depth && launched < max_rounds) {
-            rc = launch_round(launched);
-            if (rc != CIMPC_OK) return rc;
-            ++launched;
-        }
-        if (completed >= launched) {          // max_rounds reached with work left: a scheduling bug, never a silent partial solve
+        if (launched >= max_rounds) {          // round limit reached with work left: a scheduling bug, never a silent partial solve
             (void)hipStreamSynchronize(sb.st); (void)hipStreamSynchronize(sb.st_kkt);
             return fail(h, CIMPC_ERR_STATE, "newton_solve: round limit reached with unfinished rollouts");
         }
-        {   // the residual kernel's last block stamps the mapped flag when round `completed` is done
+        rc = launch_round(launched);
+        if (rc != CIMPC_OK) return rc;
+        ++launched;
+        {   // the decision kernel's last block stamps the mapped flag when round `completed` is done
             volatile int* hm = (volatile int*)h->h_ring + 8 * (completed & 1);
             const int want = (int)(completed + 1);
             long long spins = 0;
@@ -1260,28 +1238,28 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         const int n_sweep = hr[0];
         last_sweep = n_sweep;
         last_kkt = hr[1];
-        if (dbg_rounds) fprintf(stderr, "[cimpc round %lld] t %.3f ms: next sweep %d rollouts, next kkt %d, parked %d, finished %d\n", completed,
-                                1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), n_sweep, last_kkt, hr[4], hr[5]);
+        last_slots = hr[6];
+        if (dbg_rounds) fprintf(stderr, "[cimpc round %lld] t %.3f ms: next sweep %d rollouts (%d evaluation slots), next kkt %d, parked %d, finished %d\n", completed,
+                                1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), n_sweep, last_slots, last_kkt, hr[4], hr[5]);
         h->prof_kkt_systems += last_kkt;
         ++completed;
         rounds = completed;
         if ((n_sweep == 0 && last_kkt == 0) || over_budget()) break;   // newton.jl:187-277: budget ends silently
         if (hybrid) {
             // sparse tail: few rollouts left, every round pays its fixed latency for them -> the persistent
-            // kernel finishes them along their own chains; rounds already enqueued are drained first
+            // kernel finishes them along their own chains
             const int active = h->dm.B - hr[5];
-            if (active > 0 && active <= h->async_tail) draining = true;
-            if (draining && launched == completed) {
+            if (active > 0 && active <= h->async_tail) {
                 HIP_TRY(h, hipStreamSynchronize(sb.st));
                 HIP_TRY(h, hipStreamSynchronize(sb.st_kkt));
-                return run_async(false, rounds, depth > 1 ? -1 : cur_par);
+                return run_async(false, rounds, (int)(rounds & 1));
             }
         }
     }
     HIP_TRY(h, hipStreamSynchronize(sb.st));
     HIP_TRY(h, hipStreamSynchronize(sb.st_kkt));
     long long st[4];
-    HIP_TRY(h, hipMemcpy(st, S.stats, sizeof(st), hipMemcpyDeviceToHost));
+    if (int rs = read_stats(h, st); rs != CIMPC_OK) return rs;
     std::vector<int> l(h->dm.B);
     HIP_TRY(h, hipMemcpy(l.data(), S.newton_l, l.size() * sizeof(int), hipMemcpyDeviceToHost));
     h->last_stats.sweeps = st[0];

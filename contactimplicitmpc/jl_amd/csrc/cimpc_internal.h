@@ -15,6 +15,8 @@ namespace cimpc {
 // consumes items[par], solves parked after iter_cap iterations and the evaluations requested by
 // the line search are appended to items[par ^ 1].
 constexpr int QPAD = 32;   // ints between two queue counters
+constexpr int CPAD = 32;   // ints between two ROUND counters (NewtonDev::counters[k * CPAD]): every counter on its own 128-byte line -
+                           // same-line atomics serialise in the L2 at ~50 ns each, and the decision kernel issues several per workgroup
 
 struct IpQueues {
     int* items;         // [2][K][cap]  problem id = sb*H + i

@@ -19,6 +19,7 @@
 // producer has already reserved the slot (aq_pop) - and any workgroup can execute any job, so the
 // solve progresses with however many workgroups the hardware keeps resident.
 #pragma once
+#include <algorithm>
 #include <cstddef>
 #include "ip_kernel_impl.h"
 #include "newton_impl.h"
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256, (M::G == 16 ? 2 : 1)) void newton_async_kernel
         if (type == 2) {
             xfence(A.flags);                             // acquire d / dz / status of the evaluations
             account(0);
-            async_resid_job<NQ, NU>(ka, job, smem, rc, sh);      // reduction scratch [CS][256] in the (idle) table area
+            async_resid_job<NQ, NU>(ka, job, smem, rc, sh);      // reduction scratch [CS][256] + [N] in the (idle) table area
             __syncthreads();
             account(2);
             continue;
@@ -181,7 +182,8 @@ int launch_async_model(const IpParams& p, const NewtonDev& S, int waves, int gri
     const int ppw = 64 / M::G;
     const size_t lds_ip = (size_t)(L.size + waves * ppw * M::LDS_GROUP) * sizeof(double);
     const size_t lds_kkt = (size_t)(waves >= 2 ? kkt_lds_doubles<M::NQ, M::NU, 2>() : kkt_lds_doubles<M::NQ, M::NU, 1>()) * sizeof(double);
-    const size_t lds = lds_ip > lds_kkt ? lds_ip : lds_kkt;
+    const size_t lds_res = (size_t)(CS * 256 + S.N) * sizeof(double);       // residual job: partial sums of every slot + |r_e| scratch
+    const size_t lds = std::max(std::max(lds_ip, lds_kkt), lds_res);
     static LdsOptIn optin;
     if (lds_opt_in(optin, (const void*)newton_async_kernel<M>, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
     // every workgroup of this kernel must be resident (they wait for each other's jobs): clamp the grid to what the

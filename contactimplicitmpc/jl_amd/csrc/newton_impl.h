@@ -58,9 +58,17 @@ __device__ __forceinline__ void copy_n(double* dst, const double* src, int n, in
 // stays available (needed by the stale-sensitivity rule, dz_eff below).
 __device__ __forceinline__ double ls_alpha(int iter) { return ldexp(1.0, -iter); }
 
+// slot sb will have been evaluated when the round that consumes queue `par` reaches its residual launch
+__device__ __forceinline__ void list_slot(const NewtonDev& S, size_t sb, int par, int pos = -1) {
+    if (S.slot_list == nullptr) return;
+    if (pos < 0) pos = atomicAdd(&S.counters[4 * CPAD], 1);
+    S.slot_list[(size_t)par * S.dm.B * CS + pos] = (int)sb;
+}
+
 // Request the evaluation (implicit_dynamics! sweep) of slot sb: one queue entry per horizon step,
 // bucketed by the reference knot of that step.
-__device__ __forceinline__ void enqueue_eval(const NewtonDev& S, size_t sb, int b, int par, int tid, int nt) {
+// list_pos: position of the slot in the round's slot list (reset / B3 seam: slot 0 of rollout b sits at b), -1 = append
+__device__ __forceinline__ void enqueue_eval(const NewtonDev& S, size_t sb, int b, int par, int tid, int nt, int list_pos = -1) {
     const int H = S.dm.H, K = S.WQ.K;
     for (int k = tid; k < H; k += nt) {
         const int t = S.WQ.window[(size_t)b * (H + 2) + k];
@@ -70,6 +78,7 @@ __device__ __forceinline__ void enqueue_eval(const NewtonDev& S, size_t sb, int 
     if (tid == 0) {
         S.WQ.done_count[sb] = 0;
         S.need_sweep[sb] = 1;
+        list_slot(S, sb, par, list_pos);
     }
 }
 
@@ -177,7 +186,7 @@ __device__ __forceinline__ void start_line_search(const NewtonDev& S, int b, int
         for (int c = 0; c < n; ++c) enqueue_eval(S, sb0 + c, b, par, lane, nt);
         if (lane == 0) {
             for (int c = n; c < CS; ++c) S.need_sweep[sb0 + c] = 0;
-            if (S.kkt_same_round != 2) atomicAdd(&S.counters[0], 1);
+            if (S.kkt_same_round != 2) atomicAdd(&S.counters[0 * CPAD], 1);
         }
     }
 }
@@ -200,8 +209,10 @@ __device__ __forceinline__ const double* dz_eff(const NewtonDev& S, int b, int i
 
 // residual! on evaluation slot sb (candidate trajectory, nu_cand, d, dz of that slot): writes res_cand of the
 // slot and returns THIS THREAD's share of |r|_1 (the caller reduces all candidate slots in one pass)
+// `absr` (optional, LDS, [N]): |r_e| of every entry instead of the per-thread partial sums - the caller then forms the partial
+// sums of the canonical 256-thread pass itself, so the norm does not depend on how many threads computed the entries.
 template <int NQ, int NU, bool CF>
-__device__ double slot_residual(const NewtonDev& S, size_t sb, int b, const int* eff, int tid, int nt) {
+__device__ double slot_residual(const NewtonDev& S, size_t sb, int b, const int* eff, int tid, int nt, double* absr = nullptr) {
     const cimpc_dims& m = S.dm;
     const int nq = NQ > 0 ? NQ : m.nq, nu = NQ > 0 ? NU : m.nu;      // NQ = 0: runtime dimensions (models without a compiled set)
     constexpr bool cf = CF;
@@ -218,6 +229,58 @@ __device__ double slot_residual(const NewtonDev& S, size_t sb, int b, const int*
         const int s_ = eff[i];
         return s_ >= 0 ? S.dz + ((sb0 + s_) * H + i) * blk : S.dz_good + ((size_t)b * H + i) * blk;
     };
+    if constexpr (NQ > 0 && !CF) {
+        if (absr != nullptr && S.V == nullptr) {
+            // :configuration + TrackingObjective (the hot configuration).  The pass is a chain of memory round trips, not arithmetic
+            // (measured: 20 us per slot, 11 us for a lone workgroup, for 13 k multiply-adds), so it is written as ONE straight-line
+            // body per thread - a u row, a q row and a d row, indices clamped instead of branched on - and every operand is requested
+            // before the first multiply-add: one round trip for all three rows.  Same products, same summation order per row as the
+            // general loop below.
+            constexpr int nrc = NQ + NU, JM = NQ > NU ? NQ : NU;
+            const double* cu = S.cand.u + sb * H * NU; const double* ru = S.ref.u + (size_t)b * H * NU;
+            const double* cqp = S.cand.q + sb * (H + 2) * NQ; const double* rqp = S.ref.q + (size_t)b * (H + 2) * NQ;
+            const double* dd = S.d + sb * H * NQ;
+            for (int j = tid; j < H * JM; j += nt) {
+                // ---- u1[i]: R_i (u - u_ref) + du1_i^T nu_i
+                const bool on_u = j < H * NU;
+                const int ju = on_u ? j : 0, iu = ju / NU, cu_ = ju - iu * NU;
+                const double* Rm = S.R + (size_t)iu * NU * NU + cu_; const double* uu = cu + iu * NU; const double* ur = ru + iu * NU;
+                const double* A0 = dzp(iu) + (size_t)(2 * NQ + cu_) * NQ; const double* nv = nuc + iu * NQ;
+                // ---- q2[i]: Q_i (q - q_ref) - nu_i + dq1_{i+1}^T nu_{i+1} + dq0_{i+2}^T nu_{i+2}
+                const bool on_q = j < H * NQ;
+                const int jq = on_q ? j : 0, i = jq / NQ, cq = jq - i * NQ;
+                const int i1 = min(i + 1, H - 1), i2 = min(i + 2, H - 1);          // (clamped: the loads stay valid, the terms are dropped below)
+                const double* Qm = S.Q + (size_t)i * NQ * NQ + cq; const double* qq = cqp + (i + 2) * NQ; const double* qr = rqp + (i + 2) * NQ;
+                const double* A1 = dzp(i1) + (size_t)(NQ + cq) * NQ; const double* n1 = nuc + i1 * NQ;
+                const double* A2 = dzp(i2) + (size_t)cq * NQ; const double* n2 = nuc + i2 * NQ;
+                double rv[NU], du_[NU], av[NQ], vv[NQ], qv[NQ], dq_[NQ], a1[NQ], v1[NQ], a2[NQ], v2[NQ];
+#pragma unroll
+                for (int k = 0; k < NU; ++k) { rv[k] = Rm[k * NU]; du_[k] = uu[k] - ur[k]; }
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) { av[k] = A0[k]; vv[k] = nv[k]; qv[k] = Qm[k * NQ]; dq_[k] = qq[k] - qr[k]; a1[k] = A1[k]; v1[k] = n1[k]; a2[k] = A2[k]; v2[k] = n2[k]; }
+                const double nui = nuc[i * NQ + cq];
+                const double dv = dd[jq];                              // ---- rd[i] = d_i
+                double vu = 0.0, su = 0.0, vq = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int k = 0; k < NU; ++k) vu = fma(rv[k], du_[k], vu);
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) su = fma(av[k], vv[k], su);
+                vu += su;
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) vq = fma(qv[k], dq_[k], vq);
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) s1 = fma(a1[k], v1[k], s1);
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) s2 = fma(a2[k], v2[k], s2);
+                vq -= nui;
+                if (i + 1 < H) vq += s1;
+                if (i + 2 < H) vq += s2;
+                if (on_u) { r[iu * nrc + cu_] = vu; absr[iu * nrc + cu_] = fabs(vu); }
+                if (on_q) { r[i * nrc + NU + cq] = vq; absr[i * nrc + NU + cq] = fabs(vq); r[H * nrc + jq] = dv; absr[H * nrc + jq] = fabs(dv); }
+            }
+            return 0.0;
+        }
+    }
     double part = 0.0;
     for (int e = tid; e < S.N; e += nt) {
         double v = 0.0;
@@ -293,12 +356,21 @@ __device__ double slot_residual(const NewtonDev& S, size_t sb, int b, const int*
             }
         }
         r[e] = v;
-        part += fabs(v);
+        if (absr != nullptr) absr[e] = fabs(v);
+        else part += fabs(v);
     }
     return part;
 }
 
-template <int NQ, int NU, bool CF, bool ASYNC>
+// SPLIT (lock-step rounds): the stage runs as TWO launches.  SPLIT = 1 (resid_slot_kernel): one workgroup per (rollout,
+// evaluation slot `my`) forms that slot's residual and its 1-norm - a rollout that evaluated seven step lengths used to serialise
+// seven residual passes in one workgroup and set the length of the whole launch (measured: mean workgroup 42 us, longest 157 us =
+// the launch).  SPLIT = 2 (resid_decide_kernel): one workgroup per rollout reads the norms and takes the decision.  The kernel
+// boundary is the hand-over (an in-kernel hand-over needs agent-scope release fences = L2 write-backs on this multi-XCD part:
+// measured 104 -> 210 us per launch).  The arithmetic per slot is unchanged (same thread -> entry map, same reduction tree), so
+// results are bit-identical to the one-workgroup form (SPLIT = 0: the asynchronous kernel's residual job).
+constexpr int SLOT_ABS_MAX = 6144;      // longest Newton vector whose |r_e| fit the slot kernel's LDS scratch (48 KB); longer ones: 256-thread pass
+template <int NQ, int NU, bool CF, bool ASYNC, int SPLIT = 0>
 __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, double* red, double* rc, int* sh) {
     const cimpc_dims& m = S.dm;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -307,45 +379,74 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
     if (!ASYNC && blockIdx.x == 0) {   // the queue of this round has been consumed: recycle it
         const int K = S.WQ.K, par = S.WQ.par;
         for (int k = tid; k < K; k += nt) { *qcount(S.WQ, par, k) = 0; *qhead(S.WQ, k) = 0; }
-        if (tid < 8) S.counters_next[tid] = 0;      // counter block of the next round
+        if (tid < 8) S.counters_next[tid * CPAD] = 0;      // counter block of the next round
+    }
+    // (SPLIT = 2: the per-slot scalars of the rollout are requested together with its stage, one round trip for the entry checks)
+    int pre_dc = H, pre_ns = 0;
+    double pre_rc = 0.0;
+    if constexpr (SPLIT == 2) {
+        if (tid < CS) { pre_dc = S.WQ.done_count[sb0 + tid]; pre_ns = S.need_sweep[sb0 + tid]; pre_rc = S.r_cand[sb0 + tid]; }
     }
     const int stage = S.stage[b];
     if (stage == STAGE_DONE || stage == STAGE_KKT) return;
     const int ncand = (stage == STAGE_LS1) ? 2 : (stage == STAGE_LS2) ? 4 : (stage == STAGE_LS7) ? 7 : (stage == STAGE_LS3) ? 3 : 1;
     const int it0 = (stage == STAGE_LS1) ? 1 : (stage == STAGE_LS2) ? 3 : 0;      // first iterate (= slot) of the batch
-    if (S.need_sweep[sb0 + it0] == 0) return;    // nothing was evaluated for this rollout
-    if constexpr (!ASYNC) {   // an interior-point solve of this evaluation is still parked: wait for the next round
-        int pend = 0;
-        if (tid < ncand) pend = (S.WQ.done_count[sb0 + it0 + tid] < H);
-        if (__syncthreads_or(pend)) {
-            if (tid == 0) atomicAdd(&S.counters[0], 1);
+    if constexpr (SPLIT == 2) {
+        const bool mine = tid >= it0 && tid < it0 + ncand;
+        if (!__syncthreads_or(tid == it0 && pre_ns != 0)) return;    // nothing was evaluated for this rollout
+        if (__syncthreads_or(mine && pre_dc < H)) {                  // an interior-point solve of this evaluation is still parked: wait for the next round
+            if (tid == 0) atomicAdd(&S.counters[0 * CPAD], 1);
+            if (mine) list_slot(S, sb0 + tid, S.WQ.par ^ 1);         // its slots stay on the list
             return;
+        }
+        if (mine) rc[tid - it0] = pre_rc;
+    } else {
+        if (S.need_sweep[sb0 + it0] == 0) return;    // nothing was evaluated for this rollout
+        if constexpr (!ASYNC) {   // an interior-point solve of this evaluation is still parked: wait for the next round
+            int pend = 0;
+            if (tid < ncand) pend = (S.WQ.done_count[sb0 + it0 + tid] < H);
+            if (__syncthreads_or(pend)) {
+                if (tid == 0) atomicAdd(&S.counters[0 * CPAD], 1);
+                return;
+            }
         }
     }
     int& s_act = sh[0]; int& s_slot = sh[1]; int& s_iter = sh[2];
     constexpr int EFF_H = 128;                       // horizon steps the LDS table holds (longer horizons resolve on the fly)
-    __shared__ int eff[CS * EFF_H];
+    __shared__ int eff[(SPLIT ? 1 : CS) * EFF_H];
     const bool use_eff = H <= EFF_H;
-    {   // all candidate slots, ONE reduction pass (red: [CS][nt]; per slot the same pairwise tree as a single
-        // reduction, so the norms do not depend on how many candidates share the pass)
-        // effective sensitivity source of every (candidate, step), resolved ONCE (dz_eff): slot index or -1
-        for (int e = tid; e < ncand * H && use_eff; e += nt) {
-            const int c = e / H, i = e - c * H;
+    // effective sensitivity source of every step of candidate c (dz_eff), resolved ONCE into LDS: slot index or -1
+    auto resolve_eff = [&](int c, int* row) {
+        for (int i = tid; i < H && use_eff; i += nt) {
             int s_ = it0 + c;
             while (s_ >= 0 && S.ip_status[(sb0 + s_) * H + i] == 0) --s_;
-            eff[c * EFF_H + i] = s_;
+            row[i] = s_;
         }
+    };
+    if constexpr (SPLIT == 2) {
+        __syncthreads();      // rc[] (the slot kernel's norms) is in place
+    } else {   // all candidate slots in this workgroup (the asynchronous kernel's residual job): slot after slot, each norm summed
+               // as the canonical 256-thread pass sums it (see SPLIT = 1), ONE reduction tree for all of them
+        constexpr int CT = 256;
+        for (int c = 0; c < ncand; ++c) resolve_eff(c, eff + c * EFF_H);
         __syncthreads();
-#pragma unroll
-        for (int c = 0; c < CS; ++c)
-            if (c < ncand) red[c * nt + tid] = slot_residual<NQ, NU, CF>(S, sb0 + it0 + c, b, use_eff ? eff + c * EFF_H : nullptr, tid, nt);
-        __syncthreads();
-        for (int st = nt / 2; st > 0; st >>= 1) {
-            if (tid < st)
-                for (int c = 0; c < ncand; ++c) red[c * nt + tid] += red[c * nt + tid + st];
+        double* absr = red + CS * CT;               // [N] scratch behind the partial sums (the caller's buffer holds CS * 256 + N doubles)
+        for (int c = 0; c < ncand; ++c) {
+            slot_residual<NQ, NU, CF>(S, sb0 + it0 + c, b, use_eff ? eff + c * EFF_H : nullptr, tid, nt, absr);
+            __syncthreads();
+            for (int j = tid; j < CT; j += nt) {
+                double part = 0.0;
+                for (int e = j; e < S.N; e += CT) part += absr[e];
+                red[c * CT + j] = part;
+            }
             __syncthreads();
         }
-        if (tid < ncand) { rc[tid] = red[tid * nt]; S.r_cand[sb0 + it0 + tid] = red[tid * nt]; }
+        for (int st = CT / 2; st > 0; st >>= 1) {
+            for (int j = tid; j < st; j += nt)
+                for (int c = 0; c < ncand; ++c) red[c * CT + j] += red[c * CT + j + st];
+            __syncthreads();
+        }
+        if (tid < ncand) { rc[tid] = red[tid * CT]; S.r_cand[sb0 + it0 + tid] = red[tid * CT]; }
         __syncthreads();
     }
     // ---- decision (newton.jl:198-280) ------------------------------------------------------
@@ -391,10 +492,8 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
             S.ro_sweeps[b] += nref;
             S.ro_ip_iters[b] += (int)t_its_ref;
             S.ro_ip_fail[b] += (int)t_fails_ref;
-            atomicAdd((unsigned long long*)&S.stats[0], (unsigned long long)ncand);
-            atomicAdd((unsigned long long*)&S.stats[1], (unsigned long long)(ncand * H));
-            atomicAdd((unsigned long long*)&S.stats[2], (unsigned long long)t_its);
-            atomicAdd((unsigned long long*)&S.stats[3], (unsigned long long)t_fails);
+            long long* st = S.stats + (size_t)b * 4;      // this rollout's line: one decision at a time per rollout
+            st[0] += ncand; st[1] += (long long)ncand * H; st[2] += (long long)t_its; st[3] += t_fails;
         }
     }
     __syncthreads();
@@ -416,7 +515,7 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
         }
         if (tid == 0) {
             S.stage[b] = nstage;
-            atomicAdd(&S.counters[0], 1);
+            atomicAdd(&S.counters[0 * CPAD], 1);
         }
         return;
     }
@@ -434,8 +533,12 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
         // independent loads, two doubles per lane.
         const int blk = S.nths * S.nd, ita = it0 + slot;
         double* good = S.dz_good + (size_t)b * H * blk;
+        if constexpr (SPLIT == 2) {      // the table row of the ACCEPTED slot
+            resolve_eff(slot, eff);
+            __syncthreads();
+        }
         if (use_eff && (blk & 1) == 0) {
-            const int* ef = eff + slot * EFF_H;
+            const int* ef = eff + (SPLIT ? 0 : slot * EFF_H);
             const int hb = blk / 2;
             for (int e = tid; e < H * hb; e += nt) {
                 const int i = e / hb, s_ = ef[i];
@@ -476,7 +579,7 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
         } else {
             S.stage[b] = STAGE_KKT;
             if constexpr (!ASYNC) {
-                const int pos = atomicAdd(&S.counters[1], 1);
+                const int pos = atomicAdd(&S.counters[1 * CPAD], 1);
                 if (S.kkt_list != nullptr) S.kkt_list[(size_t)S.WQ.par * m.B + pos] = b;
             }
         }
@@ -502,24 +605,90 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
 #ifndef CIMPC_RESID_THREADS
 #define CIMPC_RESID_THREADS 256
 #endif
+#ifndef CIMPC_SLOT_THREADS
+#define CIMPC_SLOT_THREADS 512
+#endif
+// first launch of the stage: one workgroup per evaluated slot - its residual and 1-norm.  The slots come from the compact list the
+// requesters of the round built (NewtonDev::slot_list).  Every scalar the block needs is requested in ONE batch of loads before the
+// first branch.
+template <int NQ, int NU, bool CF>
+__global__ __launch_bounds__(CIMPC_SLOT_THREADS) void resid_slot_kernel(NewtonDev S, const int* list) {
+    constexpr int CT = 256, EFF_H = 128;
+    __shared__ double red[CT + SLOT_ABS_MAX];
+    __shared__ int eff[EFF_H];
+    const int tid = threadIdx.x, nt = blockDim.x, H = S.dm.H;
+    int my, b;
+    if (list != nullptr) {      // one block per requested slot
+        const int e = list[blockIdx.x];
+        b = e / CS; my = e - b * CS;
+    } else {                    // one block per (rollout, slot) pair, slot-major
+        my = (int)blockIdx.x / S.nb_launch; b = (int)blockIdx.x - my * S.nb_launch + S.b0;
+    }
+    const size_t sb0 = (size_t)b * CS, sb = sb0 + my;
+    const bool use_eff = H <= EFF_H;
+    const int ns_my = S.need_sweep[sb];
+    const int stage = S.stage[b];
+    const int dc = tid < CS ? S.WQ.done_count[sb0 + tid] : H;
+    const int nsl = tid < CS ? S.need_sweep[sb0 + tid] : 0;
+    int eff_i = -1;      // step i = tid: the last slot <= my whose solve of this step succeeded (dz_eff), -1 = dz_good
+    if (use_eff && tid < H) {
+#pragma unroll
+        for (int s_ = 0; s_ < CS; ++s_) {
+            const int ok = (s_ <= my) ? S.ip_status[(sb0 + s_) * H + tid] : 0;
+            if (ok != 0) eff_i = s_;
+        }
+    }
+    if (ns_my == 0 || stage == STAGE_DONE || stage == STAGE_KKT) return;
+    const int ncand = (stage == STAGE_LS1) ? 2 : (stage == STAGE_LS2) ? 4 : (stage == STAGE_LS7) ? 7 : (stage == STAGE_LS3) ? 3 : 1;
+    const int it0 = (stage == STAGE_LS1) ? 1 : (stage == STAGE_LS2) ? 3 : 0;
+    if (my < it0 || my >= it0 + ncand) return;
+    const bool mine = tid >= it0 && tid < it0 + ncand;
+    // nothing evaluated for this rollout, or one of its evaluations still has a parked solve (the decision waits a round)
+    if (__syncthreads_or((tid == it0 && nsl == 0) || (mine && dc < H))) return;
+    if (use_eff && tid < H) eff[tid] = eff_i;
+    __syncthreads();
+    // |r_e| goes to LDS and the 1-norm is summed exactly as the canonical 256-thread pass sums it: partial j = entries j, j + 256,
+    // ... in order, then the pairwise tree - the norm does not depend on the number of threads that formed the entries
+    if (S.N <= SLOT_ABS_MAX) {
+        double* absr = red + CT;
+        slot_residual<NQ, NU, CF>(S, sb, b, use_eff ? eff : nullptr, tid, nt, absr);
+        __syncthreads();
+        if (tid < CT) {
+            double part = 0.0;
+            for (int e = tid; e < S.N; e += CT) part += absr[e];
+            red[tid] = part;
+        }
+    } else {
+        const double part = tid < CT ? slot_residual<NQ, NU, CF>(S, sb, b, use_eff ? eff : nullptr, tid, CT) : 0.0;
+        if (tid < CT) red[tid] = part;
+    }
+    __syncthreads();
+    for (int st = CT / 2; st > 0; st >>= 1) {
+        if (tid < st) red[tid] += red[tid + st];
+        __syncthreads();
+    }
+    if (tid == 0) S.r_cand[sb] = red[0];
+}
+// second launch: one workgroup per rollout - decision, trajectory update, next requests
 template <int NQ, int NU, bool CF>
 __global__ __launch_bounds__(CIMPC_RESID_THREADS) void resid_decide_kernel(NewtonDev S) {
-    __shared__ double red[CS * CIMPC_RESID_THREADS];
+    __shared__ double red[2 * CIMPC_RESID_THREADS];
     __shared__ double rc[CS];
     __shared__ int sh[4];
-    resid_decide_body<NQ, NU, CF, false>(S, (int)blockIdx.x + S.b0, red, rc, sh);
+    resid_decide_body<NQ, NU, CF, false, 2>(S, (int)blockIdx.x + S.b0, red, rc, sh);
     // ---- epilogue: the LAST block to finish publishes the round's counters to host-mapped pinned
     //      memory (the host polls the stamp; no memcpy / event on the critical path)
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        const int ticket = atomicAdd(&S.counters[7], 1);
+        const int ticket = atomicAdd(&S.counters[7 * CPAD], 1);
         if (ticket == (int)gridDim.x - 1) {
-            const int n_sweep = atomicAdd(&S.counters[0], 0), n_kkt = atomicAdd(&S.counters[1], 0);
+            const int n_sweep = atomicAdd(&S.counters[0 * CPAD], 0), n_kkt = atomicAdd(&S.counters[1 * CPAD], 0);
             volatile int* hm = S.host_flag;
             hm[0] = n_sweep;
             hm[1] = n_kkt;
-            hm[4] = atomicAdd(&S.counters[2], 0);                                   // solves parked by this round
+            hm[4] = atomicAdd(&S.counters[2 * CPAD], 0);                                   // solves parked by this round
+            hm[6] = atomicAdd(&S.counters[4 * CPAD], 0);                                   // evaluation slots of the next round
             hm[5] = S.A.n_done != nullptr ? atomicAdd(S.A.n_done, 0) : 0;            // rollouts finished so far
             __threadfence_system();
             hm[2] = S.round_stamp;
@@ -926,7 +1095,7 @@ __global__ __launch_bounds__(64) void kkt_kernel_scalar(NewtonDev S, KktArgs K) 
     }
     KPROF(11)
 #ifdef CIMPC_KKT_PROF
-    if (lane == 0 && b == 0) for (int j = 0; j < 16; ++j) ((long long*)S.stats)[8 + j] = pt[j];
+    if (lane == 0 && b == 0) for (int j = 0; j < 16; ++j) ((long long*)S.stats)[8 + j] = pt[j];      // (diagnostic builds: overwrites the statistics of rollouts 2..5)
 #endif
     if (K.finish) {
         __threadfence_block();
@@ -1497,7 +1666,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     lds_sync();
     KPROF(8)
 #ifdef CIMPC_KKT_PROF
-    if (lane == 0 && b == 0) for (int j = 0; j < 16; ++j) ((long long*)S.stats)[8 + j] = pt[j];
+    if (lane == 0 && b == 0) for (int j = 0; j < 16; ++j) ((long long*)S.stats)[8 + j] = pt[j];      // (diagnostic builds: overwrites the statistics of rollouts 2..5)
 #endif
     if (K.finish) {
         __threadfence_block();

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void reset_kernel(NewtonDev S, const double* q
     for (int k = tid; k < CS * H; k += nt) S.pflag[sb0 * H + k] = 0;
     __syncthreads();
     if (S.A.on) enqueue_eval_async<BlockSync>(S, sb0, 0, 1, b, tid, nt);
-    else enqueue_eval(S, sb0, b, S.WQ.par, tid, nt);
+    else enqueue_eval(S, sb0, b, S.WQ.par, tid, nt, b - S.b0);      // round 0 evaluates slot 0 of every rollout: list entry b
 }
 
 template <int NQ, int NU>
@@ -244,7 +244,7 @@ int launch_kkt_mixed(const NewtonDev& S, const KktArgs& K0, double* ws, int* n_f
 
 __global__ __launch_bounds__(64) void enqueue_all_kernel(NewtonDev S) {
     const int b = blockIdx.x + S.b0;
-    enqueue_eval(S, (size_t)b * CS, b, S.WQ.par, threadIdx.x, 64);
+    enqueue_eval(S, (size_t)b * CS, b, S.WQ.par, threadIdx.x, 64, b - S.b0);
     if (threadIdx.x == 0) S.cur_slot[b] = 0;
     for (int k = threadIdx.x; k < S.dm.H; k += 64) S.pflag[(size_t)b * CS * S.dm.H + k] = 0;
 }
@@ -410,11 +410,16 @@ int launch_reset(const NewtonDev& S, const double* q0, const double* q1, int war
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
 template <int NQ, int NU>
-static int launch_resid_t(const NewtonDev& S, hipStream_t s) {
-    if (S.dm.mode == CIMPC_MODE_CONFIGURATIONFORCE)
+static int launch_resid_t(const NewtonDev& S, hipStream_t s, int n_slots) {
+    const int* list = (n_slots >= 0 && S.slot_list != nullptr) ? S.slot_list + (size_t)S.WQ.par * S.dm.B * CS : nullptr;
+    const int grid = list != nullptr ? n_slots : S.nb_launch * CS;
+    if (S.dm.mode == CIMPC_MODE_CONFIGURATIONFORCE) {
+        if (grid > 0) hipLaunchKernelGGL((resid_slot_kernel<NQ, NU, true>), dim3(grid), dim3(CIMPC_SLOT_THREADS), 0, s, S, list);
         hipLaunchKernelGGL((resid_decide_kernel<NQ, NU, true>), dim3(S.nb_launch), dim3(CIMPC_RESID_THREADS), 0, s, S);
-    else
+    } else {
+        if (grid > 0) hipLaunchKernelGGL((resid_slot_kernel<NQ, NU, false>), dim3(grid), dim3(CIMPC_SLOT_THREADS), 0, s, S, list);
         hipLaunchKernelGGL((resid_decide_kernel<NQ, NU, false>), dim3(S.nb_launch), dim3(CIMPC_RESID_THREADS), 0, s, S);
+    }
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
 __global__ void queue_recycle_kernel(IpQueues Q, int par) {
@@ -425,12 +430,12 @@ int launch_queue_recycle(const IpQueues& Q, int par, hipStream_t s) {
     hipLaunchKernelGGL(queue_recycle_kernel, dim3((Q.K + 255) / 256), dim3(256), 0, s, Q, par);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
-int launch_resid_decide(const NewtonDev& S, hipStream_t s) {
+int launch_resid_decide(const NewtonDev& S, hipStream_t s, int n_slots) {
     const int nq = S.dm.nq, nu = S.dm.nu;
-#define X(q, u) if (nq == q && nu == u) return launch_resid_t<q, u>(S, s);
+#define X(q, u) if (nq == q && nu == u) return launch_resid_t<q, u>(S, s, n_slots);
     CIMPC_NQNU(X)
 #undef X
-    return launch_resid_t<0, 0>(S, s);        // runtime dimensions (models without a compiled set)
+    return launch_resid_t<0, 0>(S, s, n_slots);        // runtime dimensions (models without a compiled set)
 }
 template <int NQ, int NU>
 static int launch_kkt_packed_t(const NewtonDev& S, const KktArgs& K, const int* list, int n, const int* n_dev, hipStream_t s, bool pipe) {

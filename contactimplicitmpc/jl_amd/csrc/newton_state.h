@@ -57,11 +57,15 @@ struct NewtonDev {
     int* stage;        // [B]
     int* kkt_list;     // [2][B] rollouts that entered STAGE_KKT, per round parity (compact list for the packed KKT launch)
     int* need_sweep;   // [B*CS]
-    int* counters;     // [8]: 0 = #rollouts needing a sweep, 1 = #needing KKT, 2 = parked solves, 7 = block ticket
+    int* slot_list;    // [2][B*CS] evaluation slots requested for a round (by queue parity, count in counters[4]): the residual launch
+                       // of that round gets one workgroup per ENTRY instead of one per (rollout, slot) pair - idle blocks are not free
+                       // (3584 blocks, 15 % live: 50 us per launch, most of it block dispatch)
+    int* counters;     // [8 * CPAD], counter k at k * CPAD: 0 = #rollouts needing a sweep, 1 = #needing KKT, 2 = parked solves, 3 = drained workgroups, 4 = evaluation slots requested of the next round, 7 = block ticket
     int* counters_next; // counter block of the next round (zeroed by the residual kernel)
     int* host_flag;    // host-mapped pinned {n_sweep, n_kkt, stamp}
     int round_stamp;   // value published to host_flag[2] when the round is complete
-    long long* stats;  // [4]: sweeps, ip_solves, ip_iters, ip_failures (accumulated)
+    long long* stats;  // [B][4] per rollout: sweeps, ip_solves, ip_iters, ip_failures of the running solve, speculative evaluations included
+                       // (plain stores of the rollout's decision workgroup - a global counter would be 4 same-line atomics per workgroup; the host sums)
     int* ro_sweeps;    // [B] implicit_dynamics! evaluations of the last solve
     int* ro_ip_iters;  // [B] interior-point iterations of the last solve
     int* ro_ip_fail;   // [B] failed interior-point solves of the last solve
@@ -101,7 +105,7 @@ struct GaitDev {
 int launch_gait_window(const NewtonDev& S, const GaitDev& G, int* window, int advance, hipStream_t s);
 int launch_reset(const NewtonDev& nd, const double* q0, const double* q1, int warm, hipStream_t s);
 int launch_dz_rekey(const NewtonDev& nd, double* knot, const int* window, int which, int dir, hipStream_t s);
-int launch_resid_decide(const NewtonDev& nd, hipStream_t s);
+int launch_resid_decide(const NewtonDev& nd, hipStream_t s, int n_slots = -1);   // n_slots: entries of slot_list[WQ.par] (-1: every (rollout, slot) pair gets a block)
 int launch_enqueue_all(const NewtonDev& nd, hipStream_t s);   // B3 seam: queue slot 0 of every rollout
 int launch_kkt(const NewtonDev& nd, hipStream_t s);
 bool kkt_condensed_available(const NewtonDev& nd);
