@@ -304,6 +304,7 @@ IpParams make_ip_params(cimpc_ctx* h, const TrajDev& T, int par, int* pending_co
     p.alt = h->alt_set ? h->d_alt : nullptr;
     p.d = h->S.d;
     p.dz = h->S.dz;
+    p.nu = nullptr; p.dtn = nullptr; p.dtn_ld = h->S.dtn_ld;      // (the Newton loop switches the products on, see cimpc_newton_solve_dev)
     p.status = h->S.ip_status;
     p.iters = h->S.ip_iters;
     p.zout = zout;
@@ -318,8 +319,10 @@ IpParams make_ip_params(cimpc_ctx* h, const TrajDev& T, int par, int* pending_co
 }
 
 // queue kernel + sensitivity kernel of one round
-int run_sweep(cimpc_ctx* h, int par, int* pending_counter, double* zout, hipStream_t st, int iter_cap = 0, int* drain_counter = nullptr) {
+int run_sweep(cimpc_ctx* h, int par, int* pending_counter, double* zout, hipStream_t st, int iter_cap = 0, int* drain_counter = nullptr,
+              bool with_products = false) {
     IpParams p = make_ip_params(h, h->S.cand, par, pending_counter, zout);
+    if (with_products && h->S.dtn != nullptr) { p.nu = h->S.nu_cand; p.dtn = h->S.dtn; }
     if (iter_cap > 0) p.iter_cap = iter_cap;
     if (drain_counter != nullptr && h->kn.drain_pct > 0 && p.iter_cap < h->ip.max_iter) {
         p.drain_count = drain_counter;
@@ -540,6 +543,8 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     AX(&S.d, BS * H * h->nd);
     AX(&S.dz, BS * H * h->nths * h->nd);
     AX(&S.dz_good, B * H * h->nths * h->nd);
+    S.dtn_ld = h->ki.generic ? 0 : h->ki.dtn_ld;
+    if (S.dtn_ld > 0) AX(&S.dtn, BS * H * (size_t)S.dtn_ld);
     AX(&S.ip_status, BS * H);
     AX(&S.ip_iters, BS * H);
     AX(&S.pflag, BS * H);
@@ -1083,6 +1088,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         prof_end(h, st);
         if (rc2 != CIMPC_OK) return fail(h, rc2, "reset / hand-off launch failed");
         IpParams p = make_ip_params(h, S.cand, 0, h->d_ring + 2 * CPAD, nullptr);
+        if (S.dtn != nullptr) { p.nu = S.nu_cand; p.dtn = S.dtn; }
         p.Q = Sk.WQ;
         p.iter_cap = h->ip.max_iter + 1;      // no solve is parked (solves parked by the lock-step rounds resume and finish)
         p.A = A;
@@ -1191,7 +1197,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         // it only adds rounds, so a round that serves few rollouts lets every solve run to the end
         const int tail_div = h->kn.tail_div;
         const int cap = (tail_div > 0 && last_sweep * tail_div <= h->dm.B) ? h->ip.max_iter : h->iter_cap;
-        int rr = run_sweep(h, par, d_cnt + 2 * CPAD, nullptr, sb.st, cap, d_cnt + 3 * CPAD);
+        int rr = run_sweep(h, par, d_cnt + 2 * CPAD, nullptr, sb.st, cap, d_cnt + 3 * CPAD, true);
         if (rr != CIMPC_OK) return rr;
         if (kkt && h->kkt_overlap && hipStreamWaitEvent(sb.st, sb.ev_join, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join failed");
         prof_begin(h, PC_RESID, sb.st);

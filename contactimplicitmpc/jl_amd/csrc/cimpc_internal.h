@@ -133,6 +133,12 @@ struct IpParams {
     const double* alt;     // [B][nc] altitude offsets (RLin.alt) or null
     double* d;             // [B*slots][H][nd]            dynamics violation
     double* dz;            // [B*slots][H][nths][nd]      column-major nd x (2nq+nu) sensitivities
+    // delta^T nu: the products residual! forms with the sensitivities (newton_residual.jl:125-127: dq0[t]^T nu_i, dq1[t]^T nu_i,
+    // du1[t]^T nu_i), emitted by the solve that produced them while the columns are still in registers - the decision stage then
+    // reads nths doubles per solve instead of the whole nths x nd block (58 MB per launch at B = 512, L1-thrashing column reads)
+    const double* nu;      // [B*slots][H][nd] dual candidate of the evaluation (null: no products, e.g. the B3 seam)
+    double* dtn;           // [B*slots][H][dtn_ld]  (dz column c)^T nu, c = 0 .. nths-1; null: not produced
+    int dtn_ld;
     int* status;           // [B*slots][H]  1 = converged
     int* iters;            // [B*slots][H]  IP iterations
     double* zout;          // [B*slots][H][nz] converged z (optional, null = skip)
@@ -170,6 +176,7 @@ struct KernelInfo {
     int lds_table;    // doubles
     int lds_group;    // doubles of per-problem scratch
     int tab_size;     // doubles per knot
+    int dtn_ld;       // leading dimension of the delta^T nu products the sweep emits (0: the kernel does not emit them)
     int generic;      // 1: no compiled lane-group kernel for these dimensions - the runtime-dimension kernel (ip_generic.hip) serves them
 };
 

@@ -50,14 +50,13 @@ struct Model {
     static constexpr int G = (NX <= 16 && NY <= 16) ? 16 : 32;
     static_assert(NX <= 32 && NY <= 32, "lane group holds at most 32 rows");
     static constexpr int RST_LD = G + 1;                       // padded row stride of the R tile
+    static constexpr int DTN_LD = ((NTHS + G - 1) / G) * G;    // leading dimension of the delta^T nu products (IpParams::dtn)
 #ifndef CIMPC_SENS_MAX
 #define CIMPC_SENS_MAX 16
 #endif
     static constexpr int SENS_MAX = CIMPC_SENS_MAX;             // converged problems a group may defer
-// (measured dead end: C A^-1, A^-1, Dy1 rows register-resident per knot - the 76 extra VGPRs spill, sweep launch 0.30 -> 0.47 ms)
-#ifndef CIMPC_RR_LDS
-#define CIMPC_RR_LDS 0
-#endif
+// (measured dead ends: C A^-1, A^-1, Dy1 rows register-resident per knot - the 76 extra VGPRs spill, sweep launch 0.30 -> 0.47 ms;
+//  rows of R left in the LDS tile instead of registers for a third wave per SIMD - the spills stay, 0.35 -> 0.63 ms)
 #ifndef CIMPC_SENS_ILP
 #define CIMPC_SENS_ILP 5
 #endif
@@ -93,10 +92,7 @@ struct IpSolver {
     // iterate, residual, direction
     double x, y1, y2, rdyn, rrst, rbil, Dx_, Dy1_, Dy2_;
     // factorization: column l of Q, row l of -R (strict upper part), 1/R[l,l], regularised y, 1/y1r
-    // (CIMPC_RR_LDS: row l of -R stays in the LDS tile and is read where the back-substitution uses it - 2 NY registers
-    //  fewer per lane, the price of NY LDS reads per triangular solve)
-    static constexpr bool RR_LDS = CIMPC_RR_LDS != 0 && G == 16;
-    double Qc[NY], Rr[RR_LDS ? 1 : NY], rdinv, y1r, y2r, iy1r;
+    double Qc[NY], Rr[NY], rdinv, y1r, y2r, iy1r;
 
     __device__ __forceinline__ void bind(const double* tab_, double* Rst_, int l_) {
         tab = tab_; Rst = Rst_; l = l_;
@@ -192,16 +188,14 @@ struct IpSolver {
                     Qc[r] = fma(ncoef, ak[r], Qc[r]);
                 });
             }
-            Rst[k * M::RST_LD + l] = RR_LDS ? -rk : rk;   // R[k,l], l > k (zeros elsewhere)
+            Rst[k * M::RST_LD + l] = rk;   // R[k,l], l > k (zeros elsewhere)
         });
         wave_lds_fence();
-        if constexpr (!RR_LDS) {
-            static_for<0, NY>([&](auto kc) {   // row l of R (transpose through the LDS tile)
-                constexpr int k = decltype(kc)::value;
-                Rr[k] = vy ? -Rst[l * M::RST_LD + k] : 0.0;      // kept negated: the back-substitution adds
-            });
-            wave_lds_fence();
-        }
+        static_for<0, NY>([&](auto kc) {   // row l of R (transpose through the LDS tile)
+            constexpr int k = decltype(kc)::value;
+            Rr[k] = vy ? -Rst[l * M::RST_LD + k] : 0.0;      // kept negated: the back-substitution adds
+        });
+        wave_lds_fence();
     }
 
     // t = R^-1 Q^T rhs  (qr_solve!, qr.jl:142-158); rhs lane-indexed
@@ -220,16 +214,7 @@ struct IpSolver {
         // final once step k = l + 1 is done (R[l,k] = 0 for k <= l), so x_l = c * rdinv after the loop - the same product
         // the reference forms at step l (qr.jl:150-157).
         if constexpr (G == 16) {
-            if constexpr (RR_LDS) {
-                const double* row = Rst + (vy ? l : 0) * M::RST_LD;      // (lanes beyond NY: any valid row, masked below)
-                static_rfor<NY - 1>([&](auto kc) {
-                    constexpr int k = decltype(kc)::value;
-                    const double nr = row[k];
-                    Dpp16::backsub<k>(c, rdinv, vy ? nr : 0.0);
-                });
-            } else {
-                static_rfor<NY - 1>([&](auto kc) { Dpp16::backsub<decltype(kc)::value>(c, rdinv, Rr[decltype(kc)::value]); });
-            }
+            static_rfor<NY - 1>([&](auto kc) { Dpp16::backsub<decltype(kc)::value>(c, rdinv, Rr[decltype(kc)::value]); });
         } else {
             static_rfor<NY - 1>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
@@ -385,7 +370,23 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
     const double reg = LG::template bcast<0>((l == 0) ? ps[PS - 2] : 0.0);
     S.factorize(fmax(reg, p.o.kappa_tol * p.o.gamma_reg));
     double* dzo = p.dz + pi * (size_t)(NTHS * ND);
-    auto column = [&](int c) {
+    // delta^T nu of every column (IpParams::dtn).  The columns of a chunk are parked in the R tile (idle once the rows of R sit
+    // in registers), then lane j sums column j with the SAME multiply-add chain the decision stage would run on the stored
+    // block, s = fma(dz[k, j], nu[k], s), k = 0 .. nd-1 - bit-identical to reading the block back - at nd LDS reads + nd
+    // broadcast-FMAs per chunk and lane instead of a 16-lane reduction per column (measured: +4.5 % sweep time for that form).
+    constexpr int ILP = M::SENS_ILP;       // independent right-hand sides per trip: their triangular-solve chains interleave
+    constexpr int CH0 = M::TILE / ND, CH1 = CH0 < G ? CH0 : G, CH = (CH1 / ILP) * ILP;      // columns per chunk
+    static_assert(CH >= ILP, "the R tile holds at least one trip of sensitivity columns");
+    const bool want = p.dtn != nullptr;          // (wave-uniform: a kernel parameter)
+    double* scr = S.Rst;
+    double nux = 0.0;
+    [[maybe_unused]] double nuy = 0.0;
+    if (want) {
+        const double* nv = p.nu + pi * ND;
+        nux = vx ? xld<ASYNC>(nv + l) : 0.0;
+        if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) nuy = (l < NC + NB) ? xld<ASYNC>(nv + NX + l) : 0.0;
+    }
+    auto column = [&](int c, int cc) {
         const double u = tab[L.oRthDyn + c * G + l];
         const double v = tab[L.oRthRst + c * G + l];
         double xs;
@@ -394,15 +395,31 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
         if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) {
             if (l < NC + NB) xst<ASYNC>(dzo + c * ND + NX + l, t);   // -(S.y) = +temp
         }
+        if (want) {
+            if (vx) scr[cc * ND + l] = -xs;
+            if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) { if (l < NC + NB) scr[cc * ND + NX + l] = t; }
+        }
     };
-    // SENS_ILP independent right-hand sides per trip: their triangular-solve chains interleave
-    constexpr int ILP = M::SENS_ILP;
-    int c = 0;
 #pragma unroll 1
-    for (; c + ILP <= NTHS; c += ILP) {
-        static_for<0, ILP>([&](auto jc) { column(c + decltype(jc)::value); });
+    for (int c0 = 0; c0 < NTHS; c0 += CH) {
+        const int n = NTHS - c0 < CH ? NTHS - c0 : CH;
+        int cc = 0;
+#pragma unroll 1
+        for (; cc + ILP <= n; cc += ILP) {
+            static_for<0, ILP>([&](auto jc) { column(c0 + cc + decltype(jc)::value, cc + decltype(jc)::value); });
+        }
+        for (; cc < n; ++cc) column(c0 + cc, cc);
+        if (want) {
+            wave_lds_fence();
+            const double* col = scr + (l < n ? l : 0) * ND;       // (every lane runs the broadcasts; lanes beyond the chunk discard)
+            double s_ = 0.0;
+            static_for<0, NX>([&](auto kc) { constexpr int k = decltype(kc)::value; s_ = fma(col[k], LG::template bcast<k>(nux), s_); });
+            if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE)
+                static_for<0, NC + NB>([&](auto kc) { constexpr int k = decltype(kc)::value; s_ = fma(col[NX + k], LG::template bcast<k>(nuy), s_); });
+            if (l < n) xst<ASYNC>(p.dtn + pi * (size_t)M::DTN_LD + c0 + l, s_);
+            wave_lds_fence();
+        }
     }
-    for (; c < NTHS; ++c) column(c);
     problem_done<ASYNC>(p, prob / p.H, l);
 }
 
@@ -801,6 +818,7 @@ void info_model(KernelInfo* info) {
     info->lds_table = L.size;
     info->lds_group = M::LDS_GROUP;
     info->tab_size = L.size;
+    info->dtn_ld = M::DTN_LD;
 }
 
 #define CIMPC_DEFINE_MODEL(name, q, u, w, c, b)                                              \

@@ -81,6 +81,16 @@ struct LaneGroup {
         if constexpr (G == 32) v = fmin(v, __shfl_xor(v, 16, 64));
         return v;
     }
+    // sum over the group WITHOUT the re-broadcast: every lane holds the sum in its own association (rotation-based reductions
+    // associate differently per lane) - for results that ONE designated lane keeps
+    static __device__ __forceinline__ double group_sum(double v) {
+        v += dpp_xor1(v);
+        v += dpp_xor2(v);
+        v += dpp_ror4(v);
+        v += dpp_ror8(v);
+        if constexpr (G == 32) v += __shfl_xor(v, 16, 64);
+        return v;
+    }
     // sum over the group; the result of lane 0 is re-broadcast so that every lane of the
     // group holds bit-identical data (rotation-based reductions associate differently per lane)
     static __device__ __forceinline__ double all_sum(double v) {

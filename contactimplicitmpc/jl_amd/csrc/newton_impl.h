@@ -237,6 +237,7 @@ __device__ double slot_residual(const NewtonDev& S, size_t sb, int b, const int*
             // before the first multiply-add: one round trip for all three rows.  Same products, same summation order per row as the
             // general loop below.
             constexpr int nrc = NQ + NU, JM = NQ > NU ? NQ : NU;
+            const double* dtn = S.dtn; const int dld = S.dtn_ld;
             const double* cu = S.cand.u + sb * H * NU; const double* ru = S.ref.u + (size_t)b * H * NU;
             const double* cqp = S.cand.q + sb * (H + 2) * NQ; const double* rqp = S.ref.q + (size_t)b * (H + 2) * NQ;
             const double* dd = S.d + sb * H * NQ;
@@ -245,33 +246,42 @@ __device__ double slot_residual(const NewtonDev& S, size_t sb, int b, const int*
                 const bool on_u = j < H * NU;
                 const int ju = on_u ? j : 0, iu = ju / NU, cu_ = ju - iu * NU;
                 const double* Rm = S.R + (size_t)iu * NU * NU + cu_; const double* uu = cu + iu * NU; const double* ur = ru + iu * NU;
+                // (delta^T nu: the sweep's product where this slot's own solve of the step succeeded - the usual case -, else the
+                //  dot product with the block dz_eff resolves; `own*` selects after the loads, which stay valid either way)
+                const bool ownu = dtn != nullptr && eff != nullptr && eff[iu] == it;
                 const double* A0 = dzp(iu) + (size_t)(2 * NQ + cu_) * NQ; const double* nv = nuc + iu * NQ;
                 // ---- q2[i]: Q_i (q - q_ref) - nu_i + dq1_{i+1}^T nu_{i+1} + dq0_{i+2}^T nu_{i+2}
                 const bool on_q = j < H * NQ;
                 const int jq = on_q ? j : 0, i = jq / NQ, cq = jq - i * NQ;
                 const int i1 = min(i + 1, H - 1), i2 = min(i + 2, H - 1);          // (clamped: the loads stay valid, the terms are dropped below)
                 const double* Qm = S.Q + (size_t)i * NQ * NQ + cq; const double* qq = cqp + (i + 2) * NQ; const double* qr = rqp + (i + 2) * NQ;
+                const bool own1 = dtn != nullptr && eff != nullptr && eff[i1] == it, own2 = dtn != nullptr && eff != nullptr && eff[i2] == it;
                 const double* A1 = dzp(i1) + (size_t)(NQ + cq) * NQ; const double* n1 = nuc + i1 * NQ;
                 const double* A2 = dzp(i2) + (size_t)cq * NQ; const double* n2 = nuc + i2 * NQ;
-                double rv[NU], du_[NU], av[NQ], vv[NQ], qv[NQ], dq_[NQ], a1[NQ], v1[NQ], a2[NQ], v2[NQ];
+                double rv[NU], du_[NU], qv[NQ], dq_[NQ];
 #pragma unroll
                 for (int k = 0; k < NU; ++k) { rv[k] = Rm[k * NU]; du_[k] = uu[k] - ur[k]; }
 #pragma unroll
-                for (int k = 0; k < NQ; ++k) { av[k] = A0[k]; vv[k] = nv[k]; qv[k] = Qm[k * NQ]; dq_[k] = qq[k] - qr[k]; a1[k] = A1[k]; v1[k] = n1[k]; a2[k] = A2[k]; v2[k] = n2[k]; }
+                for (int k = 0; k < NQ; ++k) { qv[k] = Qm[k * NQ]; dq_[k] = qq[k] - qr[k]; }
                 const double nui = nuc[i * NQ + cq];
                 const double dv = dd[jq];                              // ---- rd[i] = d_i
-                double vu = 0.0, su = 0.0, vq = 0.0, s1 = 0.0, s2 = 0.0;
+                double su, s1, s2;
+                if (dtn != nullptr) {
+                    su = dtn[((size_t)sb * H + iu) * dld + 2 * NQ + cu_]; s1 = dtn[((size_t)sb * H + i1) * dld + NQ + cq]; s2 = dtn[((size_t)sb * H + i2) * dld + cq];
+                }
+                auto dot = [&](const double* A, const double* n_) { double a_ = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NQ; ++k) a_ = fma(A[k], n_[k], a_);
+                    return a_; };
+                if (!ownu) su = dot(A0, nv);           // (rare: a failed solve's fallback block, or no products at all)
+                if (!own1) s1 = dot(A1, n1);
+                if (!own2) s2 = dot(A2, n2);
+                double vu = 0.0, vq = 0.0;
 #pragma unroll
                 for (int k = 0; k < NU; ++k) vu = fma(rv[k], du_[k], vu);
-#pragma unroll
-                for (int k = 0; k < NQ; ++k) su = fma(av[k], vv[k], su);
                 vu += su;
 #pragma unroll
                 for (int k = 0; k < NQ; ++k) vq = fma(qv[k], dq_[k], vq);
-#pragma unroll
-                for (int k = 0; k < NQ; ++k) s1 = fma(a1[k], v1[k], s1);
-#pragma unroll
-                for (int k = 0; k < NQ; ++k) s2 = fma(a2[k], v2[k], s2);
                 vq -= nui;
                 if (i + 1 < H) vq += s1;
                 if (i + 2 < H) vq += s2;

@@ -34,6 +34,8 @@ struct NewtonDev {
     // implicit dynamics of the last sweep
     double* d;         // [B*CS][H][nd]
     double* dz;        // [B*CS][H][nths][nd]
+    double* dtn;       // [B*CS][H][dtn_ld] delta^T nu products of every solve, emitted by the sweep (IpParams::dtn); null: not produced
+    int dtn_ld;
     double* dz_good;   // [B][H][nths][nd]  sensitivities of the rollout's ACCEPTED evaluation (the reference's ip[t].dz
                        // after the last accepted implicit_dynamics!): Jacobian data of the KKT stage and the value a
                        // failed solve falls back to (see dz_eff in newton_impl.h)

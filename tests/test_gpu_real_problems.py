@@ -85,7 +85,9 @@ def test_newton_solve_on_real_problems(gpu_required, which, kappa, H, B, perturb
         dq = np.abs(traj["q"][b] - core.traj.q).max()
         du = np.abs(traj["u"][b] - core.traj.u).max() / max(1.0, np.abs(core.traj.u).max())
         assert dq < 1e-2 and du < 5e-2, (b, dq, du)
-        np.testing.assert_allclose(rn[b], st.r_norm / core.lay.N, rtol=5e-2, atol=1e-12)
+        # residual norm at exit (1.5e-4: mostly the d entries, which a flipped interior-point iteration moves by ~1e-6 each): 2 % where
+        # the trajectories agree to 1e-6, inside the amplification band elsewhere
+        np.testing.assert_allclose(rn[b], st.r_norm / core.lay.N, rtol=2e-2 if dq < 1e-6 else 0.15, atol=1e-12)
         if dq < 1e-6:
             tight += 1
             np.testing.assert_allclose(traj["nu"][b], core.nu, rtol=0, atol=1e-4 * max(1.0, np.abs(core.nu).max()))
