@@ -36,7 +36,7 @@ struct ProfRec {
 struct RoundStreams {
     hipStream_t st = nullptr;
     hipStream_t st_kkt = nullptr;
-    hipEvent_t ev_join = nullptr, ev_round = nullptr;   // ev_round: end of a round (rounds enqueued ahead of the host)
+    hipEvent_t ev_join = nullptr;   // end of the round's KKT kernel
 };
 
 // Schedule knobs.  Every environment override is read ONCE, in cimpc_create (a handle's configuration never
@@ -635,8 +635,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         RoundStreams& r = h->rs;
         if (hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&r.st_kkt, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&r.ev_join, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&r.ev_round, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&r.ev_join, hipEventDisableTiming) != hipSuccess) {
             g_create_error = "stream creation failed"; cimpc_destroy(h); return CIMPC_ERR_HIP;
         }
     }
@@ -658,7 +657,6 @@ int cimpc_destroy(cimpc_handle h) {
         if (r.st) { (void)hipStreamSynchronize(r.st); (void)hipStreamDestroy(r.st); }
         if (r.st_kkt) { (void)hipStreamSynchronize(r.st_kkt); (void)hipStreamDestroy(r.st_kkt); }
         if (r.ev_join) (void)hipEventDestroy(r.ev_join);
-        if (r.ev_round) (void)hipEventDestroy(r.ev_round);
     }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1181,9 +1179,9 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         }
         if (kkt && h->kkt_overlap) {
             // KKT of the rollouts that start a Newton iteration, next to the sweep on its own stream.  No fork
-            // event: the host has seen the previous round's stamp, so everything before is complete.  (Launched
-            // BEFORE the sweep: the other order was measured 10 % slower - the KKT recursion is the longer leg
-            // of most rounds.)
+            // event: the host has seen the previous round's stamp, so everything before is complete (every decision
+            // block releases its results before it takes its ticket).  (Launched BEFORE the sweep: the other order was
+            // measured 10 % slower - the KKT recursion is the longer leg of most rounds.)
             prof_begin(h, PC_KKT, sb.st_kkt);
             // the list was built by the decision kernel of the previous round (its queue parity)
             int rk = (h->use_dense || h->use_mixed) ? launch_kkt_general(h, Sk, sb.st_kkt)

@@ -156,6 +156,66 @@ __device__ __forceinline__ void apply_step(const NewtonDev& S, const TrajDev& ds
     Sync::sync();
 }
 
+// The same for `count` line-search candidates at once (evaluation slots sb_first .., step lengths 2^-(it_first + c)): one pass
+// over the accepted trajectory and the step writes every candidate, and theta is formed directly from the sources (no second pass
+// over the freshly written arrays, no barrier in between).  Same values as `count` calls of apply_step: every entry is
+// fma(-alpha, Delta, x), which is what `x - alpha * Delta` contracts to.  (Measured in the decision kernel: the four candidates of a
+// deep line search cost 4 x 4.5 us one after the other and set the length of the launch.)
+template <class Sync>
+__device__ __forceinline__ void apply_steps(const NewtonDev& S, size_t sb_first, int it_first, int count, int b, int tid, int nt) {
+    const cimpc_dims& m = S.dm;
+    const int H = m.H, nq = m.nq, nu = m.nu, nw = m.nw, nr = S.nr, nd = S.nd, nth = S.nth;
+    const bool cf = m.mode == CIMPC_MODE_CONFIGURATIONFORCE;
+    const int oq = cf ? nu + m.nc + m.nb : nu;
+    const double* __restrict__ D = S.delta + (size_t)b * S.N;
+    const double* __restrict__ tq = S.traj.q + (size_t)b * (H + 2) * nq;
+    const double* __restrict__ tu = S.traj.u + (size_t)b * H * nu;
+    const double* __restrict__ tw = S.traj.w + (size_t)b * H * nw;
+    const double* __restrict__ tth = S.traj.th + (size_t)b * H * nth;
+    const double* __restrict__ tnu = S.nu + (size_t)b * H * nd;
+    double* __restrict__ cq = S.cand.q + sb_first * (H + 2) * nq;
+    double* __restrict__ cu = S.cand.u + sb_first * H * nu;
+    double* __restrict__ cth = S.cand.th + sb_first * H * nth;
+    double* __restrict__ cnu = S.nu_cand + sb_first * H * nd;
+    auto put = [&](double* dst, size_t stride, int k, double base, double dl, bool moves) {
+        for (int c = 0; c < count; ++c) dst[(size_t)c * stride + k] = moves ? fma(-ls_alpha(it_first + c), dl, base) : base;
+    };
+    for (int k = tid; k < (H + 2) * nq; k += nt) {          // q_1, q_2 are fixed by (q0, q1); q_{t+2} moves
+        const int j = k / nq, c = k - j * nq;
+        put(cq, (size_t)(H + 2) * nq, k, tq[k], j >= 2 ? D[(j - 2) * nr + oq + c] : 0.0, j >= 2);
+    }
+    for (int k = tid; k < H * nu; k += nt) {
+        const int t = k / nu, c = k - t * nu;
+        put(cu, (size_t)H * nu, k, tu[k], D[t * nr + c], true);
+    }
+    if (cf) {
+        const double* __restrict__ tg = S.traj.g + (size_t)b * H * m.nc;
+        const double* __restrict__ tb = S.traj.b + (size_t)b * H * m.nb;
+        for (int k = tid; k < H * m.nc; k += nt) { const int t = k / m.nc, c = k - t * m.nc; put(S.cand.g + sb_first * H * m.nc, (size_t)H * m.nc, k, tg[k], D[t * nr + nu + c], true); }
+        for (int k = tid; k < H * m.nb; k += nt) { const int t = k / m.nb, c = k - t * m.nb; put(S.cand.b + sb_first * H * m.nb, (size_t)H * m.nb, k, tb[k], D[t * nr + nu + m.nc + c], true); }
+    }
+    for (int k = tid; k < H * nd; k += nt) put(cnu, (size_t)H * nd, k, tnu[k], D[H * nr + k], true);
+    for (int k = tid; k < H * nth; k += nt) {               // update_theta!: th_t = [q_t; q_{t+1}; u_t; w_t; mu; h]
+        const int t = k / nth, c = k - t * nth;
+        double base, dl = 0.0;
+        bool moves = false;
+        if (c < 2 * nq) {
+            const int j = t + (c >= nq ? 1 : 0), cc = c >= nq ? c - nq : c;
+            base = tq[j * nq + cc];
+            moves = j >= 2;
+            dl = moves ? D[(j - 2) * nr + oq + cc] : 0.0;
+        } else if (c < 2 * nq + nu) {
+            base = tu[t * nu + (c - 2 * nq)]; dl = D[t * nr + (c - 2 * nq)]; moves = true;
+        } else if (c < 2 * nq + nu + nw) {
+            base = tw[t * nw + (c - 2 * nq - nu)];
+        } else {
+            base = tth[k];
+        }
+        put(cth, (size_t)H * nth, k, base, dl, moves);
+    }
+    Sync::sync();
+}
+
 // Line-search start after the KKT solve (newton.jl:223-228): candidate(s) = traj - alpha*Delta.  One
 // candidate (alpha = 1), or all seven when the rollout's previous search went deep (see above).
 // mode 1: lock-step (queue `par`), mode 2: asynchronous solve (live queues).
@@ -174,7 +234,7 @@ __device__ __forceinline__ void start_line_search(const NewtonDev& S, int b, int
         n = (n >= 7) ? 7 : (n >= 3) ? 3 : 1;
     }
     Sync::sync();
-    for (int c = 0; c < n; ++c) apply_step<Sync>(S, S.cand, S.nu_cand, sb0 + c, b, ls_alpha(c), lane, nt);
+    apply_steps<Sync>(S, sb0, 0, n, b, lane, nt);
     if (lane == 0) { S.alpha[b] = 1.0; S.ls_iter[b] = 0; S.stage[b] = (n == 7) ? STAGE_LS7 : (n == 3) ? STAGE_LS3 : STAGE_LS0; }
     if (mode == 2) {
         enqueue_eval_async<Sync>(S, sb0, 0, n, b, lane, nt);
@@ -379,6 +439,30 @@ __device__ double slot_residual(const NewtonDev& S, size_t sb, int b, const int*
 // boundary is the hand-over (an in-kernel hand-over needs agent-scope release fences = L2 write-backs on this multi-XCD part:
 // measured 104 -> 210 us per launch).  The arithmetic per slot is unchanged (same thread -> entry map, same reduction tree), so
 // results are bit-identical to the one-workgroup form (SPLIT = 0: the asynchronous kernel's residual job).
+// -DCIMPC_RESID_PROF (diagnostic builds, scripts/resid_prof.py): clock accounting of the two launches of the decision stage,
+// 100 MHz ticks summed over workgroups.  g_resid_prof[k][0] = workgroups, [k][1..12] = phases, [k][13] = lifetime sum, [k][14] = max
+// lifetime; k = 0 slot kernel, 1 decision kernel.
+#ifdef CIMPC_RESID_PROF
+static __device__ unsigned long long g_resid_prof[2][16];
+struct ResidProf {
+    long long t0, t, acc[13]; int k;
+    __device__ ResidProf(int k_) : k(k_) { t0 = t = wall_clock64(); for (int j = 0; j < 13; ++j) acc[j] = 0; }
+    __device__ void mark(int j) { const long long n = wall_clock64(); acc[j] += n - t; t = n; }
+    __device__ ~ResidProf() {
+        if (threadIdx.x != 0) return;
+        const long long te = wall_clock64();
+        atomicAdd(&g_resid_prof[k][0], 1ull);
+        for (int j = 1; j < 13; ++j) if (acc[j]) atomicAdd(&g_resid_prof[k][j], (unsigned long long)acc[j]);
+        atomicAdd(&g_resid_prof[k][13], (unsigned long long)(te - t0));
+        atomicMax(&g_resid_prof[k][14], (unsigned long long)(te - t0));
+    }
+};
+#define RPROF_BEGIN(k) ResidProf rprof_(k);
+#define RPROF(j) rprof_.mark(j);
+#else
+#define RPROF_BEGIN(k)
+#define RPROF(j)
+#endif
 constexpr int SLOT_ABS_MAX = 6144;      // longest Newton vector whose |r_e| fit the slot kernel's LDS scratch (48 KB); longer ones: 256-thread pass
 template <int NQ, int NU, bool CF, bool ASYNC, int SPLIT = 0>
 __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, double* red, double* rc, int* sh) {
@@ -391,6 +475,7 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
         for (int k = tid; k < K; k += nt) { *qcount(S.WQ, par, k) = 0; *qhead(S.WQ, k) = 0; }
         if (tid < 8) S.counters_next[tid * CPAD] = 0;      // counter block of the next round
     }
+    RPROF_BEGIN(1)
     // (SPLIT = 2: the per-slot scalars of the rollout are requested together with its stage, one round trip for the entry checks)
     int pre_dc = H, pre_ns = 0;
     double pre_rc = 0.0;
@@ -459,6 +544,7 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
         if (tid < ncand) { rc[tid] = red[tid * CT]; S.r_cand[sb0 + it0 + tid] = red[tid * CT]; }
         __syncthreads();
     }
+    RPROF(1)
     // ---- decision (newton.jl:198-280) ------------------------------------------------------
     if (tid == 0) {
         int act = 2, slot = 0, iter = 0;   // act: 0 accept initial evaluation, 1 accept step, 2 more candidates
@@ -477,6 +563,7 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
         s_act = act; s_slot = slot; s_iter = iter;
     }
     __syncthreads();
+    RPROF(2)
     {   // statistics (parallel reduction).  Global counters: every evaluation that ran (speculative
         // ones included).  Per-rollout counters: only the evaluations the reference's sequential line
         // search would have performed (candidates up to and including the accepted one).
@@ -507,22 +594,23 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
         }
     }
     __syncthreads();
+    RPROF(3)
     const int act = s_act, slot = s_slot, iter = s_iter;
     if (act == 2) {                       // next batch of candidates: (1/2, 1/4) or (1/8 .. 1/64)
         const int nstage = (stage == STAGE_LS0) ? STAGE_LS1 : STAGE_LS2;
         const int it1 = (nstage == STAGE_LS1) ? 1 : 3, nn = (nstage == STAGE_LS1) ? 2 : 4;      // iterates (= slots) it1 .. it1+nn-1
         if constexpr (ASYNC) {
-            for (int c = 0; c < nn; ++c) apply_step<BlockSync>(S, S.cand, S.nu_cand, sb0 + it1 + c, b, ls_alpha(it1 + c), tid, nt);
+            apply_steps<BlockSync>(S, sb0 + it1, it1, nn, b, tid, nt);
             if (tid == 0) S.stage[b] = nstage;
             enqueue_eval_async<BlockSync>(S, sb0, it1, nn, b, tid, nt);
             return;
         }
         if (tid == 0) for (int c = 0; c < CS; ++c) S.need_sweep[sb0 + c] = 0;
         __syncthreads();
-        for (int c = 0; c < nn; ++c) {
-            apply_step<BlockSync>(S, S.cand, S.nu_cand, sb0 + it1 + c, b, ls_alpha(it1 + c), tid, nt);
-            enqueue_eval(S, sb0 + it1 + c, b, S.WQ.par ^ 1, tid, nt);      // evaluated in the next round
-        }
+        apply_steps<BlockSync>(S, sb0 + it1, it1, nn, b, tid, nt);
+        RPROF(4)
+        for (int c = 0; c < nn; ++c) enqueue_eval(S, sb0 + it1 + c, b, S.WQ.par ^ 1, tid, nt);      // evaluated in the next round
+        RPROF(5)
         if (tid == 0) {
             S.stage[b] = nstage;
             atomicAdd(&S.counters[0 * CPAD], 1);
@@ -533,16 +621,19 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
     if (act == 1) {                       // accept: traj <- traj - alpha*Delta (newton.jl:273)
         apply_step<BlockSync>(S, S.traj, S.nu, (size_t)b, b, alpha, tid, nt);
     }
+    RPROF(6)
     {   // res <- res_cand ; r_norm <- r_cand
         double* rr = S.res + (size_t)b * S.N;
         const double* r = S.res_cand + (sb0 + it0 + slot) * S.N;
         for (int e = tid; e < S.N; e += nt) rr[e] = r[e];
     }
+    RPROF(7)
     {   // im_traj of the accepted evaluation: the sensitivities in effect (a failed step keeps what dz_eff resolves;
         // steps that resolve to dz_good itself stay as they are).  Source slots come from the table: plain
         // independent loads, two doubles per lane.
         const int blk = S.nths * S.nd, ita = it0 + slot;
         double* good = S.dz_good + (size_t)b * H * blk;
+        {
         if constexpr (SPLIT == 2) {      // the table row of the ACCEPTED slot
             resolve_eff(slot, eff);
             __syncthreads();
@@ -550,11 +641,21 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
         if (use_eff && (blk & 1) == 0) {
             const int* ef = eff + (SPLIT ? 0 : slot * EFF_H);
             const int hb = blk / 2;
-            for (int e = tid; e < H * hb; e += nt) {
-                const int i = e / hb, s_ = ef[i];
-                if (s_ >= 0) {
-                    const double2* src = reinterpret_cast<const double2*>(S.dz + ((sb0 + s_) * H + i) * (size_t)blk);
-                    reinterpret_cast<double2*>(good + (size_t)i * blk)[e - i * hb] = src[e - i * hb];
+            // four independent 16-byte loads in flight per thread before the first store (source and destination are distinct
+            // buffers, which the compiler cannot see: it kept one load - store pair in flight, 10 us per accepted evaluation)
+            constexpr int UN = 4;
+            for (int e0 = tid; e0 < H * hb; e0 += UN * nt) {
+                double2 v[UN]; bool on[UN];
+#pragma unroll
+                for (int j = 0; j < UN; ++j) {
+                    const int e = e0 + j * nt, ec = e < H * hb ? e : 0, i = ec / hb, s_ = ef[i];
+                    on[j] = e < H * hb && s_ >= 0;
+                    v[j] = reinterpret_cast<const double2*>(S.dz + ((sb0 + (s_ >= 0 ? s_ : 0)) * H + i) * (size_t)blk)[ec - i * hb];
+                }
+#pragma unroll
+                for (int j = 0; j < UN; ++j) {
+                    const int e = e0 + j * nt;
+                    if (on[j]) { const int i = e / hb; reinterpret_cast<double2*>(good + (size_t)i * blk)[e - i * hb] = v[j]; }
                 }
             }
         } else {
@@ -563,7 +664,9 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
                 good[e] = dz_eff(S, b, ita, i)[e - i * blk];
             }
         }
+        }
     }
+    RPROF(8)
     if (tid == 0) {
         const double rn = rc[slot];
         if (act == 1 && S.nlog != nullptr && S.newton_l[b] < NLOG) {      // status line of this iteration (print_status, newton.jl:290-301)
@@ -616,7 +719,7 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
 #define CIMPC_RESID_THREADS 256
 #endif
 #ifndef CIMPC_SLOT_THREADS
-#define CIMPC_SLOT_THREADS 512
+#define CIMPC_SLOT_THREADS 256
 #endif
 // first launch of the stage: one workgroup per evaluated slot - its residual and 1-norm.  The slots come from the compact list the
 // requesters of the round built (NewtonDev::slot_list).  Every scalar the block needs is requested in ONE batch of loads before the
@@ -624,9 +727,11 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
 template <int NQ, int NU, bool CF>
 __global__ __launch_bounds__(CIMPC_SLOT_THREADS) void resid_slot_kernel(NewtonDev S, const int* list) {
     constexpr int CT = 256, EFF_H = 128;
-    __shared__ double red[CT + SLOT_ABS_MAX];
+    extern __shared__ __attribute__((aligned(16))) double red[];      // [CT + min(N, SLOT_ABS_MAX)]: a small footprint keeps every block of a
+                                                                      // round resident at once (808 blocks per round on average at B = 512)
     __shared__ int eff[EFF_H];
     const int tid = threadIdx.x, nt = blockDim.x, H = S.dm.H;
+    RPROF_BEGIN(0)
     int my, b;
     if (list != nullptr) {      // one block per requested slot
         const int e = list[blockIdx.x];
@@ -657,12 +762,14 @@ __global__ __launch_bounds__(CIMPC_SLOT_THREADS) void resid_slot_kernel(NewtonDe
     if (__syncthreads_or((tid == it0 && nsl == 0) || (mine && dc < H))) return;
     if (use_eff && tid < H) eff[tid] = eff_i;
     __syncthreads();
+    RPROF(1)
     // |r_e| goes to LDS and the 1-norm is summed exactly as the canonical 256-thread pass sums it: partial j = entries j, j + 256,
     // ... in order, then the pairwise tree - the norm does not depend on the number of threads that formed the entries
     if (S.N <= SLOT_ABS_MAX) {
         double* absr = red + CT;
         slot_residual<NQ, NU, CF>(S, sb, b, use_eff ? eff : nullptr, tid, nt, absr);
         __syncthreads();
+        RPROF(2)
         if (tid < CT) {
             double part = 0.0;
             for (int e = tid; e < S.N; e += CT) part += absr[e];
@@ -678,6 +785,7 @@ __global__ __launch_bounds__(CIMPC_SLOT_THREADS) void resid_slot_kernel(NewtonDe
         __syncthreads();
     }
     if (tid == 0) S.r_cand[sb] = red[0];
+    RPROF(3)
 }
 // second launch: one workgroup per rollout - decision, trajectory update, next requests
 template <int NQ, int NU, bool CF>
@@ -688,6 +796,9 @@ __global__ __launch_bounds__(CIMPC_RESID_THREADS) void resid_decide_kernel(Newto
     resid_decide_body<NQ, NU, CF, false, 2>(S, (int)blockIdx.x + S.b0, red, rc, sh);
     // ---- epilogue: the LAST block to finish publishes the round's counters to host-mapped pinned
     //      memory (the host polls the stamp; no memcpy / event on the critical path)
+    // (The release fence per block lets the host start the next round's KKT kernel on the second stream as soon as it sees the
+    //  stamp.  Measured alternative: no fence, KKT stream ordered behind the END of this kernel by an event - this launch 53 -> 42 us,
+    //  but the KKT kernel then starts later: 9.72 -> 9.82 ms per batch step.)
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();

@@ -242,6 +242,13 @@ int launch_kkt_mixed(const NewtonDev& S, const KktArgs& K0, double* ws, int* n_f
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
 
+#ifdef CIMPC_RESID_PROF
+extern "C" int cimpc_debug_resid_prof(unsigned long long* out32) {      // diagnostic builds: read and clear the decision-stage clocks
+    unsigned long long z[32] = {0};
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(cimpc::g_resid_prof), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(cimpc::g_resid_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 __global__ __launch_bounds__(64) void enqueue_all_kernel(NewtonDev S) {
     const int b = blockIdx.x + S.b0;
     enqueue_eval(S, (size_t)b * CS, b, S.WQ.par, threadIdx.x, 64, b - S.b0);
@@ -413,11 +420,12 @@ template <int NQ, int NU>
 static int launch_resid_t(const NewtonDev& S, hipStream_t s, int n_slots) {
     const int* list = (n_slots >= 0 && S.slot_list != nullptr) ? S.slot_list + (size_t)S.WQ.par * S.dm.B * CS : nullptr;
     const int grid = list != nullptr ? n_slots : S.nb_launch * CS;
+    const size_t lds = (size_t)(256 + (S.N <= SLOT_ABS_MAX ? S.N : 0)) * sizeof(double);
     if (S.dm.mode == CIMPC_MODE_CONFIGURATIONFORCE) {
-        if (grid > 0) hipLaunchKernelGGL((resid_slot_kernel<NQ, NU, true>), dim3(grid), dim3(CIMPC_SLOT_THREADS), 0, s, S, list);
+        if (grid > 0) hipLaunchKernelGGL((resid_slot_kernel<NQ, NU, true>), dim3(grid), dim3(CIMPC_SLOT_THREADS), lds, s, S, list);
         hipLaunchKernelGGL((resid_decide_kernel<NQ, NU, true>), dim3(S.nb_launch), dim3(CIMPC_RESID_THREADS), 0, s, S);
     } else {
-        if (grid > 0) hipLaunchKernelGGL((resid_slot_kernel<NQ, NU, false>), dim3(grid), dim3(CIMPC_SLOT_THREADS), 0, s, S, list);
+        if (grid > 0) hipLaunchKernelGGL((resid_slot_kernel<NQ, NU, false>), dim3(grid), dim3(CIMPC_SLOT_THREADS), lds, s, S, list);
         hipLaunchKernelGGL((resid_decide_kernel<NQ, NU, false>), dim3(S.nb_launch), dim3(CIMPC_RESID_THREADS), 0, s, S);
     }
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
