@@ -787,13 +787,15 @@ __global__ __launch_bounds__(CIMPC_SLOT_THREADS) void resid_slot_kernel(NewtonDe
     if (tid == 0) S.r_cand[sb] = red[0];
     RPROF(3)
 }
-// second launch: one workgroup per rollout - decision, trajectory update, next requests
-template <int NQ, int NU, bool CF>
+// second launch: one workgroup per rollout - decision, trajectory update, next requests.
+// SINGLE = true: the whole stage in this one launch (residuals of the rollout's slots, then the decision - resid_decide_body with
+// SPLIT = 0): small batches, where a second launch costs more than the serialised residual passes of a rollout (B = 1: one slot).
+template <int NQ, int NU, bool CF, bool SINGLE = false>
 __global__ __launch_bounds__(CIMPC_RESID_THREADS) void resid_decide_kernel(NewtonDev S) {
-    __shared__ double red[2 * CIMPC_RESID_THREADS];
+    extern __shared__ __attribute__((aligned(16))) double red[];      // SINGLE: [CS * 256 + N], else [2 * threads]
     __shared__ double rc[CS];
     __shared__ int sh[4];
-    resid_decide_body<NQ, NU, CF, false, 2>(S, (int)blockIdx.x + S.b0, red, rc, sh);
+    resid_decide_body<NQ, NU, CF, false, SINGLE ? 0 : 2>(S, (int)blockIdx.x + S.b0, red, rc, sh);
     // ---- epilogue: the LAST block to finish publishes the round's counters to host-mapped pinned
     //      memory (the host polls the stamp; no memcpy / event on the critical path)
     // (The release fence per block lets the host start the next round's KKT kernel on the second stream as soon as it sees the

@@ -416,19 +416,26 @@ int launch_reset(const NewtonDev& S, const double* q0, const double* q1, int war
     hipLaunchKernelGGL(reset_kernel, dim3(S.nb_launch), dim3(256), 0, s, S, q0, q1, warm);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
-template <int NQ, int NU>
-static int launch_resid_t(const NewtonDev& S, hipStream_t s, int n_slots) {
+template <int NQ, int NU, bool CF>
+static int launch_resid_m(const NewtonDev& S, hipStream_t s, int n_slots) {
+    const size_t lds2 = (size_t)2 * CIMPC_RESID_THREADS * sizeof(double);
+    if (n_slots < 0) {      // small batches: one launch, the rollout's slots one after the other in its workgroup
+        const size_t lds1 = (size_t)(CS * 256 + S.N) * sizeof(double);
+        if (lds1 <= 64 * 1024) {
+            hipLaunchKernelGGL((resid_decide_kernel<NQ, NU, CF, true>), dim3(S.nb_launch), dim3(CIMPC_RESID_THREADS), lds1, s, S);
+            return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+        }
+    }
     const int* list = (n_slots >= 0 && S.slot_list != nullptr) ? S.slot_list + (size_t)S.WQ.par * S.dm.B * CS : nullptr;
     const int grid = list != nullptr ? n_slots : S.nb_launch * CS;
     const size_t lds = (size_t)(256 + (S.N <= SLOT_ABS_MAX ? S.N : 0)) * sizeof(double);
-    if (S.dm.mode == CIMPC_MODE_CONFIGURATIONFORCE) {
-        if (grid > 0) hipLaunchKernelGGL((resid_slot_kernel<NQ, NU, true>), dim3(grid), dim3(CIMPC_SLOT_THREADS), lds, s, S, list);
-        hipLaunchKernelGGL((resid_decide_kernel<NQ, NU, true>), dim3(S.nb_launch), dim3(CIMPC_RESID_THREADS), 0, s, S);
-    } else {
-        if (grid > 0) hipLaunchKernelGGL((resid_slot_kernel<NQ, NU, false>), dim3(grid), dim3(CIMPC_SLOT_THREADS), lds, s, S, list);
-        hipLaunchKernelGGL((resid_decide_kernel<NQ, NU, false>), dim3(S.nb_launch), dim3(CIMPC_RESID_THREADS), 0, s, S);
-    }
+    if (grid > 0) hipLaunchKernelGGL((resid_slot_kernel<NQ, NU, CF>), dim3(grid), dim3(CIMPC_SLOT_THREADS), lds, s, S, list);
+    hipLaunchKernelGGL((resid_decide_kernel<NQ, NU, CF, false>), dim3(S.nb_launch), dim3(CIMPC_RESID_THREADS), lds2, s, S);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+}
+template <int NQ, int NU>
+static int launch_resid_t(const NewtonDev& S, hipStream_t s, int n_slots) {
+    return S.dm.mode == CIMPC_MODE_CONFIGURATIONFORCE ? launch_resid_m<NQ, NU, true>(S, s, n_slots) : launch_resid_m<NQ, NU, false>(S, s, n_slots);
 }
 __global__ void queue_recycle_kernel(IpQueues Q, int par) {
     const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
