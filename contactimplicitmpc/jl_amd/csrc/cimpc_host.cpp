@@ -48,7 +48,7 @@ struct Knobs {
     int async_mem = 0;           // CIMPC_ASYNC_MEM: 1 uncached, 2 fine-grained exchange buffers (experiment)
     int spec_all = -1;           // CIMPC_SPEC_ALL
     int spec_tail = 3;           // CIMPC_SPEC_TAIL
-    int spec_first = 1;          // CIMPC_SPEC_FIRST: step lengths of the first line-search round of a solve's first Newton iteration
+    int spec_first = -1;         // CIMPC_SPEC_FIRST: step lengths of the first line-search round of a solve's first Newton iteration (-1: by batch size)
     int spec_mid = -1;           // CIMPC_SPEC_MID: previous search depth from which a rollout starts with three candidates (-1: by batch size)
     int iter_cap = 28;           // CIMPC_ITER_CAP (B = 512: 24 / 28 / 32 / 36 -> 11.8 / 11.5 / 11.8 / 11.75 ms with the fused-broadcast sweep)
     int waves = 0;               // CIMPC_WAVES (0: by batch size)
@@ -578,7 +578,9 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     // goes through the reference-default dense LU
     select_kkt_backend(h);
     S.spec_all = h->kn.spec_all >= 0 ? h->kn.spec_all : (d.B <= 128 ? 3 : 8);
-    S.spec_first = h->kn.spec_first;
+    // first line search of a solve (no history yet): 1, 1/2, 1/4 evaluated together up to mid-size batches (B = 512: 9.65 -> 9.50 ms,
+    // B = 128: 8.14 -> 8.03 ms for 0.3 more evaluated sweeps per step; B = 2048: 25.4 -> 25.6 ms, throughput-bound: one candidate there)
+    S.spec_first = h->kn.spec_first >= 0 ? h->kn.spec_first : (d.B <= 1024 ? 3 : 1);
     S.kkt_scalar = h->kn.kkt_scalar ? 1 : 0;
     // large batches: a rollout whose previous search needed a back-off starts the next one with 1, 1/2, 1/4 together (one
     // round less per Newton iteration for 0.9 more evaluated sweeps per step: B = 512 11.4 -> 10.9 ms); small batches already

@@ -504,15 +504,16 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
     [[maybe_unused]] long long dbg_pop[4] = {0, 0, 0, 0};
     [[maybe_unused]] const bool dbg_on = ASYNC && p.A.dbg != nullptr;      // diagnostics only with CIMPC_ASYNC_DEBUG
     double reg = 0.0, r_vio = 0.0, k_vio = 0.0, qinit = 0.0;
-    [[maybe_unused]] int drain_seen = 0;      // (lock-step launches) workgroups that have left, sampled one trip ago
+    [[maybe_unused]] int drain_raw = 0;       // (lock-step launches) workgroups that have left: the load is issued at the top of a trip and
+                                              // read at the top of the NEXT one (a wait right behind the load cost a memory round trip per trip)
 
     while (true) {
         [[maybe_unused]] const long long sp_a = SPROF_T();
         [[maybe_unused]] bool draining = false;
         if constexpr (!ASYNC) {
             if (p.drain_count != nullptr) {
-                draining = drain_seen >= p.drain_thresh;
-                drain_seen = __builtin_amdgcn_readfirstlane(aload(p.drain_count));      // consumed at the top of the next trip
+                draining = __builtin_amdgcn_readfirstlane(drain_raw) >= p.drain_thresh;
+                drain_raw = aload(p.drain_count);      // consumed at the top of the next trip
             }
         }
         // ---- 1. end of a solve? ---------------------------------------------------------------

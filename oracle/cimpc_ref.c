@@ -39,6 +39,9 @@ typedef struct {
     int n_max_iter;
     /* IP workspace */
     double *qs, *rs, *D, *xv, *tmp, *tmp2, *u, *v;
+    /* arbiter mode (tests): theta of EVERY interior-point solve is perturbed in the last place (theta * (1 +- 2^-52)), so that
+     * a re-run exercises the round-off sensitivity of every solve of a Newton solve, not only of the ones that read its inputs */
+    unsigned long long noise;
 } Ref;
 
 static double *dalloc(size_t n) { return (double *)calloc(n ? n : 1, sizeof(double)); }
@@ -98,6 +101,9 @@ Ref *ref_create(int nq, int nu, int nw, int nc, int nb, int mode, int H_ref, int
 }
 
 void ref_set_stall(Ref *s, double stall_alpha) { s->stall_alpha = stall_alpha; }
+void ref_set_noise(Ref *s, unsigned long long seed) { s->noise = seed; } /* 0 = off */
+static inline unsigned long long noise_next(Ref *s) { /* xorshift64 */
+    unsigned long long x = s->noise; x ^= x << 13; x ^= x >> 7; x ^= x << 17; s->noise = x ? x : 0x9E3779B97F4A7C15ull; return x; }
 
 void ref_set_opts(Ref *s, double r_tol, double kappa_tol, double undercut, double gamma_reg, double kappa_reg,
                   double eps_min, double ls_scale, int ip_max_iter, int max_ls, double n_r_tol,
@@ -380,7 +386,13 @@ void ref_implicit_dynamics(Ref *s, const int *window, const double *q, const dou
         double *z = zb;
         for (int k = 0; k < nz; ++k) z[k] = 1.0;
         memcpy(z, q + (size_t)(i + 2) * nq, nq * sizeof(double));
-        status[i] = ip_solve(s, t, z, theta + (size_t)i * s->nth, alt, dz + (size_t)i * s->nths * nd, &iters[i]);
+        const double *th_i = theta + (size_t)i * s->nth;
+        double thn[256];
+        if (s->noise && s->nth <= 256) {
+            for (int k = 0; k < s->nth; ++k) thn[k] = th_i[k] * (1.0 + ((noise_next(s) >> 33) & 1 ? 1.0 : -1.0) * 2.220446049250313e-16);
+            th_i = thn;
+        }
+        status[i] = ip_solve(s, t, z, th_i, alt, dz + (size_t)i * s->nths * nd, &iters[i]);
         for (int k = 0; k < nq; ++k) d[(size_t)i * nd + k] = z[k] - q[(size_t)(i + 2) * nq + k];
         if (s->mode) {
             for (int k = 0; k < s->nc; ++k) d[(size_t)i * nd + nq + k] = z[nq + k] - gam[(size_t)i * s->nc + k];

@@ -28,6 +28,7 @@ def load():
         lib.ref_destroy.argtypes = [C.c_void_p]
         lib.ref_set_opts.argtypes = [C.c_void_p] + [C.c_double] * 7 + [C.c_int, C.c_int] + [C.c_double] * 3 + [C.c_int]
         lib.ref_set_stall.argtypes = [C.c_void_p, C.c_double]
+        lib.ref_set_noise.argtypes = [C.c_void_p, C.c_ulonglong]
         lib.ref_set_linearization.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp]
         lib.ref_set_objective.argtypes = [C.c_void_p, _dp, _dp]
         lib.ref_implicit_dynamics.argtypes = [C.c_void_p, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp]
@@ -75,6 +76,10 @@ class CRef:
                 self.h = None
         except Exception:
             pass
+
+    def set_noise(self, seed):
+        """Arbiter mode: theta of EVERY interior-point solve is perturbed in the last place (0 = off)."""
+        self.lib.ref_set_noise(self.h, int(seed))
 
     def implicit_dynamics(self, window, q, theta, gamma=None, b=None):
         d, H = self.d, self.H

@@ -62,7 +62,8 @@ def _device(I, H, backend, ip_r_tol, newton_r_tol):
 
 
 def _oracle(I, H, ip_r_tol, newton_r_tol, draws):
-    """oracle/cimpc_ref.c on every rollout (condensed KKT) + `draws` re-runs with (q0, q1, theta_ref) perturbed in the last place."""
+    """oracle/cimpc_ref.c on every rollout (condensed KKT) + `draws` re-runs with (q0, q1) and the theta of EVERY interior-point
+    solve of the run perturbed in the last place."""
     from contactimplicitmpc.jl_amd.trajectory import Objective
     m, P, kappa, ro = I["m"], I["P"], I["kappa"], I["rollouts"]
     d = Dims(nq=m.nq, nu=m.nu, nw=m.nw, nc=m.nc, nb=m.nb, mode=0)
@@ -85,7 +86,10 @@ def _oracle(I, H, ip_r_tol, newton_r_tol, draws):
             # place at every knot of the first sweep, not only at the two steps that read q0 / q1)
             rp = Traj(q=refs[b].q, u=refs[b].u, w=refs[b].w, gamma=refs[b].gamma, b=refs[b].b,
                       theta=refs[b].theta * (1.0 + (rng.integers(0, 2, refs[b].theta.shape) * 2 - 1) * 2.0 ** -52))
+            # ... and theta of every LATER evaluation too (the candidates of the line searches): oracle arbiter mode
+            cr.set_noise(int(rng.integers(1, 2 ** 62)))
             o = cr.newton_solve(r["window"], rp, p0, p1, solver=1)
+            cr.set_noise(0)
             f = (o["iters"] != base[b]["iters"]) or (o["sweeps"] != base[b]["sweeps"]) or (o["ip_iters"] != base[b]["ip_iters"])
             flip[b] |= f; n_flip += int(f)
             du = np.abs(o["u"][0] - base[b]["u"][0]).max()
@@ -186,19 +190,19 @@ def test_real_gait2_full_size_newton_solve_vs_oracle(gpu_required):
     off = ~same_path
     assert off.mean() <= 1.5 * float(np.mean(per_draw)) + 0.02, rec          # no more path changes than the oracle's own last-place rate
     assert (off & ~flip).sum() <= 0.05 * B, rec                               # ... and on the rollouts where the oracle is sensitive
-    # Input noise is not the only round-off: the first Newton iteration solves the KKT system with beta_init = 1e-5 (rho ~ 1e-7,
-    # cond(Y) > 1e8), so two correct KKT solvers differ by ~1e-8 relative in the step - far more than a last-place input change.
-    # Second arbiter for rollouts the input draws left alone: the ORACLE with its other KKT backend (dense LU, the reference default,
-    # instead of the condensed recursion).  A device difference there must be matched by the oracle's own LU-vs-condensed move.
+    # `stable`: rollouts the oracle holds to 1e-9 through four draws of last-place noise on (q0, q1) AND on theta of every one of its
+    # ~230 interior-point solves (oracle arbiter mode).  The device must agree tightly there; what it may still do is hit, once in a
+    # while, the sensitive direction of an ill-conditioned solve that four draws did not hit - bounded by the oracle's own worst
+    # same-path motion under that noise.  (Recorded beside it: the oracle with its other KKT backend on those rollouts.)
     outl = np.flatnonzero(stable & (du > 1e-7 * scale))
     rec["stable_rollouts_with_u1_diff_above_1e-7"] = int(outl.size)
     lu_move = ORACLE_EXTRA["rerun_dense_lu"](outl) if outl.size else np.zeros(0)
     rec["outliers"] = [{"rollout": int(b_), "u1_diff_device_vs_oracle": float(du[b_]), "oracle_u1_move_dense_lu_vs_condensed_kkt": float(m_)}
                        for b_, m_ in zip(outl, lu_move)]
+    rec["oracle_worst_same_path_u1_move"] = float(move_same.max())
     _record("real_gait2_h40_512", rec)
-    assert stable.sum() >= 0.25 * B and np.quantile(du[stable], 0.95) <= 1e-7 * scale and outl.size <= 0.05 * stable.sum(), rec
-    for b_, m_ in zip(outl, lu_move):      # explained by the oracle's own sensitivity to the KKT solver's round-off
-        assert du[b_] <= 50 * m_ + 1e-7 * scale, rec["outliers"]
+    assert stable.sum() >= 0.25 * B and np.quantile(du[stable], 0.95) <= 1e-7 * scale and outl.size <= 0.03 * stable.sum(), rec
+    assert outl.size == 0 or du[outl].max() <= 10 * move_same.max() + 1e-7 * scale, rec
     assert np.median(du[same_path]) <= 1e-9 * scale and np.median(dq[same_path]) <= 1e-9, rec
     # on-path rollouts that contain an ill-conditioned solve: no further off than 50 x the oracle's own scatter, in distribution
     assert np.quantile(du[same_path], 0.9) <= 50 * np.quantile(move_same[~flip], 0.9) + 1e-7 * scale, rec
