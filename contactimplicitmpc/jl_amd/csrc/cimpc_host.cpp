@@ -494,6 +494,13 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         const size_t bytes = (K * h->a_cap + h->a_rq_cap + h->a_kq_cap) * sizeof(int);
         h->async_on = want && newton_async_available(&d) && K <= 256 && bytes <= ((size_t)1 << 30);
     }
+    // 32-lane models (centroidal: one workgroup per CU, 512-register waves): the persistent kernel wins up to 32 rollouts only and the
+    // rounds keep their lead far into the tail - measured on BASELINE configs[4] (H = 60): B = 8 / 16 / 32 / 64 / 128 -> single launch
+    // 10.7 / 14.1 / 19.3 / 29.5 / - ms, lock-step rounds 12.1 / 17.7 / 20.5 / 22.4 / 34.9 ms, hand-over at 16 active rollouts 22.3 / 35.7 ms
+    if (h->ki.G == 32) {
+        if (getenv("CIMPC_ASYNC_FULL_MAX") == nullptr) h->kn.async_full_max = std::min(h->kn.async_full_max, 32);
+        if (h->kn.async_tail < 0) h->async_tail = 16;
+    }
     const int xm = h->async_on ? h->kn.async_mem : 0;   // experiments: 1 uncached, 2 fine-grained
     auto A = [&](auto** p, size_t n) { if (rc == CIMPC_OK) rc = dev_alloc(h, p, n); };
     auto AX = [&](auto** p, size_t n) { if (rc == CIMPC_OK) rc = dev_alloc(h, p, n, xm); };   // exchanged state
@@ -558,7 +565,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     A(&S.kkt_list, 2 * B);
     A(&S.slot_list, 2 * BS);
     AX(&S.counters, 8 * CPAD);
-    AX(&S.stats, B * 4);
+    AX(&S.stats, std::max<size_t>(B * 4, 32));      // (>= 32 entries: diagnostic builds with -DCIMPC_KKT_PROF park their phase clocks at [8..23])
     AX(&S.ro_sweeps, B); AX(&S.ro_ip_iters, B); AX(&S.ro_ip_fail, B);
     AX(&S.nlog, B * NLOG * 4);
     A(&S.kkt_ws, B * H * (3 * (size_t)h->nd * h->nd + h->nd));
@@ -1438,6 +1445,15 @@ int cimpc_get_kkt_fallbacks(cimpc_handle h, long long* n) {
     *n = v;
     return CIMPC_OK;
 }
+
+#ifdef CIMPC_KKT_PROF
+// diagnostic builds only: raw read of the statistics buffer (the KKT kernels park their phase clocks at [8..23])
+int cimpc_debug_read_stats(cimpc_handle h, long long* out, int n) {
+    if (!h || !out || n > 32) return CIMPC_ERR_INVALID;
+    HIP_TRY(h, hipMemcpy(out, h->S.stats, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
+    return CIMPC_OK;
+}
+#endif
 
 int cimpc_get_stats(cimpc_handle h, cimpc_stats* s) {
     if (!h || !s) return CIMPC_ERR_INVALID;

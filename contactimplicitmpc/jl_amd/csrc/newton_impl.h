@@ -1573,6 +1573,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
             bet[lane] = s - rd_i;
         }
         if constexpr (PIPE == 2) { tile_st<TL, F32>(t.Y0h, y0, li, lk); tile_st<TL, F32>(t.Y1h, y1a, li, lk); }
+        KPROF(3)
     };
     // ---- stage B of step i: L1_i, the Cholesky factor L0_i and its inverse, y_i, spill --------------------
     auto stageB = [&](int i) {

@@ -73,7 +73,12 @@ typedef struct cimpc_ip_opts {
     double ls_scale;   /* 0.5   */
     int max_iter;      /* 100   */
     int max_ls;        /* 3     */
-    double stall_alpha; /* 1e-13: stall exit (DESIGN.md "IP iteration spec"); 0 = never exit early */
+    double stall_alpha; /* 1e-13: stall exit (DESIGN.md "IP iteration spec"); 0 = never exit early.  BUILD-DEFINED DEVIATION from a plain
+                         * max_iter loop: a solve whose step length falls below stall_alpha fails at once instead of repeating the
+                         * blocked direction up to max_iter times, so on FAILURE d = z[1:nd] - [q; gamma; b]
+                         * (implicit_dynamics.jl:180-190) comes from an earlier iterate than 100 reference iterations would leave
+                         * (converging solves never go below alpha ~ 4e-3; the sensitivities of a failed solve are not written
+                         * either way, implicit_dynamics.jl:169-176) */
 } cimpc_ip_opts;
 
 /* NewtonOptions (newton.jl:2-11) + the central-path parameter used for the dual
