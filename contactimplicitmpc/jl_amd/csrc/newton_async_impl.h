@@ -57,13 +57,16 @@ __device__ __noinline__ void async_kkt_job(unsigned long long ka, int b, double*
     // KKT solve heads a rollout's dependency chain here), the other waves only keep the workgroup barriers of
     // the pipeline company (one after the LDS clear, one per tick, one before the backward pass)
     const NewtonDev S = uniform_state(ka);
-    if ((int)blockDim.x >= 128) {
-        if (tid < 128) {
+    if ((int)blockDim.x >= 192) {         // three-stage pipeline on waves 0..2; the fourth wave keeps the barriers company
+        if (tid < 192) {
             const KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 2};
-            kkt_body<NQ, NU, WaveSync, 2>(S, K, b, smem, tid & 63, tid >> 6);
+            kkt_body<NQ, NU, WaveSync, 3>(S, K, b, smem, tid & 63, tid >> 6);
         } else {
-            for (int k = 0; k < S.dm.H + 3; ++k) __syncthreads();
+            for (int k = 0; k < S.dm.H + 4; ++k) __syncthreads();      // 1 (LDS clear) + H + 2 ticks + 1 (before the backward pass)
         }
+    } else if ((int)blockDim.x >= 128) {
+        const KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 2};
+        kkt_body<NQ, NU, WaveSync, 2>(S, K, b, smem, tid & 63, tid >> 6);
     } else if (tid < 64) {
         const KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 2};
         kkt_body<NQ, NU, WaveSync>(S, K, b, smem, tid);
@@ -181,7 +184,7 @@ int launch_async_model(const IpParams& p, const NewtonDev& S, int waves, int gri
     if (waves != 1 && waves != 2 && waves != 4) return CIMPC_ERR_INVALID;
     const int ppw = 64 / M::G;
     const size_t lds_ip = (size_t)(L.size + waves * ppw * M::LDS_GROUP) * sizeof(double);
-    const size_t lds_kkt = (size_t)(waves >= 2 ? kkt_lds_doubles<M::NQ, M::NU, 2>() : kkt_lds_doubles<M::NQ, M::NU, 1>()) * sizeof(double);
+    const size_t lds_kkt = (size_t)(waves >= 3 ? kkt_lds_doubles<M::NQ, M::NU, 3>() : waves >= 2 ? kkt_lds_doubles<M::NQ, M::NU, 2>() : kkt_lds_doubles<M::NQ, M::NU, 1>()) * sizeof(double);
     const size_t lds_res = (size_t)(CS * 256 + S.N) * sizeof(double);       // residual job: partial sums of every slot + |r_e| scratch
     const size_t lds = std::max(std::max(lds_ip, lds_kkt), lds_res);
     static LdsOptIn optin;

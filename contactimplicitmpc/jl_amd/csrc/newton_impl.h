@@ -1377,6 +1377,10 @@ struct KktBcast {
 // stages hand Y_ii, Y_i,i-1, L2_i, beta_i over in LDS tiles double-buffered by step parity.  A step then costs
 // max(A, B) instead of A + B; the backward pass and the recovery stay on wave 0.
 constexpr int KKT_PIPE_TILES = 27;       // 22 + second L2 tile + two Y_ii and two Y_i,i-1 hand-over tiles
+// PIPE = 3 (round 3): a third wavefront takes everything that is NOT on the recursion's dependency chain off the other two - stage
+// C of step t-2 (the products W1 = L1 L0^-1, W2 = L2 L0^-1 and yhat = L0^-T y the backward pass runs on, and their spill) next to
+// stage B of step t-1 (the chain: L1, the Cholesky factor, its inverse, y) and stage A of step t.
+constexpr int KKT_PIPE3_TILES = 29;      // 27 + third L2 slot + fourth slot of the L0^-T ring
 // tile leading dimension for a model: 16 (one MFMA block per tile) or 24 (2 x 2 blocks, masked)
 template <int NQ, int NU>
 constexpr int kkt_tld() { return (NQ <= 16 && NU <= 16) ? 16 : 24; }
@@ -1384,7 +1388,7 @@ constexpr int kkt_tld() { return (NQ <= 16 && NU <= 16) ? 16 : 24; }
 template <int NQ, int NU, int PIPE>
 constexpr int kkt_lds_doubles() {
     constexpr int T = kkt_tld<NQ, NU>();
-    return (PIPE == 2 ? KKT_PIPE_TILES : KKT_MFMA_TILES) * T * T + 13 * (T <= 16 ? 16 : 32);
+    return (PIPE == 3 ? KKT_PIPE3_TILES : PIPE == 2 ? KKT_PIPE_TILES : KKT_MFMA_TILES) * T * T + 13 * (T <= 16 ? 16 : 32);
 }
 // longest horizon the backward pass can stage: all dnu in tiles 16..21, the recovery's first level in tiles 7..15
 template <int NQ, int NU>
@@ -1404,7 +1408,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     constexpr int NB = (TL + 15) / 16;
     constexpr int VS = TL <= 16 ? 16 : 32;           // stride of the small vectors behind the tiles
     using Acc = TAcc<NB, F32>;
-    constexpr int NTILES = PIPE == 2 ? KKT_PIPE_TILES : KKT_MFMA_TILES;
+    constexpr int NTILES = PIPE == 3 ? KKT_PIPE3_TILES : PIPE == 2 ? KKT_PIPE_TILES : KKT_MFMA_TILES;
     // The body runs on ONE wavefront; its phases hand data over through LDS only.  The hand-off needs the
     // wave's LDS operations complete (lgkmcnt(0)) - NOT its global ones: a full barrier (vmcnt(0)) would
     // expose the latency of the prefetch loads and of the factor spill stores at every phase boundary.
@@ -1433,7 +1437,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     double* rpu = vec + 5 * VS;
     // vec + (6,7,8) VS: r_p(q) ring; vec + 9 VS: second beta (PIPE = 2); vec + 12 VS: scratch word
     for (int k = lane + 64 * wave; k < NTILES * TSZ + 13 * VS; k += 64 * PIPE) sm[k] = 0.0;
-    if constexpr (PIPE == 2) __syncthreads();
+    if constexpr (PIPE >= 2) __syncthreads();
     const double* rb = K.r + (size_t)b * S.N;
     const double beta = K.beta ? K.beta[b] : K.beta_scalar;
     const double rho = (double)H * beta * S.kappa;         // newton_jacobian.jl:169-186 quirk
@@ -1495,16 +1499,6 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         const int vb = NTILES * TSZ;
         sm[lane < nu ? vb + 5 * VS + lane : lane < nr ? vb + (6 + m0) * VS + (lane - nu) : TRASH] = pf_rp;
     };
-    // spill of a step's factors (n2 = nd^2 entries each): element k = lane + 64 j, clamped (surplus lanes
-    // repeat the last element: same value, same address)
-    constexpr int SP = (n2 + 63) / 64;
-    int sp_k[SP], sp_off[SP];
-#pragma unroll
-    for (int j = 0; j < SP; ++j) {
-        const int k = min(lane + 64 * j, n2 - 1);
-        sp_k[j] = k; sp_off[j] = (k % nd) + (k / nd) * TL;
-    }
-
 #ifdef CIMPC_KKT_PROF
     long long pt[16] = {0}; long long tp = clock64();
 #define KPROF(j) { const long long tn = clock64(); pt[j] += tn - tp; tp = tn; }
@@ -1512,7 +1506,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
 #define KPROF(j)
 #endif
     // ring / parity slots of step i
-    struct Slots { double *Li, *Li1, *Li2, *L1c, *L1p, *A1, *A1p, *Qi0, *Qi1, *Qi2, *yc, *y1, *y2, *q0r, *q1r, *q2r, *L2c, *Y0h, *Y1h, *bet; int p0, m0; };
+    struct Slots { double *Li, *Li1, *Li2, *L1c, *L1p, *A1, *A1p, *Qi0, *Qi1, *Qi2, *yc, *y1, *y2, *q0r, *q1r, *q2r, *L2c, *Y0h, *Y1h, *bet, *LiT, *LiT1, *LiT2; int p0, m0; };
     auto slots = [&](int i) {
         const int m0 = i % 3, m1 = (i + 2) % 3, m2 = (i + 1) % 3, p0 = i & 1, p1 = (i + 1) & 1;
         Slots t;
@@ -1523,10 +1517,15 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         t.yc = vec + (2 + m0) * VS; t.y1 = vec + (2 + m1) * VS; t.y2 = vec + (2 + m2) * VS;
         t.q0r = vec + (6 + m0) * VS; t.q1r = vec + (6 + m1) * VS; t.q2r = vec + (6 + m2) * VS;
         // hand-over buffers of the pipelined variant (by step parity); the one-wave variant keeps one set
-        t.L2c = (PIPE == 2 && p0) ? tile(22) : L2c;
-        t.Y0h = tile(23 + (PIPE == 2 ? p0 : 0));
-        t.Y1h = tile(25 + (PIPE == 2 ? p0 : 0));
-        t.bet = (PIPE == 2 && p0) ? vec + 9 * VS : bet;
+        // L2_i: one tile (PIPE 1), by step parity (PIPE 2), ring of three (PIPE 3: stage C reads it two ticks after stage A wrote it)
+        t.L2c = PIPE == 3 ? (m0 == 0 ? L2c : m0 == 1 ? tile(22) : tile(27)) : (PIPE == 2 && p0) ? tile(22) : L2c;
+        t.Y0h = tile(23 + (PIPE >= 2 ? p0 : 0));
+        t.Y1h = tile(25 + (PIPE >= 2 ? p0 : 0));
+        t.bet = (PIPE >= 2 && p0) ? vec + 9 * VS : bet;
+        // L0^-T ring (the transposed inverse factor: operand of W1 / W2): tiles 19..21 are free during the forward pass (PIPE 3:
+        // four slots - stage C reads step i-2's while stage B writes step i+1's)
+        auto lit = [&](int j) { constexpr int R = PIPE == 3 ? 4 : 3; const int q = ((j % R) + R) % R; return q < 3 ? tile(19 + q) : tile(28); };
+        t.LiT = lit(i); t.LiT1 = lit(i - 1); t.LiT2 = lit(i - 2);
         t.p0 = p0; t.m0 = m0;
         return t;
     };
@@ -1572,16 +1571,38 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
             if (i >= 2) s += tile_mv<nq, false, TL>(T2, q2r, lane);
             bet[lane] = s - rd_i;
         }
-        if constexpr (PIPE == 2) { tile_st<TL, F32>(t.Y0h, y0, li, lk); tile_st<TL, F32>(t.Y1h, y1a, li, lk); }
+        if constexpr (PIPE >= 2) { tile_st<TL, F32>(t.Y0h, y0, li, lk); tile_st<TL, F32>(t.Y1h, y1a, li, lk); }
         KPROF(3)
     };
-    // ---- stage B of step i: L1_i, the Cholesky factor L0_i and its inverse, y_i, spill --------------------
+    // ---- stage C of step i: what the backward pass runs on, formed off the dependency chain and spilled ------------
+    //   dnu_j = L0_j^-T (y_j - L1_{j+1}^T dnu_{j+1} - L2_{j+2}^T dnu_{j+2})  =  yhat_j - W1_j^T dnu_{j+1} - W2_j^T dnu_{j+2}
+    //   W1_j = L1_{j+1} L0_j^-1 ,  W2_j = L2_{j+2} L0_j^-1 ,  yhat_j = L0_j^-T y_j
+    // so that a backward step is ONE level of two independent mat-vecs instead of two dependent levels.  Step i knows L1_i and
+    // L2_i: it completes the records of steps i-1 (W1) and i-2 (W2) and writes yhat_i.  Record of a step: [W1 | W2 | - | yhat].
+    auto stageC = [&](int i) {
+        const Slots t = slots(i);
+        auto put = [&](double* g, const Acc& a) {         // accumulator -> global, compact nd x nd column-major
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int J = 0; J < NB; ++J)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * I + li, col = tile_col<F32>(J, lk, r);
+                        if (row < nd && col < nd) g[row + col * nd] = (double)a.v[I][J][r];
+                    }
+        };
+        if (i >= 1) put(ws + (size_t)(i - 1) * WSR, tile_mma<KBD, false, TL, F32>(t.L1c, t.LiT1, z4, li, lk));
+        if (i >= 2) put(ws + (size_t)(i - 2) * WSR + n2, tile_mma<KBD, false, TL, F32>(t.L2c, t.LiT2, z4, li, lk));
+        if (lane < nd) ws[(size_t)i * WSR + 3 * n2 + lane] = tile_mv<nd, true, TL>(t.Li, t.yc, lane);
+    };
+    // ---- stage B of step i: L1_i, the Cholesky factor L0_i and its inverse, y_i (the recursion's dependency chain) ---
     auto stageB = [&](int i) {
         const Slots t = slots(i);
         double* const Li = t.Li; double* const Li1 = t.Li1; double* const L1c = t.L1c; double* const L1p = t.L1p;
         double* const yc = t.yc; double* const y1 = t.y1; double* const y2 = t.y2;
         double* const L2c = t.L2c; double* const bet = t.bet;
-        if constexpr (PIPE == 2) { y0 = tile_ld<TL, F32>(t.Y0h, li, lk); y1a = tile_ld<TL, F32>(t.Y1h, li, lk); }
+        if constexpr (PIPE >= 2) { y0 = tile_ld<TL, F32>(t.Y0h, li, lk); y1a = tile_ld<TL, F32>(t.Y1h, li, lk); }
         // ---- P4: Y1 -= L2 L1_{i-1}^T ; stage Y1 as an operand ------------------------------
         if (i >= 1) {
             if (i >= 2) y1a = tile_mma<KBD, true, TL, F32>(L2c, L1p, y1a, li, lk);
@@ -1638,37 +1659,27 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
                 static_for<0, nd>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
                     Li[r + lane * TL] = xc[r];
+                    t.LiT[lane + r * TL] = xc[r];       // L0^-T: consecutive lanes on consecutive addresses
                 });
             }
         }
         lds_sync();
         KPROF(6)
-        // ---- P8: y_i = L0^-1 tv ; spill (L1_i, L2_i, L0_i^-1, y_i) for the backward pass ------
-        double yi = 0.0;
-        if (lane < nd) {
-            yi = tile_mv<nd, false, TL>(Li, tv, lane);
-            yc[lane] = yi;
-        }
-        double* wsi = ws + (size_t)i * WSR;
-#pragma unroll
-        for (int j = 0; j < SP; ++j) {
-            const double v1 = L1c[sp_off[j]], v2 = L2c[sp_off[j]];
-            wsi[sp_k[j]] = (i >= 1) ? v1 : 0.0;
-            wsi[n2 + sp_k[j]] = (i >= 2) ? v2 : 0.0;
-            wsi[2 * n2 + sp_k[j]] = Li[sp_off[j]];
-        }
-        if (lane < nd) wsi[3 * n2 + lane] = yi;
+        // ---- P8: y_i = L0^-1 tv -------------------------------------------------------------------
+        if (lane < nd) yc[lane] = tile_mv<nd, false, TL>(Li, tv, lane);
         lds_sync();
+        if constexpr (PIPE != 3) stageC(i);
         KPROF(7)
     };
-    if constexpr (PIPE == 2) {
+    if constexpr (PIPE >= 2) {
         if (wave == 0) prefetch(0);
-        for (int tck = 0; tck <= H; ++tck) {      // tick: A(tck) on wave 0 next to B(tck - 1) on wave 1
+        for (int tck = 0; tck < H + PIPE - 1; ++tck) {      // tick: A(tck) on wave 0, B(tck - 1) on wave 1, (PIPE 3) C(tck - 2) on wave 2
             if (wave == 0 && tck < H) stageA(tck);
-            if (wave == 1 && tck >= 1) stageB(tck - 1);
+            if (wave == 1 && tck >= 1 && tck <= H) stageB(tck - 1);
+            if constexpr (PIPE == 3) { if (wave == 2 && tck >= 2) stageC(tck - 2); }
             __syncthreads();
         }
-        __threadfence_block();                    // wave 1's spill stores are read back by wave 0
+        __threadfence_block();                    // the other waves' spill stores are read back by wave 0
         __syncthreads();
         if (wave != 0) return;
     } else {
@@ -1683,57 +1694,46 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     lds_sync();
     // =========================================================================================
     // backward substitution, step i = H-1 .. 0 (sequential):
-    //   dnu_i = L0_i^-T (y_i - L1_{i+1}^T dnu_{i+1} - L2_{i+2}^T dnu_{i+2})
+    //   dnu_i = L0_i^-T (y_i - L1_{i+1}^T dnu_{i+1} - L2_{i+2}^T dnu_{i+2}) = yhat_i - W1_i^T dnu_{i+1} - W2_i^T dnu_{i+2}   (stage C)
     // then the primal recovery for ALL steps at once (no dependency between steps):
     //   Du_i  = Rinv_i (rpu_i - du1_i^T dnu_i)
     //   Dq_i  = Qinv_i (rpq_i + dnu_i - dq1_{i+1}^T dnu_{i+1} - dq0_{i+2}^T dnu_{i+2})
     // =========================================================================================
     double* D = K.delta + (size_t)b * S.N;
-    // tiles 0..2: L1_j ring, 3..5: L2_j ring (slot = step % 3), tile 6: L0_i^-1
-    double* FI = tile(6);
-    double* yb = vec;                                 // y_i
+    // per step: W1_i -> tile 0, W2_i -> tile 3, yhat_i -> vec; dnu_i = yhat_i - W1_i^T dnu_{i+1} - W2_i^T dnu_{i+2}
+    double* W1t = tile(0); double* W2t = tile(3);
+    double* yb = vec;                                 // yhat_i
     double* dn_all = tile(16);                        // [H][16] all dnu (tiles 16..18; H <= 48)
     double* t_all = tile(7);                          // [H][nr] first level of the recovery (tiles 7..)
-    constexpr int PF_W = (WSR + 63) / 64;
+    constexpr int PF_W = (2 * n2 + nd + 63) / 64;
     double pf_w[PF_W];
-    // marshalling plan of the backward pass (same idea): source element, LDS destination for ring slot 0
-    // and whether the destination rotates with the step (tiles 0..2: L1 ring, 3..5: L2 ring, 6: L0^-1, vec: y)
-    int bw_src[PF_W], bw_dst[PF_W], bw_rot[PF_W];
+    // marshalling plan of the backward pass: source element of the step's record [W1 | W2 | - | yhat], LDS destination
+    int bw_src[PF_W], bw_dst[PF_W];
 #pragma unroll
     for (int j = 0; j < PF_W; ++j) {
-        const int k = lane + 64 * j, ok = k < WSR, kk = ok ? k : 0;
+        const int k = lane + 64 * j, ok = k < 2 * n2 + nd, kk = ok ? k : 0;
         const int t = kk / n2, e = kk - t * n2, r = e % nd, c = e / nd;
-        bw_src[j] = kk;
-        bw_dst[j] = !ok ? TRASH : (t == 0) ? r + c * TL : (t == 1) ? 3 * TSZ + r + c * TL : (t == 2) ? 6 * TSZ + r + c * TL
-                                                                                       : NTILES * TSZ + (kk - 3 * n2);
-        bw_rot[j] = (ok && t < 2) ? TSZ : 0;
+        bw_src[j] = t < 2 ? kk : 3 * n2 + (kk - 2 * n2);
+        bw_dst[j] = !ok ? TRASH : (t == 0) ? r + c * TL : (t == 1) ? 3 * TSZ + r + c * TL : NTILES * TSZ + (kk - 2 * n2);
     }
     auto prefetch_b = [&](int i) {
         if (i < 0) return;
         const double* wsi = ws + (size_t)i * WSR;
 #pragma unroll
-        for (int j = 0; j < PF_W; ++j) pf_w[j] = wsi[bw_src[j]];
+        for (int j = 0; j < PF_W; ++j) pf_w[j] = wsi[bw_src[j]];       // (W1 of the last step, W2 of the last two: never written, never used)
     };
     prefetch_b(H - 1);
     for (int i = H - 1; i >= 0; --i) {
-        const int s0 = i % 3, s1 = (i + 1) % 3, s2 = (i + 2) % 3;
-        double* F1s1 = tile(0 + s1);      // L1_{i+1}, L2_{i+2}: fetched one / two steps ago into ring slots s1 / s2
-        double* F2s2 = tile(3 + s2);
 #pragma unroll
-        for (int j = 0; j < PF_W; ++j) sm[bw_dst[j] + s0 * bw_rot[j]] = pf_w[j];
+        for (int j = 0; j < PF_W; ++j) sm[bw_dst[j]] = pf_w[j];
         lds_sync();
         prefetch_b(i - 1);
         if (lane < nd) {
             double s = yb[lane];
-            if (i + 1 < H) s -= tile_mv<nd, true, TL>(F1s1, dn_all + (i + 1) * VS, lane);
-            if (i + 2 < H) s -= tile_mv<nd, true, TL>(F2s2, dn_all + (i + 2) * VS, lane);
-            tv[lane] = s;
-        }
-        lds_sync();
-        if (lane < nd) {
-            const double dni = tile_mv<nd, true, TL>(FI, tv, lane);
-            dn_all[i * VS + lane] = dni;
-            D[H * nr + i * nd + lane] = dni;
+            if (i + 1 < H) s -= tile_mv<nd, true, TL>(W1t, dn_all + (i + 1) * VS, lane);
+            if (i + 2 < H) s -= tile_mv<nd, true, TL>(W2t, dn_all + (i + 2) * VS, lane);
+            dn_all[i * VS + lane] = s;
+            D[H * nr + i * nd + lane] = s;
         }
         lds_sync();
     }
@@ -1826,13 +1826,13 @@ __global__ __launch_bounds__((64 * kkt_pack<NQ, NU>()), (kkt_tld<NQ, NU>() <= 16
     kkt_body<NQ, NU, WaveSync>(S, K, list[slot], sm + (size_t)wave * kkt_lds_doubles<NQ, NU, 1>(), (int)threadIdx.x & 63);
 }
 
-// Pipelined launch: one rollout per workgroup of two wavefronts (kkt_body<..., PIPE = 2>), from the compact list.
+// Pipelined launch: one rollout per workgroup of three wavefronts (kkt_body<..., PIPE = 3>), from the compact list.
 template <int NQ, int NU>
-__global__ __launch_bounds__(128, (kkt_tld<NQ, NU>() <= 16 ? 2 : 1)) void kkt_kernel_pipe(NewtonDev S, KktArgs K, const int* list, int n, const int* n_dev) {
+__global__ __launch_bounds__(192, (kkt_tld<NQ, NU>() <= 16 ? 2 : 1)) void kkt_kernel_pipe(NewtonDev S, KktArgs K, const int* list, int n, const int* n_dev) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     if (n_dev != nullptr) n = *n_dev;
     if ((int)blockIdx.x >= n) return;
-    kkt_body<NQ, NU, WaveSync, 2>(S, K, list[blockIdx.x], sm, (int)threadIdx.x & 63, (int)threadIdx.x >> 6);
+    kkt_body<NQ, NU, WaveSync, 3>(S, K, list[blockIdx.x], sm, (int)threadIdx.x & 63, (int)threadIdx.x >> 6);
 }
 
 // (wide tiles: 105 KB of LDS allow one workgroup per CU anyway - let it use the 512-register budget)

@@ -462,11 +462,11 @@ static int launch_kkt_packed_t(const NewtonDev& S, const KktArgs& K, const int* 
         // `pipe` (host schedule, CIMPC_KKT_PIPE): where the KKT solve is on the critical path (small batches, chained rounds).
         // Next to a busy sweep the pipelined kernel takes twice the CUs for half the time - measured neutral - so the
         // packed one-wave kernel stays there.
-        if (pipe) {      // two wavefronts per rollout, software-pipelined forward recursion
-            const size_t lds2 = (size_t)kkt_lds_doubles<NQ, NU, 2>() * sizeof(double);
+        if (pipe) {      // three wavefronts per rollout, software-pipelined forward recursion
+            const size_t lds2 = (size_t)kkt_lds_doubles<NQ, NU, 3>() * sizeof(double);
             static LdsOptIn optin2;
             if (lds_opt_in(optin2, (const void*)kkt_kernel_pipe<NQ, NU>, lds2) != CIMPC_OK) return CIMPC_ERR_HIP;
-            hipLaunchKernelGGL((kkt_kernel_pipe<NQ, NU>), dim3(n), dim3(128), lds2, s, S, K, list, n, n_dev);
+            hipLaunchKernelGGL((kkt_kernel_pipe<NQ, NU>), dim3(n), dim3(192), lds2, s, S, K, list, n, n_dev);
             return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
         }
         hipLaunchKernelGGL((kkt_kernel_packed<NQ, NU>), dim3((n + PACK - 1) / PACK), dim3(64 * PACK), lds, s, S, K, list, n, n_dev);
