@@ -1706,7 +1706,10 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     double* dn_all = tile(16);                        // [H][16] all dnu (tiles 16..18; H <= 48)
     double* t_all = tile(7);                          // [H][nr] first level of the recovery (tiles 7..)
     constexpr int PF_W = (2 * n2 + nd + 63) / 64;
-    double pf_w[PF_W];
+    // The records come from global memory (L2): a load takes ~1 us, a backward step ~0.3 us - the loads run THREE steps ahead
+    // (three register sets, the loop unrolled by three so that the sets are indexed statically; a record is 4 doubles per lane).
+    constexpr int DEPTH = 3;
+    double pf_w[DEPTH][PF_W];
     // marshalling plan of the backward pass: source element of the step's record [W1 | W2 | - | yhat], LDS destination
     int bw_src[PF_W], bw_dst[PF_W];
 #pragma unroll
@@ -1716,18 +1719,20 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         bw_src[j] = t < 2 ? kk : 3 * n2 + (kk - 2 * n2);
         bw_dst[j] = !ok ? TRASH : (t == 0) ? r + c * TL : (t == 1) ? 3 * TSZ + r + c * TL : NTILES * TSZ + (kk - 2 * n2);
     }
-    auto prefetch_b = [&](int i) {
+    auto prefetch_b = [&](auto setc, int i) {
+        constexpr int set = decltype(setc)::value;
         if (i < 0) return;
         const double* wsi = ws + (size_t)i * WSR;
 #pragma unroll
-        for (int j = 0; j < PF_W; ++j) pf_w[j] = wsi[bw_src[j]];       // (W1 of the last step, W2 of the last two: never written, never used)
+        for (int j = 0; j < PF_W; ++j) pf_w[set][j] = wsi[bw_src[j]];       // (W1 of the last step, W2 of the last two: never written, never used)
     };
-    prefetch_b(H - 1);
-    for (int i = H - 1; i >= 0; --i) {
+    auto back_step = [&](auto setc, int i) {
+        constexpr int set = decltype(setc)::value;
+        if (i < 0) return;
 #pragma unroll
-        for (int j = 0; j < PF_W; ++j) sm[bw_dst[j]] = pf_w[j];
+        for (int j = 0; j < PF_W; ++j) sm[bw_dst[j]] = pf_w[set][j];
         lds_sync();
-        prefetch_b(i - 1);
+        prefetch_b(setc, i - DEPTH);
         if (lane < nd) {
             double s = yb[lane];
             if (i + 1 < H) s -= tile_mv<nd, true, TL>(W1t, dn_all + (i + 1) * VS, lane);
@@ -1736,8 +1741,15 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
             D[H * nr + i * nd + lane] = s;
         }
         lds_sync();
+    };
+    static_for<0, DEPTH>([&](auto kc) { prefetch_b(kc, H - 1 - decltype(kc)::value); });
+    for (int i = H - 1; i >= 0; i -= DEPTH) {
+        static_for<0, DEPTH>([&](auto kc) { back_step(kc, i - decltype(kc)::value); });
     }
-    // ---- primal recovery, level 1: t = r_p - C^T dnu, one output per lane and trip ---------------
+    // ---- primal recovery, level 1: t = r_p - C^T dnu, one output per lane and trip.  In the q rows both sensitivity columns are
+    //      requested before the first multiply-add (indices clamped, the terms dropped afterwards): one memory round trip per row
+    //      instead of three dependent ones.  (Two loops, one per kind of row, trip an instruction-selection bug of this compiler
+    //      in the translation unit where the tiles are reached through a generic pointer - the single loop stays.) ------------------
     for (int idx = lane; idx < H * nr; idx += 64) {
         const int i = idx / nr, c = idx - i * nr;
         double s = rb[idx];
@@ -1750,42 +1762,44 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
             s -= t0;
         } else {
             const int cq = c - nu;
+            const int i1 = min(i + 1, H - 1), i2 = min(i + 2, H - 1);
+            const double* a1 = dzb + ((size_t)i1 * nths + nq + cq) * nd;
+            const double* a2 = dzb + ((size_t)i2 * nths + cq) * nd;
+            double v1[nd], v2[nd];
+#pragma unroll
+            for (int k = 0; k < nd; ++k) { v1[k] = a1[k]; v2[k] = a2[k]; }
+            const double* dn1 = dn_all + i1 * VS;
+            const double* dn2 = dn_all + i2 * VS;
+            double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < nd; ++k) { t1 = fma(v1[k], dn1[k], t1); t2 = fma(v2[k], dn2[k], t2); }
             s += dn_all[i * VS + cq];
-            if (i + 1 < H) {
-                const double* a1 = dzb + ((size_t)(i + 1) * nths + nq + cq) * nd;
-                const double* dn1 = dn_all + (i + 1) * VS;
-                double t1 = 0.0;
-#pragma unroll
-                for (int k = 0; k < nd; ++k) t1 = fma(a1[k], dn1[k], t1);
-                s -= t1;
-            }
-            if (i + 2 < H) {
-                const double* a2 = dzb + ((size_t)(i + 2) * nths + cq) * nd;
-                const double* dn2 = dn_all + (i + 2) * VS;
-                double t2 = 0.0;
-#pragma unroll
-                for (int k = 0; k < nd; ++k) t2 = fma(a2[k], dn2[k], t2);
-                s -= t2;
-            }
+            if (i + 1 < H) s -= t1;
+            if (i + 2 < H) s -= t2;
         }
         t_all[idx] = s;
     }
     lds_sync();
-    // ---- level 2: Delta_x = P^-1 t ----------------------------------------------------------------
-    for (int idx = lane; idx < H * nr; idx += 64) {
-        const int i = idx / nr, c = idx - i * nr;
-        double s = 0.0;
-        if (c < nu) {
-            const double* Rm = S.Rinv + (size_t)i * nu * nu;
+    // ---- level 2: Delta_x = P^-1 t: a u row and a q row per trip, indices clamped instead of branched on --------------------
+    constexpr int RJ = nq > nu ? nq : nu;
+    for (int j = lane; j < H * RJ; j += 64) {
+        const bool on_u = j < H * nu, on_q = j < H * nq;
+        const int ju = on_u ? j : 0, iu = ju / nu, cu = ju - iu * nu;
+        const int jq = on_q ? j : 0, i = jq / nq, cq = jq - i * nq;
+        const double* Rm = S.Rinv + (size_t)iu * nu * nu + cu;
+        const double* Qm = S.Qinv + (size_t)i * nq * nq + cq;
+        double rv[nu], qv[nq];
 #pragma unroll
-            for (int k = 0; k < nu; ++k) s = fma(Rm[c + k * nu], t_all[i * nr + k], s);
-        } else {
-            const int cq = c - nu;
-            const double* Qm = S.Qinv + (size_t)i * nq * nq;
+        for (int k = 0; k < nu; ++k) rv[k] = Rm[k * nu];
 #pragma unroll
-            for (int k = 0; k < nq; ++k) s = fma(Qm[cq + k * nq], t_all[i * nr + nu + k], s);
-        }
-        D[idx] = s;
+        for (int k = 0; k < nq; ++k) qv[k] = Qm[k * nq];
+        double su = 0.0, sq = 0.0;
+#pragma unroll
+        for (int k = 0; k < nu; ++k) su = fma(rv[k], t_all[iu * nr + k], su);
+#pragma unroll
+        for (int k = 0; k < nq; ++k) sq = fma(qv[k], t_all[i * nr + nu + k], sq);
+        D[iu * nr + cu] = su;              // (surplus lanes recompute and rewrite row 0: same value, same address)
+        D[i * nr + nu + cq] = sq;
     }
     lds_sync();
     KPROF(8)
