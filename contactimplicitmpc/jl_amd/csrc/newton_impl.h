@@ -1431,7 +1431,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     double* Ri = tile(18);
     // tiles 19..21: extra ring slots of the backward pass
     double* vec = sm + NTILES * TSZ;
-    double* bet = vec;                                     // 16 each (PIPE = 2: second parity at vec + 144)
+    [[maybe_unused]] double* bet = vec;                    // 16 each (PIPE = 2: second parity at vec + 144)
     double* tv = vec + VS;
     // vec + (2,3,4) VS: y / dnu ring
     double* rpu = vec + 5 * VS;
@@ -1521,7 +1521,9 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         t.L2c = PIPE == 3 ? (m0 == 0 ? L2c : m0 == 1 ? tile(22) : tile(27)) : (PIPE == 2 && p0) ? tile(22) : L2c;
         t.Y0h = tile(23 + (PIPE >= 2 ? p0 : 0));
         t.Y1h = tile(25 + (PIPE >= 2 ? p0 : 0));
-        t.bet = (PIPE >= 2 && p0) ? vec + 9 * VS : bet;
+        // beta_i: by step parity (PIPE 2), ring of three (PIPE 3: read by stage C two ticks after stage A wrote it)
+        // (slot chosen as an OFFSET from one base: a select between pointers trips the compiler bug noted at the primal recovery)
+        t.bet = vec + (PIPE == 3 ? (m0 == 0 ? 0 : m0 == 1 ? 9 : 10) : (PIPE == 2 && p0) ? 9 : 0) * VS;
         // L0^-T ring (the transposed inverse factor: operand of W1 / W2): tiles 19..21 are free during the forward pass (PIPE 3:
         // four slots - stage C reads step i-2's while stage B writes step i+1's)
         auto lit = [&](int j) { constexpr int R = PIPE == 3 ? 4 : 3; const int q = ((j % R) + R) % R; return q < 3 ? tile(19 + q) : tile(28); };
@@ -1531,6 +1533,11 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     };
     const Acc z4 = tile_zero<NB, F32>();
     Acc y0 = z4, y1a = z4;                 // PIPE = 1: Y_ii / Y_i,i-1 accumulators stay in registers between the stages
+    // PIPE 3: the forward substitution y_i does not feed the next step's factor - only the backward pass wants it - and leaves
+    // the chain of stage B for stage C.  (Also tried: the down-date by L2_i moved into stage A, which knows L2_i - stage A then
+    // becomes the longer stage (quadruped 139 -> 134 us only, hopper H = 20 loop 0.82 -> 0.94 ms) and the sum Y - L1 L1^T - L2 L2^T
+    // is taken in another order than in the one- and two-wave variants, whose results must stay identical.)
+    constexpr bool OFFCHAIN = PIPE == 3;
     // ---- stage A of step i: needs factors of steps <= i-2 only --------------------------------------------
     auto stageA = [&](int i) {
         const Slots t = slots(i);
@@ -1594,14 +1601,25 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         };
         if (i >= 1) put(ws + (size_t)(i - 1) * WSR, tile_mma<KBD, false, TL, F32>(t.L1c, t.LiT1, z4, li, lk));
         if (i >= 2) put(ws + (size_t)(i - 2) * WSR + n2, tile_mma<KBD, false, TL, F32>(t.L2c, t.LiT2, z4, li, lk));
+        if constexpr (OFFCHAIN) {       // forward substitution of step i: y_i = L0_i^-1 (beta_i - L1_i y_{i-1} - L2_i y_{i-2})
+            if (lane < nd) {
+                double s = t.bet[lane];
+                if (i >= 1) s -= tile_mv<nd, false, TL>(t.L1c, t.y1, lane);
+                if (i >= 2) s -= tile_mv<nd, false, TL>(t.L2c, t.y2, lane);
+                tv[lane] = s;
+            }
+            lds_sync();
+            if (lane < nd) t.yc[lane] = tile_mv<nd, false, TL>(t.Li, tv, lane);
+            lds_sync();
+        }
         if (lane < nd) ws[(size_t)i * WSR + 3 * n2 + lane] = tile_mv<nd, true, TL>(t.Li, t.yc, lane);
     };
     // ---- stage B of step i: L1_i, the Cholesky factor L0_i and its inverse, y_i (the recursion's dependency chain) ---
     auto stageB = [&](int i) {
         const Slots t = slots(i);
         double* const Li = t.Li; double* const Li1 = t.Li1; double* const L1c = t.L1c; double* const L1p = t.L1p;
-        double* const yc = t.yc; double* const y1 = t.y1; double* const y2 = t.y2;
-        double* const L2c = t.L2c; double* const bet = t.bet;
+        [[maybe_unused]] double* const yc = t.yc; [[maybe_unused]] double* const y1 = t.y1; [[maybe_unused]] double* const y2 = t.y2;
+        double* const L2c = t.L2c; [[maybe_unused]] double* const bet = t.bet;
         if constexpr (PIPE >= 2) { y0 = tile_ld<TL, F32>(t.Y0h, li, lk); y1a = tile_ld<TL, F32>(t.Y1h, li, lk); }
         // ---- P4: Y1 -= L2 L1_{i-1}^T ; stage Y1 as an operand ------------------------------
         if (i >= 1) {
@@ -1617,11 +1635,13 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         if (i >= 1) y0 = tile_mma<KBD, true, TL, F32>(L1c, L1c, y0, li, lk);
         if (i >= 2) y0 = tile_mma<KBD, true, TL, F32>(L2c, L2c, y0, li, lk);
         tile_st<TL, F32>(Lc, y0, li, lk);
-        if (lane < nd) {
-            double s = bet[lane];
-            if (i >= 1) s -= tile_mv<nd, false, TL>(L1c, y1, lane);
-            if (i >= 2) s -= tile_mv<nd, false, TL>(L2c, y2, lane);
-            tv[lane] = s;
+        if constexpr (!OFFCHAIN) {
+            if (lane < nd) {
+                double s = bet[lane];
+                if (i >= 1) s -= tile_mv<nd, false, TL>(L1c, y1, lane);
+                if (i >= 2) s -= tile_mv<nd, false, TL>(L2c, y2, lane);
+                tv[lane] = s;
+            }
         }
         lds_sync();
         KPROF(5)
@@ -1666,8 +1686,10 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         lds_sync();
         KPROF(6)
         // ---- P8: y_i = L0^-1 tv -------------------------------------------------------------------
-        if (lane < nd) yc[lane] = tile_mv<nd, false, TL>(Li, tv, lane);
-        lds_sync();
+        if constexpr (!OFFCHAIN) {
+            if (lane < nd) yc[lane] = tile_mv<nd, false, TL>(Li, tv, lane);
+            lds_sync();
+        }
         if constexpr (PIPE != 3) stageC(i);
         KPROF(7)
     };
