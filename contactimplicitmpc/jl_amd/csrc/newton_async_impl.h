@@ -22,6 +22,9 @@
 #include <algorithm>
 #include <cstddef>
 #include "ip_kernel_impl.h"
+#ifdef CIMPC_KKT_PROF
+#undef CIMPC_KKT_PROF        // the KKT phase clocks are read from the lock-step kernels only (and this translation unit does not compile with them)
+#endif
 #include "newton_impl.h"
 
 namespace cimpc {

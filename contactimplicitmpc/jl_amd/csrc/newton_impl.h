@@ -1695,12 +1695,28 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     };
     if constexpr (PIPE >= 2) {
         if (wave == 0) prefetch(0);
+#ifdef CIMPC_KKT_WPROF
+        long long w_stage = 0, w_bar = 0;
+#endif
         for (int tck = 0; tck < H + PIPE - 1; ++tck) {      // tick: A(tck) on wave 0, B(tck - 1) on wave 1, (PIPE 3) C(tck - 2) on wave 2
+#ifdef CIMPC_KKT_WPROF
+            const long long w0 = clock64();
+#endif
             if (wave == 0 && tck < H) stageA(tck);
             if (wave == 1 && tck >= 1 && tck <= H) stageB(tck - 1);
             if constexpr (PIPE == 3) { if (wave == 2 && tck >= 2) stageC(tck - 2); }
+#ifdef CIMPC_KKT_WPROF
+            const long long w1 = clock64();
+#endif
             __syncthreads();
+#ifdef CIMPC_KKT_WPROF
+            w_stage += w1 - w0; w_bar += clock64() - w1;
+#endif
         }
+#ifdef CIMPC_KKT_WPROF
+        // (diagnostic builds) per wave: time inside its stage, time at the tick barrier -> statistics words 17 + 2 wave, 18 + 2 wave
+        if (lane == 0 && b == 0) { ((long long*)S.stats)[8 + 9 + 2 * wave] = w_stage; ((long long*)S.stats)[8 + 10 + 2 * wave] = w_bar; }
+#endif
         __threadfence_block();                    // the other waves' spill stores are read back by wave 0
         __syncthreads();
         if (wave != 0) return;
@@ -1826,7 +1842,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     lds_sync();
     KPROF(8)
 #ifdef CIMPC_KKT_PROF
-    if (lane == 0 && b == 0) for (int j = 0; j < 16; ++j) ((long long*)S.stats)[8 + j] = pt[j];      // (diagnostic builds: overwrites the statistics of rollouts 2..5)
+    if (lane == 0 && b == 0) for (int j = 0; j < 9 ; ++j) ((long long*)S.stats)[8 + j] = pt[j];      // (diagnostic builds: overwrites the statistics of rollouts 2..5)
 #endif
     if (K.finish) {
         __threadfence_block();

@@ -11,6 +11,9 @@
 // (cimpc_host.cpp); each rollout carries its own stage / alpha / beta, so rollouts that
 // backtrack and rollouts that start their next Newton iteration share the same launches.
 #include <cstdlib>
+#ifdef CIMPC_KKT_PROF
+#define CIMPC_KKT_WPROF      // per-wave clocks of the pipelined KKT kernel: this translation unit only (the asynchronous kernel's does not survive them)
+#endif
 #include "newton_impl.h"
 
 namespace cimpc {
