@@ -37,6 +37,7 @@ struct RoundStreams {
     hipStream_t st = nullptr;
     hipStream_t st_kkt = nullptr;
     hipEvent_t ev_join = nullptr;   // end of the round's KKT kernel
+    hipEvent_t ev_start = nullptr;  // the caller's stream at the start of a solve (uploads of q0 / q1 precede the reset kernel)
 };
 
 // Schedule knobs.  Every environment override is read ONCE, in cimpc_create (a handle's configuration never
@@ -159,7 +160,8 @@ struct cimpc_ctx {
     double *d_V = nullptr, *d_qt = nullptr, *d_vt = nullptr;
     int waves = 4;
     bool kkt_overlap = true;
-    int* d_ring = nullptr;       // [MAX_DEPTH][8] device counters per in-flight round
+    int* d_ring = nullptr;       // [MAX_DEPTH][8] device counters per in-flight round (behind the queue counters: Q.count .. +ctl_ints)
+    size_t ctl_ints = 0;
     int* h_ring = nullptr;       // pinned, host-mapped: {n_sweep, n_kkt, stamp}
     int* h_ring_dev = nullptr;   // device pointer of h_ring
     // asynchronous single-launch solve (newton_async_impl.h)
@@ -510,7 +512,11 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         const size_t K = d.H_ref;
         const size_t cap = B * CS * ((H + K - 1) / K + 1);
         h->Q.K = (int)K; h->Q.cap = (int)cap; h->Q.par = 0;
-        A(&h->Q.items, 2 * K * cap); A(&h->Q.count, 2 * K * QPAD); A(&h->Q.head, K * QPAD);
+        A(&h->Q.items, 2 * K * cap);
+        // queue counters, queue heads and the round counters: ONE block, cleared by one memset at the start of a solve
+        h->ctl_ints = 3 * K * QPAD + 2 * 8 * CPAD;
+        A(&h->Q.count, h->ctl_ints);
+        if (rc == CIMPC_OK) { h->Q.head = h->Q.count + 2 * K * QPAD; h->d_ring = h->Q.count + 3 * K * QPAD; }
         AX(&h->Q.done_count, B * CS);
         A(&h->d_window, B * (H + 2));
         h->Q.window = h->d_window;
@@ -602,8 +608,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     if (h->kn.waves == 1 || h->kn.waves == 2 || (h->kn.waves >= 4 && h->kn.waves <= 8)) h->waves = h->kn.waves;   // (5..8: builds with CIMPC_SWEEP_THREADS > 256)
     h->kkt_overlap = B >= 64;
     if (h->kn.kkt_overlap >= 0) h->kkt_overlap = h->kn.kkt_overlap != 0;
-    if (dev_alloc(h, &h->d_ring, 2 * 8 * CPAD) != CIMPC_OK ||
-        hipHostMalloc((void**)&h->h_ring, 32 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+    if (hipHostMalloc((void**)&h->h_ring, 32 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&h->h_ring_dev, h->h_ring, 0) != hipSuccess) {
         g_create_error = "ring allocation failed"; cimpc_destroy(h); return CIMPC_ERR_HIP;
     }
@@ -644,7 +649,8 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         RoundStreams& r = h->rs;
         if (hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&r.st_kkt, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&r.ev_join, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&r.ev_join, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&r.ev_start, hipEventDisableTiming) != hipSuccess) {
             g_create_error = "stream creation failed"; cimpc_destroy(h); return CIMPC_ERR_HIP;
         }
     }
@@ -666,6 +672,7 @@ int cimpc_destroy(cimpc_handle h) {
         if (r.st) { (void)hipStreamSynchronize(r.st); (void)hipStreamDestroy(r.st); }
         if (r.st_kkt) { (void)hipStreamSynchronize(r.st_kkt); (void)hipStreamDestroy(r.st_kkt); }
         if (r.ev_join) (void)hipEventDestroy(r.ev_join);
+        if (r.ev_start) (void)hipEventDestroy(r.ev_start);
     }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1041,8 +1048,13 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return el >= h->nt.max_time;
     };
-    HIP_TRY(h, hipMemsetAsync(S.stats, 0, (size_t)h->dm.B * 4 * sizeof(long long), h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // the solve runs on the library's streams: they wait (on the device) for what the caller's stream holds - the uploads of
+    // q0 / q1 - instead of the host waiting for it
+    if (!h->external_stream) {
+        HIP_TRY(h, hipEventRecord(h->rs.ev_start, h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->rs.st, h->rs.ev_start, 0));
+    }
+    HIP_TRY(h, hipMemsetAsync(S.stats, 0, (size_t)h->dm.B * 4 * sizeof(long long), h->external_stream ? h->stream : h->rs.st));
     // ---- one persistent launch: every rollout advances on its own chain (newton_async_impl.h).  Entered
     //      from the start (from_reset) or with the rollouts the lock-step rounds left active (hybrid). ----
     auto run_async = [&](bool from_reset, long long rounds_before, int next_par = -1) -> int {
@@ -1215,9 +1227,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         if (rr != CIMPC_OK) return fail(h, rr, "residual launch failed");
         return CIMPC_OK;
     };
-    HIP_TRY(h, hipMemsetAsync(h->Q.count, 0, 2 * h->Q.K * QPAD * sizeof(int), sb.st));
-    HIP_TRY(h, hipMemsetAsync(h->Q.head, 0, h->Q.K * QPAD * sizeof(int), sb.st));
-    HIP_TRY(h, hipMemsetAsync(h->d_ring, 0, 2 * 8 * CPAD * sizeof(int), sb.st));
+    HIP_TRY(h, hipMemsetAsync(h->Q.count, 0, h->ctl_ints * sizeof(int), sb.st));      // queue counters, heads, round counters
     if (hybrid) HIP_TRY(h, hipMemsetAsync(h->a_ctrl + 2 * (size_t)h->Q.K * QPAD, 0, 64 * sizeof(int), sb.st));
     ((volatile int*)h->h_ring)[2] = 0;
     ((volatile int*)h->h_ring)[10] = 0;
