@@ -40,72 +40,58 @@ struct RoundStreams {
     hipEvent_t ev_start = nullptr;  // the caller's stream at the start of a solve (uploads of q0 / q1 precede the reset kernel)
 };
 
-// Schedule knobs.  Every environment override is read ONCE, in cimpc_create (a handle's configuration never
-// changes afterwards and no solve-path call touches the environment).  The defaults are the measured optima
-// (DESIGN.md section 5); the overrides exist for the A/B scripts under scripts/.
+// Schedule settings.  The defaults are the measured optima.  A dozen of them keep an environment
+// override for the A/B scripts under scripts/ (read ONCE, in cimpc_create: a handle's configuration never changes
+// afterwards and no solve-path call touches the environment); the rest are constants of the build - their overrides were
+// removed in round 3, every one an untested configuration (the experiments they served are recorded in DESIGN.md).
 struct Knobs {
+    // ---- with an override ----
     int async_mode = 2;          // CIMPC_ASYNC: 0 lock-step rounds only, 1 always the single launch, 2 auto
     int async_tail = -1;         // CIMPC_ASYNC_TAIL: hybrid hand-over threshold (-1: by batch size)
-    int async_mem = 0;           // CIMPC_ASYNC_MEM: 1 uncached, 2 fine-grained exchange buffers (experiment)
-    int spec_all = -1;           // CIMPC_SPEC_ALL
-    int spec_tail = 3;           // CIMPC_SPEC_TAIL
     int spec_first = -1;         // CIMPC_SPEC_FIRST: step lengths of the first line-search round of a solve's first Newton iteration (-1: by batch size)
-    int spec_mid = -1;           // CIMPC_SPEC_MID: previous search depth from which a rollout starts with three candidates (-1: by batch size)
-    int iter_cap = 28;           // CIMPC_ITER_CAP (B = 512: 24 / 28 / 32 / 36 -> 11.8 / 11.5 / 11.8 / 11.75 ms with the fused-broadcast sweep)
-    int waves = 0;               // CIMPC_WAVES (0: by batch size)
-    int kkt_overlap = -1;        // CIMPC_KKT_OVERLAP (-1: by batch size)
-    int sweep_wgs = 0;           // CIMPC_SWEEP_WGS (0: computed)
-    int async_service = 0;       // CIMPC_ASYNC_SERVICE (0: computed)
+    int iter_cap = 28;           // CIMPC_ITER_CAP (B = 512: 20 / 24 / 28 / 32 -> 8.73 / 8.65 / 8.74 / 8.56 ms, inside the spread: profiles/r03/knobs3.log)
     bool async_debug = false;    // CIMPC_ASYNC_DEBUG
-    int async_flags = 0;         // CIMPC_ASYNC_FLAGS
-    int async_sleep = 2;         // CIMPC_ASYNC_SLEEP
-    int async_spins = 48;        // CIMPC_ASYNC_SPINS
-    int async_fan = 1;           // CIMPC_ASYNC_FAN
     double watchdog_s = 30.0;    // CIMPC_ASYNC_WATCHDOG_S
     bool debug_rounds = false;   // CIMPC_DEBUG_ROUNDS
-    bool kkt_packed = true;      // CIMPC_KKT_PACKED
     int tail_div = 8;            // CIMPC_TAIL_DIV
     int drain_pct = 95;          // CIMPC_DRAIN_PCT: drain parking once this percentage of the sweep's workgroups has left (0 = off; B = 512: 0 / 75 / 90 / 95 / 97 -> 10.68 / 10.97 / 10.48 / 10.45 / 10.47 ms)
     int drain_min = 4;           // CIMPC_DRAIN_MIN: ... for solves that have had at least this many iterations in the launch
-    bool kkt_scalar = false;     // CIMPC_KKT_SCALAR
     int async_full_max = 64;     // CIMPC_ASYNC_FULL_MAX: largest batch solved by the single persistent launch alone (larger: hybrid).
                                  // Measured 128 -> 64: B = 96 8.88 -> 8.11 ms, B = 128 9.72 -> 9.48 ms, B = 64 unchanged (6.9 ms)
-    int async_tail_grid = -1;    // CIMPC_ASYNC_TAIL_GRID: workgroups of the hybrid tail's persistent kernel (0 = the full resident set, -1 = 3 per
-                                 // rollout handed over; B = 512: 512 / 320 / 256 / 192 / 96 workgroups -> 10.85 / 10.42 / 10.35 / 10.38 / 10.6 ms)
-    int kkt_pipe = -1;           // CIMPC_KKT_PIPE: two-wave pipelined KKT kernel 0 never, 1 always, -1 where the solve is on the critical path
-    int kkt_pipe_max = 128;      // CIMPC_KKT_PIPE_MAX: ... and at most this many rollouts start an iteration (it takes twice the CUs)
+    int kkt_pipe = -1;           // CIMPC_KKT_PIPE: three-wave pipelined KKT kernel 0 never, 1 always, -1 where the solve is on the critical path
+    // ---- constants ----
+    int async_mem = 0;           // exchange buffers: ordinary device memory (uncached / fine-grained variants lost)
+    int spec_all = -1;           // speculative slots of later line-search rounds: by batch size
+    int spec_tail = 3;
+    int spec_mid = -1;           // previous search depth from which a rollout starts with three candidates: by batch size
+    int waves = 0;               // sweep workgroup size: by batch size
+    int kkt_overlap = -1;        // KKT on its own stream next to the sweep: from 64 rollouts on
+    int sweep_wgs = 0;           // persistent sweep workgroups: computed from the resident set
+    int async_service = 0;       // job-only workgroups of the asynchronous kernel: computed
+    int async_flags = 0;         // reserved
+    int async_sleep = 2;         // idle back-off of the asynchronous kernel (units of ~2 us), polls before looking around, wake-up fan
+    int async_spins = 48;
+    int async_fan = 1;
+    bool kkt_packed = true;      // two rollouts per KKT workgroup next to the sweep
+    bool kkt_scalar = false;     // scalar KKT kernel only where the MFMA one does not apply (tiles beyond 24, long horizons)
+    int async_tail_grid = -1;    // workgroups of the hybrid tail's persistent kernel: 3 per rollout handed over (B = 512: 512 / 320 / 256 / 192 / 96
+                                 // workgroups -> 10.85 / 10.42 / 10.35 / 10.38 / 10.6 ms)
+    int kkt_pipe_max = 128;      // pipelined KKT kernel for at most this many rollouts per round (it takes three times the waves)
 
     static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
     void read_environment() {
         async_mode = env_int("CIMPC_ASYNC", async_mode);
         async_tail = env_int("CIMPC_ASYNC_TAIL", async_tail);
-        async_mem = env_int("CIMPC_ASYNC_MEM", async_mem);
-        spec_all = env_int("CIMPC_SPEC_ALL", spec_all);
-        spec_tail = env_int("CIMPC_SPEC_TAIL", spec_tail);
         spec_first = env_int("CIMPC_SPEC_FIRST", spec_first);
-        spec_mid = env_int("CIMPC_SPEC_MID", spec_mid);
         iter_cap = std::max(1, env_int("CIMPC_ITER_CAP", iter_cap));
-        waves = env_int("CIMPC_WAVES", waves);
-        kkt_overlap = env_int("CIMPC_KKT_OVERLAP", kkt_overlap);
-        sweep_wgs = env_int("CIMPC_SWEEP_WGS", sweep_wgs);
-        async_service = env_int("CIMPC_ASYNC_SERVICE", async_service);
         async_debug = getenv("CIMPC_ASYNC_DEBUG") != nullptr;
-        async_flags = env_int("CIMPC_ASYNC_FLAGS", async_flags);
-        async_sleep = env_int("CIMPC_ASYNC_SLEEP", async_sleep);
-        async_spins = std::max(1, env_int("CIMPC_ASYNC_SPINS", async_spins));
-        async_fan = env_int("CIMPC_ASYNC_FAN", async_fan);
-        if (async_fan != 1 && async_fan != 2 && async_fan != 4 && async_fan != 8 && async_fan != 16) async_fan = 1;
         if (const char* v = getenv("CIMPC_ASYNC_WATCHDOG_S")) watchdog_s = atof(v);
         debug_rounds = getenv("CIMPC_DEBUG_ROUNDS") != nullptr;
-        kkt_packed = env_int("CIMPC_KKT_PACKED", 1) != 0;
         tail_div = env_int("CIMPC_TAIL_DIV", tail_div);
-        async_tail_grid = env_int("CIMPC_ASYNC_TAIL_GRID", async_tail_grid);
         async_full_max = env_int("CIMPC_ASYNC_FULL_MAX", async_full_max);
-        kkt_scalar = env_int("CIMPC_KKT_SCALAR", 0) != 0;
         drain_pct = env_int("CIMPC_DRAIN_PCT", drain_pct);
         drain_min = std::max(1, env_int("CIMPC_DRAIN_MIN", drain_min));
         kkt_pipe = env_int("CIMPC_KKT_PIPE", kkt_pipe);
-        kkt_pipe_max = env_int("CIMPC_KKT_PIPE_MAX", kkt_pipe_max);
     }
 };
 

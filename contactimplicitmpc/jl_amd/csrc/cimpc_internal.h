@@ -47,7 +47,7 @@ struct AsyncQ {
     volatile int* abort_flag;   // host-mapped: nonzero = time budget exhausted, leave
     long long* dbg;     // [16] diagnostics (busy ticks / job counts per kind of work) or null
     int n_service;      // workgroups [0, n_service) only take residual / KKT jobs
-    int flags;          // experiment switches, see xfence()
+    int flags;          // reserved (0)
     int idle_sleep;     // back-off of an idle workgroup between polls, units of s_sleep(64) (~2 us)
     int idle_spins;     // polls before an idle workgroup looks around unprompted
     int wake_fan;       // buckets woken per evaluation request (each bucket = 1/16 of the workgroups)
@@ -59,12 +59,9 @@ struct AsyncQ {
 // counter update, the consumer an agent-scope acquire fence after claiming the entry.  (Measured on
 // MI355X: replacing the per-problem fences by write-through stores + s_waitcnt was neither faster
 // nor reliably correct across XCDs, so the plain, portable form stays.)
-// flags: experiment switches (CIMPC_ASYNC_FLAGS): 1 = wave-local fences only (timing experiments: NOT coherent),
-// 2 = no in-serve retry of idle groups
-__device__ __forceinline__ void xfence(int flags) {
-    if (flags & 1) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    else __threadfence();
-}
+// (`flags` is a reserved word of AsyncQueues, always 0: the timing experiments it once switched - workgroup-scope fences, no
+// in-serve retry of idle lane groups - are gone.)
+__device__ __forceinline__ void xfence(int /*flags*/) { __threadfence(); }
 template <bool X>
 __device__ __forceinline__ double xld(const double* p) { return *p; }
 template <bool X>

@@ -25,9 +25,7 @@
 
 // wave priorities: the KKT recursion that runs next to the sweep (second stream, one wave per rollout) is the longer leg of
 // most rounds since the sweep lost a third of its instructions: it gets the issue slots first (KKT 2 / sweep 0: 11.9 -> 11.6 ms)
-#ifndef CIMPC_SWEEP_PRIO
-#define CIMPC_SWEEP_PRIO 0
-#endif
+#define CIMPC_SWEEP_PRIO 0      // (a constant of the build: the -D override is gone with the experiment it served)
 
 namespace cimpc {
 
@@ -51,15 +49,11 @@ struct Model {
     static_assert(NX <= 32 && NY <= 32, "lane group holds at most 32 rows");
     static constexpr int RST_LD = G + 1;                       // padded row stride of the R tile
     static constexpr int DTN_LD = ((NTHS + G - 1) / G) * G;    // leading dimension of the delta^T nu products (IpParams::dtn)
-#ifndef CIMPC_SENS_MAX
-#define CIMPC_SENS_MAX 16
-#endif
+#define CIMPC_SENS_MAX 16      // (a constant of the build: the -D override is gone with the experiment it served)
     static constexpr int SENS_MAX = CIMPC_SENS_MAX;             // converged problems a group may defer
 // (measured dead ends: C A^-1, A^-1, Dy1 rows register-resident per knot - the 76 extra VGPRs spill, sweep launch 0.30 -> 0.47 ms;
 //  rows of R left in the LDS tile instead of registers for a third wave per SIMD - the spills stay, 0.35 -> 0.63 ms)
-#ifndef CIMPC_SENS_ILP
-#define CIMPC_SENS_ILP 5
-#endif
+#define CIMPC_SENS_ILP 5      // (a constant of the build: the -D override is gone with the experiment it served)
     static constexpr int SENS_ILP = (NX <= 16 && NY <= 16) ? CIMPC_SENS_ILP : 2;   // sensitivity columns solved side by side
     // per-problem LDS: the R tile and theta - theta0 SHARE their space (theta - theta0 lives from the pull of a problem to the two
     // dot products a few lines below it; the tile is scratch inside factorize), then the backlog of deferred sensitivities
@@ -447,9 +441,7 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
 // Remaining-work proportional knot pick (WG-uniform result in *s_knot, -1 = no work anywhere):
 // workgroup b takes the knot holding quantile b/gridDim of the problems not yet pulled, so the
 // workgroups spread over the knots like the work does - initially and after every hop.
-#ifndef CIMPC_PICK_MAXK
-#define CIMPC_PICK_MAXK 256
-#endif
+#define CIMPC_PICK_MAXK 256      // (a constant of the build: the -D override is gone with the experiment it served)
 constexpr int PICK_MAXK = CIMPC_PICK_MAXK;
 __device__ __forceinline__ int pick_knot(const IpParams& p, int* s_rem, int* s_total, int* s_knot, int tid, int wg, int nwg) {
     const int K = p.Q.K, par = p.Q.par;
@@ -602,7 +594,7 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
         [[maybe_unused]] const long long sp_b = SPROF_T();
         // ---- 2. pull the next problem of this knot -----------------------------------------
         // (ASYNC: the queue is live - an idle group looks again every few trips while its wave is busy)
-        if (!have && (!exhausted || (ASYNC && !(p.A.flags & 2) && (++idle_trips & 7) == 0))) {
+        if (!have && (!exhausted || (ASYNC && (++idle_trips & 7) == 0))) {
             int idx = 0, item = 0;
             if constexpr (ASYNC) {       // live queue: claim only what has been published
                 const long long tq0 = dbg_on ? wall_clock64() : 0;
@@ -738,12 +730,8 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
 //  the kernel may then use the full 512-VGPR budget instead of spilling: centroidal 341 spilled VGPRs -> 0)
 // Occupancy of the 16-lane sweep: CIMPC_SWEEP_THREADS (largest workgroup launched) x CIMPC_SWEEP_OCC workgroups per CU.
 // Default 256 x 2 = 8 waves per CU (2 per SIMD, 256 VGPRs).
-#ifndef CIMPC_SWEEP_OCC
-#define CIMPC_SWEEP_OCC 2
-#endif
-#ifndef CIMPC_SWEEP_THREADS
-#define CIMPC_SWEEP_THREADS 256
-#endif
+#define CIMPC_SWEEP_OCC 2      // (a constant of the build: the -D override is gone with the experiment it served)
+#define CIMPC_SWEEP_THREADS 256      // (a constant of the build: the -D override is gone with the experiment it served)
 template <class M>
 __global__ __launch_bounds__(M::G == 16 ? CIMPC_SWEEP_THREADS : 256, M::G == 16 ? CIMPC_SWEEP_OCC : 1) void ip_queue_kernel(IpParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];

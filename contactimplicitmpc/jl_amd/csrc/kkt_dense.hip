@@ -228,9 +228,7 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-#ifndef CIMPC_BANDED_THREADS
-#define CIMPC_BANDED_THREADS 1024
-#endif
+#define CIMPC_BANDED_THREADS 1024      // (a constant of the build: the -D override is gone with the experiment it served)
 __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(NewtonDev S, KktArgs K, double* ws_all) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int b = blockIdx.x + S.b0, tid = threadIdx.x, nt = blockDim.x;

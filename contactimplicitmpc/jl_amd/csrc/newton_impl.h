@@ -712,15 +712,9 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
     }
 }
 
-#ifndef CIMPC_KKT_PRIO
-#define CIMPC_KKT_PRIO 2
-#endif
-#ifndef CIMPC_RESID_THREADS
-#define CIMPC_RESID_THREADS 256
-#endif
-#ifndef CIMPC_SLOT_THREADS
-#define CIMPC_SLOT_THREADS 256
-#endif
+#define CIMPC_KKT_PRIO 2      // (a constant of the build: the -D override is gone with the experiment it served)
+#define CIMPC_RESID_THREADS 256      // (a constant of the build: the -D override is gone with the experiment it served)
+#define CIMPC_SLOT_THREADS 256      // (a constant of the build: the -D override is gone with the experiment it served)
 // first launch of the stage: one workgroup per evaluated slot - its residual and 1-norm.  The slots come from the compact list the
 // requesters of the round built (NewtonDev::slot_list).  Every scalar the block needs is requested in ONE batch of loads before the
 // first branch.
@@ -1856,12 +1850,8 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
 // sweep workgroups the CU could hold (it needs a 256-VGPR slot on one SIMD, the sweep workgroup one on
 // each).  Two per workgroup (94 KB of LDS) leave room for exactly one sweep workgroup next to them, so
 // half as many CUs lose a sweep workgroup (measured B = 512: pack 1 / 2 / 3 -> 14.0 / 13.3 / 13.6 ms).
-#ifndef CIMPC_KKT_PACK
-#define CIMPC_KKT_PACK 2
-#endif
-#ifndef CIMPC_KKT_PACK_WAVES_PER_SIMD
-#define CIMPC_KKT_PACK_WAVES_PER_SIMD 2
-#endif
+#define CIMPC_KKT_PACK 2      // (a constant of the build: the -D override is gone with the experiment it served)
+#define CIMPC_KKT_PACK_WAVES_PER_SIMD 2      // (a constant of the build: the -D override is gone with the experiment it served)
 constexpr int KKT_PACK = CIMPC_KKT_PACK;
 template <int NQ, int NU>
 constexpr int kkt_pack() {
