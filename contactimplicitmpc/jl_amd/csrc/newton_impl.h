@@ -82,6 +82,29 @@ __device__ __forceinline__ void enqueue_eval(const NewtonDev& S, size_t sb, int 
     }
 }
 
+// The same for the consecutive slots sb .. sb+n-1 of one rollout (the candidates of a line-search batch): they share the window,
+// so one atomic per horizon step reserves the entries of all of them, and one reserves their places in the round's slot list
+// (a round of 512 rollouts x 3 candidates x 40 steps put 61 k atomics on the 60 queue counters and 1.5 k on the list counter:
+// same-address atomics serialise, the last decision blocks of a round queued behind them).
+__device__ __forceinline__ void enqueue_evals(const NewtonDev& S, size_t sb, int n, int b, int par, int tid, int nt) {
+    const int H = S.dm.H, K = S.WQ.K;
+    for (int k = tid; k < H; k += nt) {
+        const int t = S.WQ.window[(size_t)b * (H + 2) + k];
+        const int pos = atomicAdd(qcount(S.WQ, par, t), n);
+        int* it = S.WQ.items + ((size_t)par * K + t) * S.WQ.cap + pos;
+        for (int c = 0; c < n; ++c) it[c] = (int)((sb + c) * H + k);
+    }
+    if (tid == 0) {
+        int pos = 0;
+        if (S.slot_list != nullptr) pos = atomicAdd(&S.counters[4 * CPAD], n);
+        for (int c = 0; c < n; ++c) {
+            S.WQ.done_count[sb + c] = 0;
+            S.need_sweep[sb + c] = 1;
+            if (S.slot_list != nullptr) S.slot_list[(size_t)par * S.dm.B * CS + pos + c] = (int)(sb + c);
+        }
+    }
+}
+
 // Asynchronous solve: request the evaluation of slots sb0 .. sb0+nslots-1 of rollout b.  The slots'
 // candidate trajectories must have been written by the calling unit; they are released before the
 // first queue entry is published (consumers acquire after claiming an entry).
@@ -243,7 +266,7 @@ __device__ __forceinline__ void start_line_search(const NewtonDev& S, int b, int
         // candidates join the queue of the next round
         // (chained round, kkt_same_round = 2: the round's second sweep consumes par ^ 1 - nothing is requested of the next round)
         const int par = (S.kkt_same_round == 1) ? S.WQ.par : (S.WQ.par ^ 1);
-        for (int c = 0; c < n; ++c) enqueue_eval(S, sb0 + c, b, par, lane, nt);
+        enqueue_evals(S, sb0, n, b, par, lane, nt);
         if (lane == 0) {
             for (int c = n; c < CS; ++c) S.need_sweep[sb0 + c] = 0;
             if (S.kkt_same_round != 2) atomicAdd(&S.counters[0 * CPAD], 1);
@@ -443,7 +466,7 @@ __device__ double slot_residual(const NewtonDev& S, size_t sb, int b, const int*
 // 100 MHz ticks summed over workgroups.  g_resid_prof[k][0] = workgroups, [k][1..12] = phases, [k][13] = lifetime sum, [k][14] = max
 // lifetime; k = 0 slot kernel, 1 decision kernel.
 #ifdef CIMPC_RESID_PROF
-static __device__ unsigned long long g_resid_prof[2][16];
+static __device__ unsigned long long g_resid_prof[4][16];      // rows 2, 3: the same sums over the SLOW workgroups only (lifetime > 30 us)
 struct ResidProf {
     long long t0, t, acc[13]; int k;
     __device__ ResidProf(int k_) : k(k_) { t0 = t = wall_clock64(); for (int j = 0; j < 13; ++j) acc[j] = 0; }
@@ -455,6 +478,11 @@ struct ResidProf {
         for (int j = 1; j < 13; ++j) if (acc[j]) atomicAdd(&g_resid_prof[k][j], (unsigned long long)acc[j]);
         atomicAdd(&g_resid_prof[k][13], (unsigned long long)(te - t0));
         atomicMax(&g_resid_prof[k][14], (unsigned long long)(te - t0));
+        if (te - t0 > 3000) {
+            atomicAdd(&g_resid_prof[2 + k][0], 1ull);
+            for (int j = 1; j < 13; ++j) if (acc[j]) atomicAdd(&g_resid_prof[2 + k][j], (unsigned long long)acc[j]);
+            atomicAdd(&g_resid_prof[2 + k][13], (unsigned long long)(te - t0));
+        }
     }
 };
 #define RPROF_BEGIN(k) ResidProf rprof_(k);
@@ -609,7 +637,7 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
         __syncthreads();
         apply_steps<BlockSync>(S, sb0 + it1, it1, nn, b, tid, nt);
         RPROF(4)
-        for (int c = 0; c < nn; ++c) enqueue_eval(S, sb0 + it1 + c, b, S.WQ.par ^ 1, tid, nt);      // evaluated in the next round
+        enqueue_evals(S, sb0 + it1, nn, b, S.WQ.par ^ 1, tid, nt);      // evaluated in the next round
         RPROF(5)
         if (tid == 0) {
             S.stage[b] = nstage;
@@ -641,22 +669,25 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
         if (use_eff && (blk & 1) == 0) {
             const int* ef = eff + (SPLIT ? 0 : slot * EFF_H);
             const int hb = blk / 2;
-            // four independent 16-byte loads in flight per thread before the first store (source and destination are distinct
-            // buffers, which the compiler cannot see: it kept one load - store pair in flight, 10 us per accepted evaluation)
-            constexpr int UN = 4;
+            // thirteen independent 16-byte loads in flight per thread before the first store: the quadruped's 6600 pairs move in
+            // two round trips (source and destination are distinct buffers, which the compiler cannot see: it kept one load -
+            // store pair in flight, 10 us per accepted evaluation; with four in flight the blocks that accept - the slowest
+            // of a round's decision launch, 40 us against 16 on average - still spent 21 us here)
+            constexpr int UN = 13;
+            // (static_for: with a `#pragma unroll` loop the staging array stayed in scratch memory - 80 bytes per lane)
             for (int e0 = tid; e0 < H * hb; e0 += UN * nt) {
-                double2 v[UN]; bool on[UN];
-#pragma unroll
-                for (int j = 0; j < UN; ++j) {
+                typedef double v2d __attribute__((ext_vector_type(2)));      // (HIP's double2 is a class: arrays of it are not promoted to registers)
+                v2d v[UN]; int dst[UN];
+                static_for<0, UN>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
                     const int e = e0 + j * nt, ec = e < H * hb ? e : 0, i = ec / hb, s_ = ef[i];
-                    on[j] = e < H * hb && s_ >= 0;
-                    v[j] = reinterpret_cast<const double2*>(S.dz + ((sb0 + (s_ >= 0 ? s_ : 0)) * H + i) * (size_t)blk)[ec - i * hb];
-                }
-#pragma unroll
-                for (int j = 0; j < UN; ++j) {
-                    const int e = e0 + j * nt;
-                    if (on[j]) { const int i = e / hb; reinterpret_cast<double2*>(good + (size_t)i * blk)[e - i * hb] = v[j]; }
-                }
+                    dst[j] = (e < H * hb && s_ >= 0) ? i * blk + 2 * (ec - i * hb) : -1;
+                    v[j] = reinterpret_cast<const v2d*>(S.dz + ((sb0 + (s_ >= 0 ? s_ : 0)) * H + i) * (size_t)blk)[ec - i * hb];
+                });
+                static_for<0, UN>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    if (dst[j] >= 0) *reinterpret_cast<v2d*>(good + dst[j]) = v[j];
+                });
             }
         } else {
             for (int e = tid; e < H * blk; e += nt) {

@@ -246,8 +246,8 @@ int launch_kkt_mixed(const NewtonDev& S, const KktArgs& K0, double* ws, int* n_f
 }
 
 #ifdef CIMPC_RESID_PROF
-extern "C" int cimpc_debug_resid_prof(unsigned long long* out32) {      // diagnostic builds: read and clear the decision-stage clocks
-    unsigned long long z[32] = {0};
+extern "C" int cimpc_debug_resid_prof(unsigned long long* out32) {      // diagnostic builds: read and clear the decision-stage clocks (64 words)
+    unsigned long long z[64] = {0};
     if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(cimpc::g_resid_prof), sizeof(z)) != hipSuccess) return -1;
     return hipMemcpyToSymbol(HIP_SYMBOL(cimpc::g_resid_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }

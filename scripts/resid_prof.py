@@ -27,7 +27,7 @@ q1 = torch.tensor(np.stack([r[3] for r in ro]), dtype=torch.float64, device="cud
 lib = _lib.load()
 f = lib.cimpc_debug_resid_prof
 f.argtypes = [C.POINTER(C.c_ulonglong)]
-buf = (C.c_ulonglong * 32)()
+buf = (C.c_ulonglong * 64)()
 s.newton_solve_dev(q0.data_ptr(), q1.data_ptr(), False)
 f(buf)
 s.profile_enable(True); s.profile_reset()
@@ -36,7 +36,7 @@ for _ in range(steps):
     s.newton_solve_dev(q0.data_ptr(), q1.data_ptr(), False)
 f(buf)
 pr = s.profile_read()
-v = np.array(list(buf), dtype=np.float64).reshape(2, 16)
+v = np.array(list(buf), dtype=np.float64).reshape(4, 16)
 print("HIP-event time of the stage per round: %.1f us (%d rounds)" % (1e3 * pr["resid_ms"] / max(pr["resid_launches"], 1), pr["resid_launches"]))
 names = [["", "entry + effective-slot table", "residual rows", "norm"],
          ["", "entry checks", "decision", "statistics", "next candidates: apply_step", "next candidates: enqueue", "accept: apply_step", "res copy",
@@ -46,3 +46,7 @@ for k, kn in enumerate(("resid_slot_kernel", "resid_decide_kernel")):
     print("%s: %d workgroups (%.1f per round), mean lifetime %.2f us, longest %.2f us" % (kn, v[k, 0], v[k, 0] / max(pr["resid_launches"], 1), v[k, 13] / n / 100, v[k, 14] / 100))
     for j in range(1, len(names[k])):
         print("    %-34s %7.2f us per workgroup  %5.1f %%" % (names[k][j], v[k, j] / n / 100, 100 * v[k, j] / max(v[k, 13], 1)))
+    ns = max(v[2 + k, 0], 1)
+    print("  slow workgroups (> 30 us): %d (%.1f per round), mean lifetime %.2f us" % (v[2 + k, 0], v[2 + k, 0] / max(pr["resid_launches"], 1), v[2 + k, 13] / ns / 100))
+    for j in range(1, len(names[k])):
+        print("    %-34s %7.2f us per slow workgroup" % (names[k][j], v[2 + k, j] / ns / 100))
