@@ -179,10 +179,38 @@ __device__ __forceinline__ void apply_step(const NewtonDev& S, const TrajDev& ds
     Sync::sync();
 }
 
-// The same for `count` line-search candidates at once (evaluation slots sb_first .., step lengths 2^-(it_first + c)): one pass
-// over the accepted trajectory and the step writes every candidate, and theta is formed directly from the sources (no second pass
-// over the freshly written arrays, no barrier in between).  Same values as `count` calls of apply_step: every entry is
-// fma(-alpha, Delta, x), which is what `x - alpha * Delta` contracts to.  (Measured in the decision kernel: the four candidates of a
+// Accepting an evaluated candidate (newton.jl:273, traj <- traj - alpha*Delta): the slot already holds exactly that trajectory -
+// apply_steps formed it with the same multiply-adds - so the accept is a copy of the slot's arrays (q, u, theta, nu, and gamma, b
+// in cf mode), every load of a thread issued before its first store, instead of a second pass over traj and Delta with the theta
+// update behind a barrier (7 us in the blocks that set the length of a round's decision launch).
+template <int UN>
+__device__ __forceinline__ void copy_rows(double* __restrict__ dst, const double* __restrict__ src, int n, int tid, int nt) {
+    for (int e0 = tid; e0 < n; e0 += UN * nt) {
+        double v[UN];
+        static_for<0, UN>([&](auto jc) { constexpr int j = decltype(jc)::value; const int e = e0 + j * nt; v[j] = src[e < n ? e : 0]; });
+        static_for<0, UN>([&](auto jc) { constexpr int j = decltype(jc)::value; const int e = e0 + j * nt; if (e < n) dst[e] = v[j]; });
+    }
+}
+template <class Sync>
+__device__ __forceinline__ void accept_candidate(const NewtonDev& S, size_t sb, int b, int tid, int nt) {
+    const cimpc_dims& m = S.dm;
+    const int H = m.H, nq = m.nq, nu = m.nu, nd = S.nd, nth = S.nth;
+    copy_rows<2>(S.traj.q + (size_t)b * (H + 2) * nq, S.cand.q + sb * (H + 2) * nq, (H + 2) * nq, tid, nt);
+    copy_rows<2>(S.traj.u + (size_t)b * H * nu, S.cand.u + sb * H * nu, H * nu, tid, nt);
+    copy_rows<5>(S.traj.th + (size_t)b * H * nth, S.cand.th + sb * H * nth, H * nth, tid, nt);
+    copy_rows<2>(S.nu + (size_t)b * H * nd, S.nu_cand + sb * H * nd, H * nd, tid, nt);
+    if (m.mode == CIMPC_MODE_CONFIGURATIONFORCE) {
+        copy_rows<2>(S.traj.g + (size_t)b * H * m.nc, S.cand.g + sb * H * m.nc, H * m.nc, tid, nt);
+        copy_rows<2>(S.traj.b + (size_t)b * H * m.nb, S.cand.b + sb * H * m.nb, H * m.nb, tid, nt);
+    }
+    Sync::sync();
+}
+
+// Candidates x = traj - alpha*Delta for q_{t+2}, u_t, nu_t (+ gamma, b in cf mode) and update_theta! (th_t = [q_t; q_{t+1}; u_t; w_t;
+// mu; h], mu and h from traj) for `count` line-search candidates at once (evaluation slots sb_first .., step lengths
+// 2^-(it_first + c)): one pass over the accepted trajectory and the step writes every candidate, and theta is formed directly from
+// the sources (no second pass over the freshly written arrays, no barrier in between).  Every entry is fma(-alpha, Delta, x), which
+// is what `x - alpha * Delta` contracts to.  (Measured in the decision kernel: the four candidates of a
 // deep line search cost 4 x 4.5 us one after the other and set the length of the launch.)
 template <class Sync>
 __device__ __forceinline__ void apply_steps(const NewtonDev& S, size_t sb_first, int it_first, int count, int b, int tid, int nt) {
@@ -602,18 +630,23 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
             its += it; fails += fl;
             if (k < nref * H) { its_ref += it; fails_ref += fl; }
         }
-        // pack four small counters into the double reduction buffer (exact up to 2^53)
-        red[tid] = (double)its;
-        red[nt + tid] = (double)fails + 4096.0 * (double)fails_ref + 16777216.0 * (double)its_ref;
-        __syncthreads();
-        for (int st = nt / 2; st > 0; st >>= 1) {
-            if (tid < st) { red[tid] += red[tid + st]; red[nt + tid] += red[nt + tid + st]; }
-            __syncthreads();
+        // integer sums: inside a wavefront by lane exchange, then one partial per wavefront through the reduction buffer
+        // (one barrier instead of the nine of a 256-wide tree)
+        for (int o = 32; o > 0; o >>= 1) {
+            its += __shfl_xor(its, o, 64); fails += __shfl_xor(fails, o, 64);
+            its_ref += __shfl_xor(its_ref, o, 64); fails_ref += __shfl_xor(fails_ref, o, 64);
         }
-        const double t_its = red[0];
+        if ((tid & 63) == 0) {
+            double* w = red + 4 * (tid >> 6);
+            w[0] = (double)its; w[1] = (double)fails; w[2] = (double)its_ref; w[3] = (double)fails_ref;
+        }
+        __syncthreads();
         if (tid == 0) {
-            const long long packed = (long long)red[nt];
-            const long long t_fails = packed & 4095, t_fails_ref = (packed >> 12) & 4095, t_its_ref = packed >> 24;
+            long long t_its = 0, t_fails = 0, t_its_ref = 0, t_fails_ref = 0;
+            for (int w = 0; w < (nt + 63) / 64; ++w) {
+                t_its += (long long)red[4 * w]; t_fails += (long long)red[4 * w + 1];
+                t_its_ref += (long long)red[4 * w + 2]; t_fails_ref += (long long)red[4 * w + 3];
+            }
             S.ro_sweeps[b] += nref;
             S.ro_ip_iters[b] += (int)t_its_ref;
             S.ro_ip_fail[b] += (int)t_fails_ref;
@@ -647,7 +680,10 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
     }
     const double alpha = ls_alpha(iter);
     if (act == 1) {                       // accept: traj <- traj - alpha*Delta (newton.jl:273)
-        apply_step<BlockSync>(S, S.traj, S.nu, (size_t)b, b, alpha, tid, nt);
+        // (iter = 7: the search was exhausted - the reference steps with the HALVED alpha = 2^-7, which no slot holds, and keeps the
+        //  implicit-dynamics data of the last evaluation: newton.jl:255-262)
+        if (iter <= 6) accept_candidate<BlockSync>(S, sb0 + it0 + slot, b, tid, nt);
+        else apply_step<BlockSync>(S, S.traj, S.nu, (size_t)b, b, alpha, tid, nt);
     }
     RPROF(6)
     {   // res <- res_cand ; r_norm <- r_cand
