@@ -49,7 +49,12 @@ extern "C" {
                                     * (v_mfma_f32_16x16x4_f32), refined in fp64 against the matrix-free KKT operator (at most four
                                     * corrections, |r - R x|_inf <= 1e-9 max(1, |r|_inf)), fp64 solve for whatever does not get
                                     * there (ill-conditioned Schur blocks).  :configuration mode + TrackingObjective; anything
-                                    * else falls back to the backend `0` would pick.  BASELINE configs[4]. */
+                                    * else falls back to the backend `0` would pick.  BASELINE configs[4].
+                                    * Schedule: a KKT stage of this backend is a chain of launches (fp32 solve, fp64 check, up to
+                                    * four corrections, fp64 fallback), so newton_solve! runs on lock-step rounds ONLY - neither
+                                    * the single persistent launch of small batches nor the hybrid tail is used.  On equal
+                                    * schedules it is slower than the fp64 backend: a non-goal kept for
+                                    * the record, not a fast path. */
 
 typedef struct cimpc_ctx* cimpc_handle;
 

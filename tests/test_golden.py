@@ -38,6 +38,36 @@ def test_oracle_reproduces_golden(path):
         assert np.abs(o["dq1"] - g["sweep_dq1"][b]).max() < 1e-9
 
 
+# (name, model, mode, H_ref, H, B, seed, perturb) of tests/golden/make_golden.py
+_RECIPES = {"hopper_cfg": ("hopper", 0, 6, 5, 3, 31, 1e-2), "quadruped_cfg": ("quadruped", 0, 8, 6, 3, 32, 1e-2),
+            "pushbot_cf": ("pushbot", 1, 5, 4, 2, 33, 1e-2), "hopper_cf_newton": ("hopper", 1, 8, 6, 3, 34, 5e-3),
+            "hopper_velocity_newton": ("hopper", 0, 8, 6, 3, 35, 5e-3)}
+
+
+@pytest.mark.parametrize("name", sorted(_RECIPES))
+def test_shared_generator_is_pinned_by_the_committed_inputs(name):
+    """The seeded generator (contactimplicitmpc/jl_amd/synthetic.py) and the trajectory containers behind make_case are shared by
+    the product's host side, bench.py and the checker: the INPUT arrays of the committed fixtures are data, so
+    regenerating them pins the shared helpers - a change to the generator, to update_theta / the window arithmetic or to the
+    containers' layout shows up here instead of silently moving both sides of every parity test."""
+    from common import make_case
+    model, mode, H_ref, H, B, seed, perturb = _RECIPES[name]
+    g = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    d, prob, tabs, rollouts = make_case(model, mode, H_ref=H_ref, H=H, B=B, seed=seed, perturb=perturb)
+    for k in ("z0", "th0", "r0", "rz0", "rth0"):
+        np.testing.assert_array_equal(prob[k], g[k])
+    np.testing.assert_array_equal(np.stack([w for (w, _, _, _) in rollouts]), g["window"])
+    for k, key in (("q", "q_ref"), ("u", "u_ref"), ("w", "w_ref"), ("gamma", "gamma_ref"), ("b", "b_ref"), ("theta", "theta_ref")):
+        np.testing.assert_array_equal(np.stack([getattr(r, k) for (_, r, _, _) in rollouts]), g[key])
+    np.testing.assert_array_equal(np.stack([r[2] for r in rollouts]), g["q0"])
+    np.testing.assert_array_equal(np.stack([r[3] for r in rollouts]), g["q1"])
+    # update_theta! of the reference layout: theta_t = [q_t; q_{t+1}; u_t; w_t; mu; h]  (src/controller/trajectory.jl)
+    for (_, r, _, _) in rollouts:
+        for t in range(H):
+            np.testing.assert_array_equal(r.theta[t, :2 * d.nq], np.concatenate([r.q[t], r.q[t + 1]]))
+            np.testing.assert_array_equal(r.theta[t, 2 * d.nq:2 * d.nq + d.nu], r.u[t])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p) for p in FIXTURES])
 def test_hip_reproduces_golden(gpu_required, path):
