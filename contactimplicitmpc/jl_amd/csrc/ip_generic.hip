@@ -236,7 +236,10 @@ __global__ __launch_bounds__(64) void ip_generic_kernel(IpParams p, GenDims gd) 
         S.x0 = tVec[LinLayout::V_X0 * GW + l]; S.y10 = tVec[LinLayout::V_Y10 * GW + l]; S.y20 = tVec[LinLayout::V_Y20 * GW + l];
         // static partition of the knot's queue over the workgroups.  (A dynamic pull - lane 0 takes an index with atomicAdd and
         // broadcasts it - hung on the GPU: hipcc structurised that loop of a single-wave workgroup as a divergent loop whose
-        // latch never repeats the atomic, so lanes 1..63 re-read a stale index for ever.  The loop below has scalar control only.)
+        // latch never repeats the atomic, so lanes 1..63 re-read a stale index for ever.  The loop below has scalar control only.
+        //  Round 3 tried the scalar form of the pull - lane 0 claims, v_readfirstlane hands the index to the wave, uniform exit test:
+        //  the runtime-dimension tests did not finish within their time limit either, so the cause is not (only) the loop shape;
+        //  left for a session that can sit on the GPU with a debugger.)
         const int G0 = (int)gridDim.x;
         for (int idx = (int)blockIdx.x; idx < n; idx += G0) {
             const int prob = items[idx];
