@@ -122,7 +122,10 @@ struct cimpc_ctx {
     double* d_zout = nullptr;
     double *d_Q = nullptr, *d_R = nullptr, *d_Qinv = nullptr, *d_Rinv = nullptr, *d_Cg = nullptr,
            *d_Cb = nullptr;
-    double *d_q0 = nullptr, *d_q1 = nullptr;
+    double *d_q0 = nullptr, *d_q1 = nullptr;      // one allocation: d_q1 = d_q0 + B nq (uploaded by one copy)
+    double* h_qin = nullptr;     // pinned staging of [q0 | q1]
+    double* d_result = nullptr;  // end-of-solve result block (solve_finish_kernel): 8 + B (nu + 2) doubles
+    double* h_result = nullptr;  // ... its pinned host copy, valid from the end of a solve to the next call that touches the state
     double* d_rhs = nullptr;   // B1 seam staging
     double* d_pstate = nullptr;   // parked interior-point iterates
     int iter_cap = 28;            // (Knobs::iter_cap) measured B = 512: 16 / 20 / 24 / 32 / 48 -> 13.57 / 12.73 / 12.85 / 12.97 / 14.41 ms per batch step
@@ -518,8 +521,12 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     A(&h->d_V, H * d.nq * d.nq);
     A(&h->d_qt, H * d.nq);
     A(&h->d_vt, H * d.nq);
-    A(&h->d_q0, B * d.nq);
-    A(&h->d_q1, B * d.nq);
+    A(&h->d_q0, 2 * B * d.nq);
+    if (rc == CIMPC_OK) h->d_q1 = h->d_q0 + B * d.nq;
+    A(&h->d_result, 8 + B * (d.nu + 2));
+    if (rc == CIMPC_OK && (hipHostMalloc((void**)&h->h_qin, 2 * B * d.nq * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+                           hipHostMalloc((void**)&h->h_result, (8 + B * (d.nu + 2)) * sizeof(double), hipHostMallocDefault) != hipSuccess))
+        rc = CIMPC_ERR_HIP;
     A(&h->d_rhs, B * h->N);
     NewtonDev& S = h->S;
     S.dm = d;
@@ -653,6 +660,8 @@ int cimpc_destroy(cimpc_handle h) {
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->h_counters) (void)hipHostFree(h->h_counters);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
+    if (h->h_qin) (void)hipHostFree(h->h_qin);
+    if (h->h_result) (void)hipHostFree(h->h_result);
     {
         RoundStreams& r = h->rs;
         if (r.st) { (void)hipStreamSynchronize(r.st); (void)hipStreamDestroy(r.st); }
@@ -1041,6 +1050,14 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         HIP_TRY(h, hipStreamWaitEvent(h->rs.st, h->rs.ev_start, 0));
     }
     HIP_TRY(h, hipMemsetAsync(S.stats, 0, (size_t)h->dm.B * 4 * sizeof(long long), h->external_stream ? h->stream : h->rs.st));
+    // end of a solve: statistics, Newton iteration counts, r_norm and u_1 of every rollout in one block, one copy (queued on the
+    // solve's stream; the caller synchronises)
+    auto finish_results = [&](hipStream_t st) -> int {
+        int rf = launch_solve_finish(S, h->d_result, st);
+        if (rf != CIMPC_OK) return fail(h, rf, "result kernel launch failed");
+        HIP_TRY(h, hipMemcpyAsync(h->h_result, h->d_result, (8 + (size_t)h->dm.B * (h->dm.nu + 2)) * sizeof(double), hipMemcpyDeviceToHost, st));
+        return CIMPC_OK;
+    };
     // ---- one persistent launch: every rollout advances on its own chain (newton_async_impl.h).  Entered
     //      from the start (from_reset) or with the rollouts the lock-step rounds left active (hybrid). ----
     auto run_async = [&](bool from_reset, long long rounds_before, int next_par = -1) -> int {
@@ -1103,6 +1120,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         rc2 = launch_newton_async(&h->dm, p, Sk, std::min(h->waves, 4), a_grid, st);
         prof_end(h, st);
         if (rc2 != CIMPC_OK) return fail(h, rc2, "asynchronous newton launch failed");
+        if (int rf = finish_results(st); rf != CIMPC_OK) return rf;      // (queued behind the persistent kernel)
         // The host watches the persistent kernel: the reference's wall-clock budget ends the loop silently
         // (newton.jl:187-277), and a watchdog turns a kernel that stopped making progress into an error
         // instead of a hang (the kernel polls the host-mapped abort flag).
@@ -1126,17 +1144,13 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             fprintf(stderr, "[cimpc async] WG-ms: other %.2f kkt %.2f resid %.2f ip %.2f | jobs: kkt %lld resid %lld serve %lld | grid %d service %d | group-trips %.2fM active %.1f%% | group-ms pop %.1f fence %.1f | pop: cas %lld spins %lld claim-ms %.1f wait-ms %.1f\n",
                     dv[0] * 1e-5, dv[1] * 1e-5, dv[2] * 1e-5, dv[3] * 1e-5, dv[9], dv[10], dv[11], h->a_grid, h->a_service, dv[5] * 1e-6, dv[5] ? 100.0 * dv[4] / dv[5] : 0.0, dv[6] * 1e-5, dv[7] * 1e-5, dv[12], dv[13], dv[14] * 1e-5, dv[15] * 1e-5);
         }
-        long long stv[4];
-        if (int rs = read_stats(h, stv); rs != CIMPC_OK) return rs;
-        std::vector<int> l(h->dm.B);
-        HIP_TRY(h, hipMemcpy(l.data(), S.newton_l, l.size() * sizeof(int), hipMemcpyDeviceToHost));
+        const long long stv[4] = {(long long)h->h_result[0], (long long)h->h_result[1], (long long)h->h_result[2], (long long)h->h_result[3]};
         h->last_stats.sweeps = stv[0];
         h->last_stats.ip_solves = stv[1];
         h->last_stats.ip_iters = stv[2];
         h->last_stats.ip_failures = stv[3];
         h->last_stats.rounds = rounds_before + 1;
-        h->last_stats.newton_iters = 0;
-        for (int v : l) h->last_stats.newton_iters += v;
+        h->last_stats.newton_iters = (long long)h->h_result[4];
         h->prof_ip_problems += solved_before;
         h->prof_async_problems += stv[1] - solved_before;
         if (from_reset) h->prof_kkt_systems += h->last_stats.newton_iters;
@@ -1265,19 +1279,16 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             }
         }
     }
-    HIP_TRY(h, hipStreamSynchronize(sb.st));
     HIP_TRY(h, hipStreamSynchronize(sb.st_kkt));
-    long long st[4];
-    if (int rs = read_stats(h, st); rs != CIMPC_OK) return rs;
-    std::vector<int> l(h->dm.B);
-    HIP_TRY(h, hipMemcpy(l.data(), S.newton_l, l.size() * sizeof(int), hipMemcpyDeviceToHost));
+    if (int rf = finish_results(sb.st); rf != CIMPC_OK) return rf;
+    HIP_TRY(h, hipStreamSynchronize(sb.st));
+    const long long st[4] = {(long long)h->h_result[0], (long long)h->h_result[1], (long long)h->h_result[2], (long long)h->h_result[3]};
     h->last_stats.sweeps = st[0];
     h->last_stats.ip_solves = st[1];
     h->last_stats.ip_iters = st[2];
     h->last_stats.ip_failures = st[3];
     h->last_stats.rounds = rounds;
-    h->last_stats.newton_iters = 0;
-    for (int v : l) h->last_stats.newton_iters += v;
+    h->last_stats.newton_iters = (long long)h->h_result[4];
     h->prof_ip_problems += st[1];
     return CIMPC_OK;
 }
@@ -1285,13 +1296,23 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
 int cimpc_newton_solve(cimpc_handle h, const double* q0, const double* q1, int warm_start,
                        double* u1, int* newton_iters, double* r_norm) {
     if (!h || !q0 || !q1) return fail(h, CIMPC_ERR_INVALID, "null argument");
-    const size_t n = (size_t)h->dm.B * h->dm.nq * sizeof(double);
+    const size_t ne = (size_t)h->dm.B * h->dm.nq;
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipMemcpy(h->d_q0, q0, n, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->d_q1, q1, n, hipMemcpyHostToDevice));
+    // [q0 | q1] through the pinned staging buffer: one asynchronous copy on the caller's stream (the solve's streams wait for it
+    // on the device), and the results come back in the one block the solve leaves in pinned memory
+    std::memcpy(h->h_qin, q0, ne * sizeof(double));
+    std::memcpy(h->h_qin + ne, q1, ne * sizeof(double));
+    HIP_TRY(h, hipMemcpyAsync(h->d_q0, h->h_qin, 2 * ne * sizeof(double), hipMemcpyHostToDevice, h->stream));
     int rc = cimpc_newton_solve_dev(h, h->d_q0, h->d_q1, warm_start);
     if (rc != CIMPC_OK) return rc;
-    return cimpc_get_newton_info(h, newton_iters, r_norm, u1);
+    const int nu = h->dm.nu, w = nu + 2;
+    for (int b = 0; b < h->dm.B; ++b) {
+        const double* o = h->h_result + 8 + (size_t)b * w;
+        if (u1) std::memcpy(u1 + (size_t)b * nu, o, nu * sizeof(double));
+        if (newton_iters) newton_iters[b] = (int)o[nu];
+        if (r_norm) r_norm[b] = o[nu + 1] / (double)h->N;
+    }
+    return CIMPC_OK;
 }
 
 int cimpc_get_trajectory(cimpc_handle h, double* q, double* u, double* gamma, double* b, double* nu_dual) {

@@ -440,6 +440,34 @@ template <int NQ, int NU>
 static int launch_resid_t(const NewtonDev& S, hipStream_t s, int n_slots) {
     return S.dm.mode == CIMPC_MODE_CONFIGURATIONFORCE ? launch_resid_m<NQ, NU, true>(S, s, n_slots) : launch_resid_m<NQ, NU, false>(S, s, n_slots);
 }
+// End of a solve: what the host wants back, packed into ONE block (one device-to-host copy instead of five):
+//   out[0..3] = sums over the rollouts of NewtonDev::stats, out[4] = sum of the Newton iteration counts,
+//   out[8 + b (nu + 2) + ..] = [u_1 (nu) | newton iterations | r_norm] of rollout b   (core.traj.u[1], policy.jl:142).
+// Counts travel as doubles (exact below 2^53).
+__global__ __launch_bounds__(256) void solve_finish_kernel(NewtonDev S, double* out) {
+    __shared__ double red[5][256];
+    const int tid = threadIdx.x, B = S.dm.B, H = S.dm.H, nu = S.dm.nu, w = nu + 2;
+    double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int b = tid; b < B; b += 256) {
+        for (int k = 0; k < 4; ++k) acc[k] += (double)S.stats[(size_t)b * 4 + k];
+        acc[4] += (double)S.newton_l[b];
+        double* o = out + 8 + (size_t)b * w;
+        for (int k = 0; k < nu; ++k) o[k] = S.traj.u[(size_t)b * H * nu + k];
+        o[nu] = (double)S.newton_l[b];
+        o[nu + 1] = S.r_norm[b];
+    }
+    for (int k = 0; k < 5; ++k) red[k][tid] = acc[k];
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) for (int k = 0; k < 5; ++k) red[k][tid] += red[k][tid + st];
+        __syncthreads();
+    }
+    if (tid < 5) out[tid] = red[tid][0];
+}
+int launch_solve_finish(const NewtonDev& S, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(solve_finish_kernel, dim3(1), dim3(256), 0, s, S, out);
+    return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+}
 __global__ void queue_recycle_kernel(IpQueues Q, int par) {
     const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (k < Q.K) { *qcount(Q, par, k) = 0; *qhead(Q, k) = 0; }

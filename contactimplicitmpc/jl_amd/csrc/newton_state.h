@@ -119,6 +119,7 @@ int launch_kkt_mixed_raw(const NewtonDev& nd, const double* r_dev, double beta, 
 // packed variant: n_kkt rollouts from kkt_list[list_par], KKT_PACK per workgroup (dedicates whole CUs to the recursion)
 int launch_kkt_packed(const NewtonDev& nd, int n_kkt, int list_par, hipStream_t s, const int* n_dev = nullptr, int pipe = -1);
 int launch_queue_recycle(const IpQueues& Q, int par, hipStream_t s);
+int launch_solve_finish(const NewtonDev& nd, double* out, hipStream_t s);   // end-of-solve result block, see solve_finish_kernel
 // reference-default backend (dense jacobian! + LU with partial pivoting), any mode / objective (kkt_dense.hip)
 size_t kkt_dense_workspace_doubles(const NewtonDev& S, bool banded);
 int launch_kkt_dense_newton(const NewtonDev& S, double* ws, hipStream_t s, bool banded);
