@@ -195,7 +195,7 @@ def mpc_loop_latency(dims, kind, H, H_ref, device, steps=40, mode=0):
             its = 0
         u1, it, rn = s.newton_solve(a, b, warm_start=k > 0)
         its += int(it[0])
-        nxt = s.trajectory()["q"][:, 2].copy()
+        nxt = s.trajectory(which=("q",))["q"][:, 2].copy()
         s.mpc_advance(stride)
         a, b = b, nxt
     dt = time.perf_counter() - t0
@@ -228,7 +228,7 @@ def real_mpc_loop_latency(H, device, steps=60, perturb=0.02):
             its = 0
         u1, it, rn = s.newton_solve(a, b, warm_start=k > 0)
         its += int(it[0]); hist.append(int(it[0]))
-        nxt = s.trajectory()["q"][:, 2].copy()
+        nxt = s.trajectory(which=("q",))["q"][:, 2].copy()
         s.mpc_advance(stride)
         a, b = b, nxt
     dt = time.perf_counter() - t0

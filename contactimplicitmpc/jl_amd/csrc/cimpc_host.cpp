@@ -123,7 +123,8 @@ struct cimpc_ctx {
     double *d_Q = nullptr, *d_R = nullptr, *d_Qinv = nullptr, *d_Rinv = nullptr, *d_Cg = nullptr,
            *d_Cb = nullptr;
     double *d_q0 = nullptr, *d_q1 = nullptr;      // one allocation: d_q1 = d_q0 + B nq (uploaded by one copy)
-    double* h_qin = nullptr;     // pinned staging of [q0 | q1]
+    double* h_qin = nullptr;     // pinned staging of [q0 | q1], then nq doubles for the stride of cimpc_mpc_advance
+    bool advance_pending = false; // a cimpc_mpc_advance was queued on `stream` and not waited for (its staging word is in flight)
     double* d_result = nullptr;  // end-of-solve result block (solve_finish_kernel): 8 + B (nu + 2) doubles
     double* h_result = nullptr;  // ... its pinned host copy, valid from the end of a solve to the next call that touches the state
     double* d_rhs = nullptr;   // B1 seam staging
@@ -524,7 +525,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     A(&h->d_q0, 2 * B * d.nq);
     if (rc == CIMPC_OK) h->d_q1 = h->d_q0 + B * d.nq;
     A(&h->d_result, 8 + B * (d.nu + 2));
-    if (rc == CIMPC_OK && (hipHostMalloc((void**)&h->h_qin, 2 * B * d.nq * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+    if (rc == CIMPC_OK && (hipHostMalloc((void**)&h->h_qin, (2 * B + 1) * d.nq * sizeof(double), hipHostMallocDefault) != hipSuccess ||
                            hipHostMalloc((void**)&h->h_result, (8 + B * (d.nu + 2)) * sizeof(double), hipHostMallocDefault) != hipSuccess))
         rc = CIMPC_ERR_HIP;
     A(&h->d_rhs, B * h->N);
@@ -1402,13 +1403,19 @@ int cimpc_mpc_advance(cimpc_handle h, const double* stride) {
     if (!h || !stride) return fail(h, CIMPC_ERR_INVALID, "null argument");
     if (!h->window_set || !h->reference_set) return fail(h, CIMPC_ERR_STATE, "set_window / set_reference have not been called");
     HIP_TRY(h, hipSetDevice(h->device));
+    // The advance is QUEUED on the handle's stream and not waited for: whatever comes next is ordered behind it on the device
+    // (the solve's streams wait for this stream, every getter synchronises it first).  The stride goes through a pinned word;
+    // a second advance in a row waits for the first one's copy to have left it.
+    if (h->advance_pending) { HIP_TRY(h, hipStreamSynchronize(h->stream)); h->advance_pending = false; }
+    double* st_pin = h->h_qin + 2 * (size_t)h->dm.B * h->dm.nq;
+    std::memcpy(st_pin, stride, (size_t)h->dm.nq * sizeof(double));
     if (h->gait_set) {          // full reference resident: regenerate the horizon from the gait (stride as given now)
-        HIP_TRY(h, hipMemcpyAsync(h->g_stride, stride, (size_t)h->dm.nq * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->g_stride, st_pin, (size_t)h->dm.nq * sizeof(double), hipMemcpyHostToDevice, h->stream));
         if (int rk = rekey_out(h); rk != CIMPC_OK) return rk;
         int rcg = launch_gait_window(h->S, gait_dev(h), h->d_window, 1, h->stream);
         if (rcg != CIMPC_OK) return fail(h, rcg, "mpc_advance launch failed");
         if (int rk = rekey_in(h); rk != CIMPC_OK) return rk;
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->advance_pending = true;
         return CIMPC_OK;
     }
     HIP_TRY(h, hipMemcpyAsync(h->d_q0, stride, (size_t)h->dm.nq * sizeof(double), hipMemcpyHostToDevice, h->stream));   // d_q0: staging

@@ -268,13 +268,15 @@ class CIMPCSolver:
         self._check(self.lib.cimpc_get_newton_info(self.h, _ipt(it), _dp(rn), _dp(u1)), "get_newton_info")
         return u1, it, rn
 
-    def trajectory(self):
+    def trajectory(self, which=("q", "u", "gamma", "b", "nu")):
+        """core.traj after the last solve.  `which` limits the download (cimpc_get_trajectory skips NULL outputs: a control loop
+        that only wants the planned configurations asks for ("q",) - one device-to-host copy instead of five)."""
         B, H = self.B, self.H
-        q = np.zeros((B, H + 2, self.nq)); u = np.zeros((B, H, self.nu))
-        g = np.zeros((B, H, self.nc)); b = np.zeros((B, H, self.nb)); nu_dual = np.zeros((B, H, self.nd))
-        self._check(self.lib.cimpc_get_trajectory(self.h, _dp(q), _dp(u), _dp(g), _dp(b), _dp(nu_dual)),
-                    "get_trajectory")
-        return dict(q=q, u=u, gamma=g, b=b, nu=nu_dual)
+        shapes = dict(q=(B, H + 2, self.nq), u=(B, H, self.nu), gamma=(B, H, self.nc), b=(B, H, self.nb), nu=(B, H, self.nd))
+        out = {k: np.zeros(shapes[k]) for k in ("q", "u", "gamma", "b", "nu") if k in which}
+        P = lambda k: _dp(out[k]) if k in out else None
+        self._check(self.lib.cimpc_get_trajectory(self.h, P("q"), P("u"), P("gamma"), P("b"), P("nu")), "get_trajectory")
+        return out
 
     def mpc_advance(self, stride):
         """rot_n_stride!(p.traj, ..., p.stride, p.window) + update_window! (policy.jl:136-139) on the device."""
