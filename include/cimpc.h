@@ -243,7 +243,10 @@ int cimpc_get_rollout_counters(cimpc_handle h, int* sweeps, int* ip_iters, int* 
  * stride: nq doubles (get_stride, mpc_utils.jl:103-107), shared by the rollouts.
  * The Newton iterate (core.traj, nu) stays resident for warm_start = 1, as in the reference.
  * After cimpc_set_reference the H_mpc-knot arrays are rotated in place - the reference's policy only when
- * H_mpc = H_ref; after cimpc_set_gait (below) the horizon is regenerated from the full trajectory for any H_mpc. */
+ * H_mpc = H_ref; after cimpc_set_gait (below) the horizon is regenerated from the full trajectory for any H_mpc.
+ * Ordering: after cimpc_set_gait the call returns once the update is QUEUED on the handle's stream (`stride` has been copied);
+ * every later call on the handle is ordered behind it - solves wait for it on the device, getters synchronise first - so a
+ * control loop does not pay a host round trip for it.  A launch error of the update surfaces at the next synchronising call. */
 int cimpc_mpc_advance(cimpc_handle h, const double* stride);
 
 /* The controller's FULL reference trajectory (p.traj / p.ref_traj of the CIMPC policy, policy.jl:70-96): H_ref
