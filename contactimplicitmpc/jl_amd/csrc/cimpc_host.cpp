@@ -1178,7 +1178,14 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     long long launched = 0, completed = 0, rounds = 0;
     const bool dbg_rounds = h->kn.debug_rounds;
     int last_kkt = 0, last_sweep = h->dm.B, last_slots = h->dm.B;
-    auto launch_round = [&](long long r) -> int {
+    // Single rollouts (B < 4: below the persistent kernel's range) keep ONE round queued ahead of the one the host waits for: such a
+    // round is launched BLIND - KKT kernel on the full list range with its count read on the device, everything else is
+    // device-driven anyway - and costs three empty launches if the solve turns out to be over; in exchange no round waits for the
+    // host to see the previous one's stamp and launch (about 10 us per round of a 0.7 ms solve).  Warm-started solves only - the
+    // cadence of an MPC loop, five Newton iterations over eight to ten rounds: hopper H = 20 0.652 -> 0.614 ms per MPC step; the
+    // four rounds of a cold start lose more to the empty launches than they gain (0.685 -> 0.706 ms).
+    const bool ahead = h->dm.B < 4 && !h->use_mixed && warm_start != 0;
+    auto launch_round = [&](long long r, bool blind) -> int {
         // [KKT for rollouts that start an iteration] || sweep -> residual of every evaluated slot -> line-search decision
         const int slot = (int)(r & 1), par = (int)(r & 1);      // round r consumes Q[par] and leaves the next round's requests in Q[par ^ 1]
         int* d_cnt = h->d_ring + 8 * CPAD * slot;
@@ -1189,13 +1196,15 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         Sk.A.n_done = hybrid ? h->a_ctrl + 2 * (size_t)h->Q.K * QPAD + 8 : nullptr;
         Sk.round_stamp = (int)(r + 1);
         Sk.WQ = h->Q; Sk.WQ.par = par;       // the queue being consumed
-        const bool kkt = (r > 0) && last_kkt > 0;
-        const int pipe = h->kn.kkt_pipe >= 0 ? h->kn.kkt_pipe : (!h->kkt_overlap && last_kkt <= h->kn.kkt_pipe_max) ? 1 : 0;
+        const bool kkt = (r > 0) && (blind || last_kkt > 0);
+        const int n_kkt = blind ? h->dm.B : last_kkt;
+        const int* n_kkt_dev = blind ? h->d_ring + 8 * CPAD * (slot ^ 1) + 1 * CPAD : nullptr;      // the previous round's count of KKT requests
+        const int pipe = h->kn.kkt_pipe >= 0 ? h->kn.kkt_pipe : (!h->kkt_overlap && n_kkt <= h->kn.kkt_pipe_max) ? 1 : 0;
         if (kkt && !h->kkt_overlap) {   // small batches: latency matters, keep the KKT result in this round
             Sk.kkt_same_round = 1;
             prof_begin(h, PC_KKT, sb.st);
             // (same compact list / packed or pipelined kernel as the overlapped path)
-            int rr = (h->use_dense || h->use_mixed) ? launch_kkt_general(h, Sk, sb.st) : launch_kkt_packed(Sk, last_kkt, par ^ 1, sb.st, nullptr, pipe);
+            int rr = (h->use_dense || h->use_mixed) ? launch_kkt_general(h, Sk, sb.st) : launch_kkt_packed(Sk, n_kkt, par ^ 1, sb.st, n_kkt_dev, pipe);
             prof_end(h, sb.st);
             if (rr != CIMPC_OK) return fail(h, rr, "kkt launch failed");
         }
@@ -1246,9 +1255,11 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             (void)hipStreamSynchronize(sb.st); (void)hipStreamSynchronize(sb.st_kkt);
             return fail(h, CIMPC_ERR_STATE, "newton_solve: round limit reached with unfinished rollouts");
         }
-        rc = launch_round(launched);
-        if (rc != CIMPC_OK) return rc;
-        ++launched;
+        while (launched <= completed + (ahead ? 1 : 0)) {
+            rc = launch_round(launched, launched > completed);
+            if (rc != CIMPC_OK) return rc;
+            ++launched;
+        }
         {   // the decision kernel's last block stamps the mapped flag when round `completed` is done
             volatile int* hm = (volatile int*)h->h_ring + 8 * (completed & 1);
             const int want = (int)(completed + 1);
