@@ -1212,7 +1212,8 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             // KKT of the rollouts that start a Newton iteration, next to the sweep on its own stream.  No fork
             // event: the host has seen the previous round's stamp, so everything before is complete (every decision
             // block releases its results before it takes its ticket).  (Launched BEFORE the sweep: the other order was
-            // measured 10 % slower - the KKT recursion is the longer leg of most rounds.)
+            // measured 10 % slower in round 1 and 20 % slower in round 3 (8.37 -> 10.05 ms, profiles/r03/knob_order.log) - behind the
+            // persistent sweep the KKT workgroups wait for sweep workgroups to leave: 3.6 -> 6.2 ms of KKT time per step.)
             prof_begin(h, PC_KKT, sb.st_kkt);
             // the list was built by the decision kernel of the previous round (its queue parity)
             int rk = (h->use_dense || h->use_mixed) ? launch_kkt_general(h, Sk, sb.st_kkt)
