@@ -307,6 +307,9 @@ IpParams make_ip_params(cimpc_ctx* h, const TrajDev& T, int par, int* pending_co
     p.slots = CS;
     p.H = h->dm.H;
     p.o = h->ip;
+    p.kc_floor = h->ip.kappa_tol / h->ip.undercut;
+    p.tau_floor = 1.0 - h->ip.eps_min;
+    p.reg_floor = h->ip.kappa_tol * h->ip.gamma_reg;
     return p;
 }
 

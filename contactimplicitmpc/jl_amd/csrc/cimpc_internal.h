@@ -153,6 +153,12 @@ struct IpParams {
     int slots;             // evaluation slots per rollout: rollout = slot index / slots
     int H;
     cimpc_ip_opts o;
+    // uniform constants of an iteration, formed on the host (IEEE division / subtraction: the values the kernel's own expressions
+    // give) so that they arrive as scalars: computed in the kernel they were loop-invariant VECTOR registers that spilled to
+    // scratch and were re-loaded in every interior-point trip
+    double kc_floor;    // o.kappa_tol / o.undercut
+    double tau_floor;   // 1 - o.eps_min
+    double reg_floor;   // o.kappa_tol * o.gamma_reg (regularisation floor of differentiate_solution!)
     AsyncQ A;
 };
 

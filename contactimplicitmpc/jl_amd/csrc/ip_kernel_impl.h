@@ -267,7 +267,7 @@ struct IpSolver {
 
     // ONE interior-point iteration (DESIGN.md "IP iteration spec").  Returns true when the step
     // length stalled (the solve fails).  Convergence / iteration-budget checks are the caller's.
-    __device__ __forceinline__ bool iterate(const cimpc_ip_opts& o, double& reg, double& r_vio, double& k_vio) {
+    __device__ __forceinline__ bool iterate(const cimpc_ip_opts& o, double kc_floor, double tau_floor, double& reg, double& r_vio, double& k_vio) {
         reg = (k_vio < o.kappa_reg) ? k_vio * o.gamma_reg : 0.0;
         factorize(reg);
         linear_solve();                                   // predictor
@@ -277,12 +277,12 @@ struct IpSolver {
             LG::all_sum(vy ? (y1 - a_aff * Dy1_) * (y2 - a_aff * Dy2_) : 0.0) / (double)NY;
         double sg = fmin(fmax(mu_aff / mu, 0.0), 1.0);
         sg = sg * sg * sg;
-        const double kc = fmax(sg * mu, o.kappa_tol / o.undercut);
+        const double kc = fmax(sg * mu, kc_floor);                 // = o.kappa_tol / o.undercut (IpParams::kc_floor)
         // corrector residual: rdyn, rrst unchanged (same z), rbil = y1*y2 - kc + Dy1*Dy2
         rbil = vy ? ((y1 * y2 - kc) + Dy1_ * Dy2_) : 0.0;
         linear_solve();                                   // corrector
         const double vm = fmax(r_vio, k_vio);
-        const double tau = fmax(1.0 - o.eps_min, 1.0 - vm * vm);
+        const double tau = fmax(tau_floor, 1.0 - vm * vm);         // tau_floor = 1 - o.eps_min
         const double alpha = step_length(tau);
         if (alpha < o.stall_alpha) return true;           // [spec] stall exit: jammed on the boundary
         x -= alpha * Dx_;
@@ -361,11 +361,13 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
     const bool vx = S.vx, vy = S.vy;
     const size_t pi = (size_t)prob;
     const double* ps = p.pstate + pi * PS;
-    S.x = vx ? ps[l] : 0.0;
-    S.y1 = vy ? ps[NX + l] : 1.0;
-    S.y2 = vy ? ps[NX + NY + l] : 1.0;
+    int lg = l;                          // (lane index of the global-memory addresses: opaque, see serve_knot)
+    asm volatile("" : "+v"(lg));
+    S.x = vx ? ps[lg] : 0.0;
+    S.y1 = vy ? ps[NX + lg] : 1.0;
+    S.y2 = vy ? ps[NX + NY + lg] : 1.0;
     const double reg = LG::template bcast<0>((l == 0) ? ps[PS - 2] : 0.0);
-    S.factorize(fmax(reg, p.o.kappa_tol * p.o.gamma_reg));
+    S.factorize(fmax(reg, p.reg_floor));          // = o.kappa_tol * o.gamma_reg (IpParams::reg_floor)
     double* dzo = p.dz + pi * (size_t)(NTHS * ND);
     // delta^T nu of every column (IpParams::dtn).  The columns of a chunk are parked in the R tile (idle once the rows of R sit
     // in registers), then lane j sums column j with the SAME multiply-add chain the decision stage would run on the stored
@@ -380,17 +382,17 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
     [[maybe_unused]] double nuy = 0.0;
     if (want) {
         const double* nv = p.nu + pi * ND;
-        nux = vx ? xld<ASYNC>(nv + l) : 0.0;
-        if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) nuy = (l < NC + NB) ? xld<ASYNC>(nv + NX + l) : 0.0;
+        nux = vx ? xld<ASYNC>(nv + lg) : 0.0;
+        if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) nuy = (l < NC + NB) ? xld<ASYNC>(nv + NX + lg) : 0.0;
     }
     auto column = [&](int c, int cc) {
         const double u = tab[L.oRthDyn + c * G + l];
         const double v = tab[L.oRthRst + c * G + l];
         double xs;
         const double t = S.schur_solve(u, v, xs);
-        if (vx) xst<ASYNC>(dzo + c * ND + l, -xs);
+        if (vx) xst<ASYNC>(dzo + c * ND + lg, -xs);
         if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) {
-            if (l < NC + NB) xst<ASYNC>(dzo + c * ND + NX + l, t);   // -(S.y) = +temp
+            if (l < NC + NB) xst<ASYNC>(dzo + c * ND + NX + lg, t);   // -(S.y) = +temp
         }
         if (want) {
             if (vx) scr[cc * ND + l] = -xs;
@@ -430,7 +432,7 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
             static_for<0, NX>([&](auto kc) { constexpr int k = decltype(kc)::value; s_ = fma(col[k], LG::template bcast<k>(nux), s_); });
             if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE)
                 static_for<0, NC + NB>([&](auto kc) { constexpr int k = decltype(kc)::value; s_ = fma(col[NX + k], LG::template bcast<k>(nuy), s_); });
-            if (l < n) xst<ASYNC>(p.dtn + pi * (size_t)M::DTN_LD + c0 + l, s_);
+            if (l < n) xst<ASYNC>(p.dtn + pi * (size_t)M::DTN_LD + c0 + lg, s_);
             wave_lds_fence();
         }
     }
@@ -527,6 +529,11 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
     while (true) {
         [[maybe_unused]] const long long sp_a = SPROF_T();
         [[maybe_unused]] bool draining = false;
+        // lane index as the GLOBAL-memory address expressions of this trip see it: opaque per trip, so that `pointer + 8 l` is
+        // formed where it is used (end of a solve, pull) instead of being hoisted out of the loop - a dozen loop-invariant 64-bit
+        // lane addresses were live across the interior-point iteration, spilled to scratch and re-loaded every trip
+        int lg = l;
+        asm volatile("" : "+v"(lg));
         if constexpr (!ASYNC) {
             if (p.drain_count != nullptr) {
                 draining = __builtin_amdgcn_readfirstlane(drain_raw) >= p.drain_thresh;
@@ -546,8 +553,8 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
                 const int sb = prob / p.H;
                 double* ps = p.pstate + pi * PS;
                 if (code == 2) {             // park: exact state, re-queued for the next round
-                    if (vx) { ps[l] = S.x; ps[NX + 2 * NY + l] = S.rdyn; }
-                    if (vy) { ps[NX + l] = S.y1; ps[NX + NY + l] = S.y2; ps[2 * NX + 2 * NY + l] = S.rrst; ps[2 * NX + 3 * NY + l] = S.rbil; }
+                    if (vx) { ps[lg] = S.x; ps[NX + 2 * NY + lg] = S.rdyn; }
+                    if (vy) { ps[NX + lg] = S.y1; ps[NX + NY + lg] = S.y2; ps[2 * NX + 2 * NY + lg] = S.rrst; ps[2 * NX + 3 * NY + lg] = S.rbil; }
                     if (l == 0) {
                         ps[PS - 4] = r_vio; ps[PS - 3] = k_vio; ps[PS - 2] = reg; ps[PS - 1] = (double)iters;
                         p.pflag[pi] = 1;
@@ -558,19 +565,19 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
                 } else {
                     if (l == 0) { xst<ASYNC>(p.status + pi, code); xst<ASYNC>(p.iters + pi, iters); }
                     // d = z[1:nd] - [q_{i+2}; gamma_i; b_i]  (implicit_dynamics.jl:180-190)
-                    if (vx) xst<ASYNC>(p.d + pi * ND + l, S.x - qinit);
+                    if (vx) xst<ASYNC>(p.d + pi * ND + lg, S.x - qinit);
                     if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) {
-                        if (l < NC) xst<ASYNC>(p.d + pi * ND + NX + l, S.y1 - xld<ASYNC>(p.gam + pi * NC + l));
-                        else if (l < NC + NB) xst<ASYNC>(p.d + pi * ND + NX + l, S.y1 - xld<ASYNC>(p.bfr + pi * NB + (l - NC)));
+                        if (l < NC) xst<ASYNC>(p.d + pi * ND + NX + lg, S.y1 - xld<ASYNC>(p.gam + pi * NC + lg));
+                        else if (l < NC + NB) xst<ASYNC>(p.d + pi * ND + NX + lg, S.y1 - xld<ASYNC>(p.bfr + pi * NB + (lg - NC)));
                     }
                     if (p.zout != nullptr) {
                         double* zo = p.zout + pi * M::NZ;
-                        if (vx) zo[l] = S.x;
-                        if (vy) { zo[NX + l] = S.y1; zo[NX + NY + l] = S.y2; }
+                        if (vx) zo[lg] = S.x;
+                        if (vy) { zo[NX + lg] = S.y1; zo[NX + NY + lg] = S.y2; }
                     }
                     if (code == 1) {         // converged: z* parked, sensitivities deferred to an idle moment
-                        if (vx) ps[l] = S.x;
-                        if (vy) { ps[NX + l] = S.y1; ps[NX + NY + l] = S.y2; }
+                        if (vx) ps[lg] = S.x;
+                        if (vy) { ps[NX + lg] = S.y1; ps[NX + NY + lg] = S.y2; }
                         if (l == 0) ps[PS - 2] = reg;
                         push = true;
                     } else {                 // failed: the slot keeps its previous sensitivities
@@ -613,7 +620,7 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
                 const int sb = prob / p.H, i = prob - sb * p.H;
                 const size_t pi = (size_t)prob;
                 const double* th = p.theta + pi * NTH;
-                for (int k = l; k < NTH; k += G) dth[k] = xld<ASYNC>(th + k) - tab[L.oTh0 + k];
+                for (int k = lg; k < NTH; k += G) dth[k] = xld<ASYNC>(th + k) - tab[L.oTh0 + k];
                 wave_lds_fence();
                 {   // rthdyn*(th-th0), rthrst*(th-th0): constant per solve
                     double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
@@ -633,17 +640,17 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
                     S.tthdyn = a0 + a1;
                     S.tthrst = c0 + c1;
                 }
-                S.altl = (p.alt != nullptr && l < NC) ? p.alt[(size_t)(sb / p.slots) * NC + l] : 0.0;
+                S.altl = (p.alt != nullptr && l < NC) ? p.alt[(size_t)(sb / p.slots) * NC + lg] : 0.0;
                 const double* qrow = p.q + ((size_t)sb * (p.H + 2) + (i + 2)) * M::NQ;
-                qinit = vx ? xld<ASYNC>(qrow + l) : 0.0;
+                qinit = vx ? xld<ASYNC>(qrow + lg) : 0.0;
                 const double* ps = p.pstate + pi * PS;
                 if (p.pflag[pi] == 1) {      // resume a parked solve
-                    S.x = vx ? ps[l] : 0.0;
-                    S.y1 = vy ? ps[NX + l] : 1.0;
-                    S.y2 = vy ? ps[NX + NY + l] : 1.0;
-                    S.rdyn = vx ? ps[NX + 2 * NY + l] : 0.0;
-                    S.rrst = vy ? ps[2 * NX + 2 * NY + l] : 0.0;
-                    S.rbil = vy ? ps[2 * NX + 3 * NY + l] : 0.0;
+                    S.x = vx ? ps[lg] : 0.0;
+                    S.y1 = vy ? ps[NX + lg] : 1.0;
+                    S.y2 = vy ? ps[NX + NY + lg] : 1.0;
+                    S.rdyn = vx ? ps[NX + 2 * NY + lg] : 0.0;
+                    S.rrst = vy ? ps[2 * NX + 2 * NY + lg] : 0.0;
+                    S.rbil = vy ? ps[2 * NX + 3 * NY + lg] : 0.0;
                     r_vio = ps[PS - 4]; k_vio = ps[PS - 3]; reg = ps[PS - 2]; iters = (int)ps[PS - 1];
                     wave_lds_fence();
                     if (l == 0) p.pflag[pi] = 0;
@@ -685,7 +692,7 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
             if (have && !(r_vio < o.r_tol && k_vio < o.kappa_tol) && iters < o.max_iter && done_here < p.iter_cap) {
                 ++done_here;
                 ++iters;
-                stalled = S.iterate(o, reg, r_vio, k_vio);
+                stalled = S.iterate(o, p.kc_floor, p.tau_floor, reg, r_vio, k_vio);
             }
         } else {
             // one problem per group while the list holds that many; a shorter list (only when the wave has nothing else to do, or
