@@ -139,6 +139,11 @@ struct IpSolver {
     // four partial sums, 1/|a_k| comes from v_rsq_f64 + two Newton steps on the broadcast self-product of column k.
     __device__ __forceinline__ void factorize(double reg) {
         const double* tW = tab + L.oW;
+        // lane index of the 3 NY lane compares below (l == r, l == k, l > k), opaque per call: as loop invariants the 48 masks were
+        // hoisted out of every loop, overflowed the scalar register file and came back through v_readlane pairs at every use -
+        // one v_cmp where it is needed is cheaper than two v_readlane
+        int lq = l;
+        asm volatile("" : "+v"(lq));
         y1r = fmax(y1, reg);
         y2r = fmax(y2, reg);
         iy1r = fast_rcp(y1r);
@@ -146,7 +151,7 @@ struct IpSolver {
         static_for<0, NY>([&](auto ic) {
             constexpr int r = decltype(ic)::value;
             const double w = tW[r * G + l];                 // Ry1[r,l] - CAiB[r,l]   (r != l)
-            Qc[r] = (l == r) ? ((ry1d - dd) - caibd) : w;   // (D - CAiB)[r,l]
+            Qc[r] = (lq == r) ? ((ry1d - dd) - caibd) : w;  // (D - CAiB)[r,l]
         });
         // Column l stays UNNORMALISED in Qc (q_l = Qc * rdinv); the projection coefficients are
         // r_kj = (a_k . a_j) / |a_k| and the update a_j -= (r_kj / |a_k|) a_k - the same numbers as
@@ -170,9 +175,9 @@ struct IpSolver {
             // |a_k|^2 is lane k's own dot product (there a_k[r] * a_k[r], the same four partial sums a separate
             // norm loop would form): one broadcast instead of 16 multiply-adds per step
             const double invk = fast_rsqrt(LG::template bcast<k>(dot));
-            rdinv = (l == k) ? invk : rdinv;
+            rdinv = (lq == k) ? invk : rdinv;
             double rk = dot * invk;
-            rk = ((l > k) && vy) ? rk : 0.0;
+            rk = ((lq > k) && vy) ? rk : 0.0;
             const double ncoef = -(rk * invk);          // zero in lanes <= k: column k itself stays as it is during the update
             if constexpr (G == 16) {
                 Dpp16::self<k, NY>(Qc, ncoef);       // a_l -= (r_kl / |a_k|) a_k
