@@ -176,9 +176,11 @@ struct IpSolver {
             // norm loop would form): one broadcast instead of 16 multiply-adds per step
             const double invk = fast_rsqrt(LG::template bcast<k>(dot));
             rdinv = (lq == k) ? invk : rdinv;
-            double rk = dot * invk;
-            rk = ((lq > k) && vy) ? rk : 0.0;
-            const double ncoef = -(rk * invk);          // zero in lanes <= k: column k itself stays as it is during the update
+            // -r_kl = -(dot * invk), formed with the sign on the multiplier (exact) and kept NEGATED from here on: the tile then holds
+            // -R, which is what the back-substitution adds - the 16 sign flips per factorization after the transposed read are gone
+            double nrk = dot * -invk;
+            nrk = ((lq > k) && vy) ? nrk : -0.0;       // (-0.0: the masked entries keep the sign they had as -(+0.0))
+            const double ncoef = nrk * invk;            // -(r_kl / |a_k|); zero in lanes <= k: column k itself stays as it is during the update
             if constexpr (G == 16) {
                 Dpp16::self<k, NY>(Qc, ncoef);       // a_l -= (r_kl / |a_k|) a_k
             } else {
@@ -187,12 +189,12 @@ struct IpSolver {
                     Qc[r] = fma(ncoef, ak[r], Qc[r]);
                 });
             }
-            Rst[k * M::RST_LD + l] = rk;   // R[k,l], l > k (zeros elsewhere)
+            Rst[k * M::RST_LD + l] = nrk;  // -R[k,l], l > k (zeros elsewhere)
         });
         wave_lds_fence();
         static_for<0, NY>([&](auto kc) {   // row l of R (transpose through the LDS tile)
             constexpr int k = decltype(kc)::value;
-            Rr[k] = vy ? -Rst[l * M::RST_LD + k] : 0.0;      // kept negated: the back-substitution adds
+            Rr[k] = vy ? Rst[l * M::RST_LD + k] : 0.0;       // -R[l,k] (stored negated): the back-substitution adds
         });
         wave_lds_fence();
     }

@@ -65,20 +65,34 @@ struct LaneGroup {
         return __builtin_amdgcn_update_dpp(0.0, v, 0x128, 0xF, 0xF, true);
     }
 
+    // max / min of two doubles as ONE instruction.  fmax / fmin compile to v_max_f64 / v_min_f64 PLUS a canonicalising
+    // v_max_f64 x, x, x of every operand the compiler cannot prove quiet (IEEE mode: signalling NaNs) - in the butterfly below
+    // that is the freshly moved operand of every step, 5 extra instructions per reduction, 30 per interior-point iteration.
+    // No signalling NaN exists in these kernels (nothing loads raw bit patterns as doubles), and quiet NaNs behave the same.
+    static __device__ __forceinline__ double max2(double a, double b) {
+        double r;
+        asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    }
+    static __device__ __forceinline__ double min2(double a, double b) {
+        double r;
+        asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    }
     static __device__ __forceinline__ double all_max(double v) {
-        v = fmax(v, dpp_xor1(v));
-        v = fmax(v, dpp_xor2(v));
-        v = fmax(v, dpp_ror4(v));
-        v = fmax(v, dpp_ror8(v));
-        if constexpr (G == 32) v = fmax(v, __shfl_xor(v, 16, 64));
+        v = max2(v, dpp_xor1(v));
+        v = max2(v, dpp_xor2(v));
+        v = max2(v, dpp_ror4(v));
+        v = max2(v, dpp_ror8(v));
+        if constexpr (G == 32) v = max2(v, __shfl_xor(v, 16, 64));
         return v;
     }
     static __device__ __forceinline__ double all_min(double v) {
-        v = fmin(v, dpp_xor1(v));
-        v = fmin(v, dpp_xor2(v));
-        v = fmin(v, dpp_ror4(v));
-        v = fmin(v, dpp_ror8(v));
-        if constexpr (G == 32) v = fmin(v, __shfl_xor(v, 16, 64));
+        v = min2(v, dpp_xor1(v));
+        v = min2(v, dpp_xor2(v));
+        v = min2(v, dpp_ror4(v));
+        v = min2(v, dpp_ror8(v));
+        if constexpr (G == 32) v = min2(v, __shfl_xor(v, 16, 64));
         return v;
     }
     // sum over the group WITHOUT the re-broadcast: every lane holds the sum in its own association (rotation-based reductions
