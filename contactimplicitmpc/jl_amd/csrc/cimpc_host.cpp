@@ -392,7 +392,7 @@ int check_ready(cimpc_ctx* h, bool need_newton) {
 
 extern "C" {
 
-int cimpc_version(void) { return 100; }
+int cimpc_version(void) { return 103; }      // 1.03: round 3 (B2 entries, cimpc_kkt_solve_rho, CIMPC_ERR_SINGULAR, queued cimpc_mpc_advance)
 
 void cimpc_default_ip_opts(cimpc_ip_opts* o) {
     if (!o) return;
