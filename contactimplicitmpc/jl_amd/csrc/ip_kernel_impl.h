@@ -627,7 +627,26 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
                 const int sb = prob / p.H, i = prob - sb * p.H;
                 const size_t pi = (size_t)prob;
                 const double* th = p.theta + pi * NTH;
-                for (int k = lg; k < NTH; k += G) dth[k] = xld<ASYNC>(th + k) - tab[L.oTh0 + k];
+                // every input that depends on the problem id alone is REQUESTED here, in one batch, before the first LDS hand-over:
+                // theta (the runtime loop over its two chunks waited for each load in turn), the rollout's altitude, the initial
+                // configuration and the parked-solve flag (the fences of the hand-over kept these loads behind it - the pull was
+                // five to six dependent round trips instead of three: claim, problem id, inputs)
+                constexpr int NTC = (NTH + G - 1) / G;
+                double thv[NTC];
+                static_for<0, NTC>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const int k = lg + j * G;
+                    thv[j] = xld<ASYNC>(th + (k < NTH ? k : 0));
+                });
+                const double alt_in = (p.alt != nullptr && l < NC) ? p.alt[(size_t)(sb / p.slots) * NC + lg] : 0.0;
+                const double* qrow = p.q + ((size_t)sb * (p.H + 2) + (i + 2)) * M::NQ;
+                const double q_in = vx ? xld<ASYNC>(qrow + lg) : 0.0;
+                const int parked_in = p.pflag[pi];
+                static_for<0, NTC>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const int k = l + j * G;
+                    if (k < NTH) dth[k] = thv[j] - tab[L.oTh0 + k];
+                });
                 wave_lds_fence();
                 {   // rthdyn*(th-th0), rthrst*(th-th0): constant per solve
                     double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
@@ -647,11 +666,10 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
                     S.tthdyn = a0 + a1;
                     S.tthrst = c0 + c1;
                 }
-                S.altl = (p.alt != nullptr && l < NC) ? p.alt[(size_t)(sb / p.slots) * NC + lg] : 0.0;
-                const double* qrow = p.q + ((size_t)sb * (p.H + 2) + (i + 2)) * M::NQ;
-                qinit = vx ? xld<ASYNC>(qrow + lg) : 0.0;
+                S.altl = alt_in;
+                qinit = q_in;
                 const double* ps = p.pstate + pi * PS;
-                if (p.pflag[pi] == 1) {      // resume a parked solve
+                if (parked_in == 1) {        // resume a parked solve
                     S.x = vx ? ps[lg] : 0.0;
                     S.y1 = vy ? ps[NX + lg] : 1.0;
                     S.y2 = vy ? ps[NX + NY + lg] : 1.0;
