@@ -589,6 +589,7 @@ def main():
                      "ip_problems_in_rounds": prof["ip_sweep_problems"] / args.steps,
                      "ip_problems_in_async_tail": prof["async_problems"] / args.steps},
         "setup_s": t_setup,
+        "csrc_sha16": csrc_hash(),      # identity of the kernel sources this line was measured on
     }
     if multi is not None:
         out["multi_gpu"] = multi
