@@ -1229,7 +1229,8 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         // parking (iter_cap) protects a busy round from one long solve; in the sparse tail of a solve
         // it only adds rounds, so a round that serves few rollouts lets every solve run to the end
         const int tail_div = h->kn.tail_div;
-        const int cap = (tail_div > 0 && last_sweep * tail_div <= h->dm.B) ? h->ip.max_iter : h->iter_cap;
+        // (batches below tail_div rollouts never park: a round there is as long as its longest solve whichever way it is cut)
+        const int cap = (tail_div > 0 && last_sweep * tail_div <= std::max(h->dm.B, tail_div)) ? h->ip.max_iter : h->iter_cap;
         int rr = run_sweep(h, par, d_cnt + 2 * CPAD, nullptr, sb.st, cap, d_cnt + 3 * CPAD, true);
         if (rr != CIMPC_OK) return rr;
         if (kkt && h->kkt_overlap && hipStreamWaitEvent(sb.st, sb.ev_join, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join failed");
