@@ -1237,7 +1237,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         prof_begin(h, PC_RESID, sb.st);
         // the evaluation slots of this round: the compact list its requesters built (small batches run the KKT stage in the same
         // round as the evaluation of its candidates - not known to the host at launch: every (rollout, slot) pair gets a block there)
-        rr = launch_resid_decide(Sk, sb.st, h->kkt_overlap ? last_slots : -1);
+        rr = launch_resid_decide(Sk, sb.st, h->kkt_overlap ? last_slots : (h->dm.B < 4 ? -2 : -1));
         prof_end(h, sb.st);
         if (rr != CIMPC_OK) return fail(h, rr, "residual launch failed");
         return CIMPC_OK;

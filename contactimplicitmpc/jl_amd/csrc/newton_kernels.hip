@@ -422,7 +422,9 @@ int launch_reset(const NewtonDev& S, const double* q0, const double* q1, int war
 template <int NQ, int NU, bool CF>
 static int launch_resid_m(const NewtonDev& S, hipStream_t s, int n_slots) {
     const size_t lds2 = (size_t)2 * CIMPC_RESID_THREADS * sizeof(double);
-    if (n_slots < 0) {      // small batches: one launch, the rollout's slots one after the other in its workgroup
+    if (n_slots == -1) {    // small batches: one launch, the rollout's slots one after the other in its workgroup
+                            // (-2: single rollouts - the two launches over ALL (rollout, slot) pairs, a handful of blocks: a deep
+                            //  line search has seven slots, which the one workgroup would take one after the other)
         const size_t lds1 = (size_t)(CS * 256 + S.N) * sizeof(double);
         if (lds1 <= 64 * 1024) {
             hipLaunchKernelGGL((resid_decide_kernel<NQ, NU, CF, true>), dim3(S.nb_launch), dim3(CIMPC_RESID_THREADS), lds1, s, S);
