@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 QUADRUPED = dict(nq=11, nu=8, nw=2, nc=4, nb=8)
+KKT_FLOP_PER_SOLVE = 9.9e6    # one KKT solve of the quadruped H = 40 system, banded-interleaved count
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # SURVEY.md section 8d (fp64 vector/matrix nominal)
 
@@ -283,10 +284,12 @@ def real_problem_leg(B, H, device, steps=5, perturb=0.05):
             acc[k] += st[k]
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    _, _, rn = s.newton_info()
     s.close()
     return {"workload": "quadruped gait2.jld2 (reference data file), true model linearization, H=%d, %d rollouts, "
                         "U(-%.2f, %.2f) initial-configuration offsets, cold start" % (H, B, perturb, perturb),
             "value": B / dt, "unit": "MPC steps/s", "ms_per_step": 1e3 * dt,
+            "converged_rollouts": int((rn < 3e-4).sum()), "rollouts": B,
             "newton_iters_per_step": acc["newton_iters"] / (steps * B), "sweeps_per_step": acc["sweeps"] / (steps * B),
             "ip_iters_per_solve": acc["ip_iters"] / max(acc["ip_solves"], 1), "ip_failures_per_step": acc["ip_failures"] / steps,
             "linearization_build_s": t_lin}
@@ -372,6 +375,65 @@ def centroidal_payload_leg(B, H, device, steps=3):
     return out
 
 
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves, exactly as the driver's
+    torchrun command would (one process per GPU, rendezvous on 127.0.0.1), and pass our own arguments through.  The
+    ranks see WORLD_SIZE = N, so they take the normal N > 1 path; rank 0 prints the one JSON line."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(args, rank, world, dist, dev):
+    """--launch-check: the N-rank control flow of this script WITHOUT a solve (runs on a box with no GPU, gloo): rank 0
+    builds the shared problem, broadcast, every rank takes its shard of the global rollout indices, a stand-in result
+    that is a function of the global index only goes through the ONE all-gather, every rank checks its rows.  It exists
+    so that the launcher (`--gpus N` -> N ranks) is covered by the CPU test suite; it measures nothing."""
+    import torch
+    from contactimplicitmpc.jl_amd import monte_carlo as mc
+    from contactimplicitmpc.jl_amd.sharding import rollout_shard
+    from contactimplicitmpc.jl_amd.trajectory import Dims
+    H, H_ref = args.horizon, 60
+    d = Dims(**QUADRUPED)
+    n_global = world * args.rollouts if args.scaling == "weak" else args.rollouts
+    if world > 1:
+        shapes = mc.problem_shapes(H_ref, H, d.nq, d.nu, d.nw, d.nc, d.nb)
+        built = build_problem(H, H_ref) if rank == 0 else None
+        prob, obj_q, obj_u = mc.broadcast_problem(*((built[1], built[2].q, built[2].u) if rank == 0 else (None, None, None)), shapes, dev)
+    else:
+        _, prob, obj = build_problem(H, H_ref)
+    first, B = rollout_shard(n_global, rank, world)
+    ro = build_rollouts(d, prob, B, H, H_ref, 1234, args.perturb, first=first)
+    u1 = np.stack([r[3][:d.nu] for r in ro])                       # stand-in rows: a function of the global rollout index
+    it = np.arange(first, first + B)
+    rn = np.array([float(np.abs(r[2]).sum()) for r in ro])
+    g = mc.gather_results(u1, it, rn, it % 7, n_global, dev)
+    ok = bool(np.array_equal(g["u1"][first:first + B], u1) and np.array_equal(g["newton_iters"][first:first + B], it)
+              and np.array_equal(g["r_norm"][first:first + B], rn) and np.array_equal(g["newton_iters"], np.arange(n_global)))
+    if dist is not None:
+        okt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(okt.item() == 1.0)
+    if rank == 0:
+        print(json.dumps({"metric": "launch-check (no solve, nothing measured)", "value": None, "n_gpus": world, "launch_check": True,
+                          "scaling": args.scaling, "rollouts_total": n_global, "rollouts_per_gpu": B,
+                          "multi_gpu": {"gather_selfcheck_all_ranks": ok}, "rollouts_reported": int(g["u1"].shape[0])}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -387,14 +449,39 @@ def main():
     ap.add_argument("--no-real-problem", action="store_true", help="skip the leg on the real quadruped gait")
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 --pmc passes (roofline.traffic)")
     ap.add_argument("--no-centroidal", action="store_true", help="skip the centroidal payload leg (BASELINE configs[4])")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="N-rank control flow only (broadcast, shard, all-gather of stand-in rows; no solve, no GPU needed with "
+                         "CIMPC_BENCH_BACKEND=gloo): covers the launcher in the CPU test suite, measures nothing")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started bare (`python bench.py --gpus N ...`): this process becomes the launcher of the N ranks
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        # a line whose n_gpus differs from what was asked for would be read as an N-GPU measurement
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE = %d rank(s); refusing to report" % (args.gpus, world))
+    if args.launch_check:
+        backend = os.environ.get("CIMPC_BENCH_BACKEND", "nccl")
+        dist = None
+        dev = torch.device("cpu")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dev = torch.device("cuda", local_rank)
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
+        return launch_check(args, rank, world, dist, dev)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if os.environ.get("CIMPC_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d but only %d device(s) are visible (one rank per GPU over RCCL)" % (world, torch.cuda.device_count()))
     # (CIMPC_BENCH_BACKEND=gloo: validation of the N > 1 control flow on a ONE-GPU box - every rank solves on the one
     #  device, collectives on CPU tensors; the driver's runs use the default: one rank per GPU, RCCL)
     backend = os.environ.get("CIMPC_BENCH_BACKEND", "nccl")
@@ -573,11 +660,17 @@ def main():
                          "converged_rollouts": int((gathered["r_norm"] < 3e-4).sum()), "rollouts_reported": int(gathered["u1"].shape[0])},
         # the sweep kernel runs out of LDS-resident tables: its binding roof is fp64 issue (vector FMA and MFMA share the
         # 78.6 TFLOP/s fp64 peak on gfx950), not HBM - both fractions are reported, the binding one as `frac`
-        "roofline": {"bound": "mfma", "bound_detail": "fp64 issue roof (fp64 vector = fp64 MFMA dense peak = 78.6 TFLOP/s); HBM contract fraction under `hbm`",
+        # `bound` names the pipe that binds: this kernel issues NO matrix instructions (SQ_INSTS_VALU_MFMA_MOPS_F64 = 0), its
+        # roof is fp64 vector issue - the same 78.6 TFLOP/s as the fp64 MFMA dense peak on gfx950
+        "roofline": {"bound": "fp64_valu", "bound_detail": "fp64 vector-issue roof (= the fp64 MFMA dense peak, 78.6 TFLOP/s, on gfx950; the kernel issues no MFMA); HBM contract fraction under `hbm`",
                      "kernel": "ip_queue_kernel", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "flops_per_unit": flops_per_solve, "bytes_per_unit": alg["bytes_per_solve"], "units_per_launch": solves_per_launch,
                      "avg_launch_ms": avg_launch_ms,
+                     # the whole step against the same roof: every contract flop of the step (all evaluated sweeps + one
+                     # condensed KKT solve per Newton iteration, SURVEY 8d: 9.9 MFLOP banded-equivalent) over the step's wall time
+                     "step_frac": ((job_ip_solves * alg["flop_iter"] * K + job_ip_solves * alg["flop_tail"] + job_newton * KKT_FLOP_PER_SOLVE)
+                                   / dt / 1e12 / world) / FP64_VECTOR_PEAK_TFLOPS,
                      "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
                              "achieved_shared_table": solves_per_launch * alg["bytes_per_solve_shared_table"] / (avg_launch_ms * 1e-3) / 1e9 if ip_ms > 0 else 0.0,
                              "traffic_over_algorithmic": (traffic / bytes_per_launch) if traffic and bytes_per_launch else None}},
@@ -588,6 +681,10 @@ def main():
                      "async_tail_launches_per_step": prof["async_launches"] / args.steps,
                      "ip_problems_in_rounds": prof["ip_sweep_problems"] / args.steps,
                      "ip_problems_in_async_tail": prof["async_problems"] / args.steps},
+        # the two Monte-Carlo workloads side by side: the seeded synthetic batch `value` is quoted on (backtracking-heavy:
+        # a third of its rollouts never reach r_tol) and, at N = 1, the same batch size on the reference's real gait
+        "headline": {"synthetic": {"value": n_global * args.steps / dt, "unit": "MPC steps/s", "ms_per_step": 1e3 * dt / args.steps,
+                                   "converged_rollouts": int((gathered["r_norm"] < 3e-4).sum()), "rollouts": n_global}},
         "setup_s": t_setup,
         "csrc_sha16": csrc_hash(),      # identity of the kernel sources this line was measured on
     }
@@ -617,6 +714,8 @@ def main():
     if not args.no_real_problem and world == 1:      # informative second workload (N = 1 only), outside the timed region
         try:
             out["real_problem"] = real_problem_leg(B, H, local_rank)
+            # the better-conditioned workload stands beside the synthetic one in the headline block
+            out["headline"]["real_gait2"] = {k: out["real_problem"][k] for k in ("value", "unit", "ms_per_step", "converged_rollouts", "rollouts")}
         except Exception as e:
             out["real_problem"] = {"error": repr(e)}
     if not args.no_centroidal and world == 1:        # BASELINE configs[4]: per-GPU share of 512 rollouts, mixed-precision KKT next to fp64

@@ -16,4 +16,6 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F64 
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq2 -o sq2 -- $CMD > $OUT/bench_sq2.log 2>&1
 python scripts/pmc_summary.py $OUT > $OUT/pmc_summary.csv 2> $OUT/pmc_summary.err
 find $OUT -name "*stats*.csv" | head -5
-tail -1 $OUT/bench_trace.log | cut -c1-300
+# the bench line of the PROFILED run (the log also holds rocprofv3's own messages: take the JSON line, not the last line)
+grep -E '^\{"metric"' $OUT/bench_trace.log | tail -1 > $OUT/bench_under_rocprof.json
+cut -c1-300 $OUT/bench_under_rocprof.json
