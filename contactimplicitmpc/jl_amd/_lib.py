@@ -26,7 +26,7 @@ class IpOpts(C.Structure):
     _fields_ = [("r_tol", C.c_double), ("kappa_tol", C.c_double), ("undercut", C.c_double),
                 ("gamma_reg", C.c_double), ("kappa_reg", C.c_double), ("eps_min", C.c_double),
                 ("ls_scale", C.c_double), ("max_iter", C.c_int), ("max_ls", C.c_int),
-                ("stall_alpha", C.c_double)]
+                ("stall_alpha", C.c_double), ("max_time", C.c_double)]
 
 
 class NewtonOpts(C.Structure):

@@ -129,6 +129,7 @@ struct cimpc_ctx {
     double* h_result = nullptr;  // ... its pinned host copy, valid from the end of a solve to the next call that touches the state
     double* d_rhs = nullptr;   // B1 seam staging
     double* d_pstate = nullptr;   // parked interior-point iterates
+    long long ip_budget_ticks = 0;  // cimpc_ip_opts::max_time in ticks of the device's constant-rate clock (0 = unlimited)
     int iter_cap = 28;            // (Knobs::iter_cap) measured B = 512: 16 / 20 / 24 / 32 / 48 -> 13.57 / 12.73 / 12.85 / 12.97 / 14.41 ms per batch step
     NewtonDev S{};
     int* h_counters = nullptr;   // pinned
@@ -310,6 +311,7 @@ IpParams make_ip_params(cimpc_ctx* h, const TrajDev& T, int par, int* pending_co
     p.kc_floor = h->ip.kappa_tol / h->ip.undercut;
     p.tau_floor = 1.0 - h->ip.eps_min;
     p.reg_floor = h->ip.kappa_tol * h->ip.gamma_reg;
+    p.budget_ticks = h->ip_budget_ticks;
     return p;
 }
 
@@ -376,6 +378,16 @@ int read_stats(cimpc_ctx* h, long long out[4]) {
     return CIMPC_OK;
 }
 
+// cimpc_mpc_advance returns with its copy / kernels still queued on h->stream (a private NON-blocking stream): every entry point that
+// rewrites reference / gait / window / objective state with blocking NULL-stream copies must first let that work finish, or the
+// pending gait_window / rekey kernels race with the rewrite
+int drain_pending(cimpc_ctx* h) {
+    if (!h->advance_pending) return CIMPC_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->advance_pending = false;
+    return CIMPC_OK;
+}
+
 int check_ready(cimpc_ctx* h, bool need_newton) {
     if (!h) return CIMPC_ERR_INVALID;
     if (h->n_knots_set != h->dm.H_ref)
@@ -392,7 +404,7 @@ int check_ready(cimpc_ctx* h, bool need_newton) {
 
 extern "C" {
 
-int cimpc_version(void) { return 103; }      // 1.03: round 3 (B2 entries, cimpc_kkt_solve_rho, CIMPC_ERR_SINGULAR, queued cimpc_mpc_advance)
+int cimpc_version(void) { return 104; }      // 1.04: round 4 (cimpc_ip_opts::max_time - the struct grew by one double at its end)
 
 void cimpc_default_ip_opts(cimpc_ip_opts* o) {
     if (!o) return;
@@ -406,6 +418,7 @@ void cimpc_default_ip_opts(cimpc_ip_opts* o) {
     o->max_iter = 100;
     o->max_ls = 3;
     o->stall_alpha = 1.0e-13;
+    o->max_time = 0.0;       // unlimited (the reference's default, 1e5 s, is treated as unlimited too)
 }
 
 void cimpc_default_newton_opts(cimpc_newton_opts* o) {
@@ -446,6 +459,12 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     if (ip) h->ip = *ip; else cimpc_default_ip_opts(&h->ip);
     if (nt) h->nt = *nt; else cimpc_default_newton_opts(&h->nt);
     h->device = device;
+    if (h->ip.max_time > 0.0 && h->ip.max_time < 1000.0) {      // per-solve budget of the interior point (policy.jl:9,61)
+        if (h->ip.max_iter >= 128) { delete h; return fail(nullptr, CIMPC_ERR_INVALID, "ip max_time needs max_iter < 128 (the parked state packs both into one word)"); }
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) khz = 100000;      // 100 MHz
+        h->ip_budget_ticks = std::max<long long>(1, (long long)std::llround(h->ip.max_time * 1.0e3 * (double)khz));
+    }
     h->kn.read_environment();       // the only place the environment is consulted
     h->iter_cap = h->kn.iter_cap;
     if (ip_kernel_info(&h->dm, &h->ki) != CIMPC_OK) {
@@ -681,6 +700,7 @@ int cimpc_destroy(cimpc_handle h) {
 int cimpc_set_stream(cimpc_handle h, void* hip_stream) {
     if (!h) return CIMPC_ERR_INVALID;
     (void)hipStreamSynchronize(h->stream);
+    h->advance_pending = false;
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     h->stream = static_cast<hipStream_t>(hip_stream);
     h->own_stream = false;
@@ -698,8 +718,9 @@ int cimpc_set_linearization(cimpc_handle h, int t, const double* z0, const doubl
                             const double* r0, const double* rz0, const double* rth0) {
     if (!h || !z0 || !th0 || !r0 || !rz0 || !rth0) return fail(h, CIMPC_ERR_INVALID, "null argument");
     if (t < 1 || t > h->dm.H_ref) return fail(h, CIMPC_ERR_INVALID, "knot index out of range (1-based)");
+    if (int dp = drain_pending(h); dp != CIMPC_OK) return dp;
     const int nx = h->nx, ny = h->ny, nz = h->nz, nth = h->nth, G = h->ki.G;
-    const LinLayout L(nx, ny, nth, G);
+    const LinLayout L(nx, ny, nth, G, h->ki.generic ? 0 : h->nths);
     std::vector<double>& T = h->h_tab;
     std::fill(T.begin(), T.end(), 0.0);
     auto RZ = [&](int r, int c) { return rz0[r + (size_t)c * nz]; };
@@ -740,6 +761,15 @@ int cimpc_set_linearization(cimpc_handle h, int t, const double* z0, const doubl
         for (int i = 0; i < nx; ++i) T[L.oRthDyn + k * G + i] = RTH(i, k);
         for (int i = 0; i < ny; ++i) T[L.oRthRst + k * G + i] = RTH(nx + i, k);
     }
+    // right-hand sides of the sensitivity pass as the QR sees them (lin_table.h: oGs): Gs[i, c] = (CAi rthdyn[:, c])_i - rthrst[i, c]
+    // with the kernel's chain - two partial sums over even / odd k, correctly rounded multiply-adds (IpSolver::schur_solve) -
+    // so that the columns the sweep writes do not change by a bit
+    for (int c = 0; c < L.nths; ++c)
+        for (int i = 0; i < ny; ++i) {
+            double bq[2] = {0.0, 0.0};
+            for (int k = 0; k < nx; ++k) bq[k & 1] = std::fma(RTH(k, c), CAi[i + (size_t)k * ny], bq[k & 1]);
+            T[L.oGs + c * G + i] = (bq[0] + bq[1]) - RTH(nx + i, c);
+        }
     for (int i = 0; i < ny; ++i) {
         T[L.oVec + LinLayout::V_RY2 * G + i] = RZ(nx + i, nx + ny + i);
         T[L.oVec + LinLayout::V_RY1D * G + i] = RZ(nx + i, nx + i);
@@ -767,6 +797,7 @@ int cimpc_set_objective(cimpc_handle h, const double* Q, const double* R, const 
     const cimpc_dims& d = h->dm;
     const size_t H = d.H;
     HIP_TRY(h, hipSetDevice(h->device));
+    if (int dp = drain_pending(h); dp != CIMPC_OK) return dp;
     {   // contact-impulse weights below fp64 resolution (1e-100 in every example of the reference): the cf-mode KKT
         // system reduces exactly onto the :configuration solvers (newton_kernels.hip: cf_reduce_*)
         double gmax = 0.0;
@@ -817,6 +848,7 @@ int cimpc_set_altitude(cimpc_handle h, const double* alt) {
     if (!h) return CIMPC_ERR_INVALID;
     if (!alt) { h->alt_set = false; return CIMPC_OK; }
     HIP_TRY(h, hipSetDevice(h->device));
+    if (int dp = drain_pending(h); dp != CIMPC_OK) return dp;
     HIP_TRY(h, hipMemcpy(h->d_alt, alt, (size_t)h->dm.B * h->dm.nc * sizeof(double), hipMemcpyHostToDevice));
     h->alt_set = true;
     return CIMPC_OK;
@@ -865,6 +897,7 @@ int cimpc_set_window(cimpc_handle h, const int* window) {
         w0[k] = t - 1;                 // the device buckets problems by 0-based knot (newton_kernels.hip: enqueue_eval)
     }
     HIP_TRY(h, hipSetDevice(h->device));
+    if (int dp = drain_pending(h); dp != CIMPC_OK) return dp;
     if (int rk = rekey_out(h); rk != CIMPC_OK) return rk;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(h->d_window, w0.data(), w0.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -882,6 +915,7 @@ int cimpc_set_reference(cimpc_handle h, const double* q_ref, const double* u_ref
     const cimpc_dims& d = h->dm;
     const size_t B = d.B, H = d.H;
     HIP_TRY(h, hipSetDevice(h->device));
+    if (int dp = drain_pending(h); dp != CIMPC_OK) return dp;
     HIP_TRY(h, hipMemcpy(h->S.ref.q, q_ref, B * (H + 2) * d.nq * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->S.ref.u, u_ref, B * H * d.nu * sizeof(double), hipMemcpyHostToDevice));
     if (w_ref) HIP_TRY(h, hipMemcpy(h->S.ref.w, w_ref, B * H * d.nw * sizeof(double), hipMemcpyHostToDevice));
@@ -1187,7 +1221,9 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     // host to see the previous one's stamp and launch (about 10 us per round of a 0.7 ms solve).  Warm-started solves only - the
     // cadence of an MPC loop, five Newton iterations over eight to ten rounds: hopper H = 20 0.652 -> 0.614 ms per MPC step; the
     // four rounds of a cold start lose more to the empty launches than they gain (0.685 -> 0.706 ms).
-    const bool ahead = h->dm.B < 4 && !h->use_mixed && warm_start != 0;
+    // (not with a wall-clock budget: the round queued ahead would still run - and step the trajectory - after the host has stopped
+    //  waiting, newton.jl:187-277 ends silently at the check)
+    const bool ahead = h->dm.B < 4 && !h->use_mixed && warm_start != 0 && !(h->nt.max_time > 0.0 && h->nt.max_time < 1.0e6);
     auto launch_round = [&](long long r, bool blind) -> int {
         // [KKT for rollouts that start an iteration] || sweep -> residual of every evaluated slot -> line-search decision
         const int slot = (int)(r & 1), par = (int)(r & 1);      // round r consumes Q[par] and leaves the next round's requests in Q[par ^ 1]
@@ -1230,7 +1266,9 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         // it only adds rounds, so a round that serves few rollouts lets every solve run to the end
         const int tail_div = h->kn.tail_div;
         // (batches below tail_div rollouts never park: a round there is as long as its longest solve whichever way it is cut)
-        const int cap = (tail_div > 0 && last_sweep * tail_div <= std::max(h->dm.B, tail_div)) ? h->ip.max_iter : h->iter_cap;
+        // (in a blind round `last_sweep` is one round stale: the cap is then chosen without it)
+        const bool sparse = tail_div > 0 && (h->dm.B < tail_div || (!blind && (long long)last_sweep * tail_div <= h->dm.B));
+        const int cap = sparse ? h->ip.max_iter : h->iter_cap;
         int rr = run_sweep(h, par, d_cnt + 2 * CPAD, nullptr, sb.st, cap, d_cnt + 3 * CPAD, true);
         if (rr != CIMPC_OK) return rr;
         if (kkt && h->kkt_overlap && hipStreamWaitEvent(sb.st, sb.ev_join, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join failed");
@@ -1256,7 +1294,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         if (rc != CIMPC_OK) return fail(h, rc, "reset launch failed");
     }
     while (true) {
-        if (launched >= max_rounds) {          // round limit reached with work left: a scheduling bug, never a silent partial solve
+        if (completed >= max_rounds) {          // round limit reached with work left: a scheduling bug, never a silent partial solve
             (void)hipStreamSynchronize(sb.st); (void)hipStreamSynchronize(sb.st_kkt);
             return fail(h, CIMPC_ERR_STATE, "newton_solve: round limit reached with unfinished rollouts");
         }
@@ -1386,6 +1424,7 @@ int cimpc_set_gait(cimpc_handle h, const double* q, const double* u, const doubl
     if (d.H > d.H_ref) return fail(h, CIMPC_ERR_INVALID, "H_mpc must not exceed H_ref");
     if (phase) for (size_t i = 0; i < B; ++i) if (phase[i] < 0) return fail(h, CIMPC_ERR_INVALID, "negative phase");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (int dp = drain_pending(h); dp != CIMPC_OK) return dp;
     if (!h->g_q) {
         if (dev_alloc(h, &h->g_q, (K + 2) * d.nq) != CIMPC_OK || dev_alloc(h, &h->g_u, K * d.nu) != CIMPC_OK ||
             dev_alloc(h, &h->g_w, K * d.nw) != CIMPC_OK || dev_alloc(h, &h->g_g, K * d.nc) != CIMPC_OK ||
@@ -1422,7 +1461,7 @@ int cimpc_mpc_advance(cimpc_handle h, const double* stride) {
     // The advance is QUEUED on the handle's stream and not waited for: whatever comes next is ordered behind it on the device
     // (the solve's streams wait for this stream, every getter synchronises it first).  The stride goes through a pinned word;
     // a second advance in a row waits for the first one's copy to have left it.
-    if (h->advance_pending) { HIP_TRY(h, hipStreamSynchronize(h->stream)); h->advance_pending = false; }
+    if (int dp = drain_pending(h); dp != CIMPC_OK) return dp;
     double* st_pin = h->h_qin + 2 * (size_t)h->dm.B * h->dm.nq;
     std::memcpy(st_pin, stride, (size_t)h->dm.nq * sizeof(double));
     if (h->gait_set) {          // full reference resident: regenerate the horizon from the gait (stride as given now)

@@ -159,6 +159,8 @@ struct IpParams {
     double kc_floor;    // o.kappa_tol / o.undercut
     double tau_floor;   // 1 - o.eps_min
     double reg_floor;   // o.kappa_tol * o.gamma_reg (regularisation floor of differentiate_solution!)
+    // per-solve time budget (cimpc_ip_opts::max_time) in ticks of the constant-rate device clock; 0 = unlimited (no clock read)
+    long long budget_ticks;
     AsyncQ A;
 };
 

@@ -262,7 +262,10 @@ __global__ __launch_bounds__(64) void ip_generic_kernel(IpParams p, GenDims gd) 
             double r_vio = S.r_violation(), k_vio = S.k_violation(), reg = 0.0;
             int iters = 0;
             bool stalled = false;
-            while (!stalled && !(r_vio < o.r_tol && k_vio < o.kappa_tol) && iters < o.max_iter) {
+            // per-solve time budget (cimpc_ip_opts::max_time): wave-uniform clock, read once per iteration when a budget is set
+            const long long t_solve0 = p.budget_ticks > 0 ? (long long)wall_clock64() : 0;
+            while (!stalled && !(r_vio < o.r_tol && k_vio < o.kappa_tol) && iters < o.max_iter &&
+                   !(p.budget_ticks > 0 && (long long)wall_clock64() - t_solve0 >= p.budget_ticks)) {
                 ++iters;
                 stalled = S.iterate(o, reg, r_vio, k_vio);
             }

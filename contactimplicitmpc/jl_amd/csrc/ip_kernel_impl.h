@@ -58,7 +58,8 @@ struct Model {
     // per-problem LDS: the R tile and theta - theta0 SHARE their space (theta - theta0 lives from the pull of a problem to the two
     // dot products a few lines below it; the tile is scratch inside factorize), then the backlog of deferred sensitivities
     static constexpr int TILE = NY * RST_LD > NTH ? NY * RST_LD : NTH;
-    static constexpr int LDS_GROUP = ((TILE + SENS_MAX / 2) + 1) & ~1;  // doubles / problem
+    // ... then one 64-bit word per group: the clock value the running solve's time budget counts from (IpParams::budget_ticks)
+    static constexpr int LDS_GROUP = ((TILE + SENS_MAX / 2 + 1) + 1) & ~1;  // doubles / problem
 };
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -72,7 +73,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 template <class M>
 struct IpSolver {
     static constexpr int NX = M::NX, NY = M::NY, NTH = M::NTH, G = M::G;
-    static constexpr LinLayout L{NX, NY, NTH, G};
+    static constexpr LinLayout L{NX, NY, NTH, G, M::NTHS};
     using LG = LaneGroup<G>;
 
     const double* tab;   // LDS: staged linearization table
@@ -227,23 +228,25 @@ struct IpSolver {
     }
 
     // schur_solve! (schur.jl:93-110): returns temp; x = Ai*(u + B*temp), y = -temp
+    // PRE: `v` already is the right-hand side of the QR, CAi*u - v (the sensitivity pass reads it from the table: LinLayout::oGs)
+    template <bool PRE = false>
     __device__ __forceinline__ double schur_solve(double u, double v, double& xs) const {
         const double* tCAi = tab + L.oCAi; const double* tAi = tab + L.oAi; const double* tDy1 = tab + L.oDy1;
         double bq[2] = {0.0, 0.0}, w[2] = {0.0, 0.0}, xx[2] = {0.0, 0.0};
         if constexpr (G == 16) {
-            Dpp16::matvec<NX, 2>(bq, u, [&](auto kc) { return tCAi[decltype(kc)::value * G + l]; });
-            const double t = qr_solve((bq[0] + bq[1]) - v);
+            if constexpr (!PRE) Dpp16::matvec<NX, 2>(bq, u, [&](auto kc) { return tCAi[decltype(kc)::value * G + l]; });
+            const double t = qr_solve(PRE ? v : (bq[0] + bq[1]) - v);
             Dpp16::matvec<NY, 2>(w, t, [&](auto kc) { return tDy1[decltype(kc)::value * G + l]; });
             const double ww = u + (w[0] + w[1]);
             Dpp16::matvec<NX, 2>(xx, ww, [&](auto kc) { return tAi[decltype(kc)::value * G + l]; });
             xs = xx[0] + xx[1];
             return t;
         }
-        static_for<0, NX>([&](auto kc) {
+        if constexpr (!PRE) static_for<0, NX>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             bq[k & 1] = fma(tCAi[k * G + l], LG::template bcast<k>(u), bq[k & 1]);
         });
-        const double t = qr_solve((bq[0] + bq[1]) - v);
+        const double t = qr_solve(PRE ? v : (bq[0] + bq[1]) - v);
         static_for<0, NY>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             w[k & 1] = fma(tDy1[k * G + l], LG::template bcast<k>(t), w[k & 1]);
@@ -321,7 +324,7 @@ __device__ __forceinline__ int group_bcast0(int v) {
 
 template <class M>
 __device__ __forceinline__ void stage_table(double* tab, const double* src_tab, int knot, int tid) {
-    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G);
+    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G, M::NTHS);
     const double2* src = reinterpret_cast<const double2*>(src_tab + (size_t)knot * L.size);
     double2* dst = reinterpret_cast<double2*>(tab);
     for (int k = tid; k < L.size / 2; k += (int)blockDim.x) dst[k] = src[k];   // 16 B per lane, coalesced
@@ -362,7 +365,7 @@ template <class M, bool ASYNC>
 __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S, const double* tab, int prob, int l, int part = 0, int nparts = 1) {
     constexpr int NX = M::NX, NY = M::NY, NTH = M::NTH, NTHS = M::NTHS, ND = M::ND, G = M::G;
     constexpr int NC = M::NC, NB = M::NB;
-    constexpr LinLayout L(NX, NY, NTH, G);
+    constexpr LinLayout L(NX, NY, NTH, G, M::NTHS);
     constexpr int PS = 2 * NX + 4 * NY + 4;
     using LG = LaneGroup<G>;
     const bool vx = S.vx, vy = S.vy;
@@ -394,9 +397,9 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
     }
     auto column = [&](int c, int cc) {
         const double u = tab[L.oRthDyn + c * G + l];
-        const double v = tab[L.oRthRst + c * G + l];
+        const double g = tab[L.oGs + c * G + l];          // CAi * rthdyn[:, c] - rthrst[:, c], a constant of the knot (lin_table.h)
         double xs;
-        const double t = S.schur_solve(u, v, xs);
+        const double t = S.template schur_solve<true>(u, g, xs);
         if (vx) xst<ASYNC>(dzo + c * ND + lg, -xs);
         if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) {
             if (l < NC + NB) xst<ASYNC>(dzo + c * ND + NX + lg, t);   // -(S.y) = +temp
@@ -493,7 +496,7 @@ template <class M, bool ASYNC>
 __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int knot, int tid, [[maybe_unused]] long long* sp = nullptr) {
     constexpr int NX = M::NX, NY = M::NY, NTH = M::NTH, ND = M::ND, G = M::G;
     constexpr int NC = M::NC, NB = M::NB;
-    constexpr LinLayout L(NX, NY, NTH, G);
+    constexpr LinLayout L(NX, NY, NTH, G, M::NTHS);
     constexpr int PS = 2 * NX + 4 * NY + 4;
     double* tab = smem;
     const int K = p.Q.K, cap = p.Q.cap, par = p.Q.par;
@@ -510,6 +513,10 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
     int nback = 0;                                               // wave-uniform
     const bool vx = l < NX, vy = l < NY;
     const cimpc_ip_opts o = p.o;
+    // per-solve time budget (cimpc_ip_opts::max_time, policy.jl:9,61): `tbase` = clock value at which the solve's running time was
+    // zero - kept in LDS, read once per trip, and only when a budget is set (wave-uniform kernel parameter)
+    long long* tbase = reinterpret_cast<long long*>(smem + L.size + (size_t)grp * M::LDS_GROUP + M::TILE + M::SENS_MAX / 2);
+    const bool timed = p.budget_ticks > 0;
 
     [[maybe_unused]] const long long sp_t0 = SPROF_T();
     const int n = ASYNC ? 1 : *qcount(p.Q, par, knot);
@@ -549,11 +556,13 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
         }
         // ---- 1. end of a solve? ---------------------------------------------------------------
         bool push = false;
+        long long t_used = 0;                 // (budgeted solves only) device-clock ticks this solve has spent iterating
+        if (timed) t_used = (long long)wall_clock64() - *tbase;
         if (have) {
             int code = -1;
             if (stalled) code = 0;
             else if (r_vio < o.r_tol && k_vio < o.kappa_tol) code = 1;
-            else if (iters >= o.max_iter) code = 0;
+            else if (iters >= o.max_iter || (timed && t_used >= p.budget_ticks)) code = 0;      // out of iterations / out of time
             else if (done_here >= p.iter_cap || (!ASYNC && draining && done_here >= p.drain_min)) code = 2;
             if (code >= 0) {
                 const size_t pi = (size_t)prob;
@@ -563,7 +572,8 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
                     if (vx) { ps[lg] = S.x; ps[NX + 2 * NY + lg] = S.rdyn; }
                     if (vy) { ps[NX + lg] = S.y1; ps[NX + NY + lg] = S.y2; ps[2 * NX + 2 * NY + lg] = S.rrst; ps[2 * NX + 3 * NY + lg] = S.rbil; }
                     if (l == 0) {
-                        ps[PS - 4] = r_vio; ps[PS - 3] = k_vio; ps[PS - 2] = reg; ps[PS - 1] = (double)iters;
+                        // (iteration count and, for budgeted solves, the time used so far share the last word: iters < 128)
+                        ps[PS - 4] = r_vio; ps[PS - 3] = k_vio; ps[PS - 2] = reg; ps[PS - 1] = (double)((long long)iters + (timed ? t_used * 128 : 0));
                         p.pflag[pi] = 1;
                         const int pos = atomicAdd(qcount(p.Q, par ^ 1, knot), 1);
                         p.Q.items[((size_t)(par ^ 1) * K + knot) * cap + pos] = prob;
@@ -676,7 +686,10 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
                     S.rdyn = vx ? ps[NX + 2 * NY + lg] : 0.0;
                     S.rrst = vy ? ps[2 * NX + 2 * NY + lg] : 0.0;
                     S.rbil = vy ? ps[2 * NX + 3 * NY + lg] : 0.0;
-                    r_vio = ps[PS - 4]; k_vio = ps[PS - 3]; reg = ps[PS - 2]; iters = (int)ps[PS - 1];
+                    r_vio = ps[PS - 4]; k_vio = ps[PS - 3]; reg = ps[PS - 2];
+                    const long long it_word = (long long)ps[PS - 1];
+                    iters = (int)(it_word & 127);
+                    if (timed && l == 0) *tbase = (long long)wall_clock64() - (it_word >> 7);      // the time already used counts
                     wave_lds_fence();
                     if (l == 0) p.pflag[pi] = 0;
                 } else {
@@ -687,7 +700,9 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
                     k_vio = S.k_violation();
                     iters = 0;
                     reg = 0.0;
+                    if (timed && l == 0) *tbase = (long long)wall_clock64();
                 }
+                if (timed) wave_lds_fence();
                 done_here = 0;
                 stalled = false;
                 have = true;
@@ -804,7 +819,7 @@ __global__ __launch_bounds__(M::G == 16 ? CIMPC_SWEEP_THREADS : 256, M::G == 16 
 template <class M>
 __global__ __launch_bounds__(64) void ip_callback_kernel(IpCallbackArgs a) {
     constexpr int NX = M::NX, NY = M::NY, NTH = M::NTH, G = M::G;
-    constexpr LinLayout L(NX, NY, NTH, G);
+    constexpr LinLayout L(NX, NY, NTH, G, M::NTHS);
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = (int)threadIdx.x, grp = tid / G, l = tid % G;
     double* tab = smem;
@@ -849,7 +864,7 @@ __global__ __launch_bounds__(64) void ip_callback_kernel(IpCallbackArgs a) {
 
 template <class M>
 int launch_callback(const IpCallbackArgs& a, hipStream_t s) {
-    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G);
+    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G, M::NTHS);
     const int ppw = 64 / M::G;
     const size_t lds = (size_t)(L.size + ppw * M::LDS_GROUP) * sizeof(double);
     static LdsOptIn optin;
@@ -864,7 +879,7 @@ int launch_callback(const IpCallbackArgs& a, hipStream_t s) {
 // ----------------------------------------------------------------------------------------
 template <class M>
 int launch_model(const IpParams& p, int waves, hipStream_t s) {
-    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G);
+    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G, M::NTHS);
     if (waves < 1 || waves > (M::G == 16 ? CIMPC_SWEEP_THREADS : 256) / 64 || waves == 3) return CIMPC_ERR_INVALID;
     const int ppw = 64 / M::G;
     const size_t lds = (size_t)(L.size + waves * ppw * M::LDS_GROUP) * sizeof(double);
@@ -877,7 +892,7 @@ int launch_model(const IpParams& p, int waves, hipStream_t s) {
 
 template <class M>
 void info_model(KernelInfo* info) {
-    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G);
+    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G, M::NTHS);
     info->G = M::G;
     info->lds_table = L.size;
     info->lds_group = M::LDS_GROUP;

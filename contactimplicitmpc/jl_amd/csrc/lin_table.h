@@ -15,14 +15,18 @@
 namespace cimpc {
 
 struct LinLayout {
-    int nx, ny, nth, G;
+    int nx, ny, nth, G, nths;
     // offsets in doubles
-    int oW, oCAi, oAi, oDy1, oDx, oRx, oRy1, oRthDyn, oRthRst, oVec, oTh0, size;
+    int oW, oCAi, oAi, oDy1, oDx, oRx, oRy1, oRthDyn, oRthRst, oGs, oVec, oTh0, size;
+    // oGs (compiled lane-group models; nths = 0: absent): the right-hand sides of the sensitivity pass as the QR sees them,
+    //   Gs[:, c] = CAi * rthdyn[:, c] - rthrst[:, c],  c = 0 .. nths-1  (schur_solve!, schur.jl:93-110, on column c of r_theta,
+    //   linearized_solver.jl:451-479) - a constant of the knot that every converged solve used to recompute for each of its
+    //   nths columns; formed by cimpc_set_linearization with the kernel's own multiply-add chain (bit-identical columns).
     // oVec holds 8 lane-strided vectors:
     enum { V_RY2 = 0, V_RY1D, V_CAIBD, V_RDYN0, V_RRST0, V_X0, V_Y10, V_Y20, V_COUNT };
 
-    __host__ __device__ constexpr LinLayout(int nx_, int ny_, int nth_, int G_)
-        : nx(nx_), ny(ny_), nth(nth_), G(G_),
+    __host__ __device__ constexpr LinLayout(int nx_, int ny_, int nth_, int G_, int nths_ = 0)
+        : nx(nx_), ny(ny_), nth(nth_), G(G_), nths(nths_),
           oW(0),
           oCAi(oW + ny_ * G_),
           oAi(oCAi + nx_ * G_),
@@ -32,7 +36,8 @@ struct LinLayout {
           oRy1(oRx + nx_ * G_),
           oRthDyn(oRy1 + ny_ * G_),
           oRthRst(oRthDyn + nth_ * G_),
-          oVec(oRthRst + nth_ * G_),
+          oGs(oRthRst + nth_ * G_),
+          oVec(oGs + nths_ * G_),
           oTh0(oVec + V_COUNT * G_),
           size(((oTh0 + nth_) + 1) & ~1) {}
 };

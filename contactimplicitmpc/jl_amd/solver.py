@@ -35,6 +35,7 @@ class InteriorPointOptions:
     max_iter: int = 100
     max_ls: int = 3
     stall_alpha: float = 1.0e-13
+    max_time: float = 0.0          # seconds per solve (policy.jl:9,61 ip_max_time); <= 0 or >= 1000: unlimited
 
 
 @dataclass
@@ -98,7 +99,7 @@ class CIMPCSolver:
         newton_opts = newton_opts or NewtonOptions()
         self._ip = _lib.IpOpts(ip_opts.r_tol, ip_opts.kappa_tol, ip_opts.undercut, ip_opts.gamma_reg,
                                ip_opts.kappa_reg, ip_opts.eps_min, ip_opts.ls_scale, ip_opts.max_iter,
-                               ip_opts.max_ls, ip_opts.stall_alpha)
+                               ip_opts.max_ls, ip_opts.stall_alpha, ip_opts.max_time)
         self._nt = _lib.NewtonOpts(newton_opts.r_tol, newton_opts.beta_init, newton_opts.max_time,
                                    newton_opts.kappa, newton_opts.max_iter, newton_opts.kkt_backend)
         self.h = C.c_void_p()

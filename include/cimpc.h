@@ -84,6 +84,13 @@ typedef struct cimpc_ip_opts {
                          * (implicit_dynamics.jl:180-190) comes from an earlier iterate than 100 reference iterations would leave
                          * (converging solves never go below alpha ~ 4e-3; the sensitivities of a failed solve are not written
                          * either way, implicit_dynamics.jl:169-176) */
+    double max_time;    /* seconds per interior-point solve, InteriorPointOptions(max_time = mpc_opts.ip_max_time) (policy.jl:9,61;
+                         * implicit_dynamics.jl:21-33; default 1e5 there = unlimited).  <= 0 or >= 1000: unlimited (no clock is read).
+                         * Otherwise every solve carries its own budget on the DEVICE: the time it has spent iterating (the constant-rate
+                         * device clock, s_memrealtime; time parked between two launches does not count) is checked once per
+                         * iteration, a solve over budget ends like one that ran out of iterations (status 0, sensitivities keep
+                         * their previous value).  Needs max_iter < 128.  Honoured by the sweep kernels (B3 / B4); cimpc_plant_step
+                         * ignores it (the simulator's options carry none, simulator.jl:24-32). */
 } cimpc_ip_opts;
 
 /* NewtonOptions (newton.jl:2-11) + the central-path parameter used for the dual

@@ -7,10 +7,14 @@
 #   A1  LinearizedStep per knot -> cimpc_set_linearization                      src/controller/linearized_step.jl:10-31
 #   glue rot_n_stride! / update_window!                                         src/controller/policy.jl:133-141
 #
-# Usage: `include("CIMPCHip.jl")` INSIDE `module ContactImplicitMPC` (src/ContactImplicitMPC.jl, after the solver includes of
-# lines 38-42; library path in ENV["CIMPC_LIB"]).  The file defines the submodule `CIMPCHip`, which imports the package's own
-# `linear_solve!` / `LinearSolver` (so that newton.jl:218 dispatches to the GPU solvers) and, with its last line, makes the
-# constructors `hip_kkt_solver` / `hip_csc_solver` visible to `eval(opts.solver)` in the package module (newton.jl:86).
+# Usage: `include("CIMPCHip.jl")` INSIDE `module ContactImplicitMPC` (src/ContactImplicitMPC.jl), anywhere AFTER line 32 (the
+# `import RoboDojo: LinearSolver, ..., linear_solve!` the binding's own import needs) - e.g. next to the solver includes of lines
+# 38-42, or at the end of the module; library path in ENV["CIMPC_LIB"].  The file defines the submodule `CIMPCHip`, which imports
+# the package's own `linear_solve!` / `LinearSolver` (so that newton.jl:218 dispatches to the GPU solvers) and, with its last
+# line, makes the constructors `hip_kkt_solver` / `hip_csc_solver` visible to `eval(opts.solver)` in the package module
+# (newton.jl:86).  Names the package defines LATER in its include order - `friction_dim` (simulator/environment.jl),
+# `LinearizedStep` (controller/linearized_step.jl) - are NOT imported at the top: they are looked up in the parent module when a
+# `Solver` is built (`_pkg()`), so the include position does not matter for them.
 #   p   = ci_mpc_policy(ref_traj, s, obj; H_mpc, N_sample, κ_mpc, mode, n_opts, ip_opts)
 #   hip = CIMPCHip.Solver(s, ref_traj, obj; H_mpc, κ = κ_mpc, mode, n_opts, ip_opts)      # once
 #   CIMPCHip.newton_solve!(hip, p.newton, p.q0, q1, p.window, p.traj; warm_start = t > 1)   # instead of newton.jl:169
@@ -28,7 +32,9 @@ using SparseArrays
 using LinearAlgebra: SingularException
 # the package's own generic function and abstract type (both imported from RoboDojo at src/ContactImplicitMPC.jl:32): methods
 # added here are the ones newton.jl:218 `linear_solve!(core.solver, core.Δ.r, core.jac.R, core.res.r)` dispatches to
-import ..ContactImplicitMPC: linear_solve!, LinearSolver, LinearizedStep, friction_dim
+import ..ContactImplicitMPC: linear_solve!, LinearSolver
+# the package module, for names it defines after this file may have been included (resolved at call time)
+_pkg() = parentmodule(@__MODULE__)
 
 const LIB = get(ENV, "CIMPC_LIB", "libcimpc_hip.so")
 
@@ -42,6 +48,20 @@ struct IpOpts                   # <- InteriorPointOptions (policy.jl:54-61, impl
     r_tol::Cdouble; kappa_tol::Cdouble; undercut::Cdouble; gamma_reg::Cdouble
     kappa_reg::Cdouble; eps_min::Cdouble; ls_scale::Cdouble
     max_iter::Cint; max_ls::Cint; stall_alpha::Cdouble
+    max_time::Cdouble           # per-solve budget, mpc_opts.ip_max_time (policy.jl:9,61); >= 1000 s = unlimited
+end
+# RoboDojo 0.1.3 owns InteriorPointOptions and its source is not part of the reference tree: the only field names the reference
+# itself shows are r_tol, κ_tol, undercut, γ_reg, ϵ_min, max_ls, max_time, diff_sol, solver, verbose (simulator.jl:24-32,
+# policy.jl:54-61, implicit_dynamics.jl:25-32).  Every field is therefore read through `_opt` - a name this RoboDojo version does
+# not have falls back to the library's default (cimpc_default_ip_opts) instead of raising a FieldError at handle creation.
+_opt(o, name::Symbol, default) = hasproperty(o, name) ? getproperty(o, name) : default
+function IpOpts(o)
+    d = Ref(IpOpts(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0))
+    ccall((:cimpc_default_ip_opts, LIB), Cvoid, (Ref{IpOpts},), d)
+    d = d[]
+    IpOpts(_opt(o, :r_tol, d.r_tol), _opt(o, :κ_tol, d.kappa_tol), _opt(o, :undercut, d.undercut), _opt(o, :γ_reg, d.gamma_reg),
+           _opt(o, :κ_reg, d.kappa_reg), _opt(o, :ϵ_min, d.eps_min), _opt(o, :ls_scale, d.ls_scale),
+           _opt(o, :max_iter, d.max_iter), _opt(o, :max_ls, d.max_ls), d.stall_alpha, _opt(o, :max_time, d.max_time))
 end
 struct NewtonOpts               # <- NewtonOptions (newton.jl:2-11)
     r_tol::Cdouble; beta_init::Cdouble; max_time::Cdouble; kappa::Cdouble
@@ -74,17 +94,16 @@ opts)` (newton.jl:37-91): uploads one `LinearizedStep` per knot and the objectiv
 function Solver(s, ref_traj, obj; H_mpc::Int, κ::Float64, mode::Symbol = :configurationforce, n_opts, ip_opts,
                 B::Int = 1, device::Int = 0, kkt_backend = KKT_CONDENSED)
     m = s.model
-    nb = m.nc * friction_dim(s.env)
+    nb = m.nc * _pkg().friction_dim(s.env)
     dims = Dims(m.nq, m.nu, m.nw, m.nc, nb, mode == :configuration ? 0 : 1, ref_traj.H, H_mpc, B)
-    ip = Ref(IpOpts(ip_opts.r_tol, ip_opts.κ_tol, ip_opts.undercut, ip_opts.γ_reg, ip_opts.κ_reg, ip_opts.ϵ_min,
-                    ip_opts.ls_scale, ip_opts.max_iter, ip_opts.max_ls, 1e-13))
-    nt = Ref(NewtonOpts(n_opts.r_tol, n_opts.β_init, n_opts.max_time, κ, n_opts.max_iter, kkt_backend))
+    ip = Ref(IpOpts(ip_opts))
+    nt = Ref(NewtonOpts(n_opts.r_tol, n_opts.β_init, n_opts.max_time, κ, n_opts.max_iter, kkt_backend))      # newton.jl:2-11
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:cimpc_create, LIB), Cint, (Ref{Dims}, Ref{IpOpts}, Ref{NewtonOpts}, Cint, Ref{Ptr{Cvoid}}),
                 Ref(dims), ip, nt, device, h))
     hs = Solver(h[], dims)
     for t = 1:ref_traj.H                                             # A1
-        lin = LinearizedStep(s, ref_traj.z[t], ref_traj.θ[t], κ)
+        lin = _pkg().LinearizedStep(s, ref_traj.z[t], ref_traj.θ[t], κ)
         check(ccall((:cimpc_set_linearization, LIB), Cint,
                     (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
                     hs.h, t, lin.z, lin.θ, lin.r, Matrix(lin.rz), Matrix(lin.rθ)), hs.h)
@@ -106,6 +125,19 @@ function set_objective!(hs::Solver, obj, H::Int)
     check(ccall((:cimpc_set_objective, LIB), Cint,
                 (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
                 hs.h, Q, R, Cg, Cb, V, qt, vt), hs.h)
+end
+
+"""
+    set_linearization!(hs, s, t, z, θ, κ)
+
+Re-linearisation of knot `t` in flight: what `update!(lin::LinearizedStep, s, z, θ)` + `update!` of `RLin / RZLin / RθLin` do
+(linearized_step.jl:33-45, linearized_solver.jl:497-565).  The next solve on the handle uses the new table.
+"""
+function set_linearization!(hs::Solver, s, t::Int, z, θ, κ)
+    lin = _pkg().LinearizedStep(s, z, θ, κ)
+    check(ccall((:cimpc_set_linearization, LIB), Cint,
+                (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                hs.h, t, lin.z, lin.θ, lin.r, Matrix(lin.rz), Matrix(lin.rθ)), hs.h)
 end
 
 "RLin.alt of every knot (set_altitude!, implicit_dynamics.jl:141-154); alt: nc (one robot) or nc x B."
@@ -169,6 +201,28 @@ function implicit_dynamics!(hs::Solver, im_traj, traj; window = collect(1:traj.H
     return nothing
 end
 
+# ---- B2: the per-knot callbacks handed to RoboDojo's interior_point (implicit_dynamics.jl:58-68) ---------------------------------
+# z, r, Δ in the order [x; y1; y2] of linearization_var_index (index.jl:289-327); one point (vectors) or n points (nz x n).
+"""
+    rlin!(hs, r, t, z, θ, κ; alt = nothing)      # rlin!(r, z, θ, κ) of knot t, linearized_solver.jl:364-373
+"""
+function rlin!(hs::Solver, r::VecOrMat{Float64}, t::Int, z::VecOrMat{Float64}, θ::VecOrMat{Float64}, κ::Float64; alt = nothing)
+    n = size(z, 2)
+    check(ccall((:cimpc_ip_residual, LIB), Cint,
+                (Ptr{Cvoid}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}),
+                hs.h, t, n, z, θ, alt === nothing ? C_NULL : Matrix{Float64}(reshape(alt, :, n)), κ, r), hs.h)
+    return r
+end
+"""
+    linear_solve!(hs, Δ, t, z, r; reg = 0.0)     # rzlin!(rz, z; reg) + linear_solve!(Δ, rz, r; reg), linearized_solver.jl:378-444
+"""
+function linear_solve!(hs::Solver, Δ::VecOrMat{Float64}, t::Int, z::VecOrMat{Float64}, r::VecOrMat{Float64}; reg::Float64 = 0.0)
+    check(ccall((:cimpc_ip_linear_solve, LIB), Cint,
+                (Ptr{Cvoid}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}),
+                hs.h, t, size(z, 2), z, r, reg, Δ), hs.h)
+    return Δ
+end
+
 # ---- B1: LinearSolver seam ---------------------------------------------------------------------------------------------------------
 # (a) on a handle: the KKT system of the handle's device-resident sensitivities - the ENTRIES of A are not read; requires B3 / a
 #     Newton evaluation on the same handle before the call (include/cimpc.h).  Select with opts.solver = :hip_kkt_solver.
@@ -219,7 +273,7 @@ const PLANT_MODELS = Dict{Symbol,NTuple{6,Int}}(
 
 q0, q1: nq x B; u: nu x B; w: nw x B or nothing.  Sizes are checked against the model's table; unknown models are an error.
 """
-function plant_step(model::Symbol, q0::Matrix{Float64}, q1::Matrix{Float64}, u::Matrix{Float64}, μ, h_sim, opts::IpOpts;
+function plant_step(model::Symbol, q0::Matrix{Float64}, q1::Matrix{Float64}, u::Matrix{Float64}, μ, h_sim, opts;
                     w::Union{Nothing,Matrix{Float64}} = nothing)
     haskey(PLANT_MODELS, model) || error("cimpc_plant_step has no model $model (available: $(collect(keys(PLANT_MODELS))))")
     id, nq, nu, nc, nf, nw = PLANT_MODELS[model]
@@ -230,7 +284,7 @@ function plant_step(model::Symbol, q0::Matrix{Float64}, q1::Matrix{Float64}, u::
     check(ccall((:cimpc_plant_step, LIB), Cint,
                 (Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Ref{IpOpts},
                  Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cint}),
-                id, B, q0, q1, u, w === nothing ? C_NULL : w, μ, h_sim, Ref(opts), q2, γ, b, status, iters))
+                id, B, q0, q1, u, w === nothing ? C_NULL : w, μ, h_sim, Ref(opts isa IpOpts ? opts : IpOpts(opts)), q2, γ, b, status, iters))
     return q2, γ, b, status, iters
 end
 

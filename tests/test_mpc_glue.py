@@ -77,7 +77,7 @@ def test_mpc_loop_three_steps_warm_start(gpu_required):
         cores2.append(onewton.Newton(d, H, obj, onewton.NewtonOptions(r_tol=1e-5, max_iter=4, solver="condensed"),
                                      oip.IPOptions(kappa_tol=prob["kappa"]), prob["kappa"], ref))
     agree = np.ones(B, dtype=bool)
-    tight = 0
+    tight = n_split = 0
     for step in range(3):
         u1, it, rn = s.newton_solve(q0, q1, warm_start=step > 0)
         tr = s.trajectory(); cnt = s.rollout_counters()
@@ -94,6 +94,13 @@ def test_mpc_loop_three_steps_warm_start(gpu_required):
                     np.testing.assert_allclose(u1[b], cores[b].traj.u[0], rtol=0, atol=tol_u)
                     np.testing.assert_allclose(tr["q"][b], cores[b].traj.q, rtol=0, atol=tol_q)
                     tight += int(tol_q == 1e-7)
+                else:
+                    # the oracle's two KKT backends took different discrete paths here: the device (equal to backend 1 in its
+                    # counters) is still held to the NEARER of the two results, within three times their distance
+                    n_split += 1
+                    du = min(np.abs(u1[b] - c.traj.u[0]).max() for c in (cores[b], cores2[b]))
+                    dq = min(np.abs(tr["q"][b] - c.traj.q).max() for c in (cores[b], cores2[b]))
+                    assert du <= tol_u and dq <= tol_q, (b, step, du, tol_u, dq, tol_q)
             ompc.rot_n_stride(d, refs[b], stride)
             wins[b] = ompc.update_window(wins[b], H_ref)
             oq0[b], oq1[b] = oq1[b], cores[b].traj.q[2].copy()
@@ -101,6 +108,7 @@ def test_mpc_loop_three_steps_warm_start(gpu_required):
         s.mpc_advance(stride)
         q0, q1 = q1, tr["q"][:, 2].copy()
     assert agree.sum() >= B - 1 and tight >= 2 * B, (agree, tight)      # most (rollout, step) pairs are held to 1e-7
+    assert n_split <= 2, n_split                                        # the loosened comparison stays the exception
 
 
 # ---- stale sensitivities follow the KNOTS across the MPC loop (implicit_dynamics.jl:71-86, 169-176: one ip[t] per reference knot) ----
