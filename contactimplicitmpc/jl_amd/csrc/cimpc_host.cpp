@@ -58,6 +58,7 @@ struct Knobs {
     int drain_min = 4;           // CIMPC_DRAIN_MIN: ... for solves that have had at least this many iterations in the launch
     int async_full_max = 64;     // CIMPC_ASYNC_FULL_MAX: largest batch solved by the single persistent launch alone (larger: hybrid).
                                  // Measured 128 -> 64: B = 96 8.88 -> 8.11 ms, B = 128 9.72 -> 9.48 ms, B = 64 unchanged (6.9 ms)
+    bool generic_static = false; // CIMPC_GENERIC_STATIC: runtime-dimension sweep with the static queue partition of rounds 2-3 instead of the dynamic pull
     int kkt_pipe = -1;           // CIMPC_KKT_PIPE: three-wave pipelined KKT kernel 0 never, 1 always, -1 where the solve is on the critical path
     // ---- constants ----
     int async_mem = 0;           // exchange buffers: ordinary device memory (uncached / fine-grained variants lost)
@@ -92,6 +93,7 @@ struct Knobs {
         drain_pct = env_int("CIMPC_DRAIN_PCT", drain_pct);
         drain_min = std::max(1, env_int("CIMPC_DRAIN_MIN", drain_min));
         kkt_pipe = env_int("CIMPC_KKT_PIPE", kkt_pipe);
+        generic_static = env_int("CIMPC_GENERIC_STATIC", generic_static ? 1 : 0) != 0;
     }
 };
 
@@ -312,6 +314,7 @@ IpParams make_ip_params(cimpc_ctx* h, const TrajDev& T, int par, int* pending_co
     p.tau_floor = 1.0 - h->ip.eps_min;
     p.reg_floor = h->ip.kappa_tol * h->ip.gamma_reg;
     p.budget_ticks = h->ip_budget_ticks;
+    p.generic_static = h->kn.generic_static ? 1 : 0;
     return p;
 }
 

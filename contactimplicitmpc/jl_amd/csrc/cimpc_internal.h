@@ -161,6 +161,7 @@ struct IpParams {
     double reg_floor;   // o.kappa_tol * o.gamma_reg (regularisation floor of differentiate_solution!)
     // per-solve time budget (cimpc_ip_opts::max_time) in ticks of the constant-rate device clock; 0 = unlimited (no clock read)
     long long budget_ticks;
+    int generic_static;    // runtime-dimension sweep (ip_generic.hip): 1 = static partition of a knot's queue instead of the dynamic pull
     AsyncQ A;
 };
 

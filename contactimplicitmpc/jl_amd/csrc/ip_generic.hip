@@ -234,14 +234,17 @@ __global__ __launch_bounds__(64) void ip_generic_kernel(IpParams p, GenDims gd) 
         S.ry2 = tVec[LinLayout::V_RY2 * GW + l]; S.ry1d = tVec[LinLayout::V_RY1D * GW + l]; S.caibd = tVec[LinLayout::V_CAIBD * GW + l];
         S.rdyn0 = tVec[LinLayout::V_RDYN0 * GW + l]; S.rrst0 = tVec[LinLayout::V_RRST0 * GW + l];
         S.x0 = tVec[LinLayout::V_X0 * GW + l]; S.y10 = tVec[LinLayout::V_Y10 * GW + l]; S.y20 = tVec[LinLayout::V_Y20 * GW + l];
-        // static partition of the knot's queue over the workgroups.  (A dynamic pull - lane 0 takes an index with atomicAdd and
-        // broadcasts it - hung on the GPU: hipcc structurised that loop of a single-wave workgroup as a divergent loop whose
-        // latch never repeats the atomic, so lanes 1..63 re-read a stale index for ever.  The loop below has scalar control only.
-        //  Round 3 tried the scalar form of the pull - lane 0 claims, v_readfirstlane hands the index to the wave, uniform exit test:
-        //  the runtime-dimension tests did not finish within their time limit either, so the cause is not (only) the loop shape;
-        //  left for a session that can sit on the GPU with a debugger.)
+        // Problems of the knot: dynamic pull (default since round 4) or static partition over the workgroups (p.generic_static).
+        // The pull's first two forms hung on the GPU in this single-wave workgroup: `if (l == 0) idx = atomicAdd(head, 1);
+        // idx = __shfl(idx, 0)` was structurised by hipcc as a divergent loop whose latch never repeats the atomic (lanes 1..63
+        // re-read a stale index for ever, seen in the ISA), and the v_readfirstlane variant of it still sat behind the same
+        // divergent `if`.  This form has NO divergent control flow at all: every lane issues the atomic - lane 0 adds 1, the
+        // others add 0 (their return values are discarded) - and the claim of lane 0, the first active lane, reaches the wave
+        // through v_readfirstlane, so the loop condition is a scalar compare.
+        int* head = qhead(p.Q, knot);
         const int G0 = (int)gridDim.x;
-        for (int idx = (int)blockIdx.x; idx < n; idx += G0) {
+        int idx = p.generic_static ? (int)blockIdx.x : __builtin_amdgcn_readfirstlane(atomicAdd(head, l == 0 ? 1 : 0));
+        for (; idx < n; idx = p.generic_static ? idx + G0 : __builtin_amdgcn_readfirstlane(atomicAdd(head, l == 0 ? 1 : 0))) {
             const int prob = items[idx];
             const int sb = prob / p.H, i = prob - sb * p.H;
             const size_t pi = (size_t)prob;

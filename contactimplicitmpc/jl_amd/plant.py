@@ -98,6 +98,32 @@ class ImpulseDisturbance:
         return np.zeros_like(self.w[0])
 
 
+class RandomDisturbance:
+    """random_disturbances(model, w_amp, H, h) + disturbances(d, x, t), src/simulator/disturbances.jl:63-84: H samples
+    w[k] = rand(nw) .* w_amp[1] on the time grid t_k = (k - 1) h, k = 1..H; a query returns w[searchsortedlast(t_grid, t)].
+    Two things are the reference's CODE rather than its docstring and are kept: the samples are drawn in [0, w_amp) (the docstring
+    says "between 0 and -w_amplitude"), and the struct is always built from `w_amp[1]` - the per-axis branch (`length(w_amp) ==
+    model.nw`) computes a `w` that is never used (disturbances.jl:73-81).  `w_amp` with neither length 1 nor nw warns there and
+    raises here.  B > 1 draws an independent sequence per robot (one RandomDisturbance per rollout of a Monte-Carlo batch).
+    The random stream is numpy's (seeded), not Julia's: parity is in distribution and schedule, not in the draws."""
+
+    def __init__(self, nw: int, w_amp, H: int, h: float, seed: int = 0, B: int = 1):
+        w_amp = np.atleast_1d(np.asarray(w_amp, dtype=np.float64))
+        if w_amp.size not in (1, nw):
+            raise ValueError("w_amp is not of the correct size")
+        rng = np.random.default_rng(seed)
+        self.w_amp = w_amp
+        self.w = rng.random((H, B, nw)) * w_amp[0]
+        self.t = np.arange(H, dtype=np.float64) * h
+
+    def __call__(self, t):
+        k = int(np.searchsorted(self.t, t, side="right"))        # searchsortedlast: number of grid points <= t (1-based index)
+        if k < 1:
+            raise IndexError("query time before the first sample")      # d.w[0] is a BoundsError in the reference too
+        w = self.w[k - 1]
+        return w[0] if w.shape[0] == 1 else w
+
+
 def simulate(model: str, policy, q1, v1, H_sim: int, h_sim: float, mu: float, opts: InteriorPointOptions = SIM_OPTS,
              disturbances=None):
     """`simulate!(sim, q1, v1)` for B robots: q[0] = q1 - h v1, q[1] = q1; every step u = policy(q[t+1]) (B, nu),

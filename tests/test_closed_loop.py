@@ -250,6 +250,28 @@ def test_disturbance_schedules():
     assert np.count_nonzero(out.any(axis=1)) == 2 and out[3, 0] == 5.0 and out[8, 1] == -7.0
 
 
+def test_random_disturbance_schedule():
+    """random_disturbances / disturbances(d::RandomDisturbance, x, t), src/simulator/disturbances.jl:63-84: H samples in
+    [0, w_amp[1]) on the grid (k - 1) h, piecewise constant (searchsortedlast); the struct uses w_amp[1] whatever w_amp's length."""
+    from contactimplicitmpc.jl_amd.plant import RandomDisturbance
+    H, h, nw = 20, 0.01, 2
+    d = RandomDisturbance(nw, [3.0], H, h, seed=4)
+    assert d.w.shape == (H, 1, nw) and (d.w >= 0).all() and (d.w < 3.0).all() and d.w.max() > 1.5
+    np.testing.assert_array_equal(d.t, np.arange(H) * h)
+    for k in (1, 2, 7, H):                                                   # on a grid point and just before the next one: sample k
+        np.testing.assert_array_equal(d((k - 1) * h), d.w[k - 1, 0])
+        np.testing.assert_array_equal(d((k - 1) * h + 0.999 * h), d.w[k - 1, 0])
+    np.testing.assert_array_equal(d(1e9), d.w[H - 1, 0])                     # beyond the grid: the last sample
+    with pytest.raises(IndexError):
+        d(-h)
+    d2 = RandomDisturbance(nw, [3.0, 100.0], H, h, seed=4)                  # per-axis amplitudes: w_amp[1] is what is used (disturbances.jl:81)
+    np.testing.assert_array_equal(d2.w, d.w)
+    with pytest.raises(ValueError):
+        RandomDisturbance(nw, [1.0, 2.0, 3.0], H, h)
+    db = RandomDisturbance(3, 5.0, H, h, seed=1, B=16)                      # a Monte-Carlo batch: independent sequences per robot
+    assert db(0.0).shape == (16, 3) and np.unique(db(0.0)[:, 0]).size == 16
+
+
 def test_centroidal_plant_equals_the_torch_model_and_steps_along_the_trot():
     """centroidal_quadruped (BASELINE configs[4]'s model), damped and undamped: numpy plant against the torch model, and the
     undamped plant stepped from two consecutive configurations of the reference's in-place trot lands on the next one (the
