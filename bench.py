@@ -316,6 +316,50 @@ def centroidal_payload_inputs(B, H):
     return dict(m=m, P=P, kappa=kappa, rollouts=ro, Q=Q, R=R, ip_r_tol=1e-4, newton_r_tol=3e-5)
 
 
+def centroidal_velocity_objective(m, H):
+    """The objective of the example as written, examples/centroidal_quadruped/continuous_trot.jl:43-47: a TrackingVelocityObjective
+    whose Q alone is singular along a common x shift (body-x weight 0), V = 1e-3 diag(1,1,1, 1e3,1e3,1e3, 1 x 12), v_target = 0
+    (v0 = -0.0), R = 3e-3 I.  Returns (Q, R, V, v_target) as (H, n, n) / (H, nq) arrays."""
+    from contactimplicitmpc.jl_amd import lcp_models
+    Q = np.tile(lcp_models.relative_state_cost([0.0, 1, 1], 3e-1 * np.ones(3), [0.2, 0.2, 1.0])[None], (H, 1, 1))
+    R = np.tile((3e-3 * np.eye(m.nu))[None], (H, 1, 1))
+    V = np.tile(np.diag(1e-3 * np.concatenate([np.ones(3), 1e3 * np.ones(3), np.ones(12)]))[None], (H, 1, 1))
+    return Q, R, V, np.zeros((H, m.nq))
+
+
+def centroidal_velocity_leg(I, B, H, device, steps=2):
+    """BASELINE configs[4] with the example's OWN objective (`centroidal_velocity_objective`): P is block tridiagonal, the KKT
+    stage is the banded L D L^T of the interleaved ordering - the configuration is KKT-bound."""
+    import torch
+    from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions
+    m, P, kappa, ro = I["m"], I["P"], I["kappa"], I["rollouts"]
+    Q, R, V, vt = centroidal_velocity_objective(m, H)
+    s = CIMPCSolver(m.nq, m.nu, m.nw, m.nc, m.nb, P.H, H, B=B, mode=0, ip_opts=InteriorPointOptions(kappa_tol=kappa, r_tol=1e-4),
+                    newton_opts=NewtonOptions(kappa=kappa, r_tol=3e-5, max_iter=5), device=device)
+    for t in range(P.H):
+        s.set_linearization(t + 1, P.z[t], P.theta[t], P.r0[t], P.rz0[t], P.rth0[t])
+    s.set_objective(Q, R, V=V, v_target=vt)
+    s.set_window(np.stack([r["window"] for r in ro]) + 1)
+    s.set_reference(*(np.stack([r[k] for r in ro]) for k in ("q", "u", "w", "gamma", "b", "theta")))
+    q0 = torch.tensor(np.stack([r["q0"] for r in ro]), dtype=torch.float64, device="cuda")
+    q1 = torch.tensor(np.stack([r["q1"] for r in ro]), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    s.newton_solve_dev(q0.data_ptr(), q1.data_ptr(), False)
+    s.profile_enable(True); s.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        s.newton_solve_dev(q0.data_ptr(), q1.data_ptr(), False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    pr = s.profile_read(); st = s.stats()
+    _, it, rn = s.newton_info()
+    s.close()
+    return {"objective": "TrackingVelocityObjective of continuous_trot.jl:43-47 (Q singular along x, V, v_target = 0)", "kkt": "banded L D L^T (interleaved ordering)",
+            "value": B / dt, "unit": "MPC steps/s", "ms_per_step": 1e3 * dt, "newton_iters_per_step": float(it.mean()),
+            "converged_rollouts": int((rn < 3e-5).sum()), "kkt_ms_per_step": pr["kkt_ms"] / steps, "ip_sweep_ms_per_step": pr["ip_sweep_ms"] / steps,
+            "kkt_systems_per_step": pr["kkt_systems"] / steps, "ip_failures": st["ip_failures"]}
+
+
 def centroidal_payload_leg(B, H, device, steps=3):
     """BASELINE configs[4]: centroidal_quadruped with a payload (body-force disturbance w in theta:
     src/dynamics/centroidal_quadruped/model.jl:121-125, continuous_trot.jl:80-81), H = 60, on the REAL problem
@@ -369,6 +413,10 @@ def centroidal_payload_leg(B, H, device, steps=3):
                      "ip_failures": st["ip_failures"], "kkt_systems_since_create": int(it.sum()) * (steps + 1),
                      "kkt_fp64_fallbacks_since_create": s.kkt_fallbacks() if backend == 3 else 0}
         s.close()
+    try:      # the example's own objective on the same rollouts (KKT-bound: banded L D L^T)
+        out["velocity_objective"] = centroidal_velocity_leg(I, B, H, device)
+    except Exception as e:
+        out["velocity_objective"] = {"error": repr(e)}
     ref = u1s["fp64_kkt"]
     out["u1_max_abs_diff_vs_fp64_default"] = {k: float(np.abs(v - ref).max()) for k, v in u1s.items() if k != "fp64_kkt"}
     out["u1_scale"] = float(np.abs(ref).max())

@@ -58,6 +58,7 @@ struct Knobs {
     int drain_min = 4;           // CIMPC_DRAIN_MIN: ... for solves that have had at least this many iterations in the launch
     int async_full_max = 64;     // CIMPC_ASYNC_FULL_MAX: largest batch solved by the single persistent launch alone (larger: hybrid).
                                  // Measured 128 -> 64: B = 96 8.88 -> 8.11 ms, B = 128 9.72 -> 9.48 ms, B = 64 unchanged (6.9 ms)
+    int small_round = 0;         // CIMPC_SMALL_ROUND: lock-step rounds with at most this many interior-point problems run one sweep workgroup per CU (0 = off)
     bool generic_static = false; // CIMPC_GENERIC_STATIC: runtime-dimension sweep with the static queue partition of rounds 2-3 instead of the dynamic pull
     int kkt_pipe = -1;           // CIMPC_KKT_PIPE: three-wave pipelined KKT kernel 0 never, 1 always, -1 where the solve is on the critical path
     // ---- constants ----
@@ -94,6 +95,7 @@ struct Knobs {
         drain_min = std::max(1, env_int("CIMPC_DRAIN_MIN", drain_min));
         kkt_pipe = env_int("CIMPC_KKT_PIPE", kkt_pipe);
         generic_static = env_int("CIMPC_GENERIC_STATIC", generic_static ? 1 : 0) != 0;
+        small_round = env_int("CIMPC_SMALL_ROUND", small_round);
     }
 };
 
@@ -320,13 +322,16 @@ IpParams make_ip_params(cimpc_ctx* h, const TrajDev& T, int par, int* pending_co
 
 // queue kernel + sensitivity kernel of one round
 int run_sweep(cimpc_ctx* h, int par, int* pending_counter, double* zout, hipStream_t st, int iter_cap = 0, int* drain_counter = nullptr,
-              bool with_products = false) {
+              bool with_products = false, long long problems_hint = -1) {
     IpParams p = make_ip_params(h, h->S.cand, par, pending_counter, zout);
+    // a round with few problems is a latency chain: with ONE workgroup per CU every wave has its SIMD to itself (an interior-point
+    // iteration of a lone wave takes ~12 k cycles, ~15.5 k next to a second wave) - Knobs::small_round
+    if (problems_hint >= 0 && h->kn.small_round > 0 && problems_hint <= h->kn.small_round && h->ki.G == 16 && p.wpk > 256) p.wpk = 256;
     if (with_products && h->S.dtn != nullptr) { p.nu = h->S.nu_cand; p.dtn = h->S.dtn; }
     if (iter_cap > 0) p.iter_cap = iter_cap;
     if (drain_counter != nullptr && h->kn.drain_pct > 0 && p.iter_cap < h->ip.max_iter) {
         p.drain_count = drain_counter;
-        p.drain_thresh = std::max(1, (int)((long long)h->wpk * h->kn.drain_pct / 100));
+        p.drain_thresh = std::max(1, (int)((long long)p.wpk * h->kn.drain_pct / 100));
         p.drain_min = h->kn.drain_min;
     }
     prof_begin(h, PC_IP, st);
@@ -1217,7 +1222,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     // tail again, 10.7 -> 11.0-11.3 ms.)
     long long launched = 0, completed = 0, rounds = 0;
     const bool dbg_rounds = h->kn.debug_rounds;
-    int last_kkt = 0, last_sweep = h->dm.B, last_slots = h->dm.B;
+    int last_kkt = 0, last_sweep = h->dm.B, last_slots = h->dm.B, last_parked = 0;
     // Single rollouts (B < 4: below the persistent kernel's range) keep ONE round queued ahead of the one the host waits for: such a
     // round is launched BLIND - KKT kernel on the full list range with its count read on the device, everything else is
     // device-driven anyway - and costs three empty launches if the solve turns out to be over; in exchange no round waits for the
@@ -1272,7 +1277,9 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         // (in a blind round `last_sweep` is one round stale: the cap is then chosen without it)
         const bool sparse = tail_div > 0 && (h->dm.B < tail_div || (!blind && (long long)last_sweep * tail_div <= h->dm.B));
         const int cap = sparse ? h->ip.max_iter : h->iter_cap;
-        int rr = run_sweep(h, par, d_cnt + 2 * CPAD, nullptr, sb.st, cap, d_cnt + 3 * CPAD, true);
+        // problems of this round as far as the host knows them: the evaluation slots requested + the solves the last sweep parked
+        const long long hint = blind ? -1 : (long long)last_slots * h->dm.H + last_parked;
+        int rr = run_sweep(h, par, d_cnt + 2 * CPAD, nullptr, sb.st, cap, d_cnt + 3 * CPAD, true, hint);
         if (rr != CIMPC_OK) return rr;
         if (kkt && h->kkt_overlap && hipStreamWaitEvent(sb.st, sb.ev_join, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join failed");
         prof_begin(h, PC_RESID, sb.st);
@@ -1320,6 +1327,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         last_sweep = n_sweep;
         last_kkt = hr[1];
         last_slots = hr[6];
+        last_parked = hr[4];
         if (dbg_rounds) fprintf(stderr, "[cimpc round %lld] t %.3f ms: next sweep %d rollouts (%d evaluation slots), next kkt %d, parked %d, finished %d\n", completed,
                                 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), n_sweep, last_slots, last_kkt, hr[4], hr[5]);
         h->prof_kkt_systems += last_kkt;

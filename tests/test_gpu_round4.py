@@ -185,3 +185,53 @@ def test_ip_time_budget_runtime_dimension_kernel(gpu_required):
     s = make_solver(d, prob, rollouts, 4, ip_opts=InteriorPointOptions(kappa_tol=prob["kappa"], max_time=1e-8))
     got = s.implicit_dynamics(q, th); s.close()
     assert (got["status"] == 0).all() and got["iters"].max() <= 1
+
+
+@pytest.mark.gpu
+def test_config4_velocity_objective_h60_vs_oracle(gpu_required):
+    """BASELINE configs[4] with the example's OWN objective (examples/centroidal_quadruped/continuous_trot.jl:43-47: a
+    TrackingVelocityObjective, Q singular along a common x shift) at the bench leg's size H = 60, on rollouts of the bench leg's
+    exact inputs (`bench.centroidal_payload_inputs(64, 60)`, payload w_z = -5 .. -30 N): the device's banded L D L^T KKT stage against
+    the numpy oracle's dense LU of the assembled `jacobian!` matrix (N = 2880; a subset of the 64 rollouts - the oracle takes ~10 s per
+    rollout).  VERDICT r03 "missing" #4: this form had been tested at H = 50, B = 3 only."""
+    import bench
+    from oracle.dims import Dims
+    from oracle.newton import Traj
+    from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions
+    from contactimplicitmpc.jl_amd.trajectory import Objective
+    H, NB = 60, 4
+    I = bench.centroidal_payload_inputs(64, H)
+    m, P, kappa = I["m"], I["P"], I["kappa"]
+    ro = I["rollouts"][:NB // 2] + I["rollouts"][-(NB - NB // 2):]
+    Q, R, V, vt = bench.centroidal_velocity_objective(m, H)
+    s = CIMPCSolver(m.nq, m.nu, m.nw, m.nc, m.nb, P.H, H, B=NB, mode=0, ip_opts=InteriorPointOptions(kappa_tol=kappa, r_tol=1e-4),
+                    newton_opts=NewtonOptions(kappa=kappa, r_tol=3e-5, max_iter=5))
+    for t in range(P.H):
+        s.set_linearization(t + 1, P.z[t], P.theta[t], P.r0[t], P.rz0[t], P.rth0[t])
+    s.set_objective(Q, R, V=V, v_target=vt)
+    s.set_window(np.stack([r["window"] for r in ro]) + 1)
+    s.set_reference(*(np.stack([r[k] for r in ro]) for k in ("q", "u", "w", "gamma", "b", "theta")))
+    u1, it, rn = s.newton_solve(np.stack([r["q0"] for r in ro]), np.stack([r["q1"] for r in ro]))
+    tr = s.trajectory(); cnt = s.rollout_counters()
+    s.close()
+    d = Dims(nq=m.nq, nu=m.nu, nw=m.nw, nc=m.nc, nb=m.nb, mode=0)
+    tabs = [lcp.LinTable(d, P.z[t], P.theta[t], P.r0[t], P.rz0[t], P.rth0[t]) for t in range(P.H)]
+    obj = Objective(q=Q, u=R, gamma=np.zeros((H, m.nc, m.nc)), b=np.zeros((H, m.nb, m.nb)), v=V, v_target=vt)
+    assert np.abs(np.stack([r["w"] for r in ro])[:, :, 2]).min() >= 5.0          # the payload is live
+    same = 0
+    for b, r in enumerate(ro):
+        ref = Traj(q=r["q"], u=r["u"], w=r["w"], gamma=r["gamma"], b=r["b"], theta=r["theta"])
+        core = onewton.Newton(d, H, obj, onewton.NewtonOptions(r_tol=3e-5, max_iter=5, solver="lu"),
+                              oip.IPOptions(kappa_tol=kappa, r_tol=1e-4), kappa, ref)
+        st = onewton.newton_solve(core, r["q0"], r["q1"], r["window"], tabs, ref)
+        assert it[b] == st.iters and st.iters >= 2, (b, it[b], st.iters)
+        path = cnt["sweeps"][b] == st.sweeps and cnt["ip_iters"][b] == st.ip_iters
+        du = np.abs(u1[b] - core.traj.u[0]).max() / max(1.0, np.abs(core.traj.u[0]).max())
+        dq = np.abs(tr["q"][b] - core.traj.q).max()
+        if path:        # kappa = 1e-3, IP r_tol 1e-4: far from the round-off floor - the shared path is held tightly
+            same += 1
+            assert du < 1e-6 and dq < 1e-7, (b, du, dq)
+        else:
+            assert du < 5e-2 and dq < 1e-2, (b, du, dq)
+        np.testing.assert_allclose(rn[b], st.r_norm / core.lay.N, rtol=2e-2 if path else 0.15, atol=1e-12)
+    assert same >= NB - 1, same
