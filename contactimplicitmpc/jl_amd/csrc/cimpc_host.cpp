@@ -1279,6 +1279,15 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         const int cap = sparse ? h->ip.max_iter : h->iter_cap;
         // problems of this round as far as the host knows them: the evaluation slots requested + the solves the last sweep parked
         const long long hint = blind ? -1 : (long long)last_slots * h->dm.H + last_parked;
+        if (dbg_rounds && !blind) {      // diagnostics only: the problems this round's sweep will find in its queues (a blocking read)
+            std::vector<int> qc((size_t)h->Q.K * QPAD);
+            (void)hipStreamSynchronize(sb.st); (void)hipStreamSynchronize(sb.st_kkt);
+            if (hipMemcpy(qc.data(), h->Q.count + (size_t)par * h->Q.K * QPAD, qc.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) {
+                long long tot = 0;
+                for (int k = 0; k < h->Q.K; ++k) tot += qc[(size_t)k * QPAD];
+                fprintf(stderr, "[cimpc round %lld] sweep launch: %lld problems queued (host hint %lld)\n", r, tot, hint);
+            }
+        }
         int rr = run_sweep(h, par, d_cnt + 2 * CPAD, nullptr, sb.st, cap, d_cnt + 3 * CPAD, true, hint);
         if (rr != CIMPC_OK) return rr;
         if (kkt && h->kkt_overlap && hipStreamWaitEvent(sb.st, sb.ev_join, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join failed");
