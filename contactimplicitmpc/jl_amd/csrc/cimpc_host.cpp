@@ -1554,6 +1554,17 @@ int cimpc_debug_read_stats(cimpc_handle h, long long* out, int n) {
 }
 #endif
 
+#ifdef CIMPC_DEBUG_STATS
+// diagnostic builds only: the raw per-rollout statistics records + the device addresses of the neighbouring allocations
+int cimpc_debug_dump_stats(cimpc_handle h, long long* out, unsigned long long* addr8) {
+    if (!h || !out || !addr8) return CIMPC_ERR_INVALID;
+    HIP_TRY(h, hipMemcpy(out, h->S.stats, (size_t)h->dm.B * 4 * sizeof(long long), hipMemcpyDeviceToHost));
+    const void* a[8] = {h->S.kkt_list, h->S.slot_list, h->S.counters, h->S.stats, h->S.ro_sweeps, h->S.ro_ip_iters, h->S.ro_ip_fail, h->S.nlog};
+    for (int k = 0; k < 8; ++k) addr8[k] = (unsigned long long)a[k];
+    return CIMPC_OK;
+}
+#endif
+
 int cimpc_get_stats(cimpc_handle h, cimpc_stats* s) {
     if (!h || !s) return CIMPC_ERR_INVALID;
     *s = h->last_stats;

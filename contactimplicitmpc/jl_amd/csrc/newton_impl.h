@@ -62,6 +62,7 @@ __device__ __forceinline__ double ls_alpha(int iter) { return ldexp(1.0, -iter);
 __device__ __forceinline__ void list_slot(const NewtonDev& S, size_t sb, int par, int pos = -1) {
     if (S.slot_list == nullptr) return;
     if (pos < 0) pos = atomicAdd(&S.counters[4 * CPAD], 1);
+    if (pos >= S.dm.B * CS) __builtin_trap();      // (a slot is listed at most once per round: cannot happen)
     S.slot_list[(size_t)par * S.dm.B * CS + pos] = (int)sb;
 }
 
@@ -86,7 +87,9 @@ __device__ __forceinline__ void enqueue_eval(const NewtonDev& S, size_t sb, int 
 // so one atomic per horizon step reserves the entries of all of them, and one reserves their places in the round's slot list
 // (a round of 512 rollouts x 3 candidates x 40 steps put 61 k atomics on the 60 queue counters and 1.5 k on the list counter:
 // same-address atomics serialise, the last decision blocks of a round queued behind them).
-__device__ __forceinline__ void enqueue_evals(const NewtonDev& S, size_t sb, int n, int b, int par, int tid, int nt) {
+// mark: value written to need_sweep - 1 = "evaluated by the sweep this round's decision stage follows", 2 = "requested by the KKT
+// kernel that runs NEXT TO the running round for the round after it" (see the decision stage's entry checks)
+__device__ __forceinline__ void enqueue_evals(const NewtonDev& S, size_t sb, int n, int b, int par, int tid, int nt, int mark = 1) {
     const int H = S.dm.H, K = S.WQ.K;
     for (int k = tid; k < H; k += nt) {
         const int t = S.WQ.window[(size_t)b * (H + 2) + k];
@@ -97,9 +100,10 @@ __device__ __forceinline__ void enqueue_evals(const NewtonDev& S, size_t sb, int
     if (tid == 0) {
         int pos = 0;
         if (S.slot_list != nullptr) pos = atomicAdd(&S.counters[4 * CPAD], n);
+        if (pos + n > S.dm.B * CS) __builtin_trap();      // (a slot is listed at most once per round: cannot happen)
         for (int c = 0; c < n; ++c) {
             S.WQ.done_count[sb + c] = 0;
-            S.need_sweep[sb + c] = 1;
+            S.need_sweep[sb + c] = mark;
             if (S.slot_list != nullptr) S.slot_list[(size_t)par * S.dm.B * CS + pos + c] = (int)(sb + c);
         }
     }
@@ -294,7 +298,12 @@ __device__ __forceinline__ void start_line_search(const NewtonDev& S, int b, int
         // candidates join the queue of the next round
         // (chained round, kkt_same_round = 2: the round's second sweep consumes par ^ 1 - nothing is requested of the next round)
         const int par = (S.kkt_same_round == 1) ? S.WQ.par : (S.WQ.par ^ 1);
-        enqueue_evals(S, sb0, n, b, par, lane, nt);
+        // overlapped KKT kernel (kkt_same_round = 0): this round's decision kernel runs AFTER this kernel and would take the
+        // freshly requested candidates (stage LS*, need_sweep set, done_count 0) for an evaluation of ITS round with parked
+        // solves - it re-listed every one of them (round 3: each such slot sat twice on the next round's list, two residual
+        // blocks per slot, and a batch of 128 rollouts with seven-candidate searches ran over the end of the list).  Mark 2
+        // tells the decision stage "not yours yet".
+        enqueue_evals(S, sb0, n, b, par, lane, nt, S.kkt_same_round == 0 ? 2 : 1);
         if (lane == 0) {
             for (int c = n; c < CS; ++c) S.need_sweep[sb0 + c] = 0;
             if (S.kkt_same_round != 2) atomicAdd(&S.counters[0 * CPAD], 1);
@@ -545,6 +554,10 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
     if constexpr (SPLIT == 2) {
         const bool mine = tid >= it0 && tid < it0 + ncand;
         if (!__syncthreads_or(tid == it0 && pre_ns != 0)) return;    // nothing was evaluated for this rollout
+        if (__syncthreads_or(tid == it0 && pre_ns == 2)) {           // requested by this round's KKT kernel for the NEXT round: already
+            if (mine) S.need_sweep[sb0 + tid] = 1;                   // counted and listed there - from the next round on it is ours
+            return;
+        }
         if (__syncthreads_or(mine && pre_dc < H)) {                  // an interior-point solve of this evaluation is still parked: wait for the next round
             if (tid == 0) atomicAdd(&S.counters[0 * CPAD], 1);
             if (mine) list_slot(S, sb0 + tid, S.WQ.par ^ 1);         // its slots stay on the list
@@ -553,6 +566,13 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
         if (mine) rc[tid - it0] = pre_rc;
     } else {
         if (S.need_sweep[sb0 + it0] == 0) return;    // nothing was evaluated for this rollout
+        if constexpr (!ASYNC) {
+            if (S.need_sweep[sb0 + it0] == 2) {      // requested by this round's overlapped KKT kernel for the next round (see above)
+                __syncthreads();
+                if (tid < ncand) S.need_sweep[sb0 + it0 + tid] = 1;
+                return;
+            }
+        }
         if constexpr (!ASYNC) {   // an interior-point solve of this evaluation is still parked: wait for the next round
             int pend = 0;
             if (tid < ncand) pend = (S.WQ.done_count[sb0 + it0 + tid] < H);
@@ -814,13 +834,13 @@ __global__ __launch_bounds__(CIMPC_SLOT_THREADS) void resid_slot_kernel(NewtonDe
             if (ok != 0) eff_i = s_;
         }
     }
-    if (ns_my == 0 || stage == STAGE_DONE || stage == STAGE_KKT) return;
+    if (ns_my != 1 || stage == STAGE_DONE || stage == STAGE_KKT) return;      // (2 = requested for the next round, not evaluated yet)
     const int ncand = (stage == STAGE_LS1) ? 2 : (stage == STAGE_LS2) ? 4 : (stage == STAGE_LS7) ? 7 : (stage == STAGE_LS3) ? 3 : 1;
     const int it0 = (stage == STAGE_LS1) ? 1 : (stage == STAGE_LS2) ? 3 : 0;
     if (my < it0 || my >= it0 + ncand) return;
     const bool mine = tid >= it0 && tid < it0 + ncand;
     // nothing evaluated for this rollout, or one of its evaluations still has a parked solve (the decision waits a round)
-    if (__syncthreads_or((tid == it0 && nsl == 0) || (mine && dc < H))) return;
+    if (__syncthreads_or((tid == it0 && nsl != 1) || (mine && dc < H))) return;
     if (use_eff && tid < H) eff[tid] = eff_i;
     __syncthreads();
     RPROF(1)
