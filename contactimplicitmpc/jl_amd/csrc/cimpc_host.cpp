@@ -58,6 +58,7 @@ struct Knobs {
     int drain_min = 4;           // CIMPC_DRAIN_MIN: ... for solves that have had at least this many iterations in the launch
     int async_full_max = 64;     // CIMPC_ASYNC_FULL_MAX: largest batch solved by the single persistent launch alone (larger: hybrid).
                                  // Measured 128 -> 64: B = 96 8.88 -> 8.11 ms, B = 128 9.72 -> 9.48 ms, B = 64 unchanged (6.9 ms)
+    int kkt_pipe_small = 0;      // CIMPC_KKT_PIPE_SMALL: rounds whose sweep has at most this many problems run the three-wave pipelined KKT kernel (0 = off)
     int small_round = 0;         // CIMPC_SMALL_ROUND: lock-step rounds with at most this many interior-point problems run one sweep workgroup per CU (0 = off)
     bool generic_static = false; // CIMPC_GENERIC_STATIC: runtime-dimension sweep with the static queue partition of rounds 2-3 instead of the dynamic pull
     int kkt_pipe = -1;           // CIMPC_KKT_PIPE: three-wave pipelined KKT kernel 0 never, 1 always, -1 where the solve is on the critical path
@@ -96,6 +97,7 @@ struct Knobs {
         kkt_pipe = env_int("CIMPC_KKT_PIPE", kkt_pipe);
         generic_static = env_int("CIMPC_GENERIC_STATIC", generic_static ? 1 : 0) != 0;
         small_round = env_int("CIMPC_SMALL_ROUND", small_round);
+        kkt_pipe_small = env_int("CIMPC_KKT_PIPE_SMALL", kkt_pipe_small);
     }
 };
 
@@ -1246,7 +1248,11 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         const bool kkt = (r > 0) && (blind || last_kkt > 0);
         const int n_kkt = blind ? h->dm.B : last_kkt;
         const int* n_kkt_dev = blind ? h->d_ring + 8 * CPAD * (slot ^ 1) + 1 * CPAD : nullptr;      // the previous round's count of KKT requests
-        const int pipe = h->kn.kkt_pipe >= 0 ? h->kn.kkt_pipe : (!h->kkt_overlap && n_kkt <= h->kn.kkt_pipe_max) ? 1 : 0;
+        // a round whose sweep is short is as long as its KKT recursion (272 us for the packed one-wave kernel next to the sweep):
+        // there the three-wave kernel pays (Knobs::kkt_pipe_small; next to a FULL sweep it costs the sweep more than it gains)
+        const long long sweep_problems = blind ? -1 : (long long)last_slots * h->dm.H + last_parked;
+        const bool light_sweep = h->kn.kkt_pipe_small > 0 && sweep_problems >= 0 && sweep_problems <= h->kn.kkt_pipe_small && n_kkt <= h->kn.kkt_pipe_max;
+        const int pipe = h->kn.kkt_pipe >= 0 ? h->kn.kkt_pipe : ((!h->kkt_overlap && n_kkt <= h->kn.kkt_pipe_max) || light_sweep) ? 1 : 0;
         if (kkt && !h->kkt_overlap) {   // small batches: latency matters, keep the KKT result in this round
             Sk.kkt_same_round = 1;
             prof_begin(h, PC_KKT, sb.st);
