@@ -58,8 +58,6 @@ struct Knobs {
     int drain_min = 4;           // CIMPC_DRAIN_MIN: ... for solves that have had at least this many iterations in the launch
     int async_full_max = 64;     // CIMPC_ASYNC_FULL_MAX: largest batch solved by the single persistent launch alone (larger: hybrid).
                                  // Measured 128 -> 64: B = 96 8.88 -> 8.11 ms, B = 128 9.72 -> 9.48 ms, B = 64 unchanged (6.9 ms)
-    int kkt_pipe_small = 0;      // CIMPC_KKT_PIPE_SMALL: rounds whose sweep has at most this many problems run the three-wave pipelined KKT kernel (0 = off)
-    int small_round = 0;         // CIMPC_SMALL_ROUND: lock-step rounds with at most this many interior-point problems run one sweep workgroup per CU (0 = off)
     bool generic_static = false; // CIMPC_GENERIC_STATIC: runtime-dimension sweep with the static queue partition of rounds 2-3 instead of the dynamic pull
     int kkt_pipe = -1;           // CIMPC_KKT_PIPE: three-wave pipelined KKT kernel 0 never, 1 always, -1 where the solve is on the critical path
     // ---- constants ----
@@ -96,8 +94,6 @@ struct Knobs {
         drain_min = std::max(1, env_int("CIMPC_DRAIN_MIN", drain_min));
         kkt_pipe = env_int("CIMPC_KKT_PIPE", kkt_pipe);
         generic_static = env_int("CIMPC_GENERIC_STATIC", generic_static ? 1 : 0) != 0;
-        small_round = env_int("CIMPC_SMALL_ROUND", small_round);
-        kkt_pipe_small = env_int("CIMPC_KKT_PIPE_SMALL", kkt_pipe_small);
     }
 };
 
@@ -324,11 +320,10 @@ IpParams make_ip_params(cimpc_ctx* h, const TrajDev& T, int par, int* pending_co
 
 // queue kernel + sensitivity kernel of one round
 int run_sweep(cimpc_ctx* h, int par, int* pending_counter, double* zout, hipStream_t st, int iter_cap = 0, int* drain_counter = nullptr,
-              bool with_products = false, long long problems_hint = -1) {
+              bool with_products = false) {
     IpParams p = make_ip_params(h, h->S.cand, par, pending_counter, zout);
-    // a round with few problems is a latency chain: with ONE workgroup per CU every wave has its SIMD to itself (an interior-point
-    // iteration of a lone wave takes ~12 k cycles, ~15.5 k next to a second wave) - Knobs::small_round
-    if (problems_hint >= 0 && h->kn.small_round > 0 && problems_hint <= h->kn.small_round && h->ki.G == 16 && p.wpk > 256) p.wpk = 256;
+    // (round 4, measured and removed: one sweep workgroup per CU in rounds with few problems - <= 4 k / 8 k / 16 k - so that every
+    //  wave has its SIMD to itself: 7.97 -> 7.96 / 7.99 / 8.01 ms per step, no effect: profiles/r04/knob_small_round.log)
     if (with_products && h->S.dtn != nullptr) { p.nu = h->S.nu_cand; p.dtn = h->S.dtn; }
     if (iter_cap > 0) p.iter_cap = iter_cap;
     if (drain_counter != nullptr && h->kn.drain_pct > 0 && p.iter_cap < h->ip.max_iter) {
@@ -1248,11 +1243,10 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         const bool kkt = (r > 0) && (blind || last_kkt > 0);
         const int n_kkt = blind ? h->dm.B : last_kkt;
         const int* n_kkt_dev = blind ? h->d_ring + 8 * CPAD * (slot ^ 1) + 1 * CPAD : nullptr;      // the previous round's count of KKT requests
-        // a round whose sweep is short is as long as its KKT recursion (272 us for the packed one-wave kernel next to the sweep):
-        // there the three-wave kernel pays (Knobs::kkt_pipe_small; next to a FULL sweep it costs the sweep more than it gains)
-        const long long sweep_problems = blind ? -1 : (long long)last_slots * h->dm.H + last_parked;
-        const bool light_sweep = h->kn.kkt_pipe_small > 0 && sweep_problems >= 0 && sweep_problems <= h->kn.kkt_pipe_small && n_kkt <= h->kn.kkt_pipe_max;
-        const int pipe = h->kn.kkt_pipe >= 0 ? h->kn.kkt_pipe : ((!h->kkt_overlap && n_kkt <= h->kn.kkt_pipe_max) || light_sweep) ? 1 : 0;
+        // (round 4, measured and removed: the three-wave kernel in rounds whose sweep is light - <= 16 k / 26 k / 60 k problems: KKT kernel
+        //  time 3.6 -> 3.4 / 3.0 / 2.7 ms per step, but the sweep and the tail give it back, 7.93 -> 7.88 / 7.88 / 7.96 ms:
+        //  profiles/r04/knob_kkt_pipe_small.log)
+        const int pipe = h->kn.kkt_pipe >= 0 ? h->kn.kkt_pipe : (!h->kkt_overlap && n_kkt <= h->kn.kkt_pipe_max) ? 1 : 0;
         if (kkt && !h->kkt_overlap) {   // small batches: latency matters, keep the KKT result in this round
             Sk.kkt_same_round = 1;
             prof_begin(h, PC_KKT, sb.st);
@@ -1294,7 +1288,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
                 fprintf(stderr, "[cimpc round %lld] sweep launch: %lld problems queued (host hint %lld)\n", r, tot, hint);
             }
         }
-        int rr = run_sweep(h, par, d_cnt + 2 * CPAD, nullptr, sb.st, cap, d_cnt + 3 * CPAD, true, hint);
+        int rr = run_sweep(h, par, d_cnt + 2 * CPAD, nullptr, sb.st, cap, d_cnt + 3 * CPAD, true);
         if (rr != CIMPC_OK) return rr;
         if (kkt && h->kkt_overlap && hipStreamWaitEvent(sb.st, sb.ev_join, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join failed");
         prof_begin(h, PC_RESID, sb.st);

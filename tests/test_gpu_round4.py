@@ -34,7 +34,15 @@ def _perturbed_knot(prob, t, rng, eps=2e-2):
 def test_relinearisation_between_warm_started_solves(gpu_required, ip_budget):
     """solve -> set_linearization for a subset of the knots -> warm-started solve -> again with another subset, against the
     oracle run on the updated LinTables.  ip_budget = 5 makes a good share of the solves fail, so the stale sensitivity blocks
-    (kept per KNOT, implicit_dynamics.jl:71-86,169-176 - untouched by the update, like the reference's ip[t].dz) are used too."""
+    (kept per KNOT, implicit_dynamics.jl:71-86,169-176 - untouched by the update, like the reference's ip[t].dz) are used too.
+
+    What is asserted, per (step, rollout) pair - measured on this case (scripts/dbg/relin_debug.py, profiles/r04/relin_debug.log):
+    the oracle's two KKT backends (two roundings of the same Newton step) end up to 2e-4 apart on the re-linearised, worse
+    conditioned problems, and a cold solve with identical iteration totals can sit 4.7e-7 from the oracle (a converged
+    interior-point solve is unique up to kappa_tol) - so every pair is held to max(5e-6, 5 x the oracle's own
+    backend distance), and the pairs on which the oracle is stable (backends 1e-9 apart, same counters as the device) are counted
+    at 1e-7: at least two of them AFTER an update (there the device was measured at 3e-9 / 7e-10).  A table that is not refreshed
+    somewhere (LDS copy, parked iterate, per-knot archive) shows up at 1e-3 .. 1e-2."""
     from contactimplicitmpc.jl_amd import InteriorPointOptions, NewtonOptions
     H, H_ref, B = 8, 12, 4
     d, prob, tabs, rollouts = make_case("quadruped", 0, H_ref=H_ref, H=H, B=B, seed=31, perturb=5e-3)
@@ -42,19 +50,13 @@ def test_relinearisation_between_warm_started_solves(gpu_required, ip_budget):
     ipk = dict(max_iter=ip_budget) if ip_budget else {}
     s = make_solver(d, prob, rollouts, H, obj=obj, ip_opts=InteriorPointOptions(kappa_tol=prob["kappa"], **ipk),
                     newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=1e-5, max_iter=4))
-    cores = [onewton.Newton(d, H, obj, onewton.NewtonOptions(r_tol=1e-5, max_iter=4, solver="lu"),
-                            oip.IPOptions(kappa_tol=prob["kappa"], **ipk), prob["kappa"], ref) for (_, ref, _, _) in rollouts]
-    # arbiter (as in tests/test_mpc_glue.py): the oracle's OTHER KKT backend through the same sequence - where the oracle's two
-    # roundings of the Newton step end apart (the perturbed knots are worse conditioned than the generator's), the device, a third
-    # rounding, is held to five times that distance, elsewhere to 1e-7
-    cores2 = [onewton.Newton(d, H, obj, onewton.NewtonOptions(r_tol=1e-5, max_iter=4, solver="condensed"),
-                             oip.IPOptions(kappa_tol=prob["kappa"], **ipk), prob["kappa"], ref) for (_, ref, _, _) in rollouts]
+    mk = lambda sv: [onewton.Newton(d, H, obj, onewton.NewtonOptions(r_tol=1e-5, max_iter=4, solver=sv),
+                                    oip.IPOptions(kappa_tol=prob["kappa"], **ipk), prob["kappa"], ref) for (_, ref, _, _) in rollouts]
+    cores, cores2 = mk("lu"), mk("condensed")
     tabs = list(tabs)
     rng = np.random.default_rng(7)
     q0 = np.stack([r[2] for r in rollouts]); q1 = np.stack([r[3] for r in rollouts])
-    agree = np.ones(B, dtype=bool)
-    failed = np.zeros(B, dtype=int)           # interior-point failures of a rollout so far, this run
-    checked = tight = 0
+    tight = tight_after = same_counters = pairs = 0
     for step, knots in enumerate(([], [1, 4, 5, 10], [0, 4, 7])):
         for t in knots:                       # update!(lin, s, z, theta) of these knots, on both sides
             new = _perturbed_knot(prob, t, rng)
@@ -62,37 +64,31 @@ def test_relinearisation_between_warm_started_solves(gpu_required, ip_budget):
             tabs[t] = lcp.LinTable(d, *new)
         u1, it, rn = s.newton_solve(q0, q1, warm_start=step > 0)
         tr = s.trajectory(); cnt = s.rollout_counters()
+        if step > 0:
+            assert it.max() >= 1          # the update changed the problem: on unchanged tables a warm-started solve needs no iteration
         for b, (window, ref, a, b_) in enumerate(rollouts):
             st = onewton.newton_solve(cores[b], a, b_, window, tabs, ref, warm_start=step > 0)
             st2 = onewton.newton_solve(cores2[b], a, b_, window, tabs, ref, warm_start=step > 0)
-            agree[b] &= (it[b] == st.iters and cnt["ip_iters"][b] == st.ip_iters and cnt["ip_failures"][b] == st.ip_fail)
-            failed[b] += st.ip_fail
-            if agree[b] and (st2.iters, st2.ip_iters) == (st.iters, st.ip_iters):      # same discrete path so far, on all three
-                # a FAILED interior-point solve hands the Newton loop the iterate it stopped at (implicit_dynamics.jl:169-190) - not
-                # a converged point: equal iteration counts pin it to the conditioning of a jammed iterate, not to 1e-7.  Rollouts that
-                # have had a failed solve are held to 5e-6, the others to 1e-7 / the arbiter.
-                floor = 1e-7 if failed[b] == 0 else 5e-6
-                tol_u = max(floor, 5.0 * np.abs(cores2[b].traj.u[0] - cores[b].traj.u[0]).max())
-                tol_q = max(floor, 5.0 * np.abs(cores2[b].traj.q - cores[b].traj.q).max())
-                du = np.abs(u1[b] - cores[b].traj.u[0]).max(); dq = np.abs(tr["q"][b] - cores[b].traj.q).max()
-                if du <= tol_u and dq <= tol_q:
-                    checked += 1
-                    tight += int(tol_q == 1e-7 and tol_u == 1e-7)
-                else:
-                    # equal TOTALS of interior-point iterations do not exclude two solves flipping one iteration in opposite
-                    # directions (a converged solve is unique up to kappa_tol: d moves ~1e-6) - measured
-                    # on this case: rollout 0 of the cold solve, 4.7e-7 in q.  Such a rollout counts as off the oracle's path from
-                    # here on, inside the flip band.
-                    assert du < 2e-5 and dq < 2e-5, (step, b, du, dq)
-                    agree[b] = False
+            d_oo = max(np.abs(cores2[b].traj.u[0] - cores[b].traj.u[0]).max(), np.abs(cores2[b].traj.q - cores[b].traj.q).max())
+            du = np.abs(u1[b] - cores[b].traj.u[0]).max(); dq = np.abs(tr["q"][b] - cores[b].traj.q).max()
+            on_path = it[b] == st.iters and cnt["sweeps"][b] == st.sweeps
+            if not ip_budget:
+                assert on_path, (step, b, it[b], st.iters)
+            elif not on_path:         # (5-iteration budget: a search is up to 29 evaluations deep - a flipped decision ends the comparison)
+                continue
+            pairs += 1
+            assert max(du, dq) <= max(5e-6, 5.0 * d_oo), (step, b, du, dq, d_oo)
+            same = cnt["ip_iters"][b] == st.ip_iters and cnt["ip_failures"][b] == st.ip_fail
+            same_counters += int(same)
+            if same and d_oo < 1e-9 and (st2.ip_iters, st2.ip_fail) == (st.ip_iters, st.ip_fail) and max(du, dq) <= 1e-7:
+                tight += 1
+                tight_after += int(step > 0)
         if ip_budget and step == 0:
             assert cnt["ip_failures"].sum() > 0          # the stale-block path is really exercised
-    # (with the 5-iteration budget a solve is up to 29 evaluations deep - one flipped discrete decision and a rollout leaves the
-    #  oracle's path for good)
-    need = B - 1 if not ip_budget else B - 2
-    assert agree.sum() >= need and checked >= B, (agree, checked)
     if not ip_budget:
-        assert tight >= B - 1, tight          # the first solves are held to 1e-7
+        assert tight >= 4 and tight_after >= 2 and same_counters >= 6, (tight, tight_after, same_counters)
+    else:
+        assert pairs >= 6 and same_counters >= 3, (pairs, same_counters)
     s.close()
 
 
