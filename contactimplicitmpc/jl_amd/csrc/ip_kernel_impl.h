@@ -54,7 +54,10 @@ struct Model {
 // (measured dead ends: C A^-1, A^-1, Dy1 rows register-resident per knot - the 76 extra VGPRs spill, sweep launch 0.30 -> 0.47 ms;
 //  rows of R left in the LDS tile instead of registers for a third wave per SIMD - the spills stay, 0.35 -> 0.63 ms)
 #define CIMPC_SENS_ILP 5      // (a constant of the build: the -D override is gone with the experiment it served)
-    static constexpr int SENS_ILP = (NX <= 16 && NY <= 16) ? CIMPC_SENS_ILP : 2;   // sensitivity columns solved side by side
+#ifndef CIMPC_SENS_ILP32
+#define CIMPC_SENS_ILP32 2
+#endif
+    static constexpr int SENS_ILP = (NX <= 16 && NY <= 16) ? CIMPC_SENS_ILP : CIMPC_SENS_ILP32;   // sensitivity columns solved side by side
     // per-problem LDS: the R tile and theta - theta0 SHARE their space (theta - theta0 lives from the pull of a problem to the two
     // dot products a few lines below it; the tile is scratch inside factorize), then the backlog of deferred sensitivities
     static constexpr int TILE = NY * RST_LD > NTH ? NY * RST_LD : NTH;
