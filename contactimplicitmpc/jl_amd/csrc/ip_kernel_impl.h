@@ -62,7 +62,11 @@ struct Model {
     // dot products a few lines below it; the tile is scratch inside factorize), then the backlog of deferred sensitivities
     static constexpr int TILE = NY * RST_LD > NTH ? NY * RST_LD : NTH;
     // ... then one 64-bit word per group: the clock value the running solve's time budget counts from (IpParams::budget_ticks)
-    static constexpr int LDS_GROUP = ((TILE + SENS_MAX / 2 + 1) + 1) & ~1;  // doubles / problem
+    // ... then (32-lane groups) three staging vectors of G doubles: one for lane-indexed vectors that feed a matrix-vector
+    // product, two (by step parity) for the column the MGS step broadcasts - IpSolver::stage / factorize
+    static constexpr int OFF_BV = ((TILE + SENS_MAX / 2 + 1) + 1) & ~1;
+    static constexpr int BVEC = (G == 16) ? 0 : 3 * G;
+    static constexpr int LDS_GROUP = OFF_BV + BVEC;  // doubles / problem (even)
 };
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -81,6 +85,7 @@ struct IpSolver {
 
     const double* tab;   // LDS: staged linearization table
     double* Rst;         // LDS: [NY][G+1] R-factor transpose tile of this problem
+    double* bv;          // LDS (32-lane groups): staging vectors [3][G], see stage() / factorize()
     int l;               // lane within the group
     bool vx, vy;
     // per-lane constants of the knot
@@ -94,6 +99,7 @@ struct IpSolver {
 
     __device__ __forceinline__ void bind(const double* tab_, double* Rst_, int l_) {
         tab = tab_; Rst = Rst_; l = l_;
+        bv = Rst_ + M::OFF_BV;
         vx = l < NX; vy = l < NY;
         const double* tVec = tab + L.oVec;
         ry2 = tVec[LinLayout::V_RY2 * G + l];
@@ -108,6 +114,16 @@ struct IpSolver {
         tthdyn = tthrst = altl = 0.0;
     }
 
+    // 32-lane groups: a lane-indexed vector that feeds a matrix-vector product is STAGED in LDS - one store per lane - and read
+    // back with group-uniform addresses (broadcast reads, two entries per ds_read_b128): 1 + n/2 LDS instructions instead of the
+    // 2 n ds_bpermute_b32 of rounds 1-3 (the centroidal sweep was LDS-bound: SQ_INSTS_LDS 64 M per launch against 68 M VALU,
+    // the LDS pipe 40 % busy over the whole launch - profiles/r04/cent_pmc_before.csv).  Same operands, same summation order.
+    __device__ __forceinline__ void stage(double v) const {
+        wave_lds_fence();            // (LDS operations of a wavefront execute in order: earlier reads of bv are done)
+        bv[l] = v;
+        wave_lds_fence();
+    }
+
     // rlin! (linearized_solver.jl:364-373), same association as the reference expression
     __device__ __forceinline__ void residual(double kappa) {
         const double* tDx = tab + L.oDx; const double* tRx = tab + L.oRx;
@@ -118,15 +134,17 @@ struct IpSolver {
             Dpp16::pair<NX>(a, c, dx, [&](auto kc) { return tDx[decltype(kc)::value * G + l]; }, [&](auto kc) { return tRx[decltype(kc)::value * G + l]; });
             Dpp16::pair<NY>(bb, e, dy1, [&](auto kc) { return tDy1[decltype(kc)::value * G + l]; }, [&](auto kc) { return tRy1[decltype(kc)::value * G + l]; });
         } else {
+            stage(dx);
             static_for<0, NX>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
-                const double v = LG::template bcast<k>(dx);
+                const double v = bv[k];
                 a = fma(tDx[k * G + l], v, a);
                 c = fma(tRx[k * G + l], v, c);
             });
+            stage(dy1);
             static_for<0, NY>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
-                const double v = LG::template bcast<k>(dy1);
+                const double v = bv[k];
                 bb = fma(tDy1[k * G + l], v, bb);
                 e = fma(tRy1[k * G + l], v, e);
             });
@@ -161,17 +179,27 @@ struct IpSolver {
         // r_kj = (a_k . a_j) / |a_k| and the update a_j -= (r_kj / |a_k|) a_k - the same numbers as
         // q_k = a_k/|a_k|, r_kj = q_k . a_j, a_j -= r_kj q_k up to one rounding, 16 multiplies per
         // step cheaper and without a lane-divergent branch.
+        // 32-lane groups: the column the step broadcasts goes through LDS - its owner stores it (one lane per group), every lane
+        // reads it back with group-uniform addresses.  Column k + 1 is final once step k has updated it, so its owner stores it
+        // at the END of step k into the other of two buffers: the store's latency hides behind the rest of the step.
+        [[maybe_unused]] double* bc = bv + G;      // [2][G]
+        if constexpr (G != 16) {
+            wave_lds_fence();
+            if (lq == 0) static_for<0, NY>([&](auto ic) { constexpr int r = decltype(ic)::value; bc[r] = Qc[r]; });
+        }
         static_for<0, NY>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
-            [[maybe_unused]] double ak[G == 16 ? 1 : NY];     // 32-lane groups: column k broadcast once (ds_bpermute), used twice
+            [[maybe_unused]] double ak[G == 16 ? 1 : NY];     // 32-lane groups: column k read once from the staging buffer, used twice
             if constexpr (G == 16) {
                 // a_k . a_l: column k rides on the DPP source of the multiply-add (no broadcast registers)
                 Dpp16::dot<k, NY>(acc, Qc);
             } else {
+                wave_lds_fence();
+                const double* src = bc + (k & 1) * G;
                 static_for<0, NY>([&](auto ic) {
                     constexpr int r = decltype(ic)::value;
-                    ak[r] = LG::template bcast<k>(Qc[r]);
+                    ak[r] = src[r];
                     acc[r & 3] = fma(ak[r], Qc[r], acc[r & 3]);
                 });
             }
@@ -192,6 +220,10 @@ struct IpSolver {
                     constexpr int r = decltype(ic)::value;
                     Qc[r] = fma(ncoef, ak[r], Qc[r]);
                 });
+                if constexpr (k + 1 < NY) {       // column k + 1 is final: its owner publishes it for the next step
+                    double* dst = bc + ((k + 1) & 1) * G;
+                    if (lq == k + 1) static_for<0, NY>([&](auto ic) { constexpr int r = decltype(ic)::value; dst[r] = Qc[r]; });
+                }
             }
             Rst[k * M::RST_LD + l] = nrk;  // -R[k,l], l > k (zeros elsewhere)
         });
@@ -209,9 +241,10 @@ struct IpSolver {
         if constexpr (G == 16) {
             Dpp16::matvec<NY, 4>(acc, rhs, [&](auto rc) { return Qc[decltype(rc)::value]; });
         } else {
+            stage(rhs);
             static_for<0, NY>([&](auto ic) {
                 constexpr int r = decltype(ic)::value;
-                acc[r & 3] = fma(Qc[r], LG::template bcast<r>(rhs), acc[r & 3]);
+                acc[r & 3] = fma(Qc[r], bv[r], acc[r & 3]);
             });
         }
         double c = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * rdinv;   // (Q^T rhs)_l, Q = Qc * rdinv
@@ -245,19 +278,24 @@ struct IpSolver {
             xs = xx[0] + xx[1];
             return t;
         }
-        if constexpr (!PRE) static_for<0, NX>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            bq[k & 1] = fma(tCAi[k * G + l], LG::template bcast<k>(u), bq[k & 1]);
-        });
+        if constexpr (!PRE) {
+            stage(u);
+            static_for<0, NX>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                bq[k & 1] = fma(tCAi[k * G + l], bv[k], bq[k & 1]);
+            });
+        }
         const double t = qr_solve(PRE ? v : (bq[0] + bq[1]) - v);
+        stage(t);
         static_for<0, NY>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            w[k & 1] = fma(tDy1[k * G + l], LG::template bcast<k>(t), w[k & 1]);
+            w[k & 1] = fma(tDy1[k * G + l], bv[k], w[k & 1]);
         });
         const double ww = u + (w[0] + w[1]);
+        stage(ww);
         static_for<0, NX>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            xx[k & 1] = fma(tAi[k * G + l], LG::template bcast<k>(ww), xx[k & 1]);
+            xx[k & 1] = fma(tAi[k * G + l], bv[k], xx[k & 1]);
         });
         xs = xx[0] + xx[1];
         return t;

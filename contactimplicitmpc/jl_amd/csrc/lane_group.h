@@ -44,10 +44,20 @@ struct LaneGroup {
         if constexpr (G == 16) {
             return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xF, 0xF, true);  // row_newbcast:K
         } else {
-            // (measured alternatives for the 32-lane model: v_readlane + select is 50 % SLOWER - VALU -> SGPR -> VALU
-            //  hazards; DPP row_newbcast + gfx950 v_permlane16_swap gives the same sweep time as this ds_bpermute)
-            const int lane = (int)(threadIdx.x & 63);
-            return __shfl(v, (lane & ~31) | K, 64);
+            // 32-lane group = two DPP rows.  row_newbcast:(K & 15) puts lane (K & 15) of EVERY row into its own row; gfx950's
+            // v_permlane16_swap then exchanges the odd rows of one operand with the even rows of the other: with both operands
+            // = that value, the first result holds the even rows' value in both rows of a group, the second the odd rows' - the
+            // broadcast of lane K for K < 16 / K >= 16.  Three VALU instructions and NO LDS round trip: what is left on this path
+            // after round 4 are the scalar broadcasts inside dependency chains (back-substitution, 1/|a_k|, reductions), where the
+            // ~100-cycle latency of ds_bpermute was the chain.  (Vector broadcasts - matrix-vector products, the column of the
+            // MGS step - go through an LDS staging vector instead: IpSolver::stage.  Round 1-3 history: ds_bpermute for
+            // everything; v_readlane + select 50 % slower; this DPP + swap form for EVERYTHING the same sweep time as ds_bpermute.)
+            const double t = __builtin_amdgcn_update_dpp(0.0, v, 0x150 + (K & 15), 0xF, 0xF, true);
+            const unsigned lo = (unsigned)__double2loint(t), hi = (unsigned)__double2hiint(t);
+            const auto r0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+            const auto r1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+            constexpr int S = K < 16 ? 0 : 1;
+            return __hiloint2double((int)r1[S], (int)r0[S]);
         }
     }
 
