@@ -623,6 +623,10 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     // 4 waves share one staged table (throughput); measured for single rollouts too (one problem per knot anyway): B = 1
     // quadruped H = 40 cold 0.945 -> 0.926 ms, warm MPC loop 3.19 -> 3.03 ms, hopper H = 20 1.02 -> 0.97 ms against 1 wave
     h->waves = 4;
+    // (32-lane models, round 4, measured and not kept: eight waves per workgroup = two per SIMD next to the ONE table a CU has room
+    //  for - per-problem LDS cut to 3 KB by a windowed R transposition, the MGS column read twice instead of kept in 64 registers
+    //  to fit 256: the sweep becomes LDS-return-bandwidth bound again, centroidal H = 60: 64 rollouts 9.3 -> 13.4 ms per step,
+    //  128 rollouts 16.2 -> 13.6 ms - profiles/r04/cent_8wave_experiment.log)
     // the single-launch solve runs its residual jobs on the whole workgroup: 4 waves also for small batches
     // (measured B = 8: 5.2 -> 4.4 ms, B = 64: 8.5 -> 7.5 ms)
     if (h->async_on && (h->async_mode == 1 || (h->async_mode == 2 && B >= 4 && B <= h->kn.async_full_max))) h->waves = 4;
@@ -1246,7 +1250,11 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         // (round 4, measured and removed: the three-wave kernel in rounds whose sweep is light - <= 16 k / 26 k / 60 k problems: KKT kernel
         //  time 3.6 -> 3.4 / 3.0 / 2.7 ms per step, but the sweep and the tail give it back, 7.93 -> 7.88 / 7.88 / 7.96 ms:
         //  profiles/r04/knob_kkt_pipe_small.log)
-        const int pipe = h->kn.kkt_pipe >= 0 ? h->kn.kkt_pipe : (!h->kkt_overlap && n_kkt <= h->kn.kkt_pipe_max) ? 1 : 0;
+        // Wide tiles (nq or nu in 17 .. 24: the centroidal sizes) hold one rollout per CU in either kernel (105 KB / 128 KB of LDS), so the
+        // three-wave kernel costs no extra CUs there - always taken (round 4, BASELINE configs[4] at 64 rollouts: KKT 6.1 -> 3.2 ms per
+        // step, 16.3 -> 13.3 ms; at 128 rollouts 24.2 -> 21.2 ms: profiles/r04/cent_kkt_pipe.log)
+        const bool wide_tiles = (h->dm.nq > 16 || h->dm.nu > 16) && h->dm.nq <= 24 && h->dm.nu <= 24;
+        const int pipe = h->kn.kkt_pipe >= 0 ? h->kn.kkt_pipe : ((!h->kkt_overlap && n_kkt <= h->kn.kkt_pipe_max) || wide_tiles) ? 1 : 0;
         if (kkt && !h->kkt_overlap) {   // small batches: latency matters, keep the KKT result in this round
             Sk.kkt_same_round = 1;
             prof_begin(h, PC_KKT, sb.st);
