@@ -301,6 +301,55 @@ struct IpSolver {
         return t;
     }
 
+    // ---- 32-lane groups, sensitivity pass: TWO right-hand sides side by side.  The columns of r_theta are independent; solving them
+    // in pairs reads every operator entry (Q column, Dy1, Ai, the row of R) once for both, stages both vectors with one hand-over
+    // and interleaves the two back-substitution chains.  Per column the arithmetic is that of schur_solve<true> / qr_solve -
+    // same operands, same order: bit-identical columns.  The second staging vector is the MGS column buffer (idle here).
+    __device__ __forceinline__ void stage2(double v0, double v1) const {
+        wave_lds_fence();
+        bv[l] = v0; bv[G + l] = v1;
+        wave_lds_fence();
+    }
+    __device__ __forceinline__ void qr_solve2(double rhs0, double rhs1, double& t0, double& t1) const {
+        double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
+        stage2(rhs0, rhs1);
+        static_for<0, NY>([&](auto ic) {
+            constexpr int r = decltype(ic)::value;
+            a0[r & 3] = fma(Qc[r], bv[r], a0[r & 3]);
+            a1[r & 3] = fma(Qc[r], bv[G + r], a1[r & 3]);
+        });
+        double c0 = ((a0[0] + a0[1]) + (a0[2] + a0[3])) * rdinv, c1 = ((a1[0] + a1[1]) + (a1[2] + a1[3])) * rdinv;
+        static_rfor<NY - 1>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const double x0 = LG::template bcast<k>(c0 * rdinv), x1 = LG::template bcast<k>(c1 * rdinv);
+            c0 = fma(Rr[k], x0, c0);
+            c1 = fma(Rr[k], x1, c1);
+        });
+        t0 = c0 * rdinv; t1 = c1 * rdinv;
+    }
+    // (g0, g1: the pre-multiplied right-hand sides of the QR, LinLayout::oGs)
+    __device__ __forceinline__ void schur_solve2(double u0, double g0, double u1, double g1, double& t0, double& t1, double& xs0, double& xs1) const {
+        const double* tAi = tab + L.oAi; const double* tDy1 = tab + L.oDy1;
+        qr_solve2(g0, g1, t0, t1);
+        double w0[2] = {0.0, 0.0}, w1[2] = {0.0, 0.0}, x0[2] = {0.0, 0.0}, x1[2] = {0.0, 0.0};
+        stage2(t0, t1);
+        static_for<0, NY>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const double d = tDy1[k * G + l];
+            w0[k & 1] = fma(d, bv[k], w0[k & 1]);
+            w1[k & 1] = fma(d, bv[G + k], w1[k & 1]);
+        });
+        const double ww0 = u0 + (w0[0] + w0[1]), ww1 = u1 + (w1[0] + w1[1]);
+        stage2(ww0, ww1);
+        static_for<0, NX>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const double a = tAi[k * G + l];
+            x0[k & 1] = fma(a, bv[k], x0[k & 1]);
+            x1[k & 1] = fma(a, bv[G + k], x1[k & 1]);
+        });
+        xs0 = x0[0] + x0[1]; xs1 = x1[0] + x1[1];
+    }
+
     // linear_solve!(Delta, rz, r) (linearized_solver.jl:424-444)
     __device__ __forceinline__ void linear_solve() {
         const double u = rdyn;
@@ -450,6 +499,23 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
             if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) { if (l < NC + NB) scr[cc * ND + NX + l] = t; }
         }
     };
+    // 32-lane groups: columns c and c + 1 in one pass (IpSolver::schur_solve2)
+    [[maybe_unused]] auto column2 = [&](int c, int cc) {
+        if constexpr (G != 16) {
+            const double u0 = tab[L.oRthDyn + c * G + l], u1 = tab[L.oRthDyn + (c + 1) * G + l];
+            const double g0 = tab[L.oGs + c * G + l], g1 = tab[L.oGs + (c + 1) * G + l];
+            double t0, t1, xs0, xs1;
+            S.schur_solve2(u0, g0, u1, g1, t0, t1, xs0, xs1);
+            if (vx) { xst<ASYNC>(dzo + c * ND + lg, -xs0); xst<ASYNC>(dzo + (c + 1) * ND + lg, -xs1); }
+            if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) {
+                if (l < NC + NB) { xst<ASYNC>(dzo + c * ND + NX + lg, t0); xst<ASYNC>(dzo + (c + 1) * ND + NX + lg, t1); }
+            }
+            if (want) {
+                if (vx) { scr[cc * ND + l] = -xs0; scr[(cc + 1) * ND + l] = -xs1; }
+                if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) { if (l < NC + NB) { scr[cc * ND + NX + l] = t0; scr[(cc + 1) * ND + NX + l] = t1; } }
+            }
+        }
+    };
     const int lo = nparts > 1 ? (NTHS * part) / nparts : 0, hi = nparts > 1 ? (NTHS * (part + 1)) / nparts : NTHS;
     constexpr int ILP2 = ILP > 2 ? ILP - 1 : 1;     // second interleave width: a share of 7 / 8 columns runs as 4 + 3 / 4 + 4
     const bool narrow = nparts > 1 && (hi - lo) % ILP != 0;
@@ -460,7 +526,8 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
         if (!narrow) {
 #pragma unroll 1
             for (; cc + ILP <= n; cc += ILP) {
-                static_for<0, ILP>([&](auto jc) { column(c0 + cc + decltype(jc)::value, cc + decltype(jc)::value); });
+                if constexpr (G != 16 && ILP == 2) column2(c0 + cc, cc);
+                else static_for<0, ILP>([&](auto jc) { column(c0 + cc + decltype(jc)::value, cc + decltype(jc)::value); });
             }
         }
         if constexpr (ILP2 > 1) {
