@@ -55,7 +55,7 @@ struct Model {
 //  rows of R left in the LDS tile instead of registers for a third wave per SIMD - the spills stay, 0.35 -> 0.63 ms)
 #define CIMPC_SENS_ILP 5      // (a constant of the build: the -D override is gone with the experiment it served)
 #ifndef CIMPC_SENS_ILP32
-#define CIMPC_SENS_ILP32 2
+#define CIMPC_SENS_ILP32 3
 #endif
     static constexpr int SENS_ILP = (NX <= 16 && NY <= 16) ? CIMPC_SENS_ILP : CIMPC_SENS_ILP32;   // sensitivity columns solved side by side
     // per-problem LDS: the R tile and theta - theta0 SHARE their space (theta - theta0 lives from the pull of a problem to the two
@@ -301,53 +301,59 @@ struct IpSolver {
         return t;
     }
 
-    // ---- 32-lane groups, sensitivity pass: TWO right-hand sides side by side.  The columns of r_theta are independent; solving them
-    // in pairs reads every operator entry (Q column, Dy1, Ai, the row of R) once for both, stages both vectors with one hand-over
-    // and interleaves the two back-substitution chains.  Per column the arithmetic is that of schur_solve<true> / qr_solve -
-    // same operands, same order: bit-identical columns.  The second staging vector is the MGS column buffer (idle here).
-    __device__ __forceinline__ void stage2(double v0, double v1) const {
+    // ---- 32-lane groups, sensitivity pass: N right-hand sides side by side (N <= 3: the staging vector and the two MGS column
+    // buffers, idle here).  The columns of r_theta are independent; solving them together reads every operator entry (Q column,
+    // Dy1, Ai, the row of R) once for all, stages the vectors with one hand-over and interleaves the back-substitution chains.
+    // Per column the arithmetic is that of schur_solve<true> / qr_solve - same operands, same order: bit-identical columns.
+    template <int N>
+    __device__ __forceinline__ void stage_n(const double (&v)[N]) const {
+        static_assert(N <= 3, "three staging vectors per group");
         wave_lds_fence();
-        bv[l] = v0; bv[G + l] = v1;
+        static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; bv[j * G + l] = v[j]; });
         wave_lds_fence();
     }
-    __device__ __forceinline__ void qr_solve2(double rhs0, double rhs1, double& t0, double& t1) const {
-        double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
-        stage2(rhs0, rhs1);
+    template <int N>
+    __device__ __forceinline__ void qr_solve_n(const double (&rhs)[N], double (&t)[N]) const {
+        double a[N][4];
+        static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j][0] = a[j][1] = a[j][2] = a[j][3] = 0.0; });
+        stage_n<N>(rhs);
         static_for<0, NY>([&](auto ic) {
             constexpr int r = decltype(ic)::value;
-            a0[r & 3] = fma(Qc[r], bv[r], a0[r & 3]);
-            a1[r & 3] = fma(Qc[r], bv[G + r], a1[r & 3]);
+            static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j][r & 3] = fma(Qc[r], bv[j * G + r], a[j][r & 3]); });
         });
-        double c0 = ((a0[0] + a0[1]) + (a0[2] + a0[3])) * rdinv, c1 = ((a1[0] + a1[1]) + (a1[2] + a1[3])) * rdinv;
+        double c[N];
+        static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; c[j] = ((a[j][0] + a[j][1]) + (a[j][2] + a[j][3])) * rdinv; });
         static_rfor<NY - 1>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            const double x0 = LG::template bcast<k>(c0 * rdinv), x1 = LG::template bcast<k>(c1 * rdinv);
-            c0 = fma(Rr[k], x0, c0);
-            c1 = fma(Rr[k], x1, c1);
+            static_for<0, N>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const double xk = LG::template bcast<k>(c[j] * rdinv);
+                c[j] = fma(Rr[k], xk, c[j]);
+            });
         });
-        t0 = c0 * rdinv; t1 = c1 * rdinv;
+        static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; t[j] = c[j] * rdinv; });
     }
-    // (g0, g1: the pre-multiplied right-hand sides of the QR, LinLayout::oGs)
-    __device__ __forceinline__ void schur_solve2(double u0, double g0, double u1, double g1, double& t0, double& t1, double& xs0, double& xs1) const {
+    // (g: the pre-multiplied right-hand sides of the QR, LinLayout::oGs)
+    template <int N>
+    __device__ __forceinline__ void schur_solve_n(const double (&u)[N], const double (&g)[N], double (&t)[N], double (&xs)[N]) const {
         const double* tAi = tab + L.oAi; const double* tDy1 = tab + L.oDy1;
-        qr_solve2(g0, g1, t0, t1);
-        double w0[2] = {0.0, 0.0}, w1[2] = {0.0, 0.0}, x0[2] = {0.0, 0.0}, x1[2] = {0.0, 0.0};
-        stage2(t0, t1);
+        qr_solve_n<N>(g, t);
+        double w[N][2], x[N][2], ww[N];
+        static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; w[j][0] = w[j][1] = x[j][0] = x[j][1] = 0.0; });
+        stage_n<N>(t);
         static_for<0, NY>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             const double d = tDy1[k * G + l];
-            w0[k & 1] = fma(d, bv[k], w0[k & 1]);
-            w1[k & 1] = fma(d, bv[G + k], w1[k & 1]);
+            static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; w[j][k & 1] = fma(d, bv[j * G + k], w[j][k & 1]); });
         });
-        const double ww0 = u0 + (w0[0] + w0[1]), ww1 = u1 + (w1[0] + w1[1]);
-        stage2(ww0, ww1);
+        static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; ww[j] = u[j] + (w[j][0] + w[j][1]); });
+        stage_n<N>(ww);
         static_for<0, NX>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            const double a = tAi[k * G + l];
-            x0[k & 1] = fma(a, bv[k], x0[k & 1]);
-            x1[k & 1] = fma(a, bv[G + k], x1[k & 1]);
+            const double a_ = tAi[k * G + l];
+            static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; x[j][k & 1] = fma(a_, bv[j * G + k], x[j][k & 1]); });
         });
-        xs0 = x0[0] + x0[1]; xs1 = x1[0] + x1[1];
+        static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; xs[j] = x[j][0] + x[j][1]; });
     }
 
     // linear_solve!(Delta, rz, r) (linearized_solver.jl:424-444)
@@ -499,21 +505,25 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
             if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) { if (l < NC + NB) scr[cc * ND + NX + l] = t; }
         }
     };
-    // 32-lane groups: columns c and c + 1 in one pass (IpSolver::schur_solve2)
-    [[maybe_unused]] auto column2 = [&](int c, int cc) {
+    // 32-lane groups: columns c .. c + ILP - 1 in one pass (IpSolver::schur_solve_n)
+    [[maybe_unused]] auto column_n = [&](int c, int cc) {
         if constexpr (G != 16) {
-            const double u0 = tab[L.oRthDyn + c * G + l], u1 = tab[L.oRthDyn + (c + 1) * G + l];
-            const double g0 = tab[L.oGs + c * G + l], g1 = tab[L.oGs + (c + 1) * G + l];
-            double t0, t1, xs0, xs1;
-            S.schur_solve2(u0, g0, u1, g1, t0, t1, xs0, xs1);
-            if (vx) { xst<ASYNC>(dzo + c * ND + lg, -xs0); xst<ASYNC>(dzo + (c + 1) * ND + lg, -xs1); }
-            if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) {
-                if (l < NC + NB) { xst<ASYNC>(dzo + c * ND + NX + lg, t0); xst<ASYNC>(dzo + (c + 1) * ND + NX + lg, t1); }
-            }
-            if (want) {
-                if (vx) { scr[cc * ND + l] = -xs0; scr[(cc + 1) * ND + l] = -xs1; }
-                if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) { if (l < NC + NB) { scr[cc * ND + NX + l] = t0; scr[(cc + 1) * ND + NX + l] = t1; } }
-            }
+            double u[ILP], g[ILP], t[ILP], xs[ILP];
+            static_for<0, ILP>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                u[j] = tab[L.oRthDyn + (c + j) * G + l];
+                g[j] = tab[L.oGs + (c + j) * G + l];
+            });
+            S.template schur_solve_n<ILP>(u, g, t, xs);
+            static_for<0, ILP>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if (vx) xst<ASYNC>(dzo + (c + j) * ND + lg, -xs[j]);
+                if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) { if (l < NC + NB) xst<ASYNC>(dzo + (c + j) * ND + NX + lg, t[j]); }
+                if (want) {
+                    if (vx) scr[(cc + j) * ND + l] = -xs[j];
+                    if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) { if (l < NC + NB) scr[(cc + j) * ND + NX + l] = t[j]; }
+                }
+            });
         }
     };
     const int lo = nparts > 1 ? (NTHS * part) / nparts : 0, hi = nparts > 1 ? (NTHS * (part + 1)) / nparts : NTHS;
@@ -526,7 +536,7 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
         if (!narrow) {
 #pragma unroll 1
             for (; cc + ILP <= n; cc += ILP) {
-                if constexpr (G != 16 && ILP == 2) column2(c0 + cc, cc);
+                if constexpr (G != 16) column_n(c0 + cc, cc);
                 else static_for<0, ILP>([&](auto jc) { column(c0 + cc + decltype(jc)::value, cc + decltype(jc)::value); });
             }
         }
