@@ -67,7 +67,7 @@ struct Knobs {
     int spec_mid = -1;           // previous search depth from which a rollout starts with three candidates: by batch size
     int waves = 0;               // sweep workgroup size: by batch size
     int kkt_overlap = -1;        // KKT on its own stream next to the sweep: from 64 rollouts on
-    int sweep_wgs = 0;           // persistent sweep workgroups: computed from the resident set
+    int sweep_wgs = 0;           // CIMPC_SWEEP_WGS: persistent sweep workgroups (0: computed from the resident set) - sub-batch experiments
     int async_service = 0;       // job-only workgroups of the asynchronous kernel: computed
     int async_flags = 0;         // reserved
     int async_sleep = 2;         // idle back-off of the asynchronous kernel (units of ~2 us), polls before looking around, wake-up fan
@@ -94,6 +94,7 @@ struct Knobs {
         drain_min = std::max(1, env_int("CIMPC_DRAIN_MIN", drain_min));
         kkt_pipe = env_int("CIMPC_KKT_PIPE", kkt_pipe);
         generic_static = env_int("CIMPC_GENERIC_STATIC", generic_static ? 1 : 0) != 0;
+        sweep_wgs = env_int("CIMPC_SWEEP_WGS", sweep_wgs);
     }
 };
 
@@ -173,7 +174,8 @@ struct cimpc_ctx {
     std::vector<double> h_tab;       // one knot staging
     cimpc_stats last_stats{};
     // profiling
-    bool prof_on = false;
+    int prof_on = 0;             // 0 off, 1 every launch, 2 the interior-point sweep launches only (cimpc_profile_enable)
+    bool prof_open = false;      // the last prof_begin recorded an event pair (prof_end closes it)
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> ev_pool;
     double prof_ms[PC_COUNT] = {0, 0, 0, 0, 0};
@@ -246,7 +248,9 @@ bool invert(const double* A, double* Ai, int n) {
 }
 
 void prof_begin(cimpc_ctx* h, int cls, hipStream_t st = nullptr) {
-    if (!h->prof_on) return;
+    h->prof_open = false;
+    if (!h->prof_on || (h->prof_on == 2 && cls != PC_IP)) return;
+    h->prof_open = true;
     if (!st) st = h->stream;
     ProfRec r;
     auto get = [&]() {
@@ -266,7 +270,8 @@ void prof_begin(cimpc_ctx* h, int cls, hipStream_t st = nullptr) {
     h->prof_recs.push_back(r);
 }
 void prof_end(cimpc_ctx* h, hipStream_t st = nullptr) {
-    if (!h->prof_on) return;
+    if (!h->prof_on || !h->prof_open) return;
+    h->prof_open = false;
     (void)hipEventRecord(h->prof_recs.back().b, st ? st : h->stream);
 }
 void prof_collect(cimpc_ctx* h) {
@@ -1582,7 +1587,7 @@ int cimpc_get_stats(cimpc_handle h, cimpc_stats* s) {
 int cimpc_profile_enable(cimpc_handle h, int on) {
     if (!h) return CIMPC_ERR_INVALID;
     prof_collect(h);
-    h->prof_on = on != 0;
+    h->prof_on = on == 2 ? 2 : (on != 0 ? 1 : 0);
     return CIMPC_OK;
 }
 

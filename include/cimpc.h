@@ -275,7 +275,8 @@ int cimpc_get_reference(cimpc_handle h, double* q_ref, double* u_ref, double* w_
                         double* b_ref, double* theta_ref, int* window);
 
 /* ---- measurement -------------------------------------------------------------------- */
-int cimpc_profile_enable(cimpc_handle h, int on);  /* HIP-event timing of every launch */
+int cimpc_profile_enable(cimpc_handle h, int on);  /* HIP-event timing: 1 = every launch, 2 = the interior-point sweep launches only
+                                                    * (the roofline kernel: a third of the event records, less perturbation), 0 = off */
 int cimpc_profile_reset(cimpc_handle h);
 int cimpc_profile_read(cimpc_handle h, cimpc_profile* p);
 /* size in doubles of one packed linearization table and of the per-problem IP I/O

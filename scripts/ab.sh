@@ -8,7 +8,7 @@ for i in $(seq $N); do
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 k=d['kernel_time_ms_per_step']; r=d['roofline']
-print('$L ms/step %.3f value %.0f frac %.4f'%(d['ms_per_step'],d['value'],r['frac']), {a:round(b,3) for a,b in k.items()}, 'rounds', d['solver_iters']['lockstep_rounds_per_step'], 'sweeps', round(d['solver_iters']['sweeps_per_step'],3), 'avg_launch_ms %.4f'%r['avg_launch_ms'])
+print('$L ms/step %.3f value %.0f frac %.4f'%(d['ms_per_step'],d['value'],r['frac']), {a:round(b,3) for a,b in k.items() if not isinstance(b,str)}, 'rounds', d['solver_iters']['lockstep_rounds_per_step'], 'sweeps', round(d['solver_iters']['sweeps_per_step'],3), 'avg_launch_ms %.4f'%r['avg_launch_ms'])
 "
   done
 done
