@@ -1303,11 +1303,21 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         }
         int rr = run_sweep(h, par, d_cnt + 2 * CPAD, nullptr, sb.st, cap, d_cnt + 3 * CPAD, true);
         if (rr != CIMPC_OK) return rr;
-        if (kkt && h->kkt_overlap && hipStreamWaitEvent(sb.st, sb.ev_join, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join failed");
-        prof_begin(h, PC_RESID, sb.st);
         // the evaluation slots of this round: the compact list its requesters built (small batches run the KKT stage in the same
         // round as the evaluation of its candidates - not known to the host at launch: every (rollout, slot) pair gets a block there)
-        rr = launch_resid_decide(Sk, sb.st, h->kkt_overlap ? last_slots : (h->dm.B < 4 ? -2 : -1));
+        const int n_slots = h->kkt_overlap ? last_slots : (h->dm.B < 4 ? -2 : -1);
+        // round 4: the per-slot residual kernel goes in FRONT of the join with the overlapped KKT kernel (it reads the sweep's results
+        // only; the rollouts the KKT kernel works on have no slot on this round's list), the decision kernel behind it - in the
+        // rounds whose KKT recursion outlasts the sweep (about six per step of the headline batch) the 26 us of the slot kernel
+        // leave the critical path
+        const bool split_join = kkt && h->kkt_overlap && n_slots >= 0;
+        prof_begin(h, PC_RESID, sb.st);
+        if (split_join) {
+            rr = launch_resid_decide(Sk, sb.st, n_slots, 1);
+            if (rr != CIMPC_OK) return fail(h, rr, "residual launch failed");
+        }
+        if (kkt && h->kkt_overlap && hipStreamWaitEvent(sb.st, sb.ev_join, 0) != hipSuccess) return fail(h, CIMPC_ERR_HIP, "join failed");
+        rr = launch_resid_decide(Sk, sb.st, n_slots, split_join ? 2 : 0);
         prof_end(h, sb.st);
         if (rr != CIMPC_OK) return fail(h, rr, "residual launch failed");
         return CIMPC_OK;

@@ -419,14 +419,17 @@ int launch_reset(const NewtonDev& S, const double* q0, const double* q1, int war
     hipLaunchKernelGGL(reset_kernel, dim3(S.nb_launch), dim3(256), 0, s, S, q0, q1, warm);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
+// phase: 0 = both kernels, 1 = the per-slot residual kernel only, 2 = the decision kernel only (the host puts the join with the
+// overlapped KKT kernel between the two: the slot kernel reads nothing that kernel writes)
 template <int NQ, int NU, bool CF>
-static int launch_resid_m(const NewtonDev& S, hipStream_t s, int n_slots) {
+static int launch_resid_m(const NewtonDev& S, hipStream_t s, int n_slots, int phase) {
     const size_t lds2 = (size_t)2 * CIMPC_RESID_THREADS * sizeof(double);
     if (n_slots == -1) {    // small batches: one launch, the rollout's slots one after the other in its workgroup
                             // (-2: single rollouts - the two launches over ALL (rollout, slot) pairs, a handful of blocks: a deep
                             //  line search has seven slots, which the one workgroup would take one after the other)
         const size_t lds1 = (size_t)(CS * 256 + S.N) * sizeof(double);
         if (lds1 <= 64 * 1024) {
+            if (phase == 1) return CIMPC_OK;
             hipLaunchKernelGGL((resid_decide_kernel<NQ, NU, CF, true>), dim3(S.nb_launch), dim3(CIMPC_RESID_THREADS), lds1, s, S);
             return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
         }
@@ -434,13 +437,13 @@ static int launch_resid_m(const NewtonDev& S, hipStream_t s, int n_slots) {
     const int* list = (n_slots >= 0 && S.slot_list != nullptr) ? S.slot_list + (size_t)S.WQ.par * S.dm.B * CS : nullptr;
     const int grid = list != nullptr ? n_slots : S.nb_launch * CS;
     const size_t lds = (size_t)(256 + (S.N <= SLOT_ABS_MAX ? S.N : 0)) * sizeof(double);
-    if (grid > 0) hipLaunchKernelGGL((resid_slot_kernel<NQ, NU, CF>), dim3(grid), dim3(CIMPC_SLOT_THREADS), lds, s, S, list);
-    hipLaunchKernelGGL((resid_decide_kernel<NQ, NU, CF, false>), dim3(S.nb_launch), dim3(CIMPC_RESID_THREADS), lds2, s, S);
+    if (grid > 0 && phase != 2) hipLaunchKernelGGL((resid_slot_kernel<NQ, NU, CF>), dim3(grid), dim3(CIMPC_SLOT_THREADS), lds, s, S, list);
+    if (phase != 1) hipLaunchKernelGGL((resid_decide_kernel<NQ, NU, CF, false>), dim3(S.nb_launch), dim3(CIMPC_RESID_THREADS), lds2, s, S);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
 template <int NQ, int NU>
-static int launch_resid_t(const NewtonDev& S, hipStream_t s, int n_slots) {
-    return S.dm.mode == CIMPC_MODE_CONFIGURATIONFORCE ? launch_resid_m<NQ, NU, true>(S, s, n_slots) : launch_resid_m<NQ, NU, false>(S, s, n_slots);
+static int launch_resid_t(const NewtonDev& S, hipStream_t s, int n_slots, int phase) {
+    return S.dm.mode == CIMPC_MODE_CONFIGURATIONFORCE ? launch_resid_m<NQ, NU, true>(S, s, n_slots, phase) : launch_resid_m<NQ, NU, false>(S, s, n_slots, phase);
 }
 // End of a solve: what the host wants back, packed into ONE block (one device-to-host copy instead of five):
 //   out[0..3] = sums over the rollouts of NewtonDev::stats, out[4] = sum of the Newton iteration counts,
@@ -478,12 +481,12 @@ int launch_queue_recycle(const IpQueues& Q, int par, hipStream_t s) {
     hipLaunchKernelGGL(queue_recycle_kernel, dim3((Q.K + 255) / 256), dim3(256), 0, s, Q, par);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
-int launch_resid_decide(const NewtonDev& S, hipStream_t s, int n_slots) {
+int launch_resid_decide(const NewtonDev& S, hipStream_t s, int n_slots, int phase) {
     const int nq = S.dm.nq, nu = S.dm.nu;
-#define X(q, u) if (nq == q && nu == u) return launch_resid_t<q, u>(S, s, n_slots);
+#define X(q, u) if (nq == q && nu == u) return launch_resid_t<q, u>(S, s, n_slots, phase);
     CIMPC_NQNU(X)
 #undef X
-    return launch_resid_t<0, 0>(S, s, n_slots);        // runtime dimensions (models without a compiled set)
+    return launch_resid_t<0, 0>(S, s, n_slots, phase);        // runtime dimensions (models without a compiled set)
 }
 template <int NQ, int NU>
 static int launch_kkt_packed_t(const NewtonDev& S, const KktArgs& K, const int* list, int n, const int* n_dev, hipStream_t s, bool pipe) {

@@ -107,7 +107,7 @@ struct GaitDev {
 int launch_gait_window(const NewtonDev& S, const GaitDev& G, int* window, int advance, hipStream_t s);
 int launch_reset(const NewtonDev& nd, const double* q0, const double* q1, int warm, hipStream_t s);
 int launch_dz_rekey(const NewtonDev& nd, double* knot, const int* window, int which, int dir, hipStream_t s);
-int launch_resid_decide(const NewtonDev& nd, hipStream_t s, int n_slots = -1);   // n_slots: entries of slot_list[WQ.par] (-1: every (rollout, slot) pair gets a block)
+int launch_resid_decide(const NewtonDev& nd, hipStream_t s, int n_slots = -1, int phase = 0);   // n_slots: entries of slot_list[WQ.par] (-1: every (rollout, slot) pair gets a block)
 int launch_enqueue_all(const NewtonDev& nd, hipStream_t s);   // B3 seam: queue slot 0 of every rollout
 int launch_kkt(const NewtonDev& nd, hipStream_t s);
 bool kkt_condensed_available(const NewtonDev& nd);
