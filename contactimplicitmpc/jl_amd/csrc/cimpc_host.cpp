@@ -840,14 +840,18 @@ int cimpc_set_objective(cimpc_handle h, const double* Q, const double* R, const 
         select_kkt_backend(h);
     }
     std::vector<double> Qi(H * d.nq * d.nq), Ri(H * d.nu * d.nu);
+    bool r_inverted = true;
     for (size_t i = 0; i < H; ++i) {
-        // (the inverses feed the condensed solve only - also behind the cf-mode reduction)
+        // (the inverses feed the condensed solve - also behind the cf-mode reduction - and the control elimination of the banded LDL^T)
         const bool need_inv = !h->use_dense || (h->cf_reduce && V == nullptr);
         if (!invert(Q + i * d.nq * d.nq, Qi.data() + i * d.nq * d.nq, d.nq) && need_inv)
             return fail(h, CIMPC_ERR_INVALID, "objective block Q[i] is singular");
-        if (d.nu > 0 && !invert(R + i * d.nu * d.nu, Ri.data() + i * d.nu * d.nu, d.nu) && need_inv)
-            return fail(h, CIMPC_ERR_INVALID, "objective block R[i] is singular");
+        if (d.nu > 0 && !invert(R + i * d.nu * d.nu, Ri.data() + i * d.nu * d.nu, d.nu)) {
+            if (need_inv) return fail(h, CIMPC_ERR_INVALID, "objective block R[i] is singular");
+            r_inverted = false;
+        }
     }
+    h->S.band_reduce = (r_inverted && d.nu > 0) ? 1 : 0;      // kkt_dense.hip: kkt_banded_kernel
     HIP_TRY(h, hipMemcpy(h->d_Q, Q, H * d.nq * d.nq * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_R, R, H * d.nu * d.nu * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_Qinv, Qi.data(), Qi.size() * sizeof(double), hipMemcpyHostToDevice));

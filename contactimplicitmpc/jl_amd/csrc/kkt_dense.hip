@@ -181,11 +181,39 @@ __global__ __launch_bounds__(256) void kkt_dense_kernel(NewtonDev S, KktArgs K, 
 namespace {
 struct BandRows {
     const NewtonDev& S; const DenseLayout& L; const double* dzb; double rho; int s, nths;
+    const double* G;      // reduced form (controls eliminated): [H][nd x nd] du1_t R_t^-1 du1_t^T, column-major; nullptr = full form
     // entry (i, j), j <= i, of the interleaved KKT matrix
     __device__ double operator()(int i, int j) const {
         const int nq = L.nq, nu = L.nu, nr = L.nr, nd = L.nd, H = L.H;
         const int ti = i / s, ki = i - ti * s, tj = j / s, kj = j - tj * s;
         const int dt = ti - tj;
+        if (G != nullptr) {      // ordering [q_{t+2}, nu_t] per step, s = nq + nd
+            if (ki < nq) {                                       // q row
+                if (kj >= nq) return 0.0;
+                const size_t e = (size_t)kj * nq + ki;
+                if (dt == 0) {
+                    double v = S.Q[(size_t)ti * nq * nq + e];
+                    if (S.V != nullptr) {
+                        v += S.V[(size_t)ti * nq * nq + e];
+                        if (ti + 1 < H) v += S.V[(size_t)(ti + 1) * nq * nq + e];
+                    }
+                    return v;
+                }
+                if (dt == 1 && S.V != nullptr) return -S.V[(size_t)ti * nq * nq + e];
+                return 0.0;
+            }
+            const int kd = ki - nq;                              // dual row nu_t
+            const double* dz = dzb + (size_t)ti * nths * nd;
+            if (dt == 0) {
+                if (kj < nq) return (kj == kd) ? -1.0 : 0.0;     // -I at q_{t+2}
+                const double g = G[(size_t)ti * nd * nd + (size_t)(kj - nq) * nd + kd];
+                return (kj == ki) ? -rho - g : -g;               // -(rho I + du1 R^-1 du1^T)
+            }
+            if (kj >= nq) return 0.0;
+            if (dt == 1) return dz[(size_t)(nq + kj) * nd + kd]; // dq1 at q_{t+1}
+            if (dt == 2) return dz[(size_t)kj * nd + kd];        // dq0 at q_t
+            return 0.0;
+        }
         if (ki < nu) {                                           // u row: R_t (same block only)
             return (dt == 0 && kj < nu) ? S.R[(size_t)ti * nu * nu + (size_t)kj * nu + ki] : 0.0;
         }
@@ -228,17 +256,35 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// doubles of workspace per rollout: rows of L (N x (w + 1)), y (N), then G and g of the reduced form.  Sized for the FULL form
+// (the larger one) so that the host's allocation does not depend on which form a launch takes.
+__host__ __device__ inline size_t banded_ws_per_rollout(const NewtonDev& S) {
+    const size_t sF = (size_t)S.nr + S.nd, NF = (size_t)S.dm.H * sF;
+    size_t wF = 3 * sF - 1 - S.dm.nu; if (wF > NF - 1) wF = NF - 1;
+    return NF * (wF + 1) + NF + (size_t)S.dm.H * S.nd * (S.nd + 1);
+}
+
 #define CIMPC_BANDED_THREADS 1024      // (a constant of the build: the -D override is gone with the experiment it served)
 __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(NewtonDev S, KktArgs K, double* ws_all) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int b = blockIdx.x + S.b0, tid = threadIdx.x, nt = blockDim.x;
     if (K.stage != nullptr && K.stage[b] != STAGE_KKT) return;
     const DenseLayout L(S);
-    const int N = L.N, H = L.H, nr = L.nr, nd = L.nd, s = nr + nd;
+    // Round 4: the controls are eliminated first.  u_t appears in its own block only (R_t, and du1_t in the row of nu_t), so
+    //   Du_t = R_t^-1 (r_u,t - du1_t^T Dnu_t)   and the nu_t row becomes   ... - (rho I + du1_t R_t^-1 du1_t^T) Dnu_t = r_d,t - du1_t R_t^-1 r_u,t
+    // exactly: the factored matrix is the interleaved KKT matrix of [q_{t+2}, nu_t] - still symmetric quasi-definite - with
+    // s = nq + nd rows per step instead of nr + nd and half-bandwidth 3 s - 1 (centroidal H = 60: N 2880 -> 2160, w 131 -> 107,
+    // N w^2 49 M -> 25 M, a quarter fewer pivots on the sequential chain).  S.band_reduce = 0 (an R_t the host could not
+    // invert) keeps the full form.
+    const bool reduced = S.band_reduce != 0 && L.nu > 0;
+    const int H = L.H, nr = L.nr, nd = L.nd, nq = L.nq, nu = L.nu;
+    const int s = reduced ? nq + nd : nr + nd, N = H * s;
     constexpr int RB = 4;                                        // pivots per window update
-    const int w = min(3 * s - 1 - L.nu, N - 1), LW = w + 1, M = w + RB;   // window slots: pivot k+RB-1 reaches row k+RB-1+w
-    double* Lr = ws_all + (size_t)b * ((size_t)N * LW + N);      // row i: L[i][i-w .. i-1], slot w: 1 / d_i
+    const int w = min(reduced ? 3 * s - 1 : 3 * s - 1 - nu, N - 1), LW = w + 1, M = w + RB;   // window slots: pivot k+RB-1 reaches row k+RB-1+w
+    double* wsb = ws_all + (size_t)b * banded_ws_per_rollout(S);
+    double* Lr = wsb;                                            // row i: L[i][i-w .. i-1], slot w: 1 / d_i
     double* yg = Lr + (size_t)N * LW;
+    double* Gm = yg + N;                                         // reduced form: [H][nd x nd] du1 R^-1 du1^T, then [H][nd] du1 R^-1 r_u
     const int MS = M + 1;                                        // row stride: slot M is a dummy row / column
     double* W = sm;                                              // [M+1][M+1] window, slot = index mod M; BOTH triangles kept
     double* yw = W + (size_t)MS * MS;                            // [M]   right-hand side of the rows in the window
@@ -247,16 +293,55 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     const double beta = K.beta ? K.beta[b] : K.beta_scalar;
     const double rho = (double)H * beta * S.kappa;               // newton_jacobian.jl:169-186 quirk
     const double* dzb = kkt_dz(S, K, b, H, S.nths, nd);
-    const BandRows row{S, L, dzb, rho, s, S.nths};
     const double* rb = K.r + (size_t)b * S.N;
+    double* gv = Gm + (size_t)H * nd * nd;
+    if (reduced) {      // G_t = du1_t R_t^-1 du1_t^T, g_t = du1_t R_t^-1 r_u,t  (R_t^-1: NewtonDev::Rinv, symmetric); T = du1 R^-1 staged in LDS
+        double* Tm = sm;                                         // [H][nd x nu] (the window is not in use yet)
+        for (int e = tid; e < H * nd * nu; e += nt) {
+            const int t = e / (nd * nu), k = e - t * nd * nu, r = k % nd, c = k / nd;
+            const double* du = dzb + ((size_t)t * S.nths + 2 * nq) * nd;      // du1_t, nd x nu column-major
+            const double* Ri = S.Rinv + (size_t)t * nu * nu + (size_t)c * nu;
+            double a = 0.0;
+            for (int m = 0; m < nu; ++m) a = fma(du[(size_t)m * nd + r], Ri[m], a);
+            Tm[e] = a;
+        }
+        __syncthreads();
+        for (int e = tid; e < H * nd * (nd + 1); e += nt) {
+            const int t = e / (nd * (nd + 1)), k = e - t * nd * (nd + 1), r = k % nd, c = k / nd;
+            const double* Tr = Tm + (size_t)t * nd * nu;
+            double a = 0.0;
+            if (c < nd) {
+                const double* du = dzb + ((size_t)t * S.nths + 2 * nq) * nd;
+                for (int m = 0; m < nu; ++m) a = fma(Tr[(size_t)m * nd + r], du[(size_t)m * nd + c], a);
+                Gm[(size_t)t * nd * nd + (size_t)c * nd + r] = a;
+            } else {
+                for (int m = 0; m < nu; ++m) a = fma(Tr[(size_t)m * nd + r], rb[t * nr + m], a);
+                gv[t * nd + r] = a;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    const BandRows row{S, L, dzb, rho, s, S.nths, reduced ? Gm : nullptr};
     // interleaved index -> index in the reference's layout (primal segment step-major, then the duals)
-    auto orig = [&](int i) { const int t = i / s, k = i - t * s; return k < nr ? t * nr + k : H * nr + t * nd + (k - nr); };
+    auto orig = [&](int i) {
+        const int t = i / s, k = i - t * s;
+        if (reduced) return k < nq ? t * nr + nu + k : H * nr + t * nd + (k - nq);
+        return k < nr ? t * nr + k : H * nr + t * nd + (k - nr);
+    };
+    // right-hand side entry of interleaved row i (reduced form: the dual rows carry r_d - du1 R^-1 r_u)
+    auto rhs = [&](int i) {
+        const double v = rb[orig(i)];
+        if (!reduced) return v;
+        const int t = i / s, k = i - t * s;
+        return k < nq ? v : v - gv[t * nd + (k - nq)];
+    };
     // row i enters the window (columns i-w .. i): a row has at most w + 1 <= 192 entries - one per thread; the
     // values are FETCHED one block ahead (global loads of the sensitivities / weights stay off the critical path)
     auto row_value = [&](int i) -> double {
         if (i >= N) return 0.0;
         if (tid <= w) { const int j = i - w + tid; return j >= 0 ? row(i, j) : 0.0; }
-        return tid == w + 1 ? rb[orig(i)] : 0.0;                 // thread w + 1 carries the right-hand side entry
+        return tid == w + 1 ? rhs(i) : 0.0;                      // thread w + 1 carries the right-hand side entry
     };
     auto row_commit = [&](int i, double v) {
         if (i >= N) return;
@@ -409,6 +494,27 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         }
     }
     __syncthreads();
+    if (reduced) {      // Du_t = R_t^-1 (r_u,t - du1_t^T Dnu_t)
+        __threadfence_block();
+        double* tu = sm;                                         // [H][nu]
+        for (int e = tid; e < H * nu; e += nt) {
+            const int t = e / nu, m = e - t * nu;
+            const double* du = dzb + ((size_t)t * S.nths + 2 * nq + m) * nd;
+            const double* dn = D + H * nr + t * nd;
+            double a = rb[t * nr + m];
+            for (int k = 0; k < nd; ++k) a = fma(-du[k], dn[k], a);
+            tu[e] = a;
+        }
+        __syncthreads();
+        for (int e = tid; e < H * nu; e += nt) {
+            const int t = e / nu, m = e - t * nu;
+            const double* Ri = S.Rinv + (size_t)t * nu * nu + (size_t)m * nu;      // column m = row m (symmetric)
+            double a = 0.0;
+            for (int k = 0; k < nu; ++k) a = fma(Ri[k], tu[t * nu + k], a);
+            D[t * nr + m] = a;
+        }
+        __syncthreads();
+    }
     if (K.finish) {
         __threadfence_block();
         start_line_search<BlockSync>(S, b, 1, tid, nt);
@@ -419,23 +525,29 @@ static size_t banded_lds_bytes(int w) {      // window (w + 4 slots + dummy)^2, 
     const size_t MS = (size_t)w + 4 + 1;
     return (MS * MS + MS + 4 * MS + 8) * sizeof(double);
 }
-static int band_halfwidth(const NewtonDev& S) {
+static int band_halfwidth(const NewtonDev& S) {      // (the kernel's own formula: reduced form when the controls are eliminated)
+    if (S.band_reduce != 0 && S.dm.nu > 0) { const int s = S.dm.nq + S.nd; return std::min(3 * s - 1, S.dm.H * s - 1); }
     const int s = S.nr + S.nd;
     return std::min(3 * s - 1 - S.dm.nu, S.N - 1);
 }
+static size_t banded_lds_bytes(const NewtonDev& S) {      // ... and, before the window is in use, T = du1 R^-1 of every step ([H][nd x nu])
+    const size_t win = banded_lds_bytes(band_halfwidth(S));
+    const size_t pre = (S.band_reduce != 0 && S.dm.nu > 0) ? (size_t)S.dm.H * S.nd * S.dm.nu * sizeof(double) : 0;
+    return std::max(win, pre);
+}
 bool kkt_banded_available(const NewtonDev& S) {      // window + two vectors in 160 KB of LDS, back substitution: w < 192
     const int w = band_halfwidth(S);
-    return S.dm.mode == CIMPC_MODE_CONFIGURATION && w <= 190 && banded_lds_bytes(w) <= 160 * 1024;
+    return S.dm.mode == CIMPC_MODE_CONFIGURATION && w <= 190 && banded_lds_bytes(S) <= 160 * 1024;
 }
 
 size_t kkt_dense_workspace_doubles(const NewtonDev& S, bool banded) {
-    if (banded) return (size_t)S.dm.B * ((size_t)S.N * (band_halfwidth(S) + 1) + (size_t)S.N);
+    if (banded) return (size_t)S.dm.B * banded_ws_per_rollout(S);
     return (size_t)S.dm.B * ((size_t)S.N * S.N + 2 * (size_t)S.N);
 }
 
 static int launch_kkt_dense(const NewtonDev& S, const KktArgs& K, double* ws, hipStream_t s, bool banded) {
     if (banded) {
-        const size_t lds = banded_lds_bytes(band_halfwidth(S));
+        const size_t lds = banded_lds_bytes(S);
         static LdsOptIn optin;
         if (lds_opt_in(optin, (const void*)kkt_banded_kernel, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
         hipLaunchKernelGGL(kkt_banded_kernel, dim3(S.nb_launch), dim3(CIMPC_BANDED_THREADS), lds, s, S, K, ws);
