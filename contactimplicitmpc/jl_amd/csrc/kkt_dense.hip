@@ -264,7 +264,9 @@ __host__ __device__ inline size_t banded_ws_per_rollout(const NewtonDev& S) {
     return NF * (wF + 1) + NF + (size_t)S.dm.H * S.nd * (S.nd + 1);
 }
 
-#define CIMPC_BANDED_THREADS 1024      // (a constant of the build: the -D override is gone with the experiment it served)
+#ifndef CIMPC_BANDED_THREADS
+#define CIMPC_BANDED_THREADS 1024      // (build parameter: 256 / 512 / 1024 measured in round 4)
+#endif
 __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(NewtonDev S, KktArgs K, double* ws_all) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int b = blockIdx.x + S.b0, tid = threadIdx.x, nt = blockDim.x;
