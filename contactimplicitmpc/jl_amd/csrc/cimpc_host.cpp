@@ -67,6 +67,7 @@ struct Knobs {
     int spec_mid = -1;           // previous search depth from which a rollout starts with three candidates: by batch size
     int waves = 0;               // sweep workgroup size: by batch size
     int kkt_overlap = -1;        // KKT on its own stream next to the sweep: from 64 rollouts on
+    int waves32 = 0;             // CIMPC_WAVES32: waves per sweep workgroup of the 32-lane models (0: by batch size; 4 = latency build, 8 = throughput build)
     int sweep_wgs = 0;           // CIMPC_SWEEP_WGS: persistent sweep workgroups (0: computed from the resident set) - sub-batch experiments
     int async_service = 0;       // job-only workgroups of the asynchronous kernel: computed
     int async_flags = 0;         // reserved
@@ -95,6 +96,7 @@ struct Knobs {
         kkt_pipe = env_int("CIMPC_KKT_PIPE", kkt_pipe);
         generic_static = env_int("CIMPC_GENERIC_STATIC", generic_static ? 1 : 0) != 0;
         sweep_wgs = env_int("CIMPC_SWEEP_WGS", sweep_wgs);
+        waves32 = env_int("CIMPC_WAVES32", waves32);
     }
 };
 
@@ -628,10 +630,14 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     // 4 waves share one staged table (throughput); measured for single rollouts too (one problem per knot anyway): B = 1
     // quadruped H = 40 cold 0.945 -> 0.926 ms, warm MPC loop 3.19 -> 3.03 ms, hopper H = 20 1.02 -> 0.97 ms against 1 wave
     h->waves = 4;
-    // (32-lane models, round 4, measured and not kept: eight waves per workgroup = two per SIMD next to the ONE table a CU has room
-    //  for - per-problem LDS cut to 3 KB by a windowed R transposition, the MGS column read twice instead of kept in 64 registers
-    //  to fit 256: the sweep becomes LDS-return-bandwidth bound again, centroidal H = 60: 64 rollouts 9.3 -> 13.4 ms per step,
-    //  128 rollouts 16.2 -> 13.6 ms - profiles/r04/cent_8wave_experiment.log)
+    // 32-lane models (round 4): from about three problems per lane group and sweep on, the throughput build of the sweep - eight waves per
+    // workgroup, two per SIMD (ip_kernel_impl.h: ip_queue_kernel<M, WIDE>; centroidal H = 60: 64 rollouts 7.9 -> 11.6 ms of sweeps per
+    // step, 128 rollouts 14.0 -> 12.2 ms, 256 rollouts 26.0 -> 22.4 ms - profiles/r04/cent_w8b.log).  CIMPC_WAVES32 = 4 / 8 forces one.
+    // (A first form that ALSO read the MGS column twice instead of keeping it in registers was LDS-bound: cent_8wave_experiment.log.)
+    if (h->ki.G == 32) {
+        if (h->kn.waves32 > 0) h->waves = h->kn.waves32;
+        else if ((size_t)B * H >= 6000) h->waves = 8;
+    }
     // the single-launch solve runs its residual jobs on the whole workgroup: 4 waves also for small batches
     // (measured B = 8: 5.2 -> 4.4 ms, B = 64: 8.5 -> 7.5 ms)
     if (h->async_on && (h->async_mode == 1 || (h->async_mode == 2 && B >= 4 && B <= h->kn.async_full_max))) h->waves = 4;

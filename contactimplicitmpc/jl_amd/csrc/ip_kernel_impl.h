@@ -39,15 +39,25 @@ static __device__ unsigned long long g_sweep_prof[16];
 #define SPROF_T() 0ll
 #endif
 
-template <int NQ_, int NU_, int NW_, int NC_, int NB_, int MODE_>
+// WIDE_ (32-lane models only): the throughput build - see ip_queue_kernel
+template <int NQ_, int NU_, int NW_, int NC_, int NB_, int MODE_, int WIDE_ = 0>
 struct Model {
     static constexpr int NQ = NQ_, NU = NU_, NW = NW_, NC = NC_, NB = NB_, MODE = MODE_;
+    static constexpr bool WIDE = WIDE_ != 0;
+    using Wide = Model<NQ_, NU_, NW_, NC_, NB_, MODE_, 1>;
     static constexpr int NX = NQ, NY = 2 * NC + NB, NZ = NQ + 4 * NC + 2 * NB;
     static constexpr int NTH = 2 * NQ + NU + NW + 2, NTHS = 2 * NQ + NU;
     static constexpr int ND = MODE ? NQ + NC + NB : NQ;
     static constexpr int G = (NX <= 16 && NY <= 16) ? 16 : 32;
     static_assert(NX <= 32 && NY <= 32, "lane group holds at most 32 rows");
-    static constexpr int RST_LD = G + 1;                       // padded row stride of the R tile
+    // R-factor transposition buffer: lane = column produces row k of R at step k, lane l needs row l in its registers.
+    // The whole [NY][G + 1] tile (conflict-free at stride G + 1), read back once at the end - except in the throughput build of the
+    // 32-lane models (WIDE, round 4): a window of RROWS = 8 rows at stride 34 (16-byte aligned rows for ds_read_b128), read back by
+    // its eight owner lanes every eight steps - 2.2 KB instead of 8.4 KB per problem, which is what lets a workgroup hold 16
+    // problems (8 waves = two per SIMD) next to the 85 KB table of the centroidal model.
+    static constexpr bool FULL_TILE = !(WIDE && !(NX <= 16 && NY <= 16));
+    static constexpr int RROWS = FULL_TILE ? NY : 8;
+    static constexpr int RST_LD = FULL_TILE ? G + 1 : G + 2;   // padded row stride of the R tile
     static constexpr int DTN_LD = ((NTHS + G - 1) / G) * G;    // leading dimension of the delta^T nu products (IpParams::dtn)
 #define CIMPC_SENS_MAX 16      // (a constant of the build: the -D override is gone with the experiment it served)
     static constexpr int SENS_MAX = CIMPC_SENS_MAX;             // converged problems a group may defer
@@ -60,7 +70,7 @@ struct Model {
     static constexpr int SENS_ILP = (NX <= 16 && NY <= 16) ? CIMPC_SENS_ILP : CIMPC_SENS_ILP32;   // sensitivity columns solved side by side
     // per-problem LDS: the R tile and theta - theta0 SHARE their space (theta - theta0 lives from the pull of a problem to the two
     // dot products a few lines below it; the tile is scratch inside factorize), then the backlog of deferred sensitivities
-    static constexpr int TILE = NY * RST_LD > NTH ? NY * RST_LD : NTH;
+    static constexpr int TILE = RROWS * RST_LD > NTH ? RROWS * RST_LD : NTH;
     // ... then one 64-bit word per group: the clock value the running solve's time budget counts from (IpParams::budget_ticks)
     // ... then (32-lane groups) three staging vectors of G doubles: one for lane-indexed vectors that feed a matrix-vector
     // product, two (by step parity) for the column the MGS step broadcasts - IpSolver::stage / factorize
@@ -225,14 +235,33 @@ struct IpSolver {
                     if (lq == k + 1) static_for<0, NY>([&](auto ic) { constexpr int r = decltype(ic)::value; dst[r] = Qc[r]; });
                 }
             }
-            Rst[k * M::RST_LD + l] = nrk;  // -R[k,l], l > k (zeros elsewhere)
+            if constexpr (M::FULL_TILE) {
+                Rst[k * M::RST_LD + l] = nrk;  // -R[k,l], l > k (zeros elsewhere)
+            } else {
+                // window of RROWS rows: row k goes to slot k % RROWS; when the window is full (or the factorization ends) the
+                // owner lanes of its rows read them back - -R[l,j] (stored negated): the back-substitution adds
+                Rst[(k % M::RROWS) * M::RST_LD + l] = nrk;
+                if constexpr ((k % M::RROWS) == M::RROWS - 1 || k == NY - 1) {
+                    constexpr int k0 = (k / M::RROWS) * M::RROWS;
+                    wave_lds_fence();
+                    if (lq >= k0 && lq <= k) {
+                        const double* rrow = Rst + (lq - k0) * M::RST_LD;
+                        static_for<0, NY>([&](auto jc) { constexpr int j = decltype(jc)::value; Rr[j] = rrow[j]; });
+                    }
+                    wave_lds_fence();
+                }
+            }
         });
-        wave_lds_fence();
-        static_for<0, NY>([&](auto kc) {   // row l of R (transpose through the LDS tile)
-            constexpr int k = decltype(kc)::value;
-            Rr[k] = vy ? Rst[l * M::RST_LD + k] : 0.0;       // -R[l,k] (stored negated): the back-substitution adds
-        });
-        wave_lds_fence();
+        if constexpr (M::FULL_TILE) {
+            wave_lds_fence();
+            static_for<0, NY>([&](auto kc) {   // row l of R (transpose through the LDS tile)
+                constexpr int k = decltype(kc)::value;
+                Rr[k] = vy ? Rst[l * M::RST_LD + k] : 0.0;       // -R[l,k] (stored negated): the back-substitution adds
+            });
+            wave_lds_fence();
+        } else {
+            if (!vy) static_for<0, NY>([&](auto kc) { Rr[decltype(kc)::value] = 0.0; });     // (lanes beyond NY own no row)
+        }
     }
 
     // t = R^-1 Q^T rhs  (qr_solve!, qr.jl:142-158); rhs lane-indexed
@@ -897,8 +926,14 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
 // Default 256 x 2 = 8 waves per CU (2 per SIMD, 256 VGPRs).
 #define CIMPC_SWEEP_OCC 2      // (a constant of the build: the -D override is gone with the experiment it served)
 #define CIMPC_SWEEP_THREADS 256      // (a constant of the build: the -D override is gone with the experiment it served)
+// 32-lane models come in two builds of this kernel (round 4).  Model::WIDE = false: 256 threads, one wave per SIMD with the whole register
+// file (no scratch) - the latency form, right while a launch holds about one problem per lane group (configs[4] at 64 rollouts:
+// 7.9 ms of sweeps per step, 11.6 ms with the other build).  Model::WIDE = true: 512 threads = two waves per SIMD at 256 registers (the R rows
+// spill to scratch between the factorization and the back-substitutions, 324 bytes per lane) next to the ONE table a CU has room for -
+// the throughput form (Model::Wide: its own LDS layout, a windowed R transposition), 13-14 % faster from 128 rollouts on
+// (profiles/r04/cent_w8b.log, cent_two_builds.log).  The host picks by problems per sweep.
 template <class M>
-__global__ __launch_bounds__(M::G == 16 ? CIMPC_SWEEP_THREADS : 256, M::G == 16 ? CIMPC_SWEEP_OCC : 1) void ip_queue_kernel(IpParams p) {
+__global__ __launch_bounds__(M::G == 16 ? CIMPC_SWEEP_THREADS : (M::WIDE ? 512 : 256), M::G == 16 ? CIMPC_SWEEP_OCC : 1) void ip_queue_kernel(IpParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int s_knot, s_total, s_rem[PICK_MAXK];
     const int tid = (int)threadIdx.x;
@@ -998,12 +1033,23 @@ int launch_callback(const IpCallbackArgs& a, hipStream_t s) {
 template <class M>
 int launch_model(const IpParams& p, int waves, hipStream_t s) {
     constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G, M::NTHS);
-    if (waves < 1 || waves > (M::G == 16 ? CIMPC_SWEEP_THREADS : 256) / 64 || waves == 3) return CIMPC_ERR_INVALID;
+    if (waves < 1 || waves > (M::G == 16 ? CIMPC_SWEEP_THREADS : 512) / 64 || waves == 3) return CIMPC_ERR_INVALID;
     const int ppw = 64 / M::G;
     const size_t lds = (size_t)(L.size + waves * ppw * M::LDS_GROUP) * sizeof(double);
+    const int grid = p.wpk;      // persistent workgroups of the launch
+    if constexpr (M::G != 16) {
+        if (waves > 4) {         // throughput build: two waves per SIMD, its own per-problem LDS layout
+            using MW = typename M::Wide;
+            constexpr LinLayout LW(MW::NX, MW::NY, MW::NTH, MW::G, MW::NTHS);
+            const size_t lds_w = (size_t)(LW.size + waves * ppw * MW::LDS_GROUP) * sizeof(double);
+            static LdsOptIn optin_w;
+            if (lds_opt_in(optin_w, (const void*)ip_queue_kernel<MW>, lds_w) != CIMPC_OK) return CIMPC_ERR_HIP;
+            hipLaunchKernelGGL((ip_queue_kernel<MW>), dim3(grid), dim3(64 * waves), lds_w, s, p);
+            return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+        }
+    }
     static LdsOptIn optin;
     if (lds_opt_in(optin, (const void*)ip_queue_kernel<M>, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
-    const int grid = p.wpk;      // persistent workgroups of the launch
     hipLaunchKernelGGL((ip_queue_kernel<M>), dim3(grid), dim3(64 * waves), lds, s, p);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
