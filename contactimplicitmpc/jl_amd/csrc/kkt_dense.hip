@@ -264,9 +264,22 @@ __host__ __device__ inline size_t banded_ws_per_rollout(const NewtonDev& S) {
     return NF * (wF + 1) + NF + (size_t)S.dm.H * S.nd * (S.nd + 1);
 }
 
+// -DCIMPC_BANDED_PROF (diagnostic builds, with -DCIMPC_KKT_PROF for the accessor): shader-clock accounting of the banded kernel, rollout 0,
+// wavefront 0 -> NewtonDev::stats[8..]: [0] pre-pass  [1] panel  [2] fetch of the entering rows  [3] barrier A  [4] commit  [5] update
+// [6] barrier B  [7] back substitution  [8] control recovery; wavefront 4 -> stats[20..]: [0] time before barrier A  [1] update  [2] barrier B
+#ifdef CIMPC_BANDED_PROF
+#define BPROF(j) { const long long tn_ = clock64(); bp[j] += tn_ - bt; bt = tn_; }
+#else
+#define BPROF(j)
+#endif
 #ifndef CIMPC_BANDED_THREADS
 #define CIMPC_BANDED_THREADS 1024      // (build parameter: 256 / 512 / 1024 measured in round 4)
 #endif
+// RB: pivots per window update (4, or 8 where the window of w + 8 slots fits the LDS: the reduced form of every compiled model).  The
+// per-entry cost of an update pass is index arithmetic and LDS traffic, not its RB multiply-adds (profiles/r04/banded_prof_before.log:
+// update + its barrier 43 % of a solve, 7-8 k cycles per pass at RB = 4), so half as many passes are worth the deeper panel.  Every entry
+// still receives its pivots' contributions one after the other in pivot order: the factors do not depend on RB.
+template <int RB>
 __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(NewtonDev S, KktArgs K, double* ws_all) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int b = blockIdx.x + S.b0, tid = threadIdx.x, nt = blockDim.x;
@@ -281,7 +294,6 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     const bool reduced = S.band_reduce != 0 && L.nu > 0;
     const int H = L.H, nr = L.nr, nd = L.nd, nq = L.nq, nu = L.nu;
     const int s = reduced ? nq + nd : nr + nd, N = H * s;
-    constexpr int RB = 4;                                        // pivots per window update
     const int w = min(reduced ? 3 * s - 1 : 3 * s - 1 - nu, N - 1), LW = w + 1, M = w + RB;   // window slots: pivot k+RB-1 reaches row k+RB-1+w
     double* wsb = ws_all + (size_t)b * banded_ws_per_rollout(S);
     double* Lr = wsb;                                            // row i: L[i][i-w .. i-1], slot w: 1 / d_i
@@ -297,6 +309,9 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     const double* dzb = kkt_dz(S, K, b, H, S.nths, nd);
     const double* rb = K.r + (size_t)b * S.N;
     double* gv = Gm + (size_t)H * nd * nd;
+#ifdef CIMPC_BANDED_PROF
+    long long bp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, bt = clock64();
+#endif
     if (reduced) {      // G_t = du1_t R_t^-1 du1_t^T, g_t = du1_t R_t^-1 r_u,t  (R_t^-1: NewtonDev::Rinv, symmetric); T = du1 R^-1 staged in LDS
         double* Tm = sm;                                         // [H][nd x nu] (the window is not in use yet)
         for (int e = tid; e < H * nd * nu; e += nt) {
@@ -324,6 +339,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         __threadfence_block();
         __syncthreads();
     }
+    BPROF(0)
     const BandRows row{S, L, dzb, rho, s, S.nths, reduced ? Gm : nullptr};
     // interleaved index -> index in the reference's layout (primal segment step-major, then the duals)
     auto orig = [&](int i) {
@@ -340,18 +356,21 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     };
     // row i enters the window (columns i-w .. i): a row has at most w + 1 <= 192 entries - one per thread; the
     // values are FETCHED one block ahead (global loads of the sensitivities / weights stay off the critical path)
+    // (round 4: the entering rows belong to the threads FROM 128 ON - wavefront 0 runs the panel of a block on its own meanwhile)
+    const int rt = (int)nt >= 128 + w + 2 ? tid - 128 : tid;      // row-entry index of this thread (negative: none)
+    const bool fast_panel = rt != tid && M <= 128;                 // one wavefront holds the window's rows two per lane
     auto row_value = [&](int i) -> double {
-        if (i >= N) return 0.0;
-        if (tid <= w) { const int j = i - w + tid; return j >= 0 ? row(i, j) : 0.0; }
-        return tid == w + 1 ? rhs(i) : 0.0;                      // thread w + 1 carries the right-hand side entry
+        if (i >= N || rt < 0) return 0.0;
+        if (rt <= w) { const int j = i - w + rt; return j >= 0 ? row(i, j) : 0.0; }
+        return rt == w + 1 ? rhs(i) : 0.0;                       // entry w + 1 carries the right-hand side
     };
     auto row_commit = [&](int i, double v) {
-        if (i >= N) return;
+        if (i >= N || rt < 0) return;
         const int si = i % M;
-        if (tid <= w) {
-            const int j = i - w + tid;
+        if (rt <= w) {
+            const int j = i - w + rt;
             if (j >= 0) { const int sj = j % M; W[(size_t)si * MS + sj] = v; W[(size_t)sj * MS + si] = v; }   // and its mirror image
-        } else if (tid == w + 1) yw[si] = v;
+        } else if (rt == w + 1) yw[si] = v;
     };
     for (int i = 0; i < M && i < N; ++i) row_commit(i, row_value(i));
     for (int e = tid; e < RB * MS; e += nt) PL[e] = 0.0;
@@ -364,6 +383,67 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         const int nb_ = min(RB, N - k);                          // pivots of this block
         // ---- panel: the block's pivots one after the other, each column first brought up to date with the
         //      earlier pivots of the block (left-looking inside the panel) ------------------------------------
+        // Round 4: ONE wavefront runs the whole panel (two rows of the window per lane, hand-overs between the steps inside the
+        // wavefront - LDS operations of a wavefront execute in order) while the others fetch the entering rows; the workgroup meets
+        // once per block before the update instead of once per pivot (the per-pivot cost was 2.2 us, most of it four 16-wave
+        // barriers per block with two of the sixteen waves working).  Same arithmetic per entry.
+        if (fast_panel) {
+            if (tid < 64) {
+                // rows of the window by their offset q from the block's first pivot: lane tid owns q = tid and tid + 64 for the whole
+                // block, so its entries in the block's pivot columns, its multipliers and its right-hand-side entries stay in
+                // REGISTERS through the RB steps; what a step needs of another row (the pivot row's multipliers and right-hand side,
+                // the pivot itself) comes by v_readlane from the lane that owns it - no LDS round trip inside the panel.
+                auto rl = [](double v, int lane) {
+                    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+                    return __hiloint2double(hi, lo);
+                };
+                int sq[2]; bool vq[2];
+                double a[2][RB], l[2][RB], yr[2], dvr[RB];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int q = tid + 64 * hh;
+                    vq[hh] = q < M;
+                    sq[hh] = vq[hh] ? (k + q) % M : 0;
+                    yr[hh] = vq[hh] ? yw[sq[hh]] : 0.0;
+#pragma unroll
+                    for (int t = 0; t < RB; ++t) { a[hh][t] = (vq[hh] && t < nb_) ? W[(size_t)sq[hh] * MS + (k + t) % M] : 0.0; l[hh][t] = 0.0; }
+                }
+#pragma unroll
+                for (int t = 0; t < RB; ++t) {
+                    dvr[t] = 0.0;
+                    if (t < nb_) {
+                        const int p = k + t, m = min(w, N - 1 - p);
+#pragma unroll
+                        for (int u = 0; u < t; ++u) {       // left-looking: bring column t up to date with the block's earlier pivots
+                            const double lp = rl(l[0][u], t), c = dvr[u];
+#pragma unroll
+                            for (int hh = 0; hh < 2; ++hh) a[hh][t] = fma(-l[hh][u] * c, lp, a[hh][t]);
+                        }
+                        const double d = rl(a[0][t], t), inv = 1.0 / d, yp = rl(yr[0], t);
+                        dvr[t] = d;
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            const int rr = tid + 64 * hh - t;
+                            const bool coupled = vq[hh] && rr >= 1 && rr <= m;
+                            const double lv = coupled ? a[hh][t] * inv : 0.0;
+                            l[hh][t] = lv;
+                            if (coupled) {
+                                Lr[(size_t)(p + rr) * LW + (w - rr)] = lv;
+                                yr[hh] = fma(-lv, yp, yr[hh]);            // forward substitution rides along
+                            }
+                            if (vq[hh]) PL[(size_t)t * MS + sq[hh]] = lv;   // all M slots: zero where the pivot does not couple
+                        }
+                        if (tid == t) { yg[p] = yp; Lr[(size_t)p * LW + w] = inv; }
+                    }
+                }
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) if (vq[hh]) yw[sq[hh]] = yr[hh];
+                if (tid == 0) {
+#pragma unroll
+                    for (int t = 0; t < RB; ++t) dv[t] = dvr[t];
+                }
+            }
+        } else
         for (int t = 0; t < nb_; ++t) {
             const int p = k + t, sp = p % M, m = min(w, N - 1 - p);
             if (tid < M) {
@@ -390,11 +470,16 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         }
         // ---- rows entering the window: fetch for the NEXT block, commit this block's (their slots - the
         //      pivots' - are not touched by the update below) -------------------------------------------------
+        BPROF(1)
         double nxt2[RB];
 #pragma unroll
         for (int t = 0; t < RB; ++t) nxt2[t] = row_value(k + M + RB + t);
+        BPROF(2)
+        if (fast_panel) lds_barrier();        // the panel's multipliers / pivots are in place; the pivots' slots may be overwritten now
+        BPROF(3)
 #pragma unroll
         for (int t = 0; t < RB; ++t) { if (t < nb_) row_commit(k + M + t, nxt[t]); nxt[t] = nxt2[t]; }
+        BPROF(4)
         // ---- rank-nb_ update of the trailing window, rows / columns k+RB .. k+RB-1+w --------------------------
         {
             const int base = k + nb_, mt = min(w, N - base);     // mt rows / columns present
@@ -451,7 +536,9 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
                 }
             }
         }
+        BPROF(5)
         lds_barrier();
+        BPROF(6)
     }
     __syncthreads();              // full barrier: the rows of L and y in global memory are read back below
     // ---- back substitution  L^T x = D^-1 y  (wavefront 0; acc[j] collects sum_{i > j} L[i][j] x_i) ---------
@@ -496,6 +583,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         }
     }
     __syncthreads();
+    BPROF(7)
     if (reduced) {      // Du_t = R_t^-1 (r_u,t - du1_t^T Dnu_t)
         __threadfence_block();
         double* tu = sm;                                         // [H][nu]
@@ -517,23 +605,30 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         }
         __syncthreads();
     }
+    BPROF(8)
+#ifdef CIMPC_BANDED_PROF
+    if (b == 0 && (tid == 0 || tid == 256)) for (int j = 0; j < 12; ++j) ((long long*)S.stats)[8 + (tid == 0 ? 0 : 12) + j] = bp[j];
+#endif
     if (K.finish) {
         __threadfence_block();
         start_line_search<BlockSync>(S, b, 1, tid, nt);
     }
 }
 
-static size_t banded_lds_bytes(int w) {      // window (w + 4 slots + dummy)^2, right-hand side, 4 multiplier rows, pivots
-    const size_t MS = (size_t)w + 4 + 1;
-    return (MS * MS + MS + 4 * MS + 8) * sizeof(double);
+static size_t banded_lds_bytes(int w, int rb = 4) {      // window (w + rb slots + dummy)^2, right-hand side, rb multiplier rows, pivots
+    const size_t MS = (size_t)w + rb + 1;
+    return (MS * MS + MS + (size_t)rb * MS + 8) * sizeof(double);
 }
 static int band_halfwidth(const NewtonDev& S) {      // (the kernel's own formula: reduced form when the controls are eliminated)
     if (S.band_reduce != 0 && S.dm.nu > 0) { const int s = S.dm.nq + S.nd; return std::min(3 * s - 1, S.dm.H * s - 1); }
     const int s = S.nr + S.nd;
     return std::min(3 * s - 1 - S.dm.nu, S.N - 1);
 }
+static int banded_rb(const NewtonDev& S) {      // pivots per window update: 8 where that window fits
+    return banded_lds_bytes(band_halfwidth(S), 8) <= 156 * 1024 ? 8 : 4;
+}
 static size_t banded_lds_bytes(const NewtonDev& S) {      // ... and, before the window is in use, T = du1 R^-1 of every step ([H][nd x nu])
-    const size_t win = banded_lds_bytes(band_halfwidth(S));
+    const size_t win = banded_lds_bytes(band_halfwidth(S), banded_rb(S));
     const size_t pre = (S.band_reduce != 0 && S.dm.nu > 0) ? (size_t)S.dm.H * S.nd * S.dm.nu * sizeof(double) : 0;
     return std::max(win, pre);
 }
@@ -551,8 +646,14 @@ static int launch_kkt_dense(const NewtonDev& S, const KktArgs& K, double* ws, hi
     if (banded) {
         const size_t lds = banded_lds_bytes(S);
         static LdsOptIn optin;
-        if (lds_opt_in(optin, (const void*)kkt_banded_kernel, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
-        hipLaunchKernelGGL(kkt_banded_kernel, dim3(S.nb_launch), dim3(CIMPC_BANDED_THREADS), lds, s, S, K, ws);
+        if (banded_rb(S) == 8) {
+            static LdsOptIn optin8;
+            if (lds_opt_in(optin8, (const void*)kkt_banded_kernel<8>, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
+            hipLaunchKernelGGL(kkt_banded_kernel<8>, dim3(S.nb_launch), dim3(CIMPC_BANDED_THREADS), lds, s, S, K, ws);
+            return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+        }
+        if (lds_opt_in(optin, (const void*)kkt_banded_kernel<4>, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
+        hipLaunchKernelGGL(kkt_banded_kernel<4>, dim3(S.nb_launch), dim3(CIMPC_BANDED_THREADS), lds, s, S, K, ws);
         return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
     }
     hipLaunchKernelGGL(kkt_dense_kernel, dim3(S.nb_launch), dim3(256), 0, s, S, K, ws);
