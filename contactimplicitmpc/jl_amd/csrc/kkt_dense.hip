@@ -265,8 +265,8 @@ __host__ __device__ inline size_t banded_ws_per_rollout(const NewtonDev& S) {
 }
 
 // -DCIMPC_BANDED_PROF (diagnostic builds, with -DCIMPC_KKT_PROF for the accessor): shader-clock accounting of the banded kernel, rollout 0,
-// wavefront 0 -> NewtonDev::stats[8..]: [0] pre-pass  [1] panel  [2] fetch of the entering rows  [3] barrier A  [4] commit  [5] update
-// [6] barrier B  [7] back substitution  [8] control recovery; wavefront 4 -> stats[20..]: [0] time before barrier A  [1] update  [2] barrier B
+// wavefront 0 -> NewtonDev::stats[8..]: [0] pre-pass + window fill  [1] P1 diagonal block  [2] fetch issue + barrier  [3] P2 rows  [4] barrier
+// [5] stores + commit  [6] update  [7] barrier  [8] back substitution  [9] control recovery; wavefront 4 -> stats[20..], same slots
 #ifdef CIMPC_BANDED_PROF
 #define BPROF(j) { const long long tn_ = clock64(); bp[j] += tn_ - bt; bt = tn_; }
 #else
@@ -304,6 +304,9 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     double* yw = W + (size_t)MS * MS;                            // [M]   right-hand side of the rows in the window
     double* PL = yw + MS;                                        // [RB][M+1] multipliers of the block's pivots, by row SLOT
     double* dv = PL + (size_t)RB * MS;                           // [RB]  the block's pivots d
+    double* dinv = dv + RB;                                      // [RB]  their reciprocals
+    double* ypv = dinv + RB;                                     // [RB]  the pivot rows' right-hand sides (after the forward substitution among them)
+    double* L11 = ypv + RB;                                      // [RB][RB] multipliers among the block's pivot rows (row-major, strictly lower)
     const double beta = K.beta ? K.beta[b] : K.beta_scalar;
     const double rho = (double)H * beta * S.kappa;               // newton_jacobian.jl:169-186 quirk
     const double* dzb = kkt_dz(S, K, b, H, S.nths, nd);
@@ -354,236 +357,253 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         const int t = i / s, k = i - t * s;
         return k < nq ? v : v - gv[t * nd + (k - nq)];
     };
-    // row i enters the window (columns i-w .. i): a row has at most w + 1 <= 192 entries - one per thread; the
-    // values are FETCHED one block ahead (global loads of the sensitivities / weights stay off the critical path)
-    // (round 4: the entering rows belong to the threads FROM 128 ON - wavefront 0 runs the panel of a block on its own meanwhile)
-    const int rt = (int)nt >= 128 + w + 2 ? tid - 128 : tid;      // row-entry index of this thread (negative: none)
-    const bool fast_panel = rt != tid && M <= 128;                 // one wavefront holds the window's rows two per lane
-    auto row_value = [&](int i) -> double {
-        if (i >= N || rt < 0) return 0.0;
-        if (rt <= w) { const int j = i - w + rt; return j >= 0 ? row(i, j) : 0.0; }
-        return rt == w + 1 ? rhs(i) : 0.0;                       // entry w + 1 carries the right-hand side
+    // A row entering the window has w + 2 entries: columns i-w .. i and the right-hand side.  Only the LOWER triangle of the window is
+    // kept (row >= column: nothing ever reads the other one).  The entries of the RB rows that enter per block belong to the threads from
+    // 128 on, at most NE each, and are FETCHED one block ahead (global loads of the sensitivities / weights stay off the critical path).
+    constexpr int NE = 2;
+    const int EW = w + 2;
+    auto entry_value = [&](int i, int e) -> double {
+        if (i >= N) return 0.0;
+        if (e <= w) { const int j = i - w + e; return j >= 0 ? row(i, j) : 0.0; }
+        return rhs(i);
     };
-    auto row_commit = [&](int i, double v) {
-        if (i >= N || rt < 0) return;
+    auto entry_commit = [&](int i, int e, double v) {
+        if (i >= N) return;
         const int si = i % M;
-        if (rt <= w) {
-            const int j = i - w + rt;
-            if (j >= 0) { const int sj = j % M; W[(size_t)si * MS + sj] = v; W[(size_t)sj * MS + si] = v; }   // and its mirror image
-        } else if (rt == w + 1) yw[si] = v;
+        if (e <= w) { const int j = i - w + e; if (j >= 0) W[(size_t)si * MS + j % M] = v; }
+        else yw[si] = v;
     };
-    for (int i = 0; i < M && i < N; ++i) row_commit(i, row_value(i));
+    {
+        const int n0 = min(M, N) * EW;                           // the first M rows, all threads
+        for (int idx = tid; idx < n0; idx += nt) { const int i = idx / EW, e = idx - i * EW; entry_commit(i, e, entry_value(i, e)); }
+    }
     for (int e = tid; e < RB * MS; e += nt) PL[e] = 0.0;
-    __syncthreads();
-    const int tx = tid & 63, ty = tid >> 6, nty = nt >> 6;       // update: column tx + 64 q of row ty + nty p (relative to k + RB)
-    double nxt[RB];
+    int ent_t[NE], ent_e[NE];                                    // (row of the block, entry) of this thread's entering entries; -1: none
 #pragma unroll
-    for (int t = 0; t < RB; ++t) nxt[t] = row_value(M + t);      // rows entering after the first block
+    for (int n = 0; n < NE; ++n) {
+        const int idx = tid - 128 + n * ((int)nt - 128);
+        const bool on = tid >= 128 && idx < RB * EW;
+        ent_t[n] = on ? idx / EW : -1;
+        ent_e[n] = on ? idx - (idx / EW) * EW : 0;
+    }
+    double nxt[NE];
+#pragma unroll
+    for (int n = 0; n < NE; ++n) nxt[n] = ent_t[n] >= 0 ? entry_value(M + ent_t[n], ent_e[n]) : 0.0;      // rows entering after the first block
+    __syncthreads();
+    const int tx = tid & 63, ty = tid >> 6, nty = nt >> 6;
+    auto rl = [](double v, int lane) {                           // v of another lane of the wavefront (lane: uniform)
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+        return __hiloint2double(hi, lo);
+    };
+    // Round 4 (second pass): a block of RB pivots is
+    //   P1  wavefront 0: the RB x RB diagonal block - pivots, their reciprocals, the multipliers among the pivot rows, the forward
+    //       substitution among them (lane r owns pivot row r; hand-overs by v_readlane) - the only sequential part;
+    //   P2  one thread per row below the block: its RB multipliers (a triangular solve against the diagonal block, read from LDS as
+    //       broadcasts) and its right-hand-side update - the rows are independent of each other;
+    //   P3  all threads: the multipliers go to global memory (eight lanes write one row's 64 contiguous bytes), the entering rows are
+    //       committed, and the trailing window gets its rank-RB update: two rows per lane, four columns per wavefront pass, the column
+    //       multipliers read as LDS broadcasts, lower triangle only.
+    // Every entry still receives the same operations in the same order as in the one-pivot-at-a-time form (the factors are bit-identical
+    // to round 3's); what changed is who computes them and how often the workgroup meets: three LDS-only barriers per block.
+    // Before (profiles/r04/banded_prof_rb8_regpanel.log): 42 k cycles per block - the panel of all 115 rows on one wavefront 12.5 k,
+    // its scattered 8-byte stores draining at the next barrier 7.8 k, an LDS-bound update (both triangles, 9-16 LDS reads per entry) 15 k.
     for (int k = 0; k < N; k += RB) {
         const int nb_ = min(RB, N - k);                          // pivots of this block
-        // ---- panel: the block's pivots one after the other, each column first brought up to date with the
-        //      earlier pivots of the block (left-looking inside the panel) ------------------------------------
-        // Round 4: ONE wavefront runs the whole panel (two rows of the window per lane, hand-overs between the steps inside the
-        // wavefront - LDS operations of a wavefront execute in order) while the others fetch the entering rows; the workgroup meets
-        // once per block before the update instead of once per pivot (the per-pivot cost was 2.2 us, most of it four 16-wave
-        // barriers per block with two of the sixteen waves working).  Same arithmetic per entry.
-        if (fast_panel) {
-            if (tid < 64) {
-                // rows of the window by their offset q from the block's first pivot: lane tid owns q = tid and tid + 64 for the whole
-                // block, so its entries in the block's pivot columns, its multipliers and its right-hand-side entries stay in
-                // REGISTERS through the RB steps; what a step needs of another row (the pivot row's multipliers and right-hand side,
-                // the pivot itself) comes by v_readlane from the lane that owns it - no LDS round trip inside the panel.
-                auto rl = [](double v, int lane) {
-                    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-                    return __hiloint2double(hi, lo);
-                };
-                int sq[2]; bool vq[2];
-                double a[2][RB], l[2][RB], yr[2], dvr[RB];
+        if (tid < 64) {                                          // ---- P1
+            const int r = tid;
+            const bool vr = r < nb_;
+            const int sr = vr ? (k + r) % M : 0;
+            double a[RB], l[RB], dvr[RB];
+            double yr = vr ? yw[sr] : 0.0;
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const int q = tid + 64 * hh;
-                    vq[hh] = q < M;
-                    sq[hh] = vq[hh] ? (k + q) % M : 0;
-                    yr[hh] = vq[hh] ? yw[sq[hh]] : 0.0;
+            for (int t = 0; t < RB; ++t) { a[t] = (vr && t <= r && t < nb_) ? W[(size_t)sr * MS + (k + t) % M] : 0.0; l[t] = 0.0; }
 #pragma unroll
-                    for (int t = 0; t < RB; ++t) { a[hh][t] = (vq[hh] && t < nb_) ? W[(size_t)sq[hh] * MS + (k + t) % M] : 0.0; l[hh][t] = 0.0; }
+            for (int t = 0; t < RB; ++t) {
+                dvr[t] = 0.0;
+                if (t < nb_) {
+                    const int p = k + t;
+#pragma unroll
+                    for (int u = 0; u < t; ++u) {                // left-looking: bring column t up to date with the block's earlier pivots
+                        const double lp = rl(l[u], t), c = dvr[u];
+                        a[t] = fma(-l[u] * c, lp, a[t]);
+                    }
+                    const double d = rl(a[t], t), inv = 1.0 / d, yp = rl(yr, t);
+                    dvr[t] = d;
+                    const bool coupled = vr && r > t;            // (r - t < RB <= w whenever a row r exists)
+                    const double lv = coupled ? a[t] * inv : 0.0;
+                    l[t] = lv;
+                    if (coupled) {
+                        Lr[(size_t)(k + r) * LW + (w - (r - t))] = lv;
+                        yr = fma(-lv, yp, yr);                   // forward substitution rides along
+                    }
+                    if (r < RB) L11[r * RB + t] = lv;
+                    if (tid == t) { yg[p] = yp; Lr[(size_t)p * LW + w] = inv; dv[t] = d; dinv[t] = inv; ypv[t] = yp; }
                 }
+            }
+        }
+        BPROF(1)
+        double nxt2[NE];                                         // rows entering after the NEXT block: loads in flight across P1 / P2
+#pragma unroll
+        for (int n = 0; n < NE; ++n) nxt2[n] = ent_t[n] >= 0 ? entry_value(k + RB + M + ent_t[n], ent_e[n]) : 0.0;
+        lds_barrier();
+        BPROF(2)
+        if (tid >= 64 && tid < 64 + w) {                         // ---- P2: row k + q, q = RB .. RB + w - 1
+            const int q = RB + tid - 64, i = k + q;
+            if (i < N) {
+                const int sr = i % M;
+                double c[RB];                                    // l_u d_u of this row
+                double yr = yw[sr];
 #pragma unroll
                 for (int t = 0; t < RB; ++t) {
-                    dvr[t] = 0.0;
+                    c[t] = 0.0;
                     if (t < nb_) {
-                        const int p = k + t, m = min(w, N - 1 - p);
+                        const bool coupled = q - t <= w;
+                        double a = coupled ? W[(size_t)sr * MS + (k + t) % M] : 0.0;
 #pragma unroll
-                        for (int u = 0; u < t; ++u) {       // left-looking: bring column t up to date with the block's earlier pivots
-                            const double lp = rl(l[0][u], t), c = dvr[u];
-#pragma unroll
-                            for (int hh = 0; hh < 2; ++hh) a[hh][t] = fma(-l[hh][u] * c, lp, a[hh][t]);
-                        }
-                        const double d = rl(a[0][t], t), inv = 1.0 / d, yp = rl(yr[0], t);
-                        dvr[t] = d;
-#pragma unroll
-                        for (int hh = 0; hh < 2; ++hh) {
-                            const int rr = tid + 64 * hh - t;
-                            const bool coupled = vq[hh] && rr >= 1 && rr <= m;
-                            const double lv = coupled ? a[hh][t] * inv : 0.0;
-                            l[hh][t] = lv;
-                            if (coupled) {
-                                Lr[(size_t)(p + rr) * LW + (w - rr)] = lv;
-                                yr[hh] = fma(-lv, yp, yr[hh]);            // forward substitution rides along
-                            }
-                            if (vq[hh]) PL[(size_t)t * MS + sq[hh]] = lv;   // all M slots: zero where the pivot does not couple
-                        }
-                        if (tid == t) { yg[p] = yp; Lr[(size_t)p * LW + w] = inv; }
+                        for (int u = 0; u < t; ++u) a = fma(-c[u], L11[t * RB + u], a);
+                        const double lv = coupled ? a * dinv[t] : 0.0;
+                        if (coupled) yr = fma(-lv, ypv[t], yr);
+                        c[t] = lv * dv[t];
+                        PL[(size_t)t * MS + sr] = lv;            // zero where the pivot does not couple
                     }
                 }
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) if (vq[hh]) yw[sq[hh]] = yr[hh];
-                if (tid == 0) {
-#pragma unroll
-                    for (int t = 0; t < RB; ++t) dv[t] = dvr[t];
-                }
+                yw[sr] = yr;
             }
-        } else
-        for (int t = 0; t < nb_; ++t) {
-            const int p = k + t, sp = p % M, m = min(w, N - 1 - p);
-            if (tid < M) {
-                int sr = sp + tid; if (sr >= M) sr -= M;         // slot of row p + tid
-                double v = 0.0;
-                if (tid <= m) {
-                    v = W[(size_t)sr * MS + sp];
-                    for (int u = 0; u < t; ++u) v = fma(-PL[(size_t)u * MS + sr] * dv[u], PL[(size_t)u * MS + sp], v);
-                }
-                // every thread needs the updated pivot: recompute it (row p itself: sr = sp)
-                double d = W[(size_t)sp * MS + sp];
-                for (int u = 0; u < t; ++u) d = fma(-PL[(size_t)u * MS + sp] * dv[u], PL[(size_t)u * MS + sp], d);
-                const double inv = 1.0 / d, yp = yw[sp];
-                const double l = (tid >= 1 && tid <= m) ? v * inv : 0.0;
-                // (this phase only writes PL[t], dv[t], yw of the coupled rows: nothing another thread reads here)
-                if (tid >= 1 && tid <= m) {
-                    Lr[(size_t)(p + tid) * LW + (w - tid)] = l;
-                    yw[sr] = fma(-l, yp, yw[sr]);                // forward substitution rides along
-                }
-                if (tid == 0) { dv[t] = d; yg[p] = yp; Lr[(size_t)p * LW + w] = inv; }
-                PL[(size_t)t * MS + sr] = l;                     // all M slots: zero where the pivot does not couple
-            }
-            lds_barrier();
         }
-        // ---- rows entering the window: fetch for the NEXT block, commit this block's (their slots - the
-        //      pivots' - are not touched by the update below) -------------------------------------------------
-        BPROF(1)
-        double nxt2[RB];
-#pragma unroll
-        for (int t = 0; t < RB; ++t) nxt2[t] = row_value(k + M + RB + t);
-        BPROF(2)
-        if (fast_panel) lds_barrier();        // the panel's multipliers / pivots are in place; the pivots' slots may be overwritten now
         BPROF(3)
-#pragma unroll
-        for (int t = 0; t < RB; ++t) { if (t < nb_) row_commit(k + M + t, nxt[t]); nxt[t] = nxt2[t]; }
+        lds_barrier();              // the block's multipliers / pivots are in place; the pivots' slots may be overwritten now
         BPROF(4)
-        // ---- rank-nb_ update of the trailing window, rows / columns k+RB .. k+RB-1+w --------------------------
-        {
-            const int base = k + nb_, mt = min(w, N - base);     // mt rows / columns present
-            if (mt > 0) {
-                int sb = base % M;
-                double dd[RB];
+        // ---- P3 -------------------------------------------------------------------------------------------------------------------
+        for (int idx = tid; idx < w * RB; idx += nt) {           // multipliers -> rows of L in global memory, t fastest
+            const int q = RB + idx / RB, t = idx - (idx / RB) * RB, i = k + q;
+            if (i < N && t < nb_ && q - t <= w) Lr[(size_t)i * LW + (w - (q - t))] = PL[(size_t)t * MS + i % M];
+        }
 #pragma unroll
-                for (int t = 0; t < RB; ++t) dd[t] = t < nb_ ? dv[t] : 0.0;
-                const int nqf = mt >> 6, tail = mt - (nqf << 6);
-                double lj[2][RB];
-                int sjv[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    int sj = sb + tx + 64 * q; if (sj >= M) sj -= M; if (sj >= M) sj -= M;
-                    sjv[q] = q < nqf ? sj : M;
-#pragma unroll
-                    for (int t = 0; t < RB; ++t) lj[q][t] = (q < nqf && t < nb_) ? PL[(size_t)t * MS + sj] : 0.0;
-                }
-                if (nqf > 0) {
-                    for (int r0 = ty; r0 < mt; r0 += 3 * nty) {
-                        double t_[3][2], li[3][RB];
-                        double* Wi[3];
-#pragma unroll
-                        for (int u = 0; u < 3; ++u) {
-                            const int r = r0 + nty * u;
-                            const bool on = r < mt;
-                            int si = sb + (on ? r : 0); if (si >= M) si -= M; if (si >= M) si -= M;
-#pragma unroll
-                            for (int t = 0; t < RB; ++t) li[u][t] = on ? PL[(size_t)t * MS + si] * dd[t] : 0.0;
-                            Wi[u] = W + (size_t)(on ? si : M) * MS;
-#pragma unroll
-                            for (int q = 0; q < 2; ++q) if (q < nqf) t_[u][q] = Wi[u][sjv[q]];
-                        }
-#pragma unroll
-                        for (int u = 0; u < 3; ++u)
-#pragma unroll
-                            for (int q = 0; q < 2; ++q) if (q < nqf) {
-                                double acc = t_[u][q];
-#pragma unroll
-                                for (int t = 0; t < RB; ++t) acc = fma(-li[u][t], lj[q][t], acc);
-                                Wi[u][sjv[q]] = acc;
-                            }
-                    }
-                }
-                for (int e = tid; e < mt * tail; e += nt) {      // tail columns: one entry per thread over all rows
-                    const int rr = e / tail, c = (nqf << 6) + (e - rr * tail);
-                    int si = sb + rr; if (si >= M) si -= M; if (si >= M) si -= M;
-                    int sj = sb + c; if (sj >= M) sj -= M; if (sj >= M) sj -= M;
-                    double* cell = W + (size_t)si * MS + sj;
-                    double acc = *cell;
-#pragma unroll
-                    for (int t = 0; t < RB; ++t) acc = fma(-PL[(size_t)t * MS + si] * dd[t], PL[(size_t)t * MS + sj], acc);
-                    *cell = acc;
-                }
-            }
+        for (int n = 0; n < NE; ++n) {
+            if (ent_t[n] >= 0 && ent_t[n] < nb_) entry_commit(k + M + ent_t[n], ent_e[n], nxt[n]);
+            nxt[n] = nxt2[n];
         }
         BPROF(5)
-        lds_barrier();
-        BPROF(6)
-    }
-    __syncthreads();              // full barrier: the rows of L and y in global memory are read back below
-    // ---- back substitution  L^T x = D^-1 y  (wavefront 0; acc[j] collects sum_{i > j} L[i][j] x_i) ---------
-    double* D = K.delta + (size_t)b * S.N;
-    if (tid < 64) {
-        double* acc = yw;                                        // reuse: [M]
-        for (int c = tid; c < M; c += 64) acc[c] = 0.0;
-        __builtin_amdgcn_wave_barrier();
-        // the rows of L come from global memory: a ring of PD rows in flight (one wavefront, nothing else to hide the latency)
-        constexpr int PD = 16;
-        double pre[PD][3], pre_y[PD];
-        auto fetch = [&](int i, int slot) {
+        {
+            const int base = k + nb_, mt = min(w, N - base);     // mt rows / columns of the trailing window present
+            if (mt > 0) {
+                const int sb = base % M;
+                double li[2][RB];                                // -(l d) of this lane's two rows, for the whole pass
+                int si[2];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) { const int c = tid + 64 * q; pre[slot][q] = (i >= 0 && c <= w) ? Lr[(size_t)i * LW + c] : 0.0; }
-            pre_y[slot] = i >= 0 ? yg[i] : 0.0;
-        };
+                for (int u = 0; u < 2; ++u) {
+                    const int rr = tx + 64 * u;
+                    const bool on = rr < mt;
+                    int s_ = sb + (on ? rr : 0); if (s_ >= M) s_ -= M; if (s_ >= M) s_ -= M;
+                    si[u] = s_;
 #pragma unroll
-        for (int u = 0; u < PD; ++u) fetch(N - 1 - u, u);
-        for (int i0 = N - 1; i0 >= 0; i0 -= PD) {
+                    for (int t = 0; t < RB; ++t) li[u][t] = (on && t < nb_) ? -(PL[(size_t)t * MS + s_] * dv[t]) : 0.0;
+                }
+                const int ncg = (mt + 3) >> 2;
+                for (int cg = ty; cg < ncg; cg += nty) {
+                    const int c0 = cg << 2;
+                    int sj[4];
 #pragma unroll
-            for (int u = 0; u < PD; ++u) {
-                const int i = i0 - u;
-                const double cur[3] = {pre[u][0], pre[u][1], pre[u][2]}, yi = pre_y[u];
-                fetch(i - PD, u);
-                if (i < 0) continue;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                const int si = i % M;
-                // 1 / d_i sits at c = w: lane (w % 64), register (w / 64)
-                double di = 0.0;
+                    for (int v = 0; v < 4; ++v) {
+                        int s_ = sb + min(c0 + v, mt - 1); if (s_ >= M) s_ -= M; if (s_ >= M) s_ -= M;
+                        sj[v] = s_;
+                    }
+                    const bool lo_rows = c0 < 64;                // rows 0 .. 63 reach the diagonal only in the first sixteen column groups
+                    double acc[2][4];
+                    bool need[2];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) if (w / 64 == q) di = __shfl(cur[q], w % 64, 64);
-                const double xi = yi * di - acc[si];               // di = 1 / d_i
-                __builtin_amdgcn_wave_barrier();
-                if (tid == 0) { acc[si] = 0.0; D[orig(i)] = xi; }
+                    for (int u = 0; u < 2; ++u) {
+                        const int rr = tx + 64 * u;
+                        need[u] = rr < mt && rr >= c0 && (u == 1 || lo_rows);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const int c = tid + 64 * q, j = i - w + c;
-                    if (c < w && j >= 0) acc[j % M] = fma(cur[q], xi, acc[j % M]);
+                        for (int v = 0; v < 4; ++v) acc[u][v] = need[u] ? W[(size_t)si[u] * MS + sj[v]] : 0.0;
+                    }
+#pragma unroll
+                    for (int t = 0; t < RB; ++t) {
+                        double lj[4];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) lj[v] = PL[(size_t)t * MS + sj[v]];
+                        if (lo_rows) {
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) acc[0][v] = fma(li[0][t], lj[v], acc[0][v]);
+                        }
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) acc[1][v] = fma(li[1][t], lj[v], acc[1][v]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) if (need[u] && c0 + v < mt) W[(size_t)si[u] * MS + sj[v]] = acc[u][v];
                 }
             }
         }
+        BPROF(6)
+        lds_barrier();
+        BPROF(7)
     }
-    __syncthreads();
-    BPROF(7)
+    __syncthreads();              // full barrier: the rows of L and y in global memory are read back below
+    // ---- back substitution  L^T x = D^-1 y.  acc_j = sum_{i > j} L[i][j] x_i is built row by row (i descending); round 4: the pending
+    //      acc_j live in REGISTERS of wavefront 0 (column j belongs to lane (j + 192) % 64, register ((j + 192) / 64) % 3 - a band of
+    //      w < 192 columns never holds two columns of one lane in one register), x_i needs one v_readlane, and the rows of L come
+    //      through LDS in chunks of CR rows that the other fifteen wavefronts copy one chunk ahead (a contiguous piece of global memory).
+    //      Before: 3.6 k cycles per row - an LDS read-modify-write chain on acc and global-load latency behind a 16-row register ring.
+    double* D = K.delta + (size_t)b * S.N;
+    {
+        const int avail = MS * MS + MS + RB * MS + 3 * RB + RB * RB;      // doubles of LDS the window held
+        int CR = avail / (2 * (LW + 1)); if (CR > 64) CR = 64;
+        const int nch = (N + CR - 1) / CR, CS = CR * (LW + 1);
+        auto stage = [&](int ch, int t0, int nth) {              // chunk ch = rows N-1 - ch CR downwards -> buffer ch & 1  (threads t0 .. of nth)
+            const int i_hi = N - 1 - ch * CR, i_lo = max(i_hi - CR + 1, 0), n = i_hi - i_lo + 1, tot = n * LW;
+            double* bufp = sm + (size_t)(ch & 1) * CS;
+            const double* src = Lr + (size_t)i_lo * LW;
+            for (int e0 = t0; e0 < tot; e0 += 8 * nth) {
+                double tmp[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int e = e0 + u * nth; tmp[u] = e < tot ? src[e] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int e = e0 + u * nth; if (e < tot) bufp[e] = tmp[u]; }
+            }
+            for (int e = t0; e < n; e += nth) bufp[CR * LW + e] = yg[i_lo + e];
+        };
+        stage(0, tid, nt);
+        __syncthreads();
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+        for (int ch = 0; ch < nch; ++ch) {
+            if (tid >= 64) { if (ch + 1 < nch) stage(ch + 1, tid - 64, (int)nt - 64); }
+            else {
+                const int i_hi = N - 1 - ch * CR, i_lo = max(i_hi - CR + 1, 0);
+                const double* bufp = sm + (size_t)(ch & 1) * CS;
+                int ti = i_hi / s, ki = i_hi - ti * s;           // (step, index in the step) of row i, kept by counting
+
+                for (int i = i_hi; i >= i_lo; --i) {
+                    const double* Lrow = bufp + (size_t)(i - i_lo) * LW;
+                    const double di = Lrow[w], yi = bufp[CR * LW + (i - i_lo)];      // di = 1 / d_i
+                    const int bb = i - w + 192, blk = bb >> 6, bm = blk % 3;
+                    double Lv[3];
+#pragma unroll
+                    for (int sl = 0; sl < 3; ++sl) {
+                        int dB = sl - bm; if (dB < 0) dB += 3;
+                        int jj = 64 * (blk + dB) + tid; if (jj < bb) jj += 192;
+                        Lv[sl] = (jj >= 192 && jj < i + 192) ? Lrow[jj - bb] : 0.0;
+                    }
+                    const int ii = i + 192, ln = ii & 63, so = (ii >> 6) % 3;
+                    const double asel = so == 0 ? acc0 : (so == 1 ? acc1 : acc2);
+                    const double xi = yi * di - rl(asel, ln);
+                    if (tid == ln) { if (so == 0) acc0 = 0.0; else if (so == 1) acc1 = 0.0; else acc2 = 0.0; }
+                    acc0 = fma(Lv[0], xi, acc0); acc1 = fma(Lv[1], xi, acc1); acc2 = fma(Lv[2], xi, acc2);
+                    if (tid == 0) {
+                        int o;
+                        if (reduced) o = ki < nq ? ti * nr + nu + ki : H * nr + ti * nd + (ki - nq);
+                        else o = ki < nr ? ti * nr + ki : H * nr + ti * nd + (ki - nr);
+                        D[o] = xi;
+                    }
+                    if (--ki < 0) { ki = s - 1; --ti; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    BPROF(8)
     if (reduced) {      // Du_t = R_t^-1 (r_u,t - du1_t^T Dnu_t)
         __threadfence_block();
         double* tu = sm;                                         // [H][nu]
@@ -605,7 +625,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         }
         __syncthreads();
     }
-    BPROF(8)
+    BPROF(9)
 #ifdef CIMPC_BANDED_PROF
     if (b == 0 && (tid == 0 || tid == 256)) for (int j = 0; j < 12; ++j) ((long long*)S.stats)[8 + (tid == 0 ? 0 : 12) + j] = bp[j];
 #endif
@@ -615,9 +635,9 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     }
 }
 
-static size_t banded_lds_bytes(int w, int rb = 4) {      // window (w + rb slots + dummy)^2, right-hand side, rb multiplier rows, pivots
+static size_t banded_lds_bytes(int w, int rb = 4) {      // window (w + rb slots + dummy)^2, right-hand side, rb multiplier rows, pivots / reciprocals / rhs, diagonal block
     const size_t MS = (size_t)w + rb + 1;
-    return (MS * MS + MS + (size_t)rb * MS + 8) * sizeof(double);
+    return (MS * MS + MS + (size_t)rb * MS + 3 * (size_t)rb + (size_t)rb * rb) * sizeof(double);
 }
 static int band_halfwidth(const NewtonDev& S) {      // (the kernel's own formula: reduced form when the controls are eliminated)
     if (S.band_reduce != 0 && S.dm.nu > 0) { const int s = S.dm.nq + S.nd; return std::min(3 * s - 1, S.dm.H * s - 1); }

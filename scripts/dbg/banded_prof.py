@@ -25,10 +25,11 @@ lib.cimpc_debug_read_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_
 out = (C.c_longlong * 32)()
 lib.cimpc_debug_read_stats(s.h, out, 32)
 v = np.array(list(out), dtype=np.float64)
-names0 = ["pre-pass", "panel", "fetch entering rows", "barrier A", "commit", "update", "barrier B", "back substitution", "control recovery"]
-tot = v[8:17].sum()
+names0 = ["pre-pass + fill", "P1 diagonal block", "fetch issue + barrier", "P2 rows", "barrier", "stores + commit", "update", "barrier",
+          "back substitution", "control recovery"]
+tot = v[8:18].sum()
 print("wavefront 0 (k-cycles, share):")
-for n, x in zip(names0, v[8:17]):
+for n, x in zip(names0, v[8:18]):
     print("  %-22s %9.1f  %5.1f %%" % (n, x / 1e3, 100 * x / tot))
 print("  total %.1f k-cycles" % (tot / 1e3))
-print("wavefront 4 (k-cycles):", dict(zip(names0, np.round(v[20:29] / 1e3, 1))))
+print("wavefront 4 (k-cycles):", dict(zip(names0, np.round(v[20:30] / 1e3, 1))))
