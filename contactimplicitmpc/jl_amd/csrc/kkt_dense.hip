@@ -395,49 +395,43 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
         return __hiloint2double(hi, lo);
     };
+    auto wrap = [&](int x) { if (x >= M) x -= M; if (x >= M) x -= M; return x; };      // slot of an index < 3 M past a slot
     // Round 4 (second pass): a block of RB pivots is
-    //   P1  wavefront 0: the RB x RB diagonal block - pivots, their reciprocals, the multipliers among the pivot rows, the forward
-    //       substitution among them (lane r owns pivot row r; hand-overs by v_readlane) - the only sequential part;
-    //   P2  one thread per row below the block: its RB multipliers (a triangular solve against the diagonal block, read from LDS as
-    //       broadcasts) and its right-hand-side update - the rows are independent of each other;
-    //   P3  all threads: the multipliers go to global memory (eight lanes write one row's 64 contiguous bytes), the entering rows are
-    //       committed, and the trailing window gets its rank-RB update: two rows per lane, four columns per wavefront pass, the column
-    //       multipliers read as LDS broadcasts, lower triangle only.
-    // Every entry still receives the same operations in the same order as in the one-pivot-at-a-time form (the factors are bit-identical
-    // to round 3's); what changed is who computes them and how often the workgroup meets: three LDS-only barriers per block.
-    // Before (profiles/r04/banded_prof_rb8_regpanel.log): 42 k cycles per block - the panel of all 115 rows on one wavefront 12.5 k,
-    // its scattered 8-byte stores draining at the next barrier 7.8 k, an LDS-bound update (both triangles, 9-16 LDS reads per entry) 15 k.
+    //   P1  lanes 0 .. RB-1 of wavefront 0: the RB x RB diagonal block - pivots, reciprocals, the multipliers among the pivot rows, the
+    //       forward substitution among them (lane r owns pivot row r, right-looking, hand-overs by v_readlane, no branches, no global
+    //       stores) - the only sequential part;
+    //   P2  RB lanes per row below the block (lane t owns the row's entry in pivot column t): the triangular solve against the diagonal
+    //       block runs ACROSS the lanes - per pivot u two multiplies, a DPP row broadcast of l_u d_u and one multiply-add;
+    //   P3  all threads: the multipliers go to global memory (RB lanes write one row's contiguous piece), the right-hand side of the rows
+    //       below is updated, the entering rows are committed, and the lower triangle of the trailing window gets its rank-RB update
+    //       as 16 x 16 tiles on v_mfma_f64_16x16x4 (A = -(l d) of the tile's rows, B = l of its columns, K = RB).
+    // P1 / P2 apply the same operations to every entry in the same order as the one-pivot-at-a-time form.  Three LDS-only barriers per block.
+    // History (cycles per block of 8 pivots, w = 107): round-4 first form 42 k (banded_prof_rb8_regpanel.log) - the panel of all 115 rows on
+    // one wavefront 12.5 k, its scattered 8-byte stores draining at the next barrier 7.8 k, an LDS-bound update of both triangles 15 k;
+    // split into P1 / P2 / P3 with a register-tiled VALU update 27 k (banded_prof_split.log: P1 10.5 k - integer divisions for the slots,
+    // a branch per predicate -, P2 3.5 k, update 7.6 k).
+    int sk = 0;                                                  // k % M, kept by counting
     for (int k = 0; k < N; k += RB) {
         const int nb_ = min(RB, N - k);                          // pivots of this block
-        if (tid < 64) {                                          // ---- P1
+        if (tid < RB) {                                          // ---- P1
             const int r = tid;
             const bool vr = r < nb_;
-            const int sr = vr ? (k + r) % M : 0;
-            double a[RB], l[RB], dvr[RB];
+            const int sr = wrap(sk + r);
+            double a[RB];
             double yr = vr ? yw[sr] : 0.0;
 #pragma unroll
-            for (int t = 0; t < RB; ++t) { a[t] = (vr && t <= r && t < nb_) ? W[(size_t)sr * MS + (k + t) % M] : 0.0; l[t] = 0.0; }
+            for (int t = 0; t < RB; ++t) a[t] = (vr && t <= r && t < nb_) ? W[(size_t)sr * MS + wrap(sk + t)] : 0.0;
 #pragma unroll
             for (int t = 0; t < RB; ++t) {
-                dvr[t] = 0.0;
                 if (t < nb_) {
-                    const int p = k + t;
-#pragma unroll
-                    for (int u = 0; u < t; ++u) {                // left-looking: bring column t up to date with the block's earlier pivots
-                        const double lp = rl(l[u], t), c = dvr[u];
-                        a[t] = fma(-l[u] * c, lp, a[t]);
-                    }
                     const double d = rl(a[t], t), inv = 1.0 / d, yp = rl(yr, t);
-                    dvr[t] = d;
-                    const bool coupled = vr && r > t;            // (r - t < RB <= w whenever a row r exists)
-                    const double lv = coupled ? a[t] * inv : 0.0;
-                    l[t] = lv;
-                    if (coupled) {
-                        Lr[(size_t)(k + r) * LW + (w - (r - t))] = lv;
-                        yr = fma(-lv, yp, yr);                   // forward substitution rides along
-                    }
-                    if (r < RB) L11[r * RB + t] = lv;
-                    if (tid == t) { yg[p] = yp; Lr[(size_t)p * LW + w] = inv; dv[t] = d; dinv[t] = inv; ypv[t] = yp; }
+                    const double lv = r > t ? a[t] * inv : 0.0;  // (rows past the end carry zeros)
+                    yr = fma(-lv, yp, yr);                       // forward substitution rides along
+                    const double c = lv * d;
+#pragma unroll
+                    for (int t2 = t + 1; t2 < RB; ++t2) a[t2] = fma(-c, rl(lv, t2), a[t2]);      // right-looking inside the block
+                    L11[r * RB + t] = lv;
+                    dv[t] = d; dinv[t] = inv; ypv[t] = yp;       // (the same value from every lane)
                 }
             }
         }
@@ -447,105 +441,103 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         for (int n = 0; n < NE; ++n) nxt2[n] = ent_t[n] >= 0 ? entry_value(k + RB + M + ent_t[n], ent_e[n]) : 0.0;
         lds_barrier();
         BPROF(2)
-        if (tid >= 64 && tid < 64 + w) {                         // ---- P2: row k + q, q = RB .. RB + w - 1
-            const int q = RB + tid - 64, i = k + q;
-            if (i < N) {
-                const int sr = i % M;
-                double c[RB];                                    // l_u d_u of this row
-                double yr = yw[sr];
+        {                                                        // ---- P2: row k + q, q = RB .. RB + w - 1, entry t
+            constexpr int NG = 16 / RB;                          // rows per DPP row of 16 lanes
+            const int l16 = tx & 15, g = l16 / RB, t = l16 - g * RB;
+            const int q = RB + (tid >> 4) * NG + g, i = k + q;
+            const bool on = q < RB + w && i < N && t < nb_;
+            const int sr = wrap(sk + q);
+            double a = (on && q - t <= w) ? W[(size_t)sr * MS + wrap(sk + t)] : 0.0;
+            const double inv = dinv[t], d = dv[t];
+            double lm[RB];                                       // the pivot row t's multipliers for the earlier pivots
 #pragma unroll
-                for (int t = 0; t < RB; ++t) {
-                    c[t] = 0.0;
-                    if (t < nb_) {
-                        const bool coupled = q - t <= w;
-                        double a = coupled ? W[(size_t)sr * MS + (k + t) % M] : 0.0;
-#pragma unroll
-                        for (int u = 0; u < t; ++u) a = fma(-c[u], L11[t * RB + u], a);
-                        const double lv = coupled ? a * dinv[t] : 0.0;
-                        if (coupled) yr = fma(-lv, ypv[t], yr);
-                        c[t] = lv * dv[t];
-                        PL[(size_t)t * MS + sr] = lv;            // zero where the pivot does not couple
-                    }
-                }
-                yw[sr] = yr;
-            }
+            for (int u = 0; u < RB; ++u) lm[u] = u < t ? L11[t * RB + u] : 0.0;
+            static_for<0, RB - 1>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                const double c = (a * inv) * d;                  // final in lane u of the row
+                double cb = 0.0;
+                static_for<0, NG>([&](auto Gq) {
+                    constexpr int g2 = decltype(Gq)::value;
+                    const double v = __builtin_amdgcn_update_dpp(0.0, c, 0x150 + g2 * RB + u, 0xF, 0xF, true);      // row_newbcast
+                    cb = g == g2 ? v : cb;
+                });
+                a = fma(-cb, lm[u], a);
+            });
+            if (on) PL[(size_t)t * MS + sr] = a * inv;           // zero where the pivot does not couple
         }
         BPROF(3)
         lds_barrier();              // the block's multipliers / pivots are in place; the pivots' slots may be overwritten now
         BPROF(4)
         // ---- P3 -------------------------------------------------------------------------------------------------------------------
-        for (int idx = tid; idx < w * RB; idx += nt) {           // multipliers -> rows of L in global memory, t fastest
-            const int q = RB + idx / RB, t = idx - (idx / RB) * RB, i = k + q;
-            if (i < N && t < nb_ && q - t <= w) Lr[(size_t)i * LW + (w - (q - t))] = PL[(size_t)t * MS + i % M];
+        for (int idx = tid; idx < (RB - 1 + w) * RB; idx += nt) {       // multipliers -> rows of L in global memory, t fastest
+            const int q = 1 + idx / RB, t = idx - (idx / RB) * RB, i = k + q;
+            if (i < N && t < nb_ && t < q && q - t <= w)
+                Lr[(size_t)i * LW + (w - (q - t))] = q < RB ? L11[q * RB + t] : PL[(size_t)t * MS + wrap(sk + q)];
+        }
+        if (tid < nb_) { yg[k + tid] = ypv[tid]; Lr[(size_t)(k + tid) * LW + w] = dinv[tid]; }
+        if (tid >= 64 && tid < 64 + w && k + RB + tid - 64 < N) {       // right-hand side of the rows below the block
+            const int sr = wrap(sk + RB + tid - 64);
+            double yr = yw[sr];
+#pragma unroll
+            for (int t = 0; t < RB; ++t) if (t < nb_) yr = fma(-PL[(size_t)t * MS + sr], ypv[t], yr);
+            yw[sr] = yr;
         }
 #pragma unroll
         for (int n = 0; n < NE; ++n) {
-            if (ent_t[n] >= 0 && ent_t[n] < nb_) entry_commit(k + M + ent_t[n], ent_e[n], nxt[n]);
+            if (ent_t[n] >= 0 && ent_t[n] < nb_ && k + M + ent_t[n] < N) {       // row k + M + t: the slot of pivot k + t
+                const int si = wrap(sk + ent_t[n]);
+                if (ent_e[n] <= w) W[(size_t)si * MS + wrap(sk + RB + ent_t[n] + ent_e[n])] = nxt[n];   // column k + RB + t + e (>= 0)
+                else yw[si] = nxt[n];
+            }
             nxt[n] = nxt2[n];
         }
         BPROF(5)
         {
             const int base = k + nb_, mt = min(w, N - base);     // mt rows / columns of the trailing window present
             if (mt > 0) {
-                const int sb = base % M;
-                double li[2][RB];                                // -(l d) of this lane's two rows, for the whole pass
-                int si[2];
+                const int sb = wrap(sk + nb_);
+                const int nT = (mt + 15) >> 4, ntiles = nT * (nT + 1) / 2;
+                const int li = tx & 15, lk = tx >> 4;
+                for (int tl = ty; tl < ntiles; tl += nty) {
+                    int I = 0;
+                    while ((I + 1) * (I + 2) / 2 <= tl) ++I;     // tile (I, J), J <= I
+                    const int J = tl - I * (I + 1) / 2;
+                    const int ra = 16 * I + li, cb_ = 16 * J + li;
+                    const int sra = wrap(sb + min(ra, mt - 1)), scb = wrap(sb + min(cb_, mt - 1));
+                    d4 acc;
+                    double* cell[4];
+                    bool ok[4];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int rr = tx + 64 * u;
-                    const bool on = rr < mt;
-                    int s_ = sb + (on ? rr : 0); if (s_ >= M) s_ -= M; if (s_ >= M) s_ -= M;
-                    si[u] = s_;
-#pragma unroll
-                    for (int t = 0; t < RB; ++t) li[u][t] = (on && t < nb_) ? -(PL[(size_t)t * MS + s_] * dv[t]) : 0.0;
-                }
-                const int ncg = (mt + 3) >> 2;
-                for (int cg = ty; cg < ncg; cg += nty) {
-                    const int c0 = cg << 2;
-                    int sj[4];
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        int s_ = sb + min(c0 + v, mt - 1); if (s_ >= M) s_ -= M; if (s_ >= M) s_ -= M;
-                        sj[v] = s_;
-                    }
-                    const bool lo_rows = c0 < 64;                // rows 0 .. 63 reach the diagonal only in the first sixteen column groups
-                    double acc[2][4];
-                    bool need[2];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int rr = tx + 64 * u;
-                        need[u] = rr < mt && rr >= c0 && (u == 1 || lo_rows);
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) acc[u][v] = need[u] ? W[(size_t)si[u] * MS + sj[v]] : 0.0;
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int rw = 16 * I + lk + 4 * r4;
+                        ok[r4] = rw < mt && cb_ < mt && (I != J || rw >= cb_);      // lower triangle only
+                        cell[r4] = W + (size_t)wrap(sb + min(rw, mt - 1)) * MS + scb;
+                        acc[r4] = ok[r4] ? *cell[r4] : 0.0;
                     }
 #pragma unroll
-                    for (int t = 0; t < RB; ++t) {
-                        double lj[4];
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) lj[v] = PL[(size_t)t * MS + sj[v]];
-                        if (lo_rows) {
-#pragma unroll
-                            for (int v = 0; v < 4; ++v) acc[0][v] = fma(li[0][t], lj[v], acc[0][v]);
-                        }
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) acc[1][v] = fma(li[1][t], lj[v], acc[1][v]);
+                    for (int kb = 0; kb < RB / 4; ++kb) {
+                        const int t = 4 * kb + lk;
+                        const double av = ra < mt ? -(PL[(size_t)t * MS + sra] * dv[t]) : 0.0;
+                        const double bv = cb_ < mt ? PL[(size_t)t * MS + scb] : 0.0;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
                     }
 #pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) if (need[u] && c0 + v < mt) W[(size_t)si[u] * MS + sj[v]] = acc[u][v];
+                    for (int r4 = 0; r4 < 4; ++r4) if (ok[r4]) *cell[r4] = acc[r4];
                 }
             }
         }
         BPROF(6)
         lds_barrier();
         BPROF(7)
+        sk += RB; if (sk >= M) sk -= M;
     }
     __syncthreads();              // full barrier: the rows of L and y in global memory are read back below
     // ---- back substitution  L^T x = D^-1 y.  acc_j = sum_{i > j} L[i][j] x_i is built row by row (i descending); round 4: the pending
     //      acc_j live in REGISTERS of wavefront 0 (column j belongs to lane (j + 192) % 64, register ((j + 192) / 64) % 3 - a band of
     //      w < 192 columns never holds two columns of one lane in one register), x_i needs one v_readlane, and the rows of L come
     //      through LDS in chunks of CR rows that the other fifteen wavefronts copy one chunk ahead (a contiguous piece of global memory).
+    //      A lane follows its column of a register by counting: offset c = j - (i - w) grows by one per row; at c = w the column is the
+    //      row's own (x_j is read off, the sum restarts) and the lane moves on to column j - 192.
     //      Before: 3.6 k cycles per row - an LDS read-modify-write chain on acc and global-load latency behind a 16-row register ring.
     double* D = K.delta + (size_t)b * S.N;
     {
@@ -567,30 +559,41 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         };
         stage(0, tid, nt);
         __syncthreads();
-        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+        double acc[3] = {0.0, 0.0, 0.0};
+        int cc[3];                                               // offset c of this lane's column of register sl at the current row
+        {
+            const int bb = N - 1 - w + 192, blk = bb >> 6, bm = blk % 3;
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl) {
+                int dB = sl - bm; if (dB < 0) dB += 3;
+                int jj = 64 * (blk + dB) + tx; if (jj < bb) jj += 192;
+                cc[sl] = jj - bb; if (cc[sl] > w) cc[sl] -= 192;
+            }
+        }
         for (int ch = 0; ch < nch; ++ch) {
             if (tid >= 64) { if (ch + 1 < nch) stage(ch + 1, tid - 64, (int)nt - 64); }
             else {
                 const int i_hi = N - 1 - ch * CR, i_lo = max(i_hi - CR + 1, 0);
                 const double* bufp = sm + (size_t)(ch & 1) * CS;
                 int ti = i_hi / s, ki = i_hi - ti * s;           // (step, index in the step) of row i, kept by counting
-
-                for (int i = i_hi; i >= i_lo; --i) {
+                auto load = [&](int i, double (&Lv)[3], double& di, double& yi) {
                     const double* Lrow = bufp + (size_t)(i - i_lo) * LW;
-                    const double di = Lrow[w], yi = bufp[CR * LW + (i - i_lo)];      // di = 1 / d_i
-                    const int bb = i - w + 192, blk = bb >> 6, bm = blk % 3;
-                    double Lv[3];
+                    di = Lrow[w]; yi = bufp[CR * LW + (i - i_lo)];       // di = 1 / d_i
+                    const int lo = max(w - i, 0);                // columns j >= 0 only
+#pragma unroll
+                    for (int sl = 0; sl < 3; ++sl) Lv[sl] = (cc[sl] >= lo && cc[sl] < w) ? Lrow[cc[sl]] : 0.0;
+                };
+                double Lv[3], di, yi;
+                load(i_hi, Lv, di, yi);
+                for (int i = i_hi; i >= i_lo; --i) {
+                    // this row's own column: the lane / register whose offset is w
+                    const double mine = cc[0] == w ? acc[0] : (cc[1] == w ? acc[1] : acc[2]);
+                    const double xi = yi * di - rl(mine, (i + 192) & 63);
 #pragma unroll
                     for (int sl = 0; sl < 3; ++sl) {
-                        int dB = sl - bm; if (dB < 0) dB += 3;
-                        int jj = 64 * (blk + dB) + tid; if (jj < bb) jj += 192;
-                        Lv[sl] = (jj >= 192 && jj < i + 192) ? Lrow[jj - bb] : 0.0;
+                        acc[sl] = cc[sl] == w ? 0.0 : fma(Lv[sl], xi, acc[sl]);
+                        cc[sl] = cc[sl] == w ? w - 191 : cc[sl] + 1;
                     }
-                    const int ii = i + 192, ln = ii & 63, so = (ii >> 6) % 3;
-                    const double asel = so == 0 ? acc0 : (so == 1 ? acc1 : acc2);
-                    const double xi = yi * di - rl(asel, ln);
-                    if (tid == ln) { if (so == 0) acc0 = 0.0; else if (so == 1) acc1 = 0.0; else acc2 = 0.0; }
-                    acc0 = fma(Lv[0], xi, acc0); acc1 = fma(Lv[1], xi, acc1); acc2 = fma(Lv[2], xi, acc2);
                     if (tid == 0) {
                         int o;
                         if (reduced) o = ki < nq ? ti * nr + nu + ki : H * nr + ti * nd + (ki - nq);
@@ -598,6 +601,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
                         D[o] = xi;
                     }
                     if (--ki < 0) { ki = s - 1; --ti; }
+                    if (i > i_lo) load(i - 1, Lv, di, yi);
                 }
             }
             __syncthreads();
