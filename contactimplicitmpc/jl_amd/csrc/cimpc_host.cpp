@@ -1581,7 +1581,7 @@ int cimpc_get_kkt_fallbacks(cimpc_handle h, long long* n) {
 #ifdef CIMPC_KKT_PROF
 // diagnostic builds only: raw read of the statistics buffer (the KKT kernels park their phase clocks at [8..23])
 int cimpc_debug_read_stats(cimpc_handle h, long long* out, int n) {
-    if (!h || !out || n > 32) return CIMPC_ERR_INVALID;
+    if (!h || !out || n > std::max(h->dm.B * 4, 32)) return CIMPC_ERR_INVALID;
     HIP_TRY(h, hipMemcpy(out, h->S.stats, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
     return CIMPC_OK;
 }

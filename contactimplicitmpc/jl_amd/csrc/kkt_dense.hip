@@ -182,68 +182,98 @@ namespace {
 struct BandRows {
     const NewtonDev& S; const DenseLayout& L; const double* dzb; double rho; int s, nths;
     const double* G;      // reduced form (controls eliminated): [H][nd x nd] du1_t R_t^-1 du1_t^T, column-major; nullptr = full form
-    // entry (i, j), j <= i, of the interleaved KKT matrix
-    __device__ double operator()(int i, int j) const {
-        const int nq = L.nq, nu = L.nu, nr = L.nr, nd = L.nd, H = L.H;
-        const int ti = i / s, ki = i - ti * s, tj = j / s, kj = j - tj * s;
-        const int dt = ti - tj;
+    // An entry is a constant or a combination of at most three values in memory.  The two halves are separate so that a caller can
+    // ISSUE the loads of an entry long before it needs the value (the rows entering the window are fetched a block ahead: with the
+    // arithmetic next to the loads the fetching wavefronts sat out a memory latency per block - 3.7 k of 14 k cycles).
+    enum : int { CONST = 0, PLAIN = 1, NEG = 2, SUM = 3, C_MINUS = 4, DIFF = 5 };
+    //   CONST c   PLAIN x0   NEG -x0   SUM (x0 + x1) + x2   C_MINUS c - x0   DIFF x0 - x1      (absent operands: null pointer, read as 0)
+    static __device__ __forceinline__ double combine(int mode, double c, double x0, double x1, double x2) {
+        if (mode == CONST) return c;
+        if (mode == PLAIN) return x0;
+        if (mode == NEG) return -x0;
+        if (mode == SUM) return (x0 + x1) + x2;
+        if (mode == C_MINUS) return c - x0;
+        return x0 - x1;
+    }
+    // What an entry is depends on (row index in its step, column index in its step, steps between them) only - not on the step:
+    // a 32-bit DESCRIPTOR  mode | array << 3 | constant << 6 | offset inside the step's block << 8.  The kernel tabulates the
+    // descriptors of one period (s rows x w + 1 columns) once per launch; the rows entering the window then cost a table look-up
+    // and a decode instead of this case analysis per entry (round 4: the analysis, divergent across the lanes, was 3 k of 13 k
+    // cycles per block on fourteen of the sixteen wavefronts).
+    enum : int { AQ = 0, AV = 1, AG = 2, ADZ = 3, AR = 4 };      // arrays: Q, V, G (reduced form), dz (this rollout), R
+    enum : int { C0 = 0, CM1 = 1, CMRHO = 2 };                   // constants: 0, -1, -rho
+    static __device__ __forceinline__ unsigned pack(int mode, int arr, int cid, int off) { return (unsigned)mode | (unsigned)arr << 3 | (unsigned)cid << 6 | (unsigned)off << 8; }
+    __device__ unsigned desc(int dt, int ki, int kj) const {
+        const int nq = L.nq, nu = L.nu, nr = L.nr, nd = L.nd;
+        auto qrow = [&](int kq, int cq) {                        // P block: Q_t (+ V_t + V_{t+1}) on the diagonal step, -V_t one step back
+            const int e = cq * nq + kq;
+            if (dt == 0) return pack(SUM, AQ, C0, e);
+            if (dt == 1 && S.V != nullptr) return pack(NEG, AV, C0, e);
+            return pack(CONST, 0, C0, 0);
+        };
         if (G != nullptr) {      // ordering [q_{t+2}, nu_t] per step, s = nq + nd
             if (ki < nq) {                                       // q row
-                if (kj >= nq) return 0.0;
-                const size_t e = (size_t)kj * nq + ki;
-                if (dt == 0) {
-                    double v = S.Q[(size_t)ti * nq * nq + e];
-                    if (S.V != nullptr) {
-                        v += S.V[(size_t)ti * nq * nq + e];
-                        if (ti + 1 < H) v += S.V[(size_t)(ti + 1) * nq * nq + e];
-                    }
-                    return v;
-                }
-                if (dt == 1 && S.V != nullptr) return -S.V[(size_t)ti * nq * nq + e];
-                return 0.0;
+                if (kj >= nq) return pack(CONST, 0, C0, 0);
+                return qrow(ki, kj);
             }
             const int kd = ki - nq;                              // dual row nu_t
-            const double* dz = dzb + (size_t)ti * nths * nd;
             if (dt == 0) {
-                if (kj < nq) return (kj == kd) ? -1.0 : 0.0;     // -I at q_{t+2}
-                const double g = G[(size_t)ti * nd * nd + (size_t)(kj - nq) * nd + kd];
-                return (kj == ki) ? -rho - g : -g;               // -(rho I + du1 R^-1 du1^T)
+                if (kj < nq) return pack(CONST, 0, kj == kd ? CM1 : C0, 0);      // -I at q_{t+2}
+                const int off = (kj - nq) * nd + kd;
+                return kj == ki ? pack(C_MINUS, AG, CMRHO, off) : pack(NEG, AG, C0, off);      // -(rho I + du1 R^-1 du1^T)
             }
-            if (kj >= nq) return 0.0;
-            if (dt == 1) return dz[(size_t)(nq + kj) * nd + kd]; // dq1 at q_{t+1}
-            if (dt == 2) return dz[(size_t)kj * nd + kd];        // dq0 at q_t
-            return 0.0;
+            if (kj >= nq) return pack(CONST, 0, C0, 0);
+            if (dt == 1) return pack(PLAIN, ADZ, C0, (nq + kj) * nd + kd);      // dq1 at q_{t+1}
+            if (dt == 2) return pack(PLAIN, ADZ, C0, kj * nd + kd);             // dq0 at q_t
+            return pack(CONST, 0, C0, 0);
         }
         if (ki < nu) {                                           // u row: R_t (same block only)
-            return (dt == 0 && kj < nu) ? S.R[(size_t)ti * nu * nu + (size_t)kj * nu + ki] : 0.0;
+            if (dt == 0 && kj < nu) return pack(PLAIN, AR, C0, kj * nu + ki);
+            return pack(CONST, 0, C0, 0);
         }
         if (ki < nr) {                                           // q row
-            const int kq = ki - nu;
-            if (kj < nu || kj >= nr) return 0.0;                 // (lower part: no dual columns before a q row)
-            const int cq = kj - nu;
-            const size_t e = (size_t)cq * nq + kq;
-            if (dt == 0) {
-                double v = S.Q[(size_t)ti * nq * nq + e];
-                if (S.V != nullptr) {
-                    v += S.V[(size_t)ti * nq * nq + e];
-                    if (ti + 1 < H) v += S.V[(size_t)(ti + 1) * nq * nq + e];
-                }
-                return v;
-            }
-            if (dt == 1 && S.V != nullptr) return -S.V[(size_t)ti * nq * nq + e];
-            return 0.0;
+            if (kj < nu || kj >= nr) return pack(CONST, 0, C0, 0);      // (lower part: no dual columns before a q row)
+            return qrow(ki - nu, kj - nu);
         }
         const int kd = ki - nr;                                  // dual row nu_t
-        const double* dz = dzb + (size_t)ti * nths * nd;
         if (dt == 0) {
-            if (kj < nu) return dz[(size_t)(2 * nq + kj) * nd + kd];          // du1
-            if (kj < nr) return (kj - nu == kd) ? -1.0 : 0.0;                 // -I at q_{t+2}
-            return (kj == ki) ? -rho : 0.0;
+            if (kj < nu) return pack(PLAIN, ADZ, C0, (2 * nq + kj) * nd + kd);          // du1
+            if (kj < nr) return pack(CONST, 0, kj - nu == kd ? CM1 : C0, 0);            // -I at q_{t+2}
+            return pack(CONST, 0, kj == ki ? CMRHO : C0, 0);
         }
-        if (kj < nu || kj >= nr) return 0.0;
-        if (dt == 1) return dz[(size_t)(nq + kj - nu) * nd + kd];             // dq1 at q_{t+1}
-        if (dt == 2) return dz[(size_t)(kj - nu) * nd + kd];                  // dq0 at q_t
-        return 0.0;
+        if (kj < nu || kj >= nr) return pack(CONST, 0, C0, 0);
+        if (dt == 1) return pack(PLAIN, ADZ, C0, (nq + kj - nu) * nd + kd);             // dq1 at q_{t+1}
+        if (dt == 2) return pack(PLAIN, ADZ, C0, (kj - nu) * nd + kd);                  // dq0 at q_t
+        return pack(CONST, 0, C0, 0);
+    }
+    // descriptor + step of the row -> mode, constant, operand addresses (selects, one branch for the three-operand sum)
+    __device__ __forceinline__ int decode(unsigned d, int ti, const double*& p0, const double*& p1, const double*& p2, double& c) const {
+        const int mode = d & 7, arr = (d >> 3) & 7, cid = (d >> 6) & 3, off = (int)(d >> 8);
+        c = cid == C0 ? 0.0 : (cid == CM1 ? -1.0 : -rho);
+        const int nq2 = L.nq * L.nq;
+        const double* base = arr == AQ ? S.Q : arr == AV ? S.V : arr == AG ? G : arr == ADZ ? dzb : S.R;
+        const int stride = arr <= AV ? nq2 : arr == AG ? L.nd * L.nd : arr == ADZ ? nths * L.nd : L.nu * L.nu;
+        p0 = mode == CONST ? nullptr : base + (ti * stride + off);
+        p1 = p2 = nullptr;
+        if (mode == SUM && S.V != nullptr) {
+            p1 = S.V + (ti * nq2 + off);
+            if (ti + 1 < L.H) p2 = p1 + nq2;
+        }
+        return mode;
+    }
+    // entry (i, j), j <= i, of the interleaved KKT matrix: mode, constant and operand addresses
+    __device__ int terms(int i, int j, const double*& p0, const double*& p1, const double*& p2, double& c) const {
+        const int ti = i / s, tj = j / s;
+        return terms4(ti, i - ti * s, tj, j - tj * s, p0, p1, p2, c);
+    }
+    // ... with (step, index in the step) of the row and of the column given
+    __device__ int terms4(int ti, int ki, int tj, int kj, const double*& p0, const double*& p1, const double*& p2, double& c) const {
+        return decode(desc(ti - tj, ki, kj), ti, p0, p1, p2, c);
+    }
+    __device__ double operator()(int i, int j) const {
+        const double *p0, *p1, *p2; double c;
+        const int mode = terms(i, j, p0, p1, p2, c);
+        return combine(mode, c, p0 ? *p0 : 0.0, p1 ? *p1 : 0.0, p2 ? *p2 : 0.0);
     }
 };
 }  // namespace
@@ -256,17 +286,18 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// doubles of workspace per rollout: rows of L (N x (w + 1)), y (N), then G and g of the reduced form.  Sized for the FULL form
+// doubles of workspace per rollout: rows of L (N x (w + 1)), y (N), then G and g of the reduced form, then the descriptors of one period of rows.  Sized for the FULL form
 // (the larger one) so that the host's allocation does not depend on which form a launch takes.
 __host__ __device__ inline size_t banded_ws_per_rollout(const NewtonDev& S) {
     const size_t sF = (size_t)S.nr + S.nd, NF = (size_t)S.dm.H * sF;
     size_t wF = 3 * sF - 1 - S.dm.nu; if (wF > NF - 1) wF = NF - 1;
-    return NF * (wF + 1) + NF + (size_t)S.dm.H * S.nd * (S.nd + 1);
+    return NF * (wF + 1) + NF + (size_t)S.dm.H * S.nd * (S.nd + 1) + (sF * (wF + 2) + 1) / 2;      // ... and the descriptor table (32-bit words)
 }
 
 // -DCIMPC_BANDED_PROF (diagnostic builds, with -DCIMPC_KKT_PROF for the accessor): shader-clock accounting of the banded kernel, rollout 0,
-// wavefront 0 -> NewtonDev::stats[8..]: [0] pre-pass + window fill  [1] P1 diagonal block  [2] fetch issue + barrier  [3] P2 rows  [4] barrier
-// [5] stores + commit  [6] update  [7] barrier  [8] back substitution  [9] control recovery; wavefront 4 -> stats[20..], same slots
+// per wavefront: [0] pre-pass, window fill, first diagonal block  [1] fetch issue + P2  [2] barrier  [3] stores / rhs / commit
+// [4] U1 tiles  [5] barrier  [6] next diagonal block (wavefront 0) / U2 tiles (the others)  [7] barrier  [8] back substitution  [9] control
+// recovery; wavefront v -> stats[8 + 10 v ..] (the handle needs B >= 42 rollouts for the room)
 #ifdef CIMPC_BANDED_PROF
 #define BPROF(j) { const long long tn_ = clock64(); bp[j] += tn_ - bt; bt = tn_; }
 #else
@@ -279,7 +310,20 @@ __host__ __device__ inline size_t banded_ws_per_rollout(const NewtonDev& S) {
 // per-entry cost of an update pass is index arithmetic and LDS traffic, not its RB multiply-adds (profiles/r04/banded_prof_before.log:
 // update + its barrier 43 % of a solve, 7-8 k cycles per pass at RB = 4), so half as many passes are worth the deeper panel.  Every entry
 // still receives its pivots' contributions one after the other in pivot order: the factors do not depend on RB.
-template <int RB>
+// a += (c of lane K0 of this lane's DPP row of 16) * l0 + (c of lane K1) * l1, one instruction per multiply-add (lane_group.h:
+// v_fmac_f64_dpp row_newbcast and its hazard rule - one s_nop 1 after c is written).  (A bank mask on the destination instead of a zero
+// factor was tried and gives wrong results: the 64-bit DPP forms do not honour it.)
+template <int K0, int K1>
+__device__ __forceinline__ void fmac_bcast2(double& a, double c, double l0, double l1) {
+    asm("s_nop 1\n\t"
+        "v_fmac_f64_dpp %[a], %[c], %[l0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %[a], %[c], %[l1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t"
+        : [a] "+v"(a) : [c] "v"(c), [l0] "v"(l0), [l1] "v"(l1), [k0] "n"(K0), [k1] "n"(K1));
+}
+// POW2: the window has a power-of-two number of slots (where that fits the LDS): a slot index wraps with one AND instead of two
+// compare-subtract pairs - the wraps are a sixth of the instructions of a block, and every phase but P1 is issue-bound.
+__host__ __device__ inline int banded_pow2_slots(int extent) { int p = 1; while (p < extent) p <<= 1; return p; }
+template <int RB, bool POW2>
 __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(NewtonDev S, KktArgs K, double* ws_all) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int b = blockIdx.x + S.b0, tid = threadIdx.x, nt = blockDim.x;
@@ -294,7 +338,9 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     const bool reduced = S.band_reduce != 0 && L.nu > 0;
     const int H = L.H, nr = L.nr, nd = L.nd, nq = L.nq, nu = L.nu;
     const int s = reduced ? nq + nd : nr + nd, N = H * s;
-    const int w = min(reduced ? 3 * s - 1 : 3 * s - 1 - nu, N - 1), LW = w + 1, M = w + RB;   // window slots: pivot k+RB-1 reaches row k+RB-1+w
+    const int w = min(reduced ? 3 * s - 1 : 3 * s - 1 - nu, N - 1), LW = w + 1;
+    const int Mw = w + RB;                                       // rows in the window: pivot k+RB-1 reaches row k+RB-1+w
+    const int M = POW2 ? banded_pow2_slots(Mw) : Mw;             // slots (index mod M)
     double* wsb = ws_all + (size_t)b * banded_ws_per_rollout(S);
     double* Lr = wsb;                                            // row i: L[i][i-w .. i-1], slot w: 1 / d_i
     double* yg = Lr + (size_t)N * LW;
@@ -303,15 +349,18 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     double* W = sm;                                              // [M+1][M+1] window, slot = index mod M; BOTH triangles kept
     double* yw = W + (size_t)MS * MS;                            // [M]   right-hand side of the rows in the window
     double* PL = yw + MS;                                        // [RB][M+1] multipliers of the block's pivots, by row SLOT
-    double* dv = PL + (size_t)RB * MS;                           // [RB]  the block's pivots d
-    double* dinv = dv + RB;                                      // [RB]  their reciprocals
-    double* ypv = dinv + RB;                                     // [RB]  the pivot rows' right-hand sides (after the forward substitution among them)
-    double* L11 = ypv + RB;                                      // [RB][RB] multipliers among the block's pivot rows (row-major, strictly lower)
+    double* dv = PL + (size_t)RB * MS;                           // [2][RB]  the block's pivots d            (by block parity, like the next three)
+    double* dinv = dv + 2 * RB;                                  // [2][RB]  their reciprocals
+    double* ypv = dinv + 2 * RB;                                 // [2][RB]  the pivot rows' right-hand sides (after the forward substitution among them)
+    double* L11 = ypv + 2 * RB;                                  // [2][RB][RB] multipliers among the block's pivot rows (row-major, strictly lower)
+    double* nL11 = L11 + 2 * RB * RB;                            // [2][RB + 1][RB] the same negated, and a row of zeros (P2's operand: no selects)
+    int* tile_tab = (int*)(nL11 + 2 * (RB + 1) * RB);            // [<= 96] update tiles (I | J << 8), tile column 0 first
     const double beta = K.beta ? K.beta[b] : K.beta_scalar;
     const double rho = (double)H * beta * S.kappa;               // newton_jacobian.jl:169-186 quirk
     const double* dzb = kkt_dz(S, K, b, H, S.nths, nd);
     const double* rb = K.r + (size_t)b * S.N;
     double* gv = Gm + (size_t)H * nd * nd;
+    unsigned* dtab = (unsigned*)(gv + (size_t)H * nd);           // [s][w + 2] descriptors of the rows of one step (BandRows::desc)
 #ifdef CIMPC_BANDED_PROF
     long long bp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, bt = clock64();
 #endif
@@ -342,42 +391,76 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         __threadfence_block();
         __syncthreads();
     }
-    BPROF(0)
     const BandRows row{S, L, dzb, rho, s, S.nths, reduced ? Gm : nullptr};
-    // interleaved index -> index in the reference's layout (primal segment step-major, then the duals)
-    auto orig = [&](int i) {
-        const int t = i / s, k = i - t * s;
-        if (reduced) return k < nq ? t * nr + nu + k : H * nr + t * nd + (k - nq);
-        return k < nr ? t * nr + k : H * nr + t * nd + (k - nr);
-    };
-    // right-hand side entry of interleaved row i (reduced form: the dual rows carry r_d - du1 R^-1 r_u)
-    auto rhs = [&](int i) {
-        const double v = rb[orig(i)];
-        if (!reduced) return v;
-        const int t = i / s, k = i - t * s;
-        return k < nq ? v : v - gv[t * nd + (k - nq)];
-    };
+    // (interleaved index i = t s + k -> index in the reference's layout: primal segment step-major, then the duals)
     // A row entering the window has w + 2 entries: columns i-w .. i and the right-hand side.  Only the LOWER triangle of the window is
     // kept (row >= column: nothing ever reads the other one).  The entries of the RB rows that enter per block belong to the threads from
     // 128 on, at most NE each, and are FETCHED one block ahead (global loads of the sensitivities / weights stay off the critical path).
     constexpr int NE = 2;
     const int EW = w + 2;
-    auto entry_value = [&](int i, int e) -> double {
-        if (i >= N) return 0.0;
-        if (e <= w) { const int j = i - w + e; return j >= 0 ? row(i, j) : 0.0; }
-        return rhs(i);
+    struct Pending { double x0, x1, x2, c; int mode; };         // an entry whose loads are in flight
+    // entry e of row i = ti s + ki; (tj, kj): its column i - w + e likewise (unused for the right-hand side, e = w + 1).  Loads only.
+    auto entry_issue = [&](int mode, int e, int ti, int ki, const double* p0, const double* p1, const double* p2, Pending& P) {
+        if (e > w) {                                             // right-hand side (reduced form: the dual rows carry r_d - du1 R^-1 r_u)
+            p0 = rb + (reduced ? (ki < nq ? ti * nr + nu + ki : H * nr + ti * nd + (ki - nq)) : (ki < nr ? ti * nr + ki : H * nr + ti * nd + (ki - nr)));
+            p1 = (reduced && ki >= nq) ? gv + ti * nd + (ki - nq) : nullptr;
+            p2 = nullptr;
+            mode = p1 ? BandRows::DIFF : BandRows::PLAIN;
+        }
+        P.mode = mode;
+        if (p0) P.x0 = *p0;
+        if (p1) P.x1 = *p1;
+        if (p2) P.x2 = *p2;
     };
+    // entry e of row i = ti s + ki; (tj, kj): its column i - w + e likewise (unused for the right-hand side, e = w + 1).  Loads only.
+    auto entry_fetch4 = [&](int i, int e, int ti, int ki, int tj, int kj) -> Pending {
+        Pending P{0.0, 0.0, 0.0, 0.0, BandRows::CONST};
+        if (i >= N) return P;
+        const double *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
+        int mode = BandRows::CONST;
+        if (e <= w && i - w + e >= 0) mode = row.terms4(ti, ki, tj, kj, p0, p1, p2, P.c);
+        entry_issue(mode, e, ti, ki, p0, p1, p2, P);
+        return P;
+    };
+    // ... of a row past the first w (every column exists), from its tabulated descriptor
+    auto entry_fetch_d = [&](int i, int e, int ti, int ki, unsigned d) -> Pending {
+        Pending P{0.0, 0.0, 0.0, 0.0, BandRows::CONST};
+        if (i >= N) return P;
+        const double *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
+        int mode = BandRows::CONST;
+        if (e <= w) mode = row.decode(d, ti, p0, p1, p2, P.c);
+        entry_issue(mode, e, ti, ki, p0, p1, p2, P);
+        return P;
+    };
+    auto entry_fetch = [&](int i, int e) -> Pending {
+        const int j = max(i - w + min(e, w), 0), ti = i / s, tj = j / s;
+        return entry_fetch4(i, e, ti, i - ti * s, tj, j - tj * s);
+    };
+    auto entry_done = [&](const Pending& P) { return BandRows::combine(P.mode, P.c, P.x0, P.x1, P.x2); };
+    auto entry_value = [&](int i, int e) -> double { return entry_done(entry_fetch(i, e)); };
     auto entry_commit = [&](int i, int e, double v) {
         if (i >= N) return;
         const int si = i % M;
-        if (e <= w) { const int j = i - w + e; if (j >= 0) W[(size_t)si * MS + j % M] = v; }
+        if (e <= w) { const int j = i - w + e; if (j >= 0) W[si * MS + j % M] = v; }
         else yw[si] = v;
     };
+    for (int idx = tid; idx < s * EW; idx += nt) {               // descriptors of the rows of one step: entry e of row index ki sits in column
+        const int ki = idx / EW, e = idx - ki * EW;              // ki - w + e of the row's own step, counted in steps of s downwards
+        unsigned d = 0u;
+        if (e <= w) {
+            const int rel = ki - w + e, st = (rel + 3 * s) / s - 3;      // floor(rel / s), rel >= -(3 s - 1)
+            d = row.desc(-st, ki, rel - st * s);
+        }
+        dtab[idx] = d;
+    }
+    __threadfence_block();
+    __syncthreads();
     {
-        const int n0 = min(M, N) * EW;                           // the first M rows, all threads
+        const int n0 = min(Mw, N) * EW;                          // the first Mw rows, all threads
         for (int idx = tid; idx < n0; idx += nt) { const int i = idx / EW, e = idx - i * EW; entry_commit(i, e, entry_value(i, e)); }
     }
     for (int e = tid; e < RB * MS; e += nt) PL[e] = 0.0;
+    for (int e = tid; e < 2 * (RB + 1) * RB; e += nt) nL11[e] = 0.0;
     int ent_t[NE], ent_e[NE];                                    // (row of the block, entry) of this thread's entering entries; -1: none
 #pragma unroll
     for (int n = 0; n < NE; ++n) {
@@ -386,16 +469,28 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         ent_t[n] = on ? idx / EW : -1;
         ent_e[n] = on ? idx - (idx / EW) * EW : 0;
     }
-    double nxt[NE];
+    Pending nxt[NE];
+    int eti[NE], eki[NE];                                        // (step, index in the step) of the row of the NEXT fetch, advanced RB per block
+    unsigned dsc[NE];                                            // ... and its descriptor, loaded a block ahead
 #pragma unroll
-    for (int n = 0; n < NE; ++n) nxt[n] = ent_t[n] >= 0 ? entry_value(M + ent_t[n], ent_e[n]) : 0.0;      // rows entering after the first block
+    for (int n = 0; n < NE; ++n) {                               // rows entering after the first block
+        const int i = ent_t[n] >= 0 ? Mw + ent_t[n] : N, j = max(i - w + min(ent_e[n], w), 0);
+        eti[n] = i / s; eki[n] = i - eti[n] * s;
+        const int tj = j / s;
+        nxt[n] = entry_fetch4(i, ent_e[n], eti[n], eki[n], tj, j - tj * s);
+        eki[n] += RB; while (eki[n] >= s) { eki[n] -= s; ++eti[n]; }
+        dsc[n] = ent_t[n] >= 0 ? dtab[eki[n] * EW + ent_e[n]] : 0u;
+    }
     __syncthreads();
     const int tx = tid & 63, ty = tid >> 6, nty = nt >> 6;
     auto rl = [](double v, int lane) {                           // v of another lane of the wavefront (lane: uniform)
         const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
         return __hiloint2double(hi, lo);
     };
-    auto wrap = [&](int x) { if (x >= M) x -= M; if (x >= M) x -= M; return x; };      // slot of an index < 3 M past a slot
+    auto wrap = [&](int x) {                                     // slot of an index < 3 M past a slot
+        if constexpr (POW2) return x & (M - 1);
+        else { if (x >= M) x -= M; if (x >= M) x -= M; return x; }
+    };
     // Round 4 (second pass): a block of RB pivots is
     //   P1  lanes 0 .. RB-1 of wavefront 0: the RB x RB diagonal block - pivots, reciprocals, the multipliers among the pivot rows, the
     //       forward substitution among them (lane r owns pivot row r, right-looking, hand-overs by v_readlane, no branches, no global
@@ -410,198 +505,244 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     // one wavefront 12.5 k, its scattered 8-byte stores draining at the next barrier 7.8 k, an LDS-bound update of both triangles 15 k;
     // split into P1 / P2 / P3 with a register-tiled VALU update 27 k (banded_prof_split.log: P1 10.5 k - integer divisions for the slots,
     // a branch per predicate -, P2 3.5 k, update 7.6 k).
-    int sk = 0;                                                  // k % M, kept by counting
-    for (int k = 0; k < N; k += RB) {
-        const int nb_ = min(RB, N - k);                          // pivots of this block
-        if (tid < RB) {                                          // ---- P1
-            const int r = tid;
-            const bool vr = r < nb_;
-            const int sr = wrap(sk + r);
-            double a[RB];
-            double yr = vr ? yw[sr] : 0.0;
+    // Look-ahead (round 4, third pass): the sequential part P1 of block k + RB runs on wavefront 0 WHILE the other fifteen finish the update
+    // of block k.  P1 needs the next diagonal block and P2 the next pivot columns: the tiles of tile column 0 go first (phase U1, one round
+    // of all sixteen wavefronts), the rest (U2) overlaps with P1.  pivots / reciprocals / diagonal block are double-buffered by block parity
+    // (U2 of block k still reads d of block k while P1 writes the next).  Per block:  P2 | barrier | P3a + U1 | barrier | P1' || U2 | barrier.
+    int sk = 0, pb = 0, mt_tab = -1;                             // k % M by counting, parity of the block, the window size the tile table is for
+    const int wv = __builtin_amdgcn_readfirstlane(ty);
+    auto P1 = [&](int kk, int skk, int par) {                    // lanes 0 .. RB-1 of wavefront 0
+        const int nbk = min(RB, N - kk);
+        double* dvp = dv + par * RB; double* dinvp = dinv + par * RB; double* ypvp = ypv + par * RB; double* L11p = L11 + par * RB * RB;
+        double* nL11p = nL11 + par * (RB + 1) * RB;
+        const int r = tid;
+        const bool vr = r < nbk;
+        const int sr = wrap(skk + r);
+        double a[RB];
+        double yr = vr ? yw[sr] : 0.0;
 #pragma unroll
-            for (int t = 0; t < RB; ++t) a[t] = (vr && t <= r && t < nb_) ? W[(size_t)sr * MS + wrap(sk + t)] : 0.0;
+        for (int t = 0; t < RB; ++t) a[t] = (vr && t <= r && t < nbk) ? W[sr * MS + wrap(skk + t)] : 0.0;
 #pragma unroll
-            for (int t = 0; t < RB; ++t) {
-                if (t < nb_) {
-                    const double d = rl(a[t], t), inv = 1.0 / d, yp = rl(yr, t);
-                    const double lv = r > t ? a[t] * inv : 0.0;  // (rows past the end carry zeros)
-                    yr = fma(-lv, yp, yr);                       // forward substitution rides along
-                    const double c = lv * d;
+        for (int t = 0; t < RB; ++t) {
+            if (t < nbk) {
+                const double d = rl(a[t], t), inv = 1.0 / d, yp = rl(yr, t);
+                const double lv = r > t ? a[t] * inv : 0.0;      // (rows past the end carry zeros)
+                yr = fma(-lv, yp, yr);                           // forward substitution rides along
+                const double c = lv * d;
 #pragma unroll
-                    for (int t2 = t + 1; t2 < RB; ++t2) a[t2] = fma(-c, rl(lv, t2), a[t2]);      // right-looking inside the block
-                    L11[r * RB + t] = lv;
-                    dv[t] = d; dinv[t] = inv; ypv[t] = yp;       // (the same value from every lane)
-                }
+                for (int t2 = t + 1; t2 < RB; ++t2) a[t2] = fma(-c, rl(lv, t2), a[t2]);      // right-looking inside the block
+                L11p[r * RB + t] = lv; nL11p[r * RB + t] = -lv;  // (zero on and above the diagonal)
+                dvp[t] = d; dinvp[t] = inv; ypvp[t] = yp;        // (the same value from every lane)
             }
         }
-        BPROF(1)
-        double nxt2[NE];                                         // rows entering after the NEXT block: loads in flight across P1 / P2
-#pragma unroll
-        for (int n = 0; n < NE; ++n) nxt2[n] = ent_t[n] >= 0 ? entry_value(k + RB + M + ent_t[n], ent_e[n]) : 0.0;
-        lds_barrier();
-        BPROF(2)
+    };
+    if (tid < RB) P1(0, 0, 0);
+    lds_barrier();
+    BPROF(0)
+    for (int k = 0; k < N; k += RB) {
+        const int nb_ = min(RB, N - k);                          // pivots of this block
+        const double* dvp = dv + pb * RB; const double* dinvp = dinv + pb * RB; const double* ypvp = ypv + pb * RB; const double* L11p = L11 + pb * RB * RB;
+        const int base = k + nb_, mt = max(min(w, N - base), 0); // mt rows / columns of the trailing window present
+        const int nT = (mt + 15) >> 4, ntiles = nT * (nT + 1) / 2;
+        if (mt != mt_tab) {                                      // tile table (steady state: written once): tile column 0 first, then the rest
+            if (tid < ntiles) {
+                int I = tid, J = 0;
+                if (tid >= nT) {
+                    const int t2 = tid - nT;
+                    I = 0; while ((I + 1) * (I + 2) / 2 <= t2) ++I;
+                    J = t2 - I * (I + 1) / 2 + 1; I += 1;
+                }
+                tile_tab[tid] = I | (J << 8);
+            }
+            mt_tab = mt;
+        }
         {                                                        // ---- P2: row k + q, q = RB .. RB + w - 1, entry t
             constexpr int NG = 16 / RB;                          // rows per DPP row of 16 lanes
             const int l16 = tx & 15, g = l16 / RB, t = l16 - g * RB;
             const int q = RB + (tid >> 4) * NG + g, i = k + q;
             const bool on = q < RB + w && i < N && t < nb_;
             const int sr = wrap(sk + q);
-            double a = (on && q - t <= w) ? W[(size_t)sr * MS + wrap(sk + t)] : 0.0;
-            const double inv = dinv[t], d = dv[t];
-            double lm[RB];                                       // the pivot row t's multipliers for the earlier pivots
+            double a = (on && q - t <= w) ? W[sr * MS + wrap(sk + t)] : 0.0;
+            const double inv = dinvp[t], d = dvp[t];
+            double lm[NG][RB];                                   // minus the pivot row t's multipliers for the earlier pivots (zero from the
+            const double* nL11p = nL11 + pb * (RB + 1) * RB;     // diagonal on) in the column of this lane's row of the DPP row, zero in the others
+#pragma unroll                                                   // (reading a row of zeros instead of selecting doubled the LDS reads: P2 600 k cycles slower)
+            for (int u = 0; u < RB; ++u) {
+                const double v = nL11p[t * RB + u];
 #pragma unroll
-            for (int u = 0; u < RB; ++u) lm[u] = u < t ? L11[t * RB + u] : 0.0;
+                for (int g2 = 0; g2 < NG; ++g2) lm[g2][u] = g == g2 ? v : 0.0;
+            }
+            // a -= (l_u d_u) L11[t][u]: the product of lane u of the row rides on the DPP source of the multiply-add; one multiply-add per
+            // row of the DPP row, all but this lane's own with a zero factor (exact)
             static_for<0, RB - 1>([&](auto U) {
                 constexpr int u = decltype(U)::value;
                 const double c = (a * inv) * d;                  // final in lane u of the row
-                double cb = 0.0;
-                static_for<0, NG>([&](auto Gq) {
-                    constexpr int g2 = decltype(Gq)::value;
-                    const double v = __builtin_amdgcn_update_dpp(0.0, c, 0x150 + g2 * RB + u, 0xF, 0xF, true);      // row_newbcast
-                    cb = g == g2 ? v : cb;
-                });
-                a = fma(-cb, lm[u], a);
+                if constexpr (NG == 2) fmac_bcast2<u, RB + u>(a, c, lm[0][u], lm[1][u]);
+                else { fmac_bcast2<u, RB + u>(a, c, lm[0][u], lm[1][u]); fmac_bcast2<2 * RB + u, 3 * RB + u>(a, c, lm[2][u], lm[3][u]); }
             });
-            if (on) PL[(size_t)t * MS + sr] = a * inv;           // zero where the pivot does not couple
+            if (on) PL[t * MS + sr] = a * inv;           // zero where the pivot does not couple
         }
-        BPROF(3)
-        lds_barrier();              // the block's multipliers / pivots are in place; the pivots' slots may be overwritten now
-        BPROF(4)
-        // ---- P3 -------------------------------------------------------------------------------------------------------------------
-        for (int idx = tid; idx < (RB - 1 + w) * RB; idx += nt) {       // multipliers -> rows of L in global memory, t fastest
+        BPROF(1)
+        lds_barrier();              // the block's multipliers are in place; the pivots' slots may be overwritten now
+        BPROF(2)
+        // ---- P3a: multipliers -> rows of L in global memory (t fastest), right-hand side of the rows below, entering rows ---------------
+        for (int idx = tid; idx < (RB - 1 + w) * RB; idx += nt) {
             const int q = 1 + idx / RB, t = idx - (idx / RB) * RB, i = k + q;
-            if (i < N && t < nb_ && t < q && q - t <= w)
-                Lr[(size_t)i * LW + (w - (q - t))] = q < RB ? L11[q * RB + t] : PL[(size_t)t * MS + wrap(sk + q)];
+            const double* src = q < RB ? L11p + (q * RB + t) : PL + (t * MS + wrap(sk + q));      // (both in LDS: one read)
+            const double v = *src;
+            if (i < N && t < nb_ && t < q && q - t <= w) Lr[i * LW + (w - (q - t))] = v;
         }
-        if (tid < nb_) { yg[k + tid] = ypv[tid]; Lr[(size_t)(k + tid) * LW + w] = dinv[tid]; }
-        if (tid >= 64 && tid < 64 + w && k + RB + tid - 64 < N) {       // right-hand side of the rows below the block
+        if (tid < nb_) { yg[k + tid] = ypvp[tid]; Lr[(k + tid) * LW + w] = dinvp[tid]; }
+        if (tid >= 64 && tid < 64 + w && k + RB + tid - 64 < N) {
             const int sr = wrap(sk + RB + tid - 64);
             double yr = yw[sr];
 #pragma unroll
-            for (int t = 0; t < RB; ++t) if (t < nb_) yr = fma(-PL[(size_t)t * MS + sr], ypv[t], yr);
+            for (int t = 0; t < RB; ++t) if (t < nb_) yr = fma(-PL[t * MS + sr], ypvp[t], yr);
             yw[sr] = yr;
         }
 #pragma unroll
         for (int n = 0; n < NE; ++n) {
-            if (ent_t[n] >= 0 && ent_t[n] < nb_ && k + M + ent_t[n] < N) {       // row k + M + t: the slot of pivot k + t
-                const int si = wrap(sk + ent_t[n]);
-                if (ent_e[n] <= w) W[(size_t)si * MS + wrap(sk + RB + ent_t[n] + ent_e[n])] = nxt[n];   // column k + RB + t + e (>= 0)
-                else yw[si] = nxt[n];
+            if (ent_t[n] >= 0 && ent_t[n] < nb_ && k + Mw + ent_t[n] < N) {      // row k + Mw + t (Mw = M: the slot of pivot k + t)
+                const int si = wrap(sk + Mw + ent_t[n]);
+                const double v = entry_done(nxt[n]);
+                if (ent_e[n] <= w) W[si * MS + wrap(sk + RB + ent_t[n] + ent_e[n])] = v;        // column k + RB + t + e (>= 0)
+                else yw[si] = v;
             }
-            nxt[n] = nxt2[n];
         }
+        BPROF(3)
+        // ---- rank-RB update of the lower triangle of the trailing window: 16 x 16 tiles on v_mfma_f64_16x16x4 ------------------------
+        const int sb = wrap(sk + nb_);
+        const int li = tx & 15, lk = tx >> 4;
+        auto tile = [&](int tl) {
+            const int ij = __builtin_amdgcn_readfirstlane(tile_tab[tl]), I = ij & 255, J = ij >> 8;
+            const int ra = 16 * I + li, cb_ = 16 * J + li;
+            const int sra = wrap(sb + min(ra, mt - 1)), scb = wrap(sb + min(cb_, mt - 1));
+            // no predicates: addresses are clamped into the window, what a lane computes for a row / column past the end (or above the
+            // diagonal - nothing reads those cells) lands in the dummy row
+            d4 acc;
+            double* cell[4];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int rw = 16 * I + lk + 4 * r4;
+                const double* src = W + wrap(sb + min(rw, mt - 1)) * MS + scb;
+                acc[r4] = *src;
+                cell[r4] = (rw < mt && cb_ < mt) ? (double*)src : W + M * MS + li;
+            }
+#pragma unroll
+            for (int kb = 0; kb < RB / 4; ++kb) {
+                const int t = 4 * kb + lk;
+                const double av = -(PL[t * MS + sra] * dvp[t]);
+                const double bv = PL[t * MS + scb];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) *cell[r4] = acc[r4];
+        };
+        int n1 = nty * ((nT + nty - 1) / nty);                   // U1: tile column 0 and company, whole rounds; U2: two rounds at most
+        const int nu2 = nty - (nty + 3) / 4;                     // wavefronts of U2: those that do not share wavefront 0's SIMD (wave v -> SIMD v % 4)
+        { const int alt = ntiles - 2 * nu2; if (alt > n1) n1 = nty * ((alt + nty - 1) / nty); }
+        n1 = min(n1, ntiles);
+        for (int tl = wv; tl < n1; tl += nty) tile(tl);
+        BPROF(4)
+        lds_barrier();
         BPROF(5)
-        {
-            const int base = k + nb_, mt = min(w, N - base);     // mt rows / columns of the trailing window present
-            if (mt > 0) {
-                const int sb = wrap(sk + nb_);
-                const int nT = (mt + 15) >> 4, ntiles = nT * (nT + 1) / 2;
-                const int li = tx & 15, lk = tx >> 4;
-                for (int tl = ty; tl < ntiles; tl += nty) {
-                    int I = 0;
-                    while ((I + 1) * (I + 2) / 2 <= tl) ++I;     // tile (I, J), J <= I
-                    const int J = tl - I * (I + 1) / 2;
-                    const int ra = 16 * I + li, cb_ = 16 * J + li;
-                    const int sra = wrap(sb + min(ra, mt - 1)), scb = wrap(sb + min(cb_, mt - 1));
-                    d4 acc;
-                    double* cell[4];
-                    bool ok[4];
+        const int skn = wrap(sk + RB);
+        if (k + RB < N) {
+            if (tid < RB) P1(k + RB, skn, pb ^ 1);
+            else if ((wv & 3) != 0) for (int tl = n1 + (wv >> 2) * 3 + (wv & 3) - 1; tl < ntiles; tl += nu2) tile(tl);
+        }
+        // rows entering after the NEXT block: the loads are issued here, in the shadow of P1, and land during the next block's P2
 #pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        const int rw = 16 * I + lk + 4 * r4;
-                        ok[r4] = rw < mt && cb_ < mt && (I != J || rw >= cb_);      // lower triangle only
-                        cell[r4] = W + (size_t)wrap(sb + min(rw, mt - 1)) * MS + scb;
-                        acc[r4] = ok[r4] ? *cell[r4] : 0.0;
-                    }
-#pragma unroll
-                    for (int kb = 0; kb < RB / 4; ++kb) {
-                        const int t = 4 * kb + lk;
-                        const double av = ra < mt ? -(PL[(size_t)t * MS + sra] * dv[t]) : 0.0;
-                        const double bv = cb_ < mt ? PL[(size_t)t * MS + scb] : 0.0;
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) if (ok[r4]) *cell[r4] = acc[r4];
-                }
+        for (int n = 0; n < NE; ++n) {
+            if (ent_t[n] >= 0) {
+                nxt[n] = entry_fetch_d(k + RB + Mw + ent_t[n], ent_e[n], eti[n], eki[n], dsc[n]);
+                eki[n] += RB; while (eki[n] >= s) { eki[n] -= s; ++eti[n]; }
+                dsc[n] = dtab[eki[n] * EW + ent_e[n]];
             }
         }
         BPROF(6)
         lds_barrier();
         BPROF(7)
-        sk += RB; if (sk >= M) sk -= M;
+        sk = skn; pb ^= 1;
     }
     __syncthreads();              // full barrier: the rows of L and y in global memory are read back below
     // ---- back substitution  L^T x = D^-1 y.  acc_j = sum_{i > j} L[i][j] x_i is built row by row (i descending); round 4: the pending
     //      acc_j live in REGISTERS of wavefront 0 (column j belongs to lane (j + 192) % 64, register ((j + 192) / 64) % 3 - a band of
-    //      w < 192 columns never holds two columns of one lane in one register), x_i needs one v_readlane, and the rows of L come
-    //      through LDS in chunks of CR rows that the other fifteen wavefronts copy one chunk ahead (a contiguous piece of global memory).
-    //      A lane follows its column of a register by counting: offset c = j - (i - w) grows by one per row; at c = w the column is the
-    //      row's own (x_j is read off, the sum restarts) and the lane moves on to column j - 192.
-    //      Before: 3.6 k cycles per row - an LDS read-modify-write chain on acc and global-load latency behind a 16-row register ring.
+    //      w < 192 columns never holds two columns of one lane in one register) and x_i needs one v_readlane.  The other fifteen
+    //      wavefronts stage the rows of L one chunk ahead into LDS ALREADY IN THAT REGISTER LAYOUT (192 values per row, zero where the
+    //      lane's column is outside the band, then 1/d_i and y_i): a row costs wavefront 0 five LDS reads, the hand-over and four
+    //      multiply-adds, nothing else.  x is collected lane-wise (row i in lane (i + 192) % 64) and written once per 64 rows.
+    //      History: 3.6 k cycles per row (LDS read-modify-write chain on acc, global-load latency behind a 16-row register ring), 640 with
+    //      the sums in registers but the band bookkeeping on wavefront 0 (banded_prof_mfma.log).
     double* D = K.delta + (size_t)b * S.N;
     {
-        const int avail = MS * MS + MS + RB * MS + 3 * RB + RB * RB;      // doubles of LDS the window held
-        int CR = avail / (2 * (LW + 1)); if (CR > 64) CR = 64;
-        const int nch = (N + CR - 1) / CR, CS = CR * (LW + 1);
+        constexpr int RS = 194;                                  // staged row: [3][64] values, 1/d, y
+        const int avail = MS * MS + MS + RB * MS + 2 * (3 * RB + RB * RB + (RB + 1) * RB) + 48;      // doubles of LDS the window held
+        int CR = avail / (2 * RS); if (CR > 64) CR = 64;
+        const int nch = (N + CR - 1) / CR, CS = CR * RS;
         auto stage = [&](int ch, int t0, int nth) {              // chunk ch = rows N-1 - ch CR downwards -> buffer ch & 1  (threads t0 .. of nth)
-            const int i_hi = N - 1 - ch * CR, i_lo = max(i_hi - CR + 1, 0), n = i_hi - i_lo + 1, tot = n * LW;
-            double* bufp = sm + (size_t)(ch & 1) * CS;
-            const double* src = Lr + (size_t)i_lo * LW;
+            const int i_hi = N - 1 - ch * CR, i_lo = max(i_hi - CR + 1, 0), n = i_hi - i_lo + 1, tot = n * 192;
+            double* bufp = sm + (ch & 1) * CS;
             for (int e0 = t0; e0 < tot; e0 += 8 * nth) {
                 double tmp[8];
+                int dst[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int e = e0 + u * nth; tmp[u] = e < tot ? src[e] : 0.0; }
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * nth;
+                    tmp[u] = 0.0; dst[u] = -1;
+                    if (e < tot) {
+                        const int rw = e / 192, rem = e - rw * 192, sl = rem >> 6, ln = rem & 63, i = i_hi - rw;
+                        const int bb = i - w + 192, blk = bb >> 6, bm = blk % 3;
+                        int dB = sl - bm; if (dB < 0) dB += 3;
+                        int jj = 64 * (blk + dB) + ln; if (jj < bb) jj += 192;
+                        dst[u] = rw * RS + rem;
+                        if (jj >= 192 && jj < i + 192) tmp[u] = Lr[i * LW + (jj - bb)];
+                    }
+                }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int e = e0 + u * nth; if (e < tot) bufp[e] = tmp[u]; }
+                for (int u = 0; u < 8; ++u) if (dst[u] >= 0) bufp[dst[u]] = tmp[u];
             }
-            for (int e = t0; e < n; e += nth) bufp[CR * LW + e] = yg[i_lo + e];
+            for (int e = t0; e < n; e += nth) { const int i = i_hi - e; bufp[e * RS + 192] = Lr[i * LW + w]; bufp[e * RS + 193] = yg[i]; }
         };
         stage(0, tid, nt);
         __syncthreads();
         double acc[3] = {0.0, 0.0, 0.0};
-        int cc[3];                                               // offset c of this lane's column of register sl at the current row
-        {
-            const int bb = N - 1 - w + 192, blk = bb >> 6, bm = blk % 3;
-#pragma unroll
-            for (int sl = 0; sl < 3; ++sl) {
-                int dB = sl - bm; if (dB < 0) dB += 3;
-                int jj = 64 * (blk + dB) + tx; if (jj < bb) jj += 192;
-                cc[sl] = jj - bb; if (cc[sl] > w) cc[sl] -= 192;
-            }
-        }
         for (int ch = 0; ch < nch; ++ch) {
             if (tid >= 64) { if (ch + 1 < nch) stage(ch + 1, tid - 64, (int)nt - 64); }
             else {
                 const int i_hi = N - 1 - ch * CR, i_lo = max(i_hi - CR + 1, 0);
-                const double* bufp = sm + (size_t)(ch & 1) * CS;
-                int ti = i_hi / s, ki = i_hi - ti * s;           // (step, index in the step) of row i, kept by counting
-                auto load = [&](int i, double (&Lv)[3], double& di, double& yi) {
-                    const double* Lrow = bufp + (size_t)(i - i_lo) * LW;
-                    di = Lrow[w]; yi = bufp[CR * LW + (i - i_lo)];       // di = 1 / d_i
-                    const int lo = max(w - i, 0);                // columns j >= 0 only
-#pragma unroll
-                    for (int sl = 0; sl < 3; ++sl) Lv[sl] = (cc[sl] >= lo && cc[sl] < w) ? Lrow[cc[sl]] : 0.0;
-                };
-                double Lv[3], di, yi;
-                load(i_hi, Lv, di, yi);
-                for (int i = i_hi; i >= i_lo; --i) {
-                    // this row's own column: the lane / register whose offset is w
-                    const double mine = cc[0] == w ? acc[0] : (cc[1] == w ? acc[1] : acc[2]);
-                    const double xi = yi * di - rl(mine, (i + 192) & 63);
-#pragma unroll
-                    for (int sl = 0; sl < 3; ++sl) {
-                        acc[sl] = cc[sl] == w ? 0.0 : fma(Lv[sl], xi, acc[sl]);
-                        cc[sl] = cc[sl] == w ? w - 191 : cc[sl] + 1;
-                    }
-                    if (tid == 0) {
-                        int o;
-                        if (reduced) o = ki < nq ? ti * nr + nu + ki : H * nr + ti * nd + (ki - nq);
-                        else o = ki < nr ? ti * nr + ki : H * nr + ti * nd + (ki - nr);
-                        D[o] = xi;
-                    }
-                    if (--ki < 0) { ki = s - 1; --ti; }
-                    if (i > i_lo) load(i - 1, Lv, di, yi);
+                const double* bufp = sm + (ch & 1) * CS;
+                int i = i_hi;
+                while (i >= i_lo) {                              // runs of rows whose own column sits in the same register
+                    const int seg_lo = max(i_lo, ((i + 192) & ~63) - 192), so = ((i + 192) >> 6) % 3;
+                    auto run = [&](auto SO) {
+                        constexpr int so_ = decltype(SO)::value;
+                        const double* rp = bufp + (i_hi - i) * RS;
+                        double L0 = rp[tx], L1 = rp[64 + tx], L2 = rp[128 + tx], di = rp[192], yi = rp[193];      // di = 1 / d_i
+                        double xs = 0.0;
+                        for (int r = i; r >= seg_lo; --r) {
+                            const double l0 = L0, l1 = L1, l2 = L2, d_ = di, y_ = yi;
+                            if (r > seg_lo) { rp += RS; L0 = rp[tx]; L1 = rp[64 + tx]; L2 = rp[128 + tx]; di = rp[192]; yi = rp[193]; }   // next row in flight
+                            const int ln = (r + 192) & 63;
+                            const double xi = y_ * d_ - rl(acc[so_], ln);
+                            const bool own = tx == ln;
+                            xs = own ? xi : xs;
+                            acc[so_] = own ? 0.0 : acc[so_];
+                            acc[0] = fma(l0, xi, acc[0]); acc[1] = fma(l1, xi, acc[1]); acc[2] = fma(l2, xi, acc[2]);
+                        }
+                        const int lnA = (i + 192) & 63, il = i - (lnA - tx);      // the row whose x this lane collected
+                        if (tx <= lnA && il >= seg_lo) {
+                            const int ti = il / s, ki = il - ti * s;
+                            int o;
+                            if (reduced) o = ki < nq ? ti * nr + nu + ki : H * nr + ti * nd + (ki - nq);
+                            else o = ki < nr ? ti * nr + ki : H * nr + ti * nd + (ki - nr);
+                            D[o] = xs;
+                        }
+                    };
+                    if (so == 0) run(std::integral_constant<int, 0>{});
+                    else if (so == 1) run(std::integral_constant<int, 1>{});
+                    else run(std::integral_constant<int, 2>{});
+                    i = seg_lo - 1;
                 }
             }
             __syncthreads();
@@ -631,7 +772,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     }
     BPROF(9)
 #ifdef CIMPC_BANDED_PROF
-    if (b == 0 && (tid == 0 || tid == 256)) for (int j = 0; j < 12; ++j) ((long long*)S.stats)[8 + (tid == 0 ? 0 : 12) + j] = bp[j];
+    if (b == 0 && (tid & 63) == 0) for (int j = 0; j < 10; ++j) ((long long*)S.stats)[8 + (tid >> 6) * 10 + j] = bp[j];      // (needs B >= 42)
 #endif
     if (K.finish) {
         __threadfence_block();
@@ -639,10 +780,11 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     }
 }
 
-static size_t banded_lds_bytes(int w, int rb = 4) {      // window (w + rb slots + dummy)^2, right-hand side, rb multiplier rows, pivots / reciprocals / rhs, diagonal block
-    const size_t MS = (size_t)w + rb + 1;
-    return (MS * MS + MS + (size_t)rb * MS + 3 * (size_t)rb + (size_t)rb * rb) * sizeof(double);
+static size_t banded_lds_bytes_slots(int slots, int rb) {      // window (slots + dummy)^2, right-hand side, rb multiplier rows, 2 x (pivots / reciprocals / rhs, diagonal block), tile table
+    const size_t MS = (size_t)slots + 1;
+    return (MS * MS + MS + (size_t)rb * MS + 2 * (3 * (size_t)rb + (size_t)rb * rb + ((size_t)rb + 1) * rb) + 48) * sizeof(double);
 }
+static size_t banded_lds_bytes(int w, int rb = 4, bool pow2 = false) { return banded_lds_bytes_slots(pow2 ? banded_pow2_slots(w + rb) : w + rb, rb); }
 static int band_halfwidth(const NewtonDev& S) {      // (the kernel's own formula: reduced form when the controls are eliminated)
     if (S.band_reduce != 0 && S.dm.nu > 0) { const int s = S.dm.nq + S.nd; return std::min(3 * s - 1, S.dm.H * s - 1); }
     const int s = S.nr + S.nd;
@@ -651,8 +793,11 @@ static int band_halfwidth(const NewtonDev& S) {      // (the kernel's own formul
 static int banded_rb(const NewtonDev& S) {      // pivots per window update: 8 where that window fits
     return banded_lds_bytes(band_halfwidth(S), 8) <= 156 * 1024 ? 8 : 4;
 }
+static bool banded_pow2(const NewtonDev& S) {      // power-of-two slot count where THAT window fits
+    return banded_lds_bytes(band_halfwidth(S), banded_rb(S), true) <= 156 * 1024;
+}
 static size_t banded_lds_bytes(const NewtonDev& S) {      // ... and, before the window is in use, T = du1 R^-1 of every step ([H][nd x nu])
-    const size_t win = banded_lds_bytes(band_halfwidth(S), banded_rb(S));
+    const size_t win = banded_lds_bytes(band_halfwidth(S), banded_rb(S), banded_pow2(S));
     const size_t pre = (S.band_reduce != 0 && S.dm.nu > 0) ? (size_t)S.dm.H * S.nd * S.dm.nu * sizeof(double) : 0;
     return std::max(win, pre);
 }
@@ -669,16 +814,15 @@ size_t kkt_dense_workspace_doubles(const NewtonDev& S, bool banded) {
 static int launch_kkt_dense(const NewtonDev& S, const KktArgs& K, double* ws, hipStream_t s, bool banded) {
     if (banded) {
         const size_t lds = banded_lds_bytes(S);
-        static LdsOptIn optin;
-        if (banded_rb(S) == 8) {
-            static LdsOptIn optin8;
-            if (lds_opt_in(optin8, (const void*)kkt_banded_kernel<8>, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
-            hipLaunchKernelGGL(kkt_banded_kernel<8>, dim3(S.nb_launch), dim3(CIMPC_BANDED_THREADS), lds, s, S, K, ws);
-            return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
-        }
-        if (lds_opt_in(optin, (const void*)kkt_banded_kernel<4>, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
-        hipLaunchKernelGGL(kkt_banded_kernel<4>, dim3(S.nb_launch), dim3(CIMPC_BANDED_THREADS), lds, s, S, K, ws);
-        return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+        static LdsOptIn optin[4];      // one per kernel
+        auto go = [&](auto kern, int which) {
+            if (lds_opt_in(optin[which], (const void*)kern, lds) != CIMPC_OK) return (int)CIMPC_ERR_HIP;
+            hipLaunchKernelGGL(kern, dim3(S.nb_launch), dim3(CIMPC_BANDED_THREADS), lds, s, S, K, ws);
+            return hipGetLastError() == hipSuccess ? (int)CIMPC_OK : (int)CIMPC_ERR_HIP;
+        };
+        const bool p2 = banded_pow2(S);
+        if (banded_rb(S) == 8) return p2 ? go(kkt_banded_kernel<8, true>, 0) : go(kkt_banded_kernel<8, false>, 1);
+        return p2 ? go(kkt_banded_kernel<4, true>, 2) : go(kkt_banded_kernel<4, false>, 3);
     }
     hipLaunchKernelGGL(kkt_dense_kernel, dim3(S.nb_launch), dim3(256), 0, s, S, K, ws);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
