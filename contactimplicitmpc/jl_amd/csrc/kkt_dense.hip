@@ -187,13 +187,11 @@ struct BandRows {
     // arithmetic next to the loads the fetching wavefronts sat out a memory latency per block - 3.7 k of 14 k cycles).
     enum : int { CONST = 0, PLAIN = 1, NEG = 2, SUM = 3, C_MINUS = 4, DIFF = 5 };
     //   CONST c   PLAIN x0   NEG -x0   SUM (x0 + x1) + x2   C_MINUS c - x0   DIFF x0 - x1      (absent operands: null pointer, read as 0)
+    // One expression for all of them, ((c + s0 x0) + s1 x1) + x2 with s = -1 / +1 (absent operands and c read as 0: every mode's own
+    // roundings - adding zero is exact) - no branches where sixty-four lanes hold sixty-four different modes.
     static __device__ __forceinline__ double combine(int mode, double c, double x0, double x1, double x2) {
-        if (mode == CONST) return c;
-        if (mode == PLAIN) return x0;
-        if (mode == NEG) return -x0;
-        if (mode == SUM) return (x0 + x1) + x2;
-        if (mode == C_MINUS) return c - x0;
-        return x0 - x1;
+        const double a0 = (mode == NEG || mode == C_MINUS) ? -x0 : x0, a1 = mode == DIFF ? -x1 : x1;
+        return ((c + a0) + a1) + x2;
     }
     // What an entry is depends on (row index in its step, column index in its step, steps between them) only - not on the step:
     // a 32-bit DESCRIPTOR  mode | array << 3 | constant << 6 | offset inside the step's block << 8.  The kernel tabulates the
@@ -398,6 +396,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     // 128 on, at most NE each, and are FETCHED one block ahead (global loads of the sensitivities / weights stay off the critical path).
     constexpr int NE = 2;
     const int EW = w + 2;
+    const bool need2 = RB * EW > (int)blockDim.x - 128;          // (uniform: the second entry per thread exists only for the widest bands)
     struct Pending { double x0, x1, x2, c; int mode; };         // an entry whose loads are in flight
     // entry e of row i = ti s + ki; (tj, kj): its column i - w + e likewise (unused for the right-hand side, e = w + 1).  Loads only.
     auto entry_issue = [&](int mode, int e, int ti, int ki, const double* p0, const double* p1, const double* p2, Pending& P) {
@@ -585,23 +584,12 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         BPROF(1)
         lds_barrier();              // the block's multipliers are in place; the pivots' slots may be overwritten now
         BPROF(2)
-        // ---- P3a: multipliers -> rows of L in global memory (t fastest), right-hand side of the rows below, entering rows ---------------
-        for (int idx = tid; idx < (RB - 1 + w) * RB; idx += nt) {
-            const int q = 1 + idx / RB, t = idx - (idx / RB) * RB, i = k + q;
-            const double* src = q < RB ? L11p + (q * RB + t) : PL + (t * MS + wrap(sk + q));      // (both in LDS: one read)
-            const double v = *src;
-            if (i < N && t < nb_ && t < q && q - t <= w) Lr[i * LW + (w - (q - t))] = v;
-        }
-        if (tid < nb_) { yg[k + tid] = ypvp[tid]; Lr[(k + tid) * LW + w] = dinvp[tid]; }
-        if (tid >= 64 && tid < 64 + w && k + RB + tid - 64 < N) {
-            const int sr = wrap(sk + RB + tid - 64);
-            double yr = yw[sr];
-#pragma unroll
-            for (int t = 0; t < RB; ++t) if (t < nb_) yr = fma(-PL[t * MS + sr], ypvp[t], yr);
-            yw[sr] = yr;
-        }
+        // ---- P3a: entering rows, right-hand side of the rows below, multipliers -> rows of L in global memory (t fastest) ---------------
+        // (the entering rows first: their loads are the oldest memory operations in flight - behind the stores below, the wait for them
+        //  would be a wait for the stores, 2 k cycles per block)
 #pragma unroll
         for (int n = 0; n < NE; ++n) {
+            if (n > 0 && !need2) break;
             if (ent_t[n] >= 0 && ent_t[n] < nb_ && k + Mw + ent_t[n] < N) {      // row k + Mw + t (Mw = M: the slot of pivot k + t)
                 const int si = wrap(sk + Mw + ent_t[n]);
                 const double v = entry_done(nxt[n]);
@@ -609,6 +597,20 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
                 else yw[si] = v;
             }
         }
+        if (tid >= 64 && tid < 64 + w && k + RB + tid - 64 < N) {
+            const int sr = wrap(sk + RB + tid - 64);
+            double yr = yw[sr];
+#pragma unroll
+            for (int t = 0; t < RB; ++t) yr = fma(-PL[t * MS + sr], ypvp[t], yr);      // (rows below exist: the block is complete, nb_ = RB)
+            yw[sr] = yr;
+        }
+        for (int idx = tid; idx < (RB - 1 + w) * RB; idx += nt) {
+            const int q = 1 + idx / RB, t = idx - (idx / RB) * RB, i = k + q;
+            const double* src = q < RB ? L11p + (q * RB + t) : PL + (t * MS + wrap(sk + q));      // (both in LDS: one read)
+            const double v = *src;
+            if (i < N && t < nb_ && t < q && q - t <= w) Lr[i * LW + (w - (q - t))] = v;
+        }
+        if (tid < nb_) { yg[k + tid] = ypvp[tid]; Lr[(k + tid) * LW + w] = dinvp[tid]; }
         BPROF(3)
         // ---- rank-RB update of the lower triangle of the trailing window: 16 x 16 tiles on v_mfma_f64_16x16x4 ------------------------
         const int sb = wrap(sk + nb_);
@@ -654,6 +656,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         // rows entering after the NEXT block: the loads are issued here, in the shadow of P1, and land during the next block's P2
 #pragma unroll
         for (int n = 0; n < NE; ++n) {
+            if (n > 0 && !need2) break;
             if (ent_t[n] >= 0) {
                 nxt[n] = entry_fetch_d(k + RB + Mw + ent_t[n], ent_e[n], eti[n], eki[n], dsc[n]);
                 eki[n] += RB; while (eki[n] >= s) { eki[n] -= s; ++eti[n]; }
