@@ -175,7 +175,8 @@ __global__ __launch_bounds__(256) void kkt_dense_kernel(NewtonDev S, KktArgs K, 
 // backward error 3e-15..3e-14).  One workgroup per rollout; the active (w+1) x (w+1) lower-triangular window of
 // the right-looking elimination lives in LDS (circular row / column slots, no data movement), every matrix row
 // is GENERATED when it enters the window (no assembled matrix in memory), the right-hand side rides along, the
-// rows of L go to a global workspace for the back substitution (one wavefront, axpy form, LDS window).
+// rows of L go to a global workspace for the back substitution (one wavefront, axpy form, sums in registers, rows staged through LDS).
+// Round 4 rebuilt the kernel around its sequential part - see the comments at the block loop and DESIGN.md 5.2c.
 // Work: N w^2 / 2 multiply-adds (centroidal H = 60: 25 M, against (2/3) N^3 = 16 G of the dense LU).
 // ---------------------------------------------------------------------------------------------------------
 namespace {
@@ -508,6 +509,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     // of block k.  P1 needs the next diagonal block and P2 the next pivot columns: the tiles of tile column 0 go first (phase U1, one round
     // of all sixteen wavefronts), the rest (U2) overlaps with P1.  pivots / reciprocals / diagonal block are double-buffered by block parity
     // (U2 of block k still reads d of block k while P1 writes the next).  Per block:  P2 | barrier | P3a + U1 | barrier | P1' || U2 | barrier.
+    // Final (banded_prof_ag.log): 10.8 k cycles per block = 2.6 k + 3.5 k + 4.5 k; every phase but P1 is instruction-issue bound.
     int sk = 0, pb = 0, mt_tab = -1;                             // k % M by counting, parity of the block, the window size the tile table is for
     const int wv = __builtin_amdgcn_readfirstlane(ty);
     auto P1 = [&](int kk, int skk, int par) {                    // lanes 0 .. RB-1 of wavefront 0
