@@ -68,6 +68,9 @@ struct Knobs {
     int waves = 0;               // sweep workgroup size: by batch size
     int kkt_overlap = -1;        // KKT on its own stream next to the sweep: from 64 rollouts on
     int waves32 = 0;             // CIMPC_WAVES32: waves per sweep workgroup of the 32-lane models (0: by batch size; 4 = latency build, 8 = throughput build)
+    int banded_form = 0;         // CIMPC_BANDED_FORM: banded LDL^T variants the sizes in the tree never reach - bit 0: four pivots per block, bit 1: window
+                                 // of w + RB slots instead of the next power of two, bit 2: controls not eliminated (the form a singular R_t
+                                 // falls back to) - tests/test_gpu_round4.py runs every form against form 0
     int sweep_wgs = 0;           // CIMPC_SWEEP_WGS: persistent sweep workgroups (0: computed from the resident set) - sub-batch experiments
     int async_service = 0;       // job-only workgroups of the asynchronous kernel: computed
     int async_flags = 0;         // reserved
@@ -97,6 +100,7 @@ struct Knobs {
         generic_static = env_int("CIMPC_GENERIC_STATIC", generic_static ? 1 : 0) != 0;
         sweep_wgs = env_int("CIMPC_SWEEP_WGS", sweep_wgs);
         waves32 = env_int("CIMPC_WAVES32", waves32);
+        banded_form = env_int("CIMPC_BANDED_FORM", banded_form);
     }
 };
 
@@ -612,6 +616,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         return rc;
     }
     S.Q = h->d_Q; S.R = h->d_R; S.Qinv = h->d_Qinv; S.Rinv = h->d_Rinv; S.Cg = h->d_Cg; S.Cb = h->d_Cb;
+    S.band_form = h->kn.banded_form;
     S.r_tol = h->nt.r_tol; S.beta_init = h->nt.beta_init; S.kappa = h->nt.kappa; S.max_iter = h->nt.max_iter;
     // all-seven-step-lengths speculation: shortens the chain of rollouts that exhaust their line search; pays
     // when the solve is latency-bound (small batches), costs throughput otherwise (B = 2048: -8 %)
@@ -857,7 +862,7 @@ int cimpc_set_objective(cimpc_handle h, const double* Q, const double* R, const 
             r_inverted = false;
         }
     }
-    h->S.band_reduce = (r_inverted && d.nu > 0) ? 1 : 0;      // kkt_dense.hip: kkt_banded_kernel
+    h->S.band_reduce = (r_inverted && d.nu > 0 && (h->kn.banded_form & 4) == 0) ? 1 : 0;      // kkt_dense.hip: kkt_banded_kernel
     HIP_TRY(h, hipMemcpy(h->d_Q, Q, H * d.nq * d.nq * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_R, R, H * d.nu * d.nu * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_Qinv, Qi.data(), Qi.size() * sizeof(double), hipMemcpyHostToDevice));

@@ -796,10 +796,10 @@ static int band_halfwidth(const NewtonDev& S) {      // (the kernel's own formul
     return std::min(3 * s - 1 - S.dm.nu, S.N - 1);
 }
 static int banded_rb(const NewtonDev& S) {      // pivots per window update: 8 where that window fits
-    return banded_lds_bytes(band_halfwidth(S), 8) <= 156 * 1024 ? 8 : 4;
+    return ((S.band_form & 1) == 0 && banded_lds_bytes(band_halfwidth(S), 8) <= 156 * 1024) ? 8 : 4;
 }
 static bool banded_pow2(const NewtonDev& S) {      // power-of-two slot count where THAT window fits
-    return banded_lds_bytes(band_halfwidth(S), banded_rb(S), true) <= 156 * 1024;
+    return (S.band_form & 2) == 0 && banded_lds_bytes(band_halfwidth(S), banded_rb(S), true) <= 156 * 1024;
 }
 static size_t banded_lds_bytes(const NewtonDev& S) {      // ... and, before the window is in use, T = du1 R^-1 of every step ([H][nd x nu])
     const size_t win = banded_lds_bytes(band_halfwidth(S), banded_rb(S), banded_pow2(S));

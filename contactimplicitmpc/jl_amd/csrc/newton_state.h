@@ -67,6 +67,7 @@ struct NewtonDev {
     int* host_flag;    // host-mapped pinned {n_sweep, n_kkt, stamp}
     int round_stamp;   // value published to host_flag[2] when the round is complete
     int band_reduce;   // banded LDL^T backend: 1 = eliminate the controls first (every R_t inverted on the host), 0 = full interleaved form
+    int band_form;     // ... test handle (CIMPC_BANDED_FORM): bit 0 = four pivots per block, bit 1 = no power-of-two padding of the window (bit 2, host only: controls kept)
     long long* stats;  // [B][4] per rollout: sweeps, ip_solves, ip_iters, ip_failures of the running solve, speculative evaluations included
                        // (plain stores of the rollout's decision workgroup - a global counter would be 4 same-line atomics per workgroup; the host sums)
     int* ro_sweeps;    // [B] implicit_dynamics! evaluations of the last solve

@@ -245,3 +245,43 @@ def test_config4_velocity_objective_h60_vs_oracle(gpu_required):
             assert du < 5e-2 and dq < 1e-2, (b, du, dq)
         np.testing.assert_allclose(rn[b], st.r_norm / core.lay.N, rtol=2e-2 if path else 0.15, atol=1e-12)
     assert same >= NB - 1, same
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", [1, 2, 3, 4])
+def test_banded_kernel_forms_agree(gpu_required, monkeypatch, form):
+    """kkt_dense.hip: kkt_banded_kernel is compiled in four forms - eight or four pivots per block, window padded to a power of two or not -
+    and every model in the tree takes the same one (eight, padded).  CIMPC_BANDED_FORM forces the others (read in cimpc_create); each
+    applies the same operations to every entry in the same order, so one KKT solve of BASELINE configs[4] with the example's velocity
+    objective (H = 60, N = 2160 after the control elimination, w = 107) must agree with the default form to the last bit.  Form 4 keeps
+    the controls in the matrix (what a singular R_t falls back to: N = 2880, w = 131 - four pivots per block, unpadded window, four rows
+    per DPP row in P2): another elimination order, compared to 1e-9 of the solution's scale."""
+    import bench
+    from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions
+    H = 60
+    I = bench.centroidal_payload_inputs(2, H)
+    m, P, kappa, ro = I["m"], I["P"], I["kappa"], I["rollouts"][:2]
+    Q, R, V, vt = bench.centroidal_velocity_objective(m, H)
+
+    def solve():
+        s = CIMPCSolver(m.nq, m.nu, m.nw, m.nc, m.nb, P.H, H, B=2, mode=0, ip_opts=InteriorPointOptions(kappa_tol=kappa, r_tol=1e-4),
+                        newton_opts=NewtonOptions(kappa=kappa, r_tol=3e-5, max_iter=5))
+        for t in range(P.H):
+            s.set_linearization(t + 1, P.z[t], P.theta[t], P.r0[t], P.rz0[t], P.rth0[t])
+        s.set_objective(Q, R, V=V, v_target=vt)
+        s.set_window(np.stack([r["window"] for r in ro]) + 1)
+        s.set_reference(*(np.stack([r[k] for r in ro]) for k in ("q", "u", "w", "gamma", "b", "theta")))
+        s.implicit_dynamics(np.stack([r["q"] for r in ro]), np.stack([r["theta"] for r in ro]))
+        d = np.array(s.kkt_solve(np.random.default_rng(0).standard_normal((2, s.N)), 10.0))
+        s.close()
+        return d
+
+    monkeypatch.delenv("CIMPC_BANDED_FORM", raising=False)
+    ref = solve()
+    monkeypatch.setenv("CIMPC_BANDED_FORM", str(form))
+    got = solve()
+    assert np.isfinite(ref).all() and np.abs(ref).max() > 1.0
+    if form < 4:
+        np.testing.assert_array_equal(got, ref)
+    else:
+        assert np.abs(got - ref).max() <= 1e-9 * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
