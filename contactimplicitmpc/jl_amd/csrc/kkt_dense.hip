@@ -796,7 +796,9 @@ static int band_halfwidth(const NewtonDev& S) {      // (the kernel's own formul
     return std::min(3 * s - 1 - S.dm.nu, S.N - 1);
 }
 static int banded_rb(const NewtonDev& S) {      // pivots per window update: 8 where that window fits
-    return ((S.band_form & 1) == 0 && banded_lds_bytes(band_halfwidth(S), 8) <= 156 * 1024) ? 8 : 4;
+    // (P2 has 16 / RB rows per 16 lanes of 1024 threads: 128 rows below a block of eight - the LDS bound (w <= 126) is the tighter one)
+    const int w = band_halfwidth(S);
+    return ((S.band_form & 1) == 0 && w <= 128 && banded_lds_bytes(w, 8) <= 156 * 1024) ? 8 : 4;
 }
 static bool banded_pow2(const NewtonDev& S) {      // power-of-two slot count where THAT window fits
     return (S.band_form & 2) == 0 && banded_lds_bytes(band_halfwidth(S), banded_rb(S), true) <= 156 * 1024;
