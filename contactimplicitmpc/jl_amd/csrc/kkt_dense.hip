@@ -294,8 +294,8 @@ __host__ __device__ inline size_t banded_ws_per_rollout(const NewtonDev& S) {
 }
 
 // -DCIMPC_BANDED_PROF (diagnostic builds, with -DCIMPC_KKT_PROF for the accessor): shader-clock accounting of the banded kernel, rollout 0,
-// per wavefront: [0] pre-pass, window fill, first diagonal block  [1] fetch issue + P2  [2] barrier  [3] stores / rhs / commit
-// [4] U1 tiles  [5] barrier  [6] next diagonal block (wavefront 0) / U2 tiles (the others)  [7] barrier  [8] back substitution  [9] control
+// per wavefront: [0] pre-pass, window fill, first diagonal block  [1] P2  [2] barrier  [3] wavefront 0: tile (0, 0) / the others: entering rows, rhs, stores
+// [4] wavefront 0: next diagonal block / the others: tiles  [5] fetch  [6] barrier  [7] -  [8] back substitution  [9] control
 // recovery; wavefront v -> stats[8 + 10 v ..] (the handle needs B >= 42 rollouts for the room)
 #ifdef CIMPC_BANDED_PROF
 #define BPROF(j) { const long long tn_ = clock64(); bp[j] += tn_ - bt; bt = tn_; }
@@ -354,6 +354,11 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     double* L11 = ypv + 2 * RB;                                  // [2][RB][RB] multipliers among the block's pivot rows (row-major, strictly lower)
     double* nL11 = L11 + 2 * RB * RB;                            // [2][RB + 1][RB] the same negated, and a row of zeros (P2's operand: no selects)
     int* tile_tab = (int*)(nL11 + 2 * (RB + 1) * RB);            // [<= 96] update tiles (I | J << 8), tile column 0 first
+    // parameters of the entering rows' decode, read from LDS by array index (as scalar registers they were spilled: the fetch was 250
+    // instructions, a third of them v_readlane reloads):
+    unsigned long long* f_base = (unsigned long long*)(tile_tab + 96);      // [8] Q, V, G, dz, R (BandRows::AQ ..), then r, g
+    int* f_stride = (int*)(f_base + 8);                          // [8] doubles per step of those arrays
+    double* f_const = (double*)(f_stride + 8);                   // [4] 0, -1, -rho (BandRows::C0 ..)
     const double beta = K.beta ? K.beta[b] : K.beta_scalar;
     const double rho = (double)H * beta * S.kappa;               // newton_jacobian.jl:169-186 quirk
     const double* dzb = kkt_dz(S, K, b, H, S.nths, nd);
@@ -422,14 +427,30 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         entry_issue(mode, e, ti, ki, p0, p1, p2, P);
         return P;
     };
-    // ... of a row past the first w (every column exists), from its tabulated descriptor
+    // ... of a row past the first w (every column exists), from its tabulated descriptor and the parameter block in LDS
     auto entry_fetch_d = [&](int i, int e, int ti, int ki, unsigned d) -> Pending {
         Pending P{0.0, 0.0, 0.0, 0.0, BandRows::CONST};
         if (i >= N) return P;
         const double *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
-        int mode = BandRows::CONST;
-        if (e <= w) mode = row.decode(d, ti, p0, p1, p2, P.c);
-        entry_issue(mode, e, ti, ki, p0, p1, p2, P);
+        int mode;
+        if (e <= w) {
+            mode = d & 7;
+            const int arr = (d >> 3) & 7, st = f_stride[arr], o = __mul24(ti, st) + (int)(d >> 8);
+            P.c = f_const[(d >> 6) & 3];
+            p0 = mode == BandRows::CONST ? nullptr : (const double*)f_base[arr] + o;
+            if (mode == BandRows::SUM) {
+                const double* Vp = (const double*)f_base[BandRows::AV];
+                if (Vp != nullptr) { p1 = Vp + o; if (ti + 1 < H) p2 = p1 + st; }
+            }
+        } else {                                                 // right-hand side (reduced form: the dual rows carry r_d - du1 R^-1 r_u)
+            p0 = (const double*)f_base[5] + (reduced ? (ki < nq ? ti * nr + nu + ki : H * nr + ti * nd + (ki - nq)) : (ki < nr ? ti * nr + ki : H * nr + ti * nd + (ki - nr)));
+            p1 = (reduced && ki >= nq) ? (const double*)f_base[6] + (ti * nd + (ki - nq)) : nullptr;
+            mode = p1 ? BandRows::DIFF : BandRows::PLAIN;
+        }
+        P.mode = mode;
+        if (p0) P.x0 = *p0;
+        if (p1) P.x1 = *p1;
+        if (p2) P.x2 = *p2;
         return P;
     };
     auto entry_fetch = [&](int i, int e) -> Pending {
@@ -452,6 +473,14 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
             d = row.desc(-st, ki, rel - st * s);
         }
         dtab[idx] = d;
+    }
+    if (tid == 0) {
+        f_base[BandRows::AQ] = (unsigned long long)S.Q; f_base[BandRows::AV] = (unsigned long long)S.V;
+        f_base[BandRows::AG] = (unsigned long long)(reduced ? Gm : nullptr); f_base[BandRows::ADZ] = (unsigned long long)dzb;
+        f_base[BandRows::AR] = (unsigned long long)S.R; f_base[5] = (unsigned long long)rb; f_base[6] = (unsigned long long)gv; f_base[7] = 0ull;
+        f_stride[BandRows::AQ] = f_stride[BandRows::AV] = nq * nq; f_stride[BandRows::AG] = nd * nd; f_stride[BandRows::ADZ] = S.nths * nd;
+        f_stride[BandRows::AR] = nu * nu; f_stride[5] = f_stride[6] = f_stride[7] = 0;
+        f_const[BandRows::C0] = 0.0; f_const[BandRows::CM1] = -1.0; f_const[BandRows::CMRHO] = -rho; f_const[3] = 0.0;
     }
     __threadfence_block();
     __syncthreads();
@@ -512,7 +541,11 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     // Final (banded_prof_ag.log): 10.8 k cycles per block = 2.6 k + 3.5 k + 4.5 k; every phase but P1 is instruction-issue bound.
     int sk = 0, pb = 0, mt_tab = -1;                             // k % M by counting, parity of the block, the window size the tile table is for
     const int wv = __builtin_amdgcn_readfirstlane(ty);
-    auto P1 = [&](int kk, int skk, int par) {                    // lanes 0 .. RB-1 of wavefront 0
+    // Round 4, fourth pass: wavefront 0 IS the sequential chain.  After P2 it updates tile (0, 0) - the next diagonal block - and runs the
+    // next P1 straight away (the right-hand side of those eight rows it brings up to date in registers), while the other fifteen do everything
+    // else of the block: entering rows, right-hand side, stores, the other tiles, the fetch.  Two barriers per block:  P2 | chain || bulk |.
+    auto m24 = [](int a_, int b_) { return __mul24(a_, b_); };  // (v_mul_lo_u32 is a quarter-rate instruction; every product here fits 24 x 24 bits)
+    auto P1 = [&](int kk, int skk, int par, bool pending, const double* ypv_cur) {      // lanes 0 .. RB-1 of wavefront 0
         const int nbk = min(RB, N - kk);
         double* dvp = dv + par * RB; double* dinvp = dinv + par * RB; double* ypvp = ypv + par * RB; double* L11p = L11 + par * RB * RB;
         double* nL11p = nL11 + par * (RB + 1) * RB;
@@ -521,8 +554,12 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         const int sr = wrap(skk + r);
         double a[RB];
         double yr = vr ? yw[sr] : 0.0;
+        if (pending) {                                           // the block before this one still owes these rows its right-hand-side update
 #pragma unroll
-        for (int t = 0; t < RB; ++t) a[t] = (vr && t <= r && t < nbk) ? W[sr * MS + wrap(skk + t)] : 0.0;
+            for (int t = 0; t < RB; ++t) yr = fma(-PL[m24(t, MS) + sr], ypv_cur[t], yr);
+        }
+#pragma unroll
+        for (int t = 0; t < RB; ++t) a[t] = (vr && t <= r && t < nbk) ? W[m24(sr, MS) + wrap(skk + t)] : 0.0;
 #pragma unroll
         for (int t = 0; t < RB; ++t) {
             if (t < nbk) {
@@ -537,15 +574,16 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
             }
         }
     };
-    if (tid < RB) P1(0, 0, 0);
+    if (tid < RB) P1(0, 0, 0, false, ypv);
     lds_barrier();
     BPROF(0)
+    const int nbulk = (int)nt - 64, tb = tid - 64;               // the bulk threads: wavefronts 1 .. 15
     for (int k = 0; k < N; k += RB) {
         const int nb_ = min(RB, N - k);                          // pivots of this block
         const double* dvp = dv + pb * RB; const double* dinvp = dinv + pb * RB; const double* ypvp = ypv + pb * RB; const double* L11p = L11 + pb * RB * RB;
         const int base = k + nb_, mt = max(min(w, N - base), 0); // mt rows / columns of the trailing window present
         const int nT = (mt + 15) >> 4, ntiles = nT * (nT + 1) / 2;
-        if (mt != mt_tab) {                                      // tile table (steady state: written once): tile column 0 first, then the rest
+        if (mt != mt_tab) {                                      // tile table (steady state: written once): tile (0, 0) first
             if (tid < ntiles) {
                 int I = tid, J = 0;
                 if (tid >= nT) {
@@ -563,7 +601,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
             const int q = RB + (tid >> 4) * NG + g, i = k + q;
             const bool on = q < RB + w && i < N && t < nb_;
             const int sr = wrap(sk + q);
-            double a = (on && q - t <= w) ? W[sr * MS + wrap(sk + t)] : 0.0;
+            double a = (on && q - t <= w) ? W[m24(sr, MS) + wrap(sk + t)] : 0.0;
             const double inv = dinvp[t], d = dvp[t];
             double lm[NG][RB];                                   // minus the pivot row t's multipliers for the earlier pivots (zero from the
             const double* nL11p = nL11 + pb * (RB + 1) * RB;     // diagonal on) in the column of this lane's row of the DPP row, zero in the others
@@ -581,39 +619,11 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
                 if constexpr (NG == 2) fmac_bcast2<u, RB + u>(a, c, lm[0][u], lm[1][u]);
                 else { fmac_bcast2<u, RB + u>(a, c, lm[0][u], lm[1][u]); fmac_bcast2<2 * RB + u, 3 * RB + u>(a, c, lm[2][u], lm[3][u]); }
             });
-            if (on) PL[t * MS + sr] = a * inv;           // zero where the pivot does not couple
+            if (on) PL[m24(t, MS) + sr] = a * inv;               // zero where the pivot does not couple
         }
         BPROF(1)
         lds_barrier();              // the block's multipliers are in place; the pivots' slots may be overwritten now
         BPROF(2)
-        // ---- P3a: entering rows, right-hand side of the rows below, multipliers -> rows of L in global memory (t fastest) ---------------
-        // (the entering rows first: their loads are the oldest memory operations in flight - behind the stores below, the wait for them
-        //  would be a wait for the stores, 2 k cycles per block)
-#pragma unroll
-        for (int n = 0; n < NE; ++n) {
-            if (n > 0 && !need2) break;
-            if (ent_t[n] >= 0 && ent_t[n] < nb_ && k + Mw + ent_t[n] < N) {      // row k + Mw + t (Mw = M: the slot of pivot k + t)
-                const int si = wrap(sk + Mw + ent_t[n]);
-                const double v = entry_done(nxt[n]);
-                if (ent_e[n] <= w) W[si * MS + wrap(sk + RB + ent_t[n] + ent_e[n])] = v;        // column k + RB + t + e (>= 0)
-                else yw[si] = v;
-            }
-        }
-        if (tid >= 64 && tid < 64 + w && k + RB + tid - 64 < N) {
-            const int sr = wrap(sk + RB + tid - 64);
-            double yr = yw[sr];
-#pragma unroll
-            for (int t = 0; t < RB; ++t) yr = fma(-PL[t * MS + sr], ypvp[t], yr);      // (rows below exist: the block is complete, nb_ = RB)
-            yw[sr] = yr;
-        }
-        for (int idx = tid; idx < (RB - 1 + w) * RB; idx += nt) {
-            const int q = 1 + idx / RB, t = idx - (idx / RB) * RB, i = k + q;
-            const double* src = q < RB ? L11p + (q * RB + t) : PL + (t * MS + wrap(sk + q));      // (both in LDS: one read)
-            const double v = *src;
-            if (i < N && t < nb_ && t < q && q - t <= w) Lr[i * LW + (w - (q - t))] = v;
-        }
-        if (tid < nb_) { yg[k + tid] = ypvp[tid]; Lr[(k + tid) * LW + w] = dinvp[tid]; }
-        BPROF(3)
         // ---- rank-RB update of the lower triangle of the trailing window: 16 x 16 tiles on v_mfma_f64_16x16x4 ------------------------
         const int sb = wrap(sk + nb_);
         const int li = tx & 15, lk = tx >> 4;
@@ -628,46 +638,74 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int rw = 16 * I + lk + 4 * r4;
-                const double* src = W + wrap(sb + min(rw, mt - 1)) * MS + scb;
+                const double* src = W + m24(wrap(sb + min(rw, mt - 1)), MS) + scb;
                 acc[r4] = *src;
-                cell[r4] = (rw < mt && cb_ < mt) ? (double*)src : W + M * MS + li;
+                cell[r4] = (rw < mt && cb_ < mt) ? (double*)src : W + m24(M, MS) + li;
             }
 #pragma unroll
             for (int kb = 0; kb < RB / 4; ++kb) {
                 const int t = 4 * kb + lk;
-                const double av = -(PL[t * MS + sra] * dvp[t]);
-                const double bv = PL[t * MS + scb];
+                const double av = -(PL[m24(t, MS) + sra] * dvp[t]);
+                const double bv = PL[m24(t, MS) + scb];
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
             }
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) *cell[r4] = acc[r4];
         };
-        int n1 = nty * ((nT + nty - 1) / nty);                   // U1: tile column 0 and company, whole rounds; U2: two rounds at most
-        const int nu2 = nty - (nty + 3) / 4;                     // wavefronts of U2: those that do not share wavefront 0's SIMD (wave v -> SIMD v % 4)
-        { const int alt = ntiles - 2 * nu2; if (alt > n1) n1 = nty * ((alt + nty - 1) / nty); }
-        n1 = min(n1, ntiles);
-        for (int tl = wv; tl < n1; tl += nty) tile(tl);
-        BPROF(4)
-        lds_barrier();
-        BPROF(5)
         const int skn = wrap(sk + RB);
-        if (k + RB < N) {
-            if (tid < RB) P1(k + RB, skn, pb ^ 1);
-            else if ((wv & 3) != 0) for (int tl = n1 + (wv >> 2) * 3 + (wv & 3) - 1; tl < ntiles; tl += nu2) tile(tl);
-        }
-        // rows entering after the NEXT block: the loads are issued here, in the shadow of P1, and land during the next block's P2
+        if (wv == 0) {              // ---- the chain: the next diagonal block's tile, then the next diagonal block
+            if (mt > 0) tile(0);
+            BPROF(3)
+            if (k + RB < N && tid < RB) P1(k + RB, skn, pb ^ 1, true, ypvp);
+            BPROF(4)
+        } else {                    // ---- the bulk
+            // entering rows first: their loads are the oldest memory operations in flight (behind the stores below, the wait for them would
+            // be a wait for the stores)
 #pragma unroll
-        for (int n = 0; n < NE; ++n) {
-            if (n > 0 && !need2) break;
-            if (ent_t[n] >= 0) {
-                nxt[n] = entry_fetch_d(k + RB + Mw + ent_t[n], ent_e[n], eti[n], eki[n], dsc[n]);
-                eki[n] += RB; while (eki[n] >= s) { eki[n] -= s; ++eti[n]; }
-                dsc[n] = dtab[eki[n] * EW + ent_e[n]];
+            for (int n = 0; n < NE; ++n) {
+                if (n > 0 && !need2) break;
+                if (ent_t[n] >= 0 && ent_t[n] < nb_ && k + Mw + ent_t[n] < N) {      // row k + Mw + t (Mw = M: the slot of pivot k + t)
+                    const int si = wrap(sk + Mw + ent_t[n]);
+                    const double v = entry_done(nxt[n]);
+                    if (ent_e[n] <= w) W[m24(si, MS) + wrap(sk + RB + ent_t[n] + ent_e[n])] = v;       // column k + RB + t + e (>= 0)
+                    else yw[si] = v;
+                }
+            }
+            // right-hand side of the rows below the block - but for the next block's pivot rows: wavefront 0 keeps those to itself
+            if (tb >= RB && tb < w && k + RB + tb < N) {
+                const int sr = wrap(sk + RB + tb);
+                double yr = yw[sr];
+#pragma unroll
+                for (int t = 0; t < RB; ++t) yr = fma(-PL[m24(t, MS) + sr], ypvp[t], yr);      // (rows below exist: the block is complete, nb_ = RB)
+                yw[sr] = yr;
+            }
+            for (int idx = tb; idx < (RB - 1 + w) * RB; idx += nbulk) {      // multipliers -> rows of L in global memory, t fastest
+                const int q = 1 + idx / RB, t = idx - (idx / RB) * RB, i = k + q;
+                const double* src = q < RB ? L11p + (q * RB + t) : PL + (m24(t, MS) + wrap(sk + q));      // (both in LDS: one read)
+                const double v = *src;
+                if (i < N && t < nb_ && t < q && q - t <= w) Lr[m24(i, LW) + (w - (q - t))] = v;
+            }
+            if (tb < nb_) { yg[k + tb] = ypvp[tb]; Lr[m24(k + tb, LW) + w] = dinvp[tb]; }
+            BPROF(3)
+            // tiles 1 .. : the wavefronts that share wavefront 0's SIMD (4, 8, 12: wave v runs on SIMD v % 4) come last in the round-robin -
+            // with 27 tiles on 15 wavefronts they take one tile each, the others two
+            const int rank = (wv & 3) != 0 ? (wv >> 2) * 3 + (wv & 3) - 1 : (nty - nty / 4) + (wv >> 2) - 1;
+            for (int tl = 1 + rank; tl < ntiles; tl += nty - 1) tile(tl);
+            BPROF(4)
+            // rows entering after the NEXT block: the loads are issued here and land during the next block's P2
+#pragma unroll
+            for (int n = 0; n < NE; ++n) {
+                if (n > 0 && !need2) break;
+                if (ent_t[n] >= 0) {
+                    nxt[n] = entry_fetch_d(k + RB + Mw + ent_t[n], ent_e[n], eti[n], eki[n], dsc[n]);
+                    eki[n] += RB; while (eki[n] >= s) { eki[n] -= s; ++eti[n]; }
+                    dsc[n] = dtab[eki[n] * EW + ent_e[n]];
+                }
             }
         }
-        BPROF(6)
+        BPROF(5)
         lds_barrier();
-        BPROF(7)
+        BPROF(6)
         sk = skn; pb ^= 1;
     }
     __syncthreads();              // full barrier: the rows of L and y in global memory are read back below
@@ -682,7 +720,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     double* D = K.delta + (size_t)b * S.N;
     {
         constexpr int RS = 194;                                  // staged row: [3][64] values, 1/d, y
-        const int avail = MS * MS + MS + RB * MS + 2 * (3 * RB + RB * RB + (RB + 1) * RB) + 48;      // doubles of LDS the window held
+        const int avail = MS * MS + MS + RB * MS + 2 * (3 * RB + RB * RB + (RB + 1) * RB) + 64;      // doubles of LDS the window held
         int CR = avail / (2 * RS); if (CR > 64) CR = 64;
         const int nch = (N + CR - 1) / CR, CS = CR * RS;
         auto stage = [&](int ch, int t0, int nth) {              // chunk ch = rows N-1 - ch CR downwards -> buffer ch & 1  (threads t0 .. of nth)
@@ -787,7 +825,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
 
 static size_t banded_lds_bytes_slots(int slots, int rb) {      // window (slots + dummy)^2, right-hand side, rb multiplier rows, 2 x (pivots / reciprocals / rhs, diagonal block), tile table
     const size_t MS = (size_t)slots + 1;
-    return (MS * MS + MS + (size_t)rb * MS + 2 * (3 * (size_t)rb + (size_t)rb * rb + ((size_t)rb + 1) * rb) + 48) * sizeof(double);
+    return (MS * MS + MS + (size_t)rb * MS + 2 * (3 * (size_t)rb + (size_t)rb * rb + ((size_t)rb + 1) * rb) + 64) * sizeof(double);
 }
 static size_t banded_lds_bytes(int w, int rb = 4, bool pow2 = false) { return banded_lds_bytes_slots(pow2 ? banded_pow2_slots(w + rb) : w + rb, rb); }
 static int band_halfwidth(const NewtonDev& S) {      // (the kernel's own formula: reduced form when the controls are eliminated)

@@ -25,7 +25,7 @@ lib.cimpc_debug_read_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_
 out = (C.c_longlong * 168)()
 lib.cimpc_debug_read_stats(s.h, out, 168)
 v = np.array(list(out), dtype=np.float64)[8:].reshape(16, 10) / 1e3
-names0 = ["pre+fill+P1(0)", "P2", "barrier Z", "stores/rhs/commit", "U1 tiles", "barrier X", "P1'|U2+fetch", "barrier Y", "back subst", "recovery"]
+names0 = ["pre+fill+P1(0)", "P2", "barrier", "tile00 | rows/rhs/stores", "P1 next | tiles", "fetch", "barrier", "-", "back subst", "recovery"]
 print("k-cycles per phase (rollout 0 of 64), one row per wavefront; total of wavefront 0: %.1f" % v[0].sum())
 print("wave " + " ".join("%17s" % n for n in names0))
 for wv_ in range(16):
