@@ -322,8 +322,11 @@ __device__ __forceinline__ void fmac_bcast2(double& a, double c, double l0, doub
 // POW2: the window has a power-of-two number of slots (where that fits the LDS): a slot index wraps with one AND instead of two
 // compare-subtract pairs - the wraps are a sixth of the instructions of a block, and every phase but P1 is issue-bound.
 __host__ __device__ inline int banded_pow2_slots(int extent) { int p = 1; while (p < extent) p <<= 1; return p; }
-template <int RB, bool POW2>
+// SLOTS: that power of two as a compile-time constant (32 / 64 / 128: every LDS offset and the row stride SLOTS + 1 fold into the
+// instructions - fewer scalar registers to spill, shift-adds for the addresses), -1: power of two known at run time, 0: w + RB slots.
+template <int RB, int SLOTS>
 __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(NewtonDev S, KktArgs K, double* ws_all) {
+    constexpr bool POW2 = SLOTS != 0;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int b = blockIdx.x + S.b0, tid = threadIdx.x, nt = blockDim.x;
     if (K.stage != nullptr && K.stage[b] != STAGE_KKT) return;
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     const int s = reduced ? nq + nd : nr + nd, N = H * s;
     const int w = min(reduced ? 3 * s - 1 : 3 * s - 1 - nu, N - 1), LW = w + 1;
     const int Mw = w + RB;                                       // rows in the window: pivot k+RB-1 reaches row k+RB-1+w
-    const int M = POW2 ? banded_pow2_slots(Mw) : Mw;             // slots (index mod M)
+    const int M = SLOTS > 0 ? SLOTS : (POW2 ? banded_pow2_slots(Mw) : Mw);      // slots (index mod M)
     double* wsb = ws_all + (size_t)b * banded_ws_per_rollout(S);
     double* Lr = wsb;                                            // row i: L[i][i-w .. i-1], slot w: 1 / d_i
     double* yg = Lr + (size_t)N * LW;
@@ -859,15 +862,21 @@ size_t kkt_dense_workspace_doubles(const NewtonDev& S, bool banded) {
 static int launch_kkt_dense(const NewtonDev& S, const KktArgs& K, double* ws, hipStream_t s, bool banded) {
     if (banded) {
         const size_t lds = banded_lds_bytes(S);
-        static LdsOptIn optin[4];      // one per kernel
+        static LdsOptIn optin[7];      // one per kernel
         auto go = [&](auto kern, int which) {
             if (lds_opt_in(optin[which], (const void*)kern, lds) != CIMPC_OK) return (int)CIMPC_ERR_HIP;
             hipLaunchKernelGGL(kern, dim3(S.nb_launch), dim3(CIMPC_BANDED_THREADS), lds, s, S, K, ws);
             return hipGetLastError() == hipSuccess ? (int)CIMPC_OK : (int)CIMPC_ERR_HIP;
         };
         const bool p2 = banded_pow2(S);
-        if (banded_rb(S) == 8) return p2 ? go(kkt_banded_kernel<8, true>, 0) : go(kkt_banded_kernel<8, false>, 1);
-        return p2 ? go(kkt_banded_kernel<4, true>, 2) : go(kkt_banded_kernel<4, false>, 3);
+        const int slots = p2 ? banded_pow2_slots(band_halfwidth(S) + banded_rb(S)) : 0;
+        if (banded_rb(S) == 8) {
+            if (slots == 128) return go(kkt_banded_kernel<8, 128>, 4);
+            if (slots == 64) return go(kkt_banded_kernel<8, 64>, 5);
+            if (slots == 32) return go(kkt_banded_kernel<8, 32>, 6);
+            return p2 ? go(kkt_banded_kernel<8, -1>, 0) : go(kkt_banded_kernel<8, 0>, 1);
+        }
+        return p2 ? go(kkt_banded_kernel<4, -1>, 2) : go(kkt_banded_kernel<4, 0>, 3);
     }
     hipLaunchKernelGGL(kkt_dense_kernel, dim3(S.nb_launch), dim3(256), 0, s, S, K, ws);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
