@@ -303,8 +303,10 @@ __host__ __device__ inline size_t banded_ws_per_rollout(const NewtonDev& S) {
 #define BPROF(j)
 #endif
 #ifndef CIMPC_BANDED_THREADS
-#define CIMPC_BANDED_THREADS 1024      // (build parameter: 256 / 512 / 1024 measured in round 4)
+#define CIMPC_BANDED_THREADS 1024      // (256 / 512 / 1024 measured on the round-3 form)
 #endif
+static_assert(CIMPC_BANDED_THREADS == 1024, "the block phases are laid out for sixteen wavefronts: P2 covers 1024 / 16 x (16 / RB) rows below a block, "
+                                            "wavefront 0 is the chain, wavefronts 1 .. 15 the bulk");
 // RB: pivots per window update (4, or 8 where the window of w + 8 slots fits the LDS: the reduced form of every compiled model).  The
 // per-entry cost of an update pass is index arithmetic and LDS traffic, not its RB multiply-adds (profiles/r04/banded_prof_before.log:
 // update + its barrier 43 % of a solve, 7-8 k cycles per pass at RB = 4), so half as many passes are worth the deeper panel.  Every entry
