@@ -582,7 +582,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     if (tid < RB) P1(0, 0, 0, false, ypv);
     lds_barrier();
     BPROF(0)
-    const int nbulk = (int)nt - 64, tb = tid - 64;               // the bulk threads: wavefronts 1 .. 15
+    const int tb = tid - 64;             // the bulk threads: wavefronts 1 .. 15
     for (int k = 0; k < N; k += RB) {
         const int nb_ = min(RB, N - k);                          // pivots of this block
         const double* dvp = dv + pb * RB; const double* dinvp = dinv + pb * RB; const double* ypvp = ypv + pb * RB; const double* L11p = L11 + pb * RB * RB;
@@ -624,7 +624,12 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
                 if constexpr (NG == 2) fmac_bcast2<u, RB + u>(a, c, lm[0][u], lm[1][u]);
                 else { fmac_bcast2<u, RB + u>(a, c, lm[0][u], lm[1][u]); fmac_bcast2<2 * RB + u, 3 * RB + u>(a, c, lm[2][u], lm[3][u]); }
             });
-            if (on) PL[m24(t, MS) + sr] = a * inv;               // zero where the pivot does not couple
+            const double lv = a * inv;                           // zero where the pivot does not couple
+            if (on) PL[m24(t, MS) + sr] = lv;
+            // ... and into row i of L in global memory: the RB lanes of a row write one contiguous piece (the rows of the diagonal block
+            // follow from the bulk).  Nothing waits for these stores: the bulk commits its entering rows - the only wait for memory in
+            // the loop - after its tiles.
+            if (on && q - t <= w) Lr[m24(i, LW) + (w - (q - t))] = lv;
         }
         BPROF(1)
         lds_barrier();              // the block's multipliers are in place; the pivots' slots may be overwritten now
@@ -664,8 +669,26 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
             if (k + RB < N && tid < RB) P1(k + RB, skn, pb ^ 1, true, ypvp);
             BPROF(4)
         } else {                    // ---- the bulk
-            // entering rows first: their loads are the oldest memory operations in flight (behind the stores below, the wait for them would
-            // be a wait for the stores)
+            // right-hand side of the rows below the block - but for the next block's pivot rows: wavefront 0 keeps those to itself
+            if (tb >= RB && tb < w && k + RB + tb < N) {
+                const int sr = wrap(sk + RB + tb);
+                double yr = yw[sr];
+#pragma unroll
+                for (int t = 0; t < RB; ++t) yr = fma(-PL[m24(t, MS) + sr], ypvp[t], yr);      // (rows below exist: the block is complete, nb_ = RB)
+                yw[sr] = yr;
+            }
+            if (tb < (RB - 1) * RB) {                            // the diagonal block's multipliers -> rows of L (P2 stored those of the rows below)
+                const int q = 1 + tb / RB, t = tb - (tb / RB) * RB;
+                if (k + q < N && t < nb_ && t < q) Lr[m24(k + q, LW) + (w - (q - t))] = L11p[q * RB + t];
+            }
+            if (tb >= 64 && tb < 64 + nb_) { yg[k + tb - 64] = ypvp[tb - 64]; Lr[m24(k + tb - 64, LW) + w] = dinvp[tb - 64]; }
+            BPROF(3)
+            // tiles 1 .. : the wavefronts that share wavefront 0's SIMD (4, 8, 12: wave v runs on SIMD v % 4) come last in the round-robin -
+            // with 27 tiles on 15 wavefronts they take one tile each, the others two
+            const int rank = (wv & 3) != 0 ? (wv >> 2) * 3 + (wv & 3) - 1 : (nty - nty / 4) + (wv >> 2) - 1;
+            for (int tl = 1 + rank; tl < ntiles; tl += nty - 1) tile(tl);
+            BPROF(4)
+            // entering rows: their loads were issued a block ago; by now the stores of P2 that stand behind them in the memory queue are done
 #pragma unroll
             for (int n = 0; n < NE; ++n) {
                 if (n > 0 && !need2) break;
@@ -676,27 +699,6 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
                     else yw[si] = v;
                 }
             }
-            // right-hand side of the rows below the block - but for the next block's pivot rows: wavefront 0 keeps those to itself
-            if (tb >= RB && tb < w && k + RB + tb < N) {
-                const int sr = wrap(sk + RB + tb);
-                double yr = yw[sr];
-#pragma unroll
-                for (int t = 0; t < RB; ++t) yr = fma(-PL[m24(t, MS) + sr], ypvp[t], yr);      // (rows below exist: the block is complete, nb_ = RB)
-                yw[sr] = yr;
-            }
-            for (int idx = tb; idx < (RB - 1 + w) * RB; idx += nbulk) {      // multipliers -> rows of L in global memory, t fastest
-                const int q = 1 + idx / RB, t = idx - (idx / RB) * RB, i = k + q;
-                const double* src = q < RB ? L11p + (q * RB + t) : PL + (m24(t, MS) + wrap(sk + q));      // (both in LDS: one read)
-                const double v = *src;
-                if (i < N && t < nb_ && t < q && q - t <= w) Lr[m24(i, LW) + (w - (q - t))] = v;
-            }
-            if (tb < nb_) { yg[k + tb] = ypvp[tb]; Lr[m24(k + tb, LW) + w] = dinvp[tb]; }
-            BPROF(3)
-            // tiles 1 .. : the wavefronts that share wavefront 0's SIMD (4, 8, 12: wave v runs on SIMD v % 4) come last in the round-robin -
-            // with 27 tiles on 15 wavefronts they take one tile each, the others two
-            const int rank = (wv & 3) != 0 ? (wv >> 2) * 3 + (wv & 3) - 1 : (nty - nty / 4) + (wv >> 2) - 1;
-            for (int tl = 1 + rank; tl < ntiles; tl += nty - 1) tile(tl);
-            BPROF(4)
             // rows entering after the NEXT block: the loads are issued here and land during the next block's P2
 #pragma unroll
             for (int n = 0; n < NE; ++n) {
