@@ -525,30 +525,26 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         if constexpr (POW2) return x & (M - 1);
         else { if (x >= M) x -= M; if (x >= M) x -= M; return x; }
     };
-    // Round 4 (second pass): a block of RB pivots is
-    //   P1  lanes 0 .. RB-1 of wavefront 0: the RB x RB diagonal block - pivots, reciprocals, the multipliers among the pivot rows, the
-    //       forward substitution among them (lane r owns pivot row r, right-looking, hand-overs by v_readlane, no branches, no global
-    //       stores) - the only sequential part;
-    //   P2  RB lanes per row below the block (lane t owns the row's entry in pivot column t): the triangular solve against the diagonal
-    //       block runs ACROSS the lanes - per pivot u two multiplies, a DPP row broadcast of l_u d_u and one multiply-add;
-    //   P3  all threads: the multipliers go to global memory (RB lanes write one row's contiguous piece), the right-hand side of the rows
-    //       below is updated, the entering rows are committed, and the lower triangle of the trailing window gets its rank-RB update
-    //       as 16 x 16 tiles on v_mfma_f64_16x16x4 (A = -(l d) of the tile's rows, B = l of its columns, K = RB).
-    // P1 / P2 apply the same operations to every entry in the same order as the one-pivot-at-a-time form.  Three LDS-only barriers per block.
-    // History (cycles per block of 8 pivots, w = 107): round-4 first form 42 k (banded_prof_rb8_regpanel.log) - the panel of all 115 rows on
-    // one wavefront 12.5 k, its scattered 8-byte stores draining at the next barrier 7.8 k, an LDS-bound update of both triangles 15 k;
-    // split into P1 / P2 / P3 with a register-tiled VALU update 27 k (banded_prof_split.log: P1 10.5 k - integer divisions for the slots,
-    // a branch per predicate -, P2 3.5 k, update 7.6 k).
-    // Look-ahead (round 4, third pass): the sequential part P1 of block k + RB runs on wavefront 0 WHILE the other fifteen finish the update
-    // of block k.  P1 needs the next diagonal block and P2 the next pivot columns: the tiles of tile column 0 go first (phase U1, one round
-    // of all sixteen wavefronts), the rest (U2) overlaps with P1.  pivots / reciprocals / diagonal block are double-buffered by block parity
-    // (U2 of block k still reads d of block k while P1 writes the next).  Per block:  P2 | barrier | P3a + U1 | barrier | P1' || U2 | barrier.
-    // Final (banded_prof_ag.log): 10.8 k cycles per block = 2.6 k + 3.5 k + 4.5 k; every phase but P1 is instruction-issue bound.
+    // A block of RB pivots (round 4; DESIGN.md 5.2c has the path here with the phase clocks of every step):
+    //   P2   all sixteen wavefronts, RB lanes per row below the block (lane t owns the row's entry in pivot column t): the triangular solve
+    //        against the diagonal block runs ACROSS the lanes - per pivot u two multiplies and one fused multiply-add whose DPP source is the
+    //        row broadcast of l_u d_u; the lanes store their multipliers into LDS (PL) and into the row of L in global memory;
+    //   barrier
+    //   chain (wavefront 0):  tile (0, 0) of the update - the next diagonal block -, then P1 of the NEXT block on lanes 0 .. RB-1: pivots,
+    //        reciprocals, the multipliers among the pivot rows, the forward substitution among them (lane r owns pivot row r, right-looking,
+    //        hand-overs by v_readlane, no branches, no global stores) - the only sequential part of the factorisation;
+    //   bulk (wavefronts 1 .. 15), beside the chain:  right-hand side of the rows below, the other tiles of the rank-RB update of the lower
+    //        triangle (16 x 16 tiles on v_mfma_f64_16x16x4: A = -(l d) of the tile's rows, B = l of its columns, K = RB), the entering rows
+    //        committed, the next ones fetched;
+    //   barrier
+    // pivots / reciprocals / diagonal block are double-buffered by block parity (the bulk of block k reads d of block k while the chain writes
+    // the next).  Every entry receives the same operations in the same order as in the one-pivot-at-a-time form of round 3: the factors are
+    // bit-identical to it (scripts/dbg/banded_cmp.py).  Cycles per block of 8 pivots (w = 107), as the forms came: one-wave panel of all rows
+    // 42 k; P1 / P2 / P3 split 27 k; MFMA tiles, DPP solve, slots by counting 13.4 k; look-ahead in three phases 10.8 k; chain beside bulk,
+    // compile-time window, stores from P2 7.9 k - of which the P2 phase 1.8 k, the chain 4.9 k beside an issue-bound bulk of 6.1 k.
     int sk = 0, pb = 0, mt_tab = -1;                             // k % M by counting, parity of the block, the window size the tile table is for
     const int wv = __builtin_amdgcn_readfirstlane(ty);
-    // Round 4, fourth pass: wavefront 0 IS the sequential chain.  After P2 it updates tile (0, 0) - the next diagonal block - and runs the
-    // next P1 straight away (the right-hand side of those eight rows it brings up to date in registers), while the other fifteen do everything
-    // else of the block: entering rows, right-hand side, stores, the other tiles, the fetch.  Two barriers per block:  P2 | chain || bulk |.
+    // (the chain brings the right-hand side of the next block's eight pivot rows up to date in registers: `pending`)
     auto m24 = [](int a_, int b_) { return __mul24(a_, b_); };  // (v_mul_lo_u32 is a quarter-rate instruction; every product here fits 24 x 24 bits)
     auto P1 = [&](int kk, int skk, int par, bool pending, const double* ypv_cur) {      // lanes 0 .. RB-1 of wavefront 0
         const int nbk = min(RB, N - kk);
