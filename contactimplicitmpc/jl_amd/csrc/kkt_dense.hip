@@ -541,7 +541,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     // the next).  Every entry receives the same operations in the same order as in the one-pivot-at-a-time form of round 3: the factors are
     // bit-identical to it (scripts/dbg/banded_cmp.py).  Cycles per block of 8 pivots (w = 107), as the forms came: one-wave panel of all rows
     // 42 k; P1 / P2 / P3 split 27 k; MFMA tiles, DPP solve, slots by counting 13.4 k; look-ahead in three phases 10.8 k; chain beside bulk,
-    // compile-time window, stores from P2 7.9 k - of which the P2 phase 1.8 k, the chain 4.9 k beside an issue-bound bulk of 6.1 k.
+    // compile-time window, stores from P2 8.3 k - of which the P2 phase 2.1 k, the chain 5.0 k beside an issue-bound bulk of 6.2 k.
     int sk = 0, pb = 0, mt_tab = -1;                             // k % M by counting, parity of the block, the window size the tile table is for
     const int wv = __builtin_amdgcn_readfirstlane(ty);
     // (the chain brings the right-hand side of the next block's eight pivot rows up to date in registers: `pending`)
