@@ -5,7 +5,10 @@
 as L D L^T without pivoting, with a sliding (w + R) x (w + R) window in circular slots and R pivots per window update.
 This module states the same algorithm in numpy - same slot logic, same order of operations per entry - so that the
 structure (bandwidth, quasi-definiteness, blocked update) is checked on the CPU; the device kernel is compared with
-numpy's dense solve in tests/test_gpu_parity.py."""
+numpy's dense solve in tests/test_gpu_parity.py.  Round 4 (second half of the file): the control elimination the kernel starts with
+(`eliminate_controls`, `half_bandwidth_reduced`) and the organisation of a block as diagonal block / rows below / lower-triangle update in
+a power-of-two window (`chain_bulk_ldl_solve`), checked against the dense solve and the one-panel form in
+tests/test_oracle_reference_constructions.py::test_banded_ldl_control_elimination_and_chain_form."""
 import numpy as np
 
 
@@ -77,6 +80,114 @@ def blocked_ldl_solve(A, b, w, R=4):
         for t in range(Rb):
             commit(k + M + t)
         k += Rb
+    x = np.zeros(N); acc = np.zeros(N)
+    for i in range(N - 1, -1, -1):
+        x[i] = yg[i] * Lr[i, w] - acc[i]
+        for c in range(w):
+            j = i - w + c
+            if j >= 0:
+                acc[j] += Lr[i, c] * x[i]
+    return x, lmax
+
+
+# ---- round 4: the forms the device kernel takes today -----------------------------------------------------------
+
+def reduced_perm(lay, d):
+    """reference layout -> (kept, u): kept = interleaved [q_{i+2}, nu_i] per step (cf mode: the whole z_i block but u_i), u = the controls"""
+    H, nr, nd, nu = lay.H, d.nr, d.nd, d.nu
+    kept, us = [], []
+    for t in range(H):
+        us += list(range(t * nr, t * nr + nu))
+        kept += list(range(t * nr + nu, (t + 1) * nr)) + list(range(H * nr + t * nd, H * nr + (t + 1) * nd))
+    return np.array(kept), np.array(us)
+
+
+def half_bandwidth_reduced(d):
+    """s = nr - nu + nd rows per step, row nu_i still reaches back to q_i of step i - 2"""
+    return 3 * (d.nr - d.nu + d.nd) - 1
+
+
+def eliminate_controls(R, r, lay, d):
+    """u_i appears in its own block only (R_i, and du1_i in the row of nu_i): the Schur complement on the controls changes the
+    nu_i x nu_i blocks and nothing else.  Returns (A_red, r_red, recover) with recover(x_kept) -> the solution in the reference layout."""
+    kept, us = reduced_perm(lay, d)
+    Auu = R[np.ix_(us, us)]; Aku = R[np.ix_(kept, us)]
+    Ai = np.linalg.inv(Auu)
+    A_red = R[np.ix_(kept, kept)] - Aku @ Ai @ Aku.T
+    r_red = r[kept] - Aku @ (Ai @ r[us])
+
+    def recover(xk):
+        x = np.zeros(lay.N)
+        x[kept] = xk
+        x[us] = Ai @ (r[us] - Aku.T @ xk)
+        return x
+    return A_red, r_red, recover
+
+
+def chain_bulk_ldl_solve(A, b, w, RB=8):
+    """The factorisation as kkt_banded_kernel organises it since round 4, in numpy: per block of RB pivots the RB x RB diagonal block
+    first (pivots, the multipliers among the pivot rows, the forward substitution among them - the device's P1), then for every row
+    below the block its RB multipliers by a triangular solve against the diagonal block (P2), then the rank-RB update of the LOWER
+    triangle of the trailing window (the device's MFMA tiles); window of the next power of two >= w + RB slots.  Every entry
+    receives the same operations in the same order as in `blocked_ldl_solve`.  Returns (x, max |L|)."""
+    N = len(b); Mw = w + RB
+    M = 1
+    while M < Mw:
+        M <<= 1
+    W = np.zeros((M, M)); yw = np.zeros(M)
+    Lr = np.zeros((N, w + 1)); yg = np.zeros(N)
+
+    def commit(i):
+        if i < N:
+            for c in range(w + 1):
+                j = i - w + c
+                if j >= 0:
+                    W[i % M, j % M] = A[i, j]                    # lower triangle only: i >= j
+            yw[i % M] = b[i]
+
+    for i in range(min(Mw, N)):
+        commit(i)
+    lmax = 0.0
+    for k in range(0, N, RB):
+        nb = min(RB, N - k)
+        # P1: diagonal block, right-looking
+        a = np.array([[W[(k + r) % M, (k + t) % M] if t <= r else 0.0 for t in range(nb)] for r in range(nb)])
+        yr = np.array([yw[(k + r) % M] for r in range(nb)])
+        L11 = np.zeros((nb, nb)); dv = np.zeros(nb); yp = np.zeros(nb)
+        for t in range(nb):
+            dv[t] = a[t, t]; yp[t] = yr[t]
+            for r in range(t + 1, nb):
+                L11[r, t] = a[r, t] / dv[t]
+                yr[r] -= L11[r, t] * yp[t]
+            for t2 in range(t + 1, nb):
+                for r in range(t2, nb):
+                    a[r, t2] -= (L11[r, t] * dv[t]) * L11[t2, t]
+            yg[k + t] = yp[t]; Lr[k + t, w] = 1.0 / dv[t]
+            for r in range(t + 1, nb):
+                Lr[k + r, w - (r - t)] = L11[r, t]; lmax = max(lmax, abs(L11[r, t]))
+        # P2: rows below the block
+        rows = range(k + nb, min(N, k + nb + w))
+        PL = {}
+        for i in rows:
+            q = i - k
+            l = np.zeros(nb)
+            for t in range(nb):
+                if q - t <= w:
+                    v = W[i % M, (k + t) % M]
+                    for u in range(t):
+                        v -= (l[u] * dv[u]) * L11[t, u]
+                    l[t] = v / dv[t]
+                    Lr[i, w - (q - t)] = l[t]; lmax = max(lmax, abs(l[t]))
+            PL[i] = l
+            for t in range(nb):
+                yw[i % M] -= l[t] * yp[t]
+        # update of the lower triangle of the trailing window, entering rows
+        for i in rows:
+            for j in rows:
+                if j <= i:
+                    W[i % M, j % M] -= sum((PL[i][t] * dv[t]) * PL[j][t] for t in range(nb))
+        for t in range(nb):
+            commit(k + Mw + t)
     x = np.zeros(N); acc = np.zeros(N)
     for i in range(N - 1, -1, -1):
         x[i] = yg[i] * Lr[i, w] - acc[i]

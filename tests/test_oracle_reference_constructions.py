@@ -238,3 +238,48 @@ def test_interleaved_banded_ldl(model, velocity):
     back = np.abs(A @ x - r[p]).max() / (np.abs(A).sum(axis=1).max() * np.abs(x).max() + np.abs(r).max())
     assert back < 1e-12 and lmax < 1e5
     np.testing.assert_allclose(x, xs, rtol=0, atol=1e-11 * np.linalg.cond(A) * max(1.0, np.abs(xs).max()))
+
+
+@pytest.mark.parametrize("model,velocity", [("hopper", True), ("quadruped", True), ("quadruped", False)])
+def test_banded_ldl_control_elimination_and_chain_form(model, velocity):
+    """The two things round 4 changed in the banded KKT backend, on the oracle's jacobian!:
+    (1) the controls are eliminated first - u_i sits in its own block only, so the Schur complement on the controls touches the
+    nu_i x nu_i blocks and nothing else, the kept matrix [q_{i+2}, nu_i] per step is still quasi-definite with half-bandwidth
+    3 (nr - nu + nd) - 1, and the recovered solution is the dense one;
+    (2) the factorisation is organised as diagonal block / rows below / lower-triangle update per eight pivots in a power-of-two
+    window (oracle/banded.py: chain_bulk_ldl_solve) - the same factors as the one-panel form."""
+    from oracle import banded
+    from oracle.dims import HOPPER_2D as HP
+    d = Dims(**(HP if model == "hopper" else QUADRUPED))
+    H = 5
+    prob = synth.make_problem(d, 7, seed=4)
+    tabs = [lcp.LinTable(d, prob["z0"][t], prob["th0"][t], prob["r0"][t], prob["rz0"][t], prob["rth0"][t]) for t in range(7)]
+    window, ref, q0, q1 = synth.make_rollout(d, prob, H, phase=1, seed=3, perturb=1e-2)
+    tr = ref.copy(); tr.q[0], tr.q[1] = q0, q1; tr.update_theta(d, 0); tr.update_theta(d, 1)
+    im = oip.implicit_dynamics(d, tabs, window, tr.q, tr.theta, oip.IPOptions())
+    obj = synth.make_objective(d, H, kind=model, velocity=velocity)
+    if velocity:
+        obj.v = obj.v * 1e3; obj.__post_init__()
+    lay = onewton.Layout(d, H)
+    R = onewton.jacobian(lay, obj, im, 1e-5, prob["kappa"])
+    r = np.random.default_rng(1).standard_normal(lay.N)
+    xs = np.linalg.solve(R, r)
+    A, rr, recover = banded.eliminate_controls(R, r, lay, d)
+    kept, us = banded.reduced_perm(lay, d)
+    # (1) only the dual diagonal blocks change, the band shrinks, the inertia is that of the duals
+    diff = np.abs(A - R[np.ix_(kept, kept)]) > 0
+    s = d.nr - d.nu + d.nd
+    for i, j in zip(*np.nonzero(diff)):
+        assert i // s == j // s and i % s >= d.nr - d.nu and j % s >= d.nr - d.nu, (i, j)
+    w = banded.half_bandwidth_reduced(d)
+    i, j = np.nonzero(A)
+    assert np.abs(i - j).max() == min(w, len(kept) - 1) and w < banded.half_bandwidth(d)
+    assert (np.linalg.eigvalsh(A) < 0).sum() == H * d.nd
+    scale = max(1.0, np.abs(xs).max())
+    x1, lmax1 = banded.blocked_ldl_solve(A, rr, min(w, len(kept) - 1))
+    np.testing.assert_allclose(recover(x1), xs, rtol=0, atol=1e-11 * np.linalg.cond(R) * scale)
+    # (2) the chain / bulk organisation gives the same factors: same solution to round-off of the SAME operations
+    x2, lmax2 = banded.chain_bulk_ldl_solve(A, rr, min(w, len(kept) - 1))
+    assert lmax2 == pytest.approx(lmax1, rel=1e-12) and lmax2 < 1e5
+    np.testing.assert_allclose(x2, x1, rtol=0, atol=1e-13 * np.linalg.cond(A) * max(1.0, np.abs(x1).max()))
+    np.testing.assert_allclose(recover(x2), xs, rtol=0, atol=1e-11 * np.linalg.cond(R) * scale)
