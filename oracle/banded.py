@@ -7,7 +7,8 @@ This module states the same algorithm in numpy - same slot logic, same order of 
 structure (bandwidth, quasi-definiteness, blocked update) is checked on the CPU; the device kernel is compared with
 numpy's dense solve in tests/test_gpu_parity.py.  Round 4 (second half of the file): the control elimination the kernel starts with
 (`eliminate_controls`, `half_bandwidth_reduced`) and the organisation of a block as diagonal block / rows below / lower-triangle update in
-a power-of-two window (`chain_bulk_ldl_solve`), checked against the dense solve and the one-panel form in
+a power-of-two window (`chain_bulk_ldl_solve`), and the kernel's on-the-fly row generation (`reduced_entry`), checked against the dense solve,
+the one-panel form and the assembled matrix in
 tests/test_oracle_reference_constructions.py::test_banded_ldl_control_elimination_and_chain_form."""
 import numpy as np
 
@@ -196,3 +197,40 @@ def chain_bulk_ldl_solve(A, b, w, RB=8):
             if j >= 0:
                 acc[j] += Lr[i, c] * x[i]
     return x, lmax
+
+
+def reduced_entry(d, H, obj, im, rho, i, j):
+    """Entry (i, j), j <= i, of the reduced interleaved KKT matrix [q_{t+2}, nu_t] per step, as kkt_banded_kernel GENERATES it when the
+    row enters the window (kkt_dense.hip: BandRows::desc / decode - nothing is assembled on the device): from the objective blocks
+    (hessian!, newton_jacobian.jl:200-248), the sensitivities (update_jacobian!, :166-189), G_t = du1_t R_t^-1 du1_t^T and
+    rho = H beta kappa (:169-186).  :configuration mode."""
+    nq, nd = d.nq, d.nd
+    s = nq + nd
+    ti, ki, tj, kj = i // s, i % s, j // s, j % s
+    dt = ti - tj
+    if ki < nq:                                                  # q row: P block
+        if kj >= nq:
+            return 0.0
+        if dt == 0:
+            v = obj.q[ti][ki, kj]
+            if obj.v is not None:
+                v += obj.v[ti][ki, kj]
+                if ti + 1 < H:
+                    v += obj.v[ti + 1][ki, kj]
+            return v
+        if dt == 1 and obj.v is not None:
+            return -obj.v[ti][ki, kj]
+        return 0.0
+    kd = ki - nq                                                 # dual row nu_t
+    if dt == 0:
+        if kj < nq:
+            return -1.0 if kj == kd else 0.0                     # -I at q_{t+2}
+        G = im["du1"][ti] @ np.linalg.solve(obj.u[ti], im["du1"][ti].T)
+        return -rho - G[kd, kj - nq] if kj == ki else -G[kd, kj - nq]
+    if kj >= nq:
+        return 0.0
+    if dt == 1:
+        return im["dq1"][ti][kd, kj]                             # dq1 at q_{t+1}
+    if dt == 2:
+        return im["dq0"][ti][kd, kj]                             # dq0 at q_t
+    return 0.0

@@ -278,6 +278,10 @@ def test_banded_ldl_control_elimination_and_chain_form(model, velocity):
     scale = max(1.0, np.abs(xs).max())
     x1, lmax1 = banded.blocked_ldl_solve(A, rr, min(w, len(kept) - 1))
     np.testing.assert_allclose(recover(x1), xs, rtol=0, atol=1e-11 * np.linalg.cond(R) * scale)
+    # ... and entry by entry it is what the kernel generates when a row enters its window (BandRows::desc restated: banded.reduced_entry)
+    rho = H * 1e-5 * prob["kappa"]
+    gen = np.array([[banded.reduced_entry(d, H, obj, im, rho, i_, j_) if j_ <= i_ else 0.0 for j_ in range(len(kept))] for i_ in range(len(kept))])
+    np.testing.assert_allclose(gen, np.tril(A), rtol=0, atol=1e-12 * np.abs(A).max())
     # (2) the chain / bulk organisation gives the same factors: same solution to round-off of the SAME operations
     x2, lmax2 = banded.chain_bulk_ldl_solve(A, rr, min(w, len(kept) - 1))
     assert lmax2 == pytest.approx(lmax1, rel=1e-12) and lmax2 < 1e5
