@@ -260,19 +260,9 @@ struct BandRows {
         }
         return mode;
     }
-    // entry (i, j), j <= i, of the interleaved KKT matrix: mode, constant and operand addresses
-    __device__ int terms(int i, int j, const double*& p0, const double*& p1, const double*& p2, double& c) const {
-        const int ti = i / s, tj = j / s;
-        return terms4(ti, i - ti * s, tj, j - tj * s, p0, p1, p2, c);
-    }
-    // ... with (step, index in the step) of the row and of the column given
+    // entry of row (ti, ki), column (tj, kj) - (step, index in the step), j <= i - of the interleaved KKT matrix: mode, constant and operand addresses
     __device__ int terms4(int ti, int ki, int tj, int kj, const double*& p0, const double*& p1, const double*& p2, double& c) const {
         return decode(desc(ti - tj, ki, kj), ti, p0, p1, p2, c);
-    }
-    __device__ double operator()(int i, int j) const {
-        const double *p0, *p1, *p2; double c;
-        const int mode = terms(i, j, p0, p1, p2, c);
-        return combine(mode, c, p0 ? *p0 : 0.0, p1 ? *p1 : 0.0, p2 ? *p2 : 0.0);
     }
 };
 }  // namespace
