@@ -341,6 +341,144 @@ def kkt_solve_condensed(lay: Layout, obj: Objective, im, beta, kappa, r):
     return Delta
 
 
+def _condensed_system(lay: Layout, obj: Objective, im, beta, kappa, r):
+    """Y (block penta-diagonal: Y[i,0] = Y_ii, Y[i,1] = Y_{i,i-1}, Y[i,2] = Y_{i,i-2}), beta and the primal recovery of
+    `kkt_solve_condensed` (same formulas, same order of operations)."""
+    d = lay.dims
+    assert d.mode == MODE_CONFIGURATION and obj.v is None
+    H, nd = lay.H, d.nd
+    rho = H * beta * kappa
+    Qi = [np.linalg.inv(obj.q[t]) for t in range(H)]
+    Ri = [np.linalg.inv(obj.u[t]) for t in range(H)]
+    rp_u = [r[lay.pu(i)] for i in range(H)]
+    rp_q = [r[lay.pq(i)] for i in range(H)]
+    rd = [r[lay.dual(i)] for i in range(H)]
+    Y = np.zeros((H, 3, nd, nd))
+    bet = np.zeros((H, nd))
+    for i in range(H):
+        A0 = im["du1"][i]
+        Yii = A0 @ Ri[i] @ A0.T + Qi[i] + rho * np.eye(nd)
+        bi = A0 @ (Ri[i] @ rp_u[i]) - Qi[i] @ rp_q[i] - rd[i]
+        if i >= 1:
+            A1 = im["dq1"][i]
+            Yii += A1 @ Qi[i - 1] @ A1.T
+            bi += A1 @ (Qi[i - 1] @ rp_q[i - 1])
+            Y[i, 1] = -A1 @ Qi[i - 1]
+        if i >= 2:
+            A2 = im["dq0"][i]
+            Yii += A2 @ Qi[i - 2] @ A2.T
+            bi += A2 @ (Qi[i - 2] @ rp_q[i - 2])
+            Y[i, 1] += A2 @ Qi[i - 2] @ im["dq1"][i - 1].T
+            Y[i, 2] = -A2 @ Qi[i - 2]
+        Y[i, 0] = Yii
+        bet[i] = bi
+
+    def recover(dnu):
+        Delta = np.zeros(lay.N)
+        for i in range(H):
+            Delta[lay.pu(i)] = Ri[i] @ (rp_u[i] - im["du1"][i].T @ dnu[i])
+            cq = -dnu[i].copy()
+            if i + 1 < H:
+                cq += im["dq1"][i + 1].T @ dnu[i + 1]
+            if i + 2 < H:
+                cq += im["dq0"][i + 2].T @ dnu[i + 2]
+            Delta[lay.pq(i)] = Qi[i] @ (rp_q[i] - cq)
+            Delta[lay.dual(i)] = dnu[i]
+        return Delta
+    return Y, bet, recover
+
+
+def _penta_eliminate(Yd, Y1, Y2, b, n):
+    """Block Cholesky of the first n block rows of a block penta-diagonal SPD matrix (Yd[i] = Y_ii, Y1[i] = Y_{i,i-1},
+    Y2[i] = Y_{i,i-2}) with the right-hand side riding along, and its traces in the two block rows that follow: returns
+    (L0, L1, L2, y, S, c) with S = the 2 x 2 block Schur complement on rows n, n + 1 restricted to what the eliminated rows
+    contribute (to be SUBTRACTED from the matrix there) and c likewise for the right-hand side."""
+    nd = Yd.shape[1]
+    K = n + 2
+    L0 = np.zeros((K, nd, nd)); L1 = np.zeros((K, nd, nd)); L2 = np.zeros((K, nd, nd)); y = np.zeros((K, nd))
+    S = np.zeros((2, 2, nd, nd)); c = np.zeros((2, nd))
+    for i in range(min(K, len(Yd))):
+        if i >= 2 and i - 2 < n:
+            L2[i] = np.linalg.solve(L0[i - 2], Y2[i].T).T
+        if i >= 1 and i - 1 < n:
+            M = Y1[i].copy()
+            if i >= 2 and i - 2 < n:
+                M -= L2[i] @ L1[i - 1].T
+            L1[i] = np.linalg.solve(L0[i - 1], M.T).T
+        if i < n:
+            D = Yd[i].copy()
+            v = b[i].copy()
+            if i >= 1:
+                D -= L1[i] @ L1[i].T; v -= L1[i] @ y[i - 1]
+            if i >= 2:
+                D -= L2[i] @ L2[i].T; v -= L2[i] @ y[i - 2]
+            L0[i] = np.linalg.cholesky(D)
+            y[i] = np.linalg.solve(L0[i], v)
+    # what rows n, n + 1 receive from the eliminated columns (n - 2, n - 1)
+    a, bb = n, n + 1
+    if a < len(Yd):
+        if n >= 1:
+            S[0, 0] += L1[a] @ L1[a].T; c[0] += L1[a] @ y[n - 1]
+        if n >= 2:
+            S[0, 0] += L2[a] @ L2[a].T; c[0] += L2[a] @ y[n - 2]
+    if bb < len(Yd) and n >= 1:
+        S[1, 1] += L2[bb] @ L2[bb].T; c[1] += L2[bb] @ y[n - 1]
+        S[1, 0] += L2[bb] @ L1[a].T
+    return L0, L1, L2, y, S, c
+
+
+def kkt_solve_condensed_twisted(lay: Layout, obj: Objective, im, beta, kappa, r, split=None):
+    """The condensed solve with a TWISTED (two-ended) block factorisation of Y: block rows 0 .. m-1 are eliminated from the top,
+    rows H-1 .. m+2 from the bottom (the same recurrence on the reversed matrix), the two meet in a 2 x 2 block system for rows
+    m, m+1, and the substitutions run outwards from there - two independent chains of about H / 2 block steps instead of one of H
+    (the factor recurrences are those of newton_structure_solver/methods.jl:466-557).  Result-equivalent to
+    `kkt_solve_condensed`; groundwork for a two-wave device kernel."""
+    H, nd = lay.H, lay.dims.nd
+    if H < 4:
+        return kkt_solve_condensed(lay, obj, im, beta, kappa, r)
+    Y, bet, recover = _condensed_system(lay, obj, im, beta, kappa, r)
+    m = (H - 2) // 2 if split is None else split
+    assert 0 <= m <= H - 2
+    nb = H - m - 2                                               # rows eliminated from the bottom
+    # top: the matrix as it is
+    T = _penta_eliminate(Y[:, 0], Y[:, 1], Y[:, 2], bet, m)
+    # bottom: the reversed matrix  Y'_{a,b} = Y_{H-1-a, H-1-b}:  Y'_{i,i-1} = Y_{H-i, H-1-i}^T,  Y'_{i,i-2} = Y_{H+1-i, H-1-i}^T
+    Yd_r = Y[::-1, 0].copy()
+    Y1_r = np.zeros_like(Yd_r); Y2_r = np.zeros_like(Yd_r)
+    for i in range(1, H):
+        Y1_r[i] = Y[H - i, 1].T
+    for i in range(2, H):
+        Y2_r[i] = Y[H + 1 - i, 2].T
+    Bm = _penta_eliminate(Yd_r, Y1_r, Y2_r, bet[::-1].copy(), nb)
+    # middle: rows m, m+1 (reversed indices: m+1 -> nb, m -> nb + 1)
+    S = np.zeros((2 * nd, 2 * nd)); c = np.zeros(2 * nd)
+    S[:nd, :nd] = Y[m, 0] - T[4][0, 0] - Bm[4][1, 1]
+    S[nd:, nd:] = Y[m + 1, 0] - T[4][1, 1] - Bm[4][0, 0]
+    S[nd:, :nd] = Y[m + 1, 1] - T[4][1, 0] - Bm[4][1, 0].T
+    S[:nd, nd:] = S[nd:, :nd].T
+    c[:nd] = bet[m] - T[5][0] - Bm[5][1]
+    c[nd:] = bet[m + 1] - T[5][1] - Bm[5][0]
+    mid = np.linalg.solve(S, c)
+    dnu = np.zeros((H, nd))
+    dnu[m], dnu[m + 1] = mid[:nd], mid[nd:]
+    # outwards: the top chain upwards ...
+    L0, L1, L2, y = T[0], T[1], T[2], T[3]
+    for i in range(m - 1, -1, -1):
+        v = y[i].copy()
+        v -= L1[i + 1].T @ dnu[i + 1]
+        v -= L2[i + 2].T @ dnu[i + 2]
+        dnu[i] = np.linalg.solve(L0[i].T, v)
+    # ... and the bottom chain downwards (reversed indices)
+    L0, L1, L2, y = Bm[0], Bm[1], Bm[2], Bm[3]
+    dr = dnu[::-1]                                               # a view: dr[a] = dnu[H-1-a]
+    for i in range(nb - 1, -1, -1):
+        v = y[i].copy()
+        v -= L1[i + 1].T @ dr[i + 1]
+        v -= L2[i + 2].T @ dr[i + 2]
+        dr[i] = np.linalg.solve(L0[i].T, v)
+    return recover(dnu)
+
+
 # ----------------------------------------------------------------------------
 # update_traj! / reset! / newton_solve!
 # ----------------------------------------------------------------------------

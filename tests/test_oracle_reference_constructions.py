@@ -287,3 +287,30 @@ def test_banded_ldl_control_elimination_and_chain_form(model, velocity):
     assert lmax2 == pytest.approx(lmax1, rel=1e-12) and lmax2 < 1e5
     np.testing.assert_allclose(x2, x1, rtol=0, atol=1e-13 * np.linalg.cond(A) * max(1.0, np.abs(x1).max()))
     np.testing.assert_allclose(recover(x2), xs, rtol=0, atol=1e-11 * np.linalg.cond(R) * scale)
+
+
+@pytest.mark.parametrize("model,H", [("hopper", 4), ("hopper", 9), ("quadruped", 5), ("quadruped", 12)])
+def test_twisted_condensed_solve(model, H):
+    """Two-ended (twisted) block factorisation of the dual Schur complement Y (recurrences of
+    newton_structure_solver/methods.jl:466-557 run from both ends towards a 2 x 2 block system in the middle): for EVERY position of
+    the middle the solution is that of the one-ended condensed solve and of the reference's dense LU of jacobian! - the CPU statement
+    of the next KKT kernel (two chains of H / 2 block steps), oracle/newton.py: kkt_solve_condensed_twisted."""
+    from oracle.dims import HOPPER_2D as HP
+    d = Dims(**(HP if model == "hopper" else QUADRUPED))
+    prob = synth.make_problem(d, H + 2, seed=4)
+    tabs = [lcp.LinTable(d, prob["z0"][t], prob["th0"][t], prob["r0"][t], prob["rz0"][t], prob["rth0"][t]) for t in range(H + 2)]
+    window, ref, q0, q1 = synth.make_rollout(d, prob, H, phase=1, seed=3, perturb=1e-2)
+    tr = ref.copy(); tr.q[0], tr.q[1] = q0, q1; tr.update_theta(d, 0); tr.update_theta(d, 1)
+    im = oip.implicit_dynamics(d, tabs, window, tr.q, tr.theta, oip.IPOptions())
+    obj = synth.make_objective(d, H, kind=model, velocity=False)
+    lay = onewton.Layout(d, H)
+    r = np.random.default_rng(0).standard_normal(lay.N)
+    for beta in (1e-5, 1e-2, 10.0):
+        R = onewton.jacobian(lay, obj, im, beta, prob["kappa"])
+        xd = onewton.kkt_solve_lu(R, r)
+        x0 = onewton.kkt_solve_condensed(lay, obj, im, beta, prob["kappa"], r)
+        scale = max(1.0, np.abs(xd).max())
+        for split in [None] + list(range(H - 1)):
+            x1 = onewton.kkt_solve_condensed_twisted(lay, obj, im, beta, prob["kappa"], r, split=split)
+            assert np.abs(x1 - x0).max() <= 1e-9 * scale, (beta, split)
+            assert np.abs(x1 - xd).max() <= 1e-10 * np.linalg.cond(R) * scale, (beta, split)
