@@ -266,35 +266,8 @@ def kkt_solve_condensed(lay: Layout, obj: Objective, im, beta, kappa, r):
     (Y = C S^-1 C^T, compute_L!, compute_beta!, compute_y!, compute_Dnu!, compute_Dz!)
     applied to the :direct layout of newton_jacobian.jl.  Requires
     mode == :configuration and a TrackingObjective (P block diagonal, P > 0)."""
-    d = lay.dims
-    assert d.mode == MODE_CONFIGURATION and obj.v is None
-    H, nq, nu, nd = lay.H, d.nq, d.nu, d.nd
-    rho = H * beta * kappa
-    Qi = [np.linalg.inv(obj.q[t]) for t in range(H)]
-    Ri = [np.linalg.inv(obj.u[t]) for t in range(H)]
-    rp_u = [r[lay.pu(i)] for i in range(H)]
-    rp_q = [r[lay.pq(i)] for i in range(H)]
-    rd = [r[lay.dual(i)] for i in range(H)]
-    # Row block i of C: [du1_i @ u_i, -I @ q_{i+2}(blk i), dq1_i @ blk i-1, dq0_i @ blk i-2]
-    Y = np.zeros((H, 3, nd, nd))     # Y[i,0]=Y_ii, Y[i,1]=Y_{i,i-1}, Y[i,2]=Y_{i,i-2}
-    bet = np.zeros((H, nd))
-    for i in range(H):
-        A0 = im["du1"][i]
-        Yii = A0 @ Ri[i] @ A0.T + Qi[i] + rho * np.eye(nd)
-        bi = A0 @ (Ri[i] @ rp_u[i]) - Qi[i] @ rp_q[i] - rd[i]
-        if i >= 1:
-            A1 = im["dq1"][i]
-            Yii += A1 @ Qi[i - 1] @ A1.T
-            bi += A1 @ (Qi[i - 1] @ rp_q[i - 1])
-            Y[i, 1] = -A1 @ Qi[i - 1]                   # (dq1_i)(Q^-1)(-I)^T of row i-1
-        if i >= 2:
-            A2 = im["dq0"][i]
-            Yii += A2 @ Qi[i - 2] @ A2.T
-            bi += A2 @ (Qi[i - 2] @ rp_q[i - 2])
-            Y[i, 1] += A2 @ Qi[i - 2] @ im["dq1"][i - 1].T
-            Y[i, 2] = -A2 @ Qi[i - 2]
-        Y[i, 0] = Yii
-        bet[i] = bi
+    H, nd = lay.H, lay.dims.nd
+    Y, bet, recover = _condensed_system(lay, obj, im, beta, kappa, r)      # Y[i,0]=Y_ii, Y[i,1]=Y_{i,i-1}, Y[i,2]=Y_{i,i-2}
     # block Cholesky of the block-pentadiagonal SPD matrix Y = L L^T
     L0 = np.zeros((H, nd, nd)); L1 = np.zeros((H, nd, nd)); L2 = np.zeros((H, nd, nd))
     for i in range(H):
@@ -327,23 +300,14 @@ def kkt_solve_condensed(lay: Layout, obj: Objective, im, beta, kappa, r):
         if i + 2 < H:
             v -= L2[i + 2].T @ dnu[i + 2]
         dnu[i] = np.linalg.solve(L0[i].T, v)
-    # primal recovery  Delta_x = P^-1 (r_p - C^T dnu)
-    Delta = np.zeros(lay.N)
-    for i in range(H):
-        Delta[lay.pu(i)] = Ri[i] @ (rp_u[i] - im["du1"][i].T @ dnu[i])
-        cq = -dnu[i].copy()
-        if i + 1 < H:
-            cq += im["dq1"][i + 1].T @ dnu[i + 1]
-        if i + 2 < H:
-            cq += im["dq0"][i + 2].T @ dnu[i + 2]
-        Delta[lay.pq(i)] = Qi[i] @ (rp_q[i] - cq)
-        Delta[lay.dual(i)] = dnu[i]
-    return Delta
+    return recover(dnu)                                          # primal recovery  Delta_x = P^-1 (r_p - C^T dnu)
 
 
 def _condensed_system(lay: Layout, obj: Objective, im, beta, kappa, r):
-    """Y (block penta-diagonal: Y[i,0] = Y_ii, Y[i,1] = Y_{i,i-1}, Y[i,2] = Y_{i,i-2}), beta and the primal recovery of
-    `kkt_solve_condensed` (same formulas, same order of operations)."""
+    """Y (block penta-diagonal: Y[i,0] = Y_ii, Y[i,1] = Y_{i,i-1}, Y[i,2] = Y_{i,i-2}), beta and the primal recovery
+    Delta_x = P^-1 (r_p - C^T dnu) of the condensed solves (compute_Y!, compute_beta!, compute_Dz!: methods.jl:386-446,
+    476-500, 540-557 applied to the :direct layout).  Row block i of C: [du1_i @ u_i, -I @ q_{i+2} (blk i), dq1_i @ blk i-1,
+    dq0_i @ blk i-2]."""
     d = lay.dims
     assert d.mode == MODE_CONFIGURATION and obj.v is None
     H, nd = lay.H, d.nd
