@@ -149,6 +149,7 @@ struct cimpc_ctx {
     bool velocity_objective = false;
     bool use_dense = false;        // KKT through kkt_dense.hip: the reference-default dense LU (any mode / objective) ...
     bool use_banded = false;       // ... or its banded LDL^T (:configuration mode, velocity objective / on request)
+    bool band_reduce_ok = false;   // every R_t could be inverted: the banded LDL^T may eliminate the controls first (NewtonDev::band_reduce)
     bool use_mixed = false;        // condensed solve in mixed precision (CIMPC_KKT_CONDENSED_MIXED)
     double* d_mix_ws = nullptr;
     int* d_mix_nfb = nullptr;
@@ -366,8 +367,22 @@ static void select_kkt_backend(cimpc_ctx* h) {
     const bool velocity = h->S.V != nullptr;
     // (dimension sets without a compiled condensed solve - the runtime-dimension path - take the banded LDL^T / dense LU)
     h->use_dense = !cfg || want == CIMPC_KKT_DENSE_LU || want == CIMPC_KKT_BANDED_LDL || velocity || !kkt_condensed_available(h->S);
-    h->use_banded = h->use_dense && cfg && want != CIMPC_KKT_DENSE_LU && kkt_banded_available(h->S);
-    h->cf_reduce = !cfg && want != CIMPC_KKT_DENSE_LU && h->cf_tiny && kkt_cf_reduce_available(h->S);
+    // Form of the banded LDL^T.  The reduced form (controls eliminated first) needs LDS for its pre-pass as well as the
+    // window: where that does not fit (long horizons of wide models) the full interleaved form is tried, and the dense LU
+    // serves what neither fits.  avail() = the availability test of whoever would run the banded kernel on h->S.
+    auto pick_band_form = [&](auto avail) {
+        h->S.band_reduce = h->band_reduce_ok ? 1 : 0;
+        if (avail()) return true;
+        if (h->S.band_reduce == 0) return false;
+        h->S.band_reduce = 0;
+        if (avail()) return true;
+        h->S.band_reduce = 1;
+        return false;
+    };
+    h->S.band_reduce = h->band_reduce_ok ? 1 : 0;
+    h->use_banded = h->use_dense && cfg && want != CIMPC_KKT_DENSE_LU && pick_band_form([&] { return kkt_banded_available(h->S); });
+    h->cf_reduce = !cfg && want != CIMPC_KKT_DENSE_LU && h->cf_tiny &&
+                   (velocity ? pick_band_form([&] { return kkt_cf_reduce_available(h->S); }) : kkt_cf_reduce_available(h->S));
     h->use_mixed = want == CIMPC_KKT_CONDENSED_MIXED && !h->use_dense && kkt_mixed_available(h->S);
 }
 
@@ -478,7 +493,10 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     if (h->ip.max_time > 0.0 && h->ip.max_time < 1000.0) {      // per-solve budget of the interior point (policy.jl:9,61)
         if (h->ip.max_iter >= 128) { delete h; return fail(nullptr, CIMPC_ERR_INVALID, "ip max_time needs max_iter < 128 (the parked state packs both into one word)"); }
         int khz = 0;
-        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) khz = 100000;      // 100 MHz
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) {
+            delete h;      // no guessing: a budget in ticks of an unknown clock would silently be the wrong budget
+            return fail(nullptr, CIMPC_ERR_HIP, "ip max_time: the device does not report hipDeviceAttributeWallClockRate");
+        }
         h->ip_budget_ticks = std::max<long long>(1, (long long)std::llround(h->ip.max_time * 1.0e3 * (double)khz));
     }
     h->kn.read_environment();       // the only place the environment is consulted
@@ -843,26 +861,25 @@ int cimpc_set_objective(cimpc_handle h, const double* Q, const double* R, const 
         HIP_TRY(h, hipMemcpy(h->d_qt, qt.data(), qt.size() * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(h->d_vt, vt.data(), vt.size() * sizeof(double), hipMemcpyHostToDevice));
         h->S.V = h->d_V; h->S.q_target = h->d_qt; h->S.v_target = h->d_vt;
-        select_kkt_backend(h);     // P is block tridiagonal: the condensed solve does not apply (banded LDL^T / dense LU)
-        h->velocity_objective = true;
+        h->velocity_objective = true;      // P is block tridiagonal: the condensed solve does not apply (banded LDL^T / dense LU)
     } else {
         h->S.V = nullptr; h->S.q_target = nullptr; h->S.v_target = nullptr;
         h->velocity_objective = false;
-        select_kkt_backend(h);
     }
+    // the inverses first: whether every R_t could be inverted decides the form of the banded LDL^T (kkt_dense.hip:
+    // kkt_banded_kernel eliminates the controls when it can), and that form decides whether the backend fits
     std::vector<double> Qi(H * d.nq * d.nq), Ri(H * d.nu * d.nu);
-    bool r_inverted = true;
+    bool q_inverted = true, r_inverted = true;
     for (size_t i = 0; i < H; ++i) {
-        // (the inverses feed the condensed solve - also behind the cf-mode reduction - and the control elimination of the banded LDL^T)
-        const bool need_inv = !h->use_dense || (h->cf_reduce && V == nullptr);
-        if (!invert(Q + i * d.nq * d.nq, Qi.data() + i * d.nq * d.nq, d.nq) && need_inv)
-            return fail(h, CIMPC_ERR_INVALID, "objective block Q[i] is singular");
-        if (d.nu > 0 && !invert(R + i * d.nu * d.nu, Ri.data() + i * d.nu * d.nu, d.nu)) {
-            if (need_inv) return fail(h, CIMPC_ERR_INVALID, "objective block R[i] is singular");
-            r_inverted = false;
-        }
+        if (!invert(Q + i * d.nq * d.nq, Qi.data() + i * d.nq * d.nq, d.nq)) q_inverted = false;
+        if (d.nu > 0 && !invert(R + i * d.nu * d.nu, Ri.data() + i * d.nu * d.nu, d.nu)) r_inverted = false;
     }
-    h->S.band_reduce = (r_inverted && d.nu > 0 && (h->kn.banded_form & 4) == 0) ? 1 : 0;      // kkt_dense.hip: kkt_banded_kernel
+    h->band_reduce_ok = r_inverted && d.nu > 0 && (h->kn.banded_form & 4) == 0;
+    select_kkt_backend(h);
+    // (the inverses feed the condensed solve - also behind the cf-mode reduction - and the control elimination of the banded LDL^T)
+    const bool need_inv = !h->use_dense || (h->cf_reduce && V == nullptr);
+    if (need_inv && !q_inverted) return fail(h, CIMPC_ERR_INVALID, "objective block Q[i] is singular");
+    if (need_inv && !r_inverted) return fail(h, CIMPC_ERR_INVALID, "objective block R[i] is singular");
     HIP_TRY(h, hipMemcpy(h->d_Q, Q, H * d.nq * d.nq * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_R, R, H * d.nu * d.nu * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_Qinv, Qi.data(), Qi.size() * sizeof(double), hipMemcpyHostToDevice));

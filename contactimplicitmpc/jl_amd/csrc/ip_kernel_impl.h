@@ -835,7 +835,9 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
                     S.rbil = vy ? ps[2 * NX + 3 * NY + lg] : 0.0;
                     r_vio = ps[PS - 4]; k_vio = ps[PS - 3]; reg = ps[PS - 2];
                     const long long it_word = (long long)ps[PS - 1];
-                    iters = (int)(it_word & 127);
+                    // the word packs (ticks used << 7 | iterations) only when a budget is set (then max_iter < 128,
+                    // cimpc_create); without one it is the plain count, whatever max_iter is
+                    iters = timed ? (int)(it_word & 127) : (int)it_word;
                     if (timed && l == 0) *tbase = (long long)wall_clock64() - (it_word >> 7);      // the time already used counts
                     wave_lds_fence();
                     if (l == 0) p.pflag[pi] = 0;

@@ -799,9 +799,9 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         __syncthreads();
         for (int e = tid; e < H * nu; e += nt) {
             const int t = e / nu, m = e - t * nu;
-            const double* Ri = S.Rinv + (size_t)t * nu * nu + (size_t)m * nu;      // column m = row m (symmetric)
+            const double* Ri = S.Rinv + (size_t)t * nu * nu + m;      // row m of the column-major inverse (R need not be symmetric)
             double a = 0.0;
-            for (int k = 0; k < nu; ++k) a = fma(Ri[k], tu[t * nu + k], a);
+            for (int k = 0; k < nu; ++k) a = fma(Ri[(size_t)k * nu], tu[t * nu + k], a);
             D[t * nr + m] = a;
         }
         __syncthreads();
