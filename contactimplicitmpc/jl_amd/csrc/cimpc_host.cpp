@@ -60,6 +60,10 @@ struct Knobs {
                                  // Measured 128 -> 64: B = 96 8.88 -> 8.11 ms, B = 128 9.72 -> 9.48 ms, B = 64 unchanged (6.9 ms)
     bool generic_static = false; // CIMPC_GENERIC_STATIC: runtime-dimension sweep with the static queue partition of rounds 2-3 instead of the dynamic pull
     int kkt_pipe = -1;           // CIMPC_KKT_PIPE: three-wave pipelined KKT kernel 0 never, 1 always, -1 where the solve is on the critical path
+    int kkt_twisted = -1;        // CIMPC_KKT_TWISTED: twisted (two-ended) condensed solve, two workgroups per rollout: 0 never, 1 wherever the
+                                 // pipelined kernel would run, -1 = 1
+    int kkt_tw_nb = 0;           // CIMPC_KKT_TW_NB: rows eliminated from the bottom (0: the default split)
+    int kkt_tw_max = 120;        // twisted kernel for at most this many rollouts per launch (two workgroups each must be resident together)
     // ---- constants ----
     int async_mem = 0;           // exchange buffers: ordinary device memory (uncached / fine-grained variants lost)
     int spec_all = -1;           // speculative slots of later line-search rounds: by batch size
@@ -97,6 +101,8 @@ struct Knobs {
         drain_pct = env_int("CIMPC_DRAIN_PCT", drain_pct);
         drain_min = std::max(1, env_int("CIMPC_DRAIN_MIN", drain_min));
         kkt_pipe = env_int("CIMPC_KKT_PIPE", kkt_pipe);
+        kkt_twisted = env_int("CIMPC_KKT_TWISTED", kkt_twisted);
+        kkt_tw_nb = env_int("CIMPC_KKT_TW_NB", kkt_tw_nb);
         generic_static = env_int("CIMPC_GENERIC_STATIC", generic_static ? 1 : 0) != 0;
         sweep_wgs = env_int("CIMPC_SWEEP_WGS", sweep_wgs);
         waves32 = env_int("CIMPC_WAVES32", waves32);
@@ -149,6 +155,7 @@ struct cimpc_ctx {
     bool velocity_objective = false;
     bool use_dense = false;        // KKT through kkt_dense.hip: the reference-default dense LU (any mode / objective) ...
     bool use_banded = false;       // ... or its banded LDL^T (:configuration mode, velocity objective / on request)
+    long long n_kkt_twisted = 0;   // KKT launches that took the twisted kernel (cimpc_get_kkt_twisted)
     bool band_reduce_ok = false;   // every R_t could be inverted: the banded LDL^T may eliminate the controls first (NewtonDev::band_reduce)
     bool use_mixed = false;        // condensed solve in mixed precision (CIMPC_KKT_CONDENSED_MIXED)
     double* d_mix_ws = nullptr;
@@ -625,6 +632,8 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     AX(&S.ro_sweeps, B); AX(&S.ro_ip_iters, B); AX(&S.ro_ip_fail, B);
     AX(&S.nlog, B * NLOG * 4);
     A(&S.kkt_ws, B * H * (3 * (size_t)h->nd * h->nd + h->nd));
+    A(&S.kkt_tw_xch, B * (3 * (size_t)h->nd * h->nd + 4 * h->nd));      // (= kkt_tw_xch_doubles(nd))
+    A(&S.kkt_tw_flags, B * 32);                                          // (= KKT_TW_FLAGS per rollout, one line each)
     (void)ppw;
     if (rc == CIMPC_OK && hipHostMalloc((void**)&h->h_counters, 8 * CPAD * sizeof(int)) != hipSuccess)
         rc = fail(h, CIMPC_ERR_HIP, "hipHostMalloc failed");
@@ -646,6 +655,8 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     // B = 128: 8.14 -> 8.03 ms for 0.3 more evaluated sweeps per step; B = 2048: 25.4 -> 25.6 ms, throughput-bound: one candidate there)
     S.spec_first = h->kn.spec_first >= 0 ? h->kn.spec_first : (d.B <= 1024 ? 3 : 1);
     S.kkt_scalar = h->kn.kkt_scalar ? 1 : 0;
+    S.kkt_tw_nb = h->kn.kkt_tw_nb;
+    S.kkt_tw_raw = (h->kn.kkt_twisted != 0 && d.B <= h->kn.kkt_tw_max) ? 1 : 0;
     // large batches: a rollout whose previous search needed a back-off starts the next one with 1, 1/2, 1/4 together (one
     // round less per Newton iteration for 0.9 more evaluated sweeps per step: B = 512 11.4 -> 10.9 ms); small batches already
     // evaluate all seven step lengths from depth 3 on
@@ -839,6 +850,22 @@ int cimpc_set_objective(cimpc_handle h, const double* Q, const double* R, const 
     if (!h || !Q || !R) return fail(h, CIMPC_ERR_INVALID, "Q and R are required");
     const cimpc_dims& d = h->dm;
     const size_t H = d.H;
+    {   // the weights are symmetric in the reference (objective.jl: Diagonal or relative_state_cost) and every backend but the dense
+        // LU relies on it (Qinv / Rinv as symmetric operands of the condensed solve, a symmetric banded matrix): refuse, don't guess
+        auto symmetric = [&](const double* A, int n) {
+            for (size_t t = 0; t < H; ++t) {
+                const double* M = A + t * n * n;
+                double amax = 0.0, asym = 0.0;
+                for (int i = 0; i < n; ++i)
+                    for (int j = 0; j < n; ++j) { amax = std::max(amax, std::fabs(M[i + j * n])); asym = std::max(asym, std::fabs(M[i + j * n] - M[j + i * n])); }
+                if (asym > 1e-9 * amax) return false;
+            }
+            return true;
+        };
+        if (!symmetric(Q, d.nq)) return fail(h, CIMPC_ERR_INVALID, "objective block Q[i] is not symmetric");
+        if (d.nu > 0 && !symmetric(R, d.nu)) return fail(h, CIMPC_ERR_INVALID, "objective block R[i] is not symmetric");
+        if (V && !symmetric(V, d.nq)) return fail(h, CIMPC_ERR_INVALID, "objective block V[i] is not symmetric");
+    }
     HIP_TRY(h, hipSetDevice(h->device));
     if (int dp = drain_pending(h); dp != CIMPC_OK) return dp;
     {   // contact-impulse weights below fp64 resolution (1e-100 in every example of the reference): the cf-mode KKT
@@ -1090,6 +1117,7 @@ int cimpc_kkt_solve(cimpc_handle h, const double* r, double beta, double* delta)
         rc = h->cf_reduce ? launch_kkt_cf_reduced_raw(h->S, h->d_rhs, beta, h->S.delta, h->d_cf_ws, h->d_dense_ws, h->stream)
                           : launch_kkt_dense_raw(h->S, h->d_rhs, beta, h->S.delta, h->d_dense_ws, h->stream, h->use_banded);
     } else {
+        if (h->S.kkt_tw_raw != 0 && kkt_twisted_available(h->S)) h->n_kkt_twisted++;      // (launch_kkt_raw's own test)
         rc = launch_kkt_raw(h->S, h->d_rhs, beta, h->S.delta, h->stream);
     }
     prof_end(h);
@@ -1291,7 +1319,12 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         // three-wave kernel costs no extra CUs there - always taken (round 4, BASELINE configs[4] at 64 rollouts: KKT 6.1 -> 3.2 ms per
         // step, 16.3 -> 13.3 ms; at 128 rollouts 24.2 -> 21.2 ms: profiles/r04/cent_kkt_pipe.log)
         const bool wide_tiles = (h->dm.nq > 16 || h->dm.nu > 16) && h->dm.nq <= 24 && h->dm.nu <= 24;
-        const int pipe = h->kn.kkt_pipe >= 0 ? h->kn.kkt_pipe : ((!h->kkt_overlap && n_kkt <= h->kn.kkt_pipe_max) || wide_tiles) ? 1 : 0;
+        int pipe = h->kn.kkt_pipe >= 0 ? h->kn.kkt_pipe : ((!h->kkt_overlap && n_kkt <= h->kn.kkt_pipe_max) || wide_tiles) ? 1 : 0;
+        // Round 5: where the pipelined kernel runs - the solve is on the critical path - the TWISTED solve takes its place: two
+        // workgroups per rollout factor the block penta-diagonal matrix from both ends (two chains of about H / 2 steps), as long as
+        // every pair is resident at once
+        if (pipe == 1 && h->kn.kkt_twisted != 0 && n_kkt <= h->kn.kkt_tw_max && kkt_twisted_available(Sk)) pipe = 2;
+        if (kkt && pipe == 2 && !h->use_dense && !h->use_mixed && (h->kkt_overlap ? h->kn.kkt_packed : true)) h->n_kkt_twisted++;
         if (kkt && !h->kkt_overlap) {   // small batches: latency matters, keep the KKT result in this round
             Sk.kkt_same_round = 1;
             prof_begin(h, PC_KKT, sb.st);
@@ -1585,6 +1618,12 @@ int cimpc_get_newton_log(cimpc_handle h, double* log, int max_entries) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy2D(log, (size_t)max_entries * 4 * sizeof(double), h->S.nlog, (size_t)NLOG * 4 * sizeof(double),
                            (size_t)n * 4 * sizeof(double), B, hipMemcpyDeviceToHost));
+    return CIMPC_OK;
+}
+
+int cimpc_get_kkt_twisted(cimpc_handle h, long long* n) {
+    if (!h || !n) return CIMPC_ERR_INVALID;
+    *n = h->n_kkt_twisted;
     return CIMPC_OK;
 }
 

@@ -1462,9 +1462,46 @@ constexpr int KKT_PIPE_TILES = 27;       // 22 + second L2 tile + two Y_ii and t
 // C of step t-2 (the products W1 = L1 L0^-1, W2 = L2 L0^-1 and yhat = L0^-T y the backward pass runs on, and their spill) next to
 // stage B of step t-1 (the chain: L1, the Cholesky factor, its inverse, y) and stage A of step t.
 constexpr int KKT_PIPE3_TILES = 29;      // 27 + third L2 slot + fourth slot of the L0^-T ring
+// TW = 1 / 2 (round 5): the TWISTED (two-ended) factorisation - two workgroups per rollout, each a three-stage pipeline on
+// its own end of the block penta-diagonal matrix (newton_structure_solver/methods.jl:466-557 run from both ends).  TW = 1 is the
+// TOP chain: the one-ended recursion over rows 0 .. m+1, whose last two rows first receive what the rows eliminated from the
+// bottom contribute.  TW = 2 is the BOTTOM chain: chain step i = row H-1-i of the reversed matrix, nb = H-m-2 full steps and two
+// trace steps (rows m+1, m: L2', L1' only) whose products S00, S11, S10^T, c0, c1 go to the top chain through global memory;
+// the substitutions run outwards from the middle (the bottom chain receives dnu_{m+1}, dnu_m), each chain recovers its share of
+// the primal rows, the chain that finishes last starts the line search.  CPU statement with the same rings and index algebra:
+// the test oracle (newton.py: kkt_solve_condensed_twisted_device).
+constexpr int KKT_TW_TILES = 32;         // 29 + two more slots of the dq0 ring + the tile of Qinv_j dq0_{j+2}^T (bottom chain)
+// rows the top chain eliminates before the two middle rows: the bottom chain (two more products per stage A) gets the shorter half,
+// and its traces are on their way before the top chain reaches row m
+__host__ __device__ inline int kkt_tw_split(int H, int nb_override = 0) {
+    int nb = nb_override > 0 ? nb_override : (H - 6) / 2;
+    if (nb < 2) nb = 2;
+    if (nb > H - 4) nb = H - 4;
+    return H - 2 - nb;
+}
+constexpr int KKT_TW_MIN_H = 10;         // shorter horizons keep the one-ended kernels
+// per-rollout exchange block of the two chains: [S00 | S11 | S10^T] (nd x nd each), c0, c1, dnu_{m+1}, dnu_m
+__host__ __device__ constexpr int kkt_tw_xch_doubles(int nd) { return 3 * nd * nd + 4 * nd; }
+constexpr int KKT_TW_FLAGS = 32;         // ints per rollout (one 128-byte line): [0] traces ready, [1] middle dnu ready, [2] chains finished
+// Wait for the partner chain's flag (agent scope), then acquire.  Bounded: a partner that never becomes resident must not hang the
+// device - the caller poisons its result with NaN instead (the solve then fails loudly: r_norm = NaN).
+__device__ __forceinline__ bool kkt_tw_wait(const int* flag) {
+    bool ok = false;
+    for (int spins = 0; spins < (1 << 21); ++spins) {
+        if (__builtin_amdgcn_readfirstlane(aload(flag)) != 0) { ok = true; break; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    __threadfence();
+    return ok;
+}
 // tile leading dimension for a model: 16 (one MFMA block per tile) or 24 (2 x 2 blocks, masked)
 template <int NQ, int NU>
 constexpr int kkt_tld() { return (NQ <= 16 && NU <= 16) ? 16 : 24; }
+template <int NQ, int NU>
+constexpr int kkt_tw_lds_doubles() {
+    constexpr int T = kkt_tld<NQ, NU>();
+    return KKT_TW_TILES * T * T + 13 * (T <= 16 ? 16 : 32);
+}
 // doubles of LDS one recursion needs
 template <int NQ, int NU, int PIPE>
 constexpr int kkt_lds_doubles() {
@@ -1481,15 +1518,17 @@ constexpr int kkt_max_h() {
 template <int NQ, int NU>
 constexpr int kkt_pack();
 
-template <int NQ, int NU, class Sync, int PIPE = 1, bool F32 = false>
+template <int NQ, int NU, class Sync, int PIPE = 1, bool F32 = false, int TW = 0>
 __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, int b, double* sm, int lane, int wave = 0) {
     static_assert(NQ <= 24 && NU <= 24, "MFMA KKT kernel: tiles of at most 24 x 24");
+    static_assert(TW == 0 || (PIPE == 3 && !F32), "the twisted chains are three-stage pipelines in fp64");
+    constexpr bool REV = TW == 2;                     // bottom chain: chain step i = row H-1-i
     constexpr int TL = kkt_tld<NQ, NU>();            // (shadow the 16-wide defaults of the file scope)
     constexpr int TSZ = TL * TL;
     constexpr int NB = (TL + 15) / 16;
     constexpr int VS = TL <= 16 ? 16 : 32;           // stride of the small vectors behind the tiles
     using Acc = TAcc<NB, F32>;
-    constexpr int NTILES = PIPE == 3 ? KKT_PIPE3_TILES : PIPE == 2 ? KKT_PIPE_TILES : KKT_MFMA_TILES;
+    constexpr int NTILES = TW != 0 ? KKT_TW_TILES : PIPE == 3 ? KKT_PIPE3_TILES : PIPE == 2 ? KKT_PIPE_TILES : KKT_MFMA_TILES;
     // The body runs on ONE wavefront; its phases hand data over through LDS only.  The hand-off needs the
     // wave's LDS operations complete (lgkmcnt(0)) - NOT its global ones: a full barrier (vmcnt(0)) would
     // expose the latency of the prefetch loads and of the factor spill stores at every phase boundary.
@@ -1501,10 +1540,16 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     constexpr int KBU = (NU + 3) / 4, KBQ = (NQ + 3) / 4, KBD = (nd + 3) / 4;
     const cimpc_dims& m = S.dm;
     const int H = m.H;
+    // chain geometry: NS stage-A steps, of which the first NF are full steps (factor, y); row(i) = the matrix row of chain step i
+    const int msp = TW != 0 ? kkt_tw_split(H, S.kkt_tw_nb) : 0;       // twisted: middle rows msp, msp + 1
+    const int nbot = H - msp - 2;                                      // rows the bottom chain eliminates
+    const int NS = TW == 1 ? msp + 2 : TW == 2 ? nbot + 2 : H;
+    [[maybe_unused]] const int NF = TW == 2 ? nbot : NS;
+    auto row = [&](int i) { return REV ? H - 1 - i : i; };
     const int li = lane & 15, lk = lane >> 4;
     auto tile = [&](int t) { return sm + t * TSZ; };
     double* A0 = tile(0);                                  // du1_i            nd x nu
-    double* A2 = tile(1);                                  // dq0_i            nd x nq
+    double* A2 = tile(1);                                  // dq0_i            nd x nq   (bottom chain: ring of three, tiles 1, 29, 30)
     // tiles 2,3: dq1 ring (i, i-1)
     double* T0 = tile(4); double* T1 = tile(5); double* T2 = tile(6);
     double* Y1 = tile(7); double* Lc = tile(8); double* L2c = tile(9);
@@ -1526,6 +1571,13 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     const double* dzb = kkt_dz(S, K, b, H, nths, nd);
     double* ws = S.kkt_ws + (size_t)b * H * (3 * n2 + nd);
     constexpr int WSR = 3 * n2 + nd;
+    auto rec = [&](int i) { return ws + (size_t)row(i) * WSR; };      // record of chain step i (the chains' rows are disjoint)
+    // exchange block and flags of the two chains
+    [[maybe_unused]] double* const xS = TW != 0 ? S.kkt_tw_xch + (size_t)b * kkt_tw_xch_doubles(nd) : nullptr;
+    [[maybe_unused]] double* const xc = xS + 3 * n2;                  // c0, c1
+    [[maybe_unused]] double* const xdn = xS + 3 * n2 + 2 * nd;        // dnu_{m+1}, dnu_m
+    [[maybe_unused]] int* const xfl = TW != 0 ? S.kkt_tw_flags + (size_t)b * KKT_TW_FLAGS : nullptr;
+    [[maybe_unused]] bool tw_ok = true;
 
     constexpr int PF_DZ = (nd * nths + 63) / 64, PF_Q = (nq * nq + 63) / 64, PF_R = (nu * nu + 63) / 64;
     double pf_dz[PF_DZ], pf_q[PF_Q], pf_r[PF_R], pf_rp = 0.0, pf_rd = 0.0;
@@ -1536,6 +1588,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     // step (measured: 2 k of the 14 k cycles of a step).
     const int TRASH = NTILES * TSZ + 12 * VS;                // scratch double behind the vectors
     int dz_src[PF_DZ], dz_dst[PF_DZ], dz_rot[PF_DZ], q_src[PF_Q], q_dst[PF_Q], r_src[PF_R], r_dst[PF_R];
+    [[maybe_unused]] int dz_rot2[PF_DZ];                     // bottom chain: 1 for the dq0 entries (ring of three tiles)
 #pragma unroll
     for (int j = 0; j < PF_DZ; ++j) {
         const int k = lane + 64 * j, ok = k < nd * nths, kk = ok ? k : 0, r = kk % nd, c = kk / nd;
@@ -1544,6 +1597,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         dz_src[j] = kk;
         dz_dst[j] = ok ? base + r : TRASH;
         dz_rot[j] = (ok && c >= nq && c < 2 * nq) ? TSZ : 0;
+        dz_rot2[j] = (ok && c < nq) ? 1 : 0;
     }
 #pragma unroll
     for (int j = 0; j < PF_Q; ++j) {
@@ -1556,29 +1610,34 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         r_src[j] = kk; r_dst[j] = ok ? 18 * TSZ + (kk % nu) + (kk / nu) * TL : TRASH;
     }
     const int rp_src = lane < nr ? lane : 0, rd_src = lane < nd ? lane : 0;
+    // (bottom chain: the sensitivities, Rinv, r_p(u), r_d of row j = H-1-i, the weights Qinv and r_p(q) of row j-2 - they enter two
+    //  rows ahead of the operands, the rows H-1, H-2 in the preamble)
     auto prefetch = [&](int i) {
-        if (i < 0 || i >= H) return;
-        const double* dzi = dzb + (size_t)i * nths * nd;
+        if (i < 0 || i >= NS) return;
+        const int j = row(i), jq = REV ? max(j - 2, 0) : j;
+        const double* dzi = dzb + (size_t)j * nths * nd;
 #pragma unroll
-        for (int j = 0; j < PF_DZ; ++j) pf_dz[j] = dzi[dz_src[j]];
+        for (int j2 = 0; j2 < PF_DZ; ++j2) pf_dz[j2] = dzi[dz_src[j2]];
 #pragma unroll
-        for (int j = 0; j < PF_Q; ++j) pf_q[j] = S.Qinv[(size_t)i * nq * nq + q_src[j]];
+        for (int j2 = 0; j2 < PF_Q; ++j2) pf_q[j2] = S.Qinv[(size_t)jq * nq * nq + q_src[j2]];
 #pragma unroll
-        for (int j = 0; j < PF_R; ++j) pf_r[j] = S.Rinv[(size_t)i * nu * nu + r_src[j]];
-        pf_rp = rb[i * nr + rp_src];
-        pf_rd = rb[H * nr + i * nd + rd_src];
+        for (int j2 = 0; j2 < PF_R; ++j2) pf_r[j2] = S.Rinv[(size_t)j * nu * nu + r_src[j2]];
+        pf_rp = rb[(REV && lane >= nu ? jq : j) * nr + rp_src];
+        pf_rd = rb[H * nr + j * nd + rd_src];
     };
-    // registers -> LDS tiles of step i (p0 = i & 1 selects the dq1 ring slot, m0 = i % 3 the Qinv / r_p(q) slots)
-    auto commit = [&](int p0, int m0) {
+    // registers -> LDS tiles of step i (p0 = i & 1 selects the dq1 ring slot, m0 = i % 3 the dq0 slot of the bottom chain,
+    // mq the Qinv / r_p(q) slots: i % 3, bottom chain (i + 2) % 3 = the slot of chain step i + 2)
+    auto commit = [&](int p0, int m0, int mq) {
+        const int a2off = REV ? (m0 == 0 ? 0 : (27 + m0) * TSZ) : 0;      // tiles 1, 29, 30
 #pragma unroll
-        for (int j = 0; j < PF_DZ; ++j) sm[dz_dst[j] + p0 * dz_rot[j]] = pf_dz[j];
+        for (int j = 0; j < PF_DZ; ++j) sm[dz_dst[j] + p0 * dz_rot[j] + (REV ? dz_rot2[j] * a2off : 0)] = pf_dz[j];
 #pragma unroll
-        for (int j = 0; j < PF_Q; ++j) sm[q_dst[j] >= 0 ? (15 + m0) * TSZ + q_dst[j] : TRASH] = pf_q[j];
+        for (int j = 0; j < PF_Q; ++j) sm[q_dst[j] >= 0 ? (15 + mq) * TSZ + q_dst[j] : TRASH] = pf_q[j];
 #pragma unroll
         for (int j = 0; j < PF_R; ++j) sm[r_dst[j]] = pf_r[j];
-        // r_p: [u | q2] -> rpu (vec + 5 VS), q ring (vec + (6 + m0) VS)
+        // r_p: [u | q2] -> rpu (vec + 5 VS), q ring (vec + (6 + mq) VS)
         const int vb = NTILES * TSZ;
-        sm[lane < nu ? vb + 5 * VS + lane : lane < nr ? vb + (6 + m0) * VS + (lane - nu) : TRASH] = pf_rp;
+        sm[lane < nu ? vb + 5 * VS + lane : lane < nr ? vb + (6 + mq) * VS + (lane - nu) : TRASH] = pf_rp;
     };
 #ifdef CIMPC_KKT_PROF
     long long pt[16] = {0}; long long tp = clock64();
@@ -1587,7 +1646,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
 #define KPROF(j)
 #endif
     // ring / parity slots of step i
-    struct Slots { double *Li, *Li1, *Li2, *L1c, *L1p, *A1, *A1p, *Qi0, *Qi1, *Qi2, *yc, *y1, *y2, *q0r, *q1r, *q2r, *L2c, *Y0h, *Y1h, *bet, *LiT, *LiT1, *LiT2; int p0, m0; };
+    struct Slots { double *Li, *Li1, *Li2, *L1c, *L1p, *A1, *A1p, *Qi0, *Qi1, *Qi2, *yc, *y1, *y2, *q0r, *q1r, *q2r, *L2c, *Y0h, *Y1h, *bet, *LiT, *LiT1, *LiT2, *A2c, *A2p1, *A2p2; int p0, m0; };
     auto slots = [&](int i) {
         const int m0 = i % 3, m1 = (i + 2) % 3, m2 = (i + 1) % 3, p0 = i & 1, p1 = (i + 1) & 1;
         Slots t;
@@ -1609,6 +1668,9 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         // four slots - stage C reads step i-2's while stage B writes step i+1's)
         auto lit = [&](int j) { constexpr int R = PIPE == 3 ? 4 : 3; const int q = ((j % R) + R) % R; return q < 3 ? tile(19 + q) : tile(28); };
         t.LiT = lit(i); t.LiT1 = lit(i - 1); t.LiT2 = lit(i - 2);
+        // dq0 ring of the bottom chain (chain steps i, i-1, i-2 = rows j, j+1, j+2)
+        auto a2t = [&](int q) { return q == 0 ? tile(1) : tile(28 + q); };
+        t.A2c = REV ? a2t(m0) : tile(1); t.A2p1 = a2t(m1); t.A2p2 = a2t(m2);
         t.p0 = p0; t.m0 = m0;
         return t;
     };
@@ -1619,6 +1681,28 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     // becomes the longer stage (quadruped 139 -> 134 us only, hopper H = 20 loop 0.82 -> 0.94 ms) and the sum Y - L1 L1^T - L2 L2^T
     // is taken in another order than in the one- and two-wave variants, whose results must stay identical.)
     constexpr bool OFFCHAIN = PIPE == 3;
+    auto put = [&](double* g, const Acc& a) {         // accumulator -> global, compact nd x nd column-major
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int J = 0; J < NB; ++J)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * I + li, col = tile_col<F32>(J, lk, r);
+                    if (row < nd && col < nd) g[row + col * nd] = (double)a.v[I][J][r];
+                }
+    };
+    [[maybe_unused]] auto sub_g = [&](Acc& a, const double* g, bool ok) {      // accumulator -= compact block in global memory (NaN: the partner never came)
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int J = 0; J < NB; ++J)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * I + li, col = tile_col<F32>(J, lk, r);
+                    if (row < nd && col < nd) a.v[I][J][r] -= ok ? g[row + col * nd] : __builtin_nan("");
+                }
+    };
     // ---- stage A of step i: needs factors of steps <= i-2 only --------------------------------------------
     auto stageA = [&](int i) {
         const Slots t = slots(i);
@@ -1628,11 +1712,49 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         double* const L2c = t.L2c; double* const bet = t.bet;
         const int p0 = t.p0, m0 = t.m0;
         // ---- P1: step i operands -> LDS, fetch step i+1 ------------------------------------
-        commit(p0, m0);
+        commit(p0, m0, REV ? (i + 2) % 3 : m0);
         const double rd_i = pf_rd;
         lds_sync();
         prefetch(i + 1);
         KPROF(1)
+        if constexpr (REV) {
+            // Bottom chain, row j = H-1-i of the matrix = step i of the REVERSED matrix Y'_{a,b} = Y_{H-1-a,H-1-b}:
+            //   Y'_ii     = Y_jj          = Qinv_j + rho I + T0 du1_j^T + T1 dq1_j^T + T2 dq0_j^T     (T0, T1, T2 as in the top chain)
+            //   Y'_i,i-1  = Y_{j+1,j}^T   = -Qinv_j dq1_{j+1}^T + T1 dq0_{j+1}^T
+            //   Y'_i,i-2  = Y_{j+2,j}^T   = -Qinv_j dq0_{j+2}^T  =: -Tq ,   L2'_i = -Tq L0'_{i-2}^-T
+            // Ring slots follow the chain step: row j-1 = step i+1 -> slot (i+1) % 3 (Qi2 / q2r), row j-2 -> slot (i+2) % 3 (Qi1 / q1r);
+            // dq1_{j+1} is the previous step's dq1 (A1p), dq0_{j+1}, dq0_{j+2} the dq0 ring's older slots.
+            const int j = H - 1 - i;
+            double* const Qj = t.Qi0; double* const Qj1 = t.Qi2; double* const Qj2 = t.Qi1;
+            double* const rq0 = t.q0r; double* const rq1 = t.q2r; double* const rq2 = t.q1r;
+            double* const A2j = t.A2c; double* const Tq = tile(31);
+            tile_st<TL, F32>(T0, tile_mma<KBU, false, TL, F32>(A0, Ri, z4, li, lk), li, lk);
+            if (j >= 1) tile_st<TL, F32>(T1, tile_mma<KBQ, false, TL, F32>(A1, Qj1, z4, li, lk), li, lk);
+            if (j >= 2) tile_st<TL, F32>(T2, tile_mma<KBQ, false, TL, F32>(A2j, Qj2, z4, li, lk), li, lk);
+            if (i >= 2) tile_st<TL, F32>(Tq, tile_mma<KBQ, false, TL, F32>(Qj, t.A2p2, z4, li, lk), li, lk);
+            lds_sync();
+            KPROF(2)
+            y0 = tile_ld<TL, F32>(Qj, li, lk);
+            tile_add_diag<NB, F32>(y0, rho, nd, li, lk);
+            y0 = tile_mma<KBU, false, TL, F32>(T0, A0, y0, li, lk);
+            if (j >= 1) y0 = tile_mma<KBQ, false, TL, F32>(T1, A1, y0, li, lk);
+            if (j >= 2) y0 = tile_mma<KBQ, false, TL, F32>(T2, A2j, y0, li, lk);
+            y1a = z4;
+            if (i >= 1) {
+                y1a = tile_mma<KBQ, true, TL, F32>(Qj, A1p, y1a, li, lk);
+                if (j >= 1) y1a = tile_mma<KBQ, false, TL, F32>(T1, t.A2p1, y1a, li, lk);
+            }
+            if (i >= 2) tile_st<TL, F32>(L2c, tile_mma<KBD, true, TL, F32>(Tq, Li2, z4, li, lk), li, lk);
+            if (lane < nd) {   // beta_j = T0 rpu_j - Qinv_j rq_j + T1 rq_{j-1} + T2 rq_{j-2} - rd_j
+                double s = tile_mv<nu, false, TL>(T0, rpu, lane) - tile_mv<nq, false, TL>(Qj, rq0, lane);
+                if (j >= 1) s += tile_mv<nq, false, TL>(T1, rq1, lane);
+                if (j >= 2) s += tile_mv<nq, false, TL>(T2, rq2, lane);
+                bet[lane] = s - rd_i;
+            }
+            tile_st<TL, F32>(t.Y0h, y0, li, lk); tile_st<TL, F32>(t.Y1h, y1a, li, lk);
+            KPROF(3)
+            return;
+        }
         // ---- P2: T0 = du1 Rinv, T1 = dq1 Qinv_{i-1}, T2 = dq0 Qinv_{i-2}  (Qinv, Rinv symmetric)
         tile_st<TL, F32>(T0, tile_mma<KBU, false, TL, F32>(A0, Ri, z4, li, lk), li, lk);
         if (i >= 1) tile_st<TL, F32>(T1, tile_mma<KBQ, false, TL, F32>(A1, Qi1, z4, li, lk), li, lk);
@@ -1669,22 +1791,34 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     // L2_i: it completes the records of steps i-1 (W1) and i-2 (W2) and writes yhat_i.  Record of a step: [W1 | W2 | - | yhat].
     auto stageC = [&](int i) {
         const Slots t = slots(i);
-        auto put = [&](double* g, const Acc& a) {         // accumulator -> global, compact nd x nd column-major
-#pragma unroll
-            for (int I = 0; I < NB; ++I)
-#pragma unroll
-                for (int J = 0; J < NB; ++J)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * I + li, col = tile_col<F32>(J, lk, r);
-                        if (row < nd && col < nd) g[row + col * nd] = (double)a.v[I][J][r];
-                    }
-        };
-        if (i >= 1) put(ws + (size_t)(i - 1) * WSR, tile_mma<KBD, false, TL, F32>(t.L1c, t.LiT1, z4, li, lk));
-        if (i >= 2) put(ws + (size_t)(i - 2) * WSR + n2, tile_mma<KBD, false, TL, F32>(t.L2c, t.LiT2, z4, li, lk));
+        // (bottom chain, second trace step i = nbot + 1: there is no L1 of that step)
+        if (i >= 1 && !(TW == 2 && i == nbot + 1)) put(rec(i - 1), tile_mma<KBD, false, TL, F32>(t.L1c, t.LiT1, z4, li, lk));
+        if (i >= 2) put(rec(i - 2) + n2, tile_mma<KBD, false, TL, F32>(t.L2c, t.LiT2, z4, li, lk));
+        if constexpr (TW == 2) {
+            if (i >= nbot) {      // trace steps: what the eliminated rows contribute to the right-hand side of rows m+1 (c0), m (c1)
+                if (lane < nd) {
+                    double s = tile_mv<nd, false, TL>(t.L2c, t.y2, lane);           // L2'_i y'_{i-2}
+                    if (i == nbot) s += tile_mv<nd, false, TL>(t.L1c, t.y1, lane);  // + L1'_nb y'_{nb-1}
+                    xc[(i - nbot) * nd + lane] = s;
+                }
+                if (i == nbot + 1) {      // everything the top chain waits for is written: release, raise the flag
+                    __threadfence();
+                    if (lane == 0) astore(xfl + 0, 1);
+                }
+                return;
+            }
+        }
         if constexpr (OFFCHAIN) {       // forward substitution of step i: y_i = L0_i^-1 (beta_i - L1_i y_{i-1} - L2_i y_{i-2})
+            [[maybe_unused]] double cm = 0.0;
+            if constexpr (TW == 1) {
+                if (i >= msp) {       // middle rows: the bottom chain's share of the right-hand side (c1 for row m, c0 for row m+1)
+                    if (i == msp) tw_ok = kkt_tw_wait(xfl + 0);
+                    if (lane < nd) cm = tw_ok ? xc[(msp + 1 - i) * nd + lane] : __builtin_nan("");
+                }
+            }
             if (lane < nd) {
                 double s = t.bet[lane];
+                if constexpr (TW == 1) s -= cm;
                 if (i >= 1) s -= tile_mv<nd, false, TL>(t.L1c, t.y1, lane);
                 if (i >= 2) s -= tile_mv<nd, false, TL>(t.L2c, t.y2, lane);
                 tv[lane] = s;
@@ -1693,7 +1827,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
             if (lane < nd) t.yc[lane] = tile_mv<nd, false, TL>(t.Li, tv, lane);
             lds_sync();
         }
-        if (lane < nd) ws[(size_t)i * WSR + 3 * n2 + lane] = tile_mv<nd, true, TL>(t.Li, t.yc, lane);
+        if (lane < nd) rec(i)[3 * n2 + lane] = tile_mv<nd, true, TL>(t.Li, t.yc, lane);
     };
     // ---- stage B of step i: L1_i, the Cholesky factor L0_i and its inverse, y_i (the recursion's dependency chain) ---
     auto stageB = [&](int i) {
@@ -1702,6 +1836,21 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         [[maybe_unused]] double* const yc = t.yc; [[maybe_unused]] double* const y1 = t.y1; [[maybe_unused]] double* const y2 = t.y2;
         double* const L2c = t.L2c; [[maybe_unused]] double* const bet = t.bet;
         if constexpr (PIPE >= 2) { y0 = tile_ld<TL, F32>(t.Y0h, li, lk); y1a = tile_ld<TL, F32>(t.Y1h, li, lk); }
+        if constexpr (TW == 1) {
+            if (i >= msp) {       // middle rows: minus what the rows eliminated from the bottom contribute
+                if (i == msp) tw_ok = kkt_tw_wait(xfl + 0);
+                sub_g(y0, xS + (i == msp ? n2 : 0), tw_ok);                 // Y_mm -= S11 ,  Y_{m+1,m+1} -= S00
+                if (i == msp + 1) sub_g(y1a, xS + 2 * n2, tw_ok);           // Y_{m+1,m} -= S10^T
+            }
+        }
+        if constexpr (TW == 2) {
+            if (i == nbot + 1) {  // trace step of row m: S11 = L2 L2^T, S10^T = L1'_nb L2^T
+                put(xS + n2, tile_mma<KBD, false, TL, F32>(L2c, L2c, z4, li, lk));
+                put(xS + 2 * n2, tile_mma<KBD, false, TL, F32>(L1p, L2c, z4, li, lk));
+                __threadfence();
+                return;
+            }
+        }
         // ---- P4: Y1 -= L2 L1_{i-1}^T ; stage Y1 as an operand ------------------------------
         if (i >= 1) {
             if (i >= 2) y1a = tile_mma<KBD, true, TL, F32>(L2c, L1p, y1a, li, lk);
@@ -1712,6 +1861,13 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
             lds_sync();
         }
         KPROF(4)
+        if constexpr (TW == 2) {
+            if (i == nbot) {      // trace step of row m+1: S00 = L1 L1^T + L2 L2^T
+                put(xS, tile_mma<KBD, false, TL, F32>(L2c, L2c, tile_mma<KBD, false, TL, F32>(L1c, L1c, z4, li, lk), li, lk));
+                __threadfence();
+                return;
+            }
+        }
         // ---- P6: Lc = Y0 - L1 L1^T - L2 L2^T ; rhs of the forward substitution ---------------
         if (i >= 1) y0 = tile_mma<KBD, true, TL, F32>(L1c, L1c, y0, li, lk);
         if (i >= 2) y0 = tile_mma<KBD, true, TL, F32>(L2c, L2c, y0, li, lk);
@@ -1775,16 +1931,28 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         KPROF(7)
     };
     if constexpr (PIPE >= 2) {
+        if constexpr (REV) {
+            if (wave == 0) {      // preamble of the bottom chain: weights and r_p(q) of rows H-1, H-2 -> ring slots 0, 1 (chain steps 0, 1)
+                for (int k = lane; k < 2 * nq * nq; k += 64) {
+                    const int q = k / (nq * nq), e = k - q * nq * nq;
+                    sm[(15 + q) * TSZ + (e % nq) + (e / nq) * TL] = S.Qinv[(size_t)(H - 1 - q) * nq * nq + e];
+                }
+                for (int k = lane; k < 2 * nq; k += 64) {
+                    const int q = k / nq, e = k - q * nq;
+                    vec[(6 + q) * VS + e] = rb[(H - 1 - q) * nr + nu + e];
+                }
+            }
+        }
         if (wave == 0) prefetch(0);
 #ifdef CIMPC_KKT_WPROF
         long long w_stage = 0, w_bar = 0;
 #endif
-        for (int tck = 0; tck < H + PIPE - 1; ++tck) {      // tick: A(tck) on wave 0, B(tck - 1) on wave 1, (PIPE 3) C(tck - 2) on wave 2
+        for (int tck = 0; tck < NS + PIPE - 1; ++tck) {      // tick: A(tck) on wave 0, B(tck - 1) on wave 1, (PIPE 3) C(tck - 2) on wave 2
 #ifdef CIMPC_KKT_WPROF
             const long long w0 = clock64();
 #endif
-            if (wave == 0 && tck < H) stageA(tck);
-            if (wave == 1 && tck >= 1 && tck <= H) stageB(tck - 1);
+            if (wave == 0 && tck < NS) stageA(tck);
+            if (wave == 1 && tck >= 1 && tck <= NS) stageB(tck - 1);
             if constexpr (PIPE == 3) { if (wave == 2 && tck >= 2) stageC(tck - 2); }
 #ifdef CIMPC_KKT_WPROF
             const long long w1 = clock64();
@@ -1838,10 +2006,20 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         bw_src[j] = t < 2 ? kk : 3 * n2 + (kk - 2 * n2);
         bw_dst[j] = !ok ? TRASH : (t == 0) ? r + c * TL : (t == 1) ? 3 * TSZ + r + c * TL : NTILES * TSZ + (kk - 2 * n2);
     }
+    // chain-local indices: the chain substitutes its steps NBK-1 .. 0 and knows dnu of its steps 0 .. NS-1 afterwards (the bottom
+    // chain receives the two middle rows - its steps nbot, nbot + 1 - from the top chain)
+    const int NBK = TW == 2 ? nbot : NS;
+    if constexpr (TW == 2) {
+        tw_ok = kkt_tw_wait(xfl + 1);
+        if (lane < 2 * nd) dn_all[(nbot + lane / nd) * VS + lane % nd] = tw_ok ? xdn[lane] : __builtin_nan("");
+        lds_sync();
+        if (lane == 0) astore(xfl + 1, 0);        // consumed: the flag is down again for the next solve of this rollout
+    }
+    if constexpr (TW == 1) { if (lane == 0) astore(xfl + 0, 0); }      // (waves 1, 2 consumed the traces before the last tick)
     auto prefetch_b = [&](auto setc, int i) {
         constexpr int set = decltype(setc)::value;
         if (i < 0) return;
-        const double* wsi = ws + (size_t)i * WSR;
+        const double* wsi = rec(i);
 #pragma unroll
         for (int j = 0; j < PF_W; ++j) pf_w[set][j] = wsi[bw_src[j]];       // (W1 of the last step, W2 of the last two: never written, never used)
     };
@@ -1854,27 +2032,38 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         prefetch_b(setc, i - DEPTH);
         if (lane < nd) {
             double s = yb[lane];
-            if (i + 1 < H) s -= tile_mv<nd, true, TL>(W1t, dn_all + (i + 1) * VS, lane);
-            if (i + 2 < H) s -= tile_mv<nd, true, TL>(W2t, dn_all + (i + 2) * VS, lane);
+            if (i + 1 < NS) s -= tile_mv<nd, true, TL>(W1t, dn_all + (i + 1) * VS, lane);
+            if (i + 2 < NS) s -= tile_mv<nd, true, TL>(W2t, dn_all + (i + 2) * VS, lane);
             dn_all[i * VS + lane] = s;
-            D[H * nr + i * nd + lane] = s;
+            D[H * nr + row(i) * nd + lane] = s;
+            if constexpr (TW == 1) { if (i >= msp) xdn[(msp + 1 - i) * nd + lane] = s; }      // the middle rows go to the bottom chain
+        }
+        if constexpr (TW == 1) {
+            if (i == msp) {
+                __threadfence();
+                if (lane == 0) astore(xfl + 1, 1);
+            }
         }
         lds_sync();
     };
-    static_for<0, DEPTH>([&](auto kc) { prefetch_b(kc, H - 1 - decltype(kc)::value); });
-    for (int i = H - 1; i >= 0; i -= DEPTH) {
+    static_for<0, DEPTH>([&](auto kc) { prefetch_b(kc, NBK - 1 - decltype(kc)::value); });
+    for (int i = NBK - 1; i >= 0; i -= DEPTH) {
         static_for<0, DEPTH>([&](auto kc) { back_step(kc, i - decltype(kc)::value); });
     }
     // ---- primal recovery, level 1: t = r_p - C^T dnu, one output per lane and trip.  In the q rows both sensitivity columns are
     //      requested before the first multiply-add (indices clamped, the terms dropped afterwards): one memory round trip per row
     //      instead of three dependent ones.  (Two loops, one per kind of row, trip an instruction-selection bug of this compiler
     //      in the translation unit where the tiles are reached through a generic pointer - the single loop stays.) ------------------
-    for (int idx = lane; idx < H * nr; idx += 64) {
-        const int i = idx / nr, c = idx - i * nr;
-        double s = rb[idx];
+    // (twisted: the top chain recovers the primal rows 0 .. m-1 - they need dnu up to row m+1 -, the bottom chain rows m .. H-1;
+    //  dnu of matrix row j sits at the chain-local index: dnl(j))
+    const int rr0 = TW == 2 ? msp : 0, rrn = TW == 1 ? msp : TW == 2 ? H - msp : H;      // first row, number of rows
+    auto dnl = [&](int j) { return dn_all + (REV ? H - 1 - j : j) * VS; };
+    for (int idx = lane; idx < rrn * nr; idx += 64) {
+        const int il = idx / nr, c = idx - il * nr, i = rr0 + il;
+        double s = rb[rr0 * nr + idx];
         if (c < nu) {
             const double* a0 = dzb + ((size_t)i * nths + 2 * nq + c) * nd;
-            const double* dn0 = dn_all + i * VS;
+            const double* dn0 = dnl(i);
             double t0 = 0.0;
 #pragma unroll
             for (int k = 0; k < nd; ++k) t0 = fma(a0[k], dn0[k], t0);
@@ -1887,12 +2076,12 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
             double v1[nd], v2[nd];
 #pragma unroll
             for (int k = 0; k < nd; ++k) { v1[k] = a1[k]; v2[k] = a2[k]; }
-            const double* dn1 = dn_all + i1 * VS;
-            const double* dn2 = dn_all + i2 * VS;
+            const double* dn1 = dnl(i1);
+            const double* dn2 = dnl(i2);
             double t1 = 0.0, t2 = 0.0;
 #pragma unroll
             for (int k = 0; k < nd; ++k) { t1 = fma(v1[k], dn1[k], t1); t2 = fma(v2[k], dn2[k], t2); }
-            s += dn_all[i * VS + cq];
+            s += dnl(i)[cq];
             if (i + 1 < H) s -= t1;
             if (i + 2 < H) s -= t2;
         }
@@ -1901,10 +2090,10 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     lds_sync();
     // ---- level 2: Delta_x = P^-1 t: a u row and a q row per trip, indices clamped instead of branched on --------------------
     constexpr int RJ = nq > nu ? nq : nu;
-    for (int j = lane; j < H * RJ; j += 64) {
-        const bool on_u = j < H * nu, on_q = j < H * nq;
-        const int ju = on_u ? j : 0, iu = ju / nu, cu = ju - iu * nu;
-        const int jq = on_q ? j : 0, i = jq / nq, cq = jq - i * nq;
+    for (int j = lane; j < rrn * RJ; j += 64) {
+        const bool on_u = j < rrn * nu, on_q = j < rrn * nq;
+        const int ju = on_u ? j : 0, iul = ju / nu, cu = ju - iul * nu, iu = rr0 + iul;
+        const int jq = on_q ? j : 0, il = jq / nq, cq = jq - il * nq, i = rr0 + il;
         const double* Rm = S.Rinv + (size_t)iu * nu * nu + cu;
         const double* Qm = S.Qinv + (size_t)i * nq * nq + cq;
         double rv[nu], qv[nq];
@@ -1914,9 +2103,9 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         for (int k = 0; k < nq; ++k) qv[k] = Qm[k * nq];
         double su = 0.0, sq = 0.0;
 #pragma unroll
-        for (int k = 0; k < nu; ++k) su = fma(rv[k], t_all[iu * nr + k], su);
+        for (int k = 0; k < nu; ++k) su = fma(rv[k], t_all[iul * nr + k], su);
 #pragma unroll
-        for (int k = 0; k < nq; ++k) sq = fma(qv[k], t_all[i * nr + nu + k], sq);
+        for (int k = 0; k < nq; ++k) sq = fma(qv[k], t_all[il * nr + nu + k], sq);
         D[iu * nr + cu] = su;              // (surplus lanes recompute and rewrite row 0: same value, same address)
         D[i * nr + nu + cq] = sq;
     }
@@ -1925,6 +2114,15 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
 #ifdef CIMPC_KKT_PROF
     if (lane == 0 && b == 0) for (int j = 0; j < 9 ; ++j) ((long long*)S.stats)[8 + j] = pt[j];      // (diagnostic builds: overwrites the statistics of rollouts 2..5)
 #endif
+    if constexpr (TW != 0) {      // the chain that finishes last has the whole step in front of it: it starts the line search
+        __threadfence();
+        int prev = 0;
+        if (lane == 0) prev = atomicAdd(xfl + 2, 1);
+        prev = __builtin_amdgcn_readfirstlane(prev);
+        if (prev == 0) return;
+        __threadfence();
+        if (lane == 0) astore(xfl + 2, 0);
+    }
     if (K.finish) {
         __threadfence_block();
         start_line_search<Sync>(S, b, K.finish, lane, 64);
@@ -1962,6 +2160,26 @@ __global__ __launch_bounds__(192, (kkt_tld<NQ, NU>() <= 16 ? 2 : 1)) void kkt_ke
     if (n_dev != nullptr) n = *n_dev;
     if ((int)blockIdx.x >= n) return;
     kkt_body<NQ, NU, WaveSync, 3>(S, K, list[blockIdx.x], sm, (int)threadIdx.x & 63, (int)threadIdx.x >> 6);
+}
+
+// Twisted launch (round 5): TWO workgroups of three wavefronts per rollout - block 2k runs the bottom chain of rollout list[k]
+// (kkt_body<..., TW = 2>), block 2k + 1 the top chain (TW = 1).  The chains exchange the traces of the two middle rows and
+// their dnu through global memory (flags at agent scope).  The bottom chain has the LOWER block index: it waits for nothing
+// until its forward pass is done, so whatever the dispatch order, a resident bottom chain's partner is the next block to start.
+// list == nullptr: rollout blockIdx.x / 2 + S.b0 (stage filter as kkt_kernel).
+template <int NQ, int NU>
+__global__ __launch_bounds__(192, (kkt_tld<NQ, NU>() <= 16 ? 2 : 1)) void kkt_kernel_twisted(NewtonDev S, KktArgs K, const int* list, int n, const int* n_dev) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    if (n_dev != nullptr) n = *n_dev;
+    const int k = (int)blockIdx.x >> 1;
+    if (k >= n) return;
+    const int b = list != nullptr ? list[k] : k + S.b0;
+    if (list == nullptr) {
+        if (K.stage != nullptr && K.stage[b] != STAGE_KKT) return;
+        if (K.only_flag != nullptr && K.only_flag[b] == 0) return;
+    }
+    if (((int)blockIdx.x & 1) == 0) kkt_body<NQ, NU, WaveSync, 3, false, 2>(S, K, b, sm, (int)threadIdx.x & 63, (int)threadIdx.x >> 6);
+    else kkt_body<NQ, NU, WaveSync, 3, false, 1>(S, K, b, sm, (int)threadIdx.x & 63, (int)threadIdx.x >> 6);
 }
 
 // (wide tiles: 105 KB of LDS allow one workgroup per CU anyway - let it use the 512-register budget)

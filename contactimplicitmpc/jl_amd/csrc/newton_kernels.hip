@@ -489,7 +489,7 @@ int launch_resid_decide(const NewtonDev& S, hipStream_t s, int n_slots, int phas
     return launch_resid_t<0, 0>(S, s, n_slots, phase);        // runtime dimensions (models without a compiled set)
 }
 template <int NQ, int NU>
-static int launch_kkt_packed_t(const NewtonDev& S, const KktArgs& K, const int* list, int n, const int* n_dev, hipStream_t s, bool pipe) {
+static int launch_kkt_packed_t(const NewtonDev& S, const KktArgs& K, const int* list, int n, const int* n_dev, hipStream_t s, int pipe) {
     if constexpr (NQ <= 24 && NU <= 24) {
         constexpr int PACK = kkt_pack<NQ, NU>();
         const size_t lds = (size_t)PACK * kkt_lds_doubles<NQ, NU, 1>() * sizeof(double);
@@ -498,6 +498,13 @@ static int launch_kkt_packed_t(const NewtonDev& S, const KktArgs& K, const int* 
         // `pipe` (host schedule, CIMPC_KKT_PIPE): where the KKT solve is on the critical path (small batches, chained rounds).
         // Next to a busy sweep the pipelined kernel takes twice the CUs for half the time - measured neutral - so the
         // packed one-wave kernel stays there.
+        if (pipe == 2) {      // twisted: two workgroups of three wavefronts per rollout, one chain from either end
+            const size_t lds3 = (size_t)kkt_tw_lds_doubles<NQ, NU>() * sizeof(double);
+            static LdsOptIn optin3;
+            if (lds_opt_in(optin3, (const void*)kkt_kernel_twisted<NQ, NU>, lds3) != CIMPC_OK) return CIMPC_ERR_HIP;
+            hipLaunchKernelGGL((kkt_kernel_twisted<NQ, NU>), dim3(2 * n), dim3(192), lds3, s, S, K, list, n, n_dev);
+            return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+        }
         if (pipe) {      // three wavefronts per rollout, software-pipelined forward recursion
             const size_t lds2 = (size_t)kkt_lds_doubles<NQ, NU, 3>() * sizeof(double);
             static LdsOptIn optin2;
@@ -511,7 +518,7 @@ static int launch_kkt_packed_t(const NewtonDev& S, const KktArgs& K, const int* 
     return CIMPC_ERR_INVALID;
 }
 int launch_kkt_packed(const NewtonDev& S, int n_kkt, int list_par, hipStream_t s, const int* n_dev, int pipe) {
-    const bool latency = pipe >= 0 ? pipe != 0 : S.kkt_same_round == 1;
+    const int latency = pipe >= 0 ? pipe : (S.kkt_same_round == 1 ? 1 : 0);
     const int nq = S.dm.nq, nu = S.dm.nu;
     if (n_dev != nullptr) n_kkt = S.dm.B;      // upper bound of the grid; surplus workgroups leave at once
     if (n_kkt <= 0) return CIMPC_OK;
@@ -660,6 +667,12 @@ bool kkt_cf_reduce_available(const NewtonDev& S) {   // the reduced problem must
     return false;
 }
 
+bool kkt_twisted_available(const NewtonDev& S) {      // MFMA tiles, a horizon long enough for two chains, the backward staging
+    if (S.dm.mode != CIMPC_MODE_CONFIGURATION || S.kkt_list == nullptr || S.kkt_scalar != 0 || S.kkt_tw_xch == nullptr) return false;
+    if (S.dm.nq > 24 || S.dm.nu > 24 || S.dm.H < KKT_TW_MIN_H || S.dm.H > 96) return false;
+    return kkt_condensed_available(S);
+}
+
 bool kkt_condensed_available(const NewtonDev& S) {      // a compiled condensed solve exists for these (nq, nu)
     const int nq = S.dm.nq, nu = S.dm.nu;
 #define X(q, u) if (nq == q && nu == u) return true;
@@ -679,9 +692,26 @@ int launch_kkt_mixed_raw(const NewtonDev& S, const double* r_dev, double beta, d
     const KktArgs K{r_dev, delta_dev, nullptr, beta, nullptr, 0};
     return launch_kkt_mixed(S, K, ws, n_fallback, s);
 }
+template <int NQ, int NU>
+static int launch_kkt_twisted_t(const NewtonDev& S, const KktArgs& K, hipStream_t s) {
+    if constexpr (NQ <= 24 && NU <= 24) {
+        const size_t lds = (size_t)kkt_tw_lds_doubles<NQ, NU>() * sizeof(double);
+        static LdsOptIn optin;
+        if (lds_opt_in(optin, (const void*)kkt_kernel_twisted<NQ, NU>, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
+        hipLaunchKernelGGL((kkt_kernel_twisted<NQ, NU>), dim3(2 * S.nb_launch), dim3(192), lds, s, S, K, (const int*)nullptr, S.nb_launch, (const int*)nullptr);
+        return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+    }
+    return CIMPC_ERR_INVALID;
+}
 int launch_kkt_raw(const NewtonDev& S, const double* r_dev, double beta, double* delta_dev,
                    hipStream_t s) {
     KktArgs K{r_dev, delta_dev, nullptr, beta, nullptr, 0};
+    if (S.kkt_tw_raw != 0 && kkt_twisted_available(S)) {      // a lone solve is latency-bound: two chains from either end
+        const int nq = S.dm.nq, nu = S.dm.nu;
+#define X(q, u) if (nq == q && nu == u) return launch_kkt_twisted_t<q, u>(S, K, s);
+        CIMPC_NQNU(X)
+#undef X
+    }
     return launch_kkt_any(S, K, s);
 }
 

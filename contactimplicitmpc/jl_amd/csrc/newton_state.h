@@ -85,6 +85,12 @@ struct NewtonDev {
     const double* v_target; // [H][nq] (velocity objective) or null
     // KKT workspace: per rollout H * (3*nd*nd + nd) doubles (L1, L2, L0inv, y)
     double* kkt_ws;
+    // twisted condensed solve (newton_impl.h: kkt_body<..., TW>): per rollout the exchange block of the two chains
+    // ([S00 | S11 | S10^T | c0 | c1 | dnu_{m+1} | dnu_m], kkt_tw_xch_doubles(nd)) and one line of flags (KKT_TW_FLAGS ints)
+    double* kkt_tw_xch;
+    int* kkt_tw_flags;
+    int kkt_tw_nb;     // rows the bottom chain eliminates (0: kkt_tw_split's default; CIMPC_KKT_TW_NB)
+    int kkt_tw_raw;    // 1: the B1 seam (cimpc_kkt_solve: a lone solve, latency-bound) takes the twisted kernel too
     // options
     double r_tol, beta_init, kappa;
     int max_iter;
@@ -119,7 +125,9 @@ size_t kkt_mixed_workspace_doubles(const NewtonDev& nd);
 int launch_kkt_mixed_newton(const NewtonDev& nd, double* ws, int* n_fallback, hipStream_t s);
 int launch_kkt_mixed_raw(const NewtonDev& nd, const double* r_dev, double beta, double* delta_dev, double* ws, int* n_fallback, hipStream_t s);
 // packed variant: n_kkt rollouts from kkt_list[list_par], KKT_PACK per workgroup (dedicates whole CUs to the recursion)
+// (pipe: 0 packed one-wave kernel, 1 three-wave pipeline, 2 twisted = two three-wave chains per rollout, -1 by kkt_same_round)
 int launch_kkt_packed(const NewtonDev& nd, int n_kkt, int list_par, hipStream_t s, const int* n_dev = nullptr, int pipe = -1);
+bool kkt_twisted_available(const NewtonDev& nd);
 int launch_queue_recycle(const IpQueues& Q, int par, hipStream_t s);
 int launch_solve_finish(const NewtonDev& nd, double* out, hipStream_t s);   // end-of-solve result block, see solve_finish_kernel
 // reference-default backend (dense jacobian! + LU with partial pivoting), any mode / objective (kkt_dense.hip)

@@ -327,6 +327,12 @@ class CIMPCSolver:
         self._check(self.lib.cimpc_get_kkt_fallbacks(self.h, C.byref(n)), "get_kkt_fallbacks")
         return n.value
 
+    def kkt_twisted(self):
+        """KKT launches since the handle was created that took the twisted (two-ended) condensed solve."""
+        n = C.c_longlong()
+        self._check(self.lib.cimpc_get_kkt_twisted(self.h, C.byref(n)), "get_kkt_twisted")
+        return n.value
+
     def stats(self):
         s = _lib.Stats()
         self._check(self.lib.cimpc_get_stats(self.h, C.byref(s)), "get_stats")

@@ -443,6 +443,167 @@ def kkt_solve_condensed_twisted(lay: Layout, obj: Objective, im, beta, kappa, r,
     return recover(dnu)
 
 
+def kkt_tw_split(H):
+    """Rows the top chain of the device's twisted solve eliminates before the two middle rows (csrc/newton_impl.h: kkt_tw_split):
+    the bottom chain (its stage A forms two more products per step) gets the shorter half, and the top chain reaches the
+    middle rows only after the bottom chain's traces can have arrived."""
+    nb = max(2, (H - 6) // 2)
+    return H - 2 - nb
+
+
+def kkt_solve_condensed_twisted_device(lay: Layout, obj: Objective, im, beta, kappa, r, split=None):
+    """The twisted condensed solve AS THE DEVICE KERNEL RUNS IT (csrc/newton_impl.h: kkt_body<..., TW = 1 / 2>,
+    kkt_kernel_twisted): same mathematics as `kkt_solve_condensed_twisted`, restated with the kernel's data flow so that
+    its index algebra is checked on the CPU -
+      * the BOTTOM chain walks the rows downwards (chain step i = row j = H-1-i) and forms its blocks of the reversed matrix
+        directly from the operands it streams: Y'_ii = Y_jj, Y'_{i,i-1} = Y_{j+1,j}^T = -Qi_j dq1_{j+1}^T + (dq1_j Qi_{j-1}) dq0_{j+1}^T,
+        Y'_{i,i-2} = Y_{j+2,j}^T = -Qi_j dq0_{j+2}^T, with the weights and r_p(q) of row j-2 entering two rows ahead (rings of three
+        indexed by the chain step modulo 3, the dq0 ring likewise, the dq1 ring by parity);
+      * its last two steps (rows m+1, m) are TRACE steps: L2', L1' only, from which S00 = L1 L1^T + L2 L2^T, S11 = L2 L2^T,
+        S10^T = L1'(nb) L2'(nb+1)^T, c0 = L1 y'(nb-1) + L2 y'(nb-2), c1 = L2'(nb+1) y'(nb-1) go to the top chain;
+      * the TOP chain is the one-ended recursion stopped after row m+1, with Y_mm -= S11, beta_m -= c1, Y_{m+1,m+1} -= S00,
+        Y_{m+1,m} -= S10^T, beta_{m+1} -= c0 before the factor of those rows;
+      * both backward passes run on the records [W1 | W2 | yhat] of stage C: dnu_i = yhat_i - W1_i^T dnu_{i+1} - W2_i^T dnu_{i+2}
+        with W1_i = L1_{i+1} L0_i^-1, W2_i = L2_{i+2} L0_i^-1, yhat_i = L0_i^-T y_i (chain-local indices; the bottom chain starts
+        from dnu_{m+1}, dnu_m handed over by the top chain);
+      * the top chain recovers the primal rows 0 .. m-1, the bottom chain rows m .. H-1."""
+    d = lay.dims
+    assert d.mode == MODE_CONFIGURATION and obj.v is None
+    H, nd, nq = lay.H, d.nd, d.nq
+    m = kkt_tw_split(H) if split is None else split
+    nb = H - m - 2
+    assert nb >= 2 and m >= 2
+    rho = H * beta * kappa
+    Qi = [np.linalg.inv(obj.q[t]) for t in range(H)]
+    Ri = [np.linalg.inv(obj.u[t]) for t in range(H)]
+    du1, dq1, dq0 = im["du1"], im["dq1"], im["dq0"]
+    rpu = [r[lay.pu(i)] for i in range(H)]; rpq = [r[lay.pq(i)] for i in range(H)]; rd = [r[lay.dual(i)] for i in range(H)]
+    eye = np.eye(nd)
+
+    class Chain:      # the rings of one chain (slot = chain step modulo ring length), its records and its y ring
+        def __init__(self, n):
+            self.Li = [None] * 3; self.LiT = [None] * 4; self.L1 = [None] * 2; self.L2 = [None] * 3; self.y = [None] * 3
+            self.bet = [None] * 3; self.Y0 = [None] * 2; self.Y1 = [None] * 2
+            self.rec = [dict(W1=np.zeros((nd, nd)), W2=np.zeros((nd, nd)), yh=np.zeros(nd)) for _ in range(n)]
+
+    def stage_b(c, i, full=True):                 # the dependency chain: L1_i, L0_i and its inverse
+        y0, y1 = c.Y0[i & 1], c.Y1[i & 1]
+        if i >= 1:
+            if i >= 2:
+                y1 = y1 - c.L2[i % 3] @ c.L1[(i + 1) & 1].T
+            c.L1[i & 1] = y1 @ c.Li[(i + 2) % 3].T
+        if not full:
+            return
+        if i >= 1:
+            y0 = y0 - c.L1[i & 1] @ c.L1[i & 1].T
+        if i >= 2:
+            y0 = y0 - c.L2[i % 3] @ c.L2[i % 3].T
+        L0 = np.linalg.cholesky(y0)
+        c.Li[i % 3] = np.linalg.inv(L0)
+        c.LiT[i % 4] = c.Li[i % 3].T
+
+    def stage_c(c, i, full=True, skip_w1=False):  # off the chain: records of the backward pass, forward substitution
+        if i >= 1 and not skip_w1:
+            c.rec[i - 1]["W1"] = c.L1[i & 1] @ c.LiT[(i - 1) % 4].T
+        if i >= 2:
+            c.rec[i - 2]["W2"] = c.L2[i % 3] @ c.LiT[(i - 2) % 4].T
+        if not full:
+            return
+        s = c.bet[i % 3].copy()
+        if i >= 1:
+            s -= c.L1[i & 1] @ c.y[(i + 2) % 3]
+        if i >= 2:
+            s -= c.L2[i % 3] @ c.y[(i + 1) % 3]
+        c.y[i % 3] = c.Li[i % 3] @ s
+        c.rec[i]["yh"] = c.Li[i % 3].T @ c.y[i % 3]
+
+    # ---- bottom chain: stage A of the reversed matrix, rings indexed by the chain step --------------------------------
+    bot = Chain(nb)
+    Qr = [None] * 3; rqr = [None] * 3; A1r = [None] * 2; A2r = [None] * 3
+    Qr[0], Qr[1] = Qi[H - 1], Qi[H - 2]; rqr[0], rqr[1] = rpq[H - 1], rpq[H - 2]          # the preamble
+    S00 = S11 = S10T = c0 = c1 = None
+    for i in range(nb + 2):
+        j = H - 1 - i
+        m0, m1, m2, p0, p1 = i % 3, (i + 2) % 3, (i + 1) % 3, i & 1, (i + 1) & 1
+        A0 = du1[j]; A1r[p0] = dq1[j]; A2r[m0] = dq0[j]
+        if j >= 2:
+            Qr[m1] = Qi[j - 2]; rqr[m1] = rpq[j - 2]                                       # entering two rows ahead
+        Qj, Qj1, Qj2 = Qr[m0], Qr[m2], Qr[m1]
+        T0 = A0 @ Ri[j]; T1 = A1r[p0] @ Qj1; T2 = A2r[m0] @ Qj2
+        y0 = Qj + rho * eye + T0 @ A0.T + T1 @ A1r[p0].T + T2 @ A2r[m0].T
+        y1 = np.zeros((nd, nd))
+        if i >= 1:
+            y1 = -(Qj @ A1r[p1].T) + T1 @ A2r[m1].T
+        if i >= 2:
+            Tq = Qj @ A2r[m2].T
+            bot.L2[m0] = -(Tq @ bot.Li[(i + 1) % 3].T)
+        bot.bet[m0] = T0 @ rpu[j] - Qj @ rqr[m0] + T1 @ rqr[m2] + T2 @ rqr[m1] - rd[j]
+        bot.Y0[p0], bot.Y1[p0] = y0, y1
+        if i < nb:
+            stage_b(bot, i); stage_c(bot, i)
+        elif i == nb:                                                                     # trace step of row m+1
+            stage_b(bot, i, full=False)
+            S00 = bot.L1[p0] @ bot.L1[p0].T + bot.L2[m0] @ bot.L2[m0].T
+            stage_c(bot, i, full=False)
+            c0 = bot.L1[p0] @ bot.y[m1] + bot.L2[m0] @ bot.y[m2]
+        else:                                                                             # trace step of row m
+            S11 = bot.L2[m0] @ bot.L2[m0].T
+            S10T = bot.L1[p1] @ bot.L2[m0].T
+            stage_c(bot, i, full=False, skip_w1=True)
+            c1 = bot.L2[m0] @ bot.y[m2]
+    # ---- top chain: the one-ended recursion up to row m+1 ------------------------------------------------------------
+    top = Chain(m + 2)
+    for i in range(m + 2):
+        m0, p0 = i % 3, i & 1
+        A0 = du1[i]
+        T0 = A0 @ Ri[i]
+        y0 = Qi[i] + rho * eye + T0 @ A0.T
+        y1 = np.zeros((nd, nd))
+        b = T0 @ rpu[i] - Qi[i] @ rpq[i] - rd[i]
+        if i >= 1:
+            T1 = dq1[i] @ Qi[i - 1]
+            y0 += T1 @ dq1[i].T; y1 = -T1; b += T1 @ rpq[i - 1]
+        if i >= 2:
+            T2 = dq0[i] @ Qi[i - 2]
+            y0 += T2 @ dq0[i].T; y1 = y1 + T2 @ dq1[i - 1].T; b += T2 @ rpq[i - 2]
+            top.L2[m0] = -(T2 @ top.Li[(i + 1) % 3].T)
+        if i == m:
+            y0 = y0 - S11; b = b - c1
+        if i == m + 1:
+            y0 = y0 - S00; y1 = y1 - S10T; b = b - c0
+        top.Y0[p0], top.Y1[p0], top.bet[m0] = y0, y1, b
+        stage_b(top, i); stage_c(top, i)
+    # ---- backward passes on the records --------------------------------------------------------------------------------
+    dnu = np.zeros((H, nd))
+    dt = np.zeros((m + 2, nd))
+    for i in range(m + 1, -1, -1):
+        s = top.rec[i]["yh"].copy()
+        if i + 1 < m + 2:
+            s -= top.rec[i]["W1"].T @ dt[i + 1]
+        if i + 2 < m + 2:
+            s -= top.rec[i]["W2"].T @ dt[i + 2]
+        dt[i] = s
+    dnu[:m + 2] = dt
+    db = np.zeros((nb + 2, nd))
+    db[nb], db[nb + 1] = dt[m + 1], dt[m]                                                  # the hand-over
+    for i in range(nb - 1, -1, -1):
+        db[i] = bot.rec[i]["yh"] - bot.rec[i]["W1"].T @ db[i + 1] - bot.rec[i]["W2"].T @ db[i + 2]
+    for i in range(nb):
+        dnu[H - 1 - i] = db[i]
+    # ---- primal recovery (top chain: rows 0 .. m-1, bottom chain: rows m .. H-1) ----------------------------------------
+    Delta = np.zeros(lay.N)
+    for i in range(H):
+        Delta[lay.pu(i)] = Ri[i] @ (rpu[i] - du1[i].T @ dnu[i])
+        cq = -dnu[i].copy()
+        if i + 1 < H:
+            cq += dq1[i + 1].T @ dnu[i + 1]
+        if i + 2 < H:
+            cq += dq0[i + 2].T @ dnu[i + 2]
+        Delta[lay.pq(i)] = Qi[i] @ (rpq[i] - cq)
+        Delta[lay.dual(i)] = dnu[i]
+    return Delta
+
+
 # ----------------------------------------------------------------------------
 # update_traj! / reset! / newton_solve!
 # ----------------------------------------------------------------------------

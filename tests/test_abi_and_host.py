@@ -159,7 +159,7 @@ def test_every_environment_override_is_documented():
             assert f.endswith("cimpc_host.cpp"), (f, found)          # only the host's create path reads the environment
         names |= found
     readme = open(os.path.join(root, "README.md")).read()
-    assert 8 <= len(names) <= 16, sorted(names)
+    assert 8 <= len(names) <= 18, sorted(names)      # (round 5: + CIMPC_KKT_TWISTED, CIMPC_KKT_TW_NB - both driven by tests/test_gpu_round5.py)
     for n in sorted(names):
         tail = n[len("CIMPC_"):]
         assert n in readme or ("_" + tail.split("_", 1)[-1]) in readme, n + " is not documented in README.md"

@@ -305,6 +305,9 @@ def test_async_single_launch_matches_lockstep(gpu_required, monkeypatch, mode, B
     q0 = np.stack([r[2] for r in rollouts]); q1 = np.stack([r[3] for r in rollouts])
     if tail is not None:
         monkeypatch.setenv("CIMPC_ASYNC_TAIL", tail)
+    # (same arithmetic on both sides: the lock-step rounds of a small batch would take the twisted KKT solve of round 5, the
+    #  asynchronous kernel's KKT job is the one-ended pipeline - tests/test_gpu_round5.py compares the two solves)
+    monkeypatch.setenv("CIMPC_KKT_TWISTED", "0")
     outs = []
     for flag in ("0", mode):
         monkeypatch.setenv("CIMPC_ASYNC", flag)

@@ -1,0 +1,198 @@
+"""Round 5 device tests.
+
+* The TWISTED (two-ended) condensed KKT solve (csrc/newton_impl.h: kkt_body<..., TW>, kkt_kernel_twisted): two workgroups per
+  rollout factor the block penta-diagonal dual Schur complement from both ends - the recurrences of
+  /root/reference/src/controller/newton_structure_solver/methods.jl:466-557 run from either end towards the two middle rows -
+  against `numpy.linalg.solve` of the oracle's `jacobian!` matrix (the reference default `:lu_solver`, lu.jl:4-12) and against
+  the one-ended device kernels, at BASELINE.json's sizes (quadruped H = 40, centroidal H = 60) and for every position of the
+  middle on a short horizon.  CPU statement of the kernel's index algebra: oracle/newton.py: kkt_solve_condensed_twisted_device
+  (tests/test_oracle_reference_constructions.py::test_twisted_device_schedule).
+* a parked interior-point solve with max_iter >= 128 and no time budget keeps its count; non-symmetric objective
+  blocks are refused.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ip as oip, newton as onewton, synth
+
+from common import make_case, make_solver
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _record(name, payload):
+    try:
+        os.makedirs(OUT, exist_ok=True)
+        path = os.path.join(OUT, "parity_round5.json")
+        data = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                data = json.load(f)
+        data[name] = payload
+        with open(path, "w") as f:
+            json.dump(data, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _kkt_case(model, H, H_ref, B, seed=5):
+    d, prob, tabs, rollouts = make_case(model, 0, H_ref=H_ref, H=H, B=B, seed=seed)
+    obj = synth.make_objective(d, H, dense_q=True)
+    return d, prob, rollouts, obj
+
+
+def _solve_all(monkeypatch, twisted, d, prob, rollouts, obj, H, r, betas, nb=None):
+    monkeypatch.setenv("CIMPC_KKT_TWISTED", "1" if twisted else "0")
+    if nb is not None:
+        monkeypatch.setenv("CIMPC_KKT_TW_NB", str(nb))
+    else:
+        monkeypatch.delenv("CIMPC_KKT_TW_NB", raising=False)
+    s = make_solver(d, prob, rollouts, H, obj=obj)
+    q = np.stack([ro.q for (_, ro, _, _) in rollouts]); th = np.stack([ro.theta for (_, ro, _, _) in rollouts])
+    out = s.implicit_dynamics(q, th)
+    assert out["status"].all()
+    deltas = {beta: s.kkt_solve(r, beta) for beta in betas}
+    n_tw = s.kkt_twisted()
+    s.close()
+    return out, deltas, n_tw
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,H,H_ref,B", [
+    ("quadruped", 40, 60, 3),        # BASELINE configs[1..3]: 16 x 16 MFMA tiles, two chains of 21 + 2 / 17 + 2 steps
+    ("centroidal", 60, 71, 2),       # BASELINE configs[4]: 24 x 24 tiles (2 x 2 masked MFMA blocks), 151 KB of LDS per chain
+    ("hopper", 20, 24, 4),           # BASELINE configs[1] (hopper H = 20)
+    ("flamingo", 15, 20, 2),
+])
+def test_twisted_kkt_vs_dense_lu(gpu_required, monkeypatch, model, H, H_ref, B):
+    """B1 seam through the twisted kernel: equal to numpy's dense LU of the oracle's `jacobian!` matrix to 1e-10 of the solution's
+    scale where the system is well conditioned (beta = 10: every Newton iteration after the first), to the same 1e-7 as the
+    one-ended kernels at the cold start's beta = 1e-5 (cond > 1e8), and never further from the dense solve than 4 x the one-ended
+    kernel is."""
+    d, prob, rollouts, obj = _kkt_case(model, H, H_ref, B)
+    lay = onewton.Layout(d, H)
+    r = np.random.default_rng(0).standard_normal((B, lay.N))
+    betas = (1e-5, 1e-2, 10.0)
+    out1, one, n1 = _solve_all(monkeypatch, False, d, prob, rollouts, obj, H, r, betas)
+    out2, two, n2 = _solve_all(monkeypatch, True, d, prob, rollouts, obj, H, r, betas)
+    assert n1 == 0 and n2 == len(betas)             # the second handle really took the twisted kernel
+    rec = {}
+    for beta in betas:
+        e1 = e2 = e12 = 0.0
+        for b in range(B):
+            im = {k: out2[k][b] for k in ("d", "dq0", "dq1", "du1")}
+            np.testing.assert_array_equal(out1["dq0"][b], out2["dq0"][b])       # same sensitivities on both handles
+            R = onewton.jacobian(lay, obj, im, beta, prob["kappa"])
+            x = np.linalg.solve(R, r[b])
+            sc = max(1.0, np.abs(x).max())
+            assert np.isfinite(two[beta][b]).all()
+            e1 = max(e1, np.abs(one[beta][b] - x).max() / sc)
+            e2 = max(e2, np.abs(two[beta][b] - x).max() / sc)
+            e12 = max(e12, np.abs(two[beta][b] - one[beta][b]).max() / sc)
+        rec[str(beta)] = dict(one_ended_vs_dense=e1, twisted_vs_dense=e2, twisted_vs_one_ended=e12)
+        assert e2 <= (1e-10 if beta >= 1.0 else 1e-7), (beta, e2)
+        assert e2 <= max(4.0 * e1, 1e-12), (beta, e1, e2)
+    _record(f"twisted_kkt_{model}_h{H}", rec)
+
+
+@pytest.mark.gpu
+def test_twisted_kkt_every_split(gpu_required, monkeypatch):
+    """Every admissible position of the middle (CIMPC_KKT_TW_NB = rows eliminated from the bottom) gives the solution of the dense
+    solve: quadruped, H = 12."""
+    H, H_ref, B = 12, 16, 2
+    d, prob, rollouts, obj = _kkt_case("quadruped", H, H_ref, B, seed=7)
+    lay = onewton.Layout(d, H)
+    r = np.random.default_rng(1).standard_normal((B, lay.N))
+    for nb in range(2, H - 3):
+        out, two, n = _solve_all(monkeypatch, True, d, prob, rollouts, obj, H, r, (10.0,), nb=nb)
+        assert n == 1
+        for b in range(B):
+            im = {k: out[k][b] for k in ("d", "dq0", "dq1", "du1")}
+            x = np.linalg.solve(onewton.jacobian(lay, obj, im, 10.0, prob["kappa"]), r[b])
+            np.testing.assert_allclose(two[10.0][b], x, rtol=0, atol=1e-10 * max(1.0, np.abs(x).max()), err_msg=f"nb = {nb}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,H,H_ref,B", [("quadruped", 40, 60, 1), ("quadruped", 40, 60, 3), ("hopper", 20, 24, 1), ("centroidal", 16, 20, 2)])
+def test_newton_solve_twisted_vs_one_ended(gpu_required, monkeypatch, model, H, H_ref, B):
+    """newton_solve! with the twisted KKT stage (lock-step rounds of single rollouts / small batches) against the same solve with
+    the one-ended kernels: same Newton iterations, `u[1]` to 1e-8 where the discrete paths agree, and against the oracle the usual
+    bound."""
+    from contactimplicitmpc.jl_amd import NewtonOptions
+    d, prob, tabs, rollouts = make_case(model, 0, H_ref=H_ref, H=H, B=B, seed=11, perturb=1e-2)
+    obj = synth.make_objective(d, H, kind=model if model in ("quadruped", "hopper") else "quadruped")
+    q0 = np.stack([ro[2] for ro in rollouts]); q1 = np.stack([ro[3] for ro in rollouts])
+    res = {}
+    for tw in (0, 1):
+        monkeypatch.setenv("CIMPC_KKT_TWISTED", str(tw))
+        monkeypatch.setenv("CIMPC_ASYNC", "0")           # lock-step rounds: the schedule of B < 4 (the asynchronous kernel keeps its own KKT job)
+        s = make_solver(d, prob, rollouts, H, obj=obj, newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=1e-6, max_iter=4))
+        u1, it, rn = s.newton_solve(q0, q1)
+        cnt = s.rollout_counters()
+        u1w, itw, rnw = s.newton_solve(q0, q1, warm_start=True)
+        res[tw] = (u1, it, rn, u1w, itw, cnt, s.kkt_twisted())
+        s.close()
+    a, b = res[0], res[1]
+    assert a[6] == 0 and b[6] > 0
+    assert np.isfinite(b[0]).all() and np.isfinite(b[3]).all()
+    same = 0
+    for k in range(B):
+        if a[1][k] == b[1][k] and a[5]["sweeps"][k] == b[5]["sweeps"][k] and a[5]["ip_iters"][k] == b[5]["ip_iters"][k]:
+            same += 1
+            np.testing.assert_allclose(b[0][k], a[0][k], rtol=0, atol=1e-8 * max(1.0, np.abs(a[0][k]).max()))
+    assert same >= max(1, B - 1)
+    # against the oracle (cold solve)
+    ok = 0
+    for k, (window, rf, q0k, q1k) in enumerate(rollouts):
+        core = onewton.Newton(d, H, obj, onewton.NewtonOptions(r_tol=1e-6, max_iter=4, solver="lu"),
+                              oip.IPOptions(kappa_tol=prob["kappa"]), prob["kappa"], rf)
+        st = onewton.newton_solve(core, q0k, q1k, window, tabs, rf)
+        if st.iters == b[1][k]:
+            ok += int(np.abs(b[0][k] - core.traj.u[0]).max() < 1e-6 * max(1.0, np.abs(core.traj.u[0]).max()))
+    assert ok >= max(1, B - 1)
+
+
+@pytest.mark.gpu
+def test_parked_solves_keep_their_count_beyond_127_iterations(gpu_required, monkeypatch):
+    """lock-step rounds park a solve every `iter_cap` iterations; with max_iter >= 128 and NO time budget the parked
+    word is the plain count (it used to be masked to 7 bits on resume: 140 became 12, a solve that does not converge never reached
+    max_iter, was re-parked for ever and the call ended in CIMPC_ERR_STATE 'round limit reached').  Here NO solve can converge
+    (r_tol below round-off, stall exit off), so every one must take exactly max_iter = 150 iterations."""
+    from contactimplicitmpc.jl_amd import InteriorPointOptions, NewtonOptions
+    H, H_ref, B, MAXIT = 6, 8, 16, 150
+    d, prob, tabs, rollouts = make_case("quadruped", 0, H_ref=H_ref, H=H, B=B, seed=3, perturb=1e-2)
+    obj = synth.make_objective(d, H, kind="quadruped")
+    monkeypatch.setenv("CIMPC_ASYNC", "0")
+    monkeypatch.setenv("CIMPC_ITER_CAP", "12")
+    monkeypatch.setenv("CIMPC_TAIL_DIV", "0")               # park in every round, also the sparse ones
+    ipo = InteriorPointOptions(kappa_tol=prob["kappa"], r_tol=1e-30, max_iter=MAXIT, stall_alpha=0.0)
+    s = make_solver(d, prob, rollouts, H, obj=obj, ip_opts=ipo, newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=1e-6, max_iter=1))
+    q0 = np.stack([ro[2] for ro in rollouts]); q1 = np.stack([ro[3] for ro in rollouts])
+    s.newton_solve(q0, q1)
+    cnt = s.rollout_counters()
+    s.close()
+    assert (cnt["sweeps"] >= 1).all()
+    np.testing.assert_array_equal(cnt["ip_failures"], cnt["sweeps"] * H)
+    np.testing.assert_array_equal(cnt["ip_iters"], cnt["sweeps"] * H * MAXIT)
+
+
+@pytest.mark.gpu
+def test_nonsymmetric_objective_blocks_are_rejected(gpu_required):
+    """every KKT backend but the dense LU relies on symmetric weights (the condensed solve reads Qinv / Rinv as
+    symmetric operands, the banded LDL^T factors a symmetric matrix); the reference's weights are symmetric by construction
+    (objective.jl:1-47: Diagonal or `relative_state_cost`).  A clearly non-symmetric block is refused instead of solved wrongly."""
+    H, H_ref, B = 8, 10, 1
+    d, prob, tabs, rollouts = make_case("hopper", 0, H_ref=H_ref, H=H, B=B, seed=9)
+    obj = synth.make_objective(d, H, kind="hopper")
+    s = make_solver(d, prob, rollouts, H, obj=obj)
+    R = obj.u.copy(); R[3, 0, 1] += 0.1 * R[3, 0, 0]
+    with pytest.raises(Exception, match="symmetric"):
+        s.set_objective(obj.q, R, obj.gamma, obj.b)
+    Q = obj.q.copy(); Q[0, 1, 2] -= 0.05 * Q[0, 1, 1]
+    with pytest.raises(Exception, match="symmetric"):
+        s.set_objective(Q, obj.u, obj.gamma, obj.b)
+    s.set_objective(obj.q, obj.u, obj.gamma, obj.b)            # the symmetric blocks are still accepted afterwards
+    s.close()

@@ -314,3 +314,32 @@ def test_twisted_condensed_solve(model, H):
             x1 = onewton.kkt_solve_condensed_twisted(lay, obj, im, beta, prob["kappa"], r, split=split)
             assert np.abs(x1 - x0).max() <= 1e-9 * scale, (beta, split)
             assert np.abs(x1 - xd).max() <= 1e-10 * np.linalg.cond(R) * scale, (beta, split)
+
+
+@pytest.mark.parametrize("model,H", [("hopper", 9), ("quadruped", 12), ("quadruped", 20)])
+def test_twisted_device_schedule(model, H):
+    """The twisted solve restated with the DEVICE kernel's data flow (oracle/newton.py: kkt_solve_condensed_twisted_device - the
+    bottom chain forms its blocks of the reversed matrix from the operands it streams downwards, rings indexed by the chain step,
+    two trace steps, the top chain corrected in its last two rows, one-level backward passes on stage C's records, split primal
+    recovery; csrc/newton_impl.h: kkt_body<..., TW>): for every admissible split the solution of the one-ended condensed solve and
+    of the dense LU of jacobian! (newton_structure_solver/methods.jl:466-557 from both ends; lu.jl:4-12)."""
+    from oracle.dims import HOPPER_2D as HP
+    d = Dims(**(HP if model == "hopper" else QUADRUPED))
+    prob = synth.make_problem(d, H + 2, seed=4)
+    tabs = [lcp.LinTable(d, prob["z0"][t], prob["th0"][t], prob["r0"][t], prob["rz0"][t], prob["rth0"][t]) for t in range(H + 2)]
+    window, ref, q0, q1 = synth.make_rollout(d, prob, H, phase=1, seed=3, perturb=1e-2)
+    tr = ref.copy(); tr.q[0], tr.q[1] = q0, q1; tr.update_theta(d, 0); tr.update_theta(d, 1)
+    im = oip.implicit_dynamics(d, tabs, window, tr.q, tr.theta, oip.IPOptions())
+    obj = synth.make_objective(d, H, kind=model, velocity=False)
+    lay = onewton.Layout(d, H)
+    r = np.random.default_rng(0).standard_normal(lay.N)
+    assert onewton.kkt_tw_split(40) == 21 and onewton.kkt_tw_split(60) == 31 and onewton.kkt_tw_split(10) == 6      # (= the header's formula)
+    for beta in (1e-5, 1e-2, 10.0):
+        R = onewton.jacobian(lay, obj, im, beta, prob["kappa"])
+        xd = onewton.kkt_solve_lu(R, r)
+        x0 = onewton.kkt_solve_condensed(lay, obj, im, beta, prob["kappa"], r)
+        scale = max(1.0, np.abs(xd).max())
+        for split in [None] + list(range(2, H - 3)):
+            x1 = onewton.kkt_solve_condensed_twisted_device(lay, obj, im, beta, prob["kappa"], r, split=split)
+            assert np.abs(x1 - x0).max() <= 1e-9 * scale, (beta, split)
+            assert np.abs(x1 - xd).max() <= 1e-10 * np.linalg.cond(R) * scale, (beta, split)
