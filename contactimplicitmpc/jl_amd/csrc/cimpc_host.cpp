@@ -628,7 +628,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     A(&S.kkt_list, 2 * B);
     A(&S.slot_list, 2 * BS);
     AX(&S.counters, 8 * CPAD);
-    AX(&S.stats, std::max<size_t>(B * 4, 32));      // (>= 32 entries: diagnostic builds with -DCIMPC_KKT_PROF park their phase clocks at [8..23])
+    AX(&S.stats, std::max<size_t>(B * 4, 64));      // (>= 32 entries: diagnostic builds with -DCIMPC_KKT_PROF park their phase clocks at [8..23])
     AX(&S.ro_sweeps, B); AX(&S.ro_ip_iters, B); AX(&S.ro_ip_fail, B);
     AX(&S.nlog, B * NLOG * 4);
     A(&S.kkt_ws, B * H * (3 * (size_t)h->nd * h->nd + h->nd));
@@ -1639,10 +1639,10 @@ int cimpc_get_kkt_fallbacks(cimpc_handle h, long long* n) {
     return CIMPC_OK;
 }
 
-#ifdef CIMPC_KKT_PROF
+#if defined(CIMPC_KKT_PROF) || defined(CIMPC_KKT_TWPROF)
 // diagnostic builds only: raw read of the statistics buffer (the KKT kernels park their phase clocks at [8..23])
 int cimpc_debug_read_stats(cimpc_handle h, long long* out, int n) {
-    if (!h || !out || n > std::max(h->dm.B * 4, 32)) return CIMPC_ERR_INVALID;
+    if (!h || !out || n > std::max(h->dm.B * 4, 64)) return CIMPC_ERR_INVALID;
     HIP_TRY(h, hipMemcpy(out, h->S.stats, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
     return CIMPC_OK;
 }

@@ -1474,7 +1474,7 @@ constexpr int KKT_TW_TILES = 32;         // 29 + two more slots of the dq0 ring 
 // rows the top chain eliminates before the two middle rows: the bottom chain (two more products per stage A) gets the shorter half,
 // and its traces are on their way before the top chain reaches row m
 __host__ __device__ inline int kkt_tw_split(int H, int nb_override = 0) {
-    int nb = nb_override > 0 ? nb_override : (H - 6) / 2;
+    int nb = nb_override > 0 ? nb_override : (H - 8) / 2;
     if (nb < 2) nb = 2;
     if (nb > H - 4) nb = H - 4;
     return H - 2 - nb;
@@ -1562,8 +1562,24 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     // vec + (2,3,4) VS: y / dnu ring
     double* rpu = vec + 5 * VS;
     // vec + (6,7,8) VS: r_p(q) ring; vec + 9 VS: second beta (PIPE = 2); vec + 12 VS: scratch word
+#ifdef CIMPC_KKT_TWPROF
+    // (diagnostic builds) constant-rate clock stamps of the twisted chains -> statistics words 8 + 8 (TW - 1) + j (wave 0), 24 .. 27 (the waits)
+#define TWSTAMP(j) { if (TW != 0 && lane == 0 && b == 0) ((long long*)S.stats)[8 + 8 * (TW - 1) + (j)] = (long long)wall_clock64(); }
+#define TWSTAMPW(j) { if (TW != 0 && lane == 0 && b == 0) ((long long*)S.stats)[24 + (j)] = (long long)wall_clock64(); }
+#else
+#define TWSTAMP(j) {}
+#define TWSTAMPW(j) {}
+#endif
+    if (wave == 0) { TWSTAMP(0) }
+#ifdef CIMPC_KKT_TWPROF
+    if (TW != 0 && wave == 0 && lane == 0 && b == 0) {      // where the chain runs: HW_ID (wave / simd / cu / sh / se), XCC_ID
+        ((long long*)S.stats)[28 + 2 * (TW - 1)] = (long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        ((long long*)S.stats)[29 + 2 * (TW - 1)] = (long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
     for (int k = lane + 64 * wave; k < NTILES * TSZ + 13 * VS; k += 64 * PIPE) sm[k] = 0.0;
     if constexpr (PIPE >= 2) __syncthreads();
+    if (wave == 0) { TWSTAMP(1) }
     const double* rb = K.r + (size_t)b * S.N;
     const double beta = K.beta ? K.beta[b] : K.beta_scalar;
     const double rho = (double)H * beta * S.kappa;         // newton_jacobian.jl:169-186 quirk
@@ -1658,7 +1674,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         t.q0r = vec + (6 + m0) * VS; t.q1r = vec + (6 + m1) * VS; t.q2r = vec + (6 + m2) * VS;
         // hand-over buffers of the pipelined variant (by step parity); the one-wave variant keeps one set
         // L2_i: one tile (PIPE 1), by step parity (PIPE 2), ring of three (PIPE 3: stage C reads it two ticks after stage A wrote it)
-        t.L2c = PIPE == 3 ? (m0 == 0 ? L2c : m0 == 1 ? tile(22) : tile(27)) : (PIPE == 2 && p0) ? tile(22) : L2c;
+        t.L2c = tile(PIPE == 3 ? (m0 == 0 ? 9 : m0 == 1 ? 22 : 27) : (PIPE == 2 && p0) ? 22 : 9);      // (tile 9 = L2c; a select between tile INDICES, not pointers)
         t.Y0h = tile(23 + (PIPE >= 2 ? p0 : 0));
         t.Y1h = tile(25 + (PIPE >= 2 ? p0 : 0));
         // beta_i: by step parity (PIPE 2), ring of three (PIPE 3: read by stage C two ticks after stage A wrote it)
@@ -1666,11 +1682,11 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         t.bet = vec + (PIPE == 3 ? (m0 == 0 ? 0 : m0 == 1 ? 9 : 10) : (PIPE == 2 && p0) ? 9 : 0) * VS;
         // L0^-T ring (the transposed inverse factor: operand of W1 / W2): tiles 19..21 are free during the forward pass (PIPE 3:
         // four slots - stage C reads step i-2's while stage B writes step i+1's)
-        auto lit = [&](int j) { constexpr int R = PIPE == 3 ? 4 : 3; const int q = ((j % R) + R) % R; return q < 3 ? tile(19 + q) : tile(28); };
+        auto lit = [&](int j) { constexpr int R = PIPE == 3 ? 4 : 3; const int q = ((j % R) + R) % R; return tile(q < 3 ? 19 + q : 28); };
         t.LiT = lit(i); t.LiT1 = lit(i - 1); t.LiT2 = lit(i - 2);
         // dq0 ring of the bottom chain (chain steps i, i-1, i-2 = rows j, j+1, j+2)
-        auto a2t = [&](int q) { return q == 0 ? tile(1) : tile(28 + q); };
-        t.A2c = REV ? a2t(m0) : tile(1); t.A2p1 = a2t(m1); t.A2p2 = a2t(m2);
+        auto a2t = [&](int q) { return tile(q == 0 ? 1 : 28 + q); };
+        t.A2c = a2t(REV ? m0 : 0); t.A2p1 = a2t(m1); t.A2p2 = a2t(m2);
         t.p0 = p0; t.m0 = m0;
         return t;
     };
@@ -1838,7 +1854,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         if constexpr (PIPE >= 2) { y0 = tile_ld<TL, F32>(t.Y0h, li, lk); y1a = tile_ld<TL, F32>(t.Y1h, li, lk); }
         if constexpr (TW == 1) {
             if (i >= msp) {       // middle rows: minus what the rows eliminated from the bottom contribute
-                if (i == msp) tw_ok = kkt_tw_wait(xfl + 0);
+                if (i == msp) { TWSTAMPW(0) tw_ok = kkt_tw_wait(xfl + 0); TWSTAMPW(1) }
                 sub_g(y0, xS + (i == msp ? n2 : 0), tw_ok);                 // Y_mm -= S11 ,  Y_{m+1,m+1} -= S00
                 if (i == msp + 1) sub_g(y1a, xS + 2 * n2, tw_ok);           // Y_{m+1,m} -= S10^T
             }
@@ -1964,11 +1980,13 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         }
 #ifdef CIMPC_KKT_WPROF
         // (diagnostic builds) per wave: time inside its stage, time at the tick barrier -> statistics words 17 + 2 wave, 18 + 2 wave
-        if (lane == 0 && b == 0) { ((long long*)S.stats)[8 + 9 + 2 * wave] = w_stage; ((long long*)S.stats)[8 + 10 + 2 * wave] = w_bar; }
+        if (lane == 0 && b == 0) { ((long long*)S.stats)[(TW != 0 ? 32 + 8 * (TW - 1) : 8 + 9) + 2 * wave] = w_stage; ((long long*)S.stats)[(TW != 0 ? 33 + 8 * (TW - 1) : 8 + 10) + 2 * wave] = w_bar; }
 #endif
         __threadfence_block();                    // the other waves' spill stores are read back by wave 0
         __syncthreads();
-        if (wave != 0) return;
+        // (twisted chains: the other two waves come back for the primal recovery - a third of the rows each)
+        if constexpr (TW == 0) { if (wave != 0) return; }
+        if (wave == 0) { TWSTAMP(2) }
     } else {
         prefetch(0);
         for (int i = 0; i < H; ++i) {
@@ -1992,6 +2010,9 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     double* yb = vec;                                 // yhat_i
     double* dn_all = tile(16);                        // [H][16] all dnu (tiles 16..18; H <= 48)
     double* t_all = tile(7);                          // [H][nr] first level of the recovery (tiles 7..)
+    constexpr int RW = TW != 0 ? 3 : 1;                  // waves that share the primal recovery
+    [[maybe_unused]] auto rsync = [&] { if constexpr (TW != 0) __syncthreads(); else lds_sync(); };
+    if (TW == 0 || wave == 0) {                          // ---- the backward pass runs on wave 0 ----
     constexpr int PF_W = (2 * n2 + nd + 63) / 64;
     // The records come from global memory (L2): a load takes ~1 us, a backward step ~0.3 us - the loads run THREE steps ahead
     // (three register sets, the loop unrolled by three so that the sets are indexed statically; a record is 4 doubles per lane).
@@ -2011,6 +2032,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     const int NBK = TW == 2 ? nbot : NS;
     if constexpr (TW == 2) {
         tw_ok = kkt_tw_wait(xfl + 1);
+        TWSTAMP(3)
         if (lane < 2 * nd) dn_all[(nbot + lane / nd) * VS + lane % nd] = tw_ok ? xdn[lane] : __builtin_nan("");
         lds_sync();
         if (lane == 0) astore(xfl + 1, 0);        // consumed: the flag is down again for the next solve of this rollout
@@ -2050,6 +2072,9 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     for (int i = NBK - 1; i >= 0; i -= DEPTH) {
         static_for<0, DEPTH>([&](auto kc) { back_step(kc, i - decltype(kc)::value); });
     }
+    TWSTAMP(4)
+    }                                                    // ---- end of the backward pass ----
+    rsync();
     // ---- primal recovery, level 1: t = r_p - C^T dnu, one output per lane and trip.  In the q rows both sensitivity columns are
     //      requested before the first multiply-add (indices clamped, the terms dropped afterwards): one memory round trip per row
     //      instead of three dependent ones.  (Two loops, one per kind of row, trip an instruction-selection bug of this compiler
@@ -2058,7 +2083,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     //  dnu of matrix row j sits at the chain-local index: dnl(j))
     const int rr0 = TW == 2 ? msp : 0, rrn = TW == 1 ? msp : TW == 2 ? H - msp : H;      // first row, number of rows
     auto dnl = [&](int j) { return dn_all + (REV ? H - 1 - j : j) * VS; };
-    for (int idx = lane; idx < rrn * nr; idx += 64) {
+    for (int idx = lane + 64 * wave; idx < rrn * nr; idx += 64 * RW) {
         const int il = idx / nr, c = idx - il * nr, i = rr0 + il;
         double s = rb[rr0 * nr + idx];
         if (c < nu) {
@@ -2087,10 +2112,10 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         }
         t_all[idx] = s;
     }
-    lds_sync();
+    rsync();
     // ---- level 2: Delta_x = P^-1 t: a u row and a q row per trip, indices clamped instead of branched on --------------------
     constexpr int RJ = nq > nu ? nq : nu;
-    for (int j = lane; j < rrn * RJ; j += 64) {
+    for (int j = lane + 64 * wave; j < rrn * RJ; j += 64 * RW) {
         const bool on_u = j < rrn * nu, on_q = j < rrn * nq;
         const int ju = on_u ? j : 0, iul = ju / nu, cu = ju - iul * nu, iu = rr0 + iul;
         const int jq = on_q ? j : 0, il = jq / nq, cq = jq - il * nq, i = rr0 + il;
@@ -2109,16 +2134,22 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         D[iu * nr + cu] = su;              // (surplus lanes recompute and rewrite row 0: same value, same address)
         D[i * nr + nu + cq] = sq;
     }
-    lds_sync();
+    if constexpr (TW != 0) {      // the three waves' rows are complete (and visible) before wave 0 reports the chain finished
+        __threadfence_block();
+        __syncthreads();
+        if (wave != 0) return;
+    } else lds_sync();
     KPROF(8)
 #ifdef CIMPC_KKT_PROF
     if (lane == 0 && b == 0) for (int j = 0; j < 9 ; ++j) ((long long*)S.stats)[8 + j] = pt[j];      // (diagnostic builds: overwrites the statistics of rollouts 2..5)
 #endif
+    TWSTAMP(5)
     if constexpr (TW != 0) {      // the chain that finishes last has the whole step in front of it: it starts the line search
         __threadfence();
         int prev = 0;
         if (lane == 0) prev = atomicAdd(xfl + 2, 1);
         prev = __builtin_amdgcn_readfirstlane(prev);
+        TWSTAMP(6)
         if (prev == 0) return;
         __threadfence();
         if (lane == 0) astore(xfl + 2, 0);
@@ -2167,19 +2198,47 @@ __global__ __launch_bounds__(192, (kkt_tld<NQ, NU>() <= 16 ? 2 : 1)) void kkt_ke
 // their dnu through global memory (flags at agent scope).  The bottom chain has the LOWER block index: it waits for nothing
 // until its forward pass is done, so whatever the dispatch order, a resident bottom chain's partner is the next block to start.
 // list == nullptr: rollout blockIdx.x / 2 + S.b0 (stage filter as kkt_kernel).
+// The two chains are compiled as REAL functions (noinline), each with its own register allocation: inlined side by side into one
+// kernel both bodies ran 15 - 30 % slower per step than the same stages of the one-ended kernel (492 v_readlane reloads of spilled
+// scalar registers against 81; stage A 2.43 us per step against 1.88 - profiles/r05/twisted_prof_b.log).  A chain reads its
+// arguments from the kernel-argument segment (scalar loads from the constant address space) and names the dynamic LDS itself,
+// so that the tiles keep their address space (ds_ instructions, not flat ones): the LDS base travels as an address_space(3) pointer.
+struct KktTwArgs { NewtonDev S; KktArgs K; const int* list; int n; const int* n_dev; };
+template <class T, size_t OFFSET>
+__device__ __forceinline__ T kkt_kernarg(unsigned long long v) {
+    T out;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    const unsigned long long u = (((unsigned long long)hi << 32) | lo) + OFFSET;
+    __builtin_memcpy(&out, (const __attribute__((address_space(4))) T*)u, sizeof(T));
+#else
+    (void)v;
+#endif
+    return out;
+}
+using lds_double_ptr = __attribute__((address_space(3))) double*;
+template <int NQ, int NU, int TW>
+__device__ __attribute__((noinline)) void kkt_tw_chain(unsigned long long ka, int b, lds_double_ptr sm3) {
+    const NewtonDev S = kkt_kernarg<NewtonDev, offsetof(KktTwArgs, S)>(ka);
+    const KktArgs K = kkt_kernarg<KktArgs, offsetof(KktTwArgs, K)>(ka);
+    kkt_body<NQ, NU, WaveSync, 3, false, TW>(S, K, b, (double*)sm3, (int)threadIdx.x & 63, (int)threadIdx.x >> 6);
+}
 template <int NQ, int NU>
-__global__ __launch_bounds__(192, (kkt_tld<NQ, NU>() <= 16 ? 2 : 1)) void kkt_kernel_twisted(NewtonDev S, KktArgs K, const int* list, int n, const int* n_dev) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    if (n_dev != nullptr) n = *n_dev;
+__global__ __launch_bounds__(192, (kkt_tld<NQ, NU>() <= 16 ? 2 : 1)) void kkt_kernel_twisted(KktTwArgs A) {
+    int n = A.n;
+    if (A.n_dev != nullptr) n = *A.n_dev;
     const int k = (int)blockIdx.x >> 1;
     if (k >= n) return;
-    const int b = list != nullptr ? list[k] : k + S.b0;
-    if (list == nullptr) {
-        if (K.stage != nullptr && K.stage[b] != STAGE_KKT) return;
-        if (K.only_flag != nullptr && K.only_flag[b] == 0) return;
+    const int b = A.list != nullptr ? A.list[k] : k + A.S.b0;
+    if (A.list == nullptr) {
+        if (A.K.stage != nullptr && A.K.stage[b] != STAGE_KKT) return;
+        if (A.K.only_flag != nullptr && A.K.only_flag[b] == 0) return;
     }
-    if (((int)blockIdx.x & 1) == 0) kkt_body<NQ, NU, WaveSync, 3, false, 2>(S, K, b, sm, (int)threadIdx.x & 63, (int)threadIdx.x >> 6);
-    else kkt_body<NQ, NU, WaveSync, 3, false, 1>(S, K, b, sm, (int)threadIdx.x & 63, (int)threadIdx.x >> 6);
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    if (((int)blockIdx.x & 1) == 0) kkt_tw_chain<NQ, NU, 2>(ka, b, (lds_double_ptr)sm);
+    else kkt_tw_chain<NQ, NU, 1>(ka, b, (lds_double_ptr)sm);
 }
 
 // (wide tiles: 105 KB of LDS allow one workgroup per CU anyway - let it use the 512-register budget)

@@ -502,7 +502,7 @@ static int launch_kkt_packed_t(const NewtonDev& S, const KktArgs& K, const int* 
             const size_t lds3 = (size_t)kkt_tw_lds_doubles<NQ, NU>() * sizeof(double);
             static LdsOptIn optin3;
             if (lds_opt_in(optin3, (const void*)kkt_kernel_twisted<NQ, NU>, lds3) != CIMPC_OK) return CIMPC_ERR_HIP;
-            hipLaunchKernelGGL((kkt_kernel_twisted<NQ, NU>), dim3(2 * n), dim3(192), lds3, s, S, K, list, n, n_dev);
+            hipLaunchKernelGGL((kkt_kernel_twisted<NQ, NU>), dim3(2 * n), dim3(192), lds3, s, KktTwArgs{S, K, list, n, n_dev});
             return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
         }
         if (pipe) {      // three wavefronts per rollout, software-pipelined forward recursion
@@ -698,7 +698,7 @@ static int launch_kkt_twisted_t(const NewtonDev& S, const KktArgs& K, hipStream_
         const size_t lds = (size_t)kkt_tw_lds_doubles<NQ, NU>() * sizeof(double);
         static LdsOptIn optin;
         if (lds_opt_in(optin, (const void*)kkt_kernel_twisted<NQ, NU>, lds) != CIMPC_OK) return CIMPC_ERR_HIP;
-        hipLaunchKernelGGL((kkt_kernel_twisted<NQ, NU>), dim3(2 * S.nb_launch), dim3(192), lds, s, S, K, (const int*)nullptr, S.nb_launch, (const int*)nullptr);
+        hipLaunchKernelGGL((kkt_kernel_twisted<NQ, NU>), dim3(2 * S.nb_launch), dim3(192), lds, s, KktTwArgs{S, K, nullptr, S.nb_launch, nullptr});
         return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
     }
     return CIMPC_ERR_INVALID;

@@ -7,14 +7,25 @@
 #   A1  LinearizedStep per knot -> cimpc_set_linearization                      src/controller/linearized_step.jl:10-31
 #   glue rot_n_stride! / update_window!                                         src/controller/policy.jl:133-141
 #
-# Usage: `include("CIMPCHip.jl")` INSIDE `module ContactImplicitMPC` (src/ContactImplicitMPC.jl), anywhere AFTER line 32 (the
-# `import RoboDojo: LinearSolver, ..., linear_solve!` the binding's own import needs) - e.g. next to the solver includes of lines
-# 38-42, or at the end of the module; library path in ENV["CIMPC_LIB"].  The file defines the submodule `CIMPCHip`, which imports
+# DROP-IN under the reference's UNCHANGED policy (round 5): `NewtonOptions(solver = :hip_mpc_solver, ...)` - ONE changed line in
+# e.g. examples/quadruped/flat.jl:45 (`solver = :ldl_solver`).  `Newton(...)` (newton.jl:86) then builds a `HipMPCSolver <:
+# LinearSolver`, the linear-solver TYPE is a type parameter of `Newton{T,nq,nu,nw,nc,nb,nz,nθ,nν,NJ,NR,NI,O,LS,NV}`
+# (newton.jl:17-35), and the method of the package's own `newton_solve!` defined below for `LS = HipMPCSolver` is what
+# `policy(p::CIMPC, traj, t)` reaches at policy.jl:119-120 - the whole MPC step runs on the GPU with `ci_mpc_policy`, `policy`,
+# `simulate!` untouched.  The handle is built at the first solve from what `newton_solve!` receives (`core`, `s`, `im_traj`,
+# `ref_traj`): no global registry.
+#
+# Usage: `include("CIMPCHip.jl")` INSIDE `module ContactImplicitMPC` (src/ContactImplicitMPC.jl).  For the drop-in B4 method the
+# include must come AFTER `include("controller/policy.jl")` (line 108: `Newton`, `newton_solve!`, `ImplicitTrajectory`, `ContactTraj`,
+# `Simulation` exist then) - e.g. as line 111, before the visuals; for the B1 solvers alone anywhere after line 32 (the
+# `import RoboDojo: LinearSolver, ..., linear_solve!` the binding's own import needs) is enough, and the B4 method is then simply
+# not defined.  Library path in ENV["CIMPC_LIB"].  The file defines the submodule `CIMPCHip`, which imports
 # the package's own `linear_solve!` / `LinearSolver` (so that newton.jl:218 dispatches to the GPU solvers) and, with its last
-# line, makes the constructors `hip_kkt_solver` / `hip_csc_solver` visible to `eval(opts.solver)` in the package module
-# (newton.jl:86).  Names the package defines LATER in its include order - `friction_dim` (simulator/environment.jl),
+# line, makes the constructors `hip_mpc_solver` / `hip_kkt_solver` / `hip_csc_solver` visible to `eval(opts.solver)` in the package
+# module (newton.jl:86).  Names the package defines LATER in its include order - `friction_dim` (simulator/environment.jl),
 # `LinearizedStep` (controller/linearized_step.jl) - are NOT imported at the top: they are looked up in the parent module when a
 # `Solver` is built (`_pkg()`), so the include position does not matter for them.
+# Explicit form (a host that drives the handle itself):
 #   p   = ci_mpc_policy(ref_traj, s, obj; H_mpc, N_sample, κ_mpc, mode, n_opts, ip_opts)
 #   hip = CIMPCHip.Solver(s, ref_traj, obj; H_mpc, κ = κ_mpc, mode, n_opts, ip_opts)      # once
 #   CIMPCHip.newton_solve!(hip, p.newton, p.q0, q1, p.window, p.traj; warm_start = t > 1)   # instead of newton.jl:169
@@ -261,6 +272,88 @@ function linear_solve!(s::HipCSCSolver, x::Vector{Float64}, A::SparseMatrixCSC{F
     return nothing
 end
 
+# ---- B4 DROP-IN: the package's own newton_solve!, specialised on the linear-solver type parameter ---------------------------------
+# (c) opts.solver = :hip_mpc_solver.  `Newton(...)` calls `eval(opts.solver)(jac.R)` (newton.jl:86) BEFORE anything else of the MPC
+#     problem is known to a solver constructor, so the solver object starts empty; its handle is created by the first
+#     `newton_solve!` from the arguments of that call:
+#         dims      s.model, s.env, im_traj.mode, ref_traj.H (= H_ref), core.traj.H (= H_mpc)
+#         tables    im_traj.lin[t]  (the LinearizedStep of every knot, implicit_dynamics.jl:57 - no second linearization)
+#         options   core.opts (NewtonOptions), im_traj.ip[1].opts (InteriorPointOptions), κ = im_traj.ip[1].κ[1]
+#         objective core.obj
+#     Afterwards every call uploads window, reference (p.traj, rotated by the policy on the host, policy.jl:133-139), q0, q1 and the
+#     altitude `im_traj.ip[1].r.alt` (set_altitude!, policy.jl:113), re-uploads a knot whose LinearizedStep changed
+#     (set_implicit_trajectory! at t = 1, update! in flight), solves, and writes core.traj / core.ν back (the Newton iterate the
+#     next warm start and the policy's `p.newton.traj.u[1]` read).  The Newton iterate itself stays resident on the device
+#     between calls (warm_start = true never uploads it).
+mutable struct HipMPCSolver <: LinearSolver
+    hs::Union{Nothing,Solver}
+    stamps::Vector{UInt}            # per knot: hash of the LinearizedStep last uploaded
+    device::Int
+end
+"`eval(opts.solver)(jac.R)` (newton.jl:86): an empty solver - its handle is built at the first `newton_solve!`."
+hip_mpc_solver(A) = HipMPCSolver(nothing, UInt[], parse(Int, get(ENV, "CIMPC_DEVICE", "0")))
+# The reference's own Newton loop never runs with this solver type (the method below replaces it); a direct call - somebody's
+# test of the LinearSolver interface - still gets a correct solve of the matrix it passes (lu.jl:4-12 contract).
+linear_solve!(s::HipMPCSolver, x::Vector{Float64}, A::SparseMatrixCSC{Float64,Int}, b::Vector{Float64}; reg::Float64 = 0.0, fact::Bool = true) =
+    linear_solve!(HipCSCSolver(s.device), x, A, b; reg = reg, fact = fact)
+
+_lin_stamp(lin) = hash(lin.rθ, hash(lin.rz, hash(lin.r, hash(lin.z, hash(lin.θ)))))
+
+function _upload_changed_knots!(ls::HipMPCSolver, im_traj)
+    for t = 1:length(im_traj.lin)
+        st = _lin_stamp(im_traj.lin[t])
+        st == ls.stamps[t] && continue
+        lin = im_traj.lin[t]
+        check(ccall((:cimpc_set_linearization, LIB), Cint,
+                    (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                    ls.hs.h, t, lin.z, lin.θ, lin.r, Matrix(lin.rz), Matrix(lin.rθ)), ls.hs.h)
+        ls.stamps[t] = st
+    end
+end
+
+function _build_handle!(ls::HipMPCSolver, core, s, im_traj, ref_traj)
+    m = s.model
+    nb = m.nc * _pkg().friction_dim(s.env)
+    mode = im_traj.mode
+    κ = im_traj.ip[1].κ[1]
+    dims = Dims(m.nq, m.nu, m.nw, m.nc, nb, mode == :configuration ? 0 : 1, ref_traj.H, core.traj.H, 1)
+    ip = Ref(IpOpts(im_traj.ip[1].opts))
+    nt = Ref(NewtonOpts(core.opts.r_tol, core.opts.β_init, core.opts.max_time, κ, core.opts.max_iter, KKT_CONDENSED))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:cimpc_create, LIB), Cint, (Ref{Dims}, Ref{IpOpts}, Ref{NewtonOpts}, Cint, Ref{Ptr{Cvoid}}),
+                Ref(dims), ip, nt, ls.device, h))
+    ls.hs = Solver(h[], dims)
+    ls.stamps = zeros(UInt, ref_traj.H)                             # (no LinearizedStep hashes to 0: every knot is uploaded)
+    _upload_changed_knots!(ls, im_traj)
+    set_objective!(ls.hs, core.obj, core.traj.H)
+    return ls.hs
+end
+
+import ..ContactImplicitMPC                                  # the module itself: `ContactImplicitMPC.newton_solve!` below extends ITS function
+if isdefined(ContactImplicitMPC, :newton_solve!) && isdefined(ContactImplicitMPC, :Newton)
+    @eval begin
+        # Same signature as newton.jl:169-177 with the fourteenth type parameter of Newton (newton.jl:17: `LS`, the type of
+        # `core.solver`) fixed - strictly more specific than the reference's method, so policy.jl:119-120 lands here.
+        # (Qualified definition: this module has a `newton_solve!` of its own - the explicit, handle-first form above.)
+        function ContactImplicitMPC.newton_solve!(
+            core::ContactImplicitMPC.Newton{T,nq,nu,nw,nc,nb,nz,nθ,nν,NJ,NR,NI,O,HipMPCSolver,NV},
+            s::ContactImplicitMPC.Simulation{T},
+            q0::Vector{T},
+            q1::Vector{T},
+            window::Vector{Int},
+            im_traj::ContactImplicitMPC.ImplicitTrajectory{T},
+            ref_traj::ContactImplicitMPC.ContactTraj{T};
+            warm_start::Bool = false) where {T,nq,nu,nw,nc,nb,nz,nθ,nν,NJ,NR,NI,O,NV}
+            ls = core.solver
+            ls.hs === nothing && _build_handle!(ls, core, s, im_traj, ref_traj)
+            _upload_changed_knots!(ls, im_traj)
+            set_altitude!(ls.hs, im_traj.ip[1].r.alt)                   # RLin.alt as set_altitude! left it (policy.jl:113)
+            newton_solve!(ls.hs, core, q0, q1, window, ref_traj; warm_start = warm_start, full = true)
+            return nothing
+        end
+    end
+end
+
 # ---- plant side: one simulator step for B robots (RoboDojo step! inside simulate!, simulator.jl:15-63) ---------------------------
 # model symbol -> (CIMPC_PLANT_* id, nq, nu, nc, friction directions per contact, nw); mirrors include/cimpc.h and
 # contactimplicitmpc/jl_amd/plant.py: MODELS (checked by tests/test_julia_binding.py)
@@ -291,4 +384,4 @@ end
 end # module
 
 # executed in the INCLUDING module (ContactImplicitMPC): `eval(opts.solver)` of newton.jl:86 looks the constructor up there
-using .CIMPCHip: hip_kkt_solver, hip_csc_solver
+using .CIMPCHip: hip_mpc_solver, hip_kkt_solver, hip_csc_solver

@@ -447,7 +447,7 @@ def kkt_tw_split(H):
     """Rows the top chain of the device's twisted solve eliminates before the two middle rows (csrc/newton_impl.h: kkt_tw_split):
     the bottom chain (its stage A forms two more products per step) gets the shorter half, and the top chain reaches the
     middle rows only after the bottom chain's traces can have arrived."""
-    nb = max(2, (H - 6) // 2)
+    nb = max(2, (H - 8) // 2)
     return H - 2 - nb
 
 

@@ -3,6 +3,7 @@
 # steps:  t5        round-5 device tests only            tests     the whole -m gpu suite
 #         bench     the default bench line               ab:<KNOB>:<v0>:<v1>[:flags]   scripts/ab_env.py on one box
 #         prof      scripts/profile_round.sh <tag>       k:<pytest -k expression>      a subset of the suite
+#         b1stats:<KNOB>:<v>   rocprofv3 --kernel-trace --stats of 50 cold B = 1 solves under KNOB=v
 # Everything lands under gpurun_out/ (<step>_<tag>.log); every step runs under its own timeout.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
@@ -20,6 +21,15 @@ for STEP in "$@"; do
         timeout 900 python scripts/ab_env.py $KNOB $V0 $V1 $(echo $FL | tr , ' ') > gpurun_out/ab_${KNOB}_$TAG.log 2> gpurun_out/ab_${KNOB}_$TAG.err; echo "ab rc $?"
         cat gpurun_out/ab_${KNOB}_$TAG.log; tail -5 gpurun_out/ab_${KNOB}_$TAG.err ;;
     prof) bash scripts/profile_round.sh $TAG ;;
+    b1stats:*) IFS=: read -r _ KNOB V <<< "$STEP"     # rocprofv3 kernel statistics of the B = 1 cold solve under KNOB=V
+        ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/b1_$TAG_$V && env $KNOB=$V rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/b1_${TAG}_$V -o p -- python $GRAFT_REPO_ROOT/scripts/b1_cold.py 50 > /tmp/b1_${TAG}_$V.log 2>&1 )
+        F=$(find /tmp/b1_${TAG}_$V -name "*kernel_stats.csv" | head -1); cp $F gpurun_out/kernel_stats_b1_${KNOB}_${V}_$TAG.csv; tail -2 /tmp/b1_${TAG}_$V.log
+        python - <<PY
+import csv
+for r in list(csv.DictReader(open("$F")))[:10]:
+    print("%-70s calls %6s  avg %9.1f us  total %8.2f ms  %5s %%" % (r["Name"][:70], r["Calls"], float(r["AverageNs"])/1e3, float(r["TotalDurationNs"])/1e6, r["Percentage"]))
+PY
+        ;;
     *) echo "unknown step $STEP" ;;
   esac
 done

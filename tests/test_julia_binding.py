@@ -125,7 +125,7 @@ def test_b1_seam_is_a_real_drop_in():
         assert re.search(r"struct " + name + r" <: LinearSolver", body), name
         assert re.search(r"function linear_solve!\(s::" + name + r", x::Vector\{Float64\}, A::SparseMatrixCSC\{Float64,Int\}, b::Vector\{Float64\};", body), name
     tail = JL.split("\nend # module")[1]
-    assert re.search(r"using \.CIMPCHip: hip_kkt_solver, hip_csc_solver", tail)       # in the including module's scope
+    assert re.search(r"using \.CIMPCHip: hip_mpc_solver, hip_kkt_solver, hip_csc_solver", tail)       # in the including module's scope
     assert "Main." not in JL                                                            # no dependence on where the package is loaded
     assert not re.search(r"\bhs\.β", body) and not re.search(r"^\s*β::", body, flags=re.M)     # no stale mirror of core.β
     kkt = body[body.index("function linear_solve!(s::HipKKTSolver"):]
@@ -187,3 +187,68 @@ def test_b2_seam_and_relinearisation_are_bound():
     body = JL.split("\nend # module")[0]
     assert "function rlin!(hs::Solver" in body and "function linear_solve!(hs::Solver" in body
     assert "function set_linearization!(hs::Solver" in body      # update!(lin, ...) in flight, linearized_solver.jl:497-565
+
+
+# the reference's own declarations, as the survey recorded them (src/controller/newton.jl:17 and :169-177): the type parameters of
+# Newton in order, and the positional / keyword arguments of newton_solve!
+NEWTON_PARAMS = "T,nq,nu,nw,nc,nb,nz,nθ,nν,NJ,NR,NI,O,LS,NV".split(",")
+NEWTON_SOLVE_ARGS = [("core", "Newton"), ("s", "Simulation{T}"), ("q0", "Vector{T}"), ("q1", "Vector{T}"), ("window", "Vector{Int}"),
+                     ("im_traj", "ImplicitTrajectory{T}"), ("ref_traj", "ContactTraj{T}")]
+
+
+def test_reference_declarations_are_what_the_binding_was_written_against():
+    """Only where the reference tree is present (this container; not the GPU box): newton.jl still declares Newton with these
+    fifteen type parameters, `solver::LS` as a field, and newton_solve! with these seven positional arguments + warm_start."""
+    ref = "/root/reference/src/controller/newton.jl"
+    if not os.path.exists(ref):
+        import pytest
+        pytest.skip("reference tree not present")
+    src = open(ref).read()
+    m = re.search(r"mutable struct Newton\{([^}]*)\}", src)
+    assert [x.strip() for x in m.group(1).split(",")] == NEWTON_PARAMS
+    assert re.search(r"^\s*solver::LS\s*$", src, flags=re.M)
+    assert re.search(r"solver = eval\(opts\.solver\)\(jac\.R\)", src)
+    sig = src[src.index("function newton_solve!("):]
+    sig = sig[:sig.index("where T")]
+    names = re.findall(r"^\s*(\w+)::", sig, flags=re.M)
+    assert names == [a for a, _ in NEWTON_SOLVE_ARGS] + ["warm_start"]
+    pol = open("/root/reference/src/controller/policy.jl").read()
+    assert re.search(r"newton_solve!\(p\.newton, p\.s, p\.q0, q1,\s*p\.window, p\.im_traj, p\.traj, warm_start = t > 1\)", pol)
+
+
+def test_b4_is_a_drop_in_under_the_unchanged_policy():
+    """VERDICT r04 (missing 1): `policy(p::CIMPC, traj, t)` calls the PACKAGE's newton_solve! (policy.jl:119-120).  The binding
+    adds a method of that very function - qualified definition, not a function of its own - whose first argument is
+    Newton{...} with the reference's fifteen type parameters in the reference's order and the fourteenth (LS, the type of
+    core.solver, newton.jl:17-35) fixed to HipMPCSolver; the other arguments and the keyword are those of newton.jl:169-177.  The
+    solver type is a LinearSolver built by `eval(opts.solver)(jac.R)` with no other information (newton.jl:86), so its handle is
+    created lazily from the arguments of the first solve - no global registry."""
+    body = JL.split("\nend # module")[0]
+    assert re.search(r"^import \.\.ContactImplicitMPC\s*(#.*)?$", body, flags=re.M)                 # the module itself, for the qualified definition
+    assert re.search(r"mutable struct HipMPCSolver <: LinearSolver", body)
+    assert re.search(r"^hip_mpc_solver\(A\) = HipMPCSolver\(nothing,", body, flags=re.M)            # eval(opts.solver)(jac.R): one argument
+    m = re.search(r"function ContactImplicitMPC\.newton_solve!\(\s*core::ContactImplicitMPC\.Newton\{([^}]*)\},(.*?)\) where \{([^}]*)\}", body, flags=re.S)
+    assert m, "no qualified method of the package's newton_solve!"
+    params = [x.strip() for x in m.group(1).split(",")]
+    assert len(params) == len(NEWTON_PARAMS) == 15
+    want = list(NEWTON_PARAMS); want[NEWTON_PARAMS.index("LS")] = "HipMPCSolver"
+    assert params == want, params
+    free = [x.strip() for x in m.group(3).split(",")]
+    assert free == [x for x in NEWTON_PARAMS if x != "LS"]                                           # every other parameter stays free
+    rest = m.group(2)
+    pos = re.findall(r"^\s*(\w+)::(?:ContactImplicitMPC\.)?([\w{}]+)", rest, flags=re.M)
+    assert pos == [(a, t) for a, t in NEWTON_SOLVE_ARGS[1:]] + [("warm_start", "Bool")], pos
+    assert re.search(r";\s*warm_start::Bool\s*=\s*false\s*$", rest.strip()), rest[-80:]
+    fn = body[m.start():]
+    fn = fn[:fn.index("\n        end\n") + 12]
+    # lazily built handle, per-call state from the arguments, full write-back for the warm start / p.newton.traj.u[1]
+    assert "ls.hs === nothing && _build_handle!(ls, core, s, im_traj, ref_traj)" in fn
+    assert "im_traj.ip[1].r.alt" in fn and "_upload_changed_knots!(ls, im_traj)" in fn
+    assert re.search(r"newton_solve!\(ls\.hs, core, q0, q1, window, ref_traj; warm_start = warm_start, full = true\)", fn)
+    bh = body[body.index("function _build_handle!"):]
+    bh = bh[:bh.index("\nend\n")]
+    for needle in ("im_traj.mode", "ref_traj.H", "core.traj.H", "im_traj.ip[1].opts", "im_traj.ip[1].κ[1]", "core.opts.r_tol", "core.obj", "_pkg().friction_dim(s.env)"):
+        assert needle in bh, needle
+    assert "CURRENT[]" not in fn and "CURRENT[]" not in bh                                            # no global registry on this path
+    # the guard: an early include (B1 only) must not fail on names newton.jl defines later
+    assert re.search(r"if isdefined\(ContactImplicitMPC, :newton_solve!\) && isdefined\(ContactImplicitMPC, :Newton\)", body)

@@ -333,7 +333,7 @@ def test_twisted_device_schedule(model, H):
     obj = synth.make_objective(d, H, kind=model, velocity=False)
     lay = onewton.Layout(d, H)
     r = np.random.default_rng(0).standard_normal(lay.N)
-    assert onewton.kkt_tw_split(40) == 21 and onewton.kkt_tw_split(60) == 31 and onewton.kkt_tw_split(10) == 6      # (= the header's formula)
+    assert onewton.kkt_tw_split(40) == 22 and onewton.kkt_tw_split(60) == 32 and onewton.kkt_tw_split(10) == 6      # (= the header's formula)
     for beta in (1e-5, 1e-2, 10.0):
         R = onewton.jacobian(lay, obj, im, beta, prob["kappa"])
         xd = onewton.kkt_solve_lu(R, r)
