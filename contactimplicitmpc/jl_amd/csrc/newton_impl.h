@@ -1472,14 +1472,18 @@ constexpr int KKT_PIPE3_TILES = 29;      // 27 + third L2 slot + fourth slot of 
 // the test oracle (newton.py: kkt_solve_condensed_twisted_device).
 constexpr int KKT_TW_TILES = 32;         // 29 + two more slots of the dq0 ring + the tile of Qinv_j dq0_{j+2}^T (bottom chain)
 // rows the top chain eliminates before the two middle rows: the bottom chain (two more products per stage A) gets the shorter half,
-// and its traces are on their way before the top chain reaches row m
-__host__ __device__ inline int kkt_tw_split(int H, int nb_override = 0) {
-    int nb = nb_override > 0 ? nb_override : (H - 8) / 2;
+// so that its traces arrive when the top chain reaches row m.  Measured stage times (profiles/r05/twisted_prof_d.log): 16-wide
+// tiles 1.95 us per tick of the top chain against 2.2 of the bottom chain -> nb = (H - 8) / 2; 24-wide tiles (2 x 2 MFMA blocks
+// per product) 7.8 against 10.3 us -> nb = (H - 10) / 2
+__host__ __device__ inline int kkt_tw_split(int H, int nb_override = 0, bool wide = false) {
+    int nb = nb_override > 0 ? nb_override : (H - (wide ? 10 : 8)) / 2;
     if (nb < 2) nb = 2;
     if (nb > H - 4) nb = H - 4;
     return H - 2 - nb;
 }
-constexpr int KKT_TW_MIN_H = 10;         // shorter horizons keep the one-ended kernels
+// shorter horizons keep the one-ended kernels: at H = 20 (hopper, BASELINE configs[1]) the two forms take the same time - 22 us
+// against 24 us per launch, profiles/r05/loop_trace_hopper_* - and the hand-overs are all that the second workgroup adds
+constexpr int KKT_TW_MIN_H = 24;
 // per-rollout exchange block of the two chains: [S00 | S11 | S10^T] (nd x nd each), c0, c1, dnu_{m+1}, dnu_m
 __host__ __device__ constexpr int kkt_tw_xch_doubles(int nd) { return 3 * nd * nd + 4 * nd; }
 constexpr int KKT_TW_FLAGS = 32;         // ints per rollout (one 128-byte line): [0] traces ready, [1] middle dnu ready, [2] chains finished
@@ -1541,7 +1545,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     const cimpc_dims& m = S.dm;
     const int H = m.H;
     // chain geometry: NS stage-A steps, of which the first NF are full steps (factor, y); row(i) = the matrix row of chain step i
-    const int msp = TW != 0 ? kkt_tw_split(H, S.kkt_tw_nb) : 0;       // twisted: middle rows msp, msp + 1
+    const int msp = TW != 0 ? kkt_tw_split(H, S.kkt_tw_nb, TL > 16) : 0;       // twisted: middle rows msp, msp + 1
     const int nbot = H - msp - 2;                                      // rows the bottom chain eliminates
     const int NS = TW == 1 ? msp + 2 : TW == 2 ? nbot + 2 : H;
     [[maybe_unused]] const int NF = TW == 2 ? nbot : NS;
@@ -2137,27 +2141,34 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     if constexpr (TW != 0) {      // the three waves' rows are complete (and visible) before wave 0 reports the chain finished
         __threadfence_block();
         __syncthreads();
-        if (wave != 0) return;
     } else lds_sync();
     KPROF(8)
 #ifdef CIMPC_KKT_PROF
     if (lane == 0 && b == 0) for (int j = 0; j < 9 ; ++j) ((long long*)S.stats)[8 + j] = pt[j];      // (diagnostic builds: overwrites the statistics of rollouts 2..5)
 #endif
-    TWSTAMP(5)
-    if constexpr (TW != 0) {      // the chain that finishes last has the whole step in front of it: it starts the line search
+    if constexpr (TW != 0) {
+        // The chain that finishes last has the whole step in front of it: it starts the line search - with all three of its waves
+        // (after the acquire every line of the step, the trajectory and the reference comes from memory: one wave took 33 us for it,
+        // profiles/r05/twisted_prof_e.log).  The verdict of the counter reaches the other waves through an LDS word.
+        if (wave == 0) {
+            TWSTAMP(5)
+            __threadfence();
+            if (lane == 0) vec[11 * VS] = (double)atomicAdd(xfl + 2, 1);
+            TWSTAMP(6)
+        }
+        __syncthreads();
+        if ((int)vec[11 * VS] == 0) return;
         __threadfence();
-        int prev = 0;
-        if (lane == 0) prev = atomicAdd(xfl + 2, 1);
-        prev = __builtin_amdgcn_readfirstlane(prev);
-        TWSTAMP(6)
-        if (prev == 0) return;
-        __threadfence();
-        if (lane == 0) astore(xfl + 2, 0);
+        if (wave == 0 && lane == 0) astore(xfl + 2, 0);
+        if (K.finish) start_line_search<BlockSync>(S, b, K.finish, lane + 64 * wave, 192);
+        if (wave == 0) { TWSTAMP(7) }
+        return;
     }
     if (K.finish) {
         __threadfence_block();
         start_line_search<Sync>(S, b, K.finish, lane, 64);
     }
+    TWSTAMP(7)
 }
 
 
@@ -2218,14 +2229,21 @@ __device__ __forceinline__ T kkt_kernarg(unsigned long long v) {
     return out;
 }
 using lds_double_ptr = __attribute__((address_space(3))) double*;
+// (noreturn + s_endpgm inside: the kernel has nothing left to do after its chain, and a function that never returns need not
+//  save the caller's registers - with the saves the kernel needed 416 bytes of scratch per lane, and a dispatch that needs scratch
+//  of this size per wave slot pays for its allocation: kernel 98 us against 68 us between the chains' first and last clock stamp)
 template <int NQ, int NU, int TW>
-__device__ __attribute__((noinline)) void kkt_tw_chain(unsigned long long ka, int b, lds_double_ptr sm3) {
+static __device__ __attribute__((noinline, noreturn)) void kkt_tw_chain(unsigned long long ka, int b, lds_double_ptr sm3) {
     const NewtonDev S = kkt_kernarg<NewtonDev, offsetof(KktTwArgs, S)>(ka);
     const KktArgs K = kkt_kernarg<KktArgs, offsetof(KktTwArgs, K)>(ka);
     kkt_body<NQ, NU, WaveSync, 3, false, TW>(S, K, b, (double*)sm3, (int)threadIdx.x & 63, (int)threadIdx.x >> 6);
+    __builtin_amdgcn_endpgm();
 }
 template <int NQ, int NU>
 __global__ __launch_bounds__(192, (kkt_tld<NQ, NU>() <= 16 ? 2 : 1)) void kkt_kernel_twisted(KktTwArgs A) {
+#ifdef CIMPC_KKT_TWPROF
+    if (threadIdx.x == 0 && blockIdx.x < 2) ((long long*)A.S.stats)[48 + blockIdx.x] = (long long)wall_clock64();      // kernel entry of the two chains of rollout 0
+#endif
     int n = A.n;
     if (A.n_dev != nullptr) n = *A.n_dev;
     const int k = (int)blockIdx.x >> 1;

@@ -241,7 +241,7 @@ int cimpc_get_kkt_fallbacks(cimpc_handle h, long long* n);
 /* KKT launches since cimpc_create that took the TWISTED condensed solve (two workgroups per rollout factor the block
  * penta-diagonal dual Schur complement from both ends: the two-ended form of newton_structure_solver/methods.jl:466-557).  It runs
  * where a solve is latency-bound - single rollouts and small batches in newton_solve!, the B1 seam cimpc_kkt_solve - for
- * horizons of at least 10 steps; CIMPC_KKT_TWISTED=0 in the environment at cimpc_create keeps the one-ended kernels. */
+ * horizons of at least 24 steps; CIMPC_KKT_TWISTED=0 in the environment at cimpc_create keeps the one-ended kernels. */
 int cimpc_get_kkt_twisted(cimpc_handle h, long long* n);
 /* per rollout, last newton solve: implicit_dynamics! evaluations, sum of IP iterations
  * ("solver iterations to tolerance"), failed IP solves.  Each B ints; any may be NULL. */

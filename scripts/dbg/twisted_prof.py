@@ -21,10 +21,18 @@ s = make_solver(d, prob, rollouts, H, obj=obj)
 q = np.stack([r.q for (_, r, _, _) in rollouts]); th = np.stack([r.theta for (_, r, _, _) in rollouts])
 s.implicit_dynamics(q, th)
 r = np.random.default_rng(0).standard_normal((1, s.N))
+NEWTON = os.environ.get("TW_NEWTON") == "1"      # the KKT launches of newton_solve! (finish = 1: the last chain starts the line search)
+if NEWTON:
+    from contactimplicitmpc.jl_amd import NewtonOptions
+    s.close()
+    s = make_solver(d, prob, rollouts, H, obj=obj, newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=1e-9, max_iter=3))
 s.lib.cimpc_debug_read_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int]
 rows = []
 for rep in range(6):
-    s.kkt_solve(r, 10.0)
+    if NEWTON:
+        s.newton_solve(np.stack([ro[2] for ro in rollouts]), np.stack([ro[3] for ro in rollouts]))
+    else:
+        s.kkt_solve(r, 10.0)
     out = (C.c_longlong * 64)()
     s.lib.cimpc_debug_read_stats(s.h, out, 64)
     rows.append(np.array(list(out), dtype=np.float64))
@@ -32,10 +40,11 @@ v = rows[-1]
 TK = 100.0      # wall_clock64 ticks per microsecond
 top, bot, w = v[8:16], v[16:24], v[24:28]
 t0 = min(top[0], bot[0])
-names = ["enter", "LDS clear done", "forward pass done", "(bottom) middle dnu received", "backward pass done", "recovery done", "finish counter"]
+names = ["enter", "LDS clear done", "forward pass done", "(bottom) middle dnu received", "backward pass done", "recovery done", "finish counter", "line search started (last chain)"]
 print("%s H = %d, twisted KKT solve (us since the first chain entered); twisted launches: %d" % (model, H, s.kkt_twisted()))
 for j, n in enumerate(names):
     print("  %-32s top %8.2f   bottom %8.2f" % (n, (top[j] - t0) / TK, (bot[j] - t0) / TK))
+print("  kernel entry: top %.2f, bottom %.2f us" % ((v[49] - t0) / TK, (v[48] - t0) / TK))
 print("  top chain, wave 1 at row m: waits for the traces from %.2f to %.2f us" % ((w[0] - t0) / TK, (w[1] - t0) / TK))
 
 def hw(x):

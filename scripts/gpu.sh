@@ -21,6 +21,10 @@ for STEP in "$@"; do
         timeout 900 python scripts/ab_env.py $KNOB $V0 $V1 $(echo $FL | tr , ' ') > gpurun_out/ab_${KNOB}_$TAG.log 2> gpurun_out/ab_${KNOB}_$TAG.err; echo "ab rc $?"
         cat gpurun_out/ab_${KNOB}_$TAG.log; tail -5 gpurun_out/ab_${KNOB}_$TAG.err ;;
     prof) bash scripts/profile_round.sh $TAG ;;
+    looptrace:*) IFS=: read -r _ KNOB V WHICH <<< "$STEP"     # kernel trace (durations + gaps) of the warm B = 1 loop under KNOB=V
+        ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/lt_${TAG}_$V && env $KNOB=$V rocprofv3 --kernel-trace --output-format csv -d /tmp/lt_${TAG}_$V -o p -- python $GRAFT_REPO_ROOT/scripts/loop_b1.py $WHICH 40 > /tmp/lt_${TAG}_$V.log 2>&1 )
+        F=$(find /tmp/lt_${TAG}_$V -name "*kernel_trace.csv" | head -1); grep ms_per /tmp/lt_${TAG}_$V.log | tail -1
+        python scripts/trace_gaps.py $F | tee gpurun_out/loop_trace_${WHICH}_${KNOB}_${V}_$TAG.txt ;;
     b1stats:*) IFS=: read -r _ KNOB V <<< "$STEP"     # rocprofv3 kernel statistics of the B = 1 cold solve under KNOB=V
         ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/b1_$TAG_$V && env $KNOB=$V rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/b1_${TAG}_$V -o p -- python $GRAFT_REPO_ROOT/scripts/b1_cold.py 50 > /tmp/b1_${TAG}_$V.log 2>&1 )
         F=$(find /tmp/b1_${TAG}_$V -name "*kernel_stats.csv" | head -1); cp $F gpurun_out/kernel_stats_b1_${KNOB}_${V}_$TAG.csv; tail -2 /tmp/b1_${TAG}_$V.log
