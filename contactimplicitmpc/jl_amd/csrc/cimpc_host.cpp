@@ -402,7 +402,11 @@ int ensure_mixed_ws(cimpc_ctx* h) {
 // KKT stage of the Newton loop for everything that is not the plain condensed solve
 static int launch_kkt_general(cimpc_ctx* h, const NewtonDev& Sk, hipStream_t st) {
     if (h->use_mixed) return launch_kkt_mixed_newton(Sk, h->d_mix_ws, h->d_mix_nfb, st);
-    if (h->cf_reduce) return launch_kkt_cf_reduced_newton(Sk, h->d_cf_ws, h->d_dense_ws, st);
+    if (h->cf_reduce) {
+        if (h->velocity_objective && kkt_banded_twisted_available(cf_shadow(Sk))) h->n_kkt_twisted++;
+        return launch_kkt_cf_reduced_newton(Sk, h->d_cf_ws, h->d_dense_ws, st);
+    }
+    if (h->use_banded && kkt_banded_twisted_available(Sk)) h->n_kkt_twisted++;      // (launch_kkt_dense's own test)
     return launch_kkt_dense_newton(Sk, h->d_dense_ws, st, h->use_banded);
 }
 
@@ -657,6 +661,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     S.kkt_scalar = h->kn.kkt_scalar ? 1 : 0;
     S.kkt_tw_nb = h->kn.kkt_tw_nb;
     S.kkt_tw_raw = (h->kn.kkt_twisted != 0 && d.B <= h->kn.kkt_tw_max) ? 1 : 0;
+    S.kkt_tw_band = S.kkt_tw_raw;      // (the banded LDL^T is launched over all rollouts of the handle: the same bound applies)
     // large batches: a rollout whose previous search needed a back-off starts the next one with 1, 1/2, 1/4 together (one
     // round less per Newton iteration for 0.9 more evaluated sweeps per step: B = 512 11.4 -> 10.9 ms); small batches already
     // evaluate all seven step lengths from depth 3 on
@@ -1114,6 +1119,7 @@ int cimpc_kkt_solve(cimpc_handle h, const double* r, double beta, double* delta)
     } else if (h->use_dense) {
         rc = ensure_dense_ws(h);
         if (rc != CIMPC_OK) return rc;
+        if (h->cf_reduce ? (h->velocity_objective && kkt_banded_twisted_available(cf_shadow(h->S))) : (h->use_banded && kkt_banded_twisted_available(h->S))) h->n_kkt_twisted++;
         rc = h->cf_reduce ? launch_kkt_cf_reduced_raw(h->S, h->d_rhs, beta, h->S.delta, h->d_cf_ws, h->d_dense_ws, h->stream)
                           : launch_kkt_dense_raw(h->S, h->d_rhs, beta, h->S.delta, h->d_dense_ws, h->stream, h->use_banded);
     } else {

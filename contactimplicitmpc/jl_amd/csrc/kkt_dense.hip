@@ -280,8 +280,30 @@ __device__ __forceinline__ void lds_barrier() {
 __host__ __device__ inline size_t banded_ws_per_rollout(const NewtonDev& S) {
     const size_t sF = (size_t)S.nr + S.nd, NF = (size_t)S.dm.H * sF;
     size_t wF = 3 * sF - 1 - S.dm.nu; if (wF > NF - 1) wF = NF - 1;
-    return NF * (wF + 1) + NF + (size_t)S.dm.H * S.nd * (S.nd + 1) + (sF * (wF + 2) + 1) / 2;      // ... and the descriptor table (32-bit words)
+    const size_t one = NF * (wF + 1) + NF + (size_t)S.dm.H * S.nd * (S.nd + 1) + (sF * (wF + 2) + 1) / 2;      // ... and the descriptor table (32-bit words)
+    // twisted form (two chains per rollout, kkt_banded_twisted_kernel): the chains' rows of L and y together are w + 8 more than
+    // N (the bottom chain keeps the multiplier rows of the w middle rows, <= 7 dummy rows pad its matrix), each chain has its own
+    // G / g / descriptor table, and the bottom chain hands its trace (w x w + w) to the top chain
+    const size_t tw = (wF + 8) * (wF + 2) + (size_t)S.dm.H * S.nd * (S.nd + 1) + (sF * (wF + 2) + 1) / 2 + wF * (wF + 1);
+    return one + tw;
 }
+// Split of the twisted banded factorisation (CPU statement: the test oracle's banded.py: twisted_split / twisted_chain_bulk_ldl_solve):
+// `pad` decoupled dummy rows behind the matrix make N + pad - w a multiple of RB; the bottom chain eliminates Nb pivots (a multiple of
+// RB, the dummies first) of the reversed matrix, the top chain rows 0 .. m2 + w - 1 with m2 = N + pad - Nb - w (a multiple of RB): it
+// receives the bottom chain's trace on rows m2 .. m2 + w - 1 at the start of block m2 - RB.
+struct BandSplit { int pad, Nb, m2; };
+__host__ __device__ inline BandSplit banded_twisted_split(int N, int w, int RB) {
+    BandSplit sp;
+    sp.pad = ((w - N) % RB + RB) % RB;
+    const int Np = N + sp.pad;
+    int Nb = ((Np - w + RB) / 2) / RB * RB;
+    const int hi = Np - w - 2 * RB;
+    if (Nb > hi) Nb = hi / RB * RB;
+    if (Nb < RB) Nb = RB;
+    sp.Nb = Nb; sp.m2 = Np - Nb - w;
+    return sp;
+}
+constexpr int KKT_BAND_TW_FLAG0 = 4;      // words of NewtonDev::kkt_tw_flags[b]: 4 trace ready, 5 middle x ready, 6 chains finished
 
 // -DCIMPC_BANDED_PROF (diagnostic builds, with -DCIMPC_KKT_PROF for the accessor): shader-clock accounting of the banded kernel, rollout 0,
 // per wavefront: [0] pre-pass, window fill, first diagonal block  [1] P2  [2] barrier  [3] wavefront 0: tile (0, 0) / the others: entering rows, rhs, stores
@@ -316,11 +338,14 @@ __device__ __forceinline__ void fmac_bcast2(double& a, double c, double l0, doub
 __host__ __device__ inline int banded_pow2_slots(int extent) { int p = 1; while (p < extent) p <<= 1; return p; }
 // SLOTS: that power of two as a compile-time constant (32 / 64 / 128: every LDS offset and the row stride SLOTS + 1 fold into the
 // instructions - fewer scalar registers to spill, shift-adds for the addresses), -1: power of two known at run time, 0: w + RB slots.
-template <int RB, int SLOTS>
-__global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(NewtonDev S, KktArgs K, double* ws_all) {
+// TW = 0: the whole matrix on one workgroup.  TW = 1 / 2 (round 5): the TOP / BOTTOM chain of the twisted form, two workgroups per rollout
+// (kkt_banded_twisted_kernel below; needs the reduced form, RB = 8 and a compile-time power-of-two window).
+template <int RB, int SLOTS, int TW>
+__device__ __forceinline__ void kkt_banded_body(const NewtonDev& S, const KktArgs& K, double* ws_all, double* sm, int b) {
     constexpr bool POW2 = SLOTS != 0;
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int b = blockIdx.x + S.b0, tid = threadIdx.x, nt = blockDim.x;
+    static_assert(TW == 0 || (SLOTS > 0 && RB == 8), "twisted chains: compile-time power-of-two window, blocks of eight");
+    constexpr bool REV = TW == 2;
+    const int tid = threadIdx.x, nt = blockDim.x;
     if (K.stage != nullptr && K.stage[b] != STAGE_KKT) return;
     const DenseLayout L(S);
     // Round 4: the controls are eliminated first.  u_t appears in its own block only (R_t, and du1_t in the row of nu_t), so
@@ -331,14 +356,25 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     // invert) keeps the full form.
     const bool reduced = S.band_reduce != 0 && L.nu > 0;
     const int H = L.H, nr = L.nr, nd = L.nd, nq = L.nq, nu = L.nu;
-    const int s = reduced ? nq + nd : nr + nd, N = H * s;
+    const int s = reduced ? nq + nd : nr + nd, N = H * s;      // N: rows of the whole matrix
     const int w = min(reduced ? 3 * s - 1 : 3 * s - 1 - nu, N - 1), LW = w + 1;
+    // chain geometry: NP pivots are eliminated, NR >= NP rows exist in this chain's matrix
+    const BandSplit sp = TW != 0 ? banded_twisted_split(N, w, RB) : BandSplit{0, 0, 0};
+    const int NP = TW == 1 ? sp.m2 + w : TW == 2 ? sp.Nb : N;
+    const int NR = TW == 2 ? sp.Nb + w : NP;
+    [[maybe_unused]] const int pad = sp.pad, nbr = sp.Nb - sp.pad, m2 = sp.m2;      // nbr: matrix rows the bottom chain eliminates (N-1 .. N-nbr)
+    [[maybe_unused]] int* const xfl = TW != 0 ? S.kkt_tw_flags + (size_t)b * KKT_TW_FLAGS + KKT_BAND_TW_FLAG0 : nullptr;
+    [[maybe_unused]] bool tw_ok = true;
     const int Mw = w + RB;                                       // rows in the window: pivot k+RB-1 reaches row k+RB-1+w
     const int M = SLOTS > 0 ? SLOTS : (POW2 ? banded_pow2_slots(Mw) : Mw);      // slots (index mod M)
     double* wsb = ws_all + (size_t)b * banded_ws_per_rollout(S);
-    double* Lr = wsb;                                            // row i: L[i][i-w .. i-1], slot w: 1 / d_i
-    double* yg = Lr + (size_t)N * LW;
-    double* Gm = yg + N;                                         // reduced form: [H][nd x nd] du1 R^-1 du1^T, then [H][nd] du1 R^-1 r_u
+    // (twisted: rows of L / y of the top chain first, the bottom chain's behind them; G / g / descriptors per chain; then the trace)
+    const int rows_all = TW != 0 ? N + w + 8 : N;
+    double* Lr = wsb + (TW == 2 ? (size_t)(m2 + w) * LW : 0);    // row i: L[i][i-w .. i-1], slot w: 1 / d_i
+    double* yg = wsb + (size_t)rows_all * LW + (TW == 2 ? m2 + w : 0);
+    const size_t g_doubles = (size_t)H * nd * (nd + 1) + ((size_t)s * (w + 2) + 1) / 2;
+    double* Gm = wsb + (size_t)rows_all * (LW + 1) + (TW == 2 ? g_doubles : 0);      // reduced form: [H][nd x nd] du1 R^-1 du1^T, then [H][nd] du1 R^-1 r_u
+    [[maybe_unused]] double* const xtr = wsb + (size_t)rows_all * (LW + 1) + 2 * g_doubles;      // trace [w x w] (matrix order, lower triangle), then [w] right-hand side
     const int MS = M + 1;                                        // row stride: slot M is a dummy row / column
     double* W = sm;                                              // [M+1][M+1] window, slot = index mod M; BOTH triangles kept
     double* yw = W + (size_t)MS * MS;                            // [M]   right-hand side of the rows in the window
@@ -415,7 +451,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     // entry e of row i = ti s + ki; (tj, kj): its column i - w + e likewise (unused for the right-hand side, e = w + 1).  Loads only.
     auto entry_fetch4 = [&](int i, int e, int ti, int ki, int tj, int kj) -> Pending {
         Pending P{0.0, 0.0, 0.0, 0.0, BandRows::CONST};
-        if (i >= N) return P;
+        if (i >= NR) return P;
         const double *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
         int mode = BandRows::CONST;
         if (e <= w && i - w + e >= 0) mode = row.terms4(ti, ki, tj, kj, p0, p1, p2, P.c);
@@ -425,7 +461,12 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     // ... of a row past the first w (every column exists), from its tabulated descriptor and the parameter block in LDS
     auto entry_fetch_d = [&](int i, int e, int ti, int ki, unsigned d) -> Pending {
         Pending P{0.0, 0.0, 0.0, 0.0, BandRows::CONST};
-        if (i >= N) return P;
+        if (i >= NR) return P;
+        if constexpr (REV) {      // (ti, ki arrive as the REVERSED step / index of the row: matrix step H-1-ti, index s-1-ki)
+            // middle rows (behind the last pivot): their block among themselves and their right-hand side belong to the top chain
+            if (i - pad >= nbr && (e > w || i - w + e - pad >= nbr)) return P;
+            ti = H - 1 - ti; ki = s - 1 - ki;
+        }
         const double *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
         int mode;
         if (e <= w) {
@@ -448,14 +489,34 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         if (p2) P.x2 = *p2;
         return P;
     };
+    // Bottom chain: row i, entry e of the REVERSED matrix A'[i][j] = A[N-1-(i-pad)][N-1-(j-pad)] (pad decoupled dummy rows first), j = i-w+e.
+    // The matrix entry is an UPPER one (column c >= row r): by symmetry the lower entry (c, r).  Middle rows: see entry_fetch_d.
+    [[maybe_unused]] auto entry_fetch_rev = [&](int i, int e) -> Pending {
+        Pending P{0.0, 0.0, 0.0, 0.0, BandRows::CONST};
+        if (i >= NR) return P;
+        const int j = i - w + e;
+        if (e <= w && j < 0) return P;
+        if (i < pad || (e <= w && j < pad)) { P.c = (e <= w && i == j) ? 1.0 : 0.0; return P; }      // dummy rows: identity, zero right-hand side
+        if (i - pad >= nbr && (e > w || j - pad >= nbr)) return P;
+        const int r = N - 1 - (i - pad), tr = r / s, kr = r - tr * s;
+        const double *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
+        int mode = BandRows::CONST;
+        if (e <= w) {
+            const int c = N - 1 - (j - pad), tc = c / s, kc = c - tc * s;
+            mode = row.decode(row.desc(tc - tr, kc, kr), tc, p0, p1, p2, P.c);
+        }
+        entry_issue(mode, e, tr, kr, p0, p1, p2, P);
+        return P;
+    };
     auto entry_fetch = [&](int i, int e) -> Pending {
+        if constexpr (REV) return entry_fetch_rev(i, e);
         const int j = max(i - w + min(e, w), 0), ti = i / s, tj = j / s;
         return entry_fetch4(i, e, ti, i - ti * s, tj, j - tj * s);
     };
     auto entry_done = [&](const Pending& P) { return BandRows::combine(P.mode, P.c, P.x0, P.x1, P.x2); };
     auto entry_value = [&](int i, int e) -> double { return entry_done(entry_fetch(i, e)); };
     auto entry_commit = [&](int i, int e, double v) {
-        if (i >= N) return;
+        if (i >= NR) return;
         const int si = i % M;
         if (e <= w) { const int j = i - w + e; if (j >= 0) W[si * MS + j % M] = v; }
         else yw[si] = v;
@@ -464,8 +525,20 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         const int ki = idx / EW, e = idx - ki * EW;              // ki - w + e of the row's own step, counted in steps of s downwards
         unsigned d = 0u;
         if (e <= w) {
-            const int rel = ki - w + e, st = (rel + 3 * s) / s - 3;      // floor(rel / s), rel >= -(3 s - 1)
-            d = row.desc(-st, ki, rel - st * s);
+            if constexpr (REV) {
+                // reversed rows: table index ki = reversed in-step index -> matrix index kr = s-1-ki; the entry is the lower entry
+                // (c, r) with c = r + (w - e): dt steps ahead.  decode() is handed the ROW's step tr, so the offset takes dt blocks along.
+                const int kr = s - 1 - ki, crel = kr + (w - e), dt = crel / s, kc = crel - dt * s;
+                d = row.desc(dt, kc, kr);
+                const int mode = d & 7, arr = (d >> 3) & 7;
+                if (mode != BandRows::CONST) {
+                    const int stride = arr <= BandRows::AV ? nq * nq : arr == BandRows::AG ? nd * nd : arr == BandRows::ADZ ? S.nths * nd : nu * nu;
+                    d += (unsigned)(dt * stride) << 8;
+                }
+            } else {
+                const int rel = ki - w + e, st = (rel + 3 * s) / s - 3;      // floor(rel / s), rel >= -(3 s - 1)
+                d = row.desc(-st, ki, rel - st * s);
+            }
         }
         dtab[idx] = d;
     }
@@ -480,7 +553,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     __threadfence_block();
     __syncthreads();
     {
-        const int n0 = min(Mw, N) * EW;                          // the first Mw rows, all threads
+        const int n0 = min(Mw, NR) * EW;                         // the first Mw rows, all threads
         for (int idx = tid; idx < n0; idx += nt) { const int i = idx / EW, e = idx - i * EW; entry_commit(i, e, entry_value(i, e)); }
     }
     for (int e = tid; e < RB * MS; e += nt) PL[e] = 0.0;
@@ -498,10 +571,12 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     unsigned dsc[NE];                                            // ... and its descriptor, loaded a block ahead
 #pragma unroll
     for (int n = 0; n < NE; ++n) {                               // rows entering after the first block
-        const int i = ent_t[n] >= 0 ? Mw + ent_t[n] : N, j = max(i - w + min(ent_e[n], w), 0);
-        eti[n] = i / s; eki[n] = i - eti[n] * s;
+        const int i = ent_t[n] >= 0 ? Mw + ent_t[n] : NR, j = max(i - w + min(ent_e[n], w), 0);
+        const int irel = REV ? max(i - pad, 0) : i;              // (bottom chain: reversed step / index, counted behind the dummy rows)
+        eti[n] = irel / s; eki[n] = irel - eti[n] * s;
         const int tj = j / s;
-        nxt[n] = entry_fetch4(i, ent_e[n], eti[n], eki[n], tj, j - tj * s);
+        if constexpr (REV) nxt[n] = entry_fetch_rev(i, ent_e[n]);
+        else nxt[n] = entry_fetch4(i, ent_e[n], eti[n], eki[n], tj, j - tj * s);
         eki[n] += RB; while (eki[n] >= s) { eki[n] -= s; ++eti[n]; }
         dsc[n] = ent_t[n] >= 0 ? dtab[eki[n] * EW + ent_e[n]] : 0u;
     }
@@ -537,7 +612,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     // (the chain brings the right-hand side of the next block's eight pivot rows up to date in registers: `pending`)
     auto m24 = [](int a_, int b_) { return __mul24(a_, b_); };  // (v_mul_lo_u32 is a quarter-rate instruction; every product here fits 24 x 24 bits)
     auto P1 = [&](int kk, int skk, int par, bool pending, const double* ypv_cur) {      // lanes 0 .. RB-1 of wavefront 0
-        const int nbk = min(RB, N - kk);
+        const int nbk = min(RB, NP - kk);
         double* dvp = dv + par * RB; double* dinvp = dinv + par * RB; double* ypvp = ypv + par * RB; double* L11p = L11 + par * RB * RB;
         double* nL11p = nL11 + par * (RB + 1) * RB;
         const int r = tid;
@@ -569,10 +644,26 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     lds_barrier();
     BPROF(0)
     const int tb = tid - 64;             // the bulk threads: wavefronts 1 .. 15
-    for (int k = 0; k < N; k += RB) {
-        const int nb_ = min(RB, N - k);                          // pivots of this block
+    for (int k = 0; k < NP; k += RB) {
+        if constexpr (TW == 1) {
+            // The trace of the bottom chain: what the rows it eliminated contribute to rows m2 .. m2 + w - 1.  All of them are in the
+            // window now and none has been a pivot (the next diagonal block - pivots m2 .. - is formed later in this iteration).
+            if (k == m2 - RB) {
+                tw_ok = kkt_tw_wait(xfl + 0);
+                for (int e = tid; e < w * (w + 1); e += nt) {
+                    const int a = e / (w + 1), a2 = e - a * (w + 1);
+                    if (a2 <= a || a2 == w) {
+                        const double v = tw_ok ? xtr[e] : __builtin_nan("");
+                        if (a2 == w) yw[(m2 + a) & (M - 1)] += v;
+                        else W[m24(((m2 + a) & (M - 1)), MS) + ((m2 + a2) & (M - 1))] += v;
+                    }
+                }
+                lds_barrier();
+            }
+        }
+        const int nb_ = min(RB, NP - k);                         // pivots of this block
         const double* dvp = dv + pb * RB; const double* dinvp = dinv + pb * RB; const double* ypvp = ypv + pb * RB; const double* L11p = L11 + pb * RB * RB;
-        const int base = k + nb_, mt = max(min(w, N - base), 0); // mt rows / columns of the trailing window present
+        const int base = k + nb_, mt = max(min(w, NR - base), 0); // mt rows / columns of the trailing window present
         const int nT = (mt + 15) >> 4, ntiles = nT * (nT + 1) / 2;
         if (mt != mt_tab) {                                      // tile table (steady state: written once): tile (0, 0) first
             if (tid < ntiles) {
@@ -590,7 +681,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
             constexpr int NG = 16 / RB;                          // rows per DPP row of 16 lanes
             const int l16 = tx & 15, g = l16 / RB, t = l16 - g * RB;
             const int q = RB + (tid >> 4) * NG + g, i = k + q;
-            const bool on = q < RB + w && i < N && t < nb_;
+            const bool on = q < RB + w && i < NR && t < nb_;
             const int sr = wrap(sk + q);
             double a = (on && q - t <= w) ? W[m24(sr, MS) + wrap(sk + t)] : 0.0;
             const double inv = dinvp[t], d = dvp[t];
@@ -652,11 +743,11 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         if (wv == 0) {              // ---- the chain: the next diagonal block's tile, then the next diagonal block
             if (mt > 0) tile(0);
             BPROF(3)
-            if (k + RB < N && tid < RB) P1(k + RB, skn, pb ^ 1, true, ypvp);
+            if (k + RB < NP && tid < RB) P1(k + RB, skn, pb ^ 1, true, ypvp);
             BPROF(4)
         } else {                    // ---- the bulk
             // right-hand side of the rows below the block - but for the next block's pivot rows: wavefront 0 keeps those to itself
-            if (tb >= RB && tb < w && k + RB + tb < N) {
+            if (tb >= RB && tb < w && k + RB + tb < NR) {
                 const int sr = wrap(sk + RB + tb);
                 double yr = yw[sr];
 #pragma unroll
@@ -665,7 +756,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
             }
             if (tb < (RB - 1) * RB) {                            // the diagonal block's multipliers -> rows of L (P2 stored those of the rows below)
                 const int q = 1 + tb / RB, t = tb - (tb / RB) * RB;
-                if (k + q < N && t < nb_ && t < q) Lr[m24(k + q, LW) + (w - (q - t))] = L11p[q * RB + t];
+                if (k + q < NP && t < nb_ && t < q) Lr[m24(k + q, LW) + (w - (q - t))] = L11p[q * RB + t];
             }
             if (tb >= 64 && tb < 64 + nb_) { yg[k + tb - 64] = ypvp[tb - 64]; Lr[m24(k + tb - 64, LW) + w] = dinvp[tb - 64]; }
             BPROF(3)
@@ -678,7 +769,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
 #pragma unroll
             for (int n = 0; n < NE; ++n) {
                 if (n > 0 && !need2) break;
-                if (ent_t[n] >= 0 && ent_t[n] < nb_ && k + Mw + ent_t[n] < N) {      // row k + Mw + t (Mw = M: the slot of pivot k + t)
+                if (ent_t[n] >= 0 && ent_t[n] < nb_ && k + Mw + ent_t[n] < NR) {     // row k + Mw + t (Mw = M: the slot of pivot k + t)
                     const int si = wrap(sk + Mw + ent_t[n]);
                     const double v = entry_done(nxt[n]);
                     if (ent_e[n] <= w) W[m24(si, MS) + wrap(sk + RB + ent_t[n] + ent_e[n])] = v;       // column k + RB + t + e (>= 0)
@@ -701,6 +792,29 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         BPROF(6)
         sk = skn; pb ^= 1;
     }
+    if constexpr (TW == 2) {
+        // The trace.  The rows behind the last pivot entered the window with a zero middle block and right-hand side, so what stands
+        // there now is exactly what the eliminated rows contribute; the first RB of them still owe the last block's right-hand-side
+        // update (the chain keeps the next block's pivot rows to itself - there is no next block).  Written in MATRIX order: trace row
+        // a = matrix row m2 + a = reversed row NP + w - 1 - a; the matrix's lower entry (a, a2 <= a) is the window's (ia2, ia), ia2 >= ia.
+        const double* ypl = ypv + (pb ^ 1) * RB;
+        if (tid < RB && NP + tid < NR) {
+            const int sr = (NP + tid) & (M - 1);
+            double yr = yw[sr];
+#pragma unroll
+            for (int t = 0; t < RB; ++t) yr = fma(-PL[m24(t, MS) + sr], ypl[t], yr);
+            yw[sr] = yr;
+        }
+        lds_barrier();
+        for (int e = tid; e < w * (w + 1); e += nt) {
+            const int a = e / (w + 1), a2 = e - a * (w + 1), ia = NP + w - 1 - a;
+            if (a2 == w) xtr[e] = yw[ia & (M - 1)];
+            else if (a2 <= a) xtr[e] = W[m24(((NP + w - 1 - a2) & (M - 1)), MS) + (ia & (M - 1))];
+        }
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) astore(xfl + 0, 1);
+    }
     __syncthreads();              // full barrier: the rows of L and y in global memory are read back below
     // ---- back substitution  L^T x = D^-1 y.  acc_j = sum_{i > j} L[i][j] x_i is built row by row (i descending); round 4: the pending
     //      acc_j live in REGISTERS of wavefront 0 (column j belongs to lane (j + 192) % 64, register ((j + 192) / 64) % 3 - a band of
@@ -715,9 +829,16 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         constexpr int RS = 194;                                  // staged row: [3][64] values, 1/d, y
         const int avail = MS * MS + MS + RB * MS + 2 * (3 * RB + RB * RB + (RB + 1) * RB) + 64;      // doubles of LDS the window held
         int CR = avail / (2 * RS); if (CR > 64) CR = 64;
-        const int nch = (N + CR - 1) / CR, CS = CR * RS;
-        auto stage = [&](int ch, int t0, int nth) {              // chunk ch = rows N-1 - ch CR downwards -> buffer ch & 1  (threads t0 .. of nth)
-            const int i_hi = N - 1 - ch * CR, i_lo = max(i_hi - CR + 1, 0), n = i_hi - i_lo + 1, tot = n * 192;
+        const int nch = (NR + CR - 1) / CR, CS = CR * RS;
+        // matrix index of this chain's row i in the reference layout (bottom chain: reversed rows behind the dummies)
+        auto out_index = [&](int i) {
+            const int r = REV ? N - 1 - (i - pad) : i, ti = r / s, ki = r - ti * s;
+            if (reduced) return ki < nq ? ti * nr + nu + ki : H * nr + ti * nd + (ki - nq);
+            return ki < nr ? ti * nr + ki : H * nr + ti * nd + (ki - nr);
+        };
+        if constexpr (TW == 2) tw_ok = kkt_tw_wait(xfl + 1);     // the middle rows' solution (the top chain's first w values) is in D
+        auto stage = [&](int ch, int t0, int nth) {              // chunk ch = rows NR-1 - ch CR downwards -> buffer ch & 1  (threads t0 .. of nth)
+            const int i_hi = NR - 1 - ch * CR, i_lo = max(i_hi - CR + 1, 0), n = i_hi - i_lo + 1, tot = n * 192;
             double* bufp = sm + (ch & 1) * CS;
             for (int e0 = t0; e0 < tot; e0 += 8 * nth) {
                 double tmp[8];
@@ -732,13 +853,19 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
                         int dB = sl - bm; if (dB < 0) dB += 3;
                         int jj = 64 * (blk + dB) + ln; if (jj < bb) jj += 192;
                         dst[u] = rw * RS + rem;
-                        if (jj >= 192 && jj < i + 192) tmp[u] = Lr[i * LW + (jj - bb)];
+                        // (bottom chain, middle rows i >= NP: only their multipliers w.r.t. the pivots are part of the factor)
+                        if (jj >= 192 && jj < i + 192 && (!REV || i < NP || jj - 192 < NP)) tmp[u] = Lr[i * LW + (jj - bb)];
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) if (dst[u] >= 0) bufp[dst[u]] = tmp[u];
             }
-            for (int e = t0; e < n; e += nth) { const int i = i_hi - e; bufp[e * RS + 192] = Lr[i * LW + w]; bufp[e * RS + 193] = yg[i]; }
+            for (int e = t0; e < n; e += nth) {
+                const int i = i_hi - e;
+                if (REV && i >= NP) {      // given: x of matrix row N-1-(i-pad), computed by the top chain (1/d = 1, y = x, nothing pending on its column)
+                    bufp[e * RS + 192] = 1.0; bufp[e * RS + 193] = tw_ok ? D[out_index(i)] : __builtin_nan("");
+                } else { bufp[e * RS + 192] = Lr[i * LW + w]; bufp[e * RS + 193] = yg[i]; }
+            }
         };
         stage(0, tid, nt);
         __syncthreads();
@@ -746,7 +873,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
         for (int ch = 0; ch < nch; ++ch) {
             if (tid >= 64) { if (ch + 1 < nch) stage(ch + 1, tid - 64, (int)nt - 64); }
             else {
-                const int i_hi = N - 1 - ch * CR, i_lo = max(i_hi - CR + 1, 0);
+                const int i_hi = NR - 1 - ch * CR, i_lo = max(i_hi - CR + 1, 0);
                 const double* bufp = sm + (ch & 1) * CS;
                 int i = i_hi;
                 while (i >= i_lo) {                              // runs of rows whose own column sits in the same register
@@ -767,13 +894,7 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
                             acc[0] = fma(l0, xi, acc[0]); acc[1] = fma(l1, xi, acc[1]); acc[2] = fma(l2, xi, acc[2]);
                         }
                         const int lnA = (i + 192) & 63, il = i - (lnA - tx);      // the row whose x this lane collected
-                        if (tx <= lnA && il >= seg_lo) {
-                            const int ti = il / s, ki = il - ti * s;
-                            int o;
-                            if (reduced) o = ki < nq ? ti * nr + nu + ki : H * nr + ti * nd + (ki - nq);
-                            else o = ki < nr ? ti * nr + ki : H * nr + ti * nd + (ki - nr);
-                            D[o] = xs;
-                        }
+                        if (tx <= lnA && il >= seg_lo && (!REV || (il >= pad && il < NP))) D[out_index(il)] = xs;      // (not the dummy rows, not the given ones)
                     };
                     if (so == 0) run(std::integral_constant<int, 0>{});
                     else if (so == 1) run(std::integral_constant<int, 1>{});
@@ -782,9 +903,31 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
                 }
             }
             __syncthreads();
+            if constexpr (TW == 1) {      // the middle rows (this chain's last w) are solved: the bottom chain may start its back substitution
+                const int i_lo_done = max(NR - 1 - ch * CR - CR + 1, 0);
+                if (i_lo_done <= m2 && i_lo_done + CR > m2 && tid < 64) {
+                    __threadfence();
+                    if (tid == 0) astore(xfl + 1, 1);
+                }
+            }
         }
     }
     BPROF(8)
+    if constexpr (TW != 0) {
+        // The chain that finishes last has every Dnu in front of it: it recovers the controls and starts the line search.
+        int* const tw_prev = (int*)sm;      // (the staging buffers of the back substitution are free now)
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+            if (TW == 1) astore(xfl + 0, 0); else astore(xfl + 1, 0);      // consumed flags down again for the next solve of this rollout
+            *tw_prev = atomicAdd(xfl + 2, 1);
+        }
+        __syncthreads();
+        if (*tw_prev == 0) return;
+        __syncthreads();
+        __threadfence();
+        if (tid == 0) astore(xfl + 2, 0);
+    }
     if (reduced) {      // Du_t = R_t^-1 (r_u,t - du1_t^T Dnu_t)
         __threadfence_block();
         double* tu = sm;                                         // [H][nu]
@@ -816,6 +959,32 @@ __global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(Newton
     }
 }
 
+template <int RB, int SLOTS>
+__global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_kernel(NewtonDev S, KktArgs K, double* ws_all) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    kkt_banded_body<RB, SLOTS, 0>(S, K, ws_all, sm, (int)blockIdx.x + S.b0);
+}
+
+// Twisted launch (round 5): two workgroups per rollout - block 2k the bottom chain (it waits for nothing until its trace is out),
+// block 2k + 1 the top chain.  The chains are real functions with their own register allocation, like the condensed solve's
+// (newton_impl.h: kkt_tw_chain).
+struct KktBandTwArgs { NewtonDev S; KktArgs K; double* ws; };
+template <int RB, int SLOTS, int TW>
+static __device__ __attribute__((noinline)) void kkt_banded_chain(unsigned long long ka, int b, lds_double_ptr sm3) {
+    const NewtonDev S = kkt_kernarg<NewtonDev, offsetof(KktBandTwArgs, S)>(ka);
+    const KktArgs K = kkt_kernarg<KktArgs, offsetof(KktBandTwArgs, K)>(ka);
+    double* const ws = kkt_kernarg<double*, offsetof(KktBandTwArgs, ws)>(ka);
+    kkt_banded_body<RB, SLOTS, TW>(S, K, ws, (double*)sm3, b);
+}
+template <int RB, int SLOTS>
+__global__ __launch_bounds__(CIMPC_BANDED_THREADS) void kkt_banded_twisted_kernel(KktBandTwArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int b = ((int)blockIdx.x >> 1) + A.S.b0;
+    const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    if (((int)blockIdx.x & 1) == 0) kkt_banded_chain<RB, SLOTS, 2>(ka, b, (lds_double_ptr)sm);
+    else kkt_banded_chain<RB, SLOTS, 1>(ka, b, (lds_double_ptr)sm);
+}
+
 static size_t banded_lds_bytes_slots(int slots, int rb) {      // window (slots + dummy)^2, right-hand side, rb multiplier rows, 2 x (pivots / reciprocals / rhs, diagonal block), tile table
     const size_t MS = (size_t)slots + 1;
     return (MS * MS + MS + (size_t)rb * MS + 2 * (3 * (size_t)rb + (size_t)rb * rb + ((size_t)rb + 1) * rb) + 64) * sizeof(double);
@@ -844,6 +1013,18 @@ bool kkt_banded_available(const NewtonDev& S) {      // window + two vectors in 
     return S.dm.mode == CIMPC_MODE_CONFIGURATION && w <= 190 && banded_lds_bytes(S) <= 160 * 1024;
 }
 
+// the twisted form: asked for (NewtonDev::kkt_tw_band, set by the host where the launch is latency-bound), reduced form, blocks of
+// eight, compile-time power-of-two window, and a band long enough for two chains
+bool kkt_banded_twisted_available(const NewtonDev& S) {
+    if (S.kkt_tw_band == 0 || S.kkt_tw_flags == nullptr || S.band_reduce == 0 || S.dm.nu <= 0) return false;
+    if (banded_rb(S) != 8 || !banded_pow2(S)) return false;
+    const int w = band_halfwidth(S), slots = banded_pow2_slots(w + 8), N = S.dm.H * (S.dm.nq + S.nd);
+    if (slots != 128 && slots != 64 && slots != 32) return false;
+    if (N < 6 * (w + 8)) return false;
+    const BandSplit sp = banded_twisted_split(N, w, 8);
+    return sp.m2 >= 16 && sp.m2 % 8 == 0 && sp.Nb % 8 == 0 && sp.Nb - sp.pad >= 8;
+}
+
 size_t kkt_dense_workspace_doubles(const NewtonDev& S, bool banded) {
     if (banded) return (size_t)S.dm.B * banded_ws_per_rollout(S);
     return (size_t)S.dm.B * ((size_t)S.N * S.N + 2 * (size_t)S.N);
@@ -860,6 +1041,17 @@ static int launch_kkt_dense(const NewtonDev& S, const KktArgs& K, double* ws, hi
         };
         const bool p2 = banded_pow2(S);
         const int slots = p2 ? banded_pow2_slots(band_halfwidth(S) + banded_rb(S)) : 0;
+        if (kkt_banded_twisted_available(S)) {      // two chains per rollout from the two ends of the band (latency-bound launches)
+            static LdsOptIn optin_tw[3];
+            auto go_tw = [&](auto kern, int which) {
+                if (lds_opt_in(optin_tw[which], (const void*)kern, lds) != CIMPC_OK) return (int)CIMPC_ERR_HIP;
+                hipLaunchKernelGGL(kern, dim3(2 * S.nb_launch), dim3(CIMPC_BANDED_THREADS), lds, s, KktBandTwArgs{S, K, ws});
+                return hipGetLastError() == hipSuccess ? (int)CIMPC_OK : (int)CIMPC_ERR_HIP;
+            };
+            if (slots == 128) return go_tw(kkt_banded_twisted_kernel<8, 128>, 0);
+            if (slots == 64) return go_tw(kkt_banded_twisted_kernel<8, 64>, 1);
+            if (slots == 32) return go_tw(kkt_banded_twisted_kernel<8, 32>, 2);
+        }
         if (banded_rb(S) == 8) {
             if (slots == 128) return go(kkt_banded_kernel<8, 128>, 4);
             if (slots == 64) return go(kkt_banded_kernel<8, 64>, 5);

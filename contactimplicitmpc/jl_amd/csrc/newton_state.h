@@ -91,6 +91,7 @@ struct NewtonDev {
     int* kkt_tw_flags;
     int kkt_tw_nb;     // rows the bottom chain eliminates (0: kkt_tw_split's default; CIMPC_KKT_TW_NB)
     int kkt_tw_raw;    // 1: the B1 seam (cimpc_kkt_solve: a lone solve, latency-bound) takes the twisted kernel too
+    int kkt_tw_band;   // 1: the banded LDL^T takes its twisted form (two workgroups per rollout) where it is available (kkt_dense.hip)
     // options
     double r_tol, beta_init, kappa;
     int max_iter;
@@ -143,6 +144,7 @@ bool kkt_cf_reduce_available(const NewtonDev& S);
 int launch_kkt_cf_reduced_newton(const NewtonDev& S, double* ws, double* dense_ws, hipStream_t s);
 int launch_kkt_cf_reduced_raw(const NewtonDev& S, const double* r_dev, double beta, double* delta_dev, double* ws, double* dense_ws, hipStream_t s);
 bool kkt_banded_available(const NewtonDev& S);
+bool kkt_banded_twisted_available(const NewtonDev& S);
 int launch_kkt_dense_raw(const NewtonDev& S, const double* r_dev, double beta, double* delta_dev, double* ws, hipStream_t s, bool banded);
 // B1 seam: solve with caller-provided residual / beta for all rollouts, no state change
 int launch_kkt_raw(const NewtonDev& nd, const double* r_dev, double beta, double* delta_dev,

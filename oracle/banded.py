@@ -234,3 +234,145 @@ def reduced_entry(d, H, obj, im, rho, i, j):
     if dt == 2:
         return im["dq0"][ti][kd, kj]                             # dq0 at q_t
     return 0.0
+
+
+# ---- round 5: the TWISTED (two-ended) form of the banded factorisation (kkt_dense.hip: kkt_banded_kernel<..., TW>) ----------------------
+
+def _chain_eliminate(get, rhs, w, RB, NP, NR, import_at=None, import_fn=None):
+    """`chain_bulk_ldl_solve`'s elimination on an ABSTRACT band matrix: get(i, j) (j <= i), rhs(i) generate the rows as they enter the
+    window, NP pivots are eliminated (a multiple of RB unless NP = NR), NR >= NP rows exist; import_fn(W, yw, M) is called at the start
+    of the block `import_at` (the top chain receives the bottom chain's trace there).  Returns (Lr, yg, W, yw, M): the rows of L
+    (rows >= NP hold the multipliers w.r.t. the pivots only), the pivots' right-hand sides, and the window as it stands after the last pivot."""
+    assert NP == NR or NP % RB == 0
+    Mw = w + RB
+    M = 1
+    while M < Mw:
+        M <<= 1
+    W = np.zeros((M, M)); yw = np.zeros(M)
+    Lr = np.zeros((NR, w + 1)); yg = np.zeros(NR)
+
+    def commit(i):
+        if i < NR:
+            for c in range(w + 1):
+                j = i - w + c
+                if j >= 0:
+                    W[i % M, j % M] = get(i, j)
+            yw[i % M] = rhs(i)
+
+    for i in range(min(Mw, NR)):
+        commit(i)
+    for k in range(0, NP, RB):
+        if import_at is not None and k == import_at:
+            import_fn(W, yw, M)
+        nb = min(RB, NP - k)
+        a = np.array([[W[(k + r) % M, (k + t) % M] if t <= r else 0.0 for t in range(nb)] for r in range(nb)])
+        yr = np.array([yw[(k + r) % M] for r in range(nb)])
+        L11 = np.zeros((nb, nb)); dv = np.zeros(nb); yp = np.zeros(nb)
+        for t in range(nb):
+            dv[t] = a[t, t]; yp[t] = yr[t]
+            for r in range(t + 1, nb):
+                L11[r, t] = a[r, t] / dv[t]
+                yr[r] -= L11[r, t] * yp[t]
+            for t2 in range(t + 1, nb):
+                for r in range(t2, nb):
+                    a[r, t2] -= (L11[r, t] * dv[t]) * L11[t2, t]
+            yg[k + t] = yp[t]; Lr[k + t, w] = 1.0 / dv[t]
+            for r in range(t + 1, nb):
+                Lr[k + r, w - (r - t)] = L11[r, t]
+        rows = range(k + nb, min(NR, k + nb + w))
+        PL = {}
+        for i in rows:
+            q = i - k
+            l = np.zeros(nb)
+            for t in range(nb):
+                if q - t <= w:
+                    v = W[i % M, (k + t) % M]
+                    for u in range(t):
+                        v -= (l[u] * dv[u]) * L11[t, u]
+                    l[t] = v / dv[t]
+                    Lr[i, w - (q - t)] = l[t]
+            PL[i] = l
+            for t in range(nb):
+                yw[i % M] -= l[t] * yp[t]
+        for i in rows:
+            for j in rows:
+                if j <= i:
+                    W[i % M, j % M] -= sum((PL[i][t] * dv[t]) * PL[j][t] for t in range(nb))
+        for t in range(nb):
+            commit(k + Mw + t)
+    return Lr, yg, W, yw, M
+
+
+def _chain_back_substitute(Lr, yg, w, NP, NR, x_given=None):
+    """Back substitution L^T x = D^-1 y over NR rows in axpy form; rows >= NP (the middle rows of the bottom chain) take their x from
+    `x_given` and contribute through their multipliers w.r.t. the pivots only (columns >= NP of those rows are not part of the factor)."""
+    x = np.zeros(NR); acc = np.zeros(NR)
+    for i in range(NR - 1, -1, -1):
+        x[i] = x_given[i - NP] if i >= NP else yg[i] * Lr[i, w] - acc[i]
+        for c in range(w):
+            j = i - w + c
+            if j >= 0 and (i < NP or j < NP):
+                acc[j] += Lr[i, c] * x[i]
+    return x
+
+
+def twisted_split(N, w, RB=8):
+    """(pad, Nb, m2): the bottom chain eliminates Nb pivots of the reversed matrix (a multiple of RB) of which the first `pad` are decoupled
+    dummy rows appended behind the matrix so that the trace lands on a block boundary of the top chain (m2 = N + pad - Nb - w is a
+    multiple of RB); the top chain eliminates rows 0 .. m2 + w - 1 and receives the trace (rows m2 .. m2 + w - 1) at the start of block m2 - RB.
+    The split balances the two chains: the top chain has m2 - RB pivots behind it when it needs the trace, the bottom chain Nb."""
+    pad = (w - N) % RB
+    Np = N + pad
+    Nb = ((Np - w + RB) // 2) // RB * RB
+    Nb = max(RB, min(Nb, Np - w - 2 * RB))
+    return pad, Nb, Np - Nb - w
+
+
+def twisted_chain_bulk_ldl_solve(A, b, w, RB=8):
+    """The banded L D L^T as TWO chains (the device: two workgroups per rollout).  BOTTOM chain: the reversed matrix
+    A'[i', j'] = A[N-1-(i'-pad), N-1-(j'-pad)] (pad decoupled dummy rows first), Nb pivots; the rows behind its last pivot - matrix rows
+    m2 .. m2 + w - 1 in reversed order - enter its window with their couplings to the pivots but a ZERO middle block and right-hand side,
+    so that after the last pivot the window holds exactly what the eliminated rows contribute there (the trace).  TOP chain: rows
+    0 .. m2 + w - 1 of the matrix; at the start of block m2 - RB (all trace rows are in its window, none is a pivot yet) it adds the
+    trace, then runs on to its last row.  Back substitution of the top chain first (its first w values are the middle rows'), then the
+    bottom chain's with those values given.  Returns x."""
+    N = len(b)
+    pad, Nb, m2 = twisted_split(N, w, RB)
+    Nt = m2 + w
+    assert m2 % RB == 0 and Nb % RB == 0 and m2 >= RB and Nb - pad >= 1
+    nbr = Nb - pad                                               # real rows the bottom chain eliminates: matrix rows N-1 .. N-nbr = Nt
+
+    def orig(ip):                                                # reversed index -> matrix index (dummy rows: -1)
+        return N - 1 - (ip - pad) if ip >= pad else -1
+
+    def get_b(ip, jp):
+        if ip < pad or jp < pad:
+            return 1.0 if ip == jp else 0.0
+        if ip - pad >= nbr and jp - pad >= nbr:
+            return 0.0                                           # middle block: the top chain's
+        return A[orig(jp), orig(ip)]                             # (jp <= ip: matrix column >= row - the symmetric entry)
+
+    def rhs_b(ip):
+        return 0.0 if (ip < pad or ip - pad >= nbr) else b[orig(ip)]
+    Lb, yb, Wb, ywb, M = _chain_eliminate(get_b, rhs_b, w, RB, Nb, Nb + w)
+    S = np.zeros((w, w)); c = np.zeros(w)                        # trace in MATRIX order: row a <-> matrix row m2 + a = reversed row Nb + w - 1 - a
+    for a in range(w):
+        ia = Nb + w - 1 - a
+        c[a] = ywb[ia % M]
+        for a2 in range(a + 1):                                  # matrix (m2 + a, m2 + a2), a2 <= a  <->  reversed (ia2 >= ia): lower entry W[ia2, ia]
+            ia2 = Nb + w - 1 - a2
+            S[a, a2] = Wb[ia2 % M, ia % M]
+
+    def import_fn(W, yw, Mt):
+        for a in range(w):
+            yw[(m2 + a) % Mt] += c[a]
+            for a2 in range(a + 1):
+                W[(m2 + a) % Mt, (m2 + a2) % Mt] += S[a, a2]
+    Lt, yt, _, _, _ = _chain_eliminate(lambda i, j: A[i, j], lambda i: b[i], w, RB, Nt, Nt, import_at=m2 - RB, import_fn=import_fn)
+    xt = _chain_back_substitute(Lt, yt, w, Nt, Nt)
+    xb = _chain_back_substitute(Lb, yb, w, Nb, Nb + w, x_given=np.array([xt[m2 + w - 1 - a] for a in range(w)]))
+    x = np.zeros(N)
+    x[:Nt] = xt
+    for ip in range(pad, Nb):
+        x[orig(ip)] = xb[ip]
+    return x

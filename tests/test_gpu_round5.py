@@ -243,3 +243,41 @@ def test_newton_time_budget_on_a_warm_single_rollout_loop(gpu_required):
         assert 1 <= st["rounds"] < rounds_full, (st["rounds"], rounds_full)
         assert np.isfinite(a["q"]).all()
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,H,H_ref,B", [
+    ("centroidal", 60, 71, 2),       # BASELINE configs[4] with the example's objective: N = 2160, w = 107, chains of 1131 / 1032 pivots
+    ("quadruped", 40, 60, 3),        # N = 880, w = 65
+    ("hopper", 40, 44, 2),           # N = 320, w = 23 (window of 32 slots)
+])
+def test_twisted_banded_ldl_vs_dense_lu(gpu_required, monkeypatch, model, H, H_ref, B):
+    """The banded L D L^T of the velocity objective's KKT matrix as TWO chains (kkt_dense.hip: kkt_banded_twisted_kernel - the bottom
+    workgroup eliminates the reversed matrix and hands its trailing window over as the trace, the top workgroup adds it before it reaches
+    the middle rows, back substitutions outwards; CPU statement: oracle/banded.py: twisted_chain_bulk_ldl_solve) against numpy's dense
+    solve of the oracle's `jacobian!` matrix (newton_jacobian.jl:148-248 incl. the -V off-diagonal blocks) and against the one-chain
+    kernel."""
+    d, prob, tabs, rollouts = make_case(model, 0, H_ref=H_ref, H=H, B=B, seed=5)
+    obj = synth.make_objective(d, H, kind=model if model in ("quadruped", "hopper") else "quadruped", velocity=True)
+    lay = onewton.Layout(d, H)
+    r = np.random.default_rng(0).standard_normal((B, lay.N))
+    betas = (1e-2, 10.0)
+    out1, one, n1 = _solve_all(monkeypatch, False, d, prob, rollouts, obj, H, r, betas)
+    out2, two, n2 = _solve_all(monkeypatch, True, d, prob, rollouts, obj, H, r, betas)
+    assert n1 == 0 and n2 == len(betas)
+    rec = {}
+    for beta in betas:
+        e1 = e2 = e12 = 0.0
+        for b in range(B):
+            im = {k: out2[k][b] for k in ("d", "dq0", "dq1", "du1")}
+            R = onewton.jacobian(lay, obj, im, beta, prob["kappa"])
+            x = np.linalg.solve(R, r[b])
+            sc = max(1.0, np.abs(x).max())
+            assert np.isfinite(two[beta][b]).all()
+            e1 = max(e1, np.abs(one[beta][b] - x).max() / sc)
+            e2 = max(e2, np.abs(two[beta][b] - x).max() / sc)
+            e12 = max(e12, np.abs(two[beta][b] - one[beta][b]).max() / sc)
+        rec[str(beta)] = dict(one_chain_vs_dense=e1, twisted_vs_dense=e2, twisted_vs_one_chain=e12)
+        assert e2 <= 1e-9, (beta, e1, e2)
+        assert e2 <= max(10.0 * e1, 1e-11), (beta, e1, e2)
+    _record(f"twisted_banded_{model}_h{H}", rec)

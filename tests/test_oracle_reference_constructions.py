@@ -343,3 +343,28 @@ def test_twisted_device_schedule(model, H):
             x1 = onewton.kkt_solve_condensed_twisted_device(lay, obj, im, beta, prob["kappa"], r, split=split)
             assert np.abs(x1 - x0).max() <= 1e-9 * scale, (beta, split)
             assert np.abs(x1 - xd).max() <= 1e-10 * np.linalg.cond(R) * scale, (beta, split)
+
+
+@pytest.mark.parametrize("N,w,RB", [(300, 37, 8), (256, 27, 8), (540, 107, 8), (411, 53, 4)])
+def test_twisted_banded_factorisation(N, w, RB):
+    """The banded L D L^T as two chains (oracle/banded.py: twisted_chain_bulk_ldl_solve = the CPU statement of kkt_banded_twisted_kernel:
+    reversed matrix with decoupled dummy rows, zero middle block, trace handed to the top chain at a block boundary, given middle
+    values in the bottom chain's back substitution) equals the dense solve and the one-chain form on random symmetric quasi-definite
+    band matrices; the split lands on block boundaries."""
+    from oracle import banded
+    rng = np.random.default_rng(N + w)
+    A = np.zeros((N, N))
+    for i in range(N):
+        for j in range(max(0, i - w), i):
+            A[i, j] = A[j, i] = 0.05 * rng.standard_normal()
+    sign = np.where(rng.random(N) < 0.5, 1.0, -1.0)
+    A += np.diag(sign * (3.0 + np.abs(A).sum(axis=1)))
+    b = rng.standard_normal(N)
+    pad, Nb, m2 = banded.twisted_split(N, w, RB)
+    assert m2 % RB == 0 and Nb % RB == 0 and 0 <= pad < RB and m2 + w + (Nb - pad) == N
+    x0 = np.linalg.solve(A, b)
+    x1, _ = banded.chain_bulk_ldl_solve(A, b, w, RB)
+    x2 = banded.twisted_chain_bulk_ldl_solve(A, b, w, RB)
+    np.testing.assert_allclose(x1, x0, rtol=0, atol=1e-13 * max(1.0, np.abs(x0).max()))
+    np.testing.assert_allclose(x2, x0, rtol=0, atol=1e-13 * max(1.0, np.abs(x0).max()))
+    assert banded.twisted_split(2160, 107, 8) == (3, 1032, 1024)           # centroidal H = 60: the device's split (kkt_dense.hip: banded_twisted_split)
