@@ -296,7 +296,9 @@ __host__ __device__ inline BandSplit banded_twisted_split(int N, int w, int RB) 
     BandSplit sp;
     sp.pad = ((w - N) % RB + RB) % RB;
     const int Np = N + sp.pad;
-    int Nb = ((Np - w + RB) / 2) / RB * RB;
+    // (15 / 32 of the rows outside the middle: the bottom chain's block takes 3.4 us against the top chain's 3.2, and its trace has to
+    //  be written and read - profiles/r05/twisted_banded_prof_a.log: with an even split the top chain waited 57 us of 790)
+    int Nb = ((Np - w + RB) * 15 / 32) / RB * RB;
     const int hi = Np - w - 2 * RB;
     if (Nb > hi) Nb = hi / RB * RB;
     if (Nb < RB) Nb = RB;
@@ -347,6 +349,13 @@ __device__ __forceinline__ void kkt_banded_body(const NewtonDev& S, const KktArg
     constexpr bool REV = TW == 2;
     const int tid = threadIdx.x, nt = blockDim.x;
     if (K.stage != nullptr && K.stage[b] != STAGE_KKT) return;
+#ifdef CIMPC_KKT_TWPROF
+    // (diagnostic builds) constant-rate clock stamps of the twisted banded chains -> statistics words 8 + 8 (TW - 1) + j
+#define BTWSTAMP(j) { if (TW != 0 && tid == 0 && b == 0) ((long long*)S.stats)[8 + 8 * (TW - 1) + (j)] = (long long)wall_clock64(); }
+#else
+#define BTWSTAMP(j) {}
+#endif
+    BTWSTAMP(0)
     const DenseLayout L(S);
     // Round 4: the controls are eliminated first.  u_t appears in its own block only (R_t, and du1_t in the row of nu_t), so
     //   Du_t = R_t^-1 (r_u,t - du1_t^T Dnu_t)   and the nu_t row becomes   ... - (rho I + du1_t R_t^-1 du1_t^T) Dnu_t = r_d,t - du1_t R_t^-1 r_u,t
@@ -401,7 +410,9 @@ __device__ __forceinline__ void kkt_banded_body(const NewtonDev& S, const KktArg
 #endif
     if (reduced) {      // G_t = du1_t R_t^-1 du1_t^T, g_t = du1_t R_t^-1 r_u,t  (R_t^-1: NewtonDev::Rinv, symmetric); T = du1 R^-1 staged in LDS
         double* Tm = sm;                                         // [H][nd x nu] (the window is not in use yet)
-        for (int e = tid; e < H * nd * nu; e += nt) {
+        // (twisted: a chain forms G / g of the steps its rows touch only - the top chain rows < m2 + w, the bottom chain rows >= m2)
+        const int tg0 = TW == 2 ? m2 / s : 0, tg1 = TW == 1 ? min(H, (m2 + w + s - 1) / s) : H, ntg = tg1 - tg0;
+        for (int e = tid + tg0 * nd * nu; e < tg1 * nd * nu; e += nt) {
             const int t = e / (nd * nu), k = e - t * nd * nu, r = k % nd, c = k / nd;
             const double* du = dzb + ((size_t)t * S.nths + 2 * nq) * nd;      // du1_t, nd x nu column-major
             const double* Ri = S.Rinv + (size_t)t * nu * nu + (size_t)c * nu;
@@ -410,7 +421,8 @@ __device__ __forceinline__ void kkt_banded_body(const NewtonDev& S, const KktArg
             Tm[e] = a;
         }
         __syncthreads();
-        for (int e = tid; e < H * nd * (nd + 1); e += nt) {
+        (void)ntg;
+        for (int e = tid + tg0 * nd * (nd + 1); e < tg1 * nd * (nd + 1); e += nt) {
             const int t = e / (nd * (nd + 1)), k = e - t * nd * (nd + 1), r = k % nd, c = k / nd;
             const double* Tr = Tm + (size_t)t * nd * nu;
             double a = 0.0;
@@ -643,13 +655,16 @@ __device__ __forceinline__ void kkt_banded_body(const NewtonDev& S, const KktArg
     if (tid < RB) P1(0, 0, 0, false, ypv);
     lds_barrier();
     BPROF(0)
+    BTWSTAMP(1)
     const int tb = tid - 64;             // the bulk threads: wavefronts 1 .. 15
     for (int k = 0; k < NP; k += RB) {
         if constexpr (TW == 1) {
             // The trace of the bottom chain: what the rows it eliminated contribute to rows m2 .. m2 + w - 1.  All of them are in the
             // window now and none has been a pivot (the next diagonal block - pivots m2 .. - is formed later in this iteration).
             if (k == m2 - RB) {
+                BTWSTAMP(2)
                 tw_ok = kkt_tw_wait(xfl + 0);
+                BTWSTAMP(3)
                 for (int e = tid; e < w * (w + 1); e += nt) {
                     const int a = e / (w + 1), a2 = e - a * (w + 1);
                     if (a2 <= a || a2 == w) {
@@ -792,6 +807,7 @@ __device__ __forceinline__ void kkt_banded_body(const NewtonDev& S, const KktArg
         BPROF(6)
         sk = skn; pb ^= 1;
     }
+    BTWSTAMP(4)
     if constexpr (TW == 2) {
         // The trace.  The rows behind the last pivot entered the window with a zero middle block and right-hand side, so what stands
         // there now is exactly what the eliminated rows contribute; the first RB of them still owe the last block's right-hand-side
@@ -836,7 +852,9 @@ __device__ __forceinline__ void kkt_banded_body(const NewtonDev& S, const KktArg
             if (reduced) return ki < nq ? ti * nr + nu + ki : H * nr + ti * nd + (ki - nq);
             return ki < nr ? ti * nr + ki : H * nr + ti * nd + (ki - nr);
         };
+        BTWSTAMP(5)
         if constexpr (TW == 2) tw_ok = kkt_tw_wait(xfl + 1);     // the middle rows' solution (the top chain's first w values) is in D
+        BTWSTAMP(6)
         auto stage = [&](int ch, int t0, int nth) {              // chunk ch = rows NR-1 - ch CR downwards -> buffer ch & 1  (threads t0 .. of nth)
             const int i_hi = NR - 1 - ch * CR, i_lo = max(i_hi - CR + 1, 0), n = i_hi - i_lo + 1, tot = n * 192;
             double* bufp = sm + (ch & 1) * CS;
@@ -913,6 +931,7 @@ __device__ __forceinline__ void kkt_banded_body(const NewtonDev& S, const KktArg
         }
     }
     BPROF(8)
+    BTWSTAMP(7)
     if constexpr (TW != 0) {
         // The chain that finishes last has every Dnu in front of it: it recovers the controls and starts the line search.
         int* const tw_prev = (int*)sm;      // (the staging buffers of the back substitution are free now)

@@ -320,10 +320,11 @@ def twisted_split(N, w, RB=8):
     """(pad, Nb, m2): the bottom chain eliminates Nb pivots of the reversed matrix (a multiple of RB) of which the first `pad` are decoupled
     dummy rows appended behind the matrix so that the trace lands on a block boundary of the top chain (m2 = N + pad - Nb - w is a
     multiple of RB); the top chain eliminates rows 0 .. m2 + w - 1 and receives the trace (rows m2 .. m2 + w - 1) at the start of block m2 - RB.
-    The split balances the two chains: the top chain has m2 - RB pivots behind it when it needs the trace, the bottom chain Nb."""
+    The split balances the two chains: the top chain has m2 - RB pivots behind it when it needs the trace, the bottom chain Nb
+    (15 / 32 of the rows outside the middle)."""
     pad = (w - N) % RB
     Np = N + pad
-    Nb = ((Np - w + RB) // 2) // RB * RB
+    Nb = ((Np - w + RB) * 15 // 32) // RB * RB               # (the device's measured balance: the bottom chain's blocks are the slower ones)
     Nb = max(RB, min(Nb, Np - w - 2 * RB))
     return pad, Nb, Np - Nb - w
 

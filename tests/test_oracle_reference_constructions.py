@@ -367,4 +367,4 @@ def test_twisted_banded_factorisation(N, w, RB):
     x2 = banded.twisted_chain_bulk_ldl_solve(A, b, w, RB)
     np.testing.assert_allclose(x1, x0, rtol=0, atol=1e-13 * max(1.0, np.abs(x0).max()))
     np.testing.assert_allclose(x2, x0, rtol=0, atol=1e-13 * max(1.0, np.abs(x0).max()))
-    assert banded.twisted_split(2160, 107, 8) == (3, 1032, 1024)           # centroidal H = 60: the device's split (kkt_dense.hip: banded_twisted_split)
+    assert banded.twisted_split(2160, 107, 8) == (3, 960, 1096)           # centroidal H = 60: the device's split (kkt_dense.hip: banded_twisted_split)
