@@ -393,7 +393,7 @@ def centroidal_velocity_leg(I, B, H, device, steps=2):
     pr = s.profile_read(); st = s.stats()
     _, it, rn = s.newton_info()
     s.close()
-    return {"objective": "TrackingVelocityObjective of continuous_trot.jl:43-47 (Q singular along x, V, v_target = 0)", "kkt": "banded L D L^T (interleaved ordering)",
+    return {"objective": "TrackingVelocityObjective of continuous_trot.jl:43-47 (Q singular along x, V, v_target = 0)", "kkt": "banded L D L^T (interleaved ordering; twisted: two workgroups per rollout)",
             "value": B / dt, "unit": "MPC steps/s", "ms_per_step": 1e3 * dt, "newton_iters_per_step": float(it.mean()),
             "converged_rollouts": int((rn < 3e-5).sum()), "kkt_ms_per_step": pr["kkt_ms"] / steps, "ip_sweep_ms_per_step": pr["ip_sweep_ms"] / steps,
             "kkt_systems_per_step": pr["kkt_systems"] / steps, "kkt_launches_per_step": pr["kkt_launches"] / steps, "ip_failures": st["ip_failures"]}
@@ -965,8 +965,8 @@ def main():
                                 c64["ip_sweep_problems_per_step"], c64["ip_sweep_launches_per_step"], c64["ip_sweep_ms_per_step"], "32-lane groups, one 512-register wave per SIMD"),
                 kernel_roofline("kkt_kernel_twisted<18,12> (B = 64, H = 60)", kkt_condensed_flops(18, 60), c64["kkt_systems_per_step"], c64["kkt_launches_per_step"],
                                 c64["kkt_ms_per_step"], "24 x 24 tiles = 2 x 2 masked MFMA blocks"),
-                kernel_roofline("kkt_banded_kernel<8,128> (B = 64, H = 60, velocity objective)", kkt_banded_flops(18, 12, 60), v64.get("kkt_systems_per_step", 0),
-                                v64.get("kkt_launches_per_step", 0), v64.get("kkt_ms_per_step", 0.0), "SURVEY 8(d): N w^2 + 4 N w, N = 2160, w = 107; one workgroup (16 waves) per system"),
+                kernel_roofline("kkt_banded_twisted_kernel<8,128> (B = 64, H = 60, velocity objective)", kkt_banded_flops(18, 12, 60), v64.get("kkt_systems_per_step", 0),
+                                v64.get("kkt_launches_per_step", 0), v64.get("kkt_ms_per_step", 0.0), "SURVEY 8(d): N w^2 + 4 N w, N = 2160, w = 107; two workgroups (16 waves each) per system, one chain from either end of the band"),
             ]
         except Exception as e:
             out["centroidal_payload_h60"] = {"error": repr(e)}
