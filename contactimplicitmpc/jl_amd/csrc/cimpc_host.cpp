@@ -155,6 +155,7 @@ struct cimpc_ctx {
     bool velocity_objective = false;
     bool use_dense = false;        // KKT through kkt_dense.hip: the reference-default dense LU (any mode / objective) ...
     bool use_banded = false;       // ... or its banded LDL^T (:configuration mode, velocity objective / on request)
+    long long adapt32 = 0;         // 32-lane models: problems per sweep launch from which the throughput build is taken (0: the handle's one build)
     long long n_kkt_twisted = 0;   // KKT launches that took the twisted kernel (cimpc_get_kkt_twisted)
     bool band_reduce_ok = false;   // every R_t could be inverted: the banded LDL^T may eliminate the controls first (NewtonDev::band_reduce)
     bool use_mixed = false;        // condensed solve in mixed precision (CIMPC_KKT_CONDENSED_MIXED)
@@ -339,8 +340,19 @@ IpParams make_ip_params(cimpc_ctx* h, const TrajDev& T, int par, int* pending_co
 
 // queue kernel + sensitivity kernel of one round
 int run_sweep(cimpc_ctx* h, int par, int* pending_counter, double* zout, hipStream_t st, int iter_cap = 0, int* drain_counter = nullptr,
-              bool with_products = false) {
+              bool with_products = false, long long hint = -1) {
     IpParams p = make_ip_params(h, h->S.cand, par, pending_counter, zout);
+    int waves = h->waves;
+    // 32-lane models: the build of the sweep is chosen PER LAUNCH from the problems the host knows to be queued (round 5; the choice
+    // used to be made once per handle from B H): the latency build (4 waves per workgroup) below `adapt32` problems, the throughput
+    // build (8 waves, two per SIMD) from there on.  Parked iterates are the model's, not the build's: a solve may change builds.
+    if (h->ki.G == 32 && h->adapt32 > 0 && hint >= 0 && !(h->kn.waves32 == 4 || h->kn.waves32 == 8)) {
+        waves = hint >= h->adapt32 ? 8 : 4;
+        const size_t groups_per_wg = 2 * (size_t)waves;
+        size_t w = ((size_t)hint + 2 * groups_per_wg - 1) / (2 * groups_per_wg);
+        w = std::max<size_t>(w, std::min<size_t>((size_t)h->dm.H_ref, (size_t)std::max<long long>(hint, 1)));
+        p.wpk = (int)std::max<size_t>(1, std::min<size_t>(w, 256));
+    }
     // (round 4, measured and removed: one sweep workgroup per CU in rounds with few problems - <= 4 k / 8 k / 16 k - so that every
     //  wave has its SIMD to itself: 7.97 -> 7.96 / 7.99 / 8.01 ms per step, no effect: profiles/r04/knob_small_round.log)
     if (with_products && h->S.dtn != nullptr) { p.nu = h->S.nu_cand; p.dtn = h->S.dtn; }
@@ -351,7 +363,7 @@ int run_sweep(cimpc_ctx* h, int par, int* pending_counter, double* zout, hipStre
         p.drain_min = h->kn.drain_min;
     }
     prof_begin(h, PC_IP, st);
-    int rc = launch_ip_sweep(&h->dm, p, h->waves, st);
+    int rc = launch_ip_sweep(&h->dm, p, waves, st);
     prof_end(h, st);
     if (rc != CIMPC_OK) return fail(h, rc, "ip sweep launch failed");
     return CIMPC_OK;
@@ -674,8 +686,13 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     // step, 128 rollouts 14.0 -> 12.2 ms, 256 rollouts 26.0 -> 22.4 ms - profiles/r04/cent_w8b.log).  CIMPC_WAVES32 = 4 / 8 forces one.
     // (A first form that ALSO read the MGS column twice instead of keeping it in registers was LDS-bound: cent_8wave_experiment.log.)
     if (h->ki.G == 32) {
-        if (h->kn.waves32 > 0) h->waves = h->kn.waves32;
+        if (h->kn.waves32 > 0 && h->kn.waves32 < 1000) h->waves = h->kn.waves32;
         else if ((size_t)B * H >= 6000) h->waves = 8;
+        // Round 5: the build is chosen PER LAUNCH (run_sweep) from the problems queued for it - a step of 64 rollouts has launches of
+        // 3.8 k (one candidate per rollout) to 11.5 k problems (three): centroidal H = 60, 64 rollouts 7.87 -> 6.7 ms of sweeps per
+        // step (10.7 -> 9.6 ms per batch step), 128 rollouts 12.0 -> 11.5 ms; thresholds 5 / 7 / 9 / 11 k are equivalent at 64,
+        // 5 - 7 k best at 128 (profiles/r05/cent_adapt32.log).  CIMPC_WAVES32 >= 1000 sets the threshold, 4 / 8 force one build.
+        h->adapt32 = h->kn.waves32 >= 1000 ? h->kn.waves32 : (h->kn.waves32 == 4 || h->kn.waves32 == 8) ? 0 : 7000;
     }
     // the single-launch solve runs its residual jobs on the whole workgroup: 4 waves also for small batches
     // (measured B = 8: 5.2 -> 4.4 ms, B = 64: 8.5 -> 7.5 ms)
@@ -1372,7 +1389,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
                 fprintf(stderr, "[cimpc round %lld] sweep launch: %lld problems queued (host hint %lld)\n", r, tot, hint);
             }
         }
-        int rr = run_sweep(h, par, d_cnt + 2 * CPAD, nullptr, sb.st, cap, d_cnt + 3 * CPAD, true);
+        int rr = run_sweep(h, par, d_cnt + 2 * CPAD, nullptr, sb.st, cap, d_cnt + 3 * CPAD, true, hint);
         if (rr != CIMPC_OK) return rr;
         // the evaluation slots of this round: the compact list its requesters built (small batches run the KKT stage in the same
         // round as the evaluation of its candidates - not known to the host at launch: every (rollout, slot) pair gets a block there)
