@@ -346,7 +346,9 @@ int run_sweep(cimpc_ctx* h, int par, int* pending_counter, double* zout, hipStre
     // 32-lane models: the build of the sweep is chosen PER LAUNCH from the problems the host knows to be queued (round 5; the choice
     // used to be made once per handle from B H): the latency build (4 waves per workgroup) below `adapt32` problems, the throughput
     // build (8 waves, two per SIMD) from there on.  Parked iterates are the model's, not the build's: a solve may change builds.
-    if (h->ki.G == 32 && h->adapt32 > 0 && hint >= 0 && !(h->kn.waves32 == 4 || h->kn.waves32 == 8)) {
+    // (only where the host's count is complete: with the KKT stage in the same round as the evaluation of its candidates - small
+    //  batches - the requests of that round are not known at launch; a first version sized a B = 1 sweep for ONE workgroup: 1.1 -> 20 ms)
+    if (h->ki.G == 32 && h->adapt32 > 0 && hint > 0 && h->kkt_overlap && !(h->kn.waves32 == 4 || h->kn.waves32 == 8)) {
         waves = hint >= h->adapt32 ? 8 : 4;
         const size_t groups_per_wg = 2 * (size_t)waves;
         size_t w = ((size_t)hint + 2 * groups_per_wg - 1) / (2 * groups_per_wg);
