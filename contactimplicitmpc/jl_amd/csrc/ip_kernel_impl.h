@@ -75,7 +75,8 @@ struct Model {
     // ... then (32-lane groups) three staging vectors of G doubles: one for lane-indexed vectors that feed a matrix-vector
     // product, two (by step parity) for the column the MGS step broadcasts - IpSolver::stage / factorize
     static constexpr int OFF_BV = ((TILE + SENS_MAX / 2 + 1) + 1) & ~1;
-    static constexpr int BVEC = (G == 16) ? 0 : 3 * G;
+    static constexpr int NBV = CIMPC_SENS_ILP32 > 3 ? CIMPC_SENS_ILP32 : 3;      // staging vectors per 32-lane group
+    static constexpr int BVEC = (G == 16) ? 0 : NBV * G;
     static constexpr int LDS_GROUP = OFF_BV + BVEC;  // doubles / problem (even)
 };
 
@@ -336,7 +337,7 @@ struct IpSolver {
     // Per column the arithmetic is that of schur_solve<true> / qr_solve - same operands, same order: bit-identical columns.
     template <int N>
     __device__ __forceinline__ void stage_n(const double (&v)[N]) const {
-        static_assert(N <= 3, "three staging vectors per group");
+        static_assert(N <= M::NBV, "one staging vector per right-hand side");
         wave_lds_fence();
         static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; bv[j * G + l] = v[j]; });
         wave_lds_fence();
