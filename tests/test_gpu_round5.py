@@ -281,3 +281,42 @@ def test_twisted_banded_ldl_vs_dense_lu(gpu_required, monkeypatch, model, H, H_r
         assert e2 <= 1e-9, (beta, e1, e2)
         assert e2 <= max(10.0 * e1, 1e-11), (beta, e1, e2)
     _record(f"twisted_banded_{model}_h{H}", rec)
+
+
+@pytest.mark.gpu
+def test_sweep_build_chosen_per_launch_gives_the_same_solve(gpu_required, monkeypatch):
+    """Round 5: the 32-lane sweep's build (latency: 4 waves per workgroup / throughput: 8) and its number of persistent workgroups
+    are chosen per LAUNCH from the problems the host knows to be queued (cimpc_host.cpp: run_sweep).  Both builds run the same
+    arithmetic per problem and a parked iterate is the model's, not the build's: BASELINE configs[4]'s inputs at 64 rollouts
+    (launches of 3.8 k to 11.5 k problems: both builds are taken within one solve) must give the solve of either build alone -
+    same Newton iterations, reference-equivalent counters and controls."""
+    import bench
+    from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions
+    B, H = 64, 60
+    I = bench.centroidal_payload_inputs(B, H)
+    m, P, kappa, ro = I["m"], I["P"], I["kappa"], I["rollouts"]
+    q0 = np.stack([r["q0"] for r in ro]); q1 = np.stack([r["q1"] for r in ro])
+    monkeypatch.setenv("CIMPC_ASYNC", "0")
+    res = {}
+    for name, v in (("per_launch", None), ("latency", "4"), ("throughput", "8")):
+        if v is None:
+            monkeypatch.delenv("CIMPC_WAVES32", raising=False)
+        else:
+            monkeypatch.setenv("CIMPC_WAVES32", v)
+        s = CIMPCSolver(m.nq, m.nu, m.nw, m.nc, m.nb, P.H, H, B=B, mode=0, ip_opts=InteriorPointOptions(kappa_tol=kappa, r_tol=1e-4),
+                        newton_opts=NewtonOptions(kappa=kappa, r_tol=3e-5, max_iter=5))
+        for t in range(P.H):
+            s.set_linearization(t + 1, P.z[t], P.theta[t], P.r0[t], P.rz0[t], P.rth0[t])
+        s.set_objective(I["Q"], I["R"])
+        s.set_window(np.stack([r["window"] for r in ro]) + 1)
+        s.set_reference(*(np.stack([r[k] for r in ro]) for k in ("q", "u", "w", "gamma", "b", "theta")))
+        u1, it, rn = s.newton_solve(q0, q1)
+        res[name] = (u1, it, rn, s.rollout_counters())
+        s.close()
+    a = res["per_launch"]
+    for other in ("latency", "throughput"):
+        b = res[other]
+        np.testing.assert_array_equal(a[1], b[1])
+        for k in ("sweeps", "ip_iters", "ip_failures"):
+            np.testing.assert_array_equal(a[3][k], b[3][k])
+        np.testing.assert_allclose(a[0], b[0], rtol=0, atol=1e-9 * max(1.0, np.abs(b[0]).max()))
