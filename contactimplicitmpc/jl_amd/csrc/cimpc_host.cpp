@@ -460,7 +460,7 @@ int check_ready(cimpc_ctx* h, bool need_newton) {
 
 extern "C" {
 
-int cimpc_version(void) { return 104; }      // 1.04: round 4 (cimpc_ip_opts::max_time - the struct grew by one double at its end)
+int cimpc_version(void) { return 105; }      // 1.05: round 5 (+ cimpc_get_kkt_twisted; no struct changed).  1.04: round 4 (cimpc_ip_opts::max_time - the struct grew by one double at its end)
 
 void cimpc_default_ip_opts(cimpc_ip_opts* o) {
     if (!o) return;
