@@ -155,6 +155,7 @@ struct cimpc_ctx {
     bool velocity_objective = false;
     bool use_dense = false;        // KKT through kkt_dense.hip: the reference-default dense LU (any mode / objective) ...
     bool use_banded = false;       // ... or its banded LDL^T (:configuration mode, velocity objective / on request)
+    int kkt_tw_overlap_max = 0;    // overlapped rounds: twisted KKT kernel when at most this many rollouts need a solve (0: never)
     long long adapt32 = 0;         // 32-lane models: problems per sweep launch from which the throughput build is taken (0: the handle's one build)
     long long n_kkt_twisted = 0;   // KKT launches that took the twisted kernel (cimpc_get_kkt_twisted)
     bool band_reduce_ok = false;   // every R_t could be inverted: the banded LDL^T may eliminate the controls first (NewtonDev::band_reduce)
@@ -675,6 +676,11 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     S.kkt_scalar = h->kn.kkt_scalar ? 1 : 0;
     S.kkt_tw_nb = h->kn.kkt_tw_nb;
     S.kkt_tw_raw = (h->kn.kkt_twisted != 0 && d.B <= h->kn.kkt_tw_max) ? 1 : 0;
+    // Overlapped rounds (B >= 64, hybrid schedule): the twisted kernel where EVERY round's KKT set fits the pair bound, i.e. batches
+    // of up to 120 rollouts - B = 96: 5.56 -> 4.8-5.1 ms per batch step; with a bound below the batch size the rounds mix kernels
+    // and lose (B = 128: 6.04 -> 6.8 ms at 48 / 96; B = 256 and 512 within the noise: profiles/r05/ab_tw_overlap.log).
+    // (CIMPC_KKT_TWISTED >= 2: the bound itself, for the A/B lines)
+    h->kkt_tw_overlap_max = h->kn.kkt_twisted >= 2 ? h->kn.kkt_twisted : (h->kn.kkt_twisted != 0 && d.B <= h->kn.kkt_tw_max ? h->kn.kkt_tw_max : 0);
     S.kkt_tw_band = S.kkt_tw_raw;      // (the banded LDL^T is launched over all rollouts of the handle: the same bound applies)
     // large batches: a rollout whose previous search needed a back-off starts the next one with 1, 1/2, 1/4 together (one
     // round less per Newton iteration for 0.9 more evaluated sweeps per step: B = 512 11.4 -> 10.9 ms); small batches already
@@ -1349,6 +1355,10 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         // workgroups per rollout factor the block penta-diagonal matrix from both ends (two chains of about H / 2 steps), as long as
         // every pair is resident at once
         if (pipe == 1 && h->kn.kkt_twisted != 0 && n_kkt <= h->kn.kkt_tw_max && kkt_twisted_available(Sk)) pipe = 2;
+        // ... and in the OVERLAPPED rounds of larger batches when few rollouts start a Newton iteration (late rounds): the packed
+        // one-wave recursion (266 us) then outlasts the thinning sweep next to it, the twisted pair (two workgroups per rollout) does not
+        if (pipe == 0 && h->kkt_overlap && !blind && h->kn.kkt_twisted != 0 && h->kkt_tw_overlap_max > 0 && n_kkt > 0 && n_kkt <= h->kkt_tw_overlap_max &&
+            kkt_twisted_available(Sk)) pipe = 2;
         if (kkt && pipe == 2 && !h->use_dense && !h->use_mixed && (h->kkt_overlap ? h->kn.kkt_packed : true)) h->n_kkt_twisted++;
         if (kkt && !h->kkt_overlap) {   // small batches: latency matters, keep the KKT result in this round
             Sk.kkt_same_round = 1;
