@@ -73,7 +73,11 @@ def algorithmic_sizes(nq, nu, nw, nc, nb, mode=0):
     io_shared = nth + nq + nz + nd * (2 * nq + nu)
     flop_iter = 2 * ny ** 3 + ny * ny + 2 * (4 * nx * ny + 3 * ny * ny + 2 * nx * nx) + 3 * 2 * (nx + ny) * (nx + ny + nth)
     flop_tail = 2 * ny ** 3 + ny * ny + nth * (4 * nx * ny + 3 * ny * ny + 2 * nx * nx)
-    return dict(n_lin=n_lin, bytes_per_solve=8 * (n_lin + io_shared), bytes_per_solve_shared_table=8 * io_shared,
+    # what the device's sensitivity pass EXECUTES (round 5): 2 nq + nu columns instead of the reference's nth; in :configuration mode
+    # the adjoint form - nx solves with M^T (3 ny^2 each) and the product K0 + A2 Gs (2 nx ny per column)
+    nths = 2 * nq + nu
+    flop_tail_exec = 2 * ny ** 3 + ny * ny + (nx * 3 * ny * ny + nths * 2 * nx * ny if mode == 0 else nths * (4 * nx * ny + 3 * ny * ny + 2 * nx * nx))
+    return dict(flop_tail_executed=flop_tail_exec, n_lin=n_lin, bytes_per_solve=8 * (n_lin + io_shared), bytes_per_solve_shared_table=8 * io_shared,
                 flop_iter=flop_iter, flop_tail=flop_tail)
 
 
@@ -862,6 +866,10 @@ def main():
                      "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "flops_per_unit": flops_per_solve, "bytes_per_unit": alg["bytes_per_solve"], "units_per_launch": solves_per_launch,
                      "avg_launch_ms": avg_launch_ms,
+                     # `frac` counts the reference algorithm's flops per solve.  The device's sensitivity pass executes fewer
+                     # (adjoint form): the same fraction on the flops actually issued
+                     "flops_executed_per_unit": K * alg["flop_iter"] + alg["flop_tail_executed"],
+                     "frac_executed": tflops / FP64_VECTOR_PEAK_TFLOPS * (K * alg["flop_iter"] + alg["flop_tail_executed"]) / flops_per_solve,
                      # the whole step against the same roof: every contract flop of the step (all evaluated sweeps + one
                      # condensed KKT solve per Newton iteration, SURVEY 8d: 9.9 MFLOP banded-equivalent) over the step's wall time
                      "step_frac": ((job_ip_solves * alg["flop_iter"] * K + job_ip_solves * alg["flop_tail"] + job_newton * KKT_FLOP_PER_SOLVE)

@@ -804,7 +804,8 @@ int cimpc_set_linearization(cimpc_handle h, int t, const double* z0, const doubl
     if (t < 1 || t > h->dm.H_ref) return fail(h, CIMPC_ERR_INVALID, "knot index out of range (1-based)");
     if (int dp = drain_pending(h); dp != CIMPC_OK) return dp;
     const int nx = h->nx, ny = h->ny, nz = h->nz, nth = h->nth, G = h->ki.G;
-    const LinLayout L(nx, ny, nth, G, h->ki.generic ? 0 : h->nths);
+    const LinLayout L(nx, ny, nth, G, h->ki.generic ? 0 : h->nths, h->ki.generic ? 0 : h->ki.adj);
+    if (L.size != h->ki.tab_size) return fail(h, CIMPC_ERR_STATE, "table layout of the library and of the kernel differ");
     std::vector<double>& T = h->h_tab;
     std::fill(T.begin(), T.end(), 0.0);
     auto RZ = [&](int r, int c) { return rz0[r + (size_t)c * nz]; };
@@ -854,6 +855,23 @@ int cimpc_set_linearization(cimpc_handle h, int t, const double* z0, const doubl
             for (int k = 0; k < nx; ++k) bq[k & 1] = std::fma(RTH(k, c), CAi[i + (size_t)k * ny], bq[k & 1]);
             T[L.oGs + c * G + i] = (bq[0] + bq[1]) - RTH(nx + i, c);
         }
+    // constants of the adjoint form of the sensitivity pass (lin_table.h: oK0, oAiB, oWT): A^-1 rthdyn, A^-1 B (plain sums), W^T
+    if (L.adj) {
+        for (int i = 0; i < ny; ++i)
+            for (int j = 0; j < ny; ++j) T[L.oWT + i * G + j] = T[L.oW + j * G + i];
+        for (int c = 0; c < L.nths; ++c)
+            for (int i = 0; i < nx; ++i) {
+                double s = 0.0;
+                for (int k = 0; k < nx; ++k) s = std::fma(Ai[i + (size_t)k * nx], RTH(k, c), s);
+                T[L.oK0 + c * nx + i] = s;
+            }
+        for (int i = 0; i < nx; ++i)
+            for (int k = 0; k < ny; ++k) {
+                double s = 0.0;
+                for (int m = 0; m < nx; ++m) s = std::fma(Ai[i + (size_t)m * nx], RZ(m, nx + k), s);
+                T[L.oAiB + i * ny + k] = s;
+            }
+    }
     for (int i = 0; i < ny; ++i) {
         T[L.oVec + LinLayout::V_RY2 * G + i] = RZ(nx + i, nx + ny + i);
         T[L.oVec + LinLayout::V_RY1D * G + i] = RZ(nx + i, nx + i);

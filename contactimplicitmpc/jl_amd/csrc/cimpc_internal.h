@@ -183,6 +183,7 @@ struct KernelInfo {
     int lds_group;    // doubles of per-problem scratch
     int tab_size;     // doubles per knot
     int dtn_ld;       // leading dimension of the delta^T nu products the sweep emits (0: the kernel does not emit them)
+    int adj;          // 1: the table carries the constants of the adjoint sensitivity pass (lin_table.h: oK0, oAiB)
     int generic;      // 1: no compiled lane-group kernel for these dimensions - the runtime-dimension kernel (ip_generic.hip) serves them
 };
 

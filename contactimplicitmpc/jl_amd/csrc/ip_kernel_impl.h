@@ -59,6 +59,12 @@ struct Model {
     static constexpr int RROWS = FULL_TILE ? NY : 8;
     static constexpr int RST_LD = FULL_TILE ? G + 1 : G + 2;   // padded row stride of the R tile
     static constexpr int DTN_LD = ((NTHS + G - 1) / G) * G;    // leading dimension of the delta^T nu products (IpParams::dtn)
+    // Adjoint form of the sensitivity pass (round 5; configuration mode, where only the x rows of dz/dtheta are wanted):
+    // nx transposed solves M^T a_i = (A^-1 B)[i, :]^T and one small product instead of nths solves with M - `sensitivities`
+#ifndef CIMPC_SENS_ADJOINT
+#define CIMPC_SENS_ADJOINT 1
+#endif
+    static constexpr int ADJ = (CIMPC_SENS_ADJOINT && MODE == 0) ? 1 : 0;
 #define CIMPC_SENS_MAX 16      // (a constant of the build: the -D override is gone with the experiment it served)
     static constexpr int SENS_MAX = CIMPC_SENS_MAX;             // converged problems a group may defer
 // (measured dead ends: C A^-1, A^-1, Dy1 rows register-resident per knot - the 76 extra VGPRs spill, sweep launch 0.30 -> 0.47 ms;
@@ -91,7 +97,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 template <class M>
 struct IpSolver {
     static constexpr int NX = M::NX, NY = M::NY, NTH = M::NTH, G = M::G;
-    static constexpr LinLayout L{NX, NY, NTH, G, M::NTHS};
+    static constexpr LinLayout L{NX, NY, NTH, G, M::NTHS, M::ADJ};
     using LG = LaneGroup<G>;
 
     const double* tab;   // LDS: staged linearization table
@@ -170,8 +176,11 @@ struct IpSolver {
     // rzlin! + schur_factorize! + MGS factorize!.  Right-looking order: per column exactly
     // the arithmetic of the reference's left-looking loop (qr.jl:113-137); dot products use
     // four partial sums, 1/|a_k| comes from v_rsq_f64 + two Newton steps on the broadcast self-product of column k.
+    // TR (adjoint sensitivity pass, Model::ADJ): factorizes the TRANSPOSE of the Schur matrix (the table carries both
+    // orientations, lin_table.h: oWT) - qr_solve then solves with M^T.
+    template <bool TR = false>
     __device__ __forceinline__ void factorize(double reg) {
-        const double* tW = tab + L.oW;
+        const double* tW = tab + (TR ? L.oWT : L.oW);
         // lane index of the 3 NY lane compares below (l == r, l == k, l > k), opaque per call: as loop invariants the 48 masks were
         // hoisted out of every loop, overflowed the scalar register file and came back through v_readlane pairs at every use -
         // one v_cmp where it is needed is cheaper than two v_readlane
@@ -386,6 +395,40 @@ struct IpSolver {
         static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; xs[j] = x[j][0] + x[j][1]; });
     }
 
+    // ---- adjoint form of the sensitivity pass (Model::ADJ; after factorize<true>, the QR of M^T) ---------------------------
+    // dx/dtheta = A^-1 rthdyn + (A^-1 B) M^-1 Gs: the same x rows schur_solve! (schur.jl:93-110) gives column by column
+    // (linearized_solver.jl:451-479), with A2 = (A^-1 B) M^-1 formed ROW by row - row i is the solution of M^T a = (A^-1 B)[i, :]^T,
+    // nx solves instead of nths.  Every solve leaves entry k of its row in lane k; the rows go through the R tile (RROWS rows per
+    // pass) to their owner lanes: lane i < nx ends with A2[k] = entry (i, k).
+    template <int N>
+    __device__ __forceinline__ void adjoint_rows(int i0, double* dst) const {
+        const double* tB = tab + L.oAiB + i0 * NY + (vy ? l : 0);
+        double b[N], z[N];
+        static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; b[j] = vy ? tB[j * NY] : 0.0; });
+        if constexpr (G == 16) static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; z[j] = qr_solve(b[j]); });
+        else qr_solve_n<N>(b, z);
+        static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; dst[j * M::RST_LD + l] = z[j]; });
+    }
+    __device__ __forceinline__ void adjoint_factor(double (&A2)[NY]) const {
+        constexpr int AIL = G == 16 ? 4 : 3;      // solves side by side (32-lane groups: one staging vector each)
+        static_for<0, (NX + M::RROWS - 1) / M::RROWS>([&](auto pc) {
+            constexpr int r0 = decltype(pc)::value * M::RROWS, n = NX - r0 < M::RROWS ? NX - r0 : M::RROWS;
+            wave_lds_fence();
+#pragma unroll 1
+            for (int i = 0; i + AIL <= n; i += AIL) adjoint_rows<AIL>(r0 + i, Rst + i * M::RST_LD);
+            if constexpr (n % AIL != 0) adjoint_rows<n % AIL>(r0 + (n / AIL) * AIL, Rst + (n / AIL) * AIL * M::RST_LD);
+            wave_lds_fence();
+            const bool own = l >= r0 && l < r0 + n;
+            const double* row = Rst + (own ? l - r0 : 0) * M::RST_LD;
+            static_for<0, NY>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (r0 == 0) A2[k] = own ? row[k] : 0.0;
+                else A2[k] = own ? row[k] : A2[k];
+            });
+        });
+        wave_lds_fence();
+    }
+
     // linear_solve!(Delta, rz, r) (linearized_solver.jl:424-444)
     __device__ __forceinline__ void linear_solve() {
         const double u = rdyn;
@@ -450,7 +493,7 @@ __device__ __forceinline__ int group_bcast0(int v) {
 
 template <class M>
 __device__ __forceinline__ void stage_table(double* tab, const double* src_tab, int knot, int tid) {
-    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G, M::NTHS);
+    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G, M::NTHS, M::ADJ);
     const double2* src = reinterpret_cast<const double2*>(src_tab + (size_t)knot * L.size);
     double2* dst = reinterpret_cast<double2*>(tab);
     for (int k = tid; k < L.size / 2; k += (int)blockDim.x) dst[k] = src[k];   // 16 B per lane, coalesced
@@ -491,7 +534,7 @@ template <class M, bool ASYNC>
 __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S, const double* tab, int prob, int l, int part = 0, int nparts = 1) {
     constexpr int NX = M::NX, NY = M::NY, NTH = M::NTH, NTHS = M::NTHS, ND = M::ND, G = M::G;
     constexpr int NC = M::NC, NB = M::NB;
-    constexpr LinLayout L(NX, NY, NTH, G, M::NTHS);
+    constexpr LinLayout L(NX, NY, NTH, G, M::NTHS, M::ADJ);
     constexpr int PS = 2 * NX + 4 * NY + 4;
     using LG = LaneGroup<G>;
     const bool vx = S.vx, vy = S.vy;
@@ -503,7 +546,7 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
     S.y1 = vy ? ps[NX + lg] : 1.0;
     S.y2 = vy ? ps[NX + NY + lg] : 1.0;
     const double reg = LG::template bcast<0>((l == 0) ? ps[PS - 2] : 0.0);
-    S.factorize(fmax(reg, p.reg_floor));          // = o.kappa_tol * o.gamma_reg (IpParams::reg_floor)
+    S.template factorize<M::ADJ != 0>(fmax(reg, p.reg_floor));          // = o.kappa_tol * o.gamma_reg (IpParams::reg_floor)
     double* dzo = p.dz + pi * (size_t)(NTHS * ND);
     // delta^T nu of every column (IpParams::dtn).  The columns of a chunk are parked in the R tile (idle once the rows of R sit
     // in registers), then lane j sums column j with the SAME multiply-add chain the decision stage would run on the stored
@@ -557,6 +600,38 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
         }
     };
     const int lo = nparts > 1 ? (NTHS * part) / nparts : 0, hi = nparts > 1 ? (NTHS * (part + 1)) / nparts : NTHS;
+    if constexpr (M::ADJ) {
+        // Adjoint form: A2 = (A^-1 B) M^-1 once per problem (nx transposed solves), then column c of dx/dtheta is
+        // K0[:, c] + A2 Gs[:, c] - a row of the table against a row in registers, Gs read with group-uniform addresses.
+        double A2[NY];
+        S.adjoint_factor(A2);
+        constexpr int CHA = CH1;
+        const double* tK0 = tab + L.oK0 + (vx ? l : 0);
+#pragma unroll 1
+        for (int c0 = lo; c0 < hi; c0 += CHA) {
+            const int n = hi - c0 < CHA ? hi - c0 : CHA;
+#pragma unroll 2
+            for (int cc = 0; cc < n; ++cc) {
+                const int c = c0 + cc;
+                const double* g = tab + L.oGs + c * G;
+                double a[2] = {tK0[c * NX], 0.0};
+                static_for<0, NY>([&](auto kc) { constexpr int k = decltype(kc)::value; a[k & 1] = fma(A2[k], g[k], a[k & 1]); });
+                const double mx = -(a[0] + a[1]);
+                if (vx) xst<ASYNC>(dzo + c * ND + lg, mx);
+                if (want && vx) scr[cc * ND + l] = mx;
+            }
+            if (want) {
+                wave_lds_fence();
+                const double* col = scr + (l < n ? l : 0) * ND;
+                double s_ = 0.0;
+                static_for<0, NX>([&](auto kc) { constexpr int k = decltype(kc)::value; s_ = fma(col[k], LG::template bcast<k>(nux), s_); });
+                if (l < n) xst<ASYNC>(p.dtn + pi * (size_t)M::DTN_LD + c0 + lg, s_);
+                wave_lds_fence();
+            }
+        }
+        problem_done<ASYNC>(p, prob / p.H, l, part == 0);
+        return;
+    }
     constexpr int ILP2 = ILP > 2 ? ILP - 1 : 1;     // second interleave width: a share of 7 / 8 columns runs as 4 + 3 / 4 + 4
     const bool narrow = nparts > 1 && (hi - lo) % ILP != 0;
 #pragma unroll 1
@@ -644,7 +719,7 @@ template <class M, bool ASYNC>
 __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int knot, int tid, [[maybe_unused]] long long* sp = nullptr) {
     constexpr int NX = M::NX, NY = M::NY, NTH = M::NTH, ND = M::ND, G = M::G;
     constexpr int NC = M::NC, NB = M::NB;
-    constexpr LinLayout L(NX, NY, NTH, G, M::NTHS);
+    constexpr LinLayout L(NX, NY, NTH, G, M::NTHS, M::ADJ);
     constexpr int PS = 2 * NX + 4 * NY + 4;
     double* tab = smem;
     const int K = p.Q.K, cap = p.Q.cap, par = p.Q.par;
@@ -975,7 +1050,7 @@ __global__ __launch_bounds__(M::G == 16 ? CIMPC_SWEEP_THREADS : (M::WIDE ? 512 :
 template <class M>
 __global__ __launch_bounds__(64) void ip_callback_kernel(IpCallbackArgs a) {
     constexpr int NX = M::NX, NY = M::NY, NTH = M::NTH, G = M::G;
-    constexpr LinLayout L(NX, NY, NTH, G, M::NTHS);
+    constexpr LinLayout L(NX, NY, NTH, G, M::NTHS, M::ADJ);
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = (int)threadIdx.x, grp = tid / G, l = tid % G;
     double* tab = smem;
@@ -1020,7 +1095,7 @@ __global__ __launch_bounds__(64) void ip_callback_kernel(IpCallbackArgs a) {
 
 template <class M>
 int launch_callback(const IpCallbackArgs& a, hipStream_t s) {
-    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G, M::NTHS);
+    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G, M::NTHS, M::ADJ);
     const int ppw = 64 / M::G;
     const size_t lds = (size_t)(L.size + ppw * M::LDS_GROUP) * sizeof(double);
     static LdsOptIn optin;
@@ -1035,7 +1110,7 @@ int launch_callback(const IpCallbackArgs& a, hipStream_t s) {
 // ----------------------------------------------------------------------------------------
 template <class M>
 int launch_model(const IpParams& p, int waves, hipStream_t s) {
-    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G, M::NTHS);
+    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G, M::NTHS, M::ADJ);
     if (waves < 1 || waves > (M::G == 16 ? CIMPC_SWEEP_THREADS : 512) / 64 || waves == 3) return CIMPC_ERR_INVALID;
     const int ppw = 64 / M::G;
     const size_t lds = (size_t)(L.size + waves * ppw * M::LDS_GROUP) * sizeof(double);
@@ -1043,7 +1118,7 @@ int launch_model(const IpParams& p, int waves, hipStream_t s) {
     if constexpr (M::G != 16) {
         if (waves > 4) {         // throughput build: two waves per SIMD, its own per-problem LDS layout
             using MW = typename M::Wide;
-            constexpr LinLayout LW(MW::NX, MW::NY, MW::NTH, MW::G, MW::NTHS);
+            constexpr LinLayout LW(MW::NX, MW::NY, MW::NTH, MW::G, MW::NTHS, MW::ADJ);
             const size_t lds_w = (size_t)(LW.size + waves * ppw * MW::LDS_GROUP) * sizeof(double);
             static LdsOptIn optin_w;
             if (lds_opt_in(optin_w, (const void*)ip_queue_kernel<MW>, lds_w) != CIMPC_OK) return CIMPC_ERR_HIP;
@@ -1059,12 +1134,13 @@ int launch_model(const IpParams& p, int waves, hipStream_t s) {
 
 template <class M>
 void info_model(KernelInfo* info) {
-    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G, M::NTHS);
+    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G, M::NTHS, M::ADJ);
     info->G = M::G;
     info->lds_table = L.size;
     info->lds_group = M::LDS_GROUP;
     info->tab_size = L.size;
     info->dtn_ld = M::DTN_LD;
+    info->adj = M::ADJ;
 }
 
 #define CIMPC_DEFINE_MODEL(name, q, u, w, c, b)                                              \

@@ -15,18 +15,23 @@
 namespace cimpc {
 
 struct LinLayout {
-    int nx, ny, nth, G, nths;
+    int nx, ny, nth, G, nths, adj;
     // offsets in doubles
-    int oW, oCAi, oAi, oDy1, oDx, oRx, oRy1, oRthDyn, oRthRst, oGs, oVec, oTh0, size;
+    int oW, oCAi, oAi, oDy1, oDx, oRx, oRy1, oRthDyn, oRthRst, oGs, oK0, oAiB, oWT, oVec, oTh0, size;
     // oGs (compiled lane-group models; nths = 0: absent): the right-hand sides of the sensitivity pass as the QR sees them,
     //   Gs[:, c] = CAi * rthdyn[:, c] - rthrst[:, c],  c = 0 .. nths-1  (schur_solve!, schur.jl:93-110, on column c of r_theta,
     //   linearized_solver.jl:451-479) - a constant of the knot that every converged solve used to recompute for each of its
     //   nths columns; formed by cimpc_set_linearization with the kernel's own multiply-add chain (bit-identical columns).
+    // oK0, oAiB (adj = 1: models whose sensitivity pass runs in the adjoint form, ip_kernel_impl.h: sensitivities): the constants
+    //   of dx/dtheta = A^-1 rthdyn + (A^-1 B) M^-1 Gs  (the x rows of schur_solve! applied to every column at once),
+    //   K0[i, c] = (A^-1 rthdyn[:, c])_i at c*nx + i  and  AiB[i, k] = (A^-1 B)[i, k] at i*ny + k  (packed, no lane padding:
+    //   lanes read them contiguously either way and the table has to fit LDS next to sixteen problems of the centroidal model);
+    //   oWT: the Schur matrix in the other orientation (column i at i*G + j) - the adjoint pass factorizes M^T
     // oVec holds 8 lane-strided vectors:
     enum { V_RY2 = 0, V_RY1D, V_CAIBD, V_RDYN0, V_RRST0, V_X0, V_Y10, V_Y20, V_COUNT };
 
-    __host__ __device__ constexpr LinLayout(int nx_, int ny_, int nth_, int G_, int nths_ = 0)
-        : nx(nx_), ny(ny_), nth(nth_), G(G_), nths(nths_),
+    __host__ __device__ constexpr LinLayout(int nx_, int ny_, int nth_, int G_, int nths_ = 0, int adj_ = 0)
+        : nx(nx_), ny(ny_), nth(nth_), G(G_), nths(nths_), adj(adj_),
           oW(0),
           oCAi(oW + ny_ * G_),
           oAi(oCAi + nx_ * G_),
@@ -37,7 +42,10 @@ struct LinLayout {
           oRthDyn(oRy1 + ny_ * G_),
           oRthRst(oRthDyn + nth_ * G_),
           oGs(oRthRst + nth_ * G_),
-          oVec(oGs + nths_ * G_),
+          oK0(oGs + nths_ * G_),
+          oAiB(oK0 + (adj_ ? nths_ * nx_ : 0)),
+          oWT((oAiB + (adj_ ? nx_ * ny_ : 0) + 1) & ~1),
+          oVec(oWT + (adj_ ? ny_ * G_ : 0)),
           oTh0(oVec + V_COUNT * G_),
           size(((oTh0 + nth_) + 1) & ~1) {}
 };

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256, (M::G == 16 ? 2 : 1)) void newton_async_kernel
 
 template <class M>
 int launch_async_model(const IpParams& p, const NewtonDev& S, int waves, int grid, hipStream_t s) {
-    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G, M::NTHS);
+    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G, M::NTHS, M::ADJ);
     if (waves != 1 && waves != 2 && waves != 4) return CIMPC_ERR_INVALID;
     const int ppw = 64 / M::G;
     const size_t lds_ip = (size_t)(L.size + waves * ppw * M::LDS_GROUP) * sizeof(double);

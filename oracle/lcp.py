@@ -214,6 +214,29 @@ def linear_solve_mat(tab: LinTable, reg=0.0):
     return dz
 
 
+def linear_solve_mat_x_adjoint(tab: LinTable, reg=0.0, ncols=None):
+    """The x rows of linear_solve!(dz, rz, rth) (linearized_solver.jl:451-479) in the ADJOINT form the device's sensitivity
+    pass runs in :configuration mode (ip_kernel_impl.h: sensitivities, Model::ADJ) - a model of that schedule, not of a
+    reference routine.  Column c of the x rows is, by schur_solve! (schur.jl:93-110),
+
+        x_c = Ai (u_c + B M^-1 (CAi u_c - v_c)) = K0[:, c] + A2 Gs[:, c],   K0 = Ai rthdyn, Gs = CAi rthdyn - rthrst,
+
+    with A2 = (Ai B) M^-1 formed row by row from nx solves with M^T (its own MGS factorization) instead of one solve with M
+    per column.  Returns +x rows (nx x ncols), the sign of linear_solve_mat."""
+    d = tab.dims
+    n = d.nth if ncols is None else ncols
+    y1_reg = np.maximum(reg, tab.y1)
+    y2_reg = np.maximum(reg, tab.y2)
+    S = tab.S
+    M = (tab.Ry1 - np.diag(tab.Ry2 * y2_reg / y1_reg)) - S.CAiB
+    qs, rs = mgs_factorize(M.T.copy())
+    AiB = S.Ai @ S.B
+    A2 = np.stack([qr_solve(qs, rs, AiB[i]) for i in range(AiB.shape[0])])
+    K0 = S.Ai @ tab.rthdyn[:, :n]
+    Gs = S.CAi @ tab.rthdyn[:, :n] - tab.rthrst[:, :n]
+    return K0 + A2 @ Gs
+
+
 def dense_rz(tab: LinTable, z):
     """Dense rz at z with the structure of linearized_solver.jl:167-169."""
     d = tab.dims

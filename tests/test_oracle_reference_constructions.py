@@ -155,6 +155,29 @@ def test_ip_converges_like_reference_boundary_tests():
         assert np.all(z[d.nq:] > 0.0)
 
 
+@pytest.mark.parametrize("model", ["quadruped", "hopper", "centroidal", "hopper3d"])
+def test_adjoint_form_of_the_sensitivity_pass(model):
+    """The device's :configuration sensitivity pass (ip_kernel_impl.h: sensitivities, Model::ADJ) forms the x rows of
+    linear_solve!(dz, rz, rth) (linearized_solver.jl:451-479) as K0 + A2 Gs with nx solves against M^T; the oracle's model of
+    that schedule against the reference's column-by-column routine, at converged interior-point iterates (where M carries
+    y2 / y1 on its diagonal: cond ~ 1e6).  The two differ by the rounding of a QR of M against a QR of M^T, ~ cond * eps."""
+    from common import MODELS
+    d = Dims(**MODELS[model])
+    prob = synth.make_problem(d, 6, seed=5, kappa=2e-4)
+    opts = oip.IPOptions(kappa_tol=2e-4)
+    nths = 2 * d.nq + d.nu
+    for t in range(6):
+        tab = lcp.LinTable(d, prob["z0"][t], prob["th0"][t], prob["r0"][t], prob["rz0"][t], prob["rth0"][t])
+        z = oip.z_initialize(d, prob["q_ref"][t + 2])
+        status, iters, dz = oip.interior_point_solve(tab, z, prob["th0"][t], opts)
+        assert status
+        reg = opts.kappa_tol * opts.gamma_reg
+        lcp.rzlin(tab, z, reg=reg)
+        want = lcp.linear_solve_mat(tab, reg=reg)[d.ix, :nths]
+        got = lcp.linear_solve_mat_x_adjoint(tab, reg=reg, ncols=nths)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 * max(1.0, np.abs(want).max()))
+
+
 def test_configurationforce_elimination_identity():
     """The identity the device uses to solve :configurationforce KKT systems with the :configuration solvers
     (newton_kernels.hip: cf_reduce_*): with contact-impulse weights G,
