@@ -831,7 +831,7 @@ int cimpc_set_linearization(cimpc_handle h, int t, const double* z0, const doubl
         }
     for (int i = 0; i < ny; ++i)        // W[i*G + j] = Ry1[i,j] - CAiB[i,j], diagonal kept apart
         for (int j = 0; j < ny; ++j)
-            T[L.oW + i * G + j] = (i == j) ? 0.0 : RZ(nx + i, nx + j) - CAiB[i + (size_t)j * ny];
+            T[L.oW + i * L.ldw + j] = (i == j) ? 0.0 : RZ(nx + i, nx + j) - CAiB[i + (size_t)j * ny];
     for (int k = 0; k < nx; ++k) {
         for (int i = 0; i < ny; ++i) T[L.oCAi + k * G + i] = CAi[i + (size_t)k * ny];
         for (int i = 0; i < nx; ++i) T[L.oAi + k * G + i] = Ai[i + (size_t)k * nx];
@@ -855,10 +855,8 @@ int cimpc_set_linearization(cimpc_handle h, int t, const double* z0, const doubl
             for (int k = 0; k < nx; ++k) bq[k & 1] = std::fma(RTH(k, c), CAi[i + (size_t)k * ny], bq[k & 1]);
             T[L.oGs + c * G + i] = (bq[0] + bq[1]) - RTH(nx + i, c);
         }
-    // constants of the adjoint form of the sensitivity pass (lin_table.h: oK0, oAiB, oWT): A^-1 rthdyn, A^-1 B (plain sums), W^T
+    // constants of the adjoint form of the sensitivity pass (lin_table.h: oK0, oAiB): A^-1 rthdyn, A^-1 B (plain sums)
     if (L.adj) {
-        for (int i = 0; i < ny; ++i)
-            for (int j = 0; j < ny; ++j) T[L.oWT + i * G + j] = T[L.oW + j * G + i];
         for (int c = 0; c < L.nths; ++c)
             for (int i = 0; i < nx; ++i) {
                 double s = 0.0;

@@ -176,11 +176,11 @@ struct IpSolver {
     // rzlin! + schur_factorize! + MGS factorize!.  Right-looking order: per column exactly
     // the arithmetic of the reference's left-looking loop (qr.jl:113-137); dot products use
     // four partial sums, 1/|a_k| comes from v_rsq_f64 + two Newton steps on the broadcast self-product of column k.
-    // TR (adjoint sensitivity pass, Model::ADJ): factorizes the TRANSPOSE of the Schur matrix (the table carries both
-    // orientations, lin_table.h: oWT) - qr_solve then solves with M^T.
+    // TR (adjoint sensitivity pass, Model::ADJ): factorizes the TRANSPOSE of the Schur matrix (lane l reads row l of the block
+    // instead of column l; its padded leading dimension keeps both free of bank conflicts) - qr_solve then solves with M^T.
     template <bool TR = false>
     __device__ __forceinline__ void factorize(double reg) {
-        const double* tW = tab + (TR ? L.oWT : L.oW);
+        const double* tW = tab + L.oW;
         // lane index of the 3 NY lane compares below (l == r, l == k, l > k), opaque per call: as loop invariants the 48 masks were
         // hoisted out of every loop, overflowed the scalar register file and came back through v_readlane pairs at every use -
         // one v_cmp where it is needed is cheaper than two v_readlane
@@ -192,7 +192,7 @@ struct IpSolver {
         const double dd = ry2 * y2r * iy1r;
         static_for<0, NY>([&](auto ic) {
             constexpr int r = decltype(ic)::value;
-            const double w = tW[r * G + l];                 // Ry1[r,l] - CAiB[r,l]   (r != l)
+            const double w = TR ? tW[(vy ? l : 0) * L.ldw + r] : tW[r * L.ldw + l];      // Ry1[r,l] - CAiB[r,l]   (r != l)
             Qc[r] = (lq == r) ? ((ry1d - dd) - caibd) : w;  // (D - CAiB)[r,l]
         });
         // Column l stays UNNORMALISED in Qc (q_l = Qc * rdinv); the projection coefficients are
