@@ -81,7 +81,15 @@ struct Model {
     // ... then (32-lane groups) three staging vectors of G doubles: one for lane-indexed vectors that feed a matrix-vector
     // product, two (by step parity) for the column the MGS step broadcasts - IpSolver::stage / factorize
     static constexpr int OFF_BV = ((TILE + SENS_MAX / 2 + 1) + 1) & ~1;
-    static constexpr int NBV = CIMPC_SENS_ILP32 > 3 ? CIMPC_SENS_ILP32 : 3;      // staging vectors per 32-lane group
+#ifndef CIMPC_ADJ_ILP32
+#define CIMPC_ADJ_ILP32 3
+#endif
+#ifndef CIMPC_ADJ_CB
+#define CIMPC_ADJ_CB 4
+#endif
+    static constexpr int ADJ_ILP = (NX <= 16 && NY <= 16) ? 4 : CIMPC_ADJ_ILP32;      // transposed solves of the adjoint pass side by side
+    static constexpr int NBV0 = CIMPC_SENS_ILP32 > 3 ? CIMPC_SENS_ILP32 : 3;
+    static constexpr int NBV = (ADJ && ADJ_ILP > NBV0) ? ADJ_ILP : NBV0;      // staging vectors per 32-lane group
     static constexpr int BVEC = (G == 16) ? 0 : NBV * G;
     static constexpr int LDS_GROUP = OFF_BV + BVEC;  // doubles / problem (even)
 };
@@ -410,7 +418,7 @@ struct IpSolver {
         static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; dst[j * M::RST_LD + l] = z[j]; });
     }
     __device__ __forceinline__ void adjoint_factor(double (&A2)[NY]) const {
-        constexpr int AIL = G == 16 ? 4 : 3;      // solves side by side (32-lane groups: one staging vector each)
+        constexpr int AIL = M::ADJ_ILP;      // solves side by side (32-lane groups: one staging vector each)
         static_for<0, (NX + M::RROWS - 1) / M::RROWS>([&](auto pc) {
             constexpr int r0 = decltype(pc)::value * M::RROWS, n = NX - r0 < M::RROWS ? NX - r0 : M::RROWS;
             wave_lds_fence();
@@ -610,16 +618,30 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
 #pragma unroll 1
         for (int c0 = lo; c0 < hi; c0 += CHA) {
             const int n = hi - c0 < CHA ? hi - c0 : CHA;
-#pragma unroll 2
-            for (int cc = 0; cc < n; ++cc) {
-                const int c = c0 + cc;
-                const double* g = tab + L.oGs + c * G;
-                double a[2] = {tK0[c * NX], 0.0};
-                static_for<0, NY>([&](auto kc) { constexpr int k = decltype(kc)::value; a[k & 1] = fma(A2[k], g[k], a[k & 1]); });
-                const double mx = -(a[0] + a[1]);
-                if (vx) xst<ASYNC>(dzo + c * ND + lg, mx);
-                if (want && vx) scr[cc * ND + l] = mx;
-            }
+            // CB columns side by side, two partial sums each: 2 CB independent multiply-add chains (a wave of the 32-lane latency
+            // build has its SIMD to itself - the chains are the time)
+            constexpr int CB = M::WIDE ? 2 : CIMPC_ADJ_CB;      // (throughput build of the 32-lane models: 256 registers, two waves hide each other)
+            auto columns = [&](auto nb, int cc) {
+                constexpr int N = decltype(nb)::value;
+                const double* g = tab + L.oGs + (c0 + cc) * G;
+                double a[N][2];
+                static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j][0] = tK0[(c0 + cc + j) * NX]; a[j][1] = 0.0; });
+                static_for<0, NY>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j][k & 1] = fma(A2[k], g[j * G + k], a[j][k & 1]); });
+                });
+                static_for<0, N>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const double mx = -(a[j][0] + a[j][1]);
+                    if (vx) xst<ASYNC>(dzo + (c0 + cc + j) * ND + lg, mx);
+                    if (want && vx) scr[(cc + j) * ND + l] = mx;
+                });
+            };
+            int cc = 0;
+#pragma unroll 1
+            for (; cc + CB <= n; cc += CB) columns(std::integral_constant<int, CB>{}, cc);
+#pragma unroll 1
+            for (; cc < n; ++cc) columns(std::integral_constant<int, 1>{}, cc);
             if (want) {
                 wave_lds_fence();
                 const double* col = scr + (l < n ? l : 0) * ND;
