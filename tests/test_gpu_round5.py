@@ -320,3 +320,42 @@ def test_sweep_build_chosen_per_launch_gives_the_same_solve(gpu_required, monkey
         for k in ("sweeps", "ip_iters", "ip_failures"):
             np.testing.assert_array_equal(a[3][k], b[3][k])
         np.testing.assert_allclose(a[0], b[0], rtol=0, atol=1e-9 * max(1.0, np.abs(b[0]).max()))
+
+
+# ---- the adjoint form of the sensitivity pass (:configuration mode; csrc/ip_kernel_impl.h: sensitivities, Model::ADJ) ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,B,H,H_ref", [
+    ("quadruped", 5, 6, 12),       # 16-lane groups, nx = 11 rows in one pass through the tile
+    ("hopper", 4, 8, 10),          # ny = 8 < 16 lanes
+    ("hopper3d", 4, 6, 8),         # nx = 7 > ny = 6: the rows of A2 go through the tile in two passes
+    ("particle", 3, 5, 8),
+    ("centroidal", 3, 4, 6),       # 32-lane groups: three transposed solves side by side, staged through LDS
+])
+def test_adjoint_sensitivity_pass_against_the_oracle(gpu_required, model, B, H, H_ref):
+    """dq0 / dq1 / du1 of every converged solve against the oracle's column-by-column linear_solve!(dz, rz, rth)
+    (linearized_solver.jl:451-479), held to 2e-8 of the block's largest entry - two orders tighter than test_gpu_parity.py's
+    1e-6: the device forms the x rows as K0 + (A^-1 B) M^-1 Gs from nx solves with M^T, a QR of M^T where
+    the reference has one of M, and agrees to ~cond * eps (measured 3e-10 .. 2e-9)."""
+    from common import oracle_sweep
+    d, prob, tabs, rollouts = make_case(model, 0, H_ref=H_ref, H=H, B=B, seed=3)
+    opts = oip.IPOptions(kappa_tol=prob["kappa"])
+    s = make_solver(d, prob, rollouts, H)
+    ref = oracle_sweep(d, tabs, rollouts, opts)
+    q = np.stack([tr.q for tr, _ in ref]); th = np.stack([tr.theta for tr, _ in ref])
+    g = np.stack([tr.gamma for tr, _ in ref]); bb = np.stack([tr.b for tr, _ in ref])
+    out = s.implicit_dynamics(q, th, g, bb, want_z=True)
+    worst, n_ok, n = {}, 0, 0
+    for k in ("dq0", "dq1", "du1"):
+        e = 0.0
+        for b, (tr, o) in enumerate(ref):
+            ok = (out["status"][b] == o["status"]) & (out["iters"][b] == o["iters"]) & (o["status"] == 1)
+            if k == "dq0":
+                n_ok += int(ok.sum()); n += ok.size
+            scale = max(1.0, float(np.abs(o[k][ok]).max())) if ok.any() else 1.0
+            err = float(np.abs(out[k][b][ok] - o[k][ok]).max()) / scale if ok.any() else 0.0
+            e = max(e, err)
+        worst[k] = e
+    _record("adjoint_sensitivities/%s" % model, {"max_scaled_error": worst, "solves_compared": n_ok, "solves": n})
+    assert n_ok >= 0.9 * n
+    for k, e in worst.items():
+        assert e < 2e-8, (k, e)
