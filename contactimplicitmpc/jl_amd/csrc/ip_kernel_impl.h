@@ -8,7 +8,6 @@
 //   linear_solve! (vector)     linearized_solver.jl:424-444, schur_solve! schur.jl:93-110
 //   general_correction_term!, residual_violation, bilinear_violation   :401-418
 //   linear_solve! (matrix rhs, sensitivities)                          :451-479
-//     (:configuration mode: the x rows in the adjoint form - nx solves with M^T and one product, `sensitivities`)
 // and the IP iteration control frozen in DESIGN.md ("IP iteration spec"; RoboDojo 0.1.3
 // owns it upstream and its source is not available).
 //
