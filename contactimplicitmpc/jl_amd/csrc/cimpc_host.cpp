@@ -853,7 +853,7 @@ int cimpc_set_linearization(cimpc_handle h, int t, const double* z0, const doubl
         for (int i = 0; i < ny; ++i) {
             double bq[2] = {0.0, 0.0};
             for (int k = 0; k < nx; ++k) bq[k & 1] = std::fma(RTH(k, c), CAi[i + (size_t)k * ny], bq[k & 1]);
-            T[L.oGs + c * G + i] = (bq[0] + bq[1]) - RTH(nx + i, c);
+            T[L.gst ? L.oGs + i * L.nths + c : L.oGs + c * G + i] = (bq[0] + bq[1]) - RTH(nx + i, c);
         }
     // constants of the adjoint form of the sensitivity pass (lin_table.h: oK0, oAiB): A^-1 rthdyn, A^-1 B (plain sums)
     if (L.adj) {

@@ -613,6 +613,35 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
         // K0[:, c] + A2 Gs[:, c] - a row of the table against a row in registers, Gs read with group-uniform addresses.
         double A2[NY];
         S.adjoint_factor(A2);
+        if constexpr (L.gst != 0) {
+            // 16-lane groups: one COLUMN c of dx/dtheta per lane.  Entry (i, c) = K0[i, c] + sum_k A2[i, k] Gs[k, c]: row k of Gs sits in
+            // this lane's register g[k] (the table stores the block by row for these models), A2[i, k] rides on the DPP operand of the
+            // multiply-add from lane i - nx accumulators per lane, no LDS traffic in the product, every lane busy (the row-per-lane
+            // form kept 11 of 16).  The signs are folded into the operands (-K0, -A2): the accumulators hold the stored values.
+            // delta^T nu of the lane's column: the chain s = fma(dz[k, c], nu[k], s), k = 0 .. nx-1, the decision stage would run on
+            // the stored block (IpParams::dtn) - nu[k] on the DPP operand.
+            static_for<0, NY>([&](auto kc) { constexpr int k = decltype(kc)::value; A2[k] = -A2[k]; });
+            const double* tG = tab + L.oGs;
+            const double* tK = tab + L.oK0;
+#pragma unroll 1
+            for (int cb = lo; cb < hi; cb += G) {
+                const int c = cb + lg;
+                const bool vc = c < hi;
+                const int cq = vc ? c : lo;
+                double g[NY], acc[NX];
+                static_for<0, NY>([&](auto kc) { constexpr int k = decltype(kc)::value; g[k] = tG[k * NTHS + cq]; });
+                static_for<0, NX>([&](auto ic) { constexpr int i = decltype(ic)::value; acc[i] = -tK[cq * NX + i]; });
+                static_for<0, NY>([&](auto kc) { constexpr int k = decltype(kc)::value; Dpp16::outer<NX>(acc, A2[k], g[k]); });
+                if (vc) static_for<0, NX>([&](auto ic) { constexpr int i = decltype(ic)::value; xst<ASYNC>(dzo + (size_t)c * ND + i, acc[i]); });
+                if (want) {
+                    double s_ = 0.0;
+                    Dpp16::chain<NX>(s_, nux, [&](auto ic) { return acc[decltype(ic)::value]; });
+                    if (vc) xst<ASYNC>(p.dtn + pi * (size_t)M::DTN_LD + c, s_);
+                }
+            }
+            problem_done<ASYNC>(p, prob / p.H, l, part == 0);
+            return;
+        }
         constexpr int CHA = CH1;
         const double* tK0 = tab + L.oK0 + (vx ? l : 0);
 #pragma unroll 1
@@ -623,7 +652,7 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
             constexpr int CB = M::WIDE ? 2 : CIMPC_ADJ_CB;      // (throughput build of the 32-lane models: 256 registers, two waves hide each other)
             auto columns = [&](auto nb, int cc) {
                 constexpr int N = decltype(nb)::value;
-                const double* g = tab + L.oGs + (c0 + cc) * G;
+                const double* g = tab + L.oGs + (c0 + cc) * G;      // (32-lane groups: the block is stored by column, lin_table.h)
                 double a[N][2];
                 static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j][0] = tK0[(c0 + cc + j) * NX]; a[j][1] = 0.0; });
                 static_for<0, NY>([&](auto kc) {

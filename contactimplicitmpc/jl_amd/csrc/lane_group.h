@@ -216,6 +216,44 @@ struct Dpp16 {
             matvec<N - C, NACC, K0 + C>(a, v, T);
         }
     }
+    // ---- a[i] += bcast<i>(v) * t, i = 0..N-1: one entry t of this lane against N rows of v (outer-product update) ----------------
+    template <int I0, int NA, int... I>
+    static __device__ __forceinline__ void outer_c(double (&a)[NA], double v, double t, std::integer_sequence<int, I...>) {
+        constexpr int C = sizeof...(I);
+        if constexpr (C == 16) Dpp16Gen::outer16<I0>(a[I0 + I]..., v, t);
+        else if constexpr (C == 8) Dpp16Gen::outer8<I0>(a[I0 + I]..., v, t);
+        else if constexpr (C == 4) Dpp16Gen::outer4<I0>(a[I0 + I]..., v, t);
+        else if constexpr (C == 3) Dpp16Gen::outer3<I0>(a[I0 + I]..., v, t);
+        else if constexpr (C == 2) Dpp16Gen::outer2<I0>(a[I0 + I]..., v, t);
+        else Dpp16Gen::outer1<I0>(a[I0 + I]..., v, t);
+    }
+    template <int N, int I0 = 0, int NA>
+    static __device__ __forceinline__ void outer(double (&a)[NA], double v, double t) {
+        if constexpr (N > 0) {
+            constexpr int C = dpp_chunk<N>();
+            outer_c<I0>(a, v, t, std::make_integer_sequence<int, C>{});
+            outer<N - C, I0 + C>(a, v, t);
+        }
+    }
+    // ---- s += bcast<k>(v) * T(k), k = 0..N-1 in this order: ONE chain, the association of a plain loop -----------------------
+    template <int K0, class TF, int... I>
+    static __device__ __forceinline__ void chain_c(double& s, double v, TF& T, std::integer_sequence<int, I...>) {
+        constexpr int C = sizeof...(I);
+        if constexpr (C == 16) Dpp16Gen::lanes16_acc1<K0>(s, v, T(std::integral_constant<int, K0 + I>{})...);
+        else if constexpr (C == 8) Dpp16Gen::lanes8_acc1<K0>(s, v, T(std::integral_constant<int, K0 + I>{})...);
+        else if constexpr (C == 4) Dpp16Gen::lanes4_acc1<K0>(s, v, T(std::integral_constant<int, K0 + I>{})...);
+        else if constexpr (C == 3) Dpp16Gen::lanes3_acc1<K0>(s, v, T(std::integral_constant<int, K0 + I>{})...);
+        else if constexpr (C == 2) Dpp16Gen::lanes2_acc1<K0>(s, v, T(std::integral_constant<int, K0 + I>{})...);
+        else Dpp16Gen::lanes1_acc1<K0>(s, v, T(std::integral_constant<int, K0 + I>{})...);
+    }
+    template <int N, int K0 = 0, class TF>
+    static __device__ __forceinline__ void chain(double& s, double v, TF&& T) {
+        if constexpr (N > 0) {
+            constexpr int C = dpp_chunk<N>();
+            chain_c<K0>(s, v, T, std::make_integer_sequence<int, C>{});
+            chain<N - C, K0 + C>(s, v, T);
+        }
+    }
     // ---- a += bcast<k>(v) * TA(k), c += bcast<k>(v) * TC(k), k = 0..N-1: two operators on one vector, sequential chains ---
     template <int K0, class TA, class TC, int... I>
     static __device__ __forceinline__ void pair_c(double& a, double& c, double v, TA& ta, TC& tc, std::integer_sequence<int, I...>) {
