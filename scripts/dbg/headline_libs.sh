@@ -1,7 +1,8 @@
-for L in "" scripts/build/libcimpc_noadj.so scripts/build/libcimpc_noadj_pad.so; do
+# two headline-only bench lines per library build: bash scripts/dbg/headline_libs.sh "" path/a.so path/b.so
+for L in "$@"; do
   for rep in 1 2; do
-  CIMPC_LIB=$L timeout 300 python bench.py --no-cpu-baseline --no-latency --no-real-problem --no-traffic --no-centroidal > /tmp/b.json 2>/dev/null
+  CIMPC_LIB=$L timeout 300 python bench.py --no-cpu-baseline --no-latency --no-real-problem --no-traffic --no-centroidal > /tmp/b.json 2>/tmp/b.err || tail -3 /tmp/b.err
   python -c "
-import json;b=json.loads(open('/tmp/b.json').read().strip().splitlines()[-1]);print('lib=[$L]',round(b['value']),b['ms_per_step'],b['solver_iters']['lockstep_rounds_per_step'],b['roofline']['avg_launch_ms'],b['kernel_time_ms_per_step'])"
+import json;b=json.loads(open('/tmp/b.json').read().strip().splitlines()[-1]);k=b['kernel_time_ms_per_step'];print('lib=[$L]',round(b['value']),'ms %.3f'%b['ms_per_step'],'rounds',b['solver_iters']['lockstep_rounds_per_step'],'launch %.3f'%b['roofline']['avg_launch_ms'],'sweep %.2f kkt %.2f resid %.2f tail %.2f'%(k['ip_sweep'],k['kkt'],k['resid'],k['async_tail']), 'conv',b['solver_iters']['converged_rollouts'])"
   done
 done
