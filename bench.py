@@ -281,6 +281,53 @@ def real_mpc_loop_latency(H, device, steps=60, perturb=0.02):
             "newton_iters_first_steps": hist[:8]}
 
 
+def dropin_host_path_latency(H, device, steps=60, perturb=0.02):
+    """What a user of the B4 drop-in gets (julia/CIMPCHip.jl: the method of the package's own newton_solve! on
+    Newton{..., LS = HipMPCSolver}, reached from the reference's UNCHANGED policy(), policy.jl:113-142): the exact C-call sequence
+    of the binding, through ctypes with HOST arrays, on the same real gait2 loop as `mpc_loop_b1.quadruped_h40_real_gait2` - the
+    window and the rotated reference (p.traj, rotated by the policy on the host) arrive from the host at every step.
+      one_call   round 6: cimpc_mpc_solve(window, reference, alt, q0, q1 -> u1, q, u, nu)
+      five_calls round 5: cimpc_set_altitude + cimpc_set_window + cimpc_set_reference + cimpc_newton_solve + cimpc_get_trajectory
+    The knot stamps of the binding (a hash of 60 x (nz + ntheta + nz) doubles per call) are the Julia host's own work and not timed here."""
+    from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions, gait_io, lcp_models
+    m = lcp_models.Quadruped()
+    kappa = 2e-4
+    P = lcp_models.reference_problem(m, gait_io.load_gait(os.path.join(ROOT, "tests", "golden", "gaits", "quadruped_gait2.jld2")), kappa)
+    qd = 1e-2 * np.concatenate([[1.0, 0.02, 0.25], 0.25 * np.ones(m.nq - 3)])
+    r0 = lcp_models.make_rollout(P, H, 0, seed=3, perturb=perturb)
+    host = [lcp_models.make_rollout(P, H, k, seed=0, perturb=0.0) for k in range(steps + 3)]      # the policy's rotated p.traj / p.window per step
+    alt = np.zeros((1, m.nc))
+    out = {}
+    for kind in ("one_call", "five_calls"):
+        s = CIMPCSolver(m.nq, m.nu, m.nw, m.nc, m.nb, P.H, H, B=1, mode=0, ip_opts=InteriorPointOptions(kappa_tol=kappa),
+                        newton_opts=NewtonOptions(kappa=kappa, r_tol=3e-4, max_iter=5), device=device)
+        for t in range(P.H):
+            s.set_linearization(t + 1, P.z[t], P.theta[t], P.r0[t], P.rz0[t], P.rth0[t])
+        s.set_objective(np.tile(np.diag(qd)[None], (H, 1, 1)), np.tile((3e-2 * np.eye(m.nu))[None], (H, 1, 1)))
+        a, b = r0["q0"][None].copy(), r0["q1"][None].copy()
+        its, t0 = 0, None
+        for k in range(steps + 3):
+            if k == 3:
+                t0 = time.perf_counter(); its = 0
+            hk = host[k]
+            win = hk["window"][None] + 1
+            ref = {f: hk[f][None] for f in ("q", "u", "w", "gamma", "b", "theta")}
+            if kind == "one_call":
+                u1, it, rn, tr = s.mpc_solve(a, b, window=win, reference=ref, alt=alt, warm_start=k > 0, which=("q", "u", "nu"))
+            else:
+                s.set_altitude(alt)
+                s.set_window(win)
+                s.set_reference(ref["q"], ref["u"], ref["w"], ref["gamma"], ref["b"], ref["theta"])
+                u1, it, rn = s.newton_solve(a, b, warm_start=k > 0)
+                tr = s.trajectory(which=("q", "u", "nu"))
+            its += int(it[0])
+            a, b = b, tr["q"][:, 2].copy()
+        dt = time.perf_counter() - t0
+        s.close()
+        out[kind] = {"ms_per_mpc_step": 1e3 * dt / steps, "newton_iters_per_step": its / steps}
+    return out
+
+
 def real_problem_inputs(B, H, perturb=0.05):
     """Inputs of `real_problem_leg` (also the full-size parity test's, tests/test_gpu_round3_parity.py): the reference's
     quadruped gait2.jld2 linearized through the model restatement, objective of test/controller/mpc_quadruped.jl:23-27,
@@ -932,6 +979,13 @@ def main():
                               "hopper_h20 (BASELINE configs[1])": mpc_loop_latency(dict(nq=4, nu=2, nw=2, nc=1, nb=2), "hopper", 20, 30, local_rank),
                               "pushbot_h10_configurationforce (BASELINE configs[0])": mpc_loop_latency(dict(nq=2, nu=2, nw=2, nc=2, nb=4), "pushbot", 10, 16, local_rank, mode=1),
                               "quadruped_h40_real_gait2": real_mpc_loop_latency(40, local_rank)}
+        # the same real-gait loop as a user of the B4 drop-in drives it: window + rotated reference from the HOST at every step
+        try:
+            out["dropin_b4_host_path"] = dict(dropin_host_path_latency(40, local_rank),
+                                              workload="quadruped gait2, H=40, ONE robot, warm-started loop; C-call sequence of julia/CIMPCHip.jl's drop-in through ctypes with host arrays "
+                                                       "(beside mpc_loop_b1.quadruped_h40_real_gait2 = the device-resident glue cimpc_set_gait + cimpc_mpc_advance)")
+        except Exception as e:
+            out["dropin_b4_host_path"] = {"error": repr(e)}
     if world == 1 and abs(args.perturb - 0.1) > 1e-12 and not args.no_real_problem:
         # SURVEY.md 8(d) cfg 4 draws the initial conditions as q_ref + U(-0.1, 0.1); the headline batch uses 0.05 (rounds 1-4, kept for
         # continuity).  The contract's own spread stands beside it (outside the timed region, same kernels, same counting):

@@ -75,6 +75,7 @@ SIGNATURES = {
     "cimpc_kkt_solve": (C.c_int, [_h, _dp, C.c_double, _dp]),
     "cimpc_kkt_solve_rho": (C.c_int, [_h, _dp, C.c_double, _dp]),
     "cimpc_newton_solve": (C.c_int, [_h, _dp, _dp, C.c_int, _dp, _ip, _dp]),
+    "cimpc_mpc_solve": (C.c_int, [_h, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp, _ip, _dp, _dp, _dp, _dp, _dp, _dp]),
     "cimpc_newton_solve_dev": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_int]),
     "cimpc_get_trajectory": (C.c_int, [_h, _dp, _dp, _dp, _dp, _dp]),
     "cimpc_get_newton_info": (C.c_int, [_h, _ip, _dp, _dp]),

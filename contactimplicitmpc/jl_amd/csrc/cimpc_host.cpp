@@ -139,6 +139,9 @@ struct cimpc_ctx {
            *d_Cb = nullptr;
     double *d_q0 = nullptr, *d_q1 = nullptr;      // one allocation: d_q1 = d_q0 + B nq (uploaded by one copy)
     double* h_qin = nullptr;     // pinned staging of [q0 | q1], then nq doubles for the stride of cimpc_mpc_advance
+    std::vector<int> win_mirror; // 0-based window as the HOST last uploaded it (empty: unknown - cimpc_set_gait / cimpc_mpc_advance moved it on the device)
+    double* h_stage = nullptr;   // pinned staging of cimpc_mpc_solve (window, reference, altitude in; trajectory out), allocated at its first call
+    size_t h_stage_doubles = 0;
     bool advance_pending = false; // a cimpc_mpc_advance was queued on `stream` and not waited for (its staging word is in flight)
     double* d_result = nullptr;  // end-of-solve result block (solve_finish_kernel): 8 + B (nu + 2) doubles
     double* h_result = nullptr;  // ... its pinned host copy, valid from the end of a solve to the next call that touches the state
@@ -461,7 +464,7 @@ int check_ready(cimpc_ctx* h, bool need_newton) {
 
 extern "C" {
 
-int cimpc_version(void) { return 105; }      // 1.05: round 5 (+ cimpc_get_kkt_twisted; no struct changed).  1.04: round 4 (cimpc_ip_opts::max_time - the struct grew by one double at its end)
+int cimpc_version(void) { return 106; }      // 1.06: round 6 (+ cimpc_mpc_solve; no struct changed).  1.05: round 5 (+ cimpc_get_kkt_twisted; no struct changed).  1.04: round 4 (cimpc_ip_opts::max_time - the struct grew by one double at its end)
 
 void cimpc_default_ip_opts(cimpc_ip_opts* o) {
     if (!o) return;
@@ -769,6 +772,7 @@ int cimpc_destroy(cimpc_handle h) {
     if (h->h_ring) (void)hipHostFree(h->h_ring);
     if (h->h_qin) (void)hipHostFree(h->h_qin);
     if (h->h_result) (void)hipHostFree(h->h_result);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
     {
         RoundStreams& r = h->rs;
         if (r.st) { (void)hipStreamSynchronize(r.st); (void)hipStreamDestroy(r.st); }
@@ -1024,6 +1028,7 @@ int cimpc_set_window(cimpc_handle h, const int* window) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->window_set = true;
     h->gait_set = false;               // an explicit window / reference replaces the gait-generated ones
+    h->win_mirror = w0;
     return CIMPC_OK;
 }
 
@@ -1529,6 +1534,94 @@ int cimpc_newton_solve(cimpc_handle h, const double* q0, const double* q1, int w
     return CIMPC_OK;
 }
 
+// ---- B4 in ONE call (round 6): what the drop-in under the reference's unchanged policy() does per MPC step - window, reference,
+// altitude in, newton_solve!, core.traj / core.nu out (policy.jl:113-142) - without the five synchronous calls and their blocking
+// pageable copies: every input goes through ONE pinned staging block and asynchronous copies on the handle's stream (the solve's
+// streams wait for that stream on the device), the window is re-keyed only when it differs from the one last uploaded, and the
+// trajectory comes back through the same block with one synchronisation.
+int cimpc_mpc_solve(cimpc_handle h, const int* window, const double* q_ref, const double* u_ref, const double* w_ref,
+                    const double* gamma_ref, const double* b_ref, const double* theta_ref, const double* alt,
+                    const double* q0, const double* q1, int warm_start, double* u1, int* newton_iters, double* r_norm,
+                    double* q, double* u, double* gamma, double* b, double* nu_dual) {
+    if (!h || !q0 || !q1) return fail(h, CIMPC_ERR_INVALID, "null argument");
+    if (q_ref && (!u_ref || !theta_ref)) return fail(h, CIMPC_ERR_INVALID, "q_ref, u_ref, theta_ref go together");
+    const cimpc_dims& d = h->dm;
+    const size_t B = d.B, H = d.H, K = d.H_ref;
+    const size_t nwin = B * (H + 2);
+    const size_t n_q = B * (H + 2) * d.nq, n_u = B * H * d.nu, n_w = B * H * d.nw, n_g = B * H * d.nc, n_b = B * H * d.nb,
+                 n_th = B * H * h->nth, n_nu = B * H * h->nd, n_alt = B * d.nc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->h_stage) {
+        // [window (as doubles' worth of ints) | q | u | w | gamma | b | theta | alt]; the way out reuses [q | u | gamma | b | nu]
+        h->h_stage_doubles = (nwin + 1) / 2 + n_q + n_u + n_w + n_g + n_b + std::max(n_th, n_nu) + n_alt + 8;
+        if (hipHostMalloc((void**)&h->h_stage, h->h_stage_doubles * sizeof(double), hipHostMallocDefault) != hipSuccess)
+            return fail(h, CIMPC_ERR_HIP, "hipHostMalloc failed");
+    }
+    if (int dp = drain_pending(h); dp != CIMPC_OK) return dp;
+    double* stage = h->h_stage;
+    int* s_win = reinterpret_cast<int*>(stage);
+    double* s_q = stage + (nwin + 1) / 2; double* s_u = s_q + n_q; double* s_w = s_u + n_u; double* s_g = s_w + n_w;
+    double* s_b = s_g + n_g; double* s_th = s_b + n_b; double* s_alt = s_th + std::max(n_th, n_nu);
+    hipStream_t st = h->stream;
+    if (window) {
+        bool same = h->win_mirror.size() == nwin;
+        for (size_t k = 0; k < nwin; ++k) {
+            const int t = window[k];
+            if (t < 1 || t > (int)K) return fail(h, CIMPC_ERR_INVALID, "window entry out of range (1-based knot index)");
+            s_win[k] = t - 1;
+            same = same && h->win_mirror[k] == t - 1;
+        }
+        if (!same) {      // the per-knot sensitivity memory moves with the window (cimpc_set_window), stream-ordered
+            if (int rk = rekey_out(h); rk != CIMPC_OK) return rk;
+            HIP_TRY(h, hipMemcpyAsync(h->d_window, s_win, nwin * sizeof(int), hipMemcpyHostToDevice, st));
+            if (int rk = rekey_in(h); rk != CIMPC_OK) return rk;
+            h->win_mirror.assign(s_win, s_win + nwin);
+        }
+        h->window_set = true;
+        h->gait_set = false;
+    }
+    if (q_ref) {
+        auto up = [&](double* dst, double* stg, const double* src, size_t n) -> hipError_t {
+            if (n == 0) return hipSuccess;
+            if (src) std::memcpy(stg, src, n * sizeof(double)); else std::memset(stg, 0, n * sizeof(double));
+            return hipMemcpyAsync(dst, stg, n * sizeof(double), hipMemcpyHostToDevice, st);
+        };
+        HIP_TRY(h, up(h->S.ref.q, s_q, q_ref, n_q));
+        HIP_TRY(h, up(h->S.ref.u, s_u, u_ref, n_u));
+        HIP_TRY(h, up(h->S.ref.w, s_w, w_ref, n_w));                       // NULL = zeros, as cimpc_set_reference
+        if (gamma_ref) HIP_TRY(h, up(h->S.ref.g, s_g, gamma_ref, n_g));   // NULL = unchanged, as cimpc_set_reference
+        if (b_ref) HIP_TRY(h, up(h->S.ref.b, s_b, b_ref, n_b));
+        HIP_TRY(h, up(h->S.ref.th, s_th, theta_ref, n_th));
+        h->reference_set = true;
+        h->gait_set = false;
+    }
+    if (alt) {
+        std::memcpy(s_alt, alt, n_alt * sizeof(double));
+        HIP_TRY(h, hipMemcpyAsync(h->d_alt, s_alt, n_alt * sizeof(double), hipMemcpyHostToDevice, st));
+        h->alt_set = true;
+    }
+    int rc = cimpc_newton_solve(h, q0, q1, warm_start, u1, newton_iters, r_norm);
+    if (rc != CIMPC_OK) return rc;
+    if (q || u || gamma || b || nu_dual) {
+        // (the solve has completed on the library's streams; these copies run on the handle's stream, one synchronisation)
+        auto down = [&](double* stg, const double* src, double* dst, size_t n) -> hipError_t {
+            return (dst && n) ? hipMemcpyAsync(stg, src, n * sizeof(double), hipMemcpyDeviceToHost, st) : hipSuccess;
+        };
+        HIP_TRY(h, down(s_q, h->S.traj.q, q, n_q));
+        HIP_TRY(h, down(s_u, h->S.traj.u, u, n_u));
+        HIP_TRY(h, down(s_g, h->S.traj.g, gamma, n_g));
+        HIP_TRY(h, down(s_b, h->S.traj.b, b, n_b));
+        HIP_TRY(h, down(s_th, h->S.nu, nu_dual, n_nu));
+        HIP_TRY(h, hipStreamSynchronize(st));
+        if (q) std::memcpy(q, s_q, n_q * sizeof(double));
+        if (u) std::memcpy(u, s_u, n_u * sizeof(double));
+        if (gamma && n_g) std::memcpy(gamma, s_g, n_g * sizeof(double));
+        if (b && n_b) std::memcpy(b, s_b, n_b * sizeof(double));
+        if (nu_dual) std::memcpy(nu_dual, s_th, n_nu * sizeof(double));
+    }
+    return CIMPC_OK;
+}
+
 int cimpc_get_trajectory(cimpc_handle h, double* q, double* u, double* gamma, double* b, double* nu_dual) {
     if (!h) return CIMPC_ERR_INVALID;
     const cimpc_dims& d = h->dm;
@@ -1610,6 +1703,7 @@ int cimpc_set_gait(cimpc_handle h, const double* q, const double* u, const doubl
     if (int rk = rekey_in(h); rk != CIMPC_OK) return rk;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->gait_set = h->window_set = h->reference_set = true;
+    h->win_mirror.clear();             // the window now lives on the device only
     return CIMPC_OK;
 }
 
@@ -1621,6 +1715,7 @@ int cimpc_mpc_advance(cimpc_handle h, const double* stride) {
     // (the solve's streams wait for this stream, every getter synchronises it first).  The stride goes through a pinned word;
     // a second advance in a row waits for the first one's copy to have left it.
     if (int dp = drain_pending(h); dp != CIMPC_OK) return dp;
+    h->win_mirror.clear();
     double* st_pin = h->h_qin + 2 * (size_t)h->dm.B * h->dm.nq;
     std::memcpy(st_pin, stride, (size_t)h->dm.nq * sizeof(double));
     if (h->gait_set) {          // full reference resident: regenerate the horizon from the gait (stride as given now)

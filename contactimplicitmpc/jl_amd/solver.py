@@ -259,6 +259,30 @@ class CIMPCSolver:
                                                 _dp(u1), _ipt(it), _dp(rn)), "newton_solve")
         return u1, it, rn
 
+    def mpc_solve(self, q0, q1, window=None, reference=None, alt=None, warm_start=False, which=("q", "u", "nu")):
+        """One MPC step in ONE C call (cimpc_mpc_solve): optional new window (B, H+2) 1-based, reference = dict / tuple of
+        (q, u, w, gamma, b, theta) as `set_reference`, altitude (B, nc); returns (u1, newton_iters, r_norm, trajectory dict)."""
+        B, H = self.B, self.H
+        q0 = _f64(q0, (B, self.nq)); q1 = _f64(q1, (B, self.nq))
+        w = None
+        if window is not None:
+            w = np.ascontiguousarray(window, dtype=np.int32)
+            if w.shape != (B, H + 2):
+                raise ValueError(f"window shape {w.shape} != {(B, H + 2)}")
+        ref = [None] * 6
+        if reference is not None:
+            r = [reference[k] for k in ("q", "u", "w", "gamma", "b", "theta")] if isinstance(reference, dict) else list(reference)
+            shp = [(B, H + 2, self.nq), (B, H, self.nu), (B, H, self.nw), (B, H, self.nc), (B, H, self.nb), (B, H, self.nth)]
+            ref = [None if a is None else _f64(a, s) for a, s in zip(r, shp)]
+        al = _f64(alt, (B, self.nc)) if alt is not None else None
+        u1 = np.zeros((B, self.nu)); it = np.zeros(B, dtype=np.int32); rn = np.zeros(B)
+        shapes = dict(q=(B, H + 2, self.nq), u=(B, H, self.nu), gamma=(B, H, self.nc), b=(B, H, self.nb), nu=(B, H, self.nd))
+        out = {k: np.zeros(shapes[k]) for k in ("q", "u", "gamma", "b", "nu") if k in which}
+        P = lambda k: _dp(out[k]) if k in out else None
+        self._check(self.lib.cimpc_mpc_solve(self.h, _ipt(w), *[_dp(a) for a in ref], _dp(al), _dp(q0), _dp(q1), int(bool(warm_start)),
+                                             _dp(u1), _ipt(it), _dp(rn), P("q"), P("u"), P("gamma"), P("b"), P("nu")), "mpc_solve")
+        return u1, it, rn, out
+
     def newton_solve_dev(self, q0_ptr, q1_ptr, warm_start=False):
         """Same, q0/q1 already in device memory (raw pointers, e.g. torch_tensor.data_ptr())."""
         self._check(self.lib.cimpc_newton_solve_dev(self.h, C.c_void_p(q0_ptr), C.c_void_p(q1_ptr),

@@ -223,6 +223,19 @@ int cimpc_newton_solve(cimpc_handle h, const double* q0, const double* q1, int w
 int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q1_dev,
                            int warm_start);
 
+/* ---- B4, one call per MPC step (round 6) -------------------------------------------------------------------------------
+ * What a host that keeps the reference's policy() unchanged does around every newton_solve! (policy.jl:113-142; the drop-in of
+ * julia/CIMPCHip.jl): cimpc_set_altitude + cimpc_set_window + cimpc_set_reference + cimpc_newton_solve + cimpc_get_trajectory,
+ * as ONE entry - inputs staged through one pinned block and copied asynchronously on the handle's stream, the window re-keyed
+ * only when it differs from the one last uploaded, the trajectory returned with one synchronisation.  Same results as the five
+ * calls.  window B x (H+2) 1-based (NULL = unchanged); q_ref .. theta_ref as cimpc_set_reference (q_ref NULL = reference
+ * unchanged; w_ref NULL = zeros, gamma_ref / b_ref NULL = unchanged); alt B x nc (NULL = unchanged); q0, q1 B x nq;
+ * outputs as cimpc_newton_solve (u1 B x nu, newton_iters B, r_norm B) and cimpc_get_trajectory (q, u, gamma, b, nu_dual), any NULL. */
+int cimpc_mpc_solve(cimpc_handle h, const int* window, const double* q_ref, const double* u_ref, const double* w_ref,
+                    const double* gamma_ref, const double* b_ref, const double* theta_ref, const double* alt,
+                    const double* q0, const double* q1, int warm_start, double* u1, int* newton_iters, double* r_norm,
+                    double* q, double* u, double* gamma, double* b, double* nu_dual);
+
 /* ---- results of the last newton solve ----------------------------------------------- */
 /* core.traj: q B x (H+2) x nq, u B x H x nu, gamma B x H x nc, b B x H x nb; nu_dual B x H x nd.
  * Any pointer may be NULL. */

@@ -156,34 +156,78 @@ set_altitude!(hs::Solver, alt) =
     check(ccall((:cimpc_set_altitude, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), hs.h, Matrix{Float64}(reshape(alt, :, Int(hs.dims.B)))), hs.h)
 
 # ---- B4: newton_solve! ---------------------------------------------------------------------------------------------------------
+# Every buffer handed to the library is sized with `hs.dims.B` (the library reads / writes B rollouts whatever the caller meant):
+# the single-trajectory forms below REQUIRE a handle built with B = 1, the batched form takes one column / entry per rollout.
+_need_b1(hs::Solver, what) = hs.dims.B == 1 || error("CIMPCHip.$what: this form drives ONE trajectory, the handle was built with B = $(hs.dims.B) - use the batched form")
+# B x (H+2) 1-based knot indices as the ABI reads them: rollout-major = a column-major (H+2) x B Cint matrix
+_windows(hs::Solver, window::Vector{Int}) = (length(window) == hs.dims.H + 2 || error("window must have H + 2 entries"); reshape(Cint.(window), :, 1))
+function _windows(hs::Solver, windows::AbstractVector{<:AbstractVector{<:Integer}})
+    length(windows) == hs.dims.B || error("one window per rollout: got $(length(windows)), B = $(hs.dims.B)")
+    all(w -> length(w) == hs.dims.H + 2, windows) || error("every window must have H + 2 entries")
+    return Matrix{Cint}(reduce(hcat, windows))
+end
+# the six reference arrays of cimpc_set_reference for B rollouts: per field a (n, steps, B) array = B x steps x n row-major
+function _refs(hs::Solver, refs::AbstractVector, H::Int)
+    length(refs) == hs.dims.B || error("one reference trajectory per rollout: got $(length(refs)), B = $(hs.dims.B)")
+    f(sel, n) = cat((pack(sel(r), n) for r in refs)...; dims = 3)
+    return f(r -> r.q, H + 2), f(r -> r.u, H), f(r -> r.w, H), f(r -> r.γ, H), f(r -> r.b, H), f(r -> r.θ, H)
+end
+
 """
     newton_solve!(hs, core, q0, q1, window, ref_traj; warm_start = false)
 
-`newton_solve!(core, s, q0, q1, window, im_traj, ref_traj; warm_start)` (newton.jl:169-177) on the GPU: uploads window and
-reference, solves, writes `core.traj.u[1]` (read by policy.jl:142) and, with `full = true`, the whole `core.traj`, `core.ν`.
-Returns nothing and never throws for a solve that merely ran out of iterations / time (the reference returns silently too).
+`newton_solve!(core, s, q0, q1, window, im_traj, ref_traj; warm_start)` (newton.jl:169-177) on the GPU for ONE trajectory (handle
+built with B = 1): ONE C call (`cimpc_mpc_solve`: window, reference, q0, q1 in; `u[1]` and, with `full = true`, the whole
+`core.traj`, `core.ν` out).  Returns nothing and never throws for a solve that merely ran out of iterations / time (the reference
+returns silently too).  `alt`: RLin.alt (nc values) or `nothing` = unchanged.
 """
-function newton_solve!(hs::Solver, core, q0, q1, window::Vector{Int}, ref_traj; warm_start::Bool = false, full::Bool = false)
+function newton_solve!(hs::Solver, core, q0, q1, window::Vector{Int}, ref_traj; warm_start::Bool = false, full::Bool = false, alt = nothing)
+    _need_b1(hs, "newton_solve!")
     H = core.traj.H
-    check(ccall((:cimpc_set_window, LIB), Cint, (Ptr{Cvoid}, Ptr{Cint}), hs.h, Cint.(window)), hs.h)      # 1-based knots
-    check(ccall((:cimpc_set_reference, LIB), Cint,
-                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
-                hs.h, pack(ref_traj.q, H + 2), pack(ref_traj.u, H), pack(ref_traj.w, H), pack(ref_traj.γ, H),
-                pack(ref_traj.b, H), pack(ref_traj.θ, H)), hs.h)
-    u1 = zeros(length(core.traj.u[1])); iters = Ref{Cint}(0); rn = Ref{Cdouble}(0.0)
-    check(ccall((:cimpc_newton_solve, LIB), Cint,
-                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ref{Cint}, Ref{Cdouble}),
-                hs.h, q0, q1, warm_start, u1, iters, rn), hs.h)
-    core.traj.u[1] .= u1
+    B = Int(hs.dims.B)
+    nq, nu = length(core.traj.q[1]), length(core.traj.u[1]); nd = length(core.ν[1])
+    qr, ur, wr, gr, br, θr = _refs(hs, [ref_traj], H)
+    u1 = zeros(nu, B); iters = zeros(Cint, B); rn = zeros(Cdouble, B)
+    q = full ? zeros(nq, H + 2, B) : C_NULL; u = full ? zeros(nu, H, B) : C_NULL; ν = full ? zeros(nd, H, B) : C_NULL
+    a = alt === nothing ? C_NULL : Matrix{Float64}(reshape(alt, :, B))
+    check(ccall((:cimpc_mpc_solve, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+                 Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cdouble},
+                 Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                hs.h, _windows(hs, window), qr, ur, wr, gr, br, θr, a, Vector{Float64}(q0), Vector{Float64}(q1), warm_start, u1, iters, rn,
+                q, u, C_NULL, C_NULL, ν), hs.h)
+    core.traj.u[1] .= @view u1[:, 1]
     if full
-        nq, nu = length(core.traj.q[1]), length(core.traj.u[1]); nd = length(core.ν[1])
-        q = zeros(nq, H + 2); u = zeros(nu, H); ν = zeros(nd, H)
-        check(ccall((:cimpc_get_trajectory, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
-                    hs.h, q, u, C_NULL, C_NULL, ν), hs.h)
-        for t = 1:H + 2; core.traj.q[t] .= @view q[:, t]; end
-        for t = 1:H; core.traj.u[t] .= @view u[:, t]; core.ν[t] .= @view ν[:, t]; end
+        for t = 1:H + 2; core.traj.q[t] .= @view q[:, t, 1]; end
+        for t = 1:H; core.traj.u[t] .= @view u[:, t, 1]; core.ν[t] .= @view ν[:, t, 1]; end
     end
     return nothing
+end
+
+"""
+    newton_solve!(hs, q0::Matrix, q1::Matrix, windows, ref_trajs; warm_start = false) -> (u1, newton_iters, r_norm)
+
+BATCHED B4: one `newton_solve!` for each of the `B = hs.dims.B` Monte-Carlo rollouts of a handle (the serial loop of
+examples/quadruped/monte_carlo.jl:76-92, one policy per sample, as ONE call): `q0`, `q1` are nq x B (column b = rollout b),
+`windows` a vector of B windows (`p.window` of every policy), `ref_trajs` a vector of B `ContactTraj` (`p.traj`).  Returns
+`u1` (nu x B: column b = `p.newton.traj.u[1]` of rollout b, policy.jl:142), the Newton iterations and `|r|_1 / N` per rollout.
+`alt`: nc x B or `nothing` = unchanged.  `windows = nothing, ref_trajs = nothing` re-solves on the window / reference already
+resident (e.g. after `mpc_advance!`).
+"""
+function newton_solve!(hs::Solver, q0::Matrix{Float64}, q1::Matrix{Float64}, windows, ref_trajs; warm_start::Bool = false, alt = nothing)
+    B = Int(hs.dims.B); H = Int(hs.dims.H)
+    (size(q0) == (hs.dims.nq, B) && size(q1) == (hs.dims.nq, B)) || error("q0, q1 must be nq x B = $(hs.dims.nq) x $B")
+    (windows === nothing) == (ref_trajs === nothing) || error("windows and ref_trajs go together")
+    w = windows === nothing ? C_NULL : _windows(hs, windows)
+    qr, ur, wr, gr, br, θr = ref_trajs === nothing ? ntuple(_ -> C_NULL, 6) : _refs(hs, ref_trajs, H)
+    a = alt === nothing ? C_NULL : Matrix{Float64}(reshape(alt, :, B))
+    u1 = zeros(Int(hs.dims.nu), B); iters = zeros(Cint, B); rn = zeros(Cdouble, B)
+    check(ccall((:cimpc_mpc_solve, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+                 Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cdouble},
+                 Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                hs.h, w, qr, ur, wr, gr, br, θr, a, q0, q1, warm_start, u1, iters, rn, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL), hs.h)
+    return u1, iters, rn
 end
 
 "Policy glue after a solve: rot_n_stride!(p.traj, ...) + update_window! (policy.jl:136-139) on the device-resident copy."
@@ -191,8 +235,9 @@ mpc_advance!(hs::Solver, stride) = check(ccall((:cimpc_mpc_advance, LIB), Cint, 
 
 # ---- B3: implicit_dynamics! ------------------------------------------------------------------------------------------------------
 function implicit_dynamics!(hs::Solver, im_traj, traj; window = collect(1:traj.H + 2))
+    _need_b1(hs, "implicit_dynamics!")      # d, dz, status, iters below hold ONE trajectory; the library writes hs.dims.B of them
     H = length(window) - 2; nd = length(im_traj.d[1]); nq = length(traj.q[1]); nu = length(traj.u[1])
-    check(ccall((:cimpc_set_window, LIB), Cint, (Ptr{Cvoid}, Ptr{Cint}), hs.h, Cint.(window)), hs.h)
+    check(ccall((:cimpc_set_window, LIB), Cint, (Ptr{Cvoid}, Ptr{Cint}), hs.h, _windows(hs, window)), hs.h)
     d = zeros(nd, H); dz = zeros(nd, 2nq + nu, H); status = zeros(Cint, H); iters = zeros(Cint, H)
     cf = hs.dims.mode == 1
     check(ccall((:cimpc_implicit_dynamics, LIB), Cint,
@@ -297,7 +342,11 @@ hip_mpc_solver(A) = HipMPCSolver(nothing, UInt[], parse(Int, get(ENV, "CIMPC_DEV
 linear_solve!(s::HipMPCSolver, x::Vector{Float64}, A::SparseMatrixCSC{Float64,Int}, b::Vector{Float64}; reg::Float64 = 0.0, fact::Bool = true) =
     linear_solve!(HipCSCSolver(s.device), x, A, b; reg = reg, fact = fact)
 
-_lin_stamp(lin) = hash(lin.rθ, hash(lin.rz, hash(lin.r, hash(lin.z, hash(lin.θ)))))
+# A LinearizedStep is a function of its point: `update!(lin, s, z, θ)` copies (z, θ) in and recomputes r, rz, rθ from them
+# (linearized_step.jl:33-45), and set_implicit_trajectory! / update! are the only writers (policy.jl:100-107,122).  The stamp
+# therefore hashes the POINT (nz + nθ doubles per knot) and the residual vector, not the two matrices - 60 knots: 0.1 MB per
+# call instead of 1.6 MB, which at ~1 GB/s of hashing was comparable to the solve itself (VERDICT r05 weak 3).
+_lin_stamp(lin) = hash(lin.r, hash(lin.z, hash(lin.θ)))
 
 function _upload_changed_knots!(ls::HipMPCSolver, im_traj)
     for t = 1:length(im_traj.lin)
@@ -347,8 +396,9 @@ if isdefined(ContactImplicitMPC, :newton_solve!) && isdefined(ContactImplicitMPC
             ls = core.solver
             ls.hs === nothing && _build_handle!(ls, core, s, im_traj, ref_traj)
             _upload_changed_knots!(ls, im_traj)
-            set_altitude!(ls.hs, im_traj.ip[1].r.alt)                   # RLin.alt as set_altitude! left it (policy.jl:113)
-            newton_solve!(ls.hs, core, q0, q1, window, ref_traj; warm_start = warm_start, full = true)
+            # ONE C call per MPC step: window, reference (p.traj as the policy rotated it), RLin.alt as set_altitude! left it
+            # (policy.jl:113), q0, q1 in - core.traj / core.ν out (cimpc_mpc_solve)
+            newton_solve!(ls.hs, core, q0, q1, window, ref_traj; warm_start = warm_start, full = true, alt = im_traj.ip[1].r.alt)
             return nothing
         end
     end

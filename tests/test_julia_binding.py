@@ -244,7 +244,7 @@ def test_b4_is_a_drop_in_under_the_unchanged_policy():
     # lazily built handle, per-call state from the arguments, full write-back for the warm start / p.newton.traj.u[1]
     assert "ls.hs === nothing && _build_handle!(ls, core, s, im_traj, ref_traj)" in fn
     assert "im_traj.ip[1].r.alt" in fn and "_upload_changed_knots!(ls, im_traj)" in fn
-    assert re.search(r"newton_solve!\(ls\.hs, core, q0, q1, window, ref_traj; warm_start = warm_start, full = true\)", fn)
+    assert re.search(r"newton_solve!\(ls\.hs, core, q0, q1, window, ref_traj; warm_start = warm_start, full = true, alt = im_traj\.ip\[1\]\.r\.alt\)", fn)
     bh = body[body.index("function _build_handle!"):]
     bh = bh[:bh.index("\nend\n")]
     for needle in ("im_traj.mode", "ref_traj.H", "core.traj.H", "im_traj.ip[1].opts", "im_traj.ip[1].κ[1]", "core.opts.r_tol", "core.obj", "_pkg().friction_dim(s.env)"):
@@ -252,3 +252,47 @@ def test_b4_is_a_drop_in_under_the_unchanged_policy():
     assert "CURRENT[]" not in fn and "CURRENT[]" not in bh                                            # no global registry on this path
     # the guard: an early include (B1 only) must not fail on names newton.jl defines later
     assert re.search(r"if isdefined\(ContactImplicitMPC, :newton_solve!\) && isdefined\(ContactImplicitMPC, :Newton\)", body)
+
+
+def _jl_function(start):
+    """text of the top-level Julia function that starts with `start` (up to the first line that is exactly `end`)"""
+    body = JL[JL.index(start):]
+    return body[:body.index("\nend\n") + 5]
+
+
+def test_every_buffer_handed_to_the_library_is_sized_with_the_batch():
+    """VERDICT r05 (weak 3): `Solver(...; B)` accepts any B and the library reads B x (H+2) window entries and writes B x nu
+    controls, B iteration counts, B residuals whatever the caller meant - round 5's explicit forms passed H+2 entries, `zeros(nu)`,
+    `Ref{Cint}`, `Ref{Cdouble}`.  Now: the one-trajectory forms refuse a handle with B != 1 before any call, every output of
+    `cimpc_mpc_solve` is allocated with B, windows are checked against dims.H / dims.B, and there is a batched form."""
+    body = JL.split("\nend # module")[0]
+    assert re.search(r"_need_b1\(hs::Solver, what\) = hs\.dims\.B == 1 \|\| error\(", body)
+    single = _jl_function("function newton_solve!(hs::Solver, core, q0, q1, window::Vector{Int}, ref_traj;")
+    batched = _jl_function("function newton_solve!(hs::Solver, q0::Matrix{Float64}, q1::Matrix{Float64}, windows, ref_trajs;")
+    b3 = _jl_function("function implicit_dynamics!(hs::Solver, im_traj, traj;")
+    assert "_need_b1(hs," in single.split("ccall")[0] and "_need_b1(hs," in b3.split("ccall")[0]
+    for fn in (single, batched):
+        assert "cimpc_mpc_solve" in fn and "B = Int(hs.dims.B)" in fn
+        assert re.search(r"u1 = zeros\([^;]*, B\); iters = zeros\(Cint, B\); rn = zeros\(Cdouble, B\)", fn), fn
+        assert "Ref{Cint}(" not in fn and "Ref{Cdouble}(" not in fn
+        assert "_windows(hs, window" in fn                                    # never a raw Cint.(window)
+    assert "size(q0) == (hs.dims.nq, B)" in batched and "return u1, iters, rn" in batched
+    # windows / references: one per rollout, H + 2 entries each
+    assert "length(windows) == hs.dims.B" in body and "length(w) == hs.dims.H + 2" in body and "length(refs) == hs.dims.B" in body
+    assert "Cint.(window))" not in body.replace("reshape(Cint.(window), :, 1))", "")   # the only conversion left is inside _windows
+    # no single-rollout output buffers anywhere next to a batched entry point
+    for name, _, argt in julia_ccalls():
+        if name in ("cimpc_newton_solve", "cimpc_mpc_solve", "cimpc_implicit_dynamics"):
+            assert "Ref{Cint}" not in argt and "Ref{Cdouble}" not in argt, name
+
+
+def test_drop_in_does_not_rehash_the_matrices_every_step():
+    """VERDICT r05 (weak 3): the per-call stamp of a knot covers the point (z, theta) and r - what `update!` rewrites - not the
+    nz x nz and nz x n_theta matrices, and the drop-in makes ONE solve call per MPC step."""
+    body = JL.split("\nend # module")[0]
+    stamp = re.search(r"^_lin_stamp\(lin\) = (.*)$", body, flags=re.M).group(1)
+    assert "lin.z" in stamp and "lin.θ" in stamp and "lin.rz" not in stamp and "lin.rθ" not in stamp
+    m = re.search(r"function ContactImplicitMPC\.newton_solve!\(", body)
+    fn = body[m.start():]
+    fn = fn[:fn.index("\n        end\n") + 12]
+    assert "set_altitude!(ls.hs" not in fn and fn.count("newton_solve!(ls.hs") == 1
