@@ -246,21 +246,29 @@ def mpc_loop_latency(dims, kind, H, H_ref, device, steps=40, mode=0):
     return {"ms_per_mpc_step": 1e3 * dt / steps, "mpc_steps_per_s": steps / dt, "newton_iters_per_step": its / steps}
 
 
-def real_mpc_loop_latency(H, device, steps=60, perturb=0.02):
-    """The reference's own use (policy.jl:98-146 cadence, no plant): ONE robot on the real quadruped gait2 problem,
-    warm-started newton_solve! every step, reference / window advanced on the device, next state = planned q_3.
-    Starts from a perturbed configuration, so the first steps need Newton iterations and the loop then settles."""
+def real_mpc_loop_latency(H, device, steps=60, perturb=0.02, which="quadruped"):
+    """The reference's own use (policy.jl:98-146 cadence, no plant): ONE robot on a real reference problem - quadruped gait2
+    (test/controller/mpc_quadruped.jl:19-47) or hopper_2D gait_forward (examples/hopper/flat.jl:15-47: a `:joint_traj` file,
+    linearized at its own z / θ as the reference does) - warm-started newton_solve! every step, reference / window advanced on
+    the device, next state = planned q_3.  Starts from a perturbed configuration, so the first steps need Newton iterations and
+    the loop then settles."""
     from contactimplicitmpc.jl_amd import CIMPCSolver, InteriorPointOptions, NewtonOptions, gait_io, lcp_models
-    m = lcp_models.Quadruped()
     kappa = 2e-4
-    P = lcp_models.reference_problem(m, gait_io.load_gait(os.path.join(ROOT, "tests", "golden", "gaits", "quadruped_gait2.jld2")), kappa)
+    gaits = os.path.join(ROOT, "tests", "golden", "gaits")
+    if which == "hopper":
+        m = lcp_models.Hopper2D()
+        P = lcp_models.reference_problem_from_traj(m, gait_io.load_joint_traj(os.path.join(gaits, "hopper_gait_forward.jld2")), kappa)
+        qd, ud = 0.1 * np.array([0.1, 3.0, 1.0, 3.0]), np.array([1e-3, 1.0])                      # examples/hopper/flat.jl:30-34
+    else:
+        m = lcp_models.Quadruped()
+        P = lcp_models.reference_problem(m, gait_io.load_gait(os.path.join(gaits, "quadruped_gait2.jld2")), kappa)
+        qd, ud = 1e-2 * np.concatenate([[1.0, 0.02, 0.25], 0.25 * np.ones(m.nq - 3)]), 3e-2 * np.ones(m.nu)
     r = lcp_models.make_rollout(P, H, 0, seed=3, perturb=perturb)
-    qd = 1e-2 * np.concatenate([[1.0, 0.02, 0.25], 0.25 * np.ones(m.nq - 3)])
     s = CIMPCSolver(m.nq, m.nu, m.nw, m.nc, m.nb, P.H, H, B=1, mode=0, ip_opts=InteriorPointOptions(kappa_tol=kappa),
                     newton_opts=NewtonOptions(kappa=kappa, r_tol=3e-4, max_iter=5), device=device)
     for t in range(P.H):
         s.set_linearization(t + 1, P.z[t], P.theta[t], P.r0[t], P.rz0[t], P.rth0[t])
-    s.set_objective(np.tile(np.diag(qd)[None], (H, 1, 1)), np.tile((3e-2 * np.eye(m.nu))[None], (H, 1, 1)))
+    s.set_objective(np.tile(np.diag(qd)[None], (H, 1, 1)), np.tile(np.diag(ud)[None], (H, 1, 1)))
     stride = lcp_models.get_stride(m, P.q)
     s.set_gait(P.q, P.u, P.theta, stride, w=P.w, gamma=P.gamma, b=P.b)
     a, b = r["q0"][None].copy(), r["q1"][None].copy()
@@ -978,7 +986,12 @@ def main():
         out["mpc_loop_b1"] = {"quadruped_h40 (BASELINE configs[2])": mpc_loop_latency(QUADRUPED, "quadruped", 40, 60, local_rank),
                               "hopper_h20 (BASELINE configs[1])": mpc_loop_latency(dict(nq=4, nu=2, nw=2, nc=1, nb=2), "hopper", 20, 30, local_rank),
                               "pushbot_h10_configurationforce (BASELINE configs[0])": mpc_loop_latency(dict(nq=2, nu=2, nw=2, nc=2, nb=4), "pushbot", 10, 16, local_rank, mode=1),
-                              "quadruped_h40_real_gait2": real_mpc_loop_latency(40, local_rank)}
+                              "quadruped_h40_real_gait2": real_mpc_loop_latency(40, local_rank),
+                              # BASELINE configs[1] on the REAL hopper problem (examples/hopper/flat.jl:15-47 with H_mpc = 20 as the config names it; the
+                              # example itself runs H_mpc = 10 - second entry).  The gait file is a `:joint_traj` file that predates the shipped hopper
+                              # model (leg-length row off by 4e-3, tests/test_real_models.py): it is the reference's PROBLEM, linearized at the file's own z / θ.
+                              "hopper_h20_real_gait (BASELINE configs[1], real problem)": real_mpc_loop_latency(20, local_rank, which="hopper"),
+                              "hopper_h10_real_gait (examples/hopper/flat.jl H_mpc)": real_mpc_loop_latency(10, local_rank, which="hopper")}
         # the same real-gait loop as a user of the B4 drop-in drives it: window + rotated reference from the HOST at every step
         try:
             out["dropin_b4_host_path"] = dict(dropin_host_path_latency(40, local_rank),

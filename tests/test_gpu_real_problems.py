@@ -35,6 +35,8 @@ def test_reference_implicit_dynamics_test_on_device(gpu_required):
 
 @pytest.mark.parametrize("which,kappa,H,B,perturb,ip_rtol,n_rtol", [
     ("quadruped", 2e-4, 40, 8, 0.05, 1e-8, 3e-4),       # BASELINE configs[2/3] on the true problem (mpc_quadruped.jl:19-47)
+    ("hopper", 2e-4, 20, 6, 0.05, 1e-8, 3e-4),          # BASELINE configs[1] on the REAL hopper problem: gait_forward.jld2 (a :joint_traj
+                                                        # file, linearized at its own z / θ), objective and options of examples/hopper/flat.jl:30-47
     ("centroidal", 1e-3, 50, 4, 0.02, 1e-4, 3e-5),      # continuous_trot.jl:31-73 (H_mpc = 50; tracking part of the objective)
     ("centroidal_velocity", 1e-3, 50, 3, 0.01, 1e-4, 3e-5),   # ... with the example's OWN TrackingVelocityObjective (:43-47)
 ])
@@ -48,6 +50,8 @@ def test_newton_solve_on_real_problems(gpu_required, which, kappa, H, B, perturb
     rollouts = [real_rollout(d, prob, H, int(rng.integers(0, H_ref)), seed=10 + b, perturb=perturb) for b in range(B)]
     if which == "quadruped":
         obj = synth.make_objective(d, H, kind="quadruped")
+    elif which == "hopper":
+        obj = synth.make_objective(d, H, kind="hopper")      # examples/hopper/flat.jl:30-34
     elif velocity:
         # continuous_trot.jl:43-47: Q singular along a common x shift, made definite by the velocity term - the banded
         # LDL^T backend (block-tridiagonal P); the oracle solves the dense KKT system by LU
