@@ -88,6 +88,8 @@ SIGNATURES = {
     "cimpc_get_newton_log": (C.c_int, [_h, _dp, C.c_int]),
     "cimpc_get_kkt_fallbacks": (C.c_int, [_h, C.POINTER(C.c_longlong)]),
     "cimpc_get_kkt_twisted": (C.c_int, [_h, C.POINTER(C.c_longlong)]),
+    "cimpc_get_kkt_twisted_fallbacks": (C.c_int, [_h, C.POINTER(C.c_longlong)]),
+    "cimpc_debug_set_tw_spins": (C.c_int, [_h, C.c_int]),
     "cimpc_linear_solve_csc": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), _dp, _dp, _dp]),
     "cimpc_get_rollout_counters": (C.c_int, [_h, _ip, _ip, _ip]),
     "cimpc_profile_enable": (C.c_int, [_h, C.c_int]),

@@ -63,6 +63,7 @@ struct Knobs {
     int kkt_twisted = -1;        // CIMPC_KKT_TWISTED: twisted (two-ended) condensed solve, two workgroups per rollout: 0 never, 1 wherever the
                                  // pipelined kernel would run, -1 = 1
     int kkt_tw_nb = 0;           // CIMPC_KKT_TW_NB: rows eliminated from the bottom (0: the default split)
+    int kkt_tw_spins = 0;        // CIMPC_KKT_TW_SPINS: bound of a chain's wait for its partner, in polls (0: 2^21); tests force the time-out path with 1
     int kkt_tw_max = 120;        // twisted kernel for at most this many rollouts per launch (two workgroups each must be resident together)
     // ---- constants ----
     int async_mem = 0;           // exchange buffers: ordinary device memory (uncached / fine-grained variants lost)
@@ -103,6 +104,7 @@ struct Knobs {
         kkt_pipe = env_int("CIMPC_KKT_PIPE", kkt_pipe);
         kkt_twisted = env_int("CIMPC_KKT_TWISTED", kkt_twisted);
         kkt_tw_nb = env_int("CIMPC_KKT_TW_NB", kkt_tw_nb);
+        kkt_tw_spins = env_int("CIMPC_KKT_TW_SPINS", kkt_tw_spins);
         generic_static = env_int("CIMPC_GENERIC_STATIC", generic_static ? 1 : 0) != 0;
         sweep_wgs = env_int("CIMPC_SWEEP_WGS", sweep_wgs);
         waves32 = env_int("CIMPC_WAVES32", waves32);
@@ -161,6 +163,9 @@ struct cimpc_ctx {
     int kkt_tw_overlap_max = 0;    // overlapped rounds: twisted KKT kernel when at most this many rollouts need a solve (0: never)
     long long adapt32 = 0;         // 32-lane models: problems per sweep launch from which the throughput build is taken (0: the handle's one build)
     long long n_kkt_twisted = 0;   // KKT launches that took the twisted kernel (cimpc_get_kkt_twisted)
+    int* h_twfail = nullptr;       // host-mapped: hand-overs of the twisted kernels that timed out (NewtonDev::kkt_tw_fail), never reset
+    int twfail_seen = 0;           // ... its value when the host last looked
+    long long n_kkt_tw_fallbacks = 0;   // KKT stages repeated on the one-ended kernels after such a time-out (cimpc_get_kkt_twisted_fallbacks)
     bool band_reduce_ok = false;   // every R_t could be inverted: the banded LDL^T may eliminate the controls first (NewtonDev::band_reduce)
     bool use_mixed = false;        // condensed solve in mixed precision (CIMPC_KKT_CONDENSED_MIXED)
     double* d_mix_ws = nullptr;
@@ -352,7 +357,7 @@ int run_sweep(cimpc_ctx* h, int par, int* pending_counter, double* zout, hipStre
     // build (8 waves, two per SIMD) from there on.  Parked iterates are the model's, not the build's: a solve may change builds.
     // (only where the host's count is complete: with the KKT stage in the same round as the evaluation of its candidates - small
     //  batches - the requests of that round are not known at launch; a first version sized a B = 1 sweep for ONE workgroup: 1.1 -> 20 ms)
-    if (h->ki.G == 32 && h->adapt32 > 0 && hint > 0 && h->kkt_overlap && !(h->kn.waves32 == 4 || h->kn.waves32 == 8)) {
+    if (h->ki.G == 32 && h->adapt32 > 0 && hint > 0 && h->kkt_overlap && h->kn.sweep_wgs <= 0 && !(h->kn.waves32 == 4 || h->kn.waves32 == 8)) {      // (an explicit CIMPC_SWEEP_WGS keeps its grid)
         waves = hint >= h->adapt32 ? 8 : 4;
         const size_t groups_per_wg = 2 * (size_t)waves;
         size_t w = ((size_t)hint + 2 * groups_per_wg - 1) / (2 * groups_per_wg);
@@ -678,6 +683,17 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     S.spec_first = h->kn.spec_first >= 0 ? h->kn.spec_first : (d.B <= 1024 ? 3 : 1);
     S.kkt_scalar = h->kn.kkt_scalar ? 1 : 0;
     S.kkt_tw_nb = h->kn.kkt_tw_nb;
+    S.kkt_tw_epoch = 0;
+    S.kkt_tw_spins = h->kn.kkt_tw_spins > 0 ? h->kn.kkt_tw_spins : (1 << 21);
+    {
+        int* dv = nullptr;
+        if (hipHostMalloc((void**)&h->h_twfail, 4 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&dv, h->h_twfail, 0) != hipSuccess) {
+            g_create_error = "mapped counter allocation failed"; cimpc_destroy(h); return CIMPC_ERR_HIP;
+        }
+        h->h_twfail[0] = 0;
+        S.kkt_tw_fail = dv;
+    }
     S.kkt_tw_raw = (h->kn.kkt_twisted != 0 && d.B <= h->kn.kkt_tw_max) ? 1 : 0;
     // Overlapped rounds (B >= 64, hybrid schedule): the twisted kernel where EVERY round's KKT set fits the pair bound, i.e. batches
     // of up to 120 rollouts - B = 96: 5.56 -> 4.8-5.1 ms per batch step; with a bound below the batch size the rounds mix kernels
@@ -773,6 +789,7 @@ int cimpc_destroy(cimpc_handle h) {
     if (h->h_qin) (void)hipHostFree(h->h_qin);
     if (h->h_result) (void)hipHostFree(h->h_result);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->h_twfail) (void)hipHostFree(h->h_twfail);
     {
         RoundStreams& r = h->rs;
         if (r.st) { (void)hipStreamSynchronize(r.st); (void)hipStreamDestroy(r.st); }
@@ -912,9 +929,11 @@ int cimpc_set_objective(cimpc_handle h, const double* Q, const double* R, const 
             }
             return true;
         };
-        if (!symmetric(Q, d.nq)) return fail(h, CIMPC_ERR_INVALID, "objective block Q[i] is not symmetric");
-        if (d.nu > 0 && !symmetric(R, d.nu)) return fail(h, CIMPC_ERR_INVALID, "objective block R[i] is not symmetric");
-        if (V && !symmetric(V, d.nq)) return fail(h, CIMPC_ERR_INVALID, "objective block V[i] is not symmetric");
+        // (the reference-default backend - dense jacobian! + LU, on request - takes the blocks as they are, like the reference)
+        const bool lu = h->nt.kkt_backend == CIMPC_KKT_DENSE_LU;
+        if (!lu && !symmetric(Q, d.nq)) return fail(h, CIMPC_ERR_INVALID, "objective block Q[i] is not symmetric");
+        if (!lu && d.nu > 0 && !symmetric(R, d.nu)) return fail(h, CIMPC_ERR_INVALID, "objective block R[i] is not symmetric");
+        if (!lu && V && !symmetric(V, d.nq)) return fail(h, CIMPC_ERR_INVALID, "objective block V[i] is not symmetric");
     }
     HIP_TRY(h, hipSetDevice(h->device));
     if (int dp = drain_pending(h); dp != CIMPC_OK) return dp;
@@ -955,8 +974,10 @@ int cimpc_set_objective(cimpc_handle h, const double* Q, const double* R, const 
     select_kkt_backend(h);
     // (the inverses feed the condensed solve - also behind the cf-mode reduction - and the control elimination of the banded LDL^T)
     const bool need_inv = !h->use_dense || (h->cf_reduce && V == nullptr);
-    if (need_inv && !q_inverted) return fail(h, CIMPC_ERR_INVALID, "objective block Q[i] is singular");
-    if (need_inv && !r_inverted) return fail(h, CIMPC_ERR_INVALID, "objective block R[i] is singular");
+    // (a refused objective leaves NO objective: the backend selection above is already committed while the device blocks still hold
+    //  the previous call's - ADVICE r05 - so the handle goes back to "set_objective has not been called" instead of solving a mix)
+    if (need_inv && !q_inverted) { h->objective_set = false; return fail(h, CIMPC_ERR_INVALID, "objective block Q[i] is singular"); }
+    if (need_inv && !r_inverted) { h->objective_set = false; return fail(h, CIMPC_ERR_INVALID, "objective block R[i] is singular"); }
     HIP_TRY(h, hipMemcpy(h->d_Q, Q, H * d.nq * d.nq * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_R, R, H * d.nu * d.nu * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_Qinv, Qi.data(), Qi.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -1157,25 +1178,35 @@ int cimpc_kkt_solve(cimpc_handle h, const double* r, double beta, double* delta)
     const size_t n = (size_t)h->dm.B * h->N;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpyAsync(h->d_rhs, r, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    prof_begin(h, PC_KKT);
-    if (h->use_mixed) {
-        rc = ensure_mixed_ws(h);
-        if (rc != CIMPC_OK) return rc;
-        rc = launch_kkt_mixed_raw(h->S, h->d_rhs, beta, h->S.delta, h->d_mix_ws, h->d_mix_nfb, h->stream);
-    } else if (h->use_dense) {
-        rc = ensure_dense_ws(h);
-        if (rc != CIMPC_OK) return rc;
-        if (h->cf_reduce ? (h->velocity_objective && kkt_banded_twisted_available(cf_shadow(h->S))) : (h->use_banded && kkt_banded_twisted_available(h->S))) h->n_kkt_twisted++;
-        rc = h->cf_reduce ? launch_kkt_cf_reduced_raw(h->S, h->d_rhs, beta, h->S.delta, h->d_cf_ws, h->d_dense_ws, h->stream)
-                          : launch_kkt_dense_raw(h->S, h->d_rhs, beta, h->S.delta, h->d_dense_ws, h->stream, h->use_banded);
-    } else {
-        if (h->S.kkt_tw_raw != 0 && kkt_twisted_available(h->S)) h->n_kkt_twisted++;      // (launch_kkt_raw's own test)
-        rc = launch_kkt_raw(h->S, h->d_rhs, beta, h->S.delta, h->stream);
+    if (h->use_mixed) { rc = ensure_mixed_ws(h); if (rc != CIMPC_OK) return rc; }
+    else if (h->use_dense) { rc = ensure_dense_ws(h); if (rc != CIMPC_OK) return rc; }
+    // attempt 0 may take a twisted kernel (two chains per rollout with bounded hand-over waits); if one of them timed out - the
+    // mapped counter moved - the numbers are poisoned and the solve is repeated ONCE on the one-ended kernels (round 6)
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        h->S.kkt_tw_epoch += 1;
+        NewtonDev Sk = h->S;
+        if (attempt == 1) { Sk.kkt_tw_raw = 0; Sk.kkt_tw_band = 0; }
+        const int fails0 = *(volatile int*)h->h_twfail;
+        prof_begin(h, PC_KKT);
+        if (h->use_mixed) {
+            rc = launch_kkt_mixed_raw(Sk, h->d_rhs, beta, Sk.delta, h->d_mix_ws, h->d_mix_nfb, h->stream);
+        } else if (h->use_dense) {
+            if (h->cf_reduce ? (h->velocity_objective && kkt_banded_twisted_available(cf_shadow(Sk))) : (h->use_banded && kkt_banded_twisted_available(Sk))) h->n_kkt_twisted++;
+            rc = h->cf_reduce ? launch_kkt_cf_reduced_raw(Sk, h->d_rhs, beta, Sk.delta, h->d_cf_ws, h->d_dense_ws, h->stream)
+                              : launch_kkt_dense_raw(Sk, h->d_rhs, beta, Sk.delta, h->d_dense_ws, h->stream, h->use_banded);
+        } else {
+            if (Sk.kkt_tw_raw != 0 && kkt_twisted_available(Sk)) h->n_kkt_twisted++;      // (launch_kkt_raw's own test)
+            rc = launch_kkt_raw(Sk, h->d_rhs, beta, Sk.delta, h->stream);
+        }
+        prof_end(h);
+        if (rc != CIMPC_OK) return fail(h, rc, "kkt launch failed");
+        HIP_TRY(h, hipMemcpyAsync(delta, h->S.delta, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        const int fails1 = *(volatile int*)h->h_twfail;
+        if (fails1 == fails0) break;
+        h->n_kkt_tw_fallbacks += fails1 - fails0;
+        h->twfail_seen = fails1;
     }
-    prof_end(h);
-    if (rc != CIMPC_OK) return fail(h, rc, "kkt launch failed");
-    HIP_TRY(h, hipMemcpyAsync(delta, h->S.delta, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
     return CIMPC_OK;
 }
 
@@ -1349,12 +1380,20 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     // four rounds of a cold start lose more to the empty launches than they gain (0.685 -> 0.706 ms).
     // (not with a wall-clock budget: the round queued ahead would still run - and step the trajectory - after the host has stopped
     //  waiting, newton.jl:187-277 ends silently at the check)
+    const int tw_fail0 = *(volatile int*)h->h_twfail;      // time-outs of the twisted kernels' hand-overs before this solve
+    h->twfail_seen = tw_fail0;
     const bool ahead = h->dm.B < 4 && !h->use_mixed && warm_start != 0 && !(h->nt.max_time > 0.0 && h->nt.max_time < 1.0e6);
     auto launch_round = [&](long long r, bool blind) -> int {
         // [KKT for rollouts that start an iteration] || sweep -> residual of every evaluated slot -> line-search decision
         const int slot = (int)(r & 1), par = (int)(r & 1);      // round r consumes Q[par] and leaves the next round's requests in Q[par ^ 1]
         int* d_cnt = h->d_ring + 8 * CPAD * slot;
+        S.kkt_tw_epoch += 1;      // stamp of this round's KKT stage (epoch-valued hand-over flags of the twisted kernels)
+        // a hand-over of a twisted kernel timed out earlier in this solve (its rollouts were queued again): one-ended kernels from here on
+        const int tw_fails = *(volatile int*)h->h_twfail;
+        if (tw_fails != h->twfail_seen) { h->n_kkt_tw_fallbacks += tw_fails - h->twfail_seen; h->twfail_seen = tw_fails; }
+        const bool tw_off = tw_fails != tw_fail0;
         NewtonDev Sk = S;
+        if (tw_off) Sk.kkt_tw_band = 0;
         Sk.b0 = 0; Sk.nb_launch = h->dm.B; Sk.counters = d_cnt;
         Sk.counters_next = h->d_ring + 8 * CPAD * (slot ^ 1);
         Sk.host_flag = h->h_ring_dev + 8 * slot;
@@ -1371,14 +1410,16 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         // three-wave kernel costs no extra CUs there - always taken (round 4, BASELINE configs[4] at 64 rollouts: KKT 6.1 -> 3.2 ms per
         // step, 16.3 -> 13.3 ms; at 128 rollouts 24.2 -> 21.2 ms: profiles/r04/cent_kkt_pipe.log)
         const bool wide_tiles = (h->dm.nq > 16 || h->dm.nu > 16) && h->dm.nq <= 24 && h->dm.nu <= 24;
-        int pipe = h->kn.kkt_pipe >= 0 ? h->kn.kkt_pipe : ((!h->kkt_overlap && n_kkt <= h->kn.kkt_pipe_max) || wide_tiles) ? 1 : 0;
+        // (CIMPC_KKT_PIPE selects between the one-wave and the three-wave kernel only - ADVICE r05: a 2 from the environment went
+        //  to the twisted kernel past its availability test and its pair bound; the twisted form is chosen below, where both are checked)
+        int pipe = h->kn.kkt_pipe >= 0 ? std::min(h->kn.kkt_pipe, 1) : ((!h->kkt_overlap && n_kkt <= h->kn.kkt_pipe_max) || wide_tiles) ? 1 : 0;
         // Round 5: where the pipelined kernel runs - the solve is on the critical path - the TWISTED solve takes its place: two
         // workgroups per rollout factor the block penta-diagonal matrix from both ends (two chains of about H / 2 steps), as long as
         // every pair is resident at once
-        if (pipe == 1 && h->kn.kkt_twisted != 0 && n_kkt <= h->kn.kkt_tw_max && kkt_twisted_available(Sk)) pipe = 2;
+        if (pipe == 1 && !tw_off && h->kn.kkt_twisted != 0 && n_kkt <= h->kn.kkt_tw_max && kkt_twisted_available(Sk)) pipe = 2;
         // ... and in the OVERLAPPED rounds of larger batches when few rollouts start a Newton iteration (late rounds): the packed
         // one-wave recursion (266 us) then outlasts the thinning sweep next to it, the twisted pair (two workgroups per rollout) does not
-        if (pipe == 0 && h->kkt_overlap && !blind && h->kn.kkt_twisted != 0 && h->kkt_tw_overlap_max > 0 && n_kkt > 0 && n_kkt <= h->kkt_tw_overlap_max &&
+        if (pipe == 0 && !tw_off && h->kkt_overlap && !blind && h->kn.kkt_twisted != 0 && h->kkt_tw_overlap_max > 0 && n_kkt > 0 && n_kkt <= h->kkt_tw_overlap_max &&
             kkt_twisted_available(Sk)) pipe = 2;
         if (kkt && pipe == 2 && !h->use_dense && !h->use_mixed && (h->kkt_overlap ? h->kn.kkt_packed : true)) h->n_kkt_twisted++;
         if (kkt && !h->kkt_overlap) {   // small batches: latency matters, keep the KKT result in this round
@@ -1770,6 +1811,20 @@ int cimpc_get_newton_log(cimpc_handle h, double* log, int max_entries) {
 int cimpc_get_kkt_twisted(cimpc_handle h, long long* n) {
     if (!h || !n) return CIMPC_ERR_INVALID;
     *n = h->n_kkt_twisted;
+    return CIMPC_OK;
+}
+
+int cimpc_get_kkt_twisted_fallbacks(cimpc_handle h, long long* n) {
+    if (!h || !n) return CIMPC_ERR_INVALID;
+    const int cur = *(volatile int*)h->h_twfail;
+    if (cur != h->twfail_seen) { h->n_kkt_tw_fallbacks += cur - h->twfail_seen; h->twfail_seen = cur; }
+    *n = h->n_kkt_tw_fallbacks;
+    return CIMPC_OK;
+}
+
+int cimpc_debug_set_tw_spins(cimpc_handle h, int spins) {
+    if (!h) return CIMPC_ERR_INVALID;
+    h->S.kkt_tw_spins = spins > 0 ? spins : (1 << 21);
     return CIMPC_OK;
 }
 

@@ -663,7 +663,7 @@ __device__ __forceinline__ void kkt_banded_body(const NewtonDev& S, const KktArg
             // window now and none has been a pivot (the next diagonal block - pivots m2 .. - is formed later in this iteration).
             if (k == m2 - RB) {
                 BTWSTAMP(2)
-                tw_ok = kkt_tw_wait(xfl + 0);
+                tw_ok = kkt_tw_wait(xfl + 0, S.kkt_tw_epoch, S.kkt_tw_spins); if (!tw_ok) kkt_tw_give_up(xfl, S.kkt_tw_epoch, tid == 0);
                 BTWSTAMP(3)
                 for (int e = tid; e < w * (w + 1); e += nt) {
                     const int a = e / (w + 1), a2 = e - a * (w + 1);
@@ -829,7 +829,7 @@ __device__ __forceinline__ void kkt_banded_body(const NewtonDev& S, const KktArg
         }
         __threadfence();
         __syncthreads();
-        if (tid == 0) astore(xfl + 0, 1);
+        if (tid == 0) astore(xfl + 0, S.kkt_tw_epoch);
     }
     __syncthreads();              // full barrier: the rows of L and y in global memory are read back below
     // ---- back substitution  L^T x = D^-1 y.  acc_j = sum_{i > j} L[i][j] x_i is built row by row (i descending); round 4: the pending
@@ -853,7 +853,7 @@ __device__ __forceinline__ void kkt_banded_body(const NewtonDev& S, const KktArg
             return ki < nr ? ti * nr + ki : H * nr + ti * nd + (ki - nr);
         };
         BTWSTAMP(5)
-        if constexpr (TW == 2) tw_ok = kkt_tw_wait(xfl + 1);     // the middle rows' solution (the top chain's first w values) is in D
+        if constexpr (TW == 2) { tw_ok = kkt_tw_wait(xfl + 1, S.kkt_tw_epoch, S.kkt_tw_spins); if (!tw_ok) kkt_tw_give_up(xfl, S.kkt_tw_epoch, tid == 0); }     // the middle rows' solution (the top chain's first w values) is in D
         BTWSTAMP(6)
         auto stage = [&](int ch, int t0, int nth) {              // chunk ch = rows NR-1 - ch CR downwards -> buffer ch & 1  (threads t0 .. of nth)
             const int i_hi = NR - 1 - ch * CR, i_lo = max(i_hi - CR + 1, 0), n = i_hi - i_lo + 1, tot = n * 192;
@@ -925,7 +925,7 @@ __device__ __forceinline__ void kkt_banded_body(const NewtonDev& S, const KktArg
                 const int i_lo_done = max(NR - 1 - ch * CR - CR + 1, 0);
                 if (i_lo_done <= m2 && i_lo_done + CR > m2 && tid < 64) {
                     __threadfence();
-                    if (tid == 0) astore(xfl + 1, 1);
+                    if (tid == 0) astore(xfl + 1, S.kkt_tw_epoch);
                 }
             }
         }
@@ -938,14 +938,17 @@ __device__ __forceinline__ void kkt_banded_body(const NewtonDev& S, const KktArg
         __threadfence();
         __syncthreads();
         if (tid == 0) {
-            if (TW == 1) astore(xfl + 0, 0); else astore(xfl + 1, 0);      // consumed flags down again for the next solve of this rollout
-            *tw_prev = atomicAdd(xfl + 2, 1);
+            *tw_prev = atomicAdd(xfl + 2, 1);      // (epoch-valued flags: nothing to reset)
         }
         __syncthreads();
         if (*tw_prev == 0) return;
         __syncthreads();
         __threadfence();
         if (tid == 0) astore(xfl + 2, 0);
+        if (aload(xfl + 3) == S.kkt_tw_epoch) {      // a hand-over of this solve timed out (poisoned numbers): queue the KKT stage again
+            if (tid == 0) kkt_tw_requeue(S, b, K.finish);
+            return;
+        }
     }
     if (reduced) {      // Du_t = R_t^-1 (r_u,t - du1_t^T Dnu_t)
         __threadfence_block();

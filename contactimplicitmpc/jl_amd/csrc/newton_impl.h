@@ -1486,17 +1486,33 @@ __host__ __device__ inline int kkt_tw_split(int H, int nb_override = 0, bool wid
 constexpr int KKT_TW_MIN_H = 24;
 // per-rollout exchange block of the two chains: [S00 | S11 | S10^T] (nd x nd each), c0, c1, dnu_{m+1}, dnu_m
 __host__ __device__ constexpr int kkt_tw_xch_doubles(int nd) { return 3 * nd * nd + 4 * nd; }
-constexpr int KKT_TW_FLAGS = 32;         // ints per rollout (one 128-byte line): [0] traces ready, [1] middle dnu ready, [2] chains finished
-// Wait for the partner chain's flag (agent scope), then acquire.  Bounded: a partner that never becomes resident must not hang the
-// device - the caller poisons its result with NaN instead (the solve then fails loudly: r_norm = NaN).
-__device__ __forceinline__ bool kkt_tw_wait(const int* flag) {
+constexpr int KKT_TW_FLAGS = 32;         // ints per rollout (one 128-byte line): [0] traces ready, [1] middle dnu ready, [2] chains finished, [3] a hand-over of
+                                         // this launch timed out; [4..7] the same four words of the banded twisted kernel (kkt_dense.hip)
+constexpr int KKT_TW_SPINS = 1 << 21;    // default bound of a wait (NewtonDev::kkt_tw_spins; CIMPC_KKT_TW_SPINS / cimpc_debug_set_tw_spins for the tests)
+// Wait for the partner chain's flag to show THIS launch's stamp (agent scope), then acquire.  Bounded: a partner that never becomes
+// resident must not hang the device - the caller poisons its result with NaN AND marks the rollout (kkt_tw_give_up), so that the
+// solve is repeated on the one-ended kernel instead of being used.
+__device__ __forceinline__ bool kkt_tw_wait(const int* flag, int epoch, int spins_max) {
     bool ok = false;
-    for (int spins = 0; spins < (1 << 21); ++spins) {
-        if (__builtin_amdgcn_readfirstlane(aload(flag)) != 0) { ok = true; break; }
+    for (int spins = 0; spins < spins_max; ++spins) {
+        if (__builtin_amdgcn_readfirstlane(aload(flag)) == epoch) { ok = true; break; }
         __builtin_amdgcn_s_sleep(2);
     }
     __threadfence();
     return ok;
+}
+// a chain gave up waiting: word 3 of the rollout's flag line carries the launch's stamp (read by whichever chain finishes last)
+__device__ __forceinline__ void kkt_tw_give_up(int* xfl, int epoch, bool one_lane) {
+    if (one_lane) astore(xfl + 3, epoch);
+}
+// The last chain of a rollout whose hand-over timed out: the KKT stage of the rollout is queued AGAIN (it stays in STAGE_KKT; the
+// entry joins the list the decision kernel of this round builds for the next one) and the failure is counted where the host sees it.
+__device__ __forceinline__ void kkt_tw_requeue(const NewtonDev& S, int b, int finish) {
+    if (finish == 1) {
+        const int pos = atomicAdd(&S.counters[1 * CPAD], 1);
+        if (S.kkt_list != nullptr && pos < S.dm.B) S.kkt_list[(size_t)S.WQ.par * S.dm.B + pos] = b;
+    }
+    if (S.kkt_tw_fail != nullptr) { __hip_atomic_fetch_add(S.kkt_tw_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __threadfence_system(); }
 }
 // tile leading dimension for a model: 16 (one MFMA block per tile) or 24 (2 x 2 blocks, masked)
 template <int NQ, int NU>
@@ -1823,7 +1839,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
                 }
                 if (i == nbot + 1) {      // everything the top chain waits for is written: release, raise the flag
                     __threadfence();
-                    if (lane == 0) astore(xfl + 0, 1);
+                    if (lane == 0) astore(xfl + 0, S.kkt_tw_epoch);
                 }
                 return;
             }
@@ -1832,7 +1848,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
             [[maybe_unused]] double cm = 0.0;
             if constexpr (TW == 1) {
                 if (i >= msp) {       // middle rows: the bottom chain's share of the right-hand side (c1 for row m, c0 for row m+1)
-                    if (i == msp) tw_ok = kkt_tw_wait(xfl + 0);
+                    if (i == msp) { tw_ok = kkt_tw_wait(xfl + 0, S.kkt_tw_epoch, S.kkt_tw_spins); if (!tw_ok) kkt_tw_give_up(xfl, S.kkt_tw_epoch, lane == 0); }
                     if (lane < nd) cm = tw_ok ? xc[(msp + 1 - i) * nd + lane] : __builtin_nan("");
                 }
             }
@@ -1858,7 +1874,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         if constexpr (PIPE >= 2) { y0 = tile_ld<TL, F32>(t.Y0h, li, lk); y1a = tile_ld<TL, F32>(t.Y1h, li, lk); }
         if constexpr (TW == 1) {
             if (i >= msp) {       // middle rows: minus what the rows eliminated from the bottom contribute
-                if (i == msp) { TWSTAMPW(0) tw_ok = kkt_tw_wait(xfl + 0); TWSTAMPW(1) }
+                if (i == msp) { TWSTAMPW(0) tw_ok = kkt_tw_wait(xfl + 0, S.kkt_tw_epoch, S.kkt_tw_spins); TWSTAMPW(1) if (!tw_ok) kkt_tw_give_up(xfl, S.kkt_tw_epoch, lane == 0); }
                 sub_g(y0, xS + (i == msp ? n2 : 0), tw_ok);                 // Y_mm -= S11 ,  Y_{m+1,m+1} -= S00
                 if (i == msp + 1) sub_g(y1a, xS + 2 * n2, tw_ok);           // Y_{m+1,m} -= S10^T
             }
@@ -2035,13 +2051,12 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     // chain receives the two middle rows - its steps nbot, nbot + 1 - from the top chain)
     const int NBK = TW == 2 ? nbot : NS;
     if constexpr (TW == 2) {
-        tw_ok = kkt_tw_wait(xfl + 1);
+        tw_ok = kkt_tw_wait(xfl + 1, S.kkt_tw_epoch, S.kkt_tw_spins);
+        if (!tw_ok) kkt_tw_give_up(xfl, S.kkt_tw_epoch, lane == 0);
         TWSTAMP(3)
         if (lane < 2 * nd) dn_all[(nbot + lane / nd) * VS + lane % nd] = tw_ok ? xdn[lane] : __builtin_nan("");
         lds_sync();
-        if (lane == 0) astore(xfl + 1, 0);        // consumed: the flag is down again for the next solve of this rollout
-    }
-    if constexpr (TW == 1) { if (lane == 0) astore(xfl + 0, 0); }      // (waves 1, 2 consumed the traces before the last tick)
+    }      // (epoch-valued flags: nothing is reset - the next launch waits for ITS stamp)
     auto prefetch_b = [&](auto setc, int i) {
         constexpr int set = decltype(setc)::value;
         if (i < 0) return;
@@ -2067,7 +2082,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         if constexpr (TW == 1) {
             if (i == msp) {
                 __threadfence();
-                if (lane == 0) astore(xfl + 1, 1);
+                if (lane == 0) astore(xfl + 1, S.kkt_tw_epoch);
             }
         }
         lds_sync();
@@ -2160,6 +2175,10 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         if ((int)vec[11 * VS] == 0) return;
         __threadfence();
         if (wave == 0 && lane == 0) astore(xfl + 2, 0);
+        if (__builtin_amdgcn_readfirstlane(aload(xfl + 3)) == S.kkt_tw_epoch) {      // a hand-over of this solve timed out: the numbers are poisoned
+            if (wave == 0 && lane == 0) kkt_tw_requeue(S, b, K.finish);
+            return;
+        }
         if (K.finish) start_line_search<BlockSync>(S, b, K.finish, lane + 64 * wave, 192);
         if (wave == 0) { TWSTAMP(7) }
         return;

@@ -622,6 +622,18 @@ __global__ __launch_bounds__(256) void cf_reduce_post_kernel(NewtonDev S, KktArg
     }
     __syncthreads();
     if (K.finish) {
+        // (the reduced solve may have been the twisted banded kernel: a hand-over that timed out left its mark - words 3 / 7 of the
+        //  rollout's flag line carry the launch's stamp - and poisoned numbers; the KKT stage of the rollout is queued again instead)
+        if (S.kkt_tw_flags != nullptr) {
+            const int* fl = S.kkt_tw_flags + (size_t)b * KKT_TW_FLAGS;
+            if (aload(fl + 3) == S.kkt_tw_epoch || aload(fl + 7) == S.kkt_tw_epoch) {
+                if (tid == 0) {
+                    const int pos = atomicAdd(&S.counters[1 * CPAD], 1);
+                    if (S.kkt_list != nullptr && pos < S.dm.B) S.kkt_list[(size_t)S.WQ.par * S.dm.B + pos] = b;
+                }
+                return;
+            }
+        }
         __threadfence_block();
         start_line_search<BlockSync>(S, b, 1, tid, nt);
     }

@@ -89,6 +89,14 @@ struct NewtonDev {
     // ([S00 | S11 | S10^T | c0 | c1 | dnu_{m+1} | dnu_m], kkt_tw_xch_doubles(nd)) and one line of flags (KKT_TW_FLAGS ints)
     double* kkt_tw_xch;
     int* kkt_tw_flags;
+    // The flags are EPOCH-valued (round 6): a producer stores the launch's stamp `kkt_tw_epoch` (the host bumps it for every
+    // KKT stage), a consumer waits for equality and never resets - a partner that arrives after its waiter gave up cannot leave a
+    // raised flag behind for the next solve of the rollout.  A wait is bounded by `kkt_tw_spins` polls; a chain that gives up marks
+    // the rollout (flag word 3 = epoch) and counts in `kkt_tw_fail` (host-mapped): the chain that finishes last then re-queues the
+    // rollout's KKT stage instead of starting the line search on poisoned numbers, and the host serves it with the one-ended kernel.
+    int kkt_tw_epoch;
+    int kkt_tw_spins;
+    int* kkt_tw_fail;  // host-mapped counter of timed-out hand-overs (null: not counted)
     int kkt_tw_nb;     // rows the bottom chain eliminates (0: kkt_tw_split's default; CIMPC_KKT_TW_NB)
     int kkt_tw_raw;    // 1: the B1 seam (cimpc_kkt_solve: a lone solve, latency-bound) takes the twisted kernel too
     int kkt_tw_band;   // 1: the banded LDL^T takes its twisted form (two workgroups per rollout) where it is available (kkt_dense.hip)

@@ -357,6 +357,15 @@ class CIMPCSolver:
         self._check(self.lib.cimpc_get_kkt_twisted(self.h, C.byref(n)), "get_kkt_twisted")
         return n.value
 
+    def kkt_twisted_fallbacks(self):
+        """Hand-overs of the twisted kernels that timed out (their KKT stages were repeated on the one-ended kernels)."""
+        n = C.c_longlong()
+        self._check(self.lib.cimpc_get_kkt_twisted_fallbacks(self.h, C.byref(n)), "get_kkt_twisted_fallbacks")
+        return n.value
+
+    def debug_set_tw_spins(self, spins):
+        self._check(self.lib.cimpc_debug_set_tw_spins(self.h, int(spins)), "debug_set_tw_spins")
+
     def stats(self):
         s = _lib.Stats()
         self._check(self.lib.cimpc_get_stats(self.h, C.byref(s)), "get_stats")

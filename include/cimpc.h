@@ -256,6 +256,15 @@ int cimpc_get_kkt_fallbacks(cimpc_handle h, long long* n);
  * where a solve is latency-bound - single rollouts and small batches in newton_solve!, the B1 seam cimpc_kkt_solve - for
  * horizons of at least 24 steps; CIMPC_KKT_TWISTED=0 in the environment at cimpc_create keeps the one-ended kernels. */
 int cimpc_get_kkt_twisted(cimpc_handle h, long long* n);
+/* The two chains of a twisted solve hand their middle rows over through device memory with BOUNDED waits (a partner chain that is
+ * not resident - a foreign kernel saturating the device - must not hang it).  A wait that times out poisons nothing the caller
+ * sees: the rollout's KKT stage is queued again and served by the one-ended kernel (newton_solve!: the next round, the rest of
+ * that solve stays on the one-ended kernels; cimpc_kkt_solve: repeated at once).  n = hand-overs that timed out since cimpc_create. */
+int cimpc_get_kkt_twisted_fallbacks(cimpc_handle h, long long* n);
+/* TEST HOOK: bound of those waits in polls (<= 0: the default 2^21, about a second).  tests/test_gpu_round6.py forces the
+ * time-out path with 1 and then restores the default on the SAME handle (epoch-valued flags: a partner that raises its flag
+ * after the waiter gave up cannot be mistaken for the next solve's).  Also CIMPC_KKT_TW_SPINS in the environment at cimpc_create. */
+int cimpc_debug_set_tw_spins(cimpc_handle h, int spins);
 /* per rollout, last newton solve: implicit_dynamics! evaluations, sum of IP iterations
  * ("solver iterations to tolerance"), failed IP solves.  Each B ints; any may be NULL. */
 int cimpc_get_rollout_counters(cimpc_handle h, int* sweeps, int* ip_iters, int* ip_failures);
