@@ -112,8 +112,15 @@ def test_newton_solve_other_models(gpu_required, model, H, H_ref, dense_q):
             np.testing.assert_allclose(traj["q"][b], core.traj.q, rtol=0, atol=1e-7)
             np.testing.assert_allclose(traj["u"][b], core.traj.u, rtol=0, atol=1e-6)
         else:
+            # (the relaxed branch is bounded - it is the round-off flip described above and nothing else: one iteration
+            #  apart, the shorter run ended within 5 % of r_tol (the coin toss), both ends converged, and the two final iterates are
+            #  the same trajectory at the level one extra Newton step moves it; a real regression on a rollout fails one of these)
             assert abs(int(it[b]) - st.iters) <= 1
             assert rn[b] < 1e-5 or it[b] == 4
+            r_short = rn[b] if it[b] < st.iters else st.r_norm / core.lay.N
+            assert it[b] == st.iters or 0.95e-5 < r_short < 1e-5, (b, it[b], st.iters, r_short)
+            np.testing.assert_allclose(traj["q"][b], core.traj.q, rtol=0, atol=1e-5)
+            np.testing.assert_allclose(traj["u"][b], core.traj.u, rtol=0, atol=1e-5 * max(1.0, np.abs(core.traj.u).max()))
     assert same >= len(res) - 1
 
 
