@@ -63,6 +63,10 @@ struct Knobs {
     int kkt_twisted = -1;        // CIMPC_KKT_TWISTED: twisted (two-ended) condensed solve, two workgroups per rollout: 0 never, 1 wherever the
                                  // pipelined kernel would run, -1 = 1
     int kkt_tw_nb = 0;           // CIMPC_KKT_TW_NB: rows eliminated from the bottom (0: the default split)
+    int kkt_duo = 1;             // CIMPC_KKT_DUO: 0 = packed one-wave kernel next to the sweep (rounds 2-5), 1 = the duo kernel where it applies
+    int kkt_duo_hint = 20000;    // CIMPC_KKT_DUO_HINT: ... in rounds whose sweep has at most this many problems queued (a shorter launch than the packed recursion)
+    int kkt_duo_max = 256;       // CIMPC_KKT_DUO_MAX: ... for at most this many systems per launch (one workgroup per CU at a time)
+    bool lazy_dz = true;         // CIMPC_LAZY_DZ: 0 = the decision kernel copies the accepted sensitivities itself (rounds 3-5)
     int kkt_tw_spins = 0;        // CIMPC_KKT_TW_SPINS: bound of a chain's wait for its partner, in polls (0: 2^21); tests force the time-out path with 1
     int kkt_tw_max = 120;        // twisted kernel for at most this many rollouts per launch (two workgroups each must be resident together)
     // ---- constants ----
@@ -105,6 +109,10 @@ struct Knobs {
         kkt_twisted = env_int("CIMPC_KKT_TWISTED", kkt_twisted);
         kkt_tw_nb = env_int("CIMPC_KKT_TW_NB", kkt_tw_nb);
         kkt_tw_spins = env_int("CIMPC_KKT_TW_SPINS", kkt_tw_spins);
+        lazy_dz = env_int("CIMPC_LAZY_DZ", 1) != 0;
+        kkt_duo = env_int("CIMPC_KKT_DUO", kkt_duo);
+        kkt_duo_max = env_int("CIMPC_KKT_DUO_MAX", kkt_duo_max);
+        kkt_duo_hint = env_int("CIMPC_KKT_DUO_HINT", kkt_duo_hint);
         generic_static = env_int("CIMPC_GENERIC_STATIC", generic_static ? 1 : 0) != 0;
         sweep_wgs = env_int("CIMPC_SWEEP_WGS", sweep_wgs);
         waves32 = env_int("CIMPC_WAVES32", waves32);
@@ -133,6 +141,7 @@ struct cimpc_ctx {
     int* g_phase = nullptr;
     bool gait_set = false;
     int dz_producer = 0;            // who wrote the per-step sensitivity memory last: 0 nobody, 1 newton_solve (dz_good), 2 implicit_dynamics (slot 0)
+    int* d_good_src = nullptr;      // [B][H] NewtonDev::good_src (in use where the KKT stage is the condensed MFMA solve: select_kkt_backend)
     double* d_dz_knot = nullptr;    // [B][H_ref][nths*nd] per-knot archive, allocated at the first window change that needs it
     int wpk = 1;                 // persistent workgroups of a sweep launch
     double* d_alt = nullptr;
@@ -414,6 +423,9 @@ static void select_kkt_backend(cimpc_ctx* h) {
     h->cf_reduce = !cfg && want != CIMPC_KKT_DENSE_LU && h->cf_tiny &&
                    (velocity ? pick_band_form([&] { return kkt_cf_reduce_available(h->S); }) : kkt_cf_reduce_available(h->S));
     h->use_mixed = want == CIMPC_KKT_CONDENSED_MIXED && !h->use_dense && kkt_mixed_available(h->S);
+    // lazy commit of the accepted sensitivities (NewtonDev::good_src): where every KKT stage is the condensed fp64 MFMA solve
+    // (CIMPC_LAZY_DZ=0 keeps the copy at the accept, for the A/B lines)
+    h->S.good_src = (!h->use_dense && !h->use_mixed && !h->cf_reduce && h->kn.lazy_dz && kkt_lazy_commit_available(h->S)) ? h->d_good_src : nullptr;
 }
 
 int ensure_mixed_ws(cimpc_ctx* h) {
@@ -640,6 +652,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
     AX(&S.d, BS * H * h->nd);
     AX(&S.dz, BS * H * h->nths * h->nd);
     AX(&S.dz_good, B * H * h->nths * h->nd);
+    AX(&h->d_good_src, B * H);
     S.dtn_ld = h->ki.generic ? 0 : h->ki.dtn_ld;
     if (S.dtn_ld > 0) AX(&S.dtn, BS * H * (size_t)S.dtn_ld);
     AX(&S.ip_status, BS * H);
@@ -670,6 +683,10 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         return rc;
     }
     S.Q = h->d_Q; S.R = h->d_R; S.Qinv = h->d_Qinv; S.Rinv = h->d_Rinv; S.Cg = h->d_Cg; S.Cb = h->d_Cb;
+    if (hipMemset(h->d_good_src, 0xFF, B * H * sizeof(int)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {      // -1: every block is in dz_good
+        g_create_error = "hipMemset failed"; cimpc_destroy(h); return CIMPC_ERR_HIP;
+    }
+    S.kkt_scalar = h->kn.kkt_scalar ? 1 : 0;      // (select_kkt_backend reads it)
     S.band_form = h->kn.banded_form;
     S.r_tol = h->nt.r_tol; S.beta_init = h->nt.beta_init; S.kappa = h->nt.kappa; S.max_iter = h->nt.max_iter;
     // all-seven-step-lengths speculation: shortens the chain of rollouts that exhaust their line search; pays
@@ -695,6 +712,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         S.kkt_tw_fail = dv;
     }
     S.kkt_tw_raw = (h->kn.kkt_twisted != 0 && d.B <= h->kn.kkt_tw_max) ? 1 : 0;
+    if (h->kn.kkt_duo == 2 && h->kn.kkt_twisted != 0) S.kkt_tw_raw = 2;      // CIMPC_KKT_DUO=2: the duo kernel at the B1 seam (tests)
     // Overlapped rounds (B >= 64, hybrid schedule): the twisted kernel where EVERY round's KKT set fits the pair bound, i.e. batches
     // of up to 120 rollouts - B = 96: 5.56 -> 4.8-5.1 ms per batch step; with a bound below the batch size the rounds mix kernels
     // and lose (B = 128: 6.04 -> 6.8 ms at 48 / 96; B = 256 and 512 within the noise: profiles/r05/ab_tw_overlap.log).
@@ -1248,6 +1266,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     // end of a solve: statistics, Newton iteration counts, r_norm and u_1 of every rollout in one block, one copy (queued on the
     // solve's stream; the caller synchronises)
     auto finish_results = [&](hipStream_t st) -> int {
+        if (launch_dz_commit(S, st) != CIMPC_OK) return fail(h, CIMPC_ERR_HIP, "sensitivity flush launch failed");
         int rf = launch_solve_finish(S, h->d_result, st);
         if (rf != CIMPC_OK) return fail(h, rf, "result kernel launch failed");
         HIP_TRY(h, hipMemcpyAsync(h->h_result, h->d_result, (8 + (size_t)h->dm.B * (h->dm.nu + 2)) * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1421,7 +1440,20 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         // one-wave recursion (266 us) then outlasts the thinning sweep next to it, the twisted pair (two workgroups per rollout) does not
         if (pipe == 0 && !tw_off && h->kkt_overlap && !blind && h->kn.kkt_twisted != 0 && h->kkt_tw_overlap_max > 0 && n_kkt > 0 && n_kkt <= h->kkt_tw_overlap_max &&
             kkt_twisted_available(Sk)) pipe = 2;
-        if (kkt && pipe == 2 && !h->use_dense && !h->use_mixed && (h->kkt_overlap ? h->kn.kkt_packed : true)) h->n_kkt_twisted++;
+        // Round 6: the rounds' KKT stage NEXT TO the sweep (overlapped rounds, one-wave packed kernel so far) takes the DUO kernel - the
+        // two-ended solve as two one-wave chains in one workgroup, the LDS footprint of the packed kernel's workgroup - while every
+        // system gets a workgroup at once (one per CU): the packed recursion is a chain of H steps, 0.27 - 0.33 ms whatever the
+        // number of systems, and outlasted the sweep in 11 of the 16 rounds of the headline step
+        // ... in the rounds whose sweep is SHORTER than the packed recursion would be (the host knows the problems queued for it: evaluation
+        // slots requested + solves parked; a launch takes about 80 us + 1 us per 112 problems): next to a long sweep the packed kernel is
+        // off the critical path anyway and takes half as many CUs from it (B = 1024: 11.7 -> 12.5 ms with the duo kernel everywhere;
+        // B = 256: 6.46 -> 5.89 ms, B = 512 unchanged)
+        // (the evaluation slots only, not the parked solves: which solves a launch parks depends on timing, and a kernel choice that
+        //  followed it would make the iterates differ from run to run - the two kernels agree to 1e-12, not to the bit)
+        const long long sweep_problems = blind ? -1 : (long long)last_slots * h->dm.H;
+        if (pipe == 0 && !tw_off && h->kkt_overlap && h->kn.kkt_duo != 0 && h->kn.kkt_twisted != 0 && n_kkt > 0 && n_kkt <= h->kn.kkt_duo_max && sweep_problems >= 0 &&
+            sweep_problems <= h->kn.kkt_duo_hint && kkt_duo_available(Sk)) pipe = 3;
+        if (kkt && (pipe == 2 || pipe == 3) && !h->use_dense && !h->use_mixed && (h->kkt_overlap ? h->kn.kkt_packed : true)) h->n_kkt_twisted++;
         if (kkt && !h->kkt_overlap) {   // small batches: latency matters, keep the KKT result in this round
             Sk.kkt_same_round = 1;
             prof_begin(h, PC_KKT, sb.st);

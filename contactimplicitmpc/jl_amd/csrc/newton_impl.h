@@ -722,7 +722,14 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
             resolve_eff(slot, eff);
             __syncthreads();
         }
-        if (use_eff && (blk & 1) == 0) {
+        bool lazy_commit = false;
+        if constexpr (!ASYNC) lazy_commit = S.good_src != nullptr && use_eff;
+        if (lazy_commit) {
+            // Round 6: no copy - the index of the slot that holds each step's block (every entry is -1 = "in dz_good" at this point,
+            // see NewtonDev::good_src); the rollout's next KKT stage, or the flush at the end of the solve, moves the blocks
+            const int* ef = eff + (SPLIT ? 0 : slot * EFF_H);
+            for (int i = tid; i < H; i += nt) S.good_src[(size_t)b * H + i] = ef[i];
+        } else if (use_eff && (blk & 1) == 0) {
             const int* ef = eff + (SPLIT ? 0 : slot * EFF_H);
             const int hb = blk / 2;
             // thirteen independent 16-byte loads in flight per thread before the first store: the quadruped's 6600 pairs move in
@@ -1475,8 +1482,10 @@ constexpr int KKT_TW_TILES = 32;         // 29 + two more slots of the dq0 ring 
 // so that its traces arrive when the top chain reaches row m.  Measured stage times (profiles/r05/twisted_prof_d.log): 16-wide
 // tiles 1.95 us per tick of the top chain against 2.2 of the bottom chain -> nb = (H - 8) / 2; 24-wide tiles (2 x 2 MFMA blocks
 // per product) 7.8 against 10.3 us -> nb = (H - 10) / 2
-__host__ __device__ inline int kkt_tw_split(int H, int nb_override = 0, bool wide = false) {
-    int nb = nb_override > 0 ? nb_override : (H - (wide ? 10 : 8)) / 2;
+// duo (round 6, kkt_kernel_duo): both chains are ONE-wave bodies (stage A + stage B in sequence, ~6.5 us per step) - the bottom chain's
+// two extra products weigh less against a whole step than against a pipelined stage A: nb = (H - 4) / 2
+__host__ __device__ inline int kkt_tw_split(int H, int nb_override = 0, bool wide = false, bool duo = false) {
+    int nb = nb_override > 0 ? nb_override : (H - (duo ? 4 : wide ? 10 : 8)) / 2;
     if (nb < 2) nb = 2;
     if (nb > H - 4) nb = H - 4;
     return H - 2 - nb;
@@ -1517,16 +1526,21 @@ __device__ __forceinline__ void kkt_tw_requeue(const NewtonDev& S, int b, int fi
 // tile leading dimension for a model: 16 (one MFMA block per tile) or 24 (2 x 2 blocks, masked)
 template <int NQ, int NU>
 constexpr int kkt_tld() { return (NQ <= 16 && NU <= 16) ? 16 : 24; }
+constexpr int KKT_SRC_DOUBLES = 64;      // behind the vectors: the rollout's good_src row as 128 ints (H <= kkt_max_h <= 108), see NewtonDev::good_src
 template <int NQ, int NU>
 constexpr int kkt_tw_lds_doubles() {
     constexpr int T = kkt_tld<NQ, NU>();
-    return KKT_TW_TILES * T * T + 13 * (T <= 16 ? 16 : 32);
+    return KKT_TW_TILES * T * T + 13 * (T <= 16 ? 16 : 32) + KKT_SRC_DOUBLES;
 }
+// duo chains (kkt_body<..., PIPE = 1, TW>): physical tiles of a chain's slice - the 20 tiles a one-wave body needs once Y1 / Lc share
+// the tiles of T0 / T1, plus (bottom chain) two more slots of the dq0 ring and Tq
+__host__ __device__ constexpr int kkt_duo_tiles(int tw) { return tw == 2 ? 23 : 20; }
+__host__ __device__ constexpr int kkt_duo_slice_doubles(int tw) { return kkt_duo_tiles(tw) * 256 + 13 * 16 + KKT_SRC_DOUBLES; }
 // doubles of LDS one recursion needs
 template <int NQ, int NU, int PIPE>
 constexpr int kkt_lds_doubles() {
     constexpr int T = kkt_tld<NQ, NU>();
-    return (PIPE == 3 ? KKT_PIPE3_TILES : PIPE == 2 ? KKT_PIPE_TILES : KKT_MFMA_TILES) * T * T + 13 * (T <= 16 ? 16 : 32);
+    return (PIPE == 3 ? KKT_PIPE3_TILES : PIPE == 2 ? KKT_PIPE_TILES : KKT_MFMA_TILES) * T * T + 13 * (T <= 16 ? 16 : 32) + KKT_SRC_DOUBLES;
 }
 // longest horizon the backward pass can stage: all dnu in tiles 16..21, the recovery's first level in tiles 7..15
 template <int NQ, int NU>
@@ -1541,14 +1555,19 @@ constexpr int kkt_pack();
 template <int NQ, int NU, class Sync, int PIPE = 1, bool F32 = false, int TW = 0>
 __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, int b, double* sm, int lane, int wave = 0) {
     static_assert(NQ <= 24 && NU <= 24, "MFMA KKT kernel: tiles of at most 24 x 24");
-    static_assert(TW == 0 || (PIPE == 3 && !F32), "the twisted chains are three-stage pipelines in fp64");
+    static_assert(TW == 0 || ((PIPE == 3 || PIPE == 1) && !F32), "the twisted chains are three-stage pipelines or one-wave bodies, in fp64");
+    // DUO (round 6): the two-ended solve on TWO ONE-WAVE chains that are the two waves of one workgroup (kkt_kernel_duo) - the kernel
+    // that runs next to the sweep, where three-wave chains would take the sweep's CUs.  Same recurrences, same hand-over through the
+    // exchange block; the chains meet at a workgroup barrier at the end and start the line search together.
+    constexpr bool DUO = TW != 0 && PIPE == 1;
+    static_assert(!DUO || kkt_tld<NQ, NU>() == 16, "duo chains: 16-wide tiles (two slices must fit next to a sweep workgroup)");
     constexpr bool REV = TW == 2;                     // bottom chain: chain step i = row H-1-i
     constexpr int TL = kkt_tld<NQ, NU>();            // (shadow the 16-wide defaults of the file scope)
     constexpr int TSZ = TL * TL;
     constexpr int NB = (TL + 15) / 16;
     constexpr int VS = TL <= 16 ? 16 : 32;           // stride of the small vectors behind the tiles
     using Acc = TAcc<NB, F32>;
-    constexpr int NTILES = TW != 0 ? KKT_TW_TILES : PIPE == 3 ? KKT_PIPE3_TILES : PIPE == 2 ? KKT_PIPE_TILES : KKT_MFMA_TILES;
+    constexpr int NTILES = DUO ? kkt_duo_tiles(TW) : TW != 0 ? KKT_TW_TILES : PIPE == 3 ? KKT_PIPE3_TILES : PIPE == 2 ? KKT_PIPE_TILES : KKT_MFMA_TILES;
     // The body runs on ONE wavefront; its phases hand data over through LDS only.  The hand-off needs the
     // wave's LDS operations complete (lgkmcnt(0)) - NOT its global ones: a full barrier (vmcnt(0)) would
     // expose the latency of the prefetch loads and of the factor spill stores at every phase boundary.
@@ -1561,13 +1580,18 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     const cimpc_dims& m = S.dm;
     const int H = m.H;
     // chain geometry: NS stage-A steps, of which the first NF are full steps (factor, y); row(i) = the matrix row of chain step i
-    const int msp = TW != 0 ? kkt_tw_split(H, S.kkt_tw_nb, TL > 16) : 0;       // twisted: middle rows msp, msp + 1
+    const int msp = TW != 0 ? kkt_tw_split(H, S.kkt_tw_nb, TL > 16, DUO) : 0;       // twisted: middle rows msp, msp + 1
     const int nbot = H - msp - 2;                                      // rows the bottom chain eliminates
     const int NS = TW == 1 ? msp + 2 : TW == 2 ? nbot + 2 : H;
     [[maybe_unused]] const int NF = TW == 2 ? nbot : NS;
     auto row = [&](int i) { return REV ? H - 1 - i : i; };
     const int li = lane & 15, lk = lane >> 4;
-    auto tile = [&](int t) { return sm + t * TSZ; };
+    // physical tile of logical tile t.  DUO packs a chain into 20 (top) / 23 (bottom) tiles so that both slices fit the LDS one
+    // packed workgroup takes today: a one-wave body runs stage A and stage B in sequence, so Y1 and Lc (stage B only) share the
+    // tiles of T0 and T1 (stage A only); the pipeline's hand-over tiles 22 .. 28 do not exist; the bottom chain's two extra dq0
+    // ring slots and Tq follow the 20 common tiles
+    auto tix = [](int t) { return !DUO ? t : (t == 7 || t == 8) ? t - 3 : (t >= 9 && t <= 21) ? t - 2 : t >= 29 ? t - 9 : t; };
+    auto tile = [&](int t) { return sm + tix(t) * TSZ; };
     double* A0 = tile(0);                                  // du1_i            nd x nu
     double* A2 = tile(1);                                  // dq0_i            nd x nq   (bottom chain: ring of three, tiles 1, 29, 30)
     // tiles 2,3: dq1 ring (i, i-1)
@@ -1598,13 +1622,24 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     }
 #endif
     for (int k = lane + 64 * wave; k < NTILES * TSZ + 13 * VS; k += 64 * PIPE) sm[k] = 0.0;
-    if constexpr (PIPE >= 2) __syncthreads();
+    // Lazily committed sensitivities (NewtonDev::good_src): row j of the accepted evaluation sits in slot srcs[j] of the rollout's
+    // evaluation slots (-1: in dz_good).  Every row passes through this kernel's registers once - it goes on to dz_good from there.
+    const bool lazy = K.stage != nullptr && K.dz_override == nullptr && S.good_src != nullptr;
+    int* const srcs = reinterpret_cast<int*>(sm + NTILES * TSZ + 13 * VS);
+    if (lazy) for (int k = lane + 64 * wave; k < H; k += 64 * PIPE) srcs[k] = S.good_src[(size_t)b * H + k];
+    if constexpr (PIPE >= 2) __syncthreads(); else lds_sync();
     if (wave == 0) { TWSTAMP(1) }
     const double* rb = K.r + (size_t)b * S.N;
     const double beta = K.beta ? K.beta[b] : K.beta_scalar;
     const double rho = (double)H * beta * S.kappa;         // newton_jacobian.jl:169-186 quirk
     // Newton loop: the accepted evaluation's sensitivities; B1 seam (no stage): slot 0 of the last implicit_dynamics!
     const double* dzb = kkt_dz(S, K, b, H, nths, nd);
+    const double* const dz_slots = S.dz + (size_t)b * CS * H * nths * nd;
+    auto dzrow = [&](int j) -> const double* {      // sensitivities of row j: the slot the accept named, else the resident block
+        const int sl = lazy ? srcs[j] : -1;
+        const size_t off_slot = ((size_t)(sl >= 0 ? sl : 0) * H + j) * (size_t)(nths * nd), off_good = (size_t)j * (nths * nd);
+        return sl >= 0 ? dz_slots + off_slot : dzb + off_good;
+    };
     double* ws = S.kkt_ws + (size_t)b * H * (3 * n2 + nd);
     constexpr int WSR = 3 * n2 + nd;
     auto rec = [&](int i) { return ws + (size_t)row(i) * WSR; };      // record of chain step i (the chains' rows are disjoint)
@@ -1617,6 +1652,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
 
     constexpr int PF_DZ = (nd * nths + 63) / 64, PF_Q = (nq * nq + 63) / 64, PF_R = (nu * nu + 63) / 64;
     double pf_dz[PF_DZ], pf_q[PF_Q], pf_r[PF_R], pf_rp = 0.0, pf_rd = 0.0;
+    int pf_row = -1;                                      // >= 0: the prefetched block came from a slot and goes on to dz_good[row] at commit
     // Per-lane marshalling plan, computed ONCE and branch-free in the loop: which element of a step's
     // operand block this lane moves (k = lane + 64 j, clamped: surplus lanes re-load a valid element) and
     // where it lands in LDS (surplus lanes write a scratch word).  The divisions by nd / nq / nu, the tile
@@ -1638,12 +1674,12 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
 #pragma unroll
     for (int j = 0; j < PF_Q; ++j) {
         const int k = lane + 64 * j, ok = k < nq * nq, kk = ok ? k : 0;
-        q_src[j] = kk; q_dst[j] = ok ? (kk % nq) + (kk / nq) * TL : -1;
+        q_src[j] = kk; q_dst[j] = ok ? (kk % nq) + (kk / nq) * TL : -1;      // (within the ring slot: tile tix(15) + slot)
     }
 #pragma unroll
     for (int j = 0; j < PF_R; ++j) {
         const int k = lane + 64 * j, ok = k < nu * nu, kk = ok ? k : 0;
-        r_src[j] = kk; r_dst[j] = ok ? 18 * TSZ + (kk % nu) + (kk / nu) * TL : TRASH;
+        r_src[j] = kk; r_dst[j] = ok ? tix(18) * TSZ + (kk % nu) + (kk / nu) * TL : TRASH;
     }
     const int rp_src = lane < nr ? lane : 0, rd_src = lane < nd ? lane : 0;
     // (bottom chain: the sensitivities, Rinv, r_p(u), r_d of row j = H-1-i, the weights Qinv and r_p(q) of row j-2 - they enter two
@@ -1651,7 +1687,8 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     auto prefetch = [&](int i) {
         if (i < 0 || i >= NS) return;
         const int j = row(i), jq = REV ? max(j - 2, 0) : j;
-        const double* dzi = dzb + (size_t)j * nths * nd;
+        const double* dzi = dzrow(j);
+        pf_row = (lazy && srcs[j] >= 0) ? j : -1;
 #pragma unroll
         for (int j2 = 0; j2 < PF_DZ; ++j2) pf_dz[j2] = dzi[dz_src[j2]];
 #pragma unroll
@@ -1664,11 +1701,16 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     // registers -> LDS tiles of step i (p0 = i & 1 selects the dq1 ring slot, m0 = i % 3 the dq0 slot of the bottom chain,
     // mq the Qinv / r_p(q) slots: i % 3, bottom chain (i + 2) % 3 = the slot of chain step i + 2)
     auto commit = [&](int p0, int m0, int mq) {
-        const int a2off = REV ? (m0 == 0 ? 0 : (27 + m0) * TSZ) : 0;      // tiles 1, 29, 30
+        const int a2off = REV ? (m0 == 0 ? 0 : (tix(28 + m0) - 1) * TSZ) : 0;      // tiles 1, 29, 30
 #pragma unroll
         for (int j = 0; j < PF_DZ; ++j) sm[dz_dst[j] + p0 * dz_rot[j] + (REV ? dz_rot2[j] * a2off : 0)] = pf_dz[j];
+        if (pf_row >= 0) {      // lazy commit: the block of this step, still in registers, goes on to dz_good (surplus lanes rewrite element 0)
+            double* g = S.dz_good + ((size_t)b * H + pf_row) * (size_t)(nths * nd);
 #pragma unroll
-        for (int j = 0; j < PF_Q; ++j) sm[q_dst[j] >= 0 ? (15 + mq) * TSZ + q_dst[j] : TRASH] = pf_q[j];
+            for (int j = 0; j < PF_DZ; ++j) g[dz_src[j]] = pf_dz[j];
+        }
+#pragma unroll
+        for (int j = 0; j < PF_Q; ++j) sm[q_dst[j] >= 0 ? (tix(15) + mq) * TSZ + q_dst[j] : TRASH] = pf_q[j];
 #pragma unroll
         for (int j = 0; j < PF_R; ++j) sm[r_dst[j]] = pf_r[j];
         // r_p: [u | q2] -> rpu (vec + 5 VS), q ring (vec + (6 + mq) VS)
@@ -1787,7 +1829,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
                 if (j >= 2) s += tile_mv<nq, false, TL>(T2, rq2, lane);
                 bet[lane] = s - rd_i;
             }
-            tile_st<TL, F32>(t.Y0h, y0, li, lk); tile_st<TL, F32>(t.Y1h, y1a, li, lk);
+            if constexpr (PIPE >= 2) { tile_st<TL, F32>(t.Y0h, y0, li, lk); tile_st<TL, F32>(t.Y1h, y1a, li, lk); }
             KPROF(3)
             return;
         }
@@ -1884,6 +1926,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
                 put(xS + n2, tile_mma<KBD, false, TL, F32>(L2c, L2c, z4, li, lk));
                 put(xS + 2 * n2, tile_mma<KBD, false, TL, F32>(L1p, L2c, z4, li, lk));
                 __threadfence();
+                if constexpr (PIPE != 3) stageC(i);      // (one-wave chain: c1 and the flag are this wave's too)
                 return;
             }
         }
@@ -1901,6 +1944,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
             if (i == nbot) {      // trace step of row m+1: S00 = L1 L1^T + L2 L2^T
                 put(xS, tile_mma<KBD, false, TL, F32>(L2c, L2c, tile_mma<KBD, false, TL, F32>(L1c, L1c, z4, li, lk), li, lk));
                 __threadfence();
+                if constexpr (PIPE != 3) stageC(i);
                 return;
             }
         }
@@ -1911,6 +1955,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         if constexpr (!OFFCHAIN) {
             if (lane < nd) {
                 double s = bet[lane];
+                if constexpr (TW == 1) { if (i >= msp) s -= tw_ok ? xc[(msp + 1 - i) * nd + lane] : __builtin_nan(""); }      // c1 (row m), c0 (row m + 1)
                 if (i >= 1) s -= tile_mv<nd, false, TL>(L1c, y1, lane);
                 if (i >= 2) s -= tile_mv<nd, false, TL>(L2c, y2, lane);
                 tv[lane] = s;
@@ -1971,7 +2016,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
             if (wave == 0) {      // preamble of the bottom chain: weights and r_p(q) of rows H-1, H-2 -> ring slots 0, 1 (chain steps 0, 1)
                 for (int k = lane; k < 2 * nq * nq; k += 64) {
                     const int q = k / (nq * nq), e = k - q * nq * nq;
-                    sm[(15 + q) * TSZ + (e % nq) + (e / nq) * TL] = S.Qinv[(size_t)(H - 1 - q) * nq * nq + e];
+                    sm[(tix(15) + q) * TSZ + (e % nq) + (e / nq) * TL] = S.Qinv[(size_t)(H - 1 - q) * nq * nq + e];
                 }
                 for (int k = lane; k < 2 * nq; k += 64) {
                     const int q = k / nq, e = k - q * nq;
@@ -2008,8 +2053,19 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         if constexpr (TW == 0) { if (wave != 0) return; }
         if (wave == 0) { TWSTAMP(2) }
     } else {
+        if constexpr (REV) {      // preamble of the bottom chain (as above): weights and r_p(q) of rows H-1, H-2 -> ring slots 0, 1
+            for (int k = lane; k < 2 * nq * nq; k += 64) {
+                const int q = k / (nq * nq), e = k - q * nq * nq;
+                sm[(tix(15) + q) * TSZ + (e % nq) + (e / nq) * TL] = S.Qinv[(size_t)(H - 1 - q) * nq * nq + e];
+            }
+            for (int k = lane; k < 2 * nq; k += 64) {
+                const int q = k / nq, e = k - q * nq;
+                vec[(6 + q) * VS + e] = rb[(H - 1 - q) * nr + nu + e];
+            }
+            lds_sync();
+        }
         prefetch(0);
-        for (int i = 0; i < H; ++i) {
+        for (int i = 0; i < NS; ++i) {
             stageA(i);
             lds_sync();
             stageB(i);
@@ -2030,8 +2086,8 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
     double* yb = vec;                                 // yhat_i
     double* dn_all = tile(16);                        // [H][16] all dnu (tiles 16..18; H <= 48)
     double* t_all = tile(7);                          // [H][nr] first level of the recovery (tiles 7..)
-    constexpr int RW = TW != 0 ? 3 : 1;                  // waves that share the primal recovery
-    [[maybe_unused]] auto rsync = [&] { if constexpr (TW != 0) __syncthreads(); else lds_sync(); };
+    constexpr int RW = (TW != 0 && !DUO) ? 3 : 1;        // waves that share the primal recovery
+    [[maybe_unused]] auto rsync = [&] { if constexpr (TW != 0 && !DUO) __syncthreads(); else lds_sync(); };
     if (TW == 0 || wave == 0) {                          // ---- the backward pass runs on wave 0 ----
     constexpr int PF_W = (2 * n2 + nd + 63) / 64;
     // The records come from global memory (L2): a load takes ~1 us, a backward step ~0.3 us - the loads run THREE steps ahead
@@ -2045,7 +2101,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         const int k = lane + 64 * j, ok = k < 2 * n2 + nd, kk = ok ? k : 0;
         const int t = kk / n2, e = kk - t * n2, r = e % nd, c = e / nd;
         bw_src[j] = t < 2 ? kk : 3 * n2 + (kk - 2 * n2);
-        bw_dst[j] = !ok ? TRASH : (t == 0) ? r + c * TL : (t == 1) ? 3 * TSZ + r + c * TL : NTILES * TSZ + (kk - 2 * n2);
+        bw_dst[j] = !ok ? TRASH : (t == 0) ? r + c * TL : (t == 1) ? 3 * TSZ + r + c * TL : NTILES * TSZ + (kk - 2 * n2);      // (tiles 0, 3: the same in every packing)
     }
     // chain-local indices: the chain substitutes its steps NBK-1 .. 0 and knows dnu of its steps 0 .. NS-1 afterwards (the bottom
     // chain receives the two middle rows - its steps nbot, nbot + 1 - from the top chain)
@@ -2106,7 +2162,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         const int il = idx / nr, c = idx - il * nr, i = rr0 + il;
         double s = rb[rr0 * nr + idx];
         if (c < nu) {
-            const double* a0 = dzb + ((size_t)i * nths + 2 * nq + c) * nd;
+            const double* a0 = dzrow(i) + (size_t)(2 * nq + c) * nd;
             const double* dn0 = dnl(i);
             double t0 = 0.0;
 #pragma unroll
@@ -2115,8 +2171,8 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         } else {
             const int cq = c - nu;
             const int i1 = min(i + 1, H - 1), i2 = min(i + 2, H - 1);
-            const double* a1 = dzb + ((size_t)i1 * nths + nq + cq) * nd;
-            const double* a2 = dzb + ((size_t)i2 * nths + cq) * nd;
+            const double* a1 = dzrow(i1) + (size_t)(nq + cq) * nd;
+            const double* a2 = dzrow(i2) + (size_t)cq * nd;
             double v1[nd], v2[nd];
 #pragma unroll
             for (int k = 0; k < nd; ++k) { v1[k] = a1[k]; v2[k] = a2[k]; }
@@ -2153,7 +2209,22 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         D[iu * nr + cu] = su;              // (surplus lanes recompute and rewrite row 0: same value, same address)
         D[i * nr + nu + cq] = sq;
     }
-    if constexpr (TW != 0) {      // the three waves' rows are complete (and visible) before wave 0 reports the chain finished
+    // committed: the index goes back to "in dz_good".  Twisted chains reset the rows only THEY read (top: 0 .. m-1, bottom: m+2 .. H-1);
+    // the two middle rows, which both chains stream, are reset by whichever finishes last - a chain that starts late must still
+    // find the index of every row it reads as the accept left it, or as reset AFTER the blocks reached memory (the finish fence)
+    if (lazy) for (int idx = lane + 64 * wave; idx < (TW != 0 ? NS - 2 : NS); idx += 64 * RW) S.good_src[(size_t)b * H + row(idx)] = -1;
+    if constexpr (DUO) {
+        // both chains of the rollout are the two waves of this workgroup: they meet here, and the step is complete in front of both
+        __threadfence_block();
+        __syncthreads();
+        if (lazy && TW == 1 && lane < 2) S.good_src[(size_t)b * H + msp + lane] = -1;      // the middle rows (both chains streamed them)
+        if (__builtin_amdgcn_readfirstlane(aload(xfl + 3)) == S.kkt_tw_epoch) {               // a hand-over timed out (forced in the tests): poisoned numbers
+            if (TW == 1 && lane == 0) kkt_tw_requeue(S, b, K.finish);
+            return;
+        }
+        if (K.finish) start_line_search<BlockSync>(S, b, K.finish, lane + 64 * (TW - 1), 128);
+        return;
+    } else if constexpr (TW != 0) {      // the three waves' rows are complete (and visible) before wave 0 reports the chain finished
         __threadfence_block();
         __syncthreads();
     } else lds_sync();
@@ -2175,6 +2246,7 @@ __device__ __forceinline__ void kkt_body(const NewtonDev& S, const KktArgs& K, i
         if ((int)vec[11 * VS] == 0) return;
         __threadfence();
         if (wave == 0 && lane == 0) astore(xfl + 2, 0);
+        if (lazy && wave == 0 && lane < 2) S.good_src[(size_t)b * H + msp + lane] = -1;      // the middle rows (see above)
         if (__builtin_amdgcn_readfirstlane(aload(xfl + 3)) == S.kkt_tw_epoch) {      // a hand-over of this solve timed out: the numbers are poisoned
             if (wave == 0 && lane == 0) kkt_tw_requeue(S, b, K.finish);
             return;
@@ -2276,6 +2348,38 @@ __global__ __launch_bounds__(192, (kkt_tld<NQ, NU>() <= 16 ? 2 : 1)) void kkt_ke
     const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
     if (((int)blockIdx.x & 1) == 0) kkt_tw_chain<NQ, NU, 2>(ka, b, (lds_double_ptr)sm);
     else kkt_tw_chain<NQ, NU, 1>(ka, b, (lds_double_ptr)sm);
+}
+
+// Duo launch (round 6): ONE workgroup of two wavefronts per rollout - wave 0 runs the bottom chain (kkt_body<..., PIPE = 1, TW = 2>),
+// wave 1 the top chain (TW = 1), each a one-wave body on its own LDS slice (23 + 20 tiles = 90 KB: what the packed kernel's
+// workgroup of two rollouts takes, so one sweep workgroup still fits next to it on the CU).  The kernel for the rounds' KKT stage
+// NEXT TO the sweep: the packed one-wave recursion is a chain of H steps (0.27 - 0.33 ms whatever the number of systems, longer
+// than most sweeps of the late rounds: DESIGN.md section 6), two chains of H / 2 steps are not.  The chains are real functions
+// (own register allocation, see kkt_tw_chain) that end the program; they meet at a workgroup barrier inside kkt_body and start
+// the line search together.  list == nullptr: rollout blockIdx.x + S.b0 (stage filter as kkt_kernel).
+template <int NQ, int NU, int TW>
+static __device__ __attribute__((noinline, noreturn)) void kkt_duo_chain(unsigned long long ka, int b, lds_double_ptr sm3) {
+    const NewtonDev S = kkt_kernarg<NewtonDev, offsetof(KktTwArgs, S)>(ka);
+    const KktArgs K = kkt_kernarg<KktArgs, offsetof(KktTwArgs, K)>(ka);
+    kkt_body<NQ, NU, WaveSync, 1, false, TW>(S, K, b, (double*)sm3, (int)threadIdx.x & 63, 0);
+    __builtin_amdgcn_endpgm();
+}
+template <int NQ, int NU>
+__global__ __launch_bounds__(128, CIMPC_KKT_PACK_WAVES_PER_SIMD) void kkt_kernel_duo(KktTwArgs A) {
+    int n = A.n;
+    if (A.n_dev != nullptr) n = *A.n_dev;
+    const int k = (int)blockIdx.x;
+    if (k >= n) return;
+    const int b = A.list != nullptr ? A.list[k] : k + A.S.b0;
+    if (A.list == nullptr) {
+        if (A.K.stage != nullptr && A.K.stage[b] != STAGE_KKT) return;
+        if (A.K.only_flag != nullptr && A.K.only_flag[b] == 0) return;
+    }
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __builtin_amdgcn_s_setprio(CIMPC_KKT_PRIO);
+    const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    if (((int)threadIdx.x >> 6) == 0) kkt_duo_chain<NQ, NU, 2>(ka, b, (lds_double_ptr)sm);
+    else kkt_duo_chain<NQ, NU, 1>(ka, b, (lds_double_ptr)(sm + kkt_duo_slice_doubles(2)));
 }
 
 // (wide tiles: 105 KB of LDS allow one workgroup per CU anyway - let it use the 512-register budget)

@@ -469,6 +469,37 @@ __global__ __launch_bounds__(256) void solve_finish_kernel(NewtonDev S, double* 
     }
     if (tid < 5) out[tid] = red[tid][0];
 }
+// Flush of the lazily committed sensitivities (NewtonDev::good_src) at the end of a solve: the blocks an accept left in the
+// evaluation slots of a rollout that had no KKT stage afterwards (it converged, ran out of iterations, or the solve was cut
+// short) move to dz_good; afterwards every index is -1 and dz_good is what rounds 3-5 kept at all times.
+__global__ __launch_bounds__(256) void dz_commit_kernel(NewtonDev S) {
+    __shared__ int src[128];
+    const int b = blockIdx.x, tid = threadIdx.x, H = S.dm.H;
+    const int blk = S.nths * S.nd;
+    int any = 0;
+    for (int i = tid; i < H; i += 256) { const int s_ = S.good_src[(size_t)b * H + i]; src[i] = s_; any |= (s_ >= 0); }
+    if (!__syncthreads_or(any)) return;
+    double* good = S.dz_good + (size_t)b * H * blk;
+    const double* slots = S.dz + (size_t)b * CS * H * blk;
+    for (int e = tid; e < H * blk; e += 256) {
+        const int i = e / blk, s_ = src[i];
+        if (s_ >= 0) good[e] = slots[((size_t)s_ * H + i) * blk + (e - i * blk)];
+    }
+    for (int i = tid; i < H; i += 256) if (src[i] >= 0) S.good_src[(size_t)b * H + i] = -1;
+}
+int launch_dz_commit(const NewtonDev& S, hipStream_t s) {
+    if (S.good_src == nullptr) return CIMPC_OK;
+    hipLaunchKernelGGL(dz_commit_kernel, dim3(S.dm.B), dim3(256), 0, s, S);
+    return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+}
+bool kkt_lazy_commit_available(const NewtonDev& S) {      // every KKT stage of the Newton loop runs kkt_body on fp64 tiles (launch_kkt_packed / launch_kkt_t)
+    const int nq = S.dm.nq, nu = S.dm.nu;
+    if (S.dm.mode != CIMPC_MODE_CONFIGURATION || S.kkt_list == nullptr || nq > 24 || nu > 24 || S.dm.H > 96 || S.dm.H > 128 || S.kkt_scalar != 0) return false;
+#define X(q, u) if (nq == q && nu == u) return S.dm.H <= kkt_max_h<q, u>();
+    CIMPC_NQNU(X)
+#undef X
+    return false;
+}
 int launch_solve_finish(const NewtonDev& S, double* out, hipStream_t s) {
     hipLaunchKernelGGL(solve_finish_kernel, dim3(1), dim3(256), 0, s, S, out);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
@@ -498,6 +529,15 @@ static int launch_kkt_packed_t(const NewtonDev& S, const KktArgs& K, const int* 
         // `pipe` (host schedule, CIMPC_KKT_PIPE): where the KKT solve is on the critical path (small batches, chained rounds).
         // Next to a busy sweep the pipelined kernel takes twice the CUs for half the time - measured neutral - so the
         // packed one-wave kernel stays there.
+        if (pipe == 3) {      // duo: one workgroup of two one-wave chains per rollout (16-wide tiles)
+            if constexpr (kkt_tld<NQ, NU>() == 16) {
+                const size_t ldsd = (size_t)(kkt_duo_slice_doubles(1) + kkt_duo_slice_doubles(2)) * sizeof(double);
+                static LdsOptIn optind;
+                if (lds_opt_in(optind, (const void*)kkt_kernel_duo<NQ, NU>, ldsd) != CIMPC_OK) return CIMPC_ERR_HIP;
+                hipLaunchKernelGGL((kkt_kernel_duo<NQ, NU>), dim3(n), dim3(128), ldsd, s, KktTwArgs{S, K, list, n, n_dev});
+                return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
+            } else return CIMPC_ERR_INVALID;
+        }
         if (pipe == 2) {      // twisted: two workgroups of three wavefronts per rollout, one chain from either end
             const size_t lds3 = (size_t)kkt_tw_lds_doubles<NQ, NU>() * sizeof(double);
             static LdsOptIn optin3;
@@ -685,6 +725,10 @@ bool kkt_twisted_available(const NewtonDev& S) {      // MFMA tiles, a horizon l
     return kkt_condensed_available(S);
 }
 
+bool kkt_duo_available(const NewtonDev& S) {      // the twisted solve's conditions on 16-wide tiles
+    return S.dm.nq <= 16 && S.dm.nu <= 16 && kkt_twisted_available(S);
+}
+
 bool kkt_condensed_available(const NewtonDev& S) {      // a compiled condensed solve exists for these (nq, nu)
     const int nq = S.dm.nq, nu = S.dm.nu;
 #define X(q, u) if (nq == q && nu == u) return true;
@@ -718,6 +762,13 @@ static int launch_kkt_twisted_t(const NewtonDev& S, const KktArgs& K, hipStream_
 int launch_kkt_raw(const NewtonDev& S, const double* r_dev, double beta, double* delta_dev,
                    hipStream_t s) {
     KktArgs K{r_dev, delta_dev, nullptr, beta, nullptr, 0};
+    if (S.kkt_tw_raw == 2 && kkt_duo_available(S)) {      // (CIMPC_KKT_DUO=2: the duo kernel at the B1 seam too - the parity tests reach it in isolation here)
+        const int nq = S.dm.nq, nu = S.dm.nu;
+        const int* list = nullptr;
+#define X(q, u) if (nq == q && nu == u) return launch_kkt_packed_t<q, u>(S, K, list, S.nb_launch, nullptr, s, 3);
+        CIMPC_NQNU(X)
+#undef X
+    }
     if (S.kkt_tw_raw != 0 && kkt_twisted_available(S)) {      // a lone solve is latency-bound: two chains from either end
         const int nq = S.dm.nq, nu = S.dm.nu;
 #define X(q, u) if (nq == q && nu == u) return launch_kkt_twisted_t<q, u>(S, K, s);

@@ -39,6 +39,14 @@ struct NewtonDev {
     double* dz_good;   // [B][H][nths][nd]  sensitivities of the rollout's ACCEPTED evaluation (the reference's ip[t].dz
                        // after the last accepted implicit_dynamics!): Jacobian data of the KKT stage and the value a
                        // failed solve falls back to (see dz_eff in newton_impl.h)
+    // Round 6: the copy into dz_good is LAZY where the KKT stage is the condensed MFMA solve (good_src != null).  An accept records, per
+    // step, WHICH slot holds the block (good_src[b][i] = slot, -1 = dz_good itself); the KKT kernel that follows - it streams every
+    // block of the rollout through its registers anyway - reads through the index and writes the blocks to dz_good on its way
+    // (fire-and-forget stores off the recursion's chain), then resets the index.  Invariant: outside a rollout's window
+    // [accept, end of its next KKT stage] every entry is -1; dz_commit_kernel flushes what a solve leaves behind at its end
+    // (rollouts that finished without another KKT stage).  The decision kernel's accepting blocks - the slowest of every round -
+    // no longer move 105 KB each.
+    int* good_src;     // [B][H] or null (copy at the accept, as rounds 3-5)
     int* ip_status;    // [B*CS][H]
     int* ip_iters;     // [B*CS][H]
     int* pflag;        // [B*CS][H] resumable-solve flags (see IpParams)
@@ -123,6 +131,8 @@ struct GaitDev {
 };
 int launch_gait_window(const NewtonDev& S, const GaitDev& G, int* window, int advance, hipStream_t s);
 int launch_reset(const NewtonDev& nd, const double* q0, const double* q1, int warm, hipStream_t s);
+int launch_dz_commit(const NewtonDev& nd, hipStream_t s);      // flush of the lazily committed sensitivities (no-op without good_src)
+bool kkt_lazy_commit_available(const NewtonDev& nd);            // every KKT stage of these dimensions runs kkt_body (fp64 tiles)
 int launch_dz_rekey(const NewtonDev& nd, double* knot, const int* window, int which, int dir, hipStream_t s);
 int launch_resid_decide(const NewtonDev& nd, hipStream_t s, int n_slots = -1, int phase = 0);   // n_slots: entries of slot_list[WQ.par] (-1: every (rollout, slot) pair gets a block)
 int launch_enqueue_all(const NewtonDev& nd, hipStream_t s);   // B3 seam: queue slot 0 of every rollout
@@ -134,9 +144,11 @@ size_t kkt_mixed_workspace_doubles(const NewtonDev& nd);
 int launch_kkt_mixed_newton(const NewtonDev& nd, double* ws, int* n_fallback, hipStream_t s);
 int launch_kkt_mixed_raw(const NewtonDev& nd, const double* r_dev, double beta, double* delta_dev, double* ws, int* n_fallback, hipStream_t s);
 // packed variant: n_kkt rollouts from kkt_list[list_par], KKT_PACK per workgroup (dedicates whole CUs to the recursion)
-// (pipe: 0 packed one-wave kernel, 1 three-wave pipeline, 2 twisted = two three-wave chains per rollout, -1 by kkt_same_round)
+// (pipe: 0 packed one-wave kernel, 1 three-wave pipeline, 2 twisted = two three-wave chains per rollout, 3 duo = two one-wave chains in one
+//  workgroup, -1 by kkt_same_round)
 int launch_kkt_packed(const NewtonDev& nd, int n_kkt, int list_par, hipStream_t s, const int* n_dev = nullptr, int pipe = -1);
 bool kkt_twisted_available(const NewtonDev& nd);
+bool kkt_duo_available(const NewtonDev& nd);      // ... as one workgroup of two one-wave chains (pipe = 3): next to the sweep
 int launch_queue_recycle(const IpQueues& Q, int par, hipStream_t s);
 int launch_solve_finish(const NewtonDev& nd, double* out, hipStream_t s);   // end-of-solve result block, see solve_finish_kernel
 // reference-default backend (dense jacobian! + LU with partial pivoting), any mode / objective (kkt_dense.hip)

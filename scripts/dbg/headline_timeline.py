@@ -11,7 +11,7 @@ which = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 
 def short(n):
     n = n.split("(")[0]
-    for k in ("ip_queue_kernel", "kkt_kernel_packed", "kkt_kernel_twisted", "kkt_kernel_pipe", "kkt_kernel_two", "resid_slot_kernel", "resid_decide_kernel",
+    for k in ("ip_queue_kernel", "kkt_kernel_packed", "kkt_kernel_twisted", "kkt_kernel_pipe", "kkt_kernel_duo", "resid_slot_kernel", "resid_decide_kernel",
               "newton_async_kernel", "reset_kernel", "solve_finish_kernel", "async_handoff", "dz_commit"):
         if k in n:
             return k

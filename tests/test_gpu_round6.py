@@ -172,3 +172,140 @@ def test_twisted_banded_timeout_falls_back(monkeypatch):
         s.close()
     assert np.array_equal(out[0][1], out[1][1])
     np.testing.assert_allclose(out[1][0], out[0][0], rtol=0, atol=1e-9 * max(1.0, np.abs(out[0][0]).max()))
+
+
+# ---- lazy commit of the accepted sensitivities (NewtonDev::good_src) --------------------------------------------------------------
+@pytest.mark.parametrize("B,H,H_ref,ip_iter", [(1, 28, 30, 100), (3, 12, 14, 6), (96, 24, 26, 7), (160, 24, 26, 7)])
+def test_lazy_sensitivity_commit_is_bit_identical_to_the_copy(monkeypatch, B, H, H_ref, ip_iter):
+    """Round 6: an accept records WHICH slot holds each step's sensitivities and the next KKT stage moves the blocks (or the flush
+    at the end of the solve) instead of the decision kernel copying 105 KB per accepting rollout.  The numbers must not change at
+    all: same solves, same stale-sensitivity rule (a failed interior-point solve falls back to the block of the knot's last
+    successful one - forced here with a budget of 6-7 interior-point iterations), on one rollout, a small batch, the twisted /
+    overlapped rounds (B = 96) and the hybrid schedule (B = 160); then a warm-started solve and the B1 / B3 seams on the state
+    the solve left (dz_good must be complete again after the flush)."""
+    from contactimplicitmpc.jl_amd import InteriorPointOptions, NewtonOptions
+    d, prob, tabs, rollouts = make_case("quadruped", 0, H_ref=H_ref, H=H, B=B, seed=9, perturb=3e-2)
+    obj = synth.make_objective(d, H)
+    q0 = np.stack([r[2] for r in rollouts]); q1 = np.stack([r[3] for r in rollouts])
+    res = {}
+    for lazy in (0, 1):
+        monkeypatch.setenv("CIMPC_LAZY_DZ", str(lazy))
+        s = make_solver(d, prob, rollouts, H, obj=obj, ip_opts=InteriorPointOptions(kappa_tol=prob["kappa"], max_iter=ip_iter),
+                        newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=1e-7, max_iter=4))
+        a = s.newton_solve(q0, q1)
+        ta = s.trajectory()
+        fails = int(s.rollout_counters()["ip_failures"].sum())
+        b = s.newton_solve(q1, ta["q"][:, 2].copy(), warm_start=True)
+        tb = s.trajectory()
+        r = np.random.default_rng(1).standard_normal((B, s.N))
+        k = s.kkt_solve(r, 10.0) if False else None        # (B1 needs B3 on the handle first: below)
+        out = s.implicit_dynamics(tb["q"], np.stack([ro.theta for (_, ro, _, _) in rollouts]))
+        k = s.kkt_solve(r, 10.0)
+        c = s.newton_solve(q0, q1, warm_start=True)         # B4 after B3: dz_good <- slot 0 hand-over, then the lazy path again
+        res[lazy] = (a, ta, b, tb, out, k, c, fails)
+        s.close()
+    (a0, ta0, b0, tb0, o0, k0, c0, f0), (a1, ta1, b1, tb1, o1, k1, c1, f1) = res[0], res[1]
+    if ip_iter < 100:
+        assert f0 > 0, "no failing interior-point solve: the stale-sensitivity rule is not exercised"
+    for x, y in ((a0, a1), (b0, b1), (c0, c1)):
+        assert np.array_equal(x[1], y[1]) and np.array_equal(x[0], y[0]) and np.array_equal(x[2], y[2])
+    for f in ("q", "u", "nu"):
+        assert np.array_equal(ta0[f], ta1[f]) and np.array_equal(tb0[f], tb1[f])
+    assert np.array_equal(k0, k1) and np.array_equal(o0["dq0"], o1["dq0"]) and f0 == f1
+
+
+# ---- duo KKT kernel: the two-ended condensed solve as two one-wave chains in one workgroup (kkt_kernel_duo) ------------------------
+def _duo_solve(monkeypatch, duo, d, prob, rollouts, obj, H, r, betas, nb=None):
+    monkeypatch.setenv("CIMPC_KKT_TWISTED", "1" if duo else "0")
+    monkeypatch.setenv("CIMPC_KKT_DUO", "2" if duo else "0")      # 2: the duo kernel at the B1 seam too
+    if nb is not None:
+        monkeypatch.setenv("CIMPC_KKT_TW_NB", str(nb))
+    else:
+        monkeypatch.delenv("CIMPC_KKT_TW_NB", raising=False)
+    s = make_solver(d, prob, rollouts, H, obj=obj)
+    q = np.stack([ro.q for (_, ro, _, _) in rollouts]); th = np.stack([ro.theta for (_, ro, _, _) in rollouts])
+    out = s.implicit_dynamics(q, th)
+    deltas = {beta: s.kkt_solve(r, beta) for beta in betas}
+    n_tw = s.kkt_twisted()
+    s.close()
+    return out, deltas, n_tw
+
+
+@pytest.mark.parametrize("model,H,H_ref,B", [("quadruped", 40, 60, 5), ("hopper", 24, 30, 3), ("flamingo", 30, 36, 2), ("particle", 26, 30, 2)])
+def test_duo_kkt_vs_dense_lu(monkeypatch, model, H, H_ref, B):
+    """B1 seam through the duo kernel (two one-wave chains in one workgroup, the recurrences of
+    /root/reference/src/controller/newton_structure_solver/methods.jl:466-557 from both ends) against numpy's dense LU of the
+    oracle's `jacobian!` matrix: 1e-10 of the solution's scale at beta = 10, the one-ended kernel's own level at the cold start's
+    beta = 1e-5 (cond > 1e8)."""
+    from oracle import newton as onewton
+    d, prob, rollouts, obj = _tw_case(model, H, H_ref, B)
+    lay = onewton.Layout(d, H)
+    r = np.random.default_rng(0).standard_normal((B, lay.N))
+    betas = (1e-5, 1e-2, 10.0)
+    out1, one, n1 = _duo_solve(monkeypatch, False, d, prob, rollouts, obj, H, r, betas)
+    out2, two, n2 = _duo_solve(monkeypatch, True, d, prob, rollouts, obj, H, r, betas)
+    assert n1 == 0 and n2 == len(betas)
+    for beta in betas:
+        for b in range(B):
+            im = {k: out2[k][b] for k in ("d", "dq0", "dq1", "du1")}
+            x = np.linalg.solve(onewton.jacobian(lay, obj, im, beta, prob["kappa"]), r[b])
+            sc = max(1.0, np.abs(x).max())
+            assert np.isfinite(two[beta][b]).all()
+            e1 = np.abs(one[beta][b] - x).max() / sc
+            e2 = np.abs(two[beta][b] - x).max() / sc
+            assert e2 <= (1e-10 if beta >= 1.0 else 1e-7), (beta, b, e2)
+            assert e2 <= max(4.0 * e1, 1e-12), (beta, b, e1, e2)
+
+
+def test_duo_kkt_every_split(monkeypatch):
+    from oracle import newton as onewton
+    H, H_ref, B = 26, 30, 2
+    d, prob, rollouts, obj = _tw_case("quadruped", H, H_ref, B)
+    lay = onewton.Layout(d, H)
+    r = np.random.default_rng(1).standard_normal((B, lay.N))
+    for nb in list(range(2, 8)) + list(range(H - 9, H - 3)):
+        out, two, n = _duo_solve(monkeypatch, True, d, prob, rollouts, obj, H, r, (10.0,), nb=nb)
+        assert n == 1
+        for b in range(B):
+            im = {k: out[k][b] for k in ("d", "dq0", "dq1", "du1")}
+            x = np.linalg.solve(onewton.jacobian(lay, obj, im, 10.0, prob["kappa"]), r[b])
+            np.testing.assert_allclose(two[10.0][b], x, rtol=0, atol=1e-10 * max(1.0, np.abs(x).max()), err_msg=f"nb = {nb}")
+
+
+@pytest.mark.parametrize("B", [96, 200])
+def test_newton_solve_duo_vs_packed_in_overlapped_rounds(monkeypatch, B):
+    """newton_solve! of a batch whose rounds run the KKT stage next to the sweep (B >= 64, lock-step / hybrid): duo kernel against
+    the packed one-wave kernel - same Newton iterations on (nearly) every rollout, controls equal where the discrete paths agree."""
+    from contactimplicitmpc.jl_amd import NewtonOptions
+    H, H_ref = 28, 30
+    d, prob, tabs, rollouts = make_case("quadruped", 0, H_ref=H_ref, H=H, B=B, seed=13, perturb=5e-3)
+    obj = synth.make_objective(d, H)
+    q0 = np.stack([r[2] for r in rollouts]); q1 = np.stack([r[3] for r in rollouts])
+    res = {}
+    for duo in (0, 1):
+        monkeypatch.setenv("CIMPC_KKT_DUO", str(duo))
+        monkeypatch.setenv("CIMPC_KKT_TWISTED", "2" if duo else "0")      # (2: the three-wave twisted kernel stays out of the overlapped rounds)
+        s = make_solver(d, prob, rollouts, H, obj=obj, newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=1e-5, max_iter=4))
+        u1, it, rn = s.newton_solve(q0, q1)
+        cnt = s.rollout_counters()
+        res[duo] = (u1, it, rn, cnt, s.kkt_twisted())
+        s.close()
+    a, b = res[0], res[1]
+    assert a[4] == 0 and b[4] > 0, (a[4], b[4])
+    assert np.isfinite(b[0]).all()
+    # Two KKT solves 1e-12 apart: a cold solve of this synthetic batch is hundreds of interior-point solves deep and most rollouts
+    # leave the other run's discrete path somewhere (DESIGN.md section 2: the ORACLE leaves its own path on 90 % of such rollouts
+    # under 1-ulp input noise).  On the same path the controls agree; off it both runs must be solutions of the same quality, and
+    # the batch statistics must not move.
+    same = close_it = close_r = 0
+    for k in range(B):
+        if a[1][k] == b[1][k] and a[3]["sweeps"][k] == b[3]["sweeps"][k] and a[3]["ip_iters"][k] == b[3]["ip_iters"][k]:
+            same += 1
+            np.testing.assert_allclose(b[0][k], a[0][k], rtol=0, atol=5e-4 * max(1.0, np.abs(a[0][k]).max()))
+        close_it += int(abs(int(a[1][k]) - int(b[1][k])) <= 1)
+        close_r += int(b[2][k] <= 4.0 * a[2][k] + 1e-9 and a[2][k] <= 4.0 * b[2][k] + 1e-9)
+    assert same >= 0.2 * B, (same, B)
+    assert close_it >= 0.95 * B and close_r >= 0.9 * B, (close_it, close_r, B)
+    assert abs(int((a[2] < 1e-5).sum()) - int((b[2] < 1e-5).sum())) <= max(2, B // 10)
+    assert abs(float(a[3]["sweeps"].mean()) - float(b[3]["sweeps"].mean())) <= 0.05 * float(a[3]["sweeps"].mean())
+    assert abs(np.median(a[2]) / np.median(b[2]) - 1.0) < 0.25
