@@ -76,7 +76,16 @@ struct Model {
     static constexpr int SENS_ILP = (NX <= 16 && NY <= 16) ? CIMPC_SENS_ILP : CIMPC_SENS_ILP32;   // sensitivity columns solved side by side
     // per-problem LDS: the R tile and theta - theta0 SHARE their space (theta - theta0 lives from the pull of a problem to the two
     // dot products a few lines below it; the tile is scratch inside factorize), then the backlog of deferred sensitivities
-    static constexpr int TILE = RROWS * RST_LD > NTH ? RROWS * RST_LD : NTH;
+    // Round 6: the throughput build of the 32-lane models keeps R IN LDS for the whole solve - the strict upper triangle
+    // packed by column (entry (r, c), r < c, at c (c - 1) / 2 + r: NY (NY - 1) / 2 = 276 doubles for ny = 24, the size of the row window
+    // it replaces) - and the back-substitutions read their row entry per step from there.  The 24 row registers per lane were what
+    // the 256-register budget spilled: 466 MB of scratch writes per launch, 8-10 x the algorithmic traffic.  Adjoint models only
+    // (:configuration): there the tile is free for R during the solves (the transposed-solve results travel through the staging
+    // vectors, the columns of the product phase are parked in the tile AFTER the last solve).
+    static constexpr bool RLDS = !FULL_TILE && ADJ != 0;
+    static constexpr int RTRI = NY * (NY - 1) / 2;
+    static constexpr int TILE0 = RLDS ? RTRI : RROWS * RST_LD;
+    static constexpr int TILE = TILE0 > NTH ? TILE0 : NTH;
     // ... then one 64-bit word per group: the clock value the running solve's time budget counts from (IpParams::budget_ticks)
     // ... then (32-lane groups) three staging vectors of G doubles: one for lane-indexed vectors that feed a matrix-vector
     // product, two (by step parity) for the column the MGS step broadcasts - IpSolver::stage / factorize
@@ -112,6 +121,7 @@ struct IpSolver {
     double* Rst;         // LDS: [NY][G+1] R-factor transpose tile of this problem
     double* bv;          // LDS (32-lane groups): staging vectors [3][G], see stage() / factorize()
     int l;               // lane within the group
+    int csl;             // (RLDS) start of column l of the packed R triangle: l (l - 1) / 2
     bool vx, vy;
     // per-lane constants of the knot
     double ry2, ry1d, caibd, rdyn0, rrst0, x0, y10, y20;
@@ -125,6 +135,7 @@ struct IpSolver {
     __device__ __forceinline__ void bind(const double* tab_, double* Rst_, int l_) {
         tab = tab_; Rst = Rst_; l = l_;
         bv = Rst_ + M::OFF_BV;
+        csl = l_ * (l_ - 1) / 2;
         vx = l < NX; vy = l < NY;
         const double* tVec = tab + L.oVec;
         ry2 = tVec[LinLayout::V_RY2 * G + l];
@@ -253,7 +264,9 @@ struct IpSolver {
                     if (lq == k + 1) static_for<0, NY>([&](auto ic) { constexpr int r = decltype(ic)::value; dst[r] = Qc[r]; });
                 }
             }
-            if constexpr (M::FULL_TILE) {
+            if constexpr (M::RLDS) {
+                if ((lq > k) && vy) Rst[csl + k] = nrk;      // -R[k,l] -> column l, position k of the packed triangle (stays in LDS)
+            } else if constexpr (M::FULL_TILE) {
                 Rst[k * M::RST_LD + l] = nrk;  // -R[k,l], l > k (zeros elsewhere)
             } else {
                 // window of RROWS rows: row k goes to slot k % RROWS; when the window is full (or the factorization ends) the
@@ -270,7 +283,9 @@ struct IpSolver {
                 }
             }
         });
-        if constexpr (M::FULL_TILE) {
+        if constexpr (M::RLDS) {
+            wave_lds_fence();                  // the triangle is complete: the back-substitutions read it (r_entry)
+        } else if constexpr (M::FULL_TILE) {
             wave_lds_fence();
             static_for<0, NY>([&](auto kc) {   // row l of R (transpose through the LDS tile)
                 constexpr int k = decltype(kc)::value;
@@ -280,6 +295,16 @@ struct IpSolver {
         } else {
             if (!vy) static_for<0, NY>([&](auto kc) { Rr[decltype(kc)::value] = 0.0; });     // (lanes beyond NY own no row)
         }
+    }
+
+    // -R[l, K] as the back-substitution adds it (zero for K <= l): the row register, or (RLDS) the packed triangle in LDS - lanes
+    // l < K read K consecutive doubles of column K
+    template <int K>
+    __device__ __forceinline__ double r_entry() const {
+        if constexpr (M::RLDS) {
+            const double v = Rst[K * (K - 1) / 2 + ((l < K) ? l : 0)];
+            return (l < K) ? v : -0.0;
+        } else return Rr[K];
     }
 
     // t = R^-1 Q^T rhs  (qr_solve!, qr.jl:142-158); rhs lane-indexed
@@ -304,7 +329,7 @@ struct IpSolver {
             static_rfor<NY - 1>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 const double xk = LG::template bcast<k>(c * rdinv);
-                c = fma(Rr[k], xk, c);
+                c = fma(r_entry<k>(), xk, c);
             });
         }
         return c * rdinv;
@@ -372,10 +397,11 @@ struct IpSolver {
         static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; c[j] = ((a[j][0] + a[j][1]) + (a[j][2] + a[j][3])) * rdinv; });
         static_rfor<NY - 1>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
+            const double rk = r_entry<k>();
             static_for<0, N>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 const double xk = LG::template bcast<k>(c[j] * rdinv);
-                c[j] = fma(Rr[k], xk, c[j]);
+                c[j] = fma(rk, xk, c[j]);
             });
         });
         static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; t[j] = c[j] * rdinv; });
@@ -417,8 +443,32 @@ struct IpSolver {
         else qr_solve_n<N>(b, z);
         static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; dst[j * M::RST_LD + l] = z[j]; });
     }
+    // (RLDS: the tile holds R during the solves - a trip's rows go to their owner lanes through the staging vectors instead)
+    template <int N>
+    __device__ __forceinline__ void adjoint_trip(int i0, double (&A2)[NY]) const {
+        const double* tB = tab + L.oAiB + i0 * NY + (vy ? l : 0);
+        double b[N], z[N];
+        static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; b[j] = vy ? tB[j * NY] : 0.0; });
+        qr_solve_n<N>(b, z);
+        wave_lds_fence();
+        static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; bv[j * G + l] = z[j]; });
+        wave_lds_fence();
+        const int j = l - i0;
+        if (j >= 0 && j < N) {
+            const double* row = bv + j * G;
+            static_for<0, NY>([&](auto kc) { constexpr int k = decltype(kc)::value; A2[k] = row[k]; });
+        }
+    }
     __device__ __forceinline__ void adjoint_factor(double (&A2)[NY]) const {
         constexpr int AIL = M::ADJ_ILP;      // solves side by side (32-lane groups: one staging vector each)
+        if constexpr (M::RLDS) {
+            static_for<0, NY>([&](auto kc) { A2[decltype(kc)::value] = 0.0; });
+#pragma unroll 1
+            for (int i0 = 0; i0 + AIL <= NX; i0 += AIL) adjoint_trip<AIL>(i0, A2);
+            if constexpr (NX % AIL != 0) adjoint_trip<NX % AIL>((NX / AIL) * AIL, A2);
+            wave_lds_fence();
+            return;
+        }
         static_for<0, (NX + M::RROWS - 1) / M::RROWS>([&](auto pc) {
             constexpr int r0 = decltype(pc)::value * M::RROWS, n = NX - r0 < M::RROWS ? NX - r0 : M::RROWS;
             wave_lds_fence();
