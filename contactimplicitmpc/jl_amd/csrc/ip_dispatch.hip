@@ -1,7 +1,8 @@
 // Dimension dispatch of the interior-point sweep kernel: one instantiation per model of the reference
 // (src/dynamics/*/model.jl; point_foot_quadruped and centroidal_quadruped_box share the centroidal dimensions).
 // A further model is ONE line here + a five-line ip_model_<name>.hip + its (nq, nu) pair in newton_kernels.hip
-// (CIMPC_NQNU).  Not covered: centroidal_quadruped_wall (ny = 48 exceeds the 32-lane group).
+// (CIMPC_NQNU).  centroidal_quadruped_wall (ny = 48 exceeds the 32-lane group) has a 64-lane instantiation - one problem per
+// wavefront, :configuration mode only (CIMPC_MODELS64, round 6); its :configurationforce mode keeps the runtime-dimension kernel.
 #include "newton_state.h"
 
 namespace cimpc {
@@ -17,12 +18,21 @@ namespace cimpc {
     X(particle, 3, 3, 3, 1, 4)               \
     X(particle2d, 2, 2, 2, 1, 2)
 
+#define CIMPC_MODELS64(X)                    \
+    X(centroidal_wall, 18, 12, 3, 8, 32)
+
 #define X(name, q, u, w, c, b)                                                               \
     int ip_launch_##name(int mode, const IpParams& p, int waves, hipStream_t s);   \
     int ip_callback_##name(int mode, const IpCallbackArgs& a, hipStream_t s);      \
     void ip_info_##name(int mode, KernelInfo* info);
 CIMPC_MODELS(X)
 #undef X
+#define X(name, q, u, w, c, b)                                                               \
+    int ip_launch_##name(int mode, const IpParams& p, int waves, hipStream_t s);   \
+    void ip_info_##name(int mode, KernelInfo* info);
+CIMPC_MODELS64(X)
+#undef X
+#define CIMPC_IS64(dm, q, u, w, c, b) ((dm)->mode == CIMPC_MODE_CONFIGURATION && (dm)->nq == q && (dm)->nu == u && (dm)->nw == w && (dm)->nc == c && (dm)->nb == b)
 
 int ip_kernel_info(const cimpc_dims* dm, KernelInfo* info) {
 #define X(name, q, u, w, c, b)                                                          \
@@ -32,6 +42,10 @@ int ip_kernel_info(const cimpc_dims* dm, KernelInfo* info) {
         return CIMPC_OK;                                                                \
     }
     CIMPC_MODELS(X)
+#undef X
+#define X(name, q, u, w, c, b)                                                          \
+    if (CIMPC_IS64(dm, q, u, w, c, b)) { ip_info_##name(dm->mode, info); info->generic = 0; return CIMPC_OK; }
+    CIMPC_MODELS64(X)
 #undef X
     if (ip_generic_available(dm)) {      // any other model with nx, ny <= 64: runtime-dimension kernel
         ip_generic_info(dm, info);
@@ -46,6 +60,9 @@ int launch_ip_sweep(const cimpc_dims* dm, const IpParams& p, int waves, hipStrea
     if (dm->nq == q && dm->nu == u && dm->nw == w && dm->nc == c && dm->nb == b)        \
         return ip_launch_##name(dm->mode, p, waves, s);
     CIMPC_MODELS(X)
+#undef X
+#define X(name, q, u, w, c, b) if (CIMPC_IS64(dm, q, u, w, c, b)) return ip_launch_##name(dm->mode, p, waves, s);
+    CIMPC_MODELS64(X)
 #undef X
     return launch_ip_generic(dm, p, s);
 }

@@ -48,14 +48,14 @@ struct Model {
     static constexpr int NX = NQ, NY = 2 * NC + NB, NZ = NQ + 4 * NC + 2 * NB;
     static constexpr int NTH = 2 * NQ + NU + NW + 2, NTHS = 2 * NQ + NU;
     static constexpr int ND = MODE ? NQ + NC + NB : NQ;
-    static constexpr int G = (NX <= 16 && NY <= 16) ? 16 : 32;
-    static_assert(NX <= 32 && NY <= 32, "lane group holds at most 32 rows");
+    static constexpr int G = (NX <= 16 && NY <= 16) ? 16 : (NX <= 32 && NY <= 32) ? 32 : 64;
+    static_assert(NX <= 64 && NY <= 64, "lane group holds at most 64 rows");
     // R-factor transposition buffer: lane = column produces row k of R at step k, lane l needs row l in its registers.
     // The whole [NY][G + 1] tile (conflict-free at stride G + 1), read back once at the end - except in the throughput build of the
     // 32-lane models (WIDE, round 4): a window of RROWS = 8 rows at stride 34 (16-byte aligned rows for ds_read_b128), read back by
     // its eight owner lanes every eight steps - 2.2 KB instead of 8.4 KB per problem, which is what lets a workgroup hold 16
     // problems (8 waves = two per SIMD) next to the 85 KB table of the centroidal model.
-    static constexpr bool FULL_TILE = !(WIDE && !(NX <= 16 && NY <= 16));
+    static constexpr bool FULL_TILE = !(WIDE && !(NX <= 16 && NY <= 16)) && G != 64;      // (64-lane groups: R packed in LDS, see RLDS)
     static constexpr int RROWS = FULL_TILE ? NY : 8;
     static constexpr int RST_LD = FULL_TILE ? G + 1 : G + 2;   // padded row stride of the R tile
     static constexpr int DTN_LD = ((NTHS + G - 1) / G) * G;    // leading dimension of the delta^T nu products (IpParams::dtn)
@@ -83,6 +83,7 @@ struct Model {
     // (:configuration): there the tile is free for R during the solves (the transposed-solve results travel through the staging
     // vectors, the columns of the product phase are parked in the tile AFTER the last solve).
     static constexpr bool RLDS = !FULL_TILE && ADJ != 0;
+    static_assert(G != 64 || RLDS, "64-lane groups: :configuration mode only (the adjoint sensitivity pass keeps the tile free for R)");
     static constexpr int RTRI = NY * (NY - 1) / 2;
     static constexpr int TILE0 = RLDS ? RTRI : RROWS * RST_LD;
     static constexpr int TILE = TILE0 > NTH ? TILE0 : NTH;
@@ -118,6 +119,7 @@ struct IpSolver {
     using LG = LaneGroup<G>;
 
     const double* tab;   // LDS: staged linearization table
+    const double* ctab;  // the blocks a solve touches once (LinLayout::hot): = tab, or (64-lane models) the table in global memory
     double* Rst;         // LDS: [NY][G+1] R-factor transpose tile of this problem
     double* bv;          // LDS (32-lane groups): staging vectors [3][G], see stage() / factorize()
     int l;               // lane within the group
@@ -132,12 +134,13 @@ struct IpSolver {
     // factorization: column l of Q, row l of -R (strict upper part), 1/R[l,l], regularised y, 1/y1r
     double Qc[NY], Rr[NY], rdinv, y1r, y2r, iy1r;
 
-    __device__ __forceinline__ void bind(const double* tab_, double* Rst_, int l_) {
+    __device__ __forceinline__ void bind(const double* tab_, double* Rst_, int l_, const double* ctab_ = nullptr) {
         tab = tab_; Rst = Rst_; l = l_;
+        ctab = ctab_ != nullptr ? ctab_ : tab_;
         bv = Rst_ + M::OFF_BV;
         csl = l_ * (l_ - 1) / 2;
         vx = l < NX; vy = l < NY;
-        const double* tVec = tab + L.oVec;
+        const double* tVec = tab + L.oVecL;
         ry2 = tVec[LinLayout::V_RY2 * G + l];
         ry1d = tVec[LinLayout::V_RY1D * G + l];
         caibd = tVec[LinLayout::V_CAIBD * G + l];
@@ -436,7 +439,7 @@ struct IpSolver {
     // pass) to their owner lanes: lane i < nx ends with A2[k] = entry (i, k).
     template <int N>
     __device__ __forceinline__ void adjoint_rows(int i0, double* dst) const {
-        const double* tB = tab + L.oAiB + i0 * NY + (vy ? l : 0);
+        const double* tB = ctab + L.oAiB + i0 * NY + (vy ? l : 0);
         double b[N], z[N];
         static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; b[j] = vy ? tB[j * NY] : 0.0; });
         if constexpr (G == 16) static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; z[j] = qr_solve(b[j]); });
@@ -446,7 +449,7 @@ struct IpSolver {
     // (RLDS: the tile holds R during the solves - a trip's rows go to their owner lanes through the staging vectors instead)
     template <int N>
     __device__ __forceinline__ void adjoint_trip(int i0, double (&A2)[NY]) const {
-        const double* tB = tab + L.oAiB + i0 * NY + (vy ? l : 0);
+        const double* tB = ctab + L.oAiB + i0 * NY + (vy ? l : 0);
         double b[N], z[N];
         static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; b[j] = vy ? tB[j * NY] : 0.0; });
         qr_solve_n<N>(b, z);
@@ -546,6 +549,7 @@ struct IpSolver {
 template <int G>
 __device__ __forceinline__ int group_bcast0(int v) {
     if constexpr (G == 16) return __builtin_amdgcn_update_dpp(0, v, 0x150, 0xF, 0xF, true);
+    else if constexpr (G == 64) return __builtin_amdgcn_readfirstlane(v);
     else return __shfl(v, (int)(threadIdx.x & 63) & ~31, 64);
 }
 
@@ -554,7 +558,13 @@ __device__ __forceinline__ void stage_table(double* tab, const double* src_tab, 
     constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G, M::NTHS, M::ADJ);
     const double2* src = reinterpret_cast<const double2*>(src_tab + (size_t)knot * L.size);
     double2* dst = reinterpret_cast<double2*>(tab);
-    for (int k = tid; k < L.size / 2; k += (int)blockDim.x) dst[k] = src[k];   // 16 B per lane, coalesced
+    if constexpr (L.hot == L.size) {
+        for (int k = tid; k < L.size / 2; k += (int)blockDim.x) dst[k] = src[k];   // 16 B per lane, coalesced
+    } else {      // 64-lane models: the operators of the iteration and the vectors only (LinLayout::hot)
+        static_assert(L.oRthDyn % 2 == 0 && L.oVec % 2 == 0, "16-byte copies");
+        for (int k = tid; k < L.oRthDyn / 2; k += (int)blockDim.x) dst[k] = src[k];
+        for (int k = tid; k < LinLayout::V_COUNT * L.G / 2; k += (int)blockDim.x) dst[L.oVecL / 2 + k] = src[L.oVec / 2 + k];
+    }
 }
 
 // ----------------------------------------------------------------------------------------
@@ -623,8 +633,8 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
         if constexpr (M::MODE == CIMPC_MODE_CONFIGURATIONFORCE) nuy = (l < NC + NB) ? xld<ASYNC>(nv + NX + lg) : 0.0;
     }
     auto column = [&](int c, int cc) {
-        const double u = tab[L.oRthDyn + c * G + l];
-        const double g = tab[L.oGs + c * G + l];          // CAi * rthdyn[:, c] - rthrst[:, c], a constant of the knot (lin_table.h)
+        const double u = S.ctab[L.oRthDyn + c * G + l];
+        const double g = S.ctab[L.oGs + c * G + l];          // CAi * rthdyn[:, c] - rthrst[:, c], a constant of the knot (lin_table.h)
         double xs;
         const double t = S.template schur_solve<true>(u, g, xs);
         if (vx) xst<ASYNC>(dzo + c * ND + lg, -xs);
@@ -642,8 +652,8 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
             double u[ILP], g[ILP], t[ILP], xs[ILP];
             static_for<0, ILP>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                u[j] = tab[L.oRthDyn + (c + j) * G + l];
-                g[j] = tab[L.oGs + (c + j) * G + l];
+                u[j] = S.ctab[L.oRthDyn + (c + j) * G + l];
+                g[j] = S.ctab[L.oGs + (c + j) * G + l];
             });
             S.template schur_solve_n<ILP>(u, g, t, xs);
             static_for<0, ILP>([&](auto jc) {
@@ -671,8 +681,8 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
             // delta^T nu of the lane's column: the chain s = fma(dz[k, c], nu[k], s), k = 0 .. nx-1, the decision stage would run on
             // the stored block (IpParams::dtn) - nu[k] on the DPP operand.
             static_for<0, NY>([&](auto kc) { constexpr int k = decltype(kc)::value; A2[k] = -A2[k]; });
-            const double* tG = tab + L.oGs;
-            const double* tK = tab + L.oK0;
+            const double* tG = S.ctab + L.oGs;
+            const double* tK = S.ctab + L.oK0;
 #pragma unroll 1
             for (int cb = lo; cb < hi; cb += G) {
                 const int c = cb + lg;
@@ -693,7 +703,7 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
             return;
         }
         constexpr int CHA = CH1;
-        const double* tK0 = tab + L.oK0 + (vx ? l : 0);
+        const double* tK0 = S.ctab + L.oK0 + (vx ? l : 0);
 #pragma unroll 1
         for (int c0 = lo; c0 < hi; c0 += CHA) {
             const int n = hi - c0 < CHA ? hi - c0 : CHA;
@@ -702,7 +712,7 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
             constexpr int CB = M::WIDE ? 2 : CIMPC_ADJ_CB;      // (throughput build of the 32-lane models: 256 registers, two waves hide each other)
             auto columns = [&](auto nb, int cc) {
                 constexpr int N = decltype(nb)::value;
-                const double* g = tab + L.oGs + (c0 + cc) * G;      // (32-lane groups: the block is stored by column, lin_table.h)
+                const double* g = S.ctab + L.oGs + (c0 + cc) * G;      // (32-lane groups: the block is stored by column, lin_table.h)
                 double a[N][2];
                 static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j][0] = tK0[(c0 + cc + j) * NX]; a[j][1] = 0.0; });
                 static_for<0, NY>([&](auto kc) {
@@ -826,20 +836,20 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
     const int K = p.Q.K, cap = p.Q.cap, par = p.Q.par;
     const int grp = tid / G;
     const int l = tid % G;
-    double* Rst = smem + L.size + (size_t)grp * M::LDS_GROUP;   // [NY][G+1]
+    double* Rst = smem + L.hot + (size_t)grp * M::LDS_GROUP;   // [NY][G+1]
     double* dth = Rst;                                           // [NTH]  (aliases the tile, see Model::LDS_GROUP)
     // converged problems whose sensitivities are pending: ONE list per wave (kept behind the tile of the wave's first group), so
     // that a sensitivity trip is full as soon as the wave holds one problem per group, whoever solved them
     constexpr int GPW = 64 / G;                                  // lane groups per wave
     static_assert(M::SENS_MAX >= 2 * GPW, "the wave's list holds a trip's worth of problems plus one trip of new arrivals");
     const int gw = (tid & 63) / G;
-    int* backlog = reinterpret_cast<int*>(smem + L.size + (size_t)(grp - gw) * M::LDS_GROUP + M::TILE);
+    int* backlog = reinterpret_cast<int*>(smem + L.hot + (size_t)(grp - gw) * M::LDS_GROUP + M::TILE);
     int nback = 0;                                               // wave-uniform
     const bool vx = l < NX, vy = l < NY;
     const cimpc_ip_opts o = p.o;
     // per-solve time budget (cimpc_ip_opts::max_time, policy.jl:9,61): `tbase` = clock value at which the solve's running time was
     // zero - kept in LDS, read once per trip, and only when a budget is set (wave-uniform kernel parameter)
-    long long* tbase = reinterpret_cast<long long*>(smem + L.size + (size_t)grp * M::LDS_GROUP + M::TILE + M::SENS_MAX / 2);
+    long long* tbase = reinterpret_cast<long long*>(smem + L.hot + (size_t)grp * M::LDS_GROUP + M::TILE + M::SENS_MAX / 2);
     const bool timed = p.budget_ticks > 0;
 
     [[maybe_unused]] const long long sp_t0 = SPROF_T();
@@ -853,7 +863,8 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
     int* head = qhead(p.Q, knot);
     [[maybe_unused]] const int* tailp = qcount(p.Q, par, knot);
     IpSolver<M> S;
-    S.bind(tab, Rst, l);        // caches the per-lane constants of this knot's table
+    const double* ctab = (L.hot == L.size) ? tab : p.tab + (size_t)knot * L.size;      // blocks touched once per solve (64-lane models: global memory)
+    S.bind(tab, Rst, l, ctab);        // caches the per-lane constants of this knot's table
     bool have = false, exhausted = false, stalled = false;
     int prob = 0, iters = 0, done_here = 0;
     [[maybe_unused]] int idle_trips = 0, dbg_trips = 0, dbg_act = 0;
@@ -979,7 +990,7 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
                 static_for<0, NTC>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
                     const int k = l + j * G;
-                    if (k < NTH) dth[k] = thv[j] - tab[L.oTh0 + k];
+                    if (k < NTH) dth[k] = thv[j] - ctab[L.oTh0 + k];
                 });
                 wave_lds_fence();
                 {   // rthdyn*(th-th0), rthrst*(th-th0): constant per solve
@@ -987,15 +998,15 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
                     int k = 0;
                     for (; k + 1 < NTH; k += 2) {
                         const double d0 = dth[k], d1 = dth[k + 1];
-                        a0 = fma(tab[L.oRthDyn + k * G + l], d0, a0);
-                        c0 = fma(tab[L.oRthRst + k * G + l], d0, c0);
-                        a1 = fma(tab[L.oRthDyn + (k + 1) * G + l], d1, a1);
-                        c1 = fma(tab[L.oRthRst + (k + 1) * G + l], d1, c1);
+                        a0 = fma(ctab[L.oRthDyn + k * G + l], d0, a0);
+                        c0 = fma(ctab[L.oRthRst + k * G + l], d0, c0);
+                        a1 = fma(ctab[L.oRthDyn + (k + 1) * G + l], d1, a1);
+                        c1 = fma(ctab[L.oRthRst + (k + 1) * G + l], d1, c1);
                     }
                     for (; k < NTH; ++k) {
                         const double d0 = dth[k];
-                        a0 = fma(tab[L.oRthDyn + k * G + l], d0, a0);
-                        c0 = fma(tab[L.oRthRst + k * G + l], d0, c0);
+                        a0 = fma(ctab[L.oRthDyn + k * G + l], d0, a0);
+                        c0 = fma(ctab[L.oRthRst + k * G + l], d0, c0);
                     }
                     S.tthdyn = a0 + a1;
                     S.tthrst = c0 + c1;
@@ -1214,9 +1225,10 @@ int launch_model(const IpParams& p, int waves, hipStream_t s) {
     constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G, M::NTHS, M::ADJ);
     if (waves < 1 || waves > (M::G == 16 ? CIMPC_SWEEP_THREADS : 512) / 64 || waves == 3) return CIMPC_ERR_INVALID;
     const int ppw = 64 / M::G;
-    const size_t lds = (size_t)(L.size + waves * ppw * M::LDS_GROUP) * sizeof(double);
+    const size_t lds = (size_t)(L.hot + waves * ppw * M::LDS_GROUP) * sizeof(double);
     const int grid = p.wpk;      // persistent workgroups of the launch
-    if constexpr (M::G != 16) {
+    if constexpr (M::G == 64) { if (waves > 4) return CIMPC_ERR_INVALID; }      // (one build: four waves of one problem each)
+    if constexpr (M::G == 32) {
         if (waves > 4) {         // throughput build: two waves per SIMD, its own per-problem LDS layout
             using MW = typename M::Wide;
             constexpr LinLayout LW(MW::NX, MW::NY, MW::NTH, MW::G, MW::NTHS, MW::ADJ);
@@ -1237,7 +1249,7 @@ template <class M>
 void info_model(KernelInfo* info) {
     constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G, M::NTHS, M::ADJ);
     info->G = M::G;
-    info->lds_table = L.size;
+    info->lds_table = L.hot;
     info->lds_group = M::LDS_GROUP;
     info->tab_size = L.size;
     info->dtn_ld = M::DTN_LD;
@@ -1257,5 +1269,14 @@ void info_model(KernelInfo* info) {
         if (mode == 0) info_model<Model<q, u, w, c, b, 0>>(info);                            \
         else info_model<Model<q, u, w, c, b, 1>>(info);                                      \
     }
+
+// 64-lane models (ny > 32: one problem per wavefront): :configuration mode only - :configurationforce and the B2 callbacks stay
+// with the runtime-dimension kernel / are not offered (ip_dispatch.hip)
+#define CIMPC_DEFINE_MODEL64(name, q, u, w, c, b)                                            \
+    int ip_launch_##name(int mode, const IpParams& p, int waves, hipStream_t s) {            \
+        if (mode != 0) return CIMPC_ERR_INVALID;                                             \
+        return launch_model<Model<q, u, w, c, b, 0>>(p, waves, s);                           \
+    }                                                                                        \
+    void ip_info_##name(int mode, KernelInfo* info) { (void)mode; info_model<Model<q, u, w, c, b, 0>>(info); }
 
 }  // namespace cimpc

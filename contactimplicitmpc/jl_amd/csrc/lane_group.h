@@ -36,13 +36,19 @@ __device__ __forceinline__ void static_rfor(F&& f) {
 
 template <int G>
 struct LaneGroup {
-    static_assert(G == 16 || G == 32, "lane group is one or two DPP rows");
+    static_assert(G == 16 || G == 32 || G == 64, "lane group is one, two or four DPP rows (64: the whole wavefront, one problem per wave)");
 
     // value of `v` held by lane K of the caller's group
     template <int K>
     static __device__ __forceinline__ double bcast(double v) {
         if constexpr (G == 16) {
             return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xF, 0xF, true);  // row_newbcast:K
+        } else if constexpr (G == 64) {
+            // one problem per wavefront (round 6, ny > 32): the source lane is wave-uniform - two v_readlane_b32, and the value
+            // arrives in SCALAR registers (a free operand of the multiply-add that consumes it)
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane(__double2loint(v), K);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane(__double2hiint(v), K);
+            return __hiloint2double((int)hi, (int)lo);
         } else {
             // 32-lane group = two DPP rows.  row_newbcast:(K & 15) puts lane (K & 15) of EVERY row into its own row; gfx950's
             // v_permlane16_swap then exchanges the odd rows of one operand with the even rows of the other: with both operands
@@ -94,7 +100,8 @@ struct LaneGroup {
         v = max2(v, dpp_xor2(v));
         v = max2(v, dpp_ror4(v));
         v = max2(v, dpp_ror8(v));
-        if constexpr (G == 32) v = max2(v, __shfl_xor(v, 16, 64));
+        if constexpr (G >= 32) v = max2(v, __shfl_xor(v, 16, 64));
+        if constexpr (G == 64) v = max2(v, __shfl_xor(v, 32, 64));
         return v;
     }
     static __device__ __forceinline__ double all_min(double v) {
@@ -102,7 +109,8 @@ struct LaneGroup {
         v = min2(v, dpp_xor2(v));
         v = min2(v, dpp_ror4(v));
         v = min2(v, dpp_ror8(v));
-        if constexpr (G == 32) v = min2(v, __shfl_xor(v, 16, 64));
+        if constexpr (G >= 32) v = min2(v, __shfl_xor(v, 16, 64));
+        if constexpr (G == 64) v = min2(v, __shfl_xor(v, 32, 64));
         return v;
     }
     // sum over the group WITHOUT the re-broadcast: every lane holds the sum in its own association (rotation-based reductions
@@ -112,7 +120,8 @@ struct LaneGroup {
         v += dpp_xor2(v);
         v += dpp_ror4(v);
         v += dpp_ror8(v);
-        if constexpr (G == 32) v += __shfl_xor(v, 16, 64);
+        if constexpr (G >= 32) v += __shfl_xor(v, 16, 64);
+        if constexpr (G == 64) v += __shfl_xor(v, 32, 64);
         return v;
     }
     // sum over the group; the result of lane 0 is re-broadcast so that every lane of the
@@ -122,7 +131,8 @@ struct LaneGroup {
         v += dpp_xor2(v);
         v += dpp_ror4(v);
         v += dpp_ror8(v);
-        if constexpr (G == 32) v += __shfl_xor(v, 16, 64);
+        if constexpr (G >= 32) v += __shfl_xor(v, 16, 64);
+        if constexpr (G == 64) v += __shfl_xor(v, 32, 64);
         return bcast<0>(v);
     }
 };

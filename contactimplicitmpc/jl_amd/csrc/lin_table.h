@@ -19,6 +19,11 @@ struct LinLayout {
     int nx, ny, nth, G, nths, adj, ldw, gst;
     // offsets in doubles
     int oW, oCAi, oAi, oDy1, oDx, oRx, oRy1, oRthDyn, oRthRst, oGs, oK0, oAiB, oVec, oTh0, size;
+    // 64-lane models (round 6: ny > 32, one problem per wavefront): at lane stride 64 the whole table (208 KB for centroidal_quadruped_wall)
+    // does not fit a CU's LDS.  Only the operators of the interior-point ITERATION are staged - [oW, oRthDyn) and the vectors, `hot`
+    // doubles, the vectors at oVecL - ; the blocks a solve touches once (r_theta at the pull; Gs, K0, A^-1 B in the sensitivity
+    // pass; theta0) are read from the table in global memory (L2).  Other models: hot = size, oVecL = oVec.
+    int hot, oVecL;
     // oGs (compiled lane-group models; nths = 0: absent): the right-hand sides of the sensitivity pass as the QR sees them,
     //   Gs[:, c] = CAi * rthdyn[:, c] - rthrst[:, c],  c = 0 .. nths-1  (schur_solve!, schur.jl:93-110, on column c of r_theta,
     //   linearized_solver.jl:451-479) - a constant of the knot that every converged solve used to recompute for each of its
@@ -52,7 +57,9 @@ struct LinLayout {
           oAiB(oK0 + (adj_ ? nths_ * nx_ : 0)),
           oVec((oAiB + (adj_ ? nx_ * ny_ : 0) + 1) & ~1),
           oTh0(oVec + V_COUNT * G_),
-          size(((oTh0 + nth_) + 1) & ~1) {}
+          size(((oTh0 + nth_) + 1) & ~1),
+          hot(G_ == 64 ? oRthDyn + V_COUNT * G_ : size),
+          oVecL(G_ == 64 ? oRthDyn : oVec) {}
 };
 
 }  // namespace cimpc

@@ -30,7 +30,8 @@ pytestmark = pytest.mark.gpu
     ("particle2d", 1, 3, 4, 6),
     ("anydims", 0, 3, 5, 8),             # no compiled set: the runtime-dimension kernel (ip_generic.hip)
     ("anydims", 1, 3, 5, 8),
-    ("centroidal_wall", 0, 2, 4, 6),     # ny = 48 > 32 lanes: runtime-dimension kernel only
+    ("centroidal_wall", 0, 2, 4, 6),     # ny = 48 > 32 lanes: the compiled 64-lane sweep (round 6; rounds 2-5: runtime-dimension kernel)
+    ("centroidal_wall", 1, 2, 4, 6),     # ... whose :configurationforce mode keeps the runtime-dimension kernel
 ])
 def test_implicit_dynamics_matches_oracle(gpu_required, model, mode, B, H, H_ref):
     d, prob, tabs, rollouts = make_case(model, mode, H_ref=H_ref, H=H, B=B, seed=3)

@@ -309,3 +309,41 @@ def test_newton_solve_duo_vs_packed_in_overlapped_rounds(monkeypatch, B):
     assert abs(int((a[2] < 1e-5).sum()) - int((b[2] < 1e-5).sum())) <= max(2, B // 10)
     assert abs(float(a[3]["sweeps"].mean()) - float(b[3]["sweeps"].mean())) <= 0.05 * float(a[3]["sweeps"].mean())
     assert abs(np.median(a[2]) / np.median(b[2]) - 1.0) < 0.25
+
+
+# ---- compiled sweep for 32 < ny <= 64 (centroidal_quadruped_wall, ny = 48): 64-lane groups, one problem per wavefront --------------
+def test_centroidal_wall_runs_the_compiled_64_lane_sweep():
+    """/root/reference/src/dynamics/centroidal_quadruped_wall/model.jl:204-207 (nc = 8: ny = 2 nc + nb = 48) ran on the runtime-dimension
+    kernel through round 5.  :configuration mode now has a compiled instantiation (ip_model_centroidal_wall.hip: the lane-group
+    solver on 64-lane groups, R packed in LDS, the iteration's operators staged, the once-per-solve blocks read from L2) - seen
+    here by its table layout (the adjoint pass's constants are part of it) - and :configurationforce keeps the runtime-dimension
+    kernel.  Both against the oracle: implicit_dynamics! on every knot."""
+    from contactimplicitmpc.jl_amd import InteriorPointOptions
+    from common import oracle_sweep
+    from oracle import ip as oip
+    H, H_ref, B = 6, 8, 3
+    for mode in (0, 1):
+        d, prob, tabs, rollouts = make_case("centroidal_wall", mode, H_ref=H_ref, H=H, B=B, seed=4, perturb=1e-2)
+        s = make_solver(d, prob, rollouts, H, ip_opts=InteriorPointOptions(kappa_tol=prob["kappa"]))
+        tab_doubles, _ = s.query_sizes()
+        nx, ny, nth, nths, G = 18, 48, 53, 48, 64
+        generic = ny * G + 2 * nx * G + 2 * ny * G + 2 * nx * G + 2 * nth * G      # W .. RthRst at lane stride 64, no Gs / K0 / AiB
+        assert (tab_doubles > generic + nths * G) == (mode == 0), (mode, tab_doubles)
+        ref = oracle_sweep(d, tabs, rollouts, oip.IPOptions(kappa_tol=prob["kappa"]))
+        out = s.implicit_dynamics(np.stack([t.q for t, _ in ref]), np.stack([t.theta for t, _ in ref]),
+                                  gamma=np.stack([t.gamma for t, _ in ref]) if mode else None, b=np.stack([t.b for t, _ in ref]) if mode else None)
+        n = agree = 0
+        for b, (_, o) in enumerate(ref):
+            for i in range(H):
+                n += 1
+                if out["iters"][b, i] == o["iters"][i] and out["status"][b, i] == o["status"][i]:
+                    agree += 1
+                    if o["status"][i] == 1:      # (a failed solve stops at an iterate that round-off moves: converged solves only)
+                        # (the configuration rows; in :configurationforce mode d also holds y1 - [gamma; b], which a converged solve fixes
+                        #  only up to the complementarity tolerance kappa_tol - DESIGN.md section 2)
+                        np.testing.assert_allclose(out["d"][b, i][:d.nq], o["d"][i][:d.nq], rtol=0, atol=1e-5)
+                        np.testing.assert_allclose(out["d"][b, i], o["d"][i], rtol=0, atol=5.0 * prob["kappa"])
+                        for k in ("dq0", "dq1", "du1"):
+                            np.testing.assert_allclose(out[k][b, i][:d.nq], o[k][i][:d.nq], rtol=0, atol=1e-4 * max(1.0, np.abs(o[k][i]).max()))
+        assert agree >= 0.9 * n, (mode, agree, n)
+        s.close()
