@@ -65,9 +65,9 @@ struct Knobs {
     int kkt_tw_nb = 0;           // CIMPC_KKT_TW_NB: rows eliminated from the bottom (0: the default split)
     int kkt_duo = 1;             // CIMPC_KKT_DUO: 0 = packed one-wave kernel next to the sweep (rounds 2-5), 1 = the duo kernel where it applies
     int kkt_duo_hint = 20000;    // CIMPC_KKT_DUO_HINT: ... in rounds whose sweep has at most this many problems queued (a shorter launch than the packed recursion)
-    int kkt_duo_max = 256;       // CIMPC_KKT_DUO_MAX: ... for at most this many systems per launch (one workgroup per CU at a time)
+    int kkt_duo_max = 256;       // ... for at most this many systems per launch (one workgroup per CU at a time)
     bool lazy_dz = true;         // CIMPC_LAZY_DZ: 0 = the decision kernel copies the accepted sensitivities itself (rounds 3-5)
-    int kkt_tw_spins = 0;        // CIMPC_KKT_TW_SPINS: bound of a chain's wait for its partner, in polls (0: 2^21); tests force the time-out path with 1
+    int kkt_tw_spins = 0;        // bound of a chain's wait for its partner, in polls (0: 2^21); the tests force the time-out path through cimpc_debug_set_tw_spins
     int kkt_tw_max = 120;        // twisted kernel for at most this many rollouts per launch (two workgroups each must be resident together)
     // ---- constants ----
     int async_mem = 0;           // exchange buffers: ordinary device memory (uncached / fine-grained variants lost)
@@ -108,10 +108,8 @@ struct Knobs {
         kkt_pipe = env_int("CIMPC_KKT_PIPE", kkt_pipe);
         kkt_twisted = env_int("CIMPC_KKT_TWISTED", kkt_twisted);
         kkt_tw_nb = env_int("CIMPC_KKT_TW_NB", kkt_tw_nb);
-        kkt_tw_spins = env_int("CIMPC_KKT_TW_SPINS", kkt_tw_spins);
         lazy_dz = env_int("CIMPC_LAZY_DZ", 1) != 0;
         kkt_duo = env_int("CIMPC_KKT_DUO", kkt_duo);
-        kkt_duo_max = env_int("CIMPC_KKT_DUO_MAX", kkt_duo_max);
         kkt_duo_hint = env_int("CIMPC_KKT_DUO_HINT", kkt_duo_hint);
         generic_static = env_int("CIMPC_GENERIC_STATIC", generic_static ? 1 : 0) != 0;
         sweep_wgs = env_int("CIMPC_SWEEP_WGS", sweep_wgs);

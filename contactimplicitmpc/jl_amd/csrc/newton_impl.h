@@ -1497,7 +1497,7 @@ constexpr int KKT_TW_MIN_H = 24;
 __host__ __device__ constexpr int kkt_tw_xch_doubles(int nd) { return 3 * nd * nd + 4 * nd; }
 constexpr int KKT_TW_FLAGS = 32;         // ints per rollout (one 128-byte line): [0] traces ready, [1] middle dnu ready, [2] chains finished, [3] a hand-over of
                                          // this launch timed out; [4..7] the same four words of the banded twisted kernel (kkt_dense.hip)
-constexpr int KKT_TW_SPINS = 1 << 21;    // default bound of a wait (NewtonDev::kkt_tw_spins; CIMPC_KKT_TW_SPINS / cimpc_debug_set_tw_spins for the tests)
+constexpr int KKT_TW_SPINS = 1 << 21;    // default bound of a wait (NewtonDev::kkt_tw_spins; cimpc_debug_set_tw_spins for the tests)
 // Wait for the partner chain's flag to show THIS launch's stamp (agent scope), then acquire.  Bounded: a partner that never becomes
 // resident must not hang the device - the caller poisons its result with NaN AND marks the rollout (kkt_tw_give_up), so that the
 // solve is repeated on the one-ended kernel instead of being used.

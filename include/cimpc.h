@@ -263,7 +263,7 @@ int cimpc_get_kkt_twisted(cimpc_handle h, long long* n);
 int cimpc_get_kkt_twisted_fallbacks(cimpc_handle h, long long* n);
 /* TEST HOOK: bound of those waits in polls (<= 0: the default 2^21, about a second).  tests/test_gpu_round6.py forces the
  * time-out path with 1 and then restores the default on the SAME handle (epoch-valued flags: a partner that raises its flag
- * after the waiter gave up cannot be mistaken for the next solve's).  Also CIMPC_KKT_TW_SPINS in the environment at cimpc_create. */
+ * after the waiter gave up cannot be mistaken for the next solve's). */
 int cimpc_debug_set_tw_spins(cimpc_handle h, int spins);
 /* per rollout, last newton solve: implicit_dynamics! evaluations, sum of IP iterations
  * ("solver iterations to tolerance"), failed IP solves.  Each B ints; any may be NULL. */

@@ -404,6 +404,38 @@ if isdefined(ContactImplicitMPC, :newton_solve!) && isdefined(ContactImplicitMPC
     end
 end
 
+# ---- B3 DROP-IN: the package's own implicit_dynamics!, for trajectories attached to a handle ----------------------------------------
+# `implicit_dynamics!(im_traj::ImplicitTrajectory, traj::ContactTraj; threads, window)` (implicit_dynamics.jl:156-158) is called by the
+# reference's Newton loop at newton.jl:62,191,234,260.  Unlike `Newton` (whose linear-solver type is a type parameter, see B4 above),
+# `ImplicitTrajectory{T,R,RZ,Rθ,NQ}` has no user-selectable type parameter: a drop-in under the UNCHANGED call sites has to replace the
+# method of the same signature.  That is done at RUN time, on request (`CIMPCHip.enable_b3_dropin!()` - method overwriting is not
+# permitted while the package precompiles), and only trajectories attached to a handle take the GPU path: every other call runs the
+# package's original method, reached through the world age in which it was the newest (`Base.invoke_in_world`).
+#   hip = CIMPCHip.Solver(s, ref_traj, obj; H_mpc, κ, mode, n_opts, ip_opts)       # B = 1
+#   CIMPCHip.enable_b3_dropin!(); CIMPCHip.attach!(p.im_traj, hip)
+#   ... the reference's newton_solve! now evaluates implicit_dynamics! on the GPU (B3), its own KKT solve stays (or :hip_kkt_solver, B1)
+const _B3_HANDLES = IdDict{Any,Solver}()
+const _B3_WORLD = Ref{UInt}(0)
+"Route `implicit_dynamics!(im_traj, traj; window)` of THIS ImplicitTrajectory through the handle (B = 1)."
+attach!(im_traj, hs::Solver) = (_need_b1(hs, "attach!"); _B3_HANDLES[im_traj] = hs; im_traj)
+detach!(im_traj) = (delete!(_B3_HANDLES, im_traj); im_traj)
+function enable_b3_dropin!()
+    _B3_WORLD[] != 0 && return nothing
+    (isdefined(ContactImplicitMPC, :implicit_dynamics!) && isdefined(ContactImplicitMPC, :ImplicitTrajectory)) ||
+        error("CIMPCHip.enable_b3_dropin!: include CIMPCHip.jl after controller/implicit_dynamics.jl")
+    _B3_WORLD[] = Base.get_world_counter()          # the package's own method is the newest one in this world
+    @eval ContactImplicitMPC function implicit_dynamics!(im_traj::ImplicitTrajectory, traj::ContactTraj;
+                                                         threads = false, window = collect(1:traj.H + 2))
+        hs = get(CIMPCHip._B3_HANDLES, im_traj, nothing)
+        if hs === nothing      # not attached: the reference's method, unchanged
+            return Base.invoke_in_world(CIMPCHip._B3_WORLD[], implicit_dynamics!, im_traj, traj; threads = threads, window = window)
+        end
+        CIMPCHip.implicit_dynamics!(hs, im_traj, traj; window = window)
+        return nothing
+    end
+    return nothing
+end
+
 # ---- plant side: one simulator step for B robots (RoboDojo step! inside simulate!, simulator.jl:15-63) ---------------------------
 # model symbol -> (CIMPC_PLANT_* id, nq, nu, nc, friction directions per contact, nw); mirrors include/cimpc.h and
 # contactimplicitmpc/jl_amd/plant.py: MODELS (checked by tests/test_julia_binding.py)
