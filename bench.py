@@ -972,8 +972,10 @@ def main():
     out["roofline"]["kernels"] = [
         kernel_roofline("ip_queue_kernel<quadruped> (B = %d)" % B, flops_per_solve, prof["ip_sweep_problems"], prof["ip_sweep_launches"], prof["ip_sweep_ms"],
                         "the dominant kernel = roofline.frac", flops_executed=K * alg["flop_iter"] + alg["flop_tail_executed"]),
-        kernel_roofline("kkt_kernel_packed<11,8> (B = %d, next to the sweep)" % B, kkt_condensed_flops(d.nq, H), prof_all["kkt_systems"], prof_all["kkt_launches"],
-                        prof_all["kkt_ms"], "condensed f64-MFMA solve, SURVEY 8 A13: 1.2 MFLOP per system; one wavefront per system, two per workgroup - a latency chain of H block steps"),
+        kernel_roofline("kkt_kernel_duo<11,8> / kkt_kernel_packed<11,8> (B = %d, next to the sweep)" % B, kkt_condensed_flops(d.nq, H), prof_all["kkt_systems"], prof_all["kkt_launches"],
+                        prof_all["kkt_ms"], "condensed f64-MFMA solve, SURVEY 8 A13: 1.2 MFLOP per system; the HIP-event class covers both kernels of the rounds' KKT stage: "
+                        "the duo kernel (two one-wave chains per system in one workgroup, rounds whose sweep has <= 20 k problems queued) and the packed kernel "
+                        "(one wavefront per system, two per workgroup) - latency chains of H / 2 resp. H block steps; per-kernel averages: profiles/r06/kernel_stats.csv"),
     ]
     if multi is not None:
         out["multi_gpu"] = multi
