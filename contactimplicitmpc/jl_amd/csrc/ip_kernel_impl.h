@@ -97,7 +97,13 @@ struct Model {
 #ifndef CIMPC_ADJ_CB
 #define CIMPC_ADJ_CB 4
 #endif
-    static constexpr int ADJ_ILP = (NX <= 16 && NY <= 16) ? 4 : CIMPC_ADJ_ILP32;      // transposed solves of the adjoint pass side by side
+#ifndef CIMPC_ADJ_ILP64
+#define CIMPC_ADJ_ILP64 3
+#endif
+#ifndef CIMPC_ADJ_CB64
+#define CIMPC_ADJ_CB64 2      // (four columns side by side: 105 spilled VGPRs, 368 B of scratch per lane; two: none)
+#endif
+    static constexpr int ADJ_ILP = (NX <= 16 && NY <= 16) ? 4 : G == 64 ? CIMPC_ADJ_ILP64 : CIMPC_ADJ_ILP32;      // transposed solves of the adjoint pass side by side
     static constexpr int NBV0 = CIMPC_SENS_ILP32 > 3 ? CIMPC_SENS_ILP32 : 3;
     static constexpr int NBV = (ADJ && ADJ_ILP > NBV0) ? ADJ_ILP : NBV0;      // staging vectors per 32-lane group
     static constexpr int BVEC = (G == 16) ? 0 : NBV * G;
@@ -709,7 +715,7 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
             const int n = hi - c0 < CHA ? hi - c0 : CHA;
             // CB columns side by side, two partial sums each: 2 CB independent multiply-add chains (a wave of the 32-lane latency
             // build has its SIMD to itself - the chains are the time)
-            constexpr int CB = M::WIDE ? 2 : CIMPC_ADJ_CB;      // (throughput build of the 32-lane models: 256 registers, two waves hide each other)
+            constexpr int CB = M::WIDE ? 2 : G == 64 ? CIMPC_ADJ_CB64 : CIMPC_ADJ_CB;      // (throughput build of the 32-lane models: 256 registers, two waves hide each other)
             auto columns = [&](auto nb, int cc) {
                 constexpr int N = decltype(nb)::value;
                 const double* g = S.ctab + L.oGs + (c0 + cc) * G;      // (32-lane groups: the block is stored by column, lin_table.h)
