@@ -1388,7 +1388,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     // tail again, 10.7 -> 11.0-11.3 ms.)
     long long launched = 0, completed = 0, rounds = 0;
     const bool dbg_rounds = h->kn.debug_rounds;
-    int last_kkt = 0, last_sweep = h->dm.B, last_slots = h->dm.B, last_parked = 0;
+    int last_kkt = 0, last_sweep = h->dm.B, last_slots = h->dm.B, last_parked = 0, last_new_slots = h->dm.B;
     // Single rollouts (B < 4: below the persistent kernel's range) keep ONE round queued ahead of the one the host waits for: such a
     // round is launched BLIND - KKT kernel on the full list range with its count read on the device, everything else is
     // device-driven anyway - and costs three empty launches if the solve turns out to be over; in exchange no round waits for the
@@ -1446,9 +1446,10 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         // slots requested + solves parked; a launch takes about 80 us + 1 us per 112 problems): next to a long sweep the packed kernel is
         // off the critical path anyway and takes half as many CUs from it (B = 1024: 11.7 -> 12.5 ms with the duo kernel everywhere;
         // B = 256: 6.46 -> 5.89 ms, B = 512 unchanged)
-        // (the evaluation slots only, not the parked solves: which solves a launch parks depends on timing, and a kernel choice that
-        //  followed it would make the iterates differ from run to run - the two kernels agree to 1e-12, not to the bit)
-        const long long sweep_problems = blind ? -1 : (long long)last_slots * h->dm.H;
+        // (the NEWLY REQUESTED evaluation slots only - not the parked solves, not the slots re-listed while they wait for one: which
+        //  solves a launch parks depends on timing, and a kernel choice that followed it would make the iterates differ from run to
+        //  run - the two kernels agree to 1e-12, not to the bit; scripts/dbg/repro_check.py)
+        const long long sweep_problems = blind ? -1 : (long long)last_new_slots * h->dm.H;
         if (pipe == 0 && !tw_off && h->kkt_overlap && h->kn.kkt_duo != 0 && h->kn.kkt_twisted != 0 && n_kkt > 0 && n_kkt <= h->kn.kkt_duo_max && sweep_problems >= 0 &&
             sweep_problems <= h->kn.kkt_duo_hint && kkt_duo_available(Sk)) pipe = 3;
         if (kkt && (pipe == 2 || pipe == 3) && !h->use_dense && !h->use_mixed && (h->kkt_overlap ? h->kn.kkt_packed : true)) h->n_kkt_twisted++;
@@ -1551,6 +1552,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         last_sweep = n_sweep;
         last_kkt = hr[1];
         last_slots = hr[6];
+        last_new_slots = hr[7];      // (deterministic: slots that only wait for a parked solve are re-listed, not re-requested)
         last_parked = hr[4];
         if (dbg_rounds) fprintf(stderr, "[cimpc round %lld] t %.3f ms: next sweep %d rollouts (%d evaluation slots), next kkt %d, parked %d, finished %d\n", completed,
                                 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), n_sweep, last_slots, last_kkt, hr[4], hr[5]);

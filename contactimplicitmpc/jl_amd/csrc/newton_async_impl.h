@@ -61,12 +61,17 @@ __device__ __noinline__ void async_kkt_job(unsigned long long ka, int b, double*
     // the pipeline company (one after the LDS clear, one per tick, one before the backward pass)
     const NewtonDev S = uniform_state(ka);
     if ((int)blockDim.x >= 192) {         // three-stage pipeline on waves 0..2; the fourth wave keeps the barriers company
+        // Round 6: the line search is started by the WHOLE workgroup after the solve (finish = 0 inside kkt_body): on wave 0 alone the seven
+        // candidates of a tail rollout (apply_steps + 280 queue pushes) took longer than a third of the recursion itself
         if (tid < 192) {
-            const KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 2};
+            const KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 0};
             kkt_body<NQ, NU, WaveSync, 3>(S, K, b, smem, tid & 63, tid >> 6);
         } else {
             for (int k = 0; k < S.dm.H + 4; ++k) __syncthreads();      // 1 (LDS clear) + H + 2 ticks + 1 (before the backward pass)
         }
+        __threadfence_block();
+        __syncthreads();                   // wave 0's step (global memory, this workgroup's own stores) is in front of every wave
+        start_line_search<BlockSync>(S, b, 2, tid, (int)blockDim.x);
     } else if ((int)blockDim.x >= 128) {
         const KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 2};
         kkt_body<NQ, NU, WaveSync, 2>(S, K, b, smem, tid & 63, tid >> 6);

@@ -100,6 +100,7 @@ __device__ __forceinline__ void enqueue_evals(const NewtonDev& S, size_t sb, int
     if (tid == 0) {
         int pos = 0;
         if (S.slot_list != nullptr) pos = atomicAdd(&S.counters[4 * CPAD], n);
+        atomicAdd(&S.counters[5 * CPAD], n);      // NEW evaluation requests of the round (a deterministic count: slots re-listed while a solve is parked are not in it)
         if (pos + n > S.dm.B * CS) __builtin_trap();      // (a slot is listed at most once per round: cannot happen)
         for (int c = 0; c < n; ++c) {
             S.WQ.done_count[sb + c] = 0;
@@ -900,6 +901,7 @@ __global__ __launch_bounds__(CIMPC_RESID_THREADS) void resid_decide_kernel(Newto
             hm[1] = n_kkt;
             hm[4] = atomicAdd(&S.counters[2 * CPAD], 0);                                   // solves parked by this round
             hm[6] = atomicAdd(&S.counters[4 * CPAD], 0);                                   // evaluation slots of the next round
+            hm[7] = atomicAdd(&S.counters[5 * CPAD], 0);                                   // ... of which newly requested (not waiting for a parked solve)
             hm[5] = S.A.n_done != nullptr ? atomicAdd(S.A.n_done, 0) : 0;            // rollouts finished so far
             __threadfence_system();
             hm[2] = S.round_stamp;
