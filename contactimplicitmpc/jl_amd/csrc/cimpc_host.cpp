@@ -69,6 +69,10 @@ struct Knobs {
     bool lazy_dz = true;         // CIMPC_LAZY_DZ: 0 = the decision kernel copies the accepted sensitivities itself (rounds 3-5)
     int kkt_tw_spins = 0;        // bound of a chain's wait for its partner, in polls (0: 2^21); the tests force the time-out path through cimpc_debug_set_tw_spins
     int kkt_tw_max = 120;        // twisted kernel for at most this many rollouts per launch (two workgroups each must be resident together)
+    int async_kkt_tw = 1;        // CIMPC_ASYNC_KKT_TW: the persistent kernel's KKT stage as TWO cooperating jobs (the chains of the twisted solve): 0 never,
+                                 // 1 where it was measured a gain - single launches of at most 32 rollouts (quadruped H = 40, B = 4 / 16 / 32: 2.08 -> 1.85,
+                                 // 2.43 -> 2.27, 3.55 -> 3.41 ms; B = 64: 4.4 -> 4.9 ms - twice the jobs when every rollout reaches its KKT stage at once;
+                                 // hybrid tail of B = 512: no difference in six alternating pairs, the tail's chain is its interior-point evaluations) -, 2 always
     // ---- constants ----
     int async_mem = 0;           // exchange buffers: ordinary device memory (uncached / fine-grained variants lost)
     int spec_all = -1;           // speculative slots of later line-search rounds: by batch size
@@ -111,6 +115,7 @@ struct Knobs {
         lazy_dz = env_int("CIMPC_LAZY_DZ", 1) != 0;
         kkt_duo = env_int("CIMPC_KKT_DUO", kkt_duo);
         kkt_duo_hint = env_int("CIMPC_KKT_DUO_HINT", kkt_duo_hint);
+        async_kkt_tw = env_int("CIMPC_ASYNC_KKT_TW", async_kkt_tw);
         generic_static = env_int("CIMPC_GENERIC_STATIC", generic_static ? 1 : 0) != 0;
         sweep_wgs = env_int("CIMPC_SWEEP_WGS", sweep_wgs);
         waves32 = env_int("CIMPC_WAVES32", waves32);
@@ -582,7 +587,7 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         const size_t evals = 1 + 7 * (size_t)std::max(1, h->nt.max_iter);       // per rollout and solve
         h->a_cap = B * evals * ((H + K - 1) / K + 1);
         h->a_rq_cap = B * (2 + 3 * (size_t)std::max(1, h->nt.max_iter));
-        h->a_kq_cap = B * (1 + (size_t)std::max(1, h->nt.max_iter));
+        h->a_kq_cap = B * (2 + 3 * (size_t)std::max(1, h->nt.max_iter));      // (twisted KKT jobs: two entries per stage, one more after a timed-out hand-over)
         const size_t bytes = (K * h->a_cap + h->a_rq_cap + h->a_kq_cap) * sizeof(int);
         h->async_on = want && newton_async_available(&d) && K <= 256 && bytes <= ((size_t)1 << 30);
     }
@@ -1248,6 +1253,8 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     if (int sy = sync_dz_stores(h, 1); sy != CIMPC_OK) return sy;
     h->dz_producer = 1;
     NewtonDev& S = h->S;
+    const int tw_fail0 = *(volatile int*)h->h_twfail;      // time-outs of the twisted kernels' hand-overs before this solve
+    h->twfail_seen = tw_fail0;
     const auto t0 = std::chrono::steady_clock::now();
     auto over_budget = [&]() {
         if (h->nt.max_time <= 0.0) return false;
@@ -1317,6 +1324,12 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         A.dbg = h->a_dbg;
         if (h->a_dbg) HIP_TRY(h, hipMemsetAsync(h->a_dbg, 0, 16 * sizeof(long long), st));
         A.B = h->dm.B;
+        // KKT stage of the persistent kernel as two cooperating jobs (the chains of the twisted solve, newton_async_impl.h): 16-wide tiles,
+        // four-wave workgroups, a horizon the twisted form accepts, and no hand-over of this solve has timed out so far
+        A.kkt_tw = ((h->kn.async_kkt_tw == 2 || (h->kn.async_kkt_tw == 1 && from_reset && h->dm.B <= 32)) && h->kn.kkt_twisted != 0 && h->dm.nq <= 16 && h->dm.nu <= 16 && std::min(h->waves, 4) == 4 && kkt_twisted_available(Sk) &&
+                    *(volatile int*)h->h_twfail == tw_fail0) ? 1 : 0;
+        if (A.kkt_tw) h->n_kkt_twisted++;
+        S.kkt_tw_epoch += h->nt.max_iter + 2;      // the launch's KKT stages take the stamps Sk.kkt_tw_epoch + 1 + (Newton iterations done)
         prof_begin(h, PC_OTHER, st);
         int rc2 = from_reset ? launch_reset(Sk, q0_dev, q1_dev, warm_start, st) : launch_async_handoff(Sk, LQ, st);
         prof_end(h, st);
@@ -1349,6 +1362,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
             }
         }
         HIP_TRY(h, hipStreamSynchronize(st));
+        if (const int twf = *(volatile int*)h->h_twfail; twf != h->twfail_seen) { h->n_kkt_tw_fallbacks += twf - h->twfail_seen; h->twfail_seen = twf; }
         if (timed_out) return fail(h, CIMPC_ERR_HIP, "asynchronous solve: watchdog expired (no completion within CIMPC_ASYNC_WATCHDOG_S)");
         if (h->a_dbg) {
             long long dv[16];
@@ -1397,8 +1411,6 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
     // four rounds of a cold start lose more to the empty launches than they gain (0.685 -> 0.706 ms).
     // (not with a wall-clock budget: the round queued ahead would still run - and step the trajectory - after the host has stopped
     //  waiting, newton.jl:187-277 ends silently at the check)
-    const int tw_fail0 = *(volatile int*)h->h_twfail;      // time-outs of the twisted kernels' hand-overs before this solve
-    h->twfail_seen = tw_fail0;
     const bool ahead = h->dm.B < 4 && !h->use_mixed && warm_start != 0 && !(h->nt.max_time > 0.0 && h->nt.max_time < 1.0e6);
     auto launch_round = [&](long long r, bool blind) -> int {
         // [KKT for rollouts that start an iteration] || sweep -> residual of every evaluated slot -> line-search decision

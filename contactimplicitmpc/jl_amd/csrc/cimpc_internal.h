@@ -52,7 +52,12 @@ struct AsyncQ {
     int idle_spins;     // polls before an idle workgroup looks around unprompted
     int wake_fan;       // buckets woken per evaluation request (each bucket = 1/16 of the workgroups)
     int B;
+    int kkt_tw;         // 1: a rollout's KKT stage is TWO cooperating jobs - the chains of the twisted condensed solve, pushed bottom chain
+                        // first (push_kkt_job) - instead of one one-ended recursion
 };
+// KKT job words: rollout index in the low 24 bits, kind above - 0 one-ended recursion, 1 top chain, 2 bottom chain of the twisted
+// solve, 3 one-ended recursion of a rollout whose twisted hand-over timed out
+constexpr int KJOB_SHIFT = 24, KJOB_MASK = (1 << KJOB_SHIFT) - 1;
 
 // Hand-offs of the asynchronous solve follow the HIP memory model literally: the producer issues an
 // agent-scope release fence (__threadfence) after writing its results and before the queue push /
@@ -113,6 +118,24 @@ __device__ __forceinline__ void wake_ip(const AsyncQ& A, int b) {
 __device__ __forceinline__ void wake_job(const AsyncQ& A, int b) {
     atomicAdd(A.epoch + 32 * 16, 1);
     atomicAdd(A.epoch + (16 + (b & 15)) * 16, 1);
+}
+// A rollout enters its KKT stage.  Twisted form: two consecutive entries, the BOTTOM chain first.  Claims are FIFO (aq_pop advances
+// the head by compare-and-swap), so whoever claims the top chain knows that the bottom chain already has a workgroup - every
+// workgroup of the persistent kernel is resident and a claimed job is started without waiting for anything - and the bottom chain,
+// which waits for nothing until its forward pass is done, is followed by its partner as soon as any workgroup looks at the queue
+// (jobs are taken before interior-point work).  Both waits are bounded anyway (kkt_tw_wait): a time-out re-queues kind 3.
+__device__ __forceinline__ void push_kkt_job(const AsyncQ& A, int b) {
+    if (A.kkt_tw) {
+        const int pos = atomicAdd(A.kq_tail, 2);
+        astore(A.kq_items + pos, b | (2 << KJOB_SHIFT));
+        astore(A.kq_items + pos + 1, b | (1 << KJOB_SHIFT));
+        atomicAdd(A.epoch + 32 * 16, 1);
+        atomicAdd(A.epoch + (16 + (b & 15)) * 16, 1);
+        atomicAdd(A.epoch + (16 + ((b + 1) & 15)) * 16, 1);      // (a second bucket: two workgroups are wanted)
+    } else {
+        aq_push(A.kq_items, A.kq_tail, b);
+        wake_job(A, b);
+    }
 }
 __device__ __forceinline__ void wake_all(const AsyncQ& A) { for (int k = 0; k <= 32; ++k) atomicAdd(A.epoch + k * 16, 1); }
 

@@ -80,6 +80,40 @@ __device__ __noinline__ void async_kkt_job(unsigned long long ka, int b, double*
         kkt_body<NQ, NU, WaveSync>(S, K, b, smem, tid);
     }
 }
+// Twisted form of the KKT job (round 6): ONE chain of the two-ended condensed solve (kkt_body<..., PIPE = 3, TW>: the
+// three-stage pipeline on waves 0..2 from its own end of the matrix), the rollout's other chain being another workgroup's job
+// (push_kkt_job: bottom chain first, FIFO claims).  The hand-over flags are epoch-valued; inside one persistent launch the stamp of a
+// rollout's KKT stage is the launch's stamp + 1 + the Newton iterations the rollout has done (the host advances its stamp by
+// max_iter + 2 per launch).  The chain that finishes last starts the line search with the whole workgroup; a hand-over that timed
+// out re-queues the stage as a one-ended job (kind 3).
+template <int NQ, int NU, int TW>
+__device__ __noinline__ void async_kkt_tw_job(unsigned long long ka, int b, double* smem, int tid) {
+    NewtonDev S = uniform_state(ka);
+    S.kkt_tw_epoch += 1 + __builtin_amdgcn_readfirstlane(S.newton_l[b]);
+    constexpr int TL = kkt_tld<NQ, NU>();
+    const int H = S.dm.H;
+    const int msp = kkt_tw_split(H, S.kkt_tw_nb, TL > 16, false);
+    const int NS = TW == 1 ? msp + 2 : (H - msp - 2) + 2;
+    if (tid < 192) {
+        const KktArgs K{S.res, S.delta, S.beta, 0.0, S.stage, 0};
+        kkt_body<NQ, NU, WaveSync, 3, false, TW>(S, K, b, smem, tid & 63, tid >> 6);
+    } else {
+        // the fourth wave keeps the chain's workgroup barriers company: 1 (LDS clear) + NS + 2 ticks + 1 (before the backward pass) +
+        // 2 (primal recovery) + 1 (rows complete) + 1 (verdict of the finish counter)
+        for (int k = 0; k < NS + 8; ++k) __syncthreads();
+    }
+    __syncthreads();
+    // verdict of the finish counter (kkt_body: vec[11 VS], written by wave 0 before its last barrier): non-zero = the partner had finished
+    const int last = (int)smem[KKT_TW_TILES * TL * TL + 11 * (TL <= 16 ? 16 : 32)];
+    if (last == 0) return;
+    __threadfence();                      // acquire the partner's share of the step in every wave
+    int* xfl = S.kkt_tw_flags + (size_t)b * KKT_TW_FLAGS;
+    if (__builtin_amdgcn_readfirstlane(aload(xfl + 3)) == S.kkt_tw_epoch) {      // poisoned numbers: the stage again, one-ended
+        if (tid == 0) { aq_push(S.A.kq_items, S.A.kq_tail, b | (3 << KJOB_SHIFT)); wake_job(S.A, b); }
+        return;
+    }
+    start_line_search<BlockSync>(S, b, 2, tid, (int)blockDim.x);
+}
 template <int NQ, int NU>
 __device__ __noinline__ void async_resid_job(unsigned long long ka, int b, double* red, double* rc, int* sh) {
     const NewtonDev S = uniform_state(ka);
@@ -142,7 +176,17 @@ __global__ __launch_bounds__(256, (M::G == 16 ? 2 : 1)) void newton_async_kernel
         if (type == 1) {
             xfence(A.flags);                             // acquire res / traj / dz of the rollout
             account(0);
-            async_kkt_job<NQ, NU>(ka, job, smem, tid);
+            const int kind = job >> KJOB_SHIFT, jb = job & KJOB_MASK;
+            if constexpr (kkt_tld<NQ, NU>() == 16) {
+                if ((kind == 1 || kind == 2) && (int)blockDim.x >= 256) {
+                    if (kind == 2) async_kkt_tw_job<NQ, NU, 2>(ka, jb, smem, tid);
+                    else async_kkt_tw_job<NQ, NU, 1>(ka, jb, smem, tid);
+                    __syncthreads();
+                    account(1);
+                    continue;
+                }
+            }
+            async_kkt_job<NQ, NU>(ka, jb, smem, tid);
             __syncthreads();
             account(1);
             continue;
@@ -192,7 +236,11 @@ int launch_async_model(const IpParams& p, const NewtonDev& S, int waves, int gri
     if (waves != 1 && waves != 2 && waves != 4) return CIMPC_ERR_INVALID;
     const int ppw = 64 / M::G;
     const size_t lds_ip = (size_t)(L.size + waves * ppw * M::LDS_GROUP) * sizeof(double);
-    const size_t lds_kkt = (size_t)(waves >= 3 ? kkt_lds_doubles<M::NQ, M::NU, 3>() : waves >= 2 ? kkt_lds_doubles<M::NQ, M::NU, 2>() : kkt_lds_doubles<M::NQ, M::NU, 1>()) * sizeof(double);
+    size_t lds_kkt = (size_t)(waves >= 3 ? kkt_lds_doubles<M::NQ, M::NU, 3>() : waves >= 2 ? kkt_lds_doubles<M::NQ, M::NU, 2>() : kkt_lds_doubles<M::NQ, M::NU, 1>()) * sizeof(double);
+    if (p.A.kkt_tw) {      // twisted KKT jobs: four-wave workgroups, 16-wide tiles (the host sets the flag only where both hold)
+        if (waves != 4 || kkt_tld<M::NQ, M::NU>() != 16) return CIMPC_ERR_INVALID;
+        lds_kkt = std::max(lds_kkt, (size_t)kkt_tw_lds_doubles<M::NQ, M::NU>() * sizeof(double));
+    }
     const size_t lds_res = (size_t)(CS * 256 + S.N) * sizeof(double);       // residual job: partial sums of every slot + |r_e| scratch
     const size_t lds = std::max(std::max(lds_ip, lds_kkt), lds_res);
     static LdsOptIn optin;

@@ -800,8 +800,7 @@ __device__ __forceinline__ void resid_decide_body(const NewtonDev& S, int b, dou
             if (sh[3]) {
                 if (atomicAdd(S.A.n_done, 1) == S.A.B - 1) wake_all(S.A);     // the solve is over: everybody leaves
             } else {
-                aq_push(S.A.kq_items, S.A.kq_tail, b);
-                wake_job(S.A, b);
+                push_kkt_job(S.A, b);
             }
         }
     }

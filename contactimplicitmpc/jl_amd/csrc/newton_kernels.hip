@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64) void async_handoff_kernel(NewtonDev S, IpQueues
         if (stage == STAGE_DONE) {
             atomicAdd(S.A.n_done, 1);
         } else if (stage == STAGE_KKT) {
-            aq_push(S.A.kq_items, S.A.kq_tail, b);
+            push_kkt_job(S.A, b);      // (the wake-up words it bumps are read by nobody yet: the persistent kernel starts behind this one)
         } else {
             const size_t sb0 = (size_t)b * CS;
             int n = 0;

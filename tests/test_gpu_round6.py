@@ -347,3 +347,71 @@ def test_centroidal_wall_runs_the_compiled_64_lane_sweep():
                             np.testing.assert_allclose(out[k][b, i][:d.nq], o[k][i][:d.nq], rtol=0, atol=1e-4 * max(1.0, np.abs(o[k][i]).max()))
         assert agree >= 0.9 * n, (mode, agree, n)
         s.close()
+
+
+# ---- KKT stage of the persistent kernel as two cooperating jobs (the chains of the twisted solve, newton_async_impl.h) -----------------
+@pytest.mark.parametrize("model,H,H_ref,B,sched", [("quadruped", 40, 44, 8, "single"), ("quadruped", 28, 30, 24, "single"), ("hopper", 26, 30, 6, "single"),
+                                                   ("quadruped", 32, 36, 96, "hybrid")])
+def test_async_twisted_kkt_jobs_vs_the_one_ended_job(monkeypatch, model, H, H_ref, B, sched):
+    """`newton_solve!` (/root/reference/src/controller/newton.jl:169-288) in ONE persistent launch (and in the hybrid schedule's tail) with
+    every KKT stage run as two cooperating jobs - bottom chain pushed first, FIFO claims - against the same solve with the one-ended
+    three-wave job: identical Newton iteration counts, controls as close as two KKT solves 1e-12 apart leave them (the synthetic batch
+    is chaotic: compared where the discrete paths agree), no hand-over timed out."""
+    from contactimplicitmpc.jl_amd import NewtonOptions
+    d, prob, tabs, rollouts = make_case(model, 0, H_ref=H_ref, H=H, B=B, seed=7, perturb=1e-2)
+    obj = synth.make_objective(d, H, kind=model)
+    q0 = np.stack([r[2] for r in rollouts]); q1 = np.stack([r[3] for r in rollouts])
+    res = {}
+    for tw in (0, 2):
+        monkeypatch.setenv("CIMPC_ASYNC_KKT_TW", str(tw))
+        if sched == "hybrid":
+            monkeypatch.setenv("CIMPC_ASYNC_TAIL", "64")
+        s = make_solver(d, prob, rollouts, H, obj=obj, newton_opts=NewtonOptions(kappa=prob["kappa"], r_tol=1e-6, max_iter=4))
+        u1, it, rn = s.newton_solve(q0, q1)
+        cnt = s.rollout_counters()
+        u1w, itw, rnw = s.newton_solve(q0, q1, warm_start=True)
+        res[tw] = (u1, it, rn, u1w, itw, cnt, s.kkt_twisted(), s.kkt_twisted_fallbacks())
+        s.close()
+    a, b = res[0], res[2]
+    assert b[6] > a[6], "the twisted jobs did not run"
+    assert b[7] == 0
+    assert np.isfinite(b[0]).all() and np.isfinite(b[3]).all()
+    # (same bounds as the lock-step form of this comparison, test_gpu_round5.py::test_newton_solve_twisted_vs_one_ended: on the same
+    #  discrete path the controls agree to 1e-5 of their scale - the conditioning of the Newton system at its residual floor -, off it
+    #  both runs are solutions of the same quality)
+    same = (a[1] == b[1]) & (a[5]["sweeps"] == b[5]["sweeps"]) & (a[5]["ip_iters"] == b[5]["ip_iters"])
+    assert np.abs(a[1].astype(int) - b[1].astype(int)).max() <= 1
+    assert same.mean() >= 0.25, (a[1], b[1])      # (H = 40: a cold solve is ~250 interior-point solves deep, half the rollouts flip one iteration count)
+    for k in range(B):
+        tol = (1e-5 if model == "quadruped" else 2e-3) if same[k] else 2e-3
+        np.testing.assert_allclose(b[0][k], a[0][k], rtol=0, atol=tol * max(1.0, np.abs(a[0][k]).max()))
+    assert np.abs(a[4] - b[4]).max() <= 1
+
+
+def test_async_twisted_kkt_job_timeout_is_served_one_ended(monkeypatch):
+    """Forced time-out of the hand-overs inside the persistent kernel (a bound of ONE poll): the chain that finishes last queues the
+    rollout's KKT stage again as a one-ended job - finite results on the one-ended solve's discrete path, the fallbacks counted; the
+    next solve on the same handle (default bound) runs the twisted jobs again and is right."""
+    from contactimplicitmpc.jl_amd import NewtonOptions
+    H, H_ref, B = 28, 30, 8
+    d, prob, rollouts, obj = _tw_case("quadruped", H, H_ref, B)
+    opts = NewtonOptions(kappa=prob["kappa"], r_tol=1e-6, max_iter=3)
+    monkeypatch.setenv("CIMPC_ASYNC_KKT_TW", "0")
+    s0 = make_solver(d, prob, rollouts, H, obj=obj, newton_opts=opts)
+    ref_cold = _newton(s0, rollouts)
+    ref_warm = _newton(s0, rollouts, warm=True)
+    s0.close()
+    monkeypatch.setenv("CIMPC_ASYNC_KKT_TW", "2")
+    s = make_solver(d, prob, rollouts, H, obj=obj, newton_opts=opts)
+    s.debug_set_tw_spins(1)
+    got = _newton(s, rollouts)
+    n_fb = s.kkt_twisted_fallbacks()
+    assert n_fb > 0, "the forced time-out did not happen"
+    assert np.isfinite(got[0]).all() and np.isfinite(got[2]).all()
+    assert np.array_equal(got[1], ref_cold[1])
+    np.testing.assert_allclose(got[0], ref_cold[0], rtol=0, atol=1e-7 * max(1.0, np.abs(ref_cold[0]).max()))
+    s.debug_set_tw_spins(0)
+    got2 = _newton(s, rollouts, warm=True)
+    assert np.abs(got2[1] - ref_warm[1]).max() <= 1
+    assert np.isfinite(got2[0]).all() and np.isfinite(got2[3]["q"]).all()
+    s.close()
