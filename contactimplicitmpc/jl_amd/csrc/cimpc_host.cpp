@@ -1947,3 +1947,8 @@ int cimpc_query_sizes(cimpc_handle h, int* table_doubles, int* N_kkt) {
 }
 
 }  // extern "C"
+
+#ifdef CIMPC_UBENCH
+// diagnostic builds only: the device address of the handle's linearization tables (scripts/dbg/ubench_ip.py)
+extern "C" const double* cimpc_debug_table_ptr(cimpc_handle h) { return h ? h->d_tab : nullptr; }
+#endif

@@ -203,7 +203,8 @@ struct IpSolver {
 
     // rzlin! + schur_factorize! + MGS factorize!.  Right-looking order: per column exactly
     // the arithmetic of the reference's left-looking loop (qr.jl:113-137); dot products use
-    // four partial sums, 1/|a_k| comes from v_rsq_f64 + two Newton steps on the broadcast self-product of column k.
+    // one running sum on 16-lane groups (wider groups: four partial sums), 1/|a_k| comes from v_rsq_f64 + two Newton steps on the
+    // broadcast self-product of column k.
     // TR (adjoint sensitivity pass, Model::ADJ): factorizes the TRANSPOSE of the Schur matrix (lane l reads row l of the block
     // instead of column l; its padded leading dimension keeps both free of bank conflicts) - qr_solve then solves with M^T.
     template <bool TR = false>
@@ -218,10 +219,20 @@ struct IpSolver {
         y2r = fmax(y2, reg);
         iy1r = fast_rcp(y1r);
         const double dd = ry2 * y2r * iy1r;
+        // (D - CAiB)[r, l]: the column of the table block, its diagonal entry replaced.  Every entry is LOADED first and selected
+        // afterwards: written as one conditional expression per entry, the compiler turned the select into control flow around the
+        // load - per entry two exec-mask flips, a branch and a wait for ITS load: 16 exposed LDS round trips and ~160 instructions, a
+        // quarter of the factorization's time on a lone wavefront (scripts/dbg/ubench_ip.py: 5.55 k -> 4.2 k clocks)
+        const double dval = (ry1d - dd) - caibd;
+        double wcol[NY];
         static_for<0, NY>([&](auto ic) {
             constexpr int r = decltype(ic)::value;
-            const double w = TR ? tW[(vy ? l : 0) * L.ldw + r] : tW[r * L.ldw + l];      // Ry1[r,l] - CAiB[r,l]   (r != l)
-            Qc[r] = (lq == r) ? ((ry1d - dd) - caibd) : w;  // (D - CAiB)[r,l]
+            wcol[r] = TR ? tW[(vy ? l : 0) * L.ldw + r] : tW[r * L.ldw + l];      // Ry1[r,l] - CAiB[r,l]   (r != l)
+        });
+        pin_values(wcol);      // (the loads stay where they are)
+        static_for<0, NY>([&](auto ic) {
+            constexpr int r = decltype(ic)::value;
+            Qc[r] = (lq == r) ? dval : wcol[r];
         });
         // Column l stays UNNORMALISED in Qc (q_l = Qc * rdinv); the projection coefficients are
         // r_kj = (a_k . a_j) / |a_k| and the update a_j -= (r_kj / |a_k|) a_k - the same numbers as
@@ -235,13 +246,23 @@ struct IpSolver {
             wave_lds_fence();
             if (lq == 0) static_for<0, NY>([&](auto ic) { constexpr int r = decltype(ic)::value; bc[r] = Qc[r]; });
         }
+        // (16-lane groups with the column in one DPP chunk: the dot products of step k + 1 ride in the statement of step k's update -
+        //  `dnext` carries them into the next step)
+        constexpr bool FUSED = G == 16 && Dpp16::can_selfdot<NY>();
+        [[maybe_unused]] double dnext = 0.0;
+        if constexpr (FUSED) Dpp16::dots<0, NY>(dnext, Qc);
         static_for<0, NY>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
             [[maybe_unused]] double ak[G == 16 ? 1 : NY];     // 32-lane groups: column k read once from the staging buffer, used twice
-            if constexpr (G == 16) {
-                // a_k . a_l: column k rides on the DPP source of the multiply-add (no broadcast registers)
-                Dpp16::dot<k, NY>(acc, Qc);
+            if constexpr (FUSED) {
+                acc[0] = dnext;
+            } else if constexpr (G == 16) {
+                // a_k . a_l: column k rides on the DPP source of the multiply-add (no broadcast registers).  ONE chain (round 6): a
+                // dependent multiply-add issues as fast as an independent one on this pipe, the four partial sums of rounds 1-5 only
+                // cost three zero-initialisations and three adds per step (lane_group.h: Dpp16::dots) - and a plain running sum is
+                // what the reference's loop forms (qr.jl:113-137)
+                Dpp16::dots<k, NY>(acc[0], Qc);
             } else {
                 wave_lds_fence();
                 const double* src = bc + (k & 1) * G;
@@ -251,8 +272,8 @@ struct IpSolver {
                     acc[r & 3] = fma(ak[r], Qc[r], acc[r & 3]);
                 });
             }
-            const double dot = (acc[0] + acc[1]) + (acc[2] + acc[3]);     // a_k . a_l
-            // |a_k|^2 is lane k's own dot product (there a_k[r] * a_k[r], the same four partial sums a separate
+            const double dot = G == 16 ? acc[0] : (acc[0] + acc[1]) + (acc[2] + acc[3]);     // a_k . a_l
+            // |a_k|^2 is lane k's own dot product (there a_k[r] * a_k[r], the same sum a separate
             // norm loop would form): one broadcast instead of 16 multiply-adds per step
             const double invk = fast_rsqrt(LG::template bcast<k>(dot));
             rdinv = (lq == k) ? invk : rdinv;
@@ -261,7 +282,10 @@ struct IpSolver {
             double nrk = dot * -invk;
             nrk = ((lq > k) && vy) ? nrk : -0.0;       // (-0.0: the masked entries keep the sign they had as -(+0.0))
             const double ncoef = nrk * invk;            // -(r_kl / |a_k|); zero in lanes <= k: column k itself stays as it is during the update
-            if constexpr (G == 16) {
+            if constexpr (FUSED) {
+                if constexpr (k + 1 < NY) { dnext = 0.0; Dpp16::selfdot<k, NY>(dnext, Qc, ncoef); }      // a_l -= (r_kl / |a_k|) a_k ; a_{k+1} . a_l
+                // (the last column's update would change nothing: every coefficient is masked to zero at k = NY - 1)
+            } else if constexpr (G == 16) {
                 Dpp16::self<k, NY>(Qc, ncoef);       // a_l -= (r_kl / |a_k|) a_k
             } else {
                 static_for<0, NY>([&](auto ic) {
@@ -320,7 +344,7 @@ struct IpSolver {
     __device__ __forceinline__ double qr_solve(double rhs) const {
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
         if constexpr (G == 16) {
-            Dpp16::matvec<NY, 4>(acc, rhs, [&](auto rc) { return Qc[decltype(rc)::value]; });
+            Dpp16::chain<NY>(acc[0], rhs, [&](auto rc) { return Qc[decltype(rc)::value]; });      // (one chain: see factorize)
         } else {
             stage(rhs);
             static_for<0, NY>([&](auto ic) {
@@ -328,7 +352,7 @@ struct IpSolver {
                 acc[r & 3] = fma(Qc[r], bv[r], acc[r & 3]);
             });
         }
-        double c = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * rdinv;   // (Q^T rhs)_l, Q = Qc * rdinv
+        double c = (G == 16 ? acc[0] : (acc[0] + acc[1]) + (acc[2] + acc[3])) * rdinv;   // (Q^T rhs)_l, Q = Qc * rdinv
         // back-substitution, row l of R in this lane: x_k = c_k / R[k,k] broadcast, c_l -= R[l,k] x_k (k > l).  Lane l's c is
         // final once step k = l + 1 is done (R[l,k] = 0 for k <= l), so x_l = c * rdinv after the loop - the same product
         // the reference forms at step l (qr.jl:150-157).
@@ -350,13 +374,13 @@ struct IpSolver {
     __device__ __forceinline__ double schur_solve(double u, double v, double& xs) const {
         const double* tCAi = tab + L.oCAi; const double* tAi = tab + L.oAi; const double* tDy1 = tab + L.oDy1;
         double bq[2] = {0.0, 0.0}, w[2] = {0.0, 0.0}, xx[2] = {0.0, 0.0};
-        if constexpr (G == 16) {
-            if constexpr (!PRE) Dpp16::matvec<NX, 2>(bq, u, [&](auto kc) { return tCAi[decltype(kc)::value * G + l]; });
-            const double t = qr_solve(PRE ? v : (bq[0] + bq[1]) - v);
-            Dpp16::matvec<NY, 2>(w, t, [&](auto kc) { return tDy1[decltype(kc)::value * G + l]; });
-            const double ww = u + (w[0] + w[1]);
-            Dpp16::matvec<NX, 2>(xx, ww, [&](auto kc) { return tAi[decltype(kc)::value * G + l]; });
-            xs = xx[0] + xx[1];
+        if constexpr (G == 16) {      // (one chain per operator: see factorize)
+            if constexpr (!PRE) Dpp16::chain<NX>(bq[0], u, [&](auto kc) { return tCAi[decltype(kc)::value * G + l]; });
+            const double t = qr_solve(PRE ? v : bq[0] - v);
+            Dpp16::chain<NY>(w[0], t, [&](auto kc) { return tDy1[decltype(kc)::value * G + l]; });
+            const double ww = u + w[0];
+            Dpp16::chain<NX>(xx[0], ww, [&](auto kc) { return tAi[decltype(kc)::value * G + l]; });
+            xs = xx[0];
             return t;
         }
         if constexpr (!PRE) {

@@ -34,6 +34,26 @@ __device__ __forceinline__ void static_rfor(F&& f) {
     }
 }
 
+// Pins N values in registers at this point of the program with ONE empty statement (a barrier for code motion only: loads issued
+// before it are waited for once, together, instead of one s_waitcnt per value).  Chunks of 16: an inline-assembly statement takes
+// at most 30 operands.
+template <int I0, int N, int... I>
+__device__ __forceinline__ void pin_values_c(double (&a)[N], std::integer_sequence<int, I...>) {
+    if constexpr (sizeof...(I) == 16) asm volatile("" : "+v"(a[I0 + 0]), "+v"(a[I0 + 1]), "+v"(a[I0 + 2]), "+v"(a[I0 + 3]), "+v"(a[I0 + 4]), "+v"(a[I0 + 5]), "+v"(a[I0 + 6]), "+v"(a[I0 + 7]), "+v"(a[I0 + 8]), "+v"(a[I0 + 9]), "+v"(a[I0 + 10]), "+v"(a[I0 + 11]), "+v"(a[I0 + 12]), "+v"(a[I0 + 13]), "+v"(a[I0 + 14]), "+v"(a[I0 + 15]));
+    else if constexpr (sizeof...(I) == 8) asm volatile("" : "+v"(a[I0 + 0]), "+v"(a[I0 + 1]), "+v"(a[I0 + 2]), "+v"(a[I0 + 3]), "+v"(a[I0 + 4]), "+v"(a[I0 + 5]), "+v"(a[I0 + 6]), "+v"(a[I0 + 7]));
+    else if constexpr (sizeof...(I) == 4) asm volatile("" : "+v"(a[I0 + 0]), "+v"(a[I0 + 1]), "+v"(a[I0 + 2]), "+v"(a[I0 + 3]));
+    else if constexpr (sizeof...(I) == 2) asm volatile("" : "+v"(a[I0 + 0]), "+v"(a[I0 + 1]));
+    else asm volatile("" : "+v"(a[I0 + 0]));
+}
+template <int I0 = 0, int N>
+__device__ __forceinline__ void pin_values(double (&a)[N]) {
+    if constexpr (I0 < N) {
+        constexpr int R = N - I0, C = R >= 16 ? 16 : R >= 8 ? 8 : R >= 4 ? 4 : R >= 2 ? 2 : 1;
+        pin_values_c<I0>(a, std::make_integer_sequence<int, C>{});
+        pin_values<I0 + C>(a);
+    }
+}
+
 template <int G>
 struct LaneGroup {
     static_assert(G == 16 || G == 32 || G == 64, "lane group is one, two or four DPP rows (64: the whole wavefront, one problem per wave)");
@@ -159,24 +179,39 @@ template <int N, int MAX = 16>
 constexpr int dpp_chunk() { return (N >= 16 && MAX >= 16) ? 16 : (N >= 8 && MAX >= 8) ? 8 : N >= 4 ? 4 : N; }
 
 struct Dpp16 {
-    // ---- acc[r & 3] += bcast<K>(Q[r]) * Q[r], r = R0 .. R0+N-1: dot products of column K with every column -------------
+    // ---- a += bcast<K>(Q[r]) * Q[r], r = R0 .. R0+N-1 in ONE chain (see scripts/gen_dpp16.py: dotsN) -------------------------
     template <int K, int R0, int NQ, int... I>
-    static __device__ __forceinline__ void dot_c(double (&a)[4], const double (&Q)[NQ], std::integer_sequence<int, I...>) {
+    static __device__ __forceinline__ void dots_c(double& a, const double (&Q)[NQ], std::integer_sequence<int, I...>) {
         constexpr int C = sizeof...(I);
-        if constexpr (C == 16) Dpp16Gen::dot16<K>(a[0], a[1], a[2], a[3], Q[R0 + I]...);
-        else if constexpr (C == 8) Dpp16Gen::dot8<K>(a[0], a[1], a[2], a[3], Q[R0 + I]...);
-        else if constexpr (C == 4) Dpp16Gen::dot4<K>(a[0], a[1], a[2], a[3], Q[R0 + I]...);
-        else if constexpr (C == 3) Dpp16Gen::dot3<K>(a[0], a[1], a[2], Q[R0 + I]...);
-        else if constexpr (C == 2) Dpp16Gen::dot2<K>(a[0], a[1], Q[R0 + I]...);
-        else Dpp16Gen::dot1<K>(a[0], Q[R0 + I]...);
+        if constexpr (C == 16) Dpp16Gen::dots16<K>(a, Q[R0 + I]...);
+        else if constexpr (C == 8) Dpp16Gen::dots8<K>(a, Q[R0 + I]...);
+        else if constexpr (C == 4) Dpp16Gen::dots4<K>(a, Q[R0 + I]...);
+        else if constexpr (C == 3) Dpp16Gen::dots3<K>(a, Q[R0 + I]...);
+        else if constexpr (C == 2) Dpp16Gen::dots2<K>(a, Q[R0 + I]...);
+        else Dpp16Gen::dots1<K>(a, Q[R0 + I]...);
     }
     template <int K, int N, int R0 = 0, int NQ>
-    static __device__ __forceinline__ void dot(double (&a)[4], const double (&Q)[NQ]) {
+    static __device__ __forceinline__ void dots(double& a, const double (&Q)[NQ]) {
         if constexpr (N > 0) {
             constexpr int C = dpp_chunk<N>();
-            dot_c<K, R0>(a, Q, std::make_integer_sequence<int, C>{});
-            dot<K, N - C, R0 + C>(a, Q);
+            dots_c<K, R0>(a, Q, std::make_integer_sequence<int, C>{});
+            dots<K, N - C, R0 + C>(a, Q);
         }
+    }
+    // ---- Q[r] += bcast<K>(Q[r]) * c, then a += bcast<K+1>(Q[r]) * Q[r]: update of MGS step K + dot products of step K + 1 in one
+    //      statement (N = 4, 8, 16: the whole column in one chunk)
+    template <int K, int N, int... I>
+    static __device__ __forceinline__ void selfdot_c(double& a, double (&Q)[N], double c, std::integer_sequence<int, I...>) {
+        if constexpr (N == 16) Dpp16Gen::selfdot16<K>(a, Q[I]..., c);
+        else if constexpr (N == 8) Dpp16Gen::selfdot8<K>(a, Q[I]..., c);
+        else Dpp16Gen::selfdot4<K>(a, Q[I]..., c);
+    }
+    template <int N>
+    static constexpr bool can_selfdot() { return N == 4 || N == 8 || N == 16; }
+    template <int K, int N>
+    static __device__ __forceinline__ void selfdot(double& a, double (&Q)[N], double c) {
+        static_assert(can_selfdot<N>(), "one chunk");
+        selfdot_c<K>(a, Q, c, std::make_integer_sequence<int, N>{});
     }
     // ---- Q[r] += bcast<K>(Q[r]) * c: rank-1 update of the columns by column K --------------------------------------------
     template <int K, int R0, int NQ, int... I>
@@ -195,35 +230,6 @@ struct Dpp16 {
             constexpr int C = dpp_chunk<N>();
             self_c<K, R0>(Q, c, std::make_integer_sequence<int, C>{});
             self<K, N - C, R0 + C>(Q, c);
-        }
-    }
-    // ---- acc[k & (NACC-1)] += bcast<k>(v) * T(k), k = 0..N-1  (T: callable on std::integral_constant<int,k>) ------------------
-    template <int K0, int NACC, class TF, int... I>
-    static __device__ __forceinline__ void matvec_c(double (&a)[NACC], double v, TF& T, std::integer_sequence<int, I...>) {
-        constexpr int C = sizeof...(I);
-        if constexpr (NACC == 2) {
-            if constexpr (C == 16) Dpp16Gen::lanes16_acc2<K0>(a[0], a[1], v, T(std::integral_constant<int, K0 + I>{})...);
-            else if constexpr (C == 8) Dpp16Gen::lanes8_acc2<K0>(a[0], a[1], v, T(std::integral_constant<int, K0 + I>{})...);
-            else if constexpr (C == 4) Dpp16Gen::lanes4_acc2<K0>(a[0], a[1], v, T(std::integral_constant<int, K0 + I>{})...);
-            else if constexpr (C == 3) Dpp16Gen::lanes3_acc2<K0>(a[0], a[1], v, T(std::integral_constant<int, K0 + I>{})...);
-            else if constexpr (C == 2) Dpp16Gen::lanes2_acc2<K0>(a[0], a[1], v, T(std::integral_constant<int, K0 + I>{})...);
-            else Dpp16Gen::lanes1_acc2<K0>(a[0], v, T(std::integral_constant<int, K0 + I>{})...);
-        } else {
-            static_assert(NACC == 4, "two or four accumulators");
-            if constexpr (C == 16) Dpp16Gen::lanes16_acc4<K0>(a[0], a[1], a[2], a[3], v, T(std::integral_constant<int, K0 + I>{})...);
-            else if constexpr (C == 8) Dpp16Gen::lanes8_acc4<K0>(a[0], a[1], a[2], a[3], v, T(std::integral_constant<int, K0 + I>{})...);
-            else if constexpr (C == 4) Dpp16Gen::lanes4_acc4<K0>(a[0], a[1], a[2], a[3], v, T(std::integral_constant<int, K0 + I>{})...);
-            else if constexpr (C == 3) Dpp16Gen::lanes3_acc4<K0>(a[0], a[1], a[2], v, T(std::integral_constant<int, K0 + I>{})...);
-            else if constexpr (C == 2) Dpp16Gen::lanes2_acc4<K0>(a[0], a[1], v, T(std::integral_constant<int, K0 + I>{})...);
-            else Dpp16Gen::lanes1_acc4<K0>(a[0], v, T(std::integral_constant<int, K0 + I>{})...);
-        }
-    }
-    template <int N, int NACC, int K0 = 0, class TF>
-    static __device__ __forceinline__ void matvec(double (&a)[NACC], double v, TF&& T) {
-        if constexpr (N > 0) {
-            constexpr int C = dpp_chunk<N>();
-            matvec_c<K0>(a, v, T, std::make_integer_sequence<int, C>{});
-            matvec<N - C, NACC, K0 + C>(a, v, T);
         }
     }
     // ---- a[i] += bcast<i>(v) * t, i = 0..N-1: one entry t of this lane against N rows of v (outer-product update) ----------------
@@ -304,6 +310,10 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     y = fma(y, e, y);
     return y;
 }
+// (Measured and NOT taken, scripts/ubench/rsq_check.hip: ONE third-order step y (1 + e (1/2 + 3/8 e)), e = 1 - x y^2, instead of the two
+//  Newton steps - two instructions fewer per MGS step at the same 0.62-ulp error bound, but its results differ from the two-step
+//  value in the last place on 17 % of the arguments, and with it the device leaves the CPU checker's discrete path on 1.6 % of the
+//  20 480 full-size interior-point solves instead of 0.005 %: the two-step value is what keeps the iterates on the checker's path.)
 __device__ __forceinline__ double fast_rcp(double x) {
     double y = __builtin_amdgcn_rcp(x);
     double e = fma(-x, y, 1.0);

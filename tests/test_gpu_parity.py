@@ -300,10 +300,15 @@ def test_newton_solve_configurationforce_and_velocity(gpu_required, model, mode,
                               oip.IPOptions(kappa_tol=prob["kappa"]), prob["kappa"], ref)
         st = onewton.newton_solve(core, q0, q1, window, tabs, ref)
         if it[b] == st.iters and cnt["sweeps"][b] == st.sweeps and cnt["ip_iters"][b] == st.ip_iters:
+            # equal TOTALS do not exclude two interior-point solves flipping one iteration in opposite directions (DESIGN.md section 2,
+            # round 4): such a rollout agrees like an off-path one (1e-4) and does not count as "same"
+            if np.abs(traj["q"][b] - core.traj.q).max() > 1e-7 or np.abs(traj["u"][b] - core.traj.u).max() > 1e-7:
+                np.testing.assert_allclose(traj["q"][b], core.traj.q, rtol=0, atol=1e-4)
+                continue
             same += 1       # same discrete path (see DESIGN.md section 2 on roundoff-level flips)
-            np.testing.assert_allclose(traj["q"][b], core.traj.q, rtol=0, atol=1e-7)
-            np.testing.assert_allclose(traj["u"][b], core.traj.u, rtol=0, atol=1e-7)
-            np.testing.assert_allclose(rn[b], st.r_norm / core.lay.N, rtol=1e-3, atol=1e-9)
+            # (|r|_1 / N of a converged solve: it moves by |dr/dx| |dx| with the |dx| <= 1e-7 asserted above - 3e-9 was seen on a 7e-7 norm
+            #  when the sweep's dot products went from four partial sums to the reference loop's running sum)
+            np.testing.assert_allclose(rn[b], st.r_norm / core.lay.N, rtol=1e-3, atol=1e-8)
     assert same >= B - 1
 
 
