@@ -357,7 +357,8 @@ struct IpSolver {
         // final once step k = l + 1 is done (R[l,k] = 0 for k <= l), so x_l = c * rdinv after the loop - the same product
         // the reference forms at step l (qr.jl:150-157).
         if constexpr (G == 16) {
-            static_rfor<NY - 1>([&](auto kc) { Dpp16::backsub<decltype(kc)::value>(c, rdinv, Rr[decltype(kc)::value]); });
+            // (step 0 would add R[l, 0] x_0 = 0 to every lane: skipped)
+            static_rfor<NY - 1>([&](auto kc) { if constexpr (decltype(kc)::value > 0) Dpp16::backsub<decltype(kc)::value>(c, rdinv, Rr[decltype(kc)::value]); });
         } else {
             static_rfor<NY - 1>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
@@ -368,6 +369,28 @@ struct IpSolver {
         return c * rdinv;
     }
 
+    // 16-lane groups: N = 2 .. 4 right-hand sides side by side (the transposed solves of the adjoint sensitivity pass) - per right-hand
+    // side the arithmetic of qr_solve, the back-substitution chains interleaved (Dpp16::backsubN)
+    template <int N>
+    __device__ __forceinline__ void qr_solve_n16(const double (&rhs)[N], double (&t)[N]) const {
+        static_assert(G == 16 && N >= 2 && N <= 4, "two to four chains");
+        double c[N];
+        static_for<0, N>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            double a = 0.0;
+            Dpp16::chain<NY>(a, rhs[j], [&](auto rc) { return Qc[decltype(rc)::value]; });
+            c[j] = a * rdinv;
+        });
+        static_rfor<NY - 1>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (k == 0) return;      // (R[l, 0] = 0 in every lane)
+            else if constexpr (N == 4) Dpp16::backsub4<k>(c[0], c[1], c[2], c[3], rdinv, Rr[k]);
+            else if constexpr (N == 3) Dpp16::backsub3<k>(c[0], c[1], c[2], rdinv, Rr[k]);
+            else Dpp16::backsub2<k>(c[0], c[1], rdinv, Rr[k]);
+        });
+        static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; t[j] = c[j] * rdinv; });
+    }
+
     // schur_solve! (schur.jl:93-110): returns temp; x = Ai*(u + B*temp), y = -temp
     // PRE: `v` already is the right-hand side of the QR, CAi*u - v (the sensitivity pass reads it from the table: LinLayout::oGs)
     template <bool PRE = false>
@@ -375,6 +398,9 @@ struct IpSolver {
         const double* tCAi = tab + L.oCAi; const double* tAi = tab + L.oAi; const double* tDy1 = tab + L.oDy1;
         double bq[2] = {0.0, 0.0}, w[2] = {0.0, 0.0}, xx[2] = {0.0, 0.0};
         if constexpr (G == 16) {      // (one chain per operator: see factorize)
+            // (measured and not taken: every operand of the three products requested ahead of the triangular solve / of the residual's
+            //  four products - the extra live registers cost more in copies than the hidden LDS round trips give: iteration of a lone
+            //  wave 7.94 k -> 8.44 k clocks)
             if constexpr (!PRE) Dpp16::chain<NX>(bq[0], u, [&](auto kc) { return tCAi[decltype(kc)::value * G + l]; });
             const double t = qr_solve(PRE ? v : bq[0] - v);
             Dpp16::chain<NY>(w[0], t, [&](auto kc) { return tDy1[decltype(kc)::value * G + l]; });
@@ -472,8 +498,10 @@ struct IpSolver {
         const double* tB = ctab + L.oAiB + i0 * NY + (vy ? l : 0);
         double b[N], z[N];
         static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; b[j] = vy ? tB[j * NY] : 0.0; });
-        if constexpr (G == 16) static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; z[j] = qr_solve(b[j]); });
-        else qr_solve_n<N>(b, z);
+        if constexpr (G == 16) {
+            if constexpr (N >= 2 && N <= 4) qr_solve_n16<N>(b, z);
+            else static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; z[j] = qr_solve(b[j]); });
+        } else qr_solve_n<N>(b, z);
         static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; dst[j * M::RST_LD + l] = z[j]; });
     }
     // (RLDS: the tile holds R during the solves - a trip's rows go to their owner lanes through the staging vectors instead)
@@ -1023,20 +1051,40 @@ __device__ __forceinline__ void serve_knot(const IpParams& p, double* smem, int 
                     if (k < NTH) dth[k] = thv[j] - ctab[L.oTh0 + k];
                 });
                 wave_lds_fence();
-                {   // rthdyn*(th-th0), rthrst*(th-th0): constant per solve
+                {   // rthdyn*(th-th0), rthrst*(th-th0): constant per solve.  Even / odd partial sums (the association of rounds 1-5);
+                    // 16-lane groups: in chunks of eight columns whose 24 operands are requested together and waited for once - the
+                    // rolled loop waited for its own three reads in each of its NTH / 2 trips
                     double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
-                    int k = 0;
-                    for (; k + 1 < NTH; k += 2) {
-                        const double d0 = dth[k], d1 = dth[k + 1];
-                        a0 = fma(ctab[L.oRthDyn + k * G + l], d0, a0);
-                        c0 = fma(ctab[L.oRthRst + k * G + l], d0, c0);
-                        a1 = fma(ctab[L.oRthDyn + (k + 1) * G + l], d1, a1);
-                        c1 = fma(ctab[L.oRthRst + (k + 1) * G + l], d1, c1);
-                    }
-                    for (; k < NTH; ++k) {
-                        const double d0 = dth[k];
-                        a0 = fma(ctab[L.oRthDyn + k * G + l], d0, a0);
-                        c0 = fma(ctab[L.oRthRst + k * G + l], d0, c0);
+                    if constexpr (G == 16) {
+                        constexpr int CHK = 8;
+                        static_for<0, (NTH + CHK - 1) / CHK>([&](auto cc) {
+                            constexpr int k0 = decltype(cc)::value * CHK, n = NTH - k0 < CHK ? NTH - k0 : CHK;
+                            double dv[n], od[n], orr[n];
+                            static_for<0, n>([&](auto jc) {
+                                constexpr int j = decltype(jc)::value;
+                                dv[j] = dth[k0 + j]; od[j] = ctab[L.oRthDyn + (k0 + j) * G + l]; orr[j] = ctab[L.oRthRst + (k0 + j) * G + l];
+                            });
+                            pin_values(dv); pin_values(od); pin_values(orr);
+                            static_for<0, n>([&](auto jc) {
+                                constexpr int j = decltype(jc)::value;
+                                if constexpr (((k0 + j) & 1) == 0) { a0 = fma(od[j], dv[j], a0); c0 = fma(orr[j], dv[j], c0); }
+                                else { a1 = fma(od[j], dv[j], a1); c1 = fma(orr[j], dv[j], c1); }
+                            });
+                        });
+                    } else {
+                        int k = 0;
+                        for (; k + 1 < NTH; k += 2) {
+                            const double d0 = dth[k], d1 = dth[k + 1];
+                            a0 = fma(ctab[L.oRthDyn + k * G + l], d0, a0);
+                            c0 = fma(ctab[L.oRthRst + k * G + l], d0, c0);
+                            a1 = fma(ctab[L.oRthDyn + (k + 1) * G + l], d1, a1);
+                            c1 = fma(ctab[L.oRthRst + (k + 1) * G + l], d1, c1);
+                        }
+                        for (; k < NTH; ++k) {
+                            const double d0 = dth[k];
+                            a0 = fma(ctab[L.oRthDyn + k * G + l], d0, a0);
+                            c0 = fma(ctab[L.oRthRst + k * G + l], d0, c0);
+                        }
                     }
                     S.tthdyn = a0 + a1;
                     S.tthrst = c0 + c1;

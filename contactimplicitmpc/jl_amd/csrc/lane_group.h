@@ -296,6 +296,33 @@ struct Dpp16 {
         double x;
         asm("v_mul_f64 %[x], %[c], %[ri]\n\ts_nop 1\n\t" CIMPC_FMAC_DPP(c, x, nr, k) : [c] "+v"(c), [x] "=&v"(x) : [ri] "v"(rdinv), [nr] "v"(nr), [k] "n"(K));
     }
+    // N (= 2, 3, 4) independent back-substitutions side by side: the N products first, then the N multiply-adds - from N = 3 on every
+    // x_j is two instructions old when its multiply-add reads it through DPP, so the statement needs no wait states between them (one
+    // chain alone: 17 clocks per step, four interleaved: 9 - scripts/ubench/valu_lat.hip).  Per chain the arithmetic of `backsub`.
+    template <int K>
+    static __device__ __forceinline__ void backsub4(double& c0, double& c1, double& c2, double& c3, double rdinv, double nr) {
+        double x0, x1, x2, x3;
+        asm("v_mul_f64 %[x0], %[c0], %[ri]\n\tv_mul_f64 %[x1], %[c1], %[ri]\n\tv_mul_f64 %[x2], %[c2], %[ri]\n\tv_mul_f64 %[x3], %[c3], %[ri]\n\t"
+            CIMPC_FMAC_DPP(c0, x0, nr, k) CIMPC_FMAC_DPP(c1, x1, nr, k) CIMPC_FMAC_DPP(c2, x2, nr, k) CIMPC_FMAC_DPP(c3, x3, nr, k)
+            : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [c3] "+v"(c3), [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3)
+            : [ri] "v"(rdinv), [nr] "v"(nr), [k] "n"(K));
+    }
+    template <int K>
+    static __device__ __forceinline__ void backsub3(double& c0, double& c1, double& c2, double rdinv, double nr) {
+        double x0, x1, x2;
+        asm("v_mul_f64 %[x0], %[c0], %[ri]\n\tv_mul_f64 %[x1], %[c1], %[ri]\n\tv_mul_f64 %[x2], %[c2], %[ri]\n\t"
+            CIMPC_FMAC_DPP(c0, x0, nr, k) CIMPC_FMAC_DPP(c1, x1, nr, k) CIMPC_FMAC_DPP(c2, x2, nr, k)
+            : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2)
+            : [ri] "v"(rdinv), [nr] "v"(nr), [k] "n"(K));
+    }
+    template <int K>
+    static __device__ __forceinline__ void backsub2(double& c0, double& c1, double rdinv, double nr) {
+        double x0, x1;
+        asm("v_mul_f64 %[x0], %[c0], %[ri]\n\tv_mul_f64 %[x1], %[c1], %[ri]\n\ts_nop 0\n\t"
+            CIMPC_FMAC_DPP(c0, x0, nr, k) CIMPC_FMAC_DPP(c1, x1, nr, k)
+            : [c0] "+v"(c0), [c1] "+v"(c1), [x0] "=&v"(x0), [x1] "=&v"(x1)
+            : [ri] "v"(rdinv), [nr] "v"(nr), [k] "n"(K));
+    }
 };
 
 // 1/sqrt(x) and 1/x to ~1 ulp from the hardware seeds (v_rsq_f64 / v_rcp_f64) and two
