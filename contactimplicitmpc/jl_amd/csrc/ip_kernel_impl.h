@@ -203,8 +203,8 @@ struct IpSolver {
 
     // rzlin! + schur_factorize! + MGS factorize!.  Right-looking order: per column exactly
     // the arithmetic of the reference's left-looking loop (qr.jl:113-137); dot products use
-    // one running sum on 16-lane groups (wider groups: four partial sums), 1/|a_k| comes from v_rsq_f64 + two Newton steps on the
-    // broadcast self-product of column k.
+    // one running sum (the order of the reference's loop), 1/|a_k| comes from v_rsq_f64 + two Newton steps on the broadcast
+    // self-product of column k.
     // TR (adjoint sensitivity pass, Model::ADJ): factorizes the TRANSPOSE of the Schur matrix (lane l reads row l of the block
     // instead of column l; its padded leading dimension keeps both free of bank conflicts) - qr_solve then solves with M^T.
     template <bool TR = false>
@@ -253,7 +253,7 @@ struct IpSolver {
         if constexpr (FUSED) Dpp16::dots<0, NY>(dnext, Qc);
         static_for<0, NY>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            double acc[1] = {0.0};
             [[maybe_unused]] double ak[G == 16 ? 1 : NY];     // 32-lane groups: column k read once from the staging buffer, used twice
             if constexpr (FUSED) {
                 acc[0] = dnext;
@@ -269,10 +269,10 @@ struct IpSolver {
                 static_for<0, NY>([&](auto ic) {
                     constexpr int r = decltype(ic)::value;
                     ak[r] = src[r];
-                    acc[r & 3] = fma(ak[r], Qc[r], acc[r & 3]);
+                    acc[0] = fma(ak[r], Qc[r], acc[0]);      // (one running sum here too: the reference loop's order)
                 });
             }
-            const double dot = G == 16 ? acc[0] : (acc[0] + acc[1]) + (acc[2] + acc[3]);     // a_k . a_l
+            const double dot = acc[0];     // a_k . a_l
             // |a_k|^2 is lane k's own dot product (there a_k[r] * a_k[r], the same sum a separate
             // norm loop would form): one broadcast instead of 16 multiply-adds per step
             const double invk = fast_rsqrt(LG::template bcast<k>(dot));
@@ -342,17 +342,17 @@ struct IpSolver {
 
     // t = R^-1 Q^T rhs  (qr_solve!, qr.jl:142-158); rhs lane-indexed
     __device__ __forceinline__ double qr_solve(double rhs) const {
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        double acc = 0.0;
         if constexpr (G == 16) {
-            Dpp16::chain<NY>(acc[0], rhs, [&](auto rc) { return Qc[decltype(rc)::value]; });      // (one chain: see factorize)
+            Dpp16::chain<NY>(acc, rhs, [&](auto rc) { return Qc[decltype(rc)::value]; });      // (one chain: see factorize)
         } else {
             stage(rhs);
             static_for<0, NY>([&](auto ic) {
                 constexpr int r = decltype(ic)::value;
-                acc[r & 3] = fma(Qc[r], bv[r], acc[r & 3]);
+                acc = fma(Qc[r], bv[r], acc);
             });
         }
-        double c = (G == 16 ? acc[0] : (acc[0] + acc[1]) + (acc[2] + acc[3])) * rdinv;   // (Q^T rhs)_l, Q = Qc * rdinv
+        double c = acc * rdinv;   // (Q^T rhs)_l, Q = Qc * rdinv
         // back-substitution, row l of R in this lane: x_k = c_k / R[k,k] broadcast, c_l -= R[l,k] x_k (k > l).  Lane l's c is
         // final once step k = l + 1 is done (R[l,k] = 0 for k <= l), so x_l = c * rdinv after the loop - the same product
         // the reference forms at step l (qr.jl:150-157).
@@ -362,8 +362,10 @@ struct IpSolver {
         } else {
             static_rfor<NY - 1>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
-                const double xk = LG::template bcast<k>(c * rdinv);
-                c = fma(r_entry<k>(), xk, c);
+                if constexpr (k > 0) {
+                    const double xk = LG::template bcast<k>(c * rdinv);
+                    c = fma(r_entry<k>(), xk, c);
+                }
             });
         }
         return c * rdinv;
@@ -396,7 +398,7 @@ struct IpSolver {
     template <bool PRE = false>
     __device__ __forceinline__ double schur_solve(double u, double v, double& xs) const {
         const double* tCAi = tab + L.oCAi; const double* tAi = tab + L.oAi; const double* tDy1 = tab + L.oDy1;
-        double bq[2] = {0.0, 0.0}, w[2] = {0.0, 0.0}, xx[2] = {0.0, 0.0};
+        double bq[1] = {0.0}, w[1] = {0.0}, xx[1] = {0.0};
         if constexpr (G == 16) {      // (one chain per operator: see factorize)
             // (measured and not taken: every operand of the three products requested ahead of the triangular solve / of the residual's
             //  four products - the extra live registers cost more in copies than the hidden LDS round trips give: iteration of a lone
@@ -413,22 +415,22 @@ struct IpSolver {
             stage(u);
             static_for<0, NX>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
-                bq[k & 1] = fma(tCAi[k * G + l], bv[k], bq[k & 1]);
+                bq[0] = fma(tCAi[k * G + l], bv[k], bq[0]);
             });
         }
-        const double t = qr_solve(PRE ? v : (bq[0] + bq[1]) - v);
+        const double t = qr_solve(PRE ? v : bq[0] - v);
         stage(t);
         static_for<0, NY>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            w[k & 1] = fma(tDy1[k * G + l], bv[k], w[k & 1]);
+            w[0] = fma(tDy1[k * G + l], bv[k], w[0]);
         });
-        const double ww = u + (w[0] + w[1]);
+        const double ww = u + w[0];
         stage(ww);
         static_for<0, NX>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            xx[k & 1] = fma(tAi[k * G + l], bv[k], xx[k & 1]);
+            xx[0] = fma(tAi[k * G + l], bv[k], xx[0]);
         });
-        xs = xx[0] + xx[1];
+        xs = xx[0];
         return t;
     }
 
@@ -445,17 +447,18 @@ struct IpSolver {
     }
     template <int N>
     __device__ __forceinline__ void qr_solve_n(const double (&rhs)[N], double (&t)[N]) const {
-        double a[N][4];
-        static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j][0] = a[j][1] = a[j][2] = a[j][3] = 0.0; });
+        double a[N];
+        static_for<0, N>([&](auto jc) { a[decltype(jc)::value] = 0.0; });
         stage_n<N>(rhs);
         static_for<0, NY>([&](auto ic) {
             constexpr int r = decltype(ic)::value;
-            static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j][r & 3] = fma(Qc[r], bv[j * G + r], a[j][r & 3]); });
+            static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j] = fma(Qc[r], bv[j * G + r], a[j]); });
         });
         double c[N];
-        static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; c[j] = ((a[j][0] + a[j][1]) + (a[j][2] + a[j][3])) * rdinv; });
+        static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; c[j] = a[j] * rdinv; });
         static_rfor<NY - 1>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
+            if constexpr (k == 0) return;      // (R[l, 0] = 0 in every lane)
             const double rk = r_entry<k>();
             static_for<0, N>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
@@ -470,22 +473,22 @@ struct IpSolver {
     __device__ __forceinline__ void schur_solve_n(const double (&u)[N], const double (&g)[N], double (&t)[N], double (&xs)[N]) const {
         const double* tAi = tab + L.oAi; const double* tDy1 = tab + L.oDy1;
         qr_solve_n<N>(g, t);
-        double w[N][2], x[N][2], ww[N];
-        static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; w[j][0] = w[j][1] = x[j][0] = x[j][1] = 0.0; });
+        double w[N], x[N], ww[N];
+        static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; w[j] = x[j] = 0.0; });
         stage_n<N>(t);
         static_for<0, NY>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             const double d = tDy1[k * G + l];
-            static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; w[j][k & 1] = fma(d, bv[j * G + k], w[j][k & 1]); });
+            static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; w[j] = fma(d, bv[j * G + k], w[j]); });
         });
-        static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; ww[j] = u[j] + (w[j][0] + w[j][1]); });
+        static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; ww[j] = u[j] + w[j]; });
         stage_n<N>(ww);
         static_for<0, NX>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             const double a_ = tAi[k * G + l];
-            static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; x[j][k & 1] = fma(a_, bv[j * G + k], x[j][k & 1]); });
+            static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; x[j] = fma(a_, bv[j * G + k], x[j]); });
         });
-        static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; xs[j] = x[j][0] + x[j][1]; });
+        static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; xs[j] = x[j]; });
     }
 
     // ---- adjoint form of the sensitivity pass (Model::ADJ; after factorize<true>, the QR of M^T) ---------------------------
