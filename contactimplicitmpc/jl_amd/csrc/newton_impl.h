@@ -307,7 +307,10 @@ __device__ __forceinline__ void start_line_search(const NewtonDev& S, int b, int
         enqueue_evals(S, sb0, n, b, par, lane, nt, S.kkt_same_round == 0 ? 2 : 1);
         if (lane == 0) {
             for (int c = n; c < CS; ++c) S.need_sweep[sb0 + c] = 0;
-            if (S.kkt_same_round != 2) atomicAdd(&S.counters[0 * CPAD], 1);
+            // (counter 0 = rollouts that need a sweep in the NEXT round: only the overlapped KKT kernel requests one there.  With the KKT
+            //  stage in the same round as the evaluation of its candidates - small batches - the count made the host launch one more,
+            //  empty round after the decision that ended a solve: three launches, ~40 us of a 0.55 ms single-rollout solve)
+            if (S.kkt_same_round == 0) atomicAdd(&S.counters[0 * CPAD], 1);
         }
     }
 }

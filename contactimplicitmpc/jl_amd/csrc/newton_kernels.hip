@@ -472,24 +472,22 @@ __global__ __launch_bounds__(256) void solve_finish_kernel(NewtonDev S, double* 
 // Flush of the lazily committed sensitivities (NewtonDev::good_src) at the end of a solve: the blocks an accept left in the
 // evaluation slots of a rollout that had no KKT stage afterwards (it converged, ran out of iterations, or the solve was cut
 // short) move to dz_good; afterwards every index is -1 and dz_good is what rounds 3-5 kept at all times.
+// (one workgroup per (rollout, step): with one per rollout a lone rollout's 105 KB went through 256 threads in 52 dependent trips -
+//  22 us at the end of every B = 1 solve)
 __global__ __launch_bounds__(256) void dz_commit_kernel(NewtonDev S) {
-    __shared__ int src[128];
-    const int b = blockIdx.x, tid = threadIdx.x, H = S.dm.H;
+    const int b = blockIdx.x, i = blockIdx.y, tid = threadIdx.x, H = S.dm.H;
     const int blk = S.nths * S.nd;
-    int any = 0;
-    for (int i = tid; i < H; i += 256) { const int s_ = S.good_src[(size_t)b * H + i]; src[i] = s_; any |= (s_ >= 0); }
-    if (!__syncthreads_or(any)) return;
-    double* good = S.dz_good + (size_t)b * H * blk;
-    const double* slots = S.dz + (size_t)b * CS * H * blk;
-    for (int e = tid; e < H * blk; e += 256) {
-        const int i = e / blk, s_ = src[i];
-        if (s_ >= 0) good[e] = slots[((size_t)s_ * H + i) * blk + (e - i * blk)];
-    }
-    for (int i = tid; i < H; i += 256) if (src[i] >= 0) S.good_src[(size_t)b * H + i] = -1;
+    const int s_ = S.good_src[(size_t)b * H + i];      // (uniform: every thread reads the same word)
+    if (s_ < 0) return;
+    double* good = S.dz_good + ((size_t)b * H + i) * blk;
+    const double* slot = S.dz + (((size_t)b * CS + s_) * H + i) * blk;
+    for (int e = tid; e < blk; e += 256) good[e] = slot[e];
+    __syncthreads();                                     // every thread has read the index before it is reset
+    if (tid == 0) S.good_src[(size_t)b * H + i] = -1;
 }
 int launch_dz_commit(const NewtonDev& S, hipStream_t s) {
     if (S.good_src == nullptr) return CIMPC_OK;
-    hipLaunchKernelGGL(dz_commit_kernel, dim3(S.dm.B), dim3(256), 0, s, S);
+    hipLaunchKernelGGL(dz_commit_kernel, dim3(S.dm.B, S.dm.H), dim3(256), 0, s, S);
     return hipGetLastError() == hipSuccess ? CIMPC_OK : CIMPC_ERR_HIP;
 }
 bool kkt_lazy_commit_available(const NewtonDev& S) {      // every KKT stage of the Newton loop runs kkt_body on fp64 tiles (launch_kkt_packed / launch_kkt_t)
