@@ -236,39 +236,48 @@ __device__ __forceinline__ void apply_steps(const NewtonDev& S, size_t sb_first,
     auto put = [&](double* dst, size_t stride, int k, double base, double dl, bool moves) {
         for (int c = 0; c < count; ++c) dst[(size_t)c * stride + k] = moves ? fma(-ls_alpha(it_first + c), dl, base) : base;
     };
-    for (int k = tid; k < (H + 2) * nq; k += nt) {          // q_1, q_2 are fixed by (q0, q1); q_{t+2} moves
+    // UN entries per trip: the sources of all of them are requested before the first store (round 6: one entry per trip made the
+    // 7-candidate start of a deep line search a chain of ~12 dependent load round trips - 22 us in the ten workgroups that set the
+    // length of every decision launch, scripts/resid_prof.py)
+    auto rows = [&](auto unc, int n, double* dst, size_t stride, auto&& src) {
+        constexpr int UN = decltype(unc)::value;
+        for (int e0 = tid; e0 < n; e0 += UN * nt) {
+            double base[UN], dl[UN]; bool mv[UN];
+            static_for<0, UN>([&](auto jc) { constexpr int j = decltype(jc)::value; const int e = e0 + j * nt; src(e < n ? e : 0, base[j], dl[j], mv[j]); });
+            static_for<0, UN>([&](auto jc) { constexpr int j = decltype(jc)::value; const int e = e0 + j * nt; if (e < n) put(dst, stride, e, base[j], dl[j], mv[j]); });
+        }
+    };
+    rows(std::integral_constant<int, 2>{}, (H + 2) * nq, cq, (size_t)(H + 2) * nq, [&](int k, double& base, double& dl, bool& mv) {          // q_1, q_2 are fixed by (q0, q1); q_{t+2} moves
         const int j = k / nq, c = k - j * nq;
-        put(cq, (size_t)(H + 2) * nq, k, tq[k], j >= 2 ? D[(j - 2) * nr + oq + c] : 0.0, j >= 2);
-    }
-    for (int k = tid; k < H * nu; k += nt) {
+        base = tq[k]; mv = j >= 2; dl = mv ? D[(j - 2) * nr + oq + c] : 0.0;
+    });
+    rows(std::integral_constant<int, 2>{}, H * nu, cu, (size_t)H * nu, [&](int k, double& base, double& dl, bool& mv) {
         const int t = k / nu, c = k - t * nu;
-        put(cu, (size_t)H * nu, k, tu[k], D[t * nr + c], true);
-    }
+        base = tu[k]; dl = D[t * nr + c]; mv = true;
+    });
     if (cf) {
         const double* __restrict__ tg = S.traj.g + (size_t)b * H * m.nc;
         const double* __restrict__ tb = S.traj.b + (size_t)b * H * m.nb;
         for (int k = tid; k < H * m.nc; k += nt) { const int t = k / m.nc, c = k - t * m.nc; put(S.cand.g + sb_first * H * m.nc, (size_t)H * m.nc, k, tg[k], D[t * nr + nu + c], true); }
         for (int k = tid; k < H * m.nb; k += nt) { const int t = k / m.nb, c = k - t * m.nb; put(S.cand.b + sb_first * H * m.nb, (size_t)H * m.nb, k, tb[k], D[t * nr + nu + m.nc + c], true); }
     }
-    for (int k = tid; k < H * nd; k += nt) put(cnu, (size_t)H * nd, k, tnu[k], D[H * nr + k], true);
-    for (int k = tid; k < H * nth; k += nt) {               // update_theta!: th_t = [q_t; q_{t+1}; u_t; w_t; mu; h]
+    rows(std::integral_constant<int, 2>{}, H * nd, cnu, (size_t)H * nd, [&](int k, double& base, double& dl, bool& mv) { base = tnu[k]; dl = D[H * nr + k]; mv = true; });
+    rows(std::integral_constant<int, 3>{}, H * nth, cth, (size_t)H * nth, [&](int k, double& base, double& dl, bool& mv) {               // update_theta!: th_t = [q_t; q_{t+1}; u_t; w_t; mu; h]
         const int t = k / nth, c = k - t * nth;
-        double base, dl = 0.0;
-        bool moves = false;
+        dl = 0.0; mv = false;
         if (c < 2 * nq) {
             const int j = t + (c >= nq ? 1 : 0), cc = c >= nq ? c - nq : c;
             base = tq[j * nq + cc];
-            moves = j >= 2;
-            dl = moves ? D[(j - 2) * nr + oq + cc] : 0.0;
+            mv = j >= 2;
+            dl = mv ? D[(j - 2) * nr + oq + cc] : 0.0;
         } else if (c < 2 * nq + nu) {
-            base = tu[t * nu + (c - 2 * nq)]; dl = D[t * nr + (c - 2 * nq)]; moves = true;
+            base = tu[t * nu + (c - 2 * nq)]; dl = D[t * nr + (c - 2 * nq)]; mv = true;
         } else if (c < 2 * nq + nu + nw) {
             base = tw[t * nw + (c - 2 * nq - nu)];
         } else {
             base = tth[k];
         }
-        put(cth, (size_t)H * nth, k, base, dl, moves);
-    }
+    });
     Sync::sync();
 }
 
