@@ -420,3 +420,36 @@ def test_async_twisted_kkt_job_timeout_is_served_one_ended(monkeypatch):
     assert np.abs(got2[1] - ref_warm[1]).max() <= 1
     assert np.isfinite(got2[0]).all() and np.isfinite(got2[3]["q"]).all()
     s.close()
+
+
+def test_twisted_solves_next_to_a_saturating_foreign_kernel(monkeypatch):
+    """the twisted chains' hand-over relies on both workgroups of a rollout being resident.  Here the device is kept
+    busy by a foreign workload on another stream (a queue of large fp64 matrix products from torch) while warm-started Newton solves of
+    three rollouts run their KKT stages on the twisted kernel: every result must be finite and equal to the one-ended kernels' - whether
+    the chains met in time or a hand-over timed out and the stage was repeated one-ended (counted, never NaN)."""
+    import torch
+    from contactimplicitmpc.jl_amd import NewtonOptions
+    H, H_ref, B = 28, 30, 3
+    d, prob, rollouts, obj = _tw_case("quadruped", H, H_ref, B)
+    opts = NewtonOptions(kappa=prob["kappa"], r_tol=1e-6, max_iter=3)
+    monkeypatch.setenv("CIMPC_KKT_TWISTED", "0")
+    s0 = make_solver(d, prob, rollouts, H, obj=obj, newton_opts=opts)
+    ref = [_newton(s0, rollouts)] + [_newton(s0, rollouts, warm=True) for _ in range(3)]
+    s0.close()
+    monkeypatch.setenv("CIMPC_KKT_TWISTED", "1")
+    s = make_solver(d, prob, rollouts, H, obj=obj, newton_opts=opts)
+    a = torch.randn(6144, 6144, dtype=torch.float64, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(12):                     # ~1 s of queued foreign work: every CU busy while the solves run
+            a = (a @ a) * 1e-4
+    got = [_newton(s, rollouts)] + [_newton(s, rollouts, warm=True) for _ in range(3)]
+    busy = not side.query()                     # (the foreign queue outlived the solves: they did run next to it)
+    torch.cuda.synchronize()
+    assert s.kkt_twisted() > 0
+    for g, r in zip(got, ref):
+        assert np.isfinite(g[0]).all() and np.isfinite(g[2]).all() and np.isfinite(g[3]["q"]).all()
+        assert np.abs(g[1].astype(int) - r[1].astype(int)).max() <= 1
+        np.testing.assert_allclose(g[0], r[0], rtol=0, atol=1e-5 * max(1.0, np.abs(r[0]).max()))
+    assert busy, "the foreign workload finished before the solves did - enlarge it"
+    s.close()
