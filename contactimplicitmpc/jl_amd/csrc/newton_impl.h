@@ -236,7 +236,9 @@ __device__ __forceinline__ void apply_steps(const NewtonDev& S, size_t sb_first,
     auto put = [&](double* dst, size_t stride, int k, double base, double dl, bool moves) {
         for (int c = 0; c < count; ++c) dst[(size_t)c * stride + k] = moves ? fma(-ls_alpha(it_first + c), dl, base) : base;
     };
-    // UN entries per trip: the sources of all of them are requested before the first store (round 6: one entry per trip made the
+    // UN entries per trip (sized so that 192-256 threads cover a quadruped H = 40 array in ONE trip): the sources of all of them are
+    // requested before the first store - one array after the other: with all four arrays gathered in one pass the KKT chains this
+    // function is inlined into lost 6 us to register pressure (scripts/dbg/twisted_prof.py) - (round 6: one entry per trip made the
     // 7-candidate start of a deep line search a chain of ~12 dependent load round trips - 22 us in the ten workgroups that set the
     // length of every decision launch, scripts/resid_prof.py)
     auto rows = [&](auto unc, int n, double* dst, size_t stride, auto&& src) {
@@ -247,7 +249,7 @@ __device__ __forceinline__ void apply_steps(const NewtonDev& S, size_t sb_first,
             static_for<0, UN>([&](auto jc) { constexpr int j = decltype(jc)::value; const int e = e0 + j * nt; if (e < n) put(dst, stride, e, base[j], dl[j], mv[j]); });
         }
     };
-    rows(std::integral_constant<int, 2>{}, (H + 2) * nq, cq, (size_t)(H + 2) * nq, [&](int k, double& base, double& dl, bool& mv) {          // q_1, q_2 are fixed by (q0, q1); q_{t+2} moves
+    rows(std::integral_constant<int, 3>{}, (H + 2) * nq, cq, (size_t)(H + 2) * nq, [&](int k, double& base, double& dl, bool& mv) {          // q_1, q_2 are fixed by (q0, q1); q_{t+2} moves
         const int j = k / nq, c = k - j * nq;
         base = tq[k]; mv = j >= 2; dl = mv ? D[(j - 2) * nr + oq + c] : 0.0;
     });
@@ -261,8 +263,8 @@ __device__ __forceinline__ void apply_steps(const NewtonDev& S, size_t sb_first,
         for (int k = tid; k < H * m.nc; k += nt) { const int t = k / m.nc, c = k - t * m.nc; put(S.cand.g + sb_first * H * m.nc, (size_t)H * m.nc, k, tg[k], D[t * nr + nu + c], true); }
         for (int k = tid; k < H * m.nb; k += nt) { const int t = k / m.nb, c = k - t * m.nb; put(S.cand.b + sb_first * H * m.nb, (size_t)H * m.nb, k, tb[k], D[t * nr + nu + m.nc + c], true); }
     }
-    rows(std::integral_constant<int, 2>{}, H * nd, cnu, (size_t)H * nd, [&](int k, double& base, double& dl, bool& mv) { base = tnu[k]; dl = D[H * nr + k]; mv = true; });
-    rows(std::integral_constant<int, 3>{}, H * nth, cth, (size_t)H * nth, [&](int k, double& base, double& dl, bool& mv) {               // update_theta!: th_t = [q_t; q_{t+1}; u_t; w_t; mu; h]
+    rows(std::integral_constant<int, 3>{}, H * nd, cnu, (size_t)H * nd, [&](int k, double& base, double& dl, bool& mv) { base = tnu[k]; dl = D[H * nr + k]; mv = true; });
+    rows(std::integral_constant<int, 8>{}, H * nth, cth, (size_t)H * nth, [&](int k, double& base, double& dl, bool& mv) {               // update_theta!: th_t = [q_t; q_{t+1}; u_t; w_t; mu; h]
         const int t = k / nth, c = k - t * nth;
         dl = 0.0; mv = false;
         if (c < 2 * nq) {
