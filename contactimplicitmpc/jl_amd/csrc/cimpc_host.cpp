@@ -379,6 +379,8 @@ int run_sweep(cimpc_ctx* h, int par, int* pending_counter, double* zout, hipStre
     // (round 4, measured and removed: one sweep workgroup per CU in rounds with few problems - <= 4 k / 8 k / 16 k - so that every
     //  wave has its SIMD to itself: 7.97 -> 7.96 / 7.99 / 8.01 ms per step, no effect: profiles/r04/knob_small_round.log)
     if (with_products && h->S.dtn != nullptr) { p.nu = h->S.nu_cand; p.dtn = h->S.dtn; }
+    // single rollouts (B < 4: at most 7 B problems per knot): one workgroup per knot, no remaining-work scans (IpParams::direct)
+    if (h->dm.B < 4 && h->kn.sweep_wgs <= 0) { p.direct = 1; p.wpk = h->dm.H_ref; }
     if (iter_cap > 0) p.iter_cap = iter_cap;
     if (drain_counter != nullptr && h->kn.drain_pct > 0 && p.iter_cap < h->ip.max_iter) {
         p.drain_count = drain_counter;

@@ -185,6 +185,8 @@ struct IpParams {
     // per-solve time budget (cimpc_ip_opts::max_time) in ticks of the constant-rate device clock; 0 = unlimited (no clock read)
     long long budget_ticks;
     int generic_static;    // runtime-dimension sweep (ip_generic.hip): 1 = static partition of a knot's queue instead of the dynamic pull
+    int direct;            // 1: workgroup k serves knot k's queue and leaves (launches of single rollouts: at most a handful of problems per knot -
+                           // the two remaining-work scans of the persistent form, ~3 us each, are a tenth of such a launch); grid = K
     AsyncQ A;
 };
 

@@ -1211,6 +1211,11 @@ __global__ __launch_bounds__(M::G == 16 ? CIMPC_SWEEP_THREADS : (M::WIDE ? 512 :
     __builtin_amdgcn_s_setprio(CIMPC_SWEEP_PRIO);
     [[maybe_unused]] long long sp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     [[maybe_unused]] const long long sp_life = SPROF_T();
+    if (p.direct) {      // single rollouts: workgroup k = knot k, no remaining-work scan before or after (IpParams::direct)
+        const int knot = (int)blockIdx.x;
+        if (knot < p.Q.K && aload(qcount(p.Q, p.Q.par, knot)) > 0) serve_knot<M, false>(p, smem, knot, tid, sp);
+        return;
+    }
     while (true) {
         [[maybe_unused]] const long long sp_t = SPROF_T();
         __syncthreads();            // every wave is done with the staged table
