@@ -14,57 +14,7 @@ extern "C" int cimpc_debug_sweep_prof(unsigned long long* out16) {
 #endif
 
 #ifdef CIMPC_UBENCH
-// diagnostic builds only (-DCIMPC_UBENCH, scripts/dbg/ubench_ip.py): shader-clock cost of the interior-point primitives on `waves`
-// wavefronts of ONE workgroup (4 problems per wave, the same problem in every group) - what a lone wave pays per call, i.e. the
-// latency chain the small batches, the launch tails and the asynchronous solve run on.
-namespace cimpc {
-template <class M>
-__global__ __launch_bounds__(256, 2) void ip_ubench_kernel(const double* tabs, cimpc_ip_opts o, int reps, long long* out) {
-    constexpr LinLayout L(M::NX, M::NY, M::NTH, M::G, M::NTHS, M::ADJ);
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int tid = (int)threadIdx.x, grp = tid / M::G, l = tid % M::G;
-    stage_table<M>(smem, tabs, 0, tid);
-    __syncthreads();
-    IpSolver<M> S;
-    S.bind(smem, smem + L.hot + (size_t)grp * M::LDS_GROUP, l);
-    S.x = S.vx ? S.x0 : 0.0; S.y1 = 1.0; S.y2 = 1.0;
-    long long t[8];
-    double sink = 0.0;
-    auto opaque = [&] { asm volatile("" : "+v"(S.x), "+v"(S.y1), "+v"(S.y2)); };
-    t[0] = (long long)__builtin_amdgcn_s_memtime();
-#pragma unroll 1
-    for (int r = 0; r < reps; ++r) { S.residual(1e-3); sink += S.rdyn + S.rrst; opaque(); }
-    t[1] = (long long)__builtin_amdgcn_s_memtime();
-#pragma unroll 1
-    for (int r = 0; r < reps; ++r) { sink += S.r_violation() + S.k_violation(); S.rdyn += 1e-30; opaque(); }
-    t[2] = (long long)__builtin_amdgcn_s_memtime();
-#pragma unroll 1
-    for (int r = 0; r < reps; ++r) { S.factorize(1e-9); sink += S.rdinv; S.y1 += 1e-30 * S.rdinv; opaque(); }
-    t[3] = (long long)__builtin_amdgcn_s_memtime();
-#pragma unroll 1
-    for (int r = 0; r < reps; ++r) { S.linear_solve(); sink += S.Dx_ + S.Dy1_; S.rdyn += 1e-30 * S.Dx_; opaque(); }
-    t[4] = (long long)__builtin_amdgcn_s_memtime();
-#pragma unroll 1
-    for (int r = 0; r < reps; ++r) { sink += S.step_length(0.99); S.Dy1_ += 1e-30; opaque(); }
-    t[5] = (long long)__builtin_amdgcn_s_memtime();
-    double reg = 0.0, r_vio = 1.0, k_vio = 1.0;
-    S.x = S.vx ? S.x0 : 0.0; S.y1 = 1.0; S.y2 = 1.0;
-    S.residual(0.0); r_vio = S.r_violation(); k_vio = S.k_violation();
-    int its = 0;
-#pragma unroll 1
-    for (int r = 0; r < reps; ++r) {
-        if (r_vio < o.r_tol && k_vio < o.kappa_tol) { S.x = S.vx ? S.x0 : 0.0; S.y1 = 1.0; S.y2 = 1.0; S.residual(0.0); r_vio = S.r_violation(); k_vio = S.k_violation(); }
-        (void)S.iterate(o, o.kappa_tol / o.undercut, 1.0 - o.eps_min, reg, r_vio, k_vio);
-        ++its;
-    }
-    t[6] = (long long)__builtin_amdgcn_s_memtime();
-    if ((tid & 63) == 0) {
-        long long* w = out + 8 * (tid >> 6);
-        for (int k = 0; k < 6; ++k) w[k] = t[k + 1] - t[k];
-        w[6] = its; w[7] = (long long)(sink * 1e-300);
-    }
-}
-}  // namespace cimpc
+// diagnostic builds only (-DCIMPC_UBENCH, scripts/dbg/ubench_ip.py): see ip_kernel_impl.h: ip_ubench_kernel
 extern "C" int cimpc_ubench_ip_quadruped(const double* tabs_dev, const cimpc_ip_opts* o, int waves, int reps, long long* out_host) {
     using M = cimpc::Model<11, 8, 2, 4, 8, 0>;
     constexpr cimpc::LinLayout L(M::NX, M::NY, M::NTH, M::G, M::NTHS, M::ADJ);
