@@ -254,7 +254,8 @@ struct IpSolver {
         static_for<0, NY>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             double acc[1] = {0.0};
-            [[maybe_unused]] double ak[G == 16 ? 1 : NY];     // 32-lane groups: column k read once from the staging buffer, used twice
+            constexpr int NCH = (NY + 15) / 16;
+            [[maybe_unused]] double akc[NCH];      // wide groups: this lane's share of column k (entry (l & 15) of every chunk of 16 rows)
             if constexpr (FUSED) {
                 acc[0] = dnext;
             } else if constexpr (G == 16) {
@@ -265,11 +266,19 @@ struct IpSolver {
                 Dpp16::dots<k, NY>(acc[0], Qc);
             } else {
                 wave_lds_fence();
+                // Round 6: every 16-lane ROW picks the column up spread over its lanes - lane i of a row holds entries i, 16 + i, ... (one
+                // ds_read_b64 per chunk of 16 rows) - and the multiply-adds take their entry through DPP row_newbcast, as the 16-lane form
+                // does: 2-3 LDS reads per step and wave instead of NY / 2 broadcast ds_read_b128 (a broadcast costs the LDS pipe what a
+                // full-width read costs: the 32-lane factorization slowed down with every wave added to the CU, scripts/dbg/ubench_ip.py).
+                // Same products, same order: bit-identical.
                 const double* src = bc + (k & 1) * G;
-                static_for<0, NY>([&](auto ic) {
-                    constexpr int r = decltype(ic)::value;
-                    ak[r] = src[r];
-                    acc[0] = fma(ak[r], Qc[r], acc[0]);      // (one running sum here too: the reference loop's order)
+                static_for<0, NCH>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value, n = NY - 16 * j < 16 ? NY - 16 * j : 16;
+                    akc[j] = src[16 * j + ((lq & 15) < n ? (lq & 15) : 0)];
+                });
+                static_for<0, NCH>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value, n = NY - 16 * j < 16 ? NY - 16 * j : 16;
+                    Dpp16::chain<n>(acc[0], akc[j], [&](auto ic) { return Qc[16 * j + decltype(ic)::value]; });      // (one running sum here too: the reference loop's order)
                 });
             }
             const double dot = acc[0];     // a_k . a_l
@@ -288,9 +297,9 @@ struct IpSolver {
             } else if constexpr (G == 16) {
                 Dpp16::self<k, NY>(Qc, ncoef);       // a_l -= (r_kl / |a_k|) a_k
             } else {
-                static_for<0, NY>([&](auto ic) {
-                    constexpr int r = decltype(ic)::value;
-                    Qc[r] = fma(ncoef, ak[r], Qc[r]);
+                static_for<0, NCH>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value, n = NY - 16 * j < 16 ? NY - 16 * j : 16;
+                    Dpp16::outer_at<n, 16 * j>(Qc, akc[j], ncoef);
                 });
                 if constexpr (k + 1 < NY) {       // column k + 1 is final: its owner publishes it for the next step
                     double* dst = bc + ((k + 1) & 1) * G;

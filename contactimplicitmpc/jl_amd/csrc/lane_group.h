@@ -251,6 +251,26 @@ struct Dpp16 {
             outer<N - C, I0 + C>(a, v, t);
         }
     }
+    // ---- a[A0 + i] += bcast<B0 + i>(v) * t, i = 0..N-1: `outer` on a window of a longer register array (wide lane groups: chunk j of a column
+    //      that every 16-lane row holds spread over its lanes - IpSolver::factorize)
+    template <int A0, int B0, int NA, int... I>
+    static __device__ __forceinline__ void outer_at_c(double (&a)[NA], double v, double t, std::integer_sequence<int, I...>) {
+        constexpr int C = sizeof...(I);
+        if constexpr (C == 16) Dpp16Gen::outer16<B0>(a[A0 + I]..., v, t);
+        else if constexpr (C == 8) Dpp16Gen::outer8<B0>(a[A0 + I]..., v, t);
+        else if constexpr (C == 4) Dpp16Gen::outer4<B0>(a[A0 + I]..., v, t);
+        else if constexpr (C == 3) Dpp16Gen::outer3<B0>(a[A0 + I]..., v, t);
+        else if constexpr (C == 2) Dpp16Gen::outer2<B0>(a[A0 + I]..., v, t);
+        else Dpp16Gen::outer1<B0>(a[A0 + I]..., v, t);
+    }
+    template <int N, int A0, int B0 = 0, int NA>
+    static __device__ __forceinline__ void outer_at(double (&a)[NA], double v, double t) {
+        if constexpr (N > 0) {
+            constexpr int C = dpp_chunk<N>();
+            outer_at_c<A0, B0>(a, v, t, std::make_integer_sequence<int, C>{});
+            outer_at<N - C, A0 + C, B0 + C>(a, v, t);
+        }
+    }
     // ---- s += bcast<k>(v) * T(k), k = 0..N-1 in this order: ONE chain, the association of a plain loop -----------------------
     template <int K0, class TF, int... I>
     static __device__ __forceinline__ void chain_c(double& s, double v, TF& T, std::integer_sequence<int, I...>) {
