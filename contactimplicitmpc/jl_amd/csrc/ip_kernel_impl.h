@@ -169,6 +169,39 @@ struct IpSolver {
         wave_lds_fence();
     }
 
+    // 32-lane groups (round 6): a lane-indexed vector as two ROW-SPREAD chunks - entries 0..15 and 16..31 in the lanes of EVERY 16-lane row
+    // of the group (two v_permlane16_swap: the even row's and the odd row's registers in both rows) - so that a matrix-vector product
+    // takes its vector entry through DPP row_newbcast like the 16-lane form, without the LDS staging vector (a broadcast ds_read_b128
+    // costs the LDS pipe what a full-width read costs, and the pipe is what bounds this form).  Same products in the same order.
+    __device__ __forceinline__ void spread32(double v, double& c0, double& c1) const {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto r0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto r1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        c0 = __hiloint2double((int)r1[0], (int)r0[0]);
+        c1 = __hiloint2double((int)r1[1], (int)r0[1]);
+    }
+    // acc += sum_k v_k T(k), k = 0 .. N-1 ascending (T: callable on std::integral_constant<int, k>)
+    template <int N, class TF>
+    __device__ __forceinline__ void mv32(double& acc, double v, TF&& T) const {
+        static_assert(G == 32 && N <= 32, "two row-spread chunks");
+        double c0, c1;
+        spread32(v, c0, c1);
+        // (statements of four: the throughput build runs at 256 registers - sixteen table operands at once spilled 333 of them)
+        Dpp16::chain<(N < 16 ? N : 16), 0, 4>(acc, c0, [&](auto kc) { return T(kc); });
+        if constexpr (N > 16) Dpp16::chain<N - 16, 0, 4>(acc, c1, [&](auto kc) { return T(std::integral_constant<int, 16 + decltype(kc)::value>{}); });
+    }
+    // a += sum_k v_k TA(k), c += sum_k v_k TC(k): two operators on one vector
+    template <int N, class TA, class TC>
+    __device__ __forceinline__ void pair32(double& a, double& c, double v, TA&& ta, TC&& tc) const {
+        static_assert(G == 32 && N <= 32, "two row-spread chunks");
+        double c0, c1;
+        spread32(v, c0, c1);
+        Dpp16::pair<(N < 16 ? N : 16), 0, 4>(a, c, c0, [&](auto kc) { return ta(kc); }, [&](auto kc) { return tc(kc); });
+        if constexpr (N > 16)
+            Dpp16::pair<N - 16, 0, 4>(a, c, c1, [&](auto kc) { return ta(std::integral_constant<int, 16 + decltype(kc)::value>{}); },
+                                [&](auto kc) { return tc(std::integral_constant<int, 16 + decltype(kc)::value>{}); });
+    }
+
     // rlin! (linearized_solver.jl:364-373), same association as the reference expression
     __device__ __forceinline__ void residual(double kappa) {
         const double* tDx = tab + L.oDx; const double* tRx = tab + L.oRx;
@@ -178,6 +211,9 @@ struct IpSolver {
         if constexpr (G == 16) {       // broadcast fused into the multiply-add (lane_group.h: Dpp16), same summation order
             Dpp16::pair<NX>(a, c, dx, [&](auto kc) { return tDx[decltype(kc)::value * G + l]; }, [&](auto kc) { return tRx[decltype(kc)::value * G + l]; });
             Dpp16::pair<NY>(bb, e, dy1, [&](auto kc) { return tDy1[decltype(kc)::value * G + l]; }, [&](auto kc) { return tRy1[decltype(kc)::value * G + l]; });
+        } else if constexpr (G == 32) {
+            pair32<NX>(a, c, dx, [&](auto kc) { return tDx[decltype(kc)::value * G + l]; }, [&](auto kc) { return tRx[decltype(kc)::value * G + l]; });
+            pair32<NY>(bb, e, dy1, [&](auto kc) { return tDy1[decltype(kc)::value * G + l]; }, [&](auto kc) { return tRy1[decltype(kc)::value * G + l]; });
         } else {
             stage(dx);
             static_for<0, NX>([&](auto kc) {
@@ -355,6 +391,8 @@ struct IpSolver {
         if constexpr (G == 16) {
             Dpp16::chain<NY>(acc, rhs, [&](auto rc) { return Qc[decltype(rc)::value]; });      // (one chain: see factorize)
         } else {
+            // (32-lane groups: this product keeps the staging vector - with the row-spread form here AND in schur_solve the throughput
+            //  build spilled 320 registers; of the two placements this one measured better: iteration 40.2 k -> 36.7 k clocks at eight waves)
             stage(rhs);
             static_for<0, NY>([&](auto ic) {
                 constexpr int r = decltype(ic)::value;
@@ -420,6 +458,15 @@ struct IpSolver {
             xs = xx[0];
             return t;
         }
+        if constexpr (G == 32) {
+            if constexpr (!PRE) mv32<NX>(bq[0], u, [&](auto kc) { return tCAi[decltype(kc)::value * G + l]; });
+            const double t = qr_solve(PRE ? v : bq[0] - v);
+            mv32<NY>(w[0], t, [&](auto kc) { return tDy1[decltype(kc)::value * G + l]; });
+            const double ww = u + w[0];
+            mv32<NX>(xx[0], ww, [&](auto kc) { return tAi[decltype(kc)::value * G + l]; });
+            xs = xx[0];
+            return t;
+        }
         if constexpr (!PRE) {
             stage(u);
             static_for<0, NX>([&](auto kc) {
@@ -458,11 +505,15 @@ struct IpSolver {
     __device__ __forceinline__ void qr_solve_n(const double (&rhs)[N], double (&t)[N]) const {
         double a[N];
         static_for<0, N>([&](auto jc) { a[decltype(jc)::value] = 0.0; });
-        stage_n<N>(rhs);
-        static_for<0, NY>([&](auto ic) {
-            constexpr int r = decltype(ic)::value;
-            static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j] = fma(Qc[r], bv[j * G + r], a[j]); });
-        });
+        if constexpr (G == 32) {
+            static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; mv32<NY>(a[j], rhs[j], [&](auto rc) { return Qc[decltype(rc)::value]; }); });
+        } else {
+            stage_n<N>(rhs);
+            static_for<0, NY>([&](auto ic) {
+                constexpr int r = decltype(ic)::value;
+                static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j] = fma(Qc[r], bv[j * G + r], a[j]); });
+            });
+        }
         double c[N];
         static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; c[j] = a[j] * rdinv; });
         static_rfor<NY - 1>([&](auto kc) {
@@ -484,6 +535,16 @@ struct IpSolver {
         qr_solve_n<N>(g, t);
         double w[N], x[N], ww[N];
         static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; w[j] = x[j] = 0.0; });
+        if constexpr (G == 32) {
+            static_for<0, N>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                mv32<NY>(w[j], t[j], [&](auto kc) { return tDy1[decltype(kc)::value * G + l]; });
+                ww[j] = u[j] + w[j];
+                mv32<NX>(x[j], ww[j], [&](auto kc) { return tAi[decltype(kc)::value * G + l]; });
+                xs[j] = x[j];
+            });
+            return;
+        }
         stage_n<N>(t);
         static_for<0, NY>([&](auto kc) {
             constexpr int k = decltype(kc)::value;

@@ -282,12 +282,13 @@ struct Dpp16 {
         else if constexpr (C == 2) Dpp16Gen::lanes2_acc1<K0>(s, v, T(std::integral_constant<int, K0 + I>{})...);
         else Dpp16Gen::lanes1_acc1<K0>(s, v, T(std::integral_constant<int, K0 + I>{})...);
     }
-    template <int N, int K0 = 0, class TF>
+    // (MAX: largest statement - a statement holds all its operands in registers at once: 16 doubles are 32 VGPRs)
+    template <int N, int K0 = 0, int MAX = 16, class TF>
     static __device__ __forceinline__ void chain(double& s, double v, TF&& T) {
         if constexpr (N > 0) {
-            constexpr int C = dpp_chunk<N>();
+            constexpr int C = dpp_chunk<N, MAX>();
             chain_c<K0>(s, v, T, std::make_integer_sequence<int, C>{});
-            chain<N - C, K0 + C>(s, v, T);
+            chain<N - C, K0 + C, MAX>(s, v, T);
         }
     }
     // ---- a += bcast<k>(v) * TA(k), c += bcast<k>(v) * TC(k), k = 0..N-1: two operators on one vector, sequential chains ---
@@ -301,12 +302,12 @@ struct Dpp16 {
         else if constexpr (C == 2) Dpp16Gen::pair2<K0>(a, c, v, ta(std::integral_constant<int, K0 + 0>{}), tc(std::integral_constant<int, K0 + 0>{}), ta(std::integral_constant<int, K0 + 1>{}), tc(std::integral_constant<int, K0 + 1>{}));
         else Dpp16Gen::pair1<K0>(a, c, v, ta(std::integral_constant<int, K0>{}), tc(std::integral_constant<int, K0>{}));
     }
-    template <int N, int K0 = 0, class TA, class TC>
+    template <int N, int K0 = 0, int MAX = 8, class TA, class TC>
     static __device__ __forceinline__ void pair(double& a, double& c, double v, TA&& ta, TC&& tc) {
         if constexpr (N > 0) {
-            constexpr int C = dpp_chunk<N, 8>();
+            constexpr int C = dpp_chunk<N, MAX>();
             pair_c<K0>(a, c, v, ta, tc, std::make_integer_sequence<int, C>{});
-            pair<N - C, K0 + C>(a, c, v, ta, tc);
+            pair<N - C, K0 + C, MAX>(a, c, v, ta, tc);
         }
     }
     // back-substitution step K of an upper-triangular solve kept one ROW per lane (nr = -R[l,K], zero for K <= l):
