@@ -846,6 +846,16 @@ __device__ __forceinline__ void sensitivities(const IpParams& p, IpSolver<M>& S,
                 const double* g = S.ctab + L.oGs + (c0 + cc) * G;      // (32-lane groups: the block is stored by column, lin_table.h)
                 double a[N][2];
                 static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j][0] = tK0[(c0 + cc + j) * NX]; a[j][1] = 0.0; });
+                if constexpr (G == 32 && (NY % 2) == 0 && NY > 16) {
+                    // round 6: the column of Gs is picked up spread over every 16-lane row (two ds_read_b64 instead of NY / 2 broadcast
+                    // ds_read_b128) and reaches the multiply-adds through DPP - same products, same even / odd partial sums
+                    static_for<0, N>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        const double g0 = g[j * G + (l & 15)], g1 = g[j * G + 16 + ((l & 15) < NY - 16 ? (l & 15) : 0)];
+                        Dpp16::chain2<16, 0, 8>(a[j], g0, [&](auto kc) { return A2[decltype(kc)::value]; });
+                        Dpp16::chain2<NY - 16, 0, 8>(a[j], g1, [&](auto kc) { return A2[16 + decltype(kc)::value]; });
+                    });
+                } else
                 static_for<0, NY>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
                     static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j][k & 1] = fma(A2[k], g[j * G + k], a[j][k & 1]); });

@@ -251,6 +251,26 @@ struct Dpp16 {
             outer<N - C, I0 + C>(a, v, t);
         }
     }
+    // ---- acc[k & 1] += bcast<k>(v) * T(k), k = K0 .. K0+N-1: even / odd partial sums (the sensitivity product of the wide lane groups) ----
+    template <int K0, class TF, int... I>
+    static __device__ __forceinline__ void chain2_c(double (&a)[2], double v, TF& T, std::integer_sequence<int, I...>) {
+        static_assert((K0 & 1) == 0, "chunks start on an even index");
+        constexpr int C = sizeof...(I);
+        if constexpr (C == 16) Dpp16Gen::lanes16_acc2<K0>(a[0], a[1], v, T(std::integral_constant<int, K0 + I>{})...);
+        else if constexpr (C == 8) Dpp16Gen::lanes8_acc2<K0>(a[0], a[1], v, T(std::integral_constant<int, K0 + I>{})...);
+        else if constexpr (C == 4) Dpp16Gen::lanes4_acc2<K0>(a[0], a[1], v, T(std::integral_constant<int, K0 + I>{})...);
+        else if constexpr (C == 2) Dpp16Gen::lanes2_acc2<K0>(a[0], a[1], v, T(std::integral_constant<int, K0 + I>{})...);
+        else static_assert(C == 16 || C == 8 || C == 4 || C == 2, "even chunk sizes");
+    }
+    template <int N, int K0 = 0, int MAX = 16, class TF>
+    static __device__ __forceinline__ void chain2(double (&a)[2], double v, TF&& T) {
+        if constexpr (N > 0) {
+            constexpr int C0 = dpp_chunk<N, MAX>(), C = C0 == 3 ? 2 : C0;
+            static_assert(C != 1, "an even number of terms per row-spread chunk");
+            chain2_c<K0>(a, v, T, std::make_integer_sequence<int, C>{});
+            chain2<N - C, K0 + C, MAX>(a, v, T);
+        }
+    }
     // ---- a[A0 + i] += bcast<B0 + i>(v) * t, i = 0..N-1: `outer` on a window of a longer register array (wide lane groups: chunk j of a column
     //      that every 16-lane row holds spread over its lanes - IpSolver::factorize)
     template <int A0, int B0, int NA, int... I>
