@@ -441,7 +441,7 @@ def test_twisted_solves_next_to_a_saturating_foreign_kernel(monkeypatch):
     a = torch.randn(6144, 6144, dtype=torch.float64, device="cuda")
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
-        for _ in range(12):                     # ~1 s of queued foreign work: every CU busy while the solves run
+        for _ in range(30):                     # ~0.2 s of queued foreign work: every CU busy while the solves run
             a = (a @ a) * 1e-4
     got = [_newton(s, rollouts)] + [_newton(s, rollouts, warm=True) for _ in range(3)]
     busy = not side.query()                     # (the foreign queue outlived the solves: they did run next to it)
