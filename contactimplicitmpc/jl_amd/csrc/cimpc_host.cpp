@@ -56,8 +56,9 @@ struct Knobs {
     int tail_div = 8;            // CIMPC_TAIL_DIV
     int drain_pct = 95;          // CIMPC_DRAIN_PCT: drain parking once this percentage of the sweep's workgroups has left (0 = off; B = 512: 0 / 75 / 90 / 95 / 97 -> 10.68 / 10.97 / 10.48 / 10.45 / 10.47 ms)
     int drain_min = 4;           // CIMPC_DRAIN_MIN: ... for solves that have had at least this many iterations in the launch
-    int async_full_max = 64;     // CIMPC_ASYNC_FULL_MAX: largest batch solved by the single persistent launch alone (larger: hybrid).
-                                 // Measured 128 -> 64: B = 96 8.88 -> 8.11 ms, B = 128 9.72 -> 9.48 ms, B = 64 unchanged (6.9 ms)
+    int async_full_max = 32;     // CIMPC_ASYNC_FULL_MAX: largest batch solved by the single persistent launch alone (larger: hybrid).
+                                 // Measured 128 -> 64 (round 3): B = 96 8.88 -> 8.11 ms, B = 128 9.72 -> 9.48 ms, B = 64 unchanged (6.9 ms); 64 -> 32 (round 6,
+                                 // after the rounds' sweep and KKT stage got faster): B = 64 5.0-5.7 -> 4.35-4.4 ms, B = 48 4.54 -> 4.07 ms with the hand-over at 32
     bool generic_static = false; // CIMPC_GENERIC_STATIC: runtime-dimension sweep with the static queue partition of rounds 2-3 instead of the dynamic pull
     int kkt_pipe = -1;           // CIMPC_KKT_PIPE: three-wave pipelined KKT kernel 0 never, 1 always, -1 where the solve is on the critical path
     int kkt_twisted = -1;        // CIMPC_KKT_TWISTED: twisted (two-ended) condensed solve, two workgroups per rollout: 0 never, 1 wherever the
@@ -583,6 +584,9 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         // their sparse tail, which auto mode hands over to the asynchronous kernel.
         h->async_mode = h->kn.async_mode;
         h->async_tail = std::min(256, std::max(64, d.B / 6));     // measured: B = 512 -> 80 .. 96, B = 2048 -> 256
+        // (round 6, mid-size batches: B = 48 / 64 / 96 best at 32 - 4.07 / 4.35 / 4.41 ms -, B = 128 at 32-48 - 4.91 -, B = 192 at 48 - 4.76 ms against 5.30
+        //  with the rule above: scripts/dbg/headline_b.sh)
+        if (d.B < 256) h->async_tail = std::max(32, d.B / 4);
         if (h->kn.async_tail >= 0) h->async_tail = h->kn.async_tail;
         const bool want = h->async_mode != 0;
         const size_t K = d.H_ref;
