@@ -583,7 +583,8 @@ int cimpc_create(const cimpc_dims* dims, const cimpc_ip_opts* ip, const cimpc_ne
         // (B = 64: 8.1 vs 11.2 ms), the rounds win for large batches (B = 512: 16.5 vs 21.7 ms) - except for
         // their sparse tail, which auto mode hands over to the asynchronous kernel.
         h->async_mode = h->kn.async_mode;
-        h->async_tail = std::min(256, std::max(64, d.B / 6));     // measured: B = 512 -> 80 .. 96, B = 2048 -> 256
+        h->async_tail = std::min(96, std::max(64, d.B / 6));      // measured: B = 512 -> 48 .. 96 flat; B = 1024 / 2048 -> 96 (11.1 / 18.85 ms against 11.4 / 19.5 at 170 / 256:
+                                                                   // the persistent kernel's chains do not get shorter with more rollouts handed over, the rounds do)
         // (round 6, mid-size batches: B = 48 / 64 / 96 best at 32 - 4.07 / 4.35 / 4.41 ms -, B = 128 at 32-48 - 4.91 -, B = 192 at 48 - 4.76 ms against 5.30
         //  with the rule above: scripts/dbg/headline_b.sh)
         if (d.B < 256) h->async_tail = std::max(32, d.B / 4);
