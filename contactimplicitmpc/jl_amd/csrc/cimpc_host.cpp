@@ -73,7 +73,8 @@ struct Knobs {
     int async_kkt_tw = 1;        // CIMPC_ASYNC_KKT_TW: the persistent kernel's KKT stage as TWO cooperating jobs (the chains of the twisted solve): 0 never,
                                  // 1 where it was measured a gain - single launches of at most 32 rollouts (quadruped H = 40, B = 4 / 16 / 32: 2.08 -> 1.85,
                                  // 2.43 -> 2.27, 3.55 -> 3.41 ms; B = 64: 4.4 -> 4.9 ms - twice the jobs when every rollout reaches its KKT stage at once;
-                                 // hybrid tail of B = 512: no difference in six alternating pairs, the tail's chain is its interior-point evaluations) -, 2 always
+                                 // hybrid tail of B = 512: no difference in six alternating pairs, the tail's chain is its interior-point evaluations) and hybrid
+                                 // tails of at most 32 rollouts (B = 48 / 64 / 96 / 128: -1.5 / -3 / -1 / 0 % in alternating pairs) -, 2 always
     // ---- constants ----
     int async_mem = 0;           // exchange buffers: ordinary device memory (uncached / fine-grained variants lost)
     int spec_all = -1;           // speculative slots of later line-search rounds: by batch size
@@ -1333,7 +1334,7 @@ int cimpc_newton_solve_dev(cimpc_handle h, const double* q0_dev, const double* q
         A.B = h->dm.B;
         // KKT stage of the persistent kernel as two cooperating jobs (the chains of the twisted solve, newton_async_impl.h): 16-wide tiles,
         // four-wave workgroups, a horizon the twisted form accepts, and no hand-over of this solve has timed out so far
-        A.kkt_tw = ((h->kn.async_kkt_tw == 2 || (h->kn.async_kkt_tw == 1 && from_reset && h->dm.B <= 32)) && h->kn.kkt_twisted != 0 && h->dm.nq <= 16 && h->dm.nu <= 16 && std::min(h->waves, 4) == 4 && kkt_twisted_available(Sk) &&
+        A.kkt_tw = ((h->kn.async_kkt_tw == 2 || (h->kn.async_kkt_tw == 1 && (from_reset ? h->dm.B <= 32 : h->async_tail <= 32))) && h->kn.kkt_twisted != 0 && h->dm.nq <= 16 && h->dm.nu <= 16 && std::min(h->waves, 4) == 4 && kkt_twisted_available(Sk) &&
                     *(volatile int*)h->h_twfail == tw_fail0) ? 1 : 0;
         if (A.kkt_tw) h->n_kkt_twisted++;
         S.kkt_tw_epoch += h->nt.max_iter + 2;      // the launch's KKT stages take the stamps Sk.kkt_tw_epoch + 1 + (Newton iterations done)
