@@ -609,7 +609,7 @@ def centroidal_payload_leg(B, H, device, steps=3):
         u1, it, rn = s.newton_info()
         u1s[name] = u1.copy()
         out[name] = {"value": B / dt, "unit": "MPC steps/s", "ms_per_step": 1e3 * dt, "newton_iters_per_step": float(it.mean()),
-                     "schedule": "lock-step rounds" if lockstep else "library default for this batch size (single persistent launch)",
+                     "schedule": "lock-step rounds" if lockstep else "library default for this batch size (32-lane models: single persistent launch up to 32 rollouts, above it rounds + persistent tail)",
                      "kkt_ms_per_step": pr["kkt_ms"] / steps, "ip_sweep_ms_per_step": pr["ip_sweep_ms"] / steps,
                      "resid_ms_per_step": pr["resid_ms"] / steps, "async_ms_per_step": pr["async_ms"] / steps,
                      "kkt_launches_per_step": pr["kkt_launches"] / steps, "kkt_systems_per_step": pr["kkt_systems"] / steps,
