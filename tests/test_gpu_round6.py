@@ -356,7 +356,7 @@ def test_centroidal_wall_runs_the_compiled_64_lane_sweep():
 
 # ---- KKT stage of the persistent kernel as two cooperating jobs (the chains of the twisted solve, newton_async_impl.h) -----------------
 @pytest.mark.parametrize("model,H,H_ref,B,sched", [("quadruped", 40, 44, 8, "single"), ("quadruped", 28, 30, 24, "single"), ("hopper", 26, 30, 6, "single"),
-                                                   ("quadruped", 32, 36, 96, "hybrid")])
+                                                   ("quadruped", 32, 36, 96, "hybrid"), ("quadruped", 32, 36, 48, "hybrid_default")])
 def test_async_twisted_kkt_jobs_vs_the_one_ended_job(monkeypatch, model, H, H_ref, B, sched):
     """`newton_solve!` (/root/reference/src/controller/newton.jl:169-288) in ONE persistent launch (and in the hybrid schedule's tail) with
     every KKT stage run as two cooperating jobs - bottom chain pushed first, FIFO claims - against the same solve with the one-ended
@@ -367,7 +367,10 @@ def test_async_twisted_kkt_jobs_vs_the_one_ended_job(monkeypatch, model, H, H_re
     obj = synth.make_objective(d, H, kind=model)
     q0 = np.stack([r[2] for r in rollouts]); q1 = np.stack([r[3] for r in rollouts])
     res = {}
-    for tw in (0, 2):
+    # ("hybrid_default": the library's own choice - 32 < B < 256 hands over at max(32, B / 4) active rollouts and takes the two-job stage
+    #  in tails of at most 32 - against the one-ended job under the same schedule)
+    on = 1 if sched == "hybrid_default" else 2
+    for tw in (0, on):
         monkeypatch.setenv("CIMPC_ASYNC_KKT_TW", str(tw))
         if sched == "hybrid":
             monkeypatch.setenv("CIMPC_ASYNC_TAIL", "64")
@@ -377,7 +380,7 @@ def test_async_twisted_kkt_jobs_vs_the_one_ended_job(monkeypatch, model, H, H_re
         u1w, itw, rnw = s.newton_solve(q0, q1, warm_start=True)
         res[tw] = (u1, it, rn, u1w, itw, cnt, s.kkt_twisted(), s.kkt_twisted_fallbacks())
         s.close()
-    a, b = res[0], res[2]
+    a, b = res[0], res[on]
     assert b[6] > a[6], "the twisted jobs did not run"
     assert b[7] == 0
     assert np.isfinite(b[0]).all() and np.isfinite(b[3]).all()
