@@ -241,21 +241,36 @@ __device__ __forceinline__ void apply_steps(const NewtonDev& S, size_t sb_first,
     // function is inlined into lost 6 us to register pressure (scripts/dbg/twisted_prof.py) - (round 6: one entry per trip made the
     // 7-candidate start of a deep line search a chain of ~12 dependent load round trips - 22 us in the ten workgroups that set the
     // length of every decision launch, scripts/resid_prof.py)
-    auto rows = [&](auto unc, int n, double* dst, size_t stride, auto&& src) {
+    // (round 6, end: theta is no longer gathered entry by entry - the choice between four source arrays per entry was compiled as a
+    //  pointer table in scratch memory with a full wait behind every lookup, eight dependent round trips per trip, 15-23 us for the four
+    //  candidates of a deep search in the ~14 workgroups that set the length of every decision launch (scripts/resid_prof.py).  Every
+    //  q / u entry now writes its own candidate array AND the one or two places of theta that hold it; w and the constant tail of
+    //  theta are plain copies: five independent gathers, no select on a pointer, no load under a lane condition.)
+    auto rows = [&](auto unc, int n, auto&& src, auto&& sink) {
         constexpr int UN = decltype(unc)::value;
         for (int e0 = tid; e0 < n; e0 += UN * nt) {
             double base[UN], dl[UN]; bool mv[UN];
             static_for<0, UN>([&](auto jc) { constexpr int j = decltype(jc)::value; const int e = e0 + j * nt; src(e < n ? e : 0, base[j], dl[j], mv[j]); });
-            static_for<0, UN>([&](auto jc) { constexpr int j = decltype(jc)::value; const int e = e0 + j * nt; if (e < n) put(dst, stride, e, base[j], dl[j], mv[j]); });
+            static_for<0, UN>([&](auto jc) { constexpr int j = decltype(jc)::value; const int e = e0 + j * nt; if (e < n) sink(e, base[j], dl[j], mv[j]); });
         }
     };
-    rows(std::integral_constant<int, 3>{}, (H + 2) * nq, cq, (size_t)(H + 2) * nq, [&](int k, double& base, double& dl, bool& mv) {          // q_1, q_2 are fixed by (q0, q1); q_{t+2} moves
+    const size_t sth = (size_t)H * nth;
+    rows(std::integral_constant<int, 3>{}, (H + 2) * nq, [&](int k, double& base, double& dl, bool& mv) {          // q_1, q_2 are fixed by (q0, q1); q_{t+2} moves
         const int j = k / nq, c = k - j * nq;
-        base = tq[k]; mv = j >= 2; dl = mv ? D[(j - 2) * nr + oq + c] : 0.0;
+        base = tq[k]; mv = j >= 2; dl = D[mv ? (j - 2) * nr + oq + c : 0];      // (a fixed entry reads D[0] and ignores it: no load under a lane condition)
+    }, [&](int k, double base, double dl, bool mv) {                                  // update_theta!: th_t = [q_t; q_{t+1}; u_t; w_t; mu; h]
+        const int j = k / nq, c = k - j * nq;
+        put(cq, (size_t)(H + 2) * nq, k, base, dl, mv);
+        if (j < H) put(cth, sth, j * nth + c, base, dl, mv);                      // q_t of step j
+        if (j >= 1 && j <= H) put(cth, sth, (j - 1) * nth + nq + c, base, dl, mv);      // q_{t+1} of step j - 1
     });
-    rows(std::integral_constant<int, 2>{}, H * nu, cu, (size_t)H * nu, [&](int k, double& base, double& dl, bool& mv) {
+    rows(std::integral_constant<int, 2>{}, H * nu, [&](int k, double& base, double& dl, bool& mv) {
         const int t = k / nu, c = k - t * nu;
         base = tu[k]; dl = D[t * nr + c]; mv = true;
+    }, [&](int k, double base, double dl, bool mv) {
+        const int t = k / nu, c = k - t * nu;
+        put(cu, (size_t)H * nu, k, base, dl, mv);
+        put(cth, sth, t * nth + 2 * nq + c, base, dl, mv);
     });
     if (cf) {
         const double* __restrict__ tg = S.traj.g + (size_t)b * H * m.nc;
@@ -263,23 +278,14 @@ __device__ __forceinline__ void apply_steps(const NewtonDev& S, size_t sb_first,
         for (int k = tid; k < H * m.nc; k += nt) { const int t = k / m.nc, c = k - t * m.nc; put(S.cand.g + sb_first * H * m.nc, (size_t)H * m.nc, k, tg[k], D[t * nr + nu + c], true); }
         for (int k = tid; k < H * m.nb; k += nt) { const int t = k / m.nb, c = k - t * m.nb; put(S.cand.b + sb_first * H * m.nb, (size_t)H * m.nb, k, tb[k], D[t * nr + nu + m.nc + c], true); }
     }
-    rows(std::integral_constant<int, 3>{}, H * nd, cnu, (size_t)H * nd, [&](int k, double& base, double& dl, bool& mv) { base = tnu[k]; dl = D[H * nr + k]; mv = true; });
-    rows(std::integral_constant<int, 8>{}, H * nth, cth, (size_t)H * nth, [&](int k, double& base, double& dl, bool& mv) {               // update_theta!: th_t = [q_t; q_{t+1}; u_t; w_t; mu; h]
-        const int t = k / nth, c = k - t * nth;
-        dl = 0.0; mv = false;
-        if (c < 2 * nq) {
-            const int j = t + (c >= nq ? 1 : 0), cc = c >= nq ? c - nq : c;
-            base = tq[j * nq + cc];
-            mv = j >= 2;
-            dl = mv ? D[(j - 2) * nr + oq + cc] : 0.0;
-        } else if (c < 2 * nq + nu) {
-            base = tu[t * nu + (c - 2 * nq)]; dl = D[t * nr + (c - 2 * nq)]; mv = true;
-        } else if (c < 2 * nq + nu + nw) {
-            base = tw[t * nw + (c - 2 * nq - nu)];
-        } else {
-            base = tth[k];
-        }
-    });
+    rows(std::integral_constant<int, 3>{}, H * nd, [&](int k, double& base, double& dl, bool& mv) { base = tnu[k]; dl = D[H * nr + k]; mv = true; },
+         [&](int k, double base, double dl, bool mv) { put(cnu, (size_t)H * nd, k, base, dl, mv); });
+    const int o_w = 2 * nq + nu, o_c = o_w + nw, n_c = nth - o_c;      // theta's w_t, then its constant tail (mu, h)
+    rows(std::integral_constant<int, 1>{}, H * nw, [&](int k, double& base, double& dl, bool& mv) { base = tw[k]; dl = 0.0; mv = false; },
+         [&](int k, double base, double dl, bool mv) { const int t = k / nw; put(cth, sth, t * nth + o_w + (k - t * nw), base, dl, mv); });
+    if (n_c > 0)
+        rows(std::integral_constant<int, 1>{}, H * n_c, [&](int k, double& base, double& dl, bool& mv) { const int t = k / n_c; base = tth[t * nth + o_c + (k - t * n_c)]; dl = 0.0; mv = false; },
+             [&](int k, double base, double dl, bool mv) { const int t = k / n_c; put(cth, sth, t * nth + o_c + (k - t * n_c), base, dl, mv); });
     Sync::sync();
 }
 
